@@ -1,0 +1,129 @@
+/*
+ * kanzi_hip.h -- C-ABI of libkanzi_hip.so: the MI355X (gfx950) implementation of Kanzi's per-block
+ * hot path.  Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * What each entry point replaces in the reference (K/ = java/src/main/java/io/github/flanglet/kanzi/):
+ *
+ *   kz_transform_forward / _inverse / _max_encoded_len
+ *       K/ByteTransform.java:36,48,56  (boolean forward(SliceByteArray,SliceByteArray), inverse, getMaxEncodedLength)
+ *       for the codecs K/transform/BWTBlockCodec.java:71-213, K/transform/SBRT.java:87-214 (RANK, MTFT),
+ *       K/transform/ZRLT.java:54-233.   "false" is a normal outcome (Sequence.java:95-105) -> return 0.
+ *   kz_entropy_encode / kz_entropy_decode
+ *       K/EntropyEncoder.java:34 (int encode(byte[],int,int)) + dispose(), K/EntropyDecoder.java:33
+ *       for K/entropy/ANSRangeEncoder.java:263-305, K/entropy/ANSRangeDecoder.java:189-236,
+ *       K/entropy/NullEntropyEncoder.java:66-81.  The codec's output is a bit string (MSB first,
+ *       K/bitstream/DefaultOutputBitStream.java:103-123): the Java adapter calls
+ *       obs.writeBits(out, 0, nbits) once.
+ *   kz_encode_blocks / kz_decode_blocks  (batched, the form in which the GPU pays off)
+ *       the span transform.forward ... ee.dispose of EncodingTask.encodeBlock
+ *       (K/io/CompressedOutputStream.java:792-985) resp. ed.decode ... transform.inverse of
+ *       DecodingTask.decodeBlock (K/io/CompressedInputStream.java:1286-1344), including the block
+ *       header (mode / skipFlags / postTransformLength / header checksum, :861-896,:977-985) and the
+ *       raw "transformed copy" fallback (:926-973).  Output per block = the block's private
+ *       byte-aligned stream of `bits` bits, ready for the ordered emission loop (:1024-1035).
+ *
+ * Return convention: >= 0 success (meaning documented per call); negative = -(K/Error.java code).
+ * A kz_ctx is single-threaded (one HIP stream, one scratch arena); use one per host thread / GPU,
+ * exactly like the reference creates one codec instance per task (CompressedOutputStream.java:792,907).
+ */
+#ifndef KANZI_HIP_H
+#define KANZI_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KZ_ABI_VERSION 1
+
+/* transform ids: K/transform/TransformFactory.java:36-60 */
+enum { KZ_T_NONE = 0, KZ_T_BWT = 1, KZ_T_LZ = 3, KZ_T_ZRLT = 6, KZ_T_MTFT = 7, KZ_T_RANK = 8,
+       KZ_T_SRT = 13, KZ_T_LZX = 16 };
+/* entropy ids: K/entropy/EntropyCodecFactory.java */
+enum { KZ_E_NONE = 0, KZ_E_HUFFMAN = 1, KZ_E_FPAQ = 2, KZ_E_ANS0 = 5 };
+/* error codes: K/Error.java (returned negated) */
+enum { KZ_ERR_MISSING_PARAM = 1, KZ_ERR_BLOCK_SIZE = 2, KZ_ERR_INVALID_CODEC = 3, KZ_ERR_INVALID_PARAM = 10,
+       KZ_ERR_PROCESS_BLOCK = 13, KZ_ERR_READ_FILE = 15, KZ_ERR_WRITE_FILE = 16, KZ_ERR_CRC_CHECK = 19,
+       KZ_ERR_INVALID_FILE = 21, KZ_ERR_DEVICE = 126, KZ_ERR_UNKNOWN = 127 };
+
+/* pointer location flags for the batched calls */
+enum { KZ_MEM_HOST = 0, KZ_MEM_DEVICE = 1 };
+
+#define KZ_MAX_STAGES 16
+enum { KZ_STAGE_BWT_FWD = 0, KZ_STAGE_SBRT_FWD = 1, KZ_STAGE_ZRLT_FWD = 2, KZ_STAGE_ENTROPY_ENC = 3,
+       KZ_STAGE_FRAME_ENC = 4, KZ_STAGE_ENTROPY_DEC = 5, KZ_STAGE_ZRLT_INV = 6, KZ_STAGE_SBRT_INV = 7,
+       KZ_STAGE_BWT_INV = 8, KZ_STAGE_FRAME_DEC = 9 };
+
+typedef struct kz_ctx kz_ctx;
+
+int32_t     kz_abi_version(void);
+kz_ctx*     kz_ctx_create(int32_t deviceId);          /* NULL if no HIP device / out of memory */
+void        kz_ctx_destroy(kz_ctx* ctx);
+const char* kz_last_error(kz_ctx* ctx);
+/* HIP stream the context launches on (as void* = hipStream_t) so callers can bracket it with events */
+void*       kz_ctx_stream(kz_ctx* ctx);
+
+/* ---- ByteTransform mirror (host buffers; one block) ------------------------------------------ */
+/* returns 1 = applied (*produced bytes written), 0 = declined (dst untouched), <0 = error */
+int32_t kz_transform_forward(kz_ctx* ctx, uint32_t type, const uint8_t* src, int32_t n,
+                             uint8_t* dst, int32_t dstCap, int32_t* produced);
+int32_t kz_transform_inverse(kz_ctx* ctx, uint32_t type, const uint8_t* src, int32_t n,
+                             uint8_t* dst, int32_t dstCap, int32_t* produced);
+int32_t kz_transform_max_encoded_len(uint32_t type, int32_t n);
+
+/* ---- EntropyEncoder / EntropyDecoder mirror (host buffers; one block) ------------------------- */
+/* returns number of BITS written to out (MSB first, last byte zero padded), <0 = error */
+int64_t kz_entropy_encode(kz_ctx* ctx, uint32_t type, const uint8_t* src, int32_t n,
+                          uint8_t* out, int64_t outCapBytes);
+/* decodes `count` bytes from the bit string in[0..inBits); returns count, or <0; *bitsConsumed set */
+int32_t kz_entropy_decode(kz_ctx* ctx, uint32_t type, const uint8_t* in, int64_t inBits,
+                          uint8_t* dst, int32_t count, int64_t* bitsConsumed);
+
+/* ---- fused, batched block API ----------------------------------------------------------------- */
+typedef struct {
+  int64_t bits;                 /* enc: bit length W of the block's private stream */
+  int32_t length;               /* enc: postTransformLength ; dec: decoded length */
+  int32_t status;               /* 0 ok, else -(K/Error.java code) */
+  uint8_t skipFlags;            /* Sequence.getSkipFlags() (K/transform/Sequence.java:243) */
+  uint8_t mode;                 /* block mode byte (CompressedOutputStream.java:861-880) */
+  uint8_t pad[6];
+} kz_block_result;
+
+/*
+ * Encode nBlocks independent blocks.  Block b is in[b*inStride .. +lengths[b]); its private stream
+ * is written at out[b*outStride ..] (outStride >= kz_max_block_stream_bytes(maxLength)).
+ * `lengths` and `results` are host arrays.  memKind says where in/out live (KZ_MEM_HOST: pageable or
+ * pinned host memory, copied over PCIe inside the call; KZ_MEM_DEVICE: HBM pointers, no copies).
+ * transformType = 8 x 6-bit ids, first transform in the top slot (TransformFactory.java:29-31).
+ */
+int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType,
+                         const uint8_t* in, int64_t inStride, const int32_t* lengths, int32_t nBlocks,
+                         uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind);
+/*
+ * Decode nBlocks block streams.  Stream b is in[b*inStride ..] with bitLengths[b] bits (W, header
+ * included).  Decoded bytes go to out[b*outStride ..] (capacity outStride each, >= blockSize).
+ */
+int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
+                         const uint8_t* in, int64_t inStride, const int64_t* bitLengths, int32_t nBlocks,
+                         uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind);
+int64_t kz_max_block_stream_bytes(int32_t blockLength);
+
+/* ---- whole .knz stream on host memory (K/io/CompressedOutputStream / CompressedInputStream) --- */
+/* returns compressed size in bytes or <0 */
+int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
+                    const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstCap);
+int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstCap);
+uint64_t kz_transform_type(const int32_t* types, int32_t nb);
+
+/* ---- instrumentation (bench.py / roofline) ----------------------------------------------------- */
+void    kz_set_timing(kz_ctx* ctx, int32_t enable);     /* hipEvent-bracket every stage of the next calls */
+int32_t kz_get_stage_count(kz_ctx* ctx);
+float   kz_get_stage_ms(kz_ctx* ctx, int32_t stage);    /* accumulated since last kz_reset_timing */
+int64_t kz_get_stage_alg_bytes(kz_ctx* ctx, int32_t stage);
+void    kz_reset_timing(kz_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

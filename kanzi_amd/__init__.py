@@ -1,0 +1,375 @@
+"""kanzi_amd -- MI355X-native (gfx950 HIP) implementation of Kanzi's per-block hot path.
+
+Python host-side mirror of the reference's plugin interfaces, bound to the C-ABI in
+``include/kanzi_hip.h`` with ctypes.  The product path is the HIP library ``libkanzi_hip.so``;
+there is NO CPU fallback: importing works everywhere (so the ABI can be inspected), but creating a
+:class:`Context` without the library or without a GPU raises.
+
+Reference interfaces mirrored (K/ = java/src/main/java/io/github/flanglet/kanzi/):
+  * ``ByteTransform``  K/ByteTransform.java:36,48,56      -> :class:`BWTBlockCodec`, :class:`SBRT`, :class:`ZRLT`
+  * ``EntropyEncoder`` K/EntropyEncoder.java:34,41,48     -> :class:`ANSRangeEncoder`, :class:`NullEntropyEncoder`
+  * ``EntropyDecoder`` K/EntropyDecoder.java:33           -> :class:`ANSRangeDecoder`, :class:`NullEntropyDecoder`
+  * ``Sequence`` / block span of EncodingTask.encodeBlock -> :func:`encode_blocks` / :func:`decode_blocks`
+  * ``CompressedOutputStream`` / ``CompressedInputStream`` -> same-named classes (whole .knz stream)
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkanzi_hip.so")
+
+# transform ids (K/transform/TransformFactory.java:36-60) and entropy ids (K/entropy/EntropyCodecFactory.java)
+NONE_TYPE, BWT_TYPE, LZ_TYPE, ZRLT_TYPE, MTFT_TYPE, RANK_TYPE, SRT_TYPE, LZX_TYPE = 0, 1, 3, 6, 7, 8, 13, 16
+E_NONE, E_HUFFMAN, E_FPAQ, E_ANS0 = 0, 1, 2, 5
+TRANSFORM_IDS = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "LZX": 16}
+ENTROPY_IDS = {"NONE": 0, "HUFFMAN": 1, "FPAQ": 2, "ANS0": 5}
+MEM_HOST, MEM_DEVICE = 0, 1
+
+STAGE_NAMES = ["bwt_fwd", "sbrt_fwd", "zrlt_fwd", "entropy_enc", "frame_enc",
+               "entropy_dec", "zrlt_inv", "sbrt_inv", "bwt_inv", "frame_dec"]
+
+
+class KanziError(RuntimeError):
+    """Mirror of KanziIOException(code) (K/io/KanziIOException.java); code = K/Error.java value."""
+
+    def __init__(self, code, msg=""):
+        super().__init__("kanzi error %d %s" % (code, msg))
+        self.code = code
+
+
+class BlockResult(ctypes.Structure):
+    _fields_ = [("bits", ctypes.c_int64), ("length", ctypes.c_int32), ("status", ctypes.c_int32),
+                ("skipFlags", ctypes.c_uint8), ("mode", ctypes.c_uint8), ("pad", ctypes.c_uint8 * 6)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libkanzi_hip.so and declare every symbol of include/kanzi_hip.h. Raises if missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libkanzi_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the product path)")
+    L = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, u8p, i32p, i64p = c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p
+    sig = {
+        "kz_abi_version": (c.c_int32, []),
+        "kz_ctx_create": (vp, [c.c_int32]),
+        "kz_ctx_destroy": (None, [vp]),
+        "kz_last_error": (c.c_char_p, [vp]),
+        "kz_ctx_stream": (vp, [vp]),
+        "kz_transform_forward": (c.c_int32, [vp, c.c_uint32, u8p, c.c_int32, u8p, c.c_int32, i32p]),
+        "kz_transform_inverse": (c.c_int32, [vp, c.c_uint32, u8p, c.c_int32, u8p, c.c_int32, i32p]),
+        "kz_transform_max_encoded_len": (c.c_int32, [c.c_uint32, c.c_int32]),
+        "kz_entropy_encode": (c.c_int64, [vp, c.c_uint32, u8p, c.c_int32, u8p, c.c_int64]),
+        "kz_entropy_decode": (c.c_int32, [vp, c.c_uint32, u8p, c.c_int64, u8p, c.c_int32, i64p]),
+        "kz_encode_blocks": (c.c_int32, [vp, c.c_uint64, c.c_uint32, u8p, c.c_int64, i32p, c.c_int32, u8p, c.c_int64, vp, c.c_int32]),
+        "kz_decode_blocks": (c.c_int32, [vp, c.c_uint64, c.c_uint32, c.c_int32, u8p, c.c_int64, i64p, c.c_int32, u8p, c.c_int64, vp, c.c_int32]),
+        "kz_max_block_stream_bytes": (c.c_int64, [c.c_int32]),
+        "kz_compress": (c.c_int64, [vp, c.c_uint64, c.c_uint32, c.c_int32, u8p, c.c_int64, u8p, c.c_int64]),
+        "kz_decompress": (c.c_int64, [vp, u8p, c.c_int64, u8p, c.c_int64]),
+        "kz_transform_type": (c.c_uint64, [i32p, c.c_int32]),
+        "kz_set_timing": (None, [vp, c.c_int32]),
+        "kz_get_stage_count": (c.c_int32, [vp]),
+        "kz_get_stage_ms": (c.c_float, [vp, c.c_int32]),
+        "kz_get_stage_alg_bytes": (c.c_int64, [vp, c.c_int32]),
+        "kz_reset_timing": (None, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_error", "kz_ctx_stream",
+               "kz_transform_forward", "kz_transform_inverse", "kz_transform_max_encoded_len",
+               "kz_entropy_encode", "kz_entropy_decode", "kz_encode_blocks", "kz_decode_blocks",
+               "kz_max_block_stream_bytes", "kz_compress", "kz_decompress", "kz_transform_type",
+               "kz_set_timing", "kz_get_stage_count", "kz_get_stage_ms", "kz_get_stage_alg_bytes", "kz_reset_timing"]
+
+
+def transform_type(names):
+    """'BWT+RANK+ZRLT' or a list of names/ids -> 48-bit id word (TransformFactory.java:132-158)."""
+    if isinstance(names, str):
+        names = [s for s in names.split("+") if s]
+    ids = [TRANSFORM_IDS[x.upper()] if isinstance(x, str) else int(x) for x in names]
+    if not 1 <= len(ids) <= 8:
+        raise ValueError("Only 1 to 8 transforms allowed")          # Sequence.java:42-43
+    t = 0
+    for i in range(8):
+        t = (t << 6) | (ids[i] if i < len(ids) else 0)
+    return t
+
+
+def _ptr(a):
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return int(a)
+
+
+class Context:
+    """One HIP stream + scratch arena on one GPU (kz_ctx). Not thread-safe, like a reference codec instance."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.h = self.lib.kz_ctx_create(int(device))
+        if not self.h:
+            raise RuntimeError("kz_ctx_create(%d) failed: no usable HIP device (the HIP path has no CPU fallback)" % device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.kz_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def error(self):
+        return self.lib.kz_last_error(self.h).decode("utf-8", "replace")
+
+    def check(self, rc):
+        if rc < 0:
+            raise KanziError(-rc, self.error())
+        return rc
+
+    @property
+    def stream(self):
+        return self.lib.kz_ctx_stream(self.h)
+
+    # ---- instrumentation ----
+    def set_timing(self, on):
+        self.lib.kz_set_timing(self.h, 1 if on else 0)
+
+    def reset_timing(self):
+        self.lib.kz_reset_timing(self.h)
+
+    def stage_times(self):
+        out = {}
+        for i, nm in enumerate(STAGE_NAMES):
+            ms = float(self.lib.kz_get_stage_ms(self.h, i))
+            if ms > 0:
+                out[nm] = {"ms": ms, "alg_bytes": int(self.lib.kz_get_stage_alg_bytes(self.h, i))}
+        return out
+
+
+class SliceByteArray:
+    """K/SliceByteArray.java:35-37."""
+
+    def __init__(self, array=None, length=None, index=0):
+        self.array = array if array is not None else np.zeros(0, dtype=np.uint8)
+        self.length = len(self.array) if length is None else length
+        self.index = index
+
+
+class _Transform:
+    """ByteTransform mirror. forward/inverse return True (applied) or False (declined), advancing
+    src.index / dst.index exactly like the reference codecs do on success."""
+    TYPE = None
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def getMaxEncodedLength(self, n):
+        return int(self.ctx.lib.kz_transform_max_encoded_len(self.TYPE, n))
+
+    def _run(self, fn, src, dst):
+        if src.length == 0:
+            return True
+        s = np.ascontiguousarray(src.array[src.index:src.index + src.length], dtype=np.uint8)
+        cap = len(dst.array) - dst.index if fn is self.ctx.lib.kz_transform_inverse else dst.length - dst.index
+        if cap <= 0:
+            return False
+        out = np.empty(cap, dtype=np.uint8)
+        produced = ctypes.c_int32(0)
+        rc = fn(self.ctx.h, self.TYPE, s.ctypes.data, src.length, out.ctypes.data, cap, ctypes.addressof(produced))
+        self.ctx.check(rc)
+        if rc == 0:
+            return False
+        dst.array[dst.index:dst.index + produced.value] = out[:produced.value]
+        src.index += src.length
+        dst.index += produced.value
+        return True
+
+    def forward(self, src, dst):
+        return self._run(self.ctx.lib.kz_transform_forward, src, dst)
+
+    def inverse(self, src, dst):
+        return self._run(self.ctx.lib.kz_transform_inverse, src, dst)
+
+
+class BWTBlockCodec(_Transform):
+    TYPE = BWT_TYPE            # K/transform/BWTBlockCodec.java
+
+
+class ZRLT(_Transform):
+    TYPE = ZRLT_TYPE           # K/transform/ZRLT.java
+
+
+class SBRT(_Transform):
+    MODE_MTF, MODE_RANK, MODE_TIMESTAMP = 1, 2, 3   # K/transform/SBRT.java:35-37
+
+    def __init__(self, ctx, mode=2):
+        super().__init__(ctx)
+        if mode not in (1, 2):
+            raise ValueError("Invalid mode parameter")
+        self.TYPE = RANK_TYPE if mode == 2 else MTFT_TYPE
+
+
+class _EntropyEncoder:
+    TYPE = None
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.bits = []         # list of (bytes, nbits) appended, like the OutputBitStream given at construction
+
+    def encode(self, block, blkptr, count):
+        """EntropyEncoder.encode: returns count on success. Output bit string appended to self.bits."""
+        if count == 0:
+            return 0
+        s = np.ascontiguousarray(block[blkptr:blkptr + count], dtype=np.uint8)
+        cap = int(self.ctx.lib.kz_max_block_stream_bytes(count))
+        out = np.zeros(cap, dtype=np.uint8)
+        nbits = self.ctx.lib.kz_entropy_encode(self.ctx.h, self.TYPE, s.ctypes.data, count, out.ctypes.data, cap)
+        self.ctx.check(nbits)
+        self.bits.append((out[:(nbits + 7) // 8].tobytes(), int(nbits)))
+        return count
+
+    def dispose(self):
+        pass
+
+
+class _EntropyDecoder:
+    TYPE = None
+
+    def __init__(self, ctx, data, nbits):
+        self.ctx, self.data, self.nbits = ctx, data, nbits
+
+    def decode(self, block, blkptr, count):
+        if count == 0:
+            return 0
+        s = np.frombuffer(bytes(self.data) + b"\0" * 16, dtype=np.uint8)
+        out = np.empty(count, dtype=np.uint8)
+        used = ctypes.c_int64(0)
+        rc = self.ctx.lib.kz_entropy_decode(self.ctx.h, self.TYPE, s.ctypes.data, self.nbits, out.ctypes.data, count, ctypes.addressof(used))
+        if rc < 0:
+            return -1
+        block[blkptr:blkptr + count] = out
+        return count
+
+
+class ANSRangeEncoder(_EntropyEncoder):
+    TYPE = E_ANS0              # K/entropy/ANSRangeEncoder.java (order 0)
+
+
+class ANSRangeDecoder(_EntropyDecoder):
+    TYPE = E_ANS0
+
+
+class NullEntropyEncoder(_EntropyEncoder):
+    TYPE = E_NONE
+
+
+class NullEntropyDecoder(_EntropyDecoder):
+    TYPE = E_NONE
+
+
+def max_block_stream_bytes(n):
+    return int(load_library().kz_max_block_stream_bytes(int(n)))
+
+
+def encode_blocks(ctx, transform, entropy, inp, in_stride, lengths, out, out_stride, mem=MEM_HOST):
+    """Fused batched encode (kz_encode_blocks). `inp`/`out`: numpy uint8 arrays (host) or integer device
+    pointers (mem=MEM_DEVICE). Returns a ctypes array of BlockResult."""
+    tt = transform if isinstance(transform, int) else transform_type(transform)
+    et = entropy if isinstance(entropy, int) else ENTROPY_IDS[entropy.upper()]
+    lens = np.ascontiguousarray(lengths, dtype=np.int32)
+    res = (BlockResult * len(lens))()
+    rc = ctx.lib.kz_encode_blocks(ctx.h, tt, et, _ptr(inp), int(in_stride), lens.ctypes.data, len(lens),
+                                  _ptr(out), int(out_stride), ctypes.addressof(res), mem)
+    ctx.check(rc)
+    return res
+
+
+def decode_blocks(ctx, transform, entropy, block_size, inp, in_stride, bit_lengths, out, out_stride, mem=MEM_HOST):
+    tt = transform if isinstance(transform, int) else transform_type(transform)
+    et = entropy if isinstance(entropy, int) else ENTROPY_IDS[entropy.upper()]
+    bl = np.ascontiguousarray(bit_lengths, dtype=np.int64)
+    res = (BlockResult * len(bl))()
+    rc = ctx.lib.kz_decode_blocks(ctx.h, tt, et, int(block_size), _ptr(inp), int(in_stride), bl.ctypes.data, len(bl),
+                                  _ptr(out), int(out_stride), ctypes.addressof(res), mem)
+    ctx.check(rc)
+    return res
+
+
+class CompressedOutputStream:
+    """K/io/CompressedOutputStream.java: write() bytes, close() -> .knz bytes in self.output.
+    ctx keys mirror the reference's Map (transform, entropy, blockSize)."""
+
+    def __init__(self, ctx, transform="BWT+RANK+ZRLT", entropy="ANS0", blockSize=4 * 1024 * 1024):
+        if blockSize > 1024 * 1024 * 1024:
+            raise ValueError("The block size must be at most 1 GB")              # CompressedOutputStream.java:165-174
+        if blockSize < 1024:
+            raise ValueError("The block size must be at least 1024")
+        if blockSize & 15:
+            raise ValueError("The block size must be a multiple of 16")
+        self.ctx = ctx
+        self.tt = transform_type(transform)
+        self.et = ENTROPY_IDS[entropy.upper()]
+        self.blockSize = blockSize
+        self._chunks = []
+        self.closed = False
+        self.output = None
+
+    def write(self, data):
+        if self.closed:
+            raise KanziError(16, "Stream closed")                                # ERR_WRITE_FILE
+        self._chunks.append(bytes(data))
+
+    def close(self):
+        if self.closed:
+            return
+        self.closed = True
+        src = np.frombuffer(b"".join(self._chunks), dtype=np.uint8)
+        n = len(src)
+        cap = n + n // 4 + 65536
+        dst = np.empty(cap, dtype=np.uint8)
+        sp = src.ctypes.data if n else dst.ctypes.data
+        rc = self.ctx.lib.kz_compress(self.ctx.h, self.tt, self.et, self.blockSize, sp, n, dst.ctypes.data, cap)
+        self.ctx.check(rc)
+        self.output = dst[:rc].tobytes()
+
+
+class CompressedInputStream:
+    """K/io/CompressedInputStream.java: read() the whole decoded stream."""
+
+    def __init__(self, ctx, data):
+        self.ctx, self.data = ctx, bytes(data)
+
+    def read(self, max_size=None):
+        src = np.frombuffer(self.data + b"\0" * 16, dtype=np.uint8)
+        cap = max_size if max_size is not None else self._declared_size()
+        dst = np.empty(max(cap, 1), dtype=np.uint8)
+        rc = self.ctx.lib.kz_decompress(self.ctx.h, src.ctypes.data, len(self.data), dst.ctypes.data, cap)
+        self.ctx.check(rc)
+        return dst[:rc].tobytes()
+
+    def _declared_size(self):
+        # stream header: 32+4+2+5+48+28 bits then szMask (2) and the size (CompressedOutputStream.java:236-290)
+        v = int.from_bytes(self.data[:24], "big")
+        total = 24 * 8
+        szmask = (v >> (total - 121)) & 3
+        if szmask == 0:
+            return max(len(self.data) * 64, 1 << 20)
+        size = (v >> (total - 121 - 16 * szmask)) & ((1 << (16 * szmask)) - 1)
+        return int(size)

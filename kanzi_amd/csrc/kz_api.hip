@@ -1,0 +1,709 @@
+// kz_api.hip -- C-ABI entry points (include/kanzi_hip.h), the per-batch pipeline driver that plays
+// the role of K/transform/Sequence.java + the codec span of EncodingTask.encodeBlock /
+// DecodingTask.decodeBlock, the block-header kernels, and the host-side .knz stream framing.
+#include "kz_device.h"
+#include "kz_internal.h"
+#include <stdlib.h>
+#include <algorithm>
+
+typedef uint32_t u32;
+typedef uint8_t u8;
+typedef unsigned long long u64;
+
+// =================================================================================================
+// context / arena
+extern "C" int32_t kz_abi_version(void) { return KZ_ABI_VERSION; }
+
+extern "C" kz_ctx* kz_ctx_create(int32_t deviceId) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return nullptr;   // fail loudly: no CPU fallback
+  if (deviceId < 0 || deviceId >= ndev) return nullptr;
+  if (hipSetDevice(deviceId) != hipSuccess) return nullptr;
+  kz_ctx* ctx = new kz_ctx();
+  ctx->device = deviceId;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+  if (hipHostMalloc((void**)&ctx->hpin, 1 << 20, hipHostMallocDefault) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return nullptr; }
+  return ctx;
+}
+extern "C" void kz_ctx_destroy(kz_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  if (ctx->arena) hipFree(ctx->arena);
+  if (ctx->hpin) hipHostFree(ctx->hpin);
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+extern "C" const char* kz_last_error(kz_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+extern "C" void* kz_ctx_stream(kz_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int kz_arena_reserve(kz_ctx* ctx, size_t total) {
+  ctx->arenaTop = 0;
+  if (total <= ctx->arenaCap) return 0;
+  if (ctx->arena) { hipStreamSynchronize(ctx->stream); hipFree(ctx->arena); ctx->arena = nullptr; ctx->arenaCap = 0; }
+  total = kz_align(total + (total >> 3), 1 << 20);
+  KZ_HIP(hipMalloc((void**)&ctx->arena, total));
+  ctx->arenaCap = total;
+  return 0;
+}
+void* kz_arena_alloc(kz_ctx* ctx, size_t bytes) {
+  size_t top = kz_align(ctx->arenaTop, 256);
+  if (top + bytes > ctx->arenaCap) return nullptr;
+  ctx->arenaTop = top + bytes;
+  return ctx->arena + top;
+}
+
+// ---- timing --------------------------------------------------------------------------------------
+extern "C" void kz_set_timing(kz_ctx* ctx, int32_t enable) { ctx->timing = enable != 0; }
+extern "C" int32_t kz_get_stage_count(kz_ctx*) { return KZ_MAX_STAGES; }
+extern "C" float kz_get_stage_ms(kz_ctx* ctx, int32_t s) { return (s >= 0 && s < KZ_MAX_STAGES) ? ctx->stageMs[s] : 0.f; }
+extern "C" int64_t kz_get_stage_alg_bytes(kz_ctx* ctx, int32_t s) { return (s >= 0 && s < KZ_MAX_STAGES) ? ctx->stageAlgBytes[s] : 0; }
+extern "C" void kz_reset_timing(kz_ctx* ctx) { for (int i = 0; i < KZ_MAX_STAGES; i++) { ctx->stageMs[i] = 0; ctx->stageAlgBytes[i] = 0; } }
+
+void kz_stage_begin(kz_ctx* ctx, hipEvent_t* e0) {
+  *e0 = nullptr;
+  if (!ctx->timing) return;
+  hipEventCreate(e0);
+  hipEventRecord(*e0, ctx->stream);
+}
+void kz_stage_end(kz_ctx* ctx, hipEvent_t e0, int stageId, int64_t algBytes) {
+  if (!ctx->timing || !e0) return;
+  hipEvent_t e1; hipEventCreate(&e1);
+  hipEventRecord(e1, ctx->stream);
+  hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  ctx->stageMs[stageId] += ms; ctx->stageAlgBytes[stageId] += algBytes;
+  hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
+// =================================================================================================
+// ids / sizes
+extern "C" int32_t kz_transform_max_encoded_len(uint32_t type, int32_t n) {
+  switch (type) {
+    case KZ_T_BWT: return n + 33;                                    // BWTBlockCodec.java:40,222
+    case KZ_T_SRT: return n + 1024;                                  // SRT.java:30,365
+    case KZ_T_LZ: case KZ_T_LZX: return ((n <= 1024) ? n + 16 : n + (n / 64)) + 2;   // LZCodec.java:961-964
+    default: return n;                                               // ZRLT.java:243, SBRT.java:224
+  }
+}
+extern "C" uint64_t kz_transform_type(const int32_t* types, int32_t nb) {   // TransformFactory.java:132-158
+  uint64_t t = 0;
+  for (int i = 0; i < 8; i++) t = (t << 6) | (uint64_t)((i < nb) ? (types[i] & 0x3F) : 0);
+  return t;
+}
+static int split_types(uint64_t tt, int* types) {                    // TransformFactory.java:240-266
+  int nbtr = 0;
+  for (int i = 0; i < 8; i++) if (((tt >> (42 - 6 * i)) & 0x3F) != KZ_T_NONE) nbtr++;
+  if (nbtr == 0) nbtr = 1;
+  int k = 0;
+  for (int i = 0; i < nbtr; i++) { int t = (int)((tt >> (42 - 6 * i)) & 0x3F); if (t != KZ_T_NONE || i == 0) types[k++] = t; }
+  return k;
+}
+static bool transform_supported(int t) { return t == KZ_T_NONE || t == KZ_T_BWT || t == KZ_T_RANK || t == KZ_T_MTFT || t == KZ_T_ZRLT; }
+static bool entropy_supported(int e) { return e == KZ_E_NONE || e == KZ_E_ANS0; }
+static int seq_max_len(const int* types, int nb, int n) {             // Sequence.java:215-226
+  int req = n;
+  for (int i = 0; i < nb; i++) req = std::max(req, kz_transform_max_encoded_len((uint32_t)types[i], req));
+  return req;
+}
+extern "C" int64_t kz_max_block_stream_bytes(int32_t n) { return (int64_t)kz_align((size_t)n + (size_t)(n >> 3) + 1024, 256); }
+
+// =================================================================================================
+// small device helpers
+__global__ void k_mask_len(const int32_t* __restrict__ len, const int32_t* __restrict__ mask, int32_t* __restrict__ out, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) out[b] = mask[b] ? len[b] : 0;
+}
+// pass-through for blocks whose stage did not run (mask==0) or declined (flag==0)
+__global__ void k_passthrough(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride, const int32_t* __restrict__ lenOld,
+                              int32_t* __restrict__ lenNew, const int32_t* __restrict__ mask, const int32_t* __restrict__ flag,
+                              int32_t* __restrict__ applied) {
+  const int b = blockIdx.y;
+  const bool ran = mask[b] != 0 && flag[b] != 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { applied[b] = ran ? 1 : 0; if (!ran) lenNew[b] = lenOld[b]; }
+  if (ran) return;
+  const int n = lenOld[b];
+  const u8* s = src + (int64_t)b * stride;
+  u8* d = dst + (int64_t)b * stride;
+  for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += gridDim.x * blockDim.x * 16) {
+    if (i + 16 <= n) *(uint4*)(d + i) = *(const uint4*)(s + i);
+    else for (int k = i; k < n; k++) d[k] = s[k];
+  }
+}
+__global__ void k_copy_bytes(const u8* __restrict__ src, int64_t sstride, u8* __restrict__ dst, int64_t dstride,
+                             const int32_t* __restrict__ len, const int32_t* __restrict__ dstOff, const int32_t* __restrict__ cond) {
+  const int b = blockIdx.y;
+  if (cond && !cond[b]) return;
+  const int n = len[b];
+  const u8* s = src + (int64_t)b * sstride;
+  u8* d = dst + (int64_t)b * dstride + (dstOff ? dstOff[b] : 0);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+__device__ __forceinline__ u32 kz_mix32(u32 c, u32 h, u32 v) {        // CompressedOutputStream.java:89-93
+  c ^= h * ~v;
+  c = (c << 13) | (c >> 19);
+  return c * 5u + 0x52DCE729u;
+}
+__device__ __forceinline__ u8 kz_block_cksum(u32 mode, u32 hsf, u32 postLen, u64 written) {   // :977-985
+  const u32 HASH = 0x1E35A7BDu;
+  u32 c = HASH * 0x01030507u;
+  c = kz_mix32(c, HASH, mode);
+  c = kz_mix32(c, HASH, hsf);
+  c = kz_mix32(c, HASH, postLen);
+  c = kz_mix32(c, HASH, (u32)(written >> 32));
+  c = kz_mix32(c, HASH, (u32)written);
+  c = (c >> 23) ^ (c >> 3);
+  return (u8)c;
+}
+
+struct FrameEnc {
+  int32_t* postLen;      // = batch d_len after the chain
+  int32_t* skipFlags;    // [B]
+  int32_t* hdrBytes;     // [B]
+  int32_t* isCopy;       // [B] small block (<= 15 bytes): raw copy block
+  int32_t* fallback;     // [B]
+  int64_t* bits;         // [B] entropy payload bits -> final W
+  int nbFunctions;
+};
+
+// before entropy: header size per block (CompressedOutputStream.java:825-826, :861-896)
+__global__ void k_frame_prepare(FrameEnc F, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int postLen = F.postLen[b];
+  const int dataSize = (postLen < 256) ? 1 : (kz_ilog2((u32)postLen) >> 3) + 1;
+  const bool two = !F.isCopy[b] && F.nbFunctions > 4;
+  F.hdrBytes[b] = 1 + (two ? 1 : 0) + dataSize + 1;
+}
+// after entropy: decide the raw "transformed copy" fallback (:926-973)
+__global__ void k_frame_decide(FrameEnc F, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int64_t written = 8LL * F.hdrBytes[b] + F.bits[b];
+  const int64_t entropyBytes = (written + 7) >> 3;
+  F.fallback[b] = (!F.isCopy[b] && (int64_t)F.postLen[b] < entropyBytes) ? 1 : 0;
+}
+__global__ void k_frame_header(FrameEnc F, u8* __restrict__ out, int64_t outStride, kz_block_result* __restrict__ res, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  u8* o = out + (int64_t)b * outStride;
+  const int postLen = F.postLen[b];
+  const u32 skipFlags = (u32)F.skipFlags[b] & 0xFF;
+  const int nb = F.nbFunctions;
+  const int dataSize = (postLen < 256) ? 1 : (kz_ilog2((u32)postLen) >> 3) + 1;
+  u32 mode = F.isCopy[b] ? 0x80u : 0u;
+  mode |= (u32)(((dataSize - 1) & 3) << 5);
+  u32 hsf = skipFlags;
+  int idx = 0;
+  int64_t written;
+  if (postLen == 0) { res[b].bits = 0; res[b].length = 0; res[b].status = 0; res[b].skipFlags = 0xFF; res[b].mode = 0; return; }
+  if (F.fallback[b]) {
+    const u32 copyMode = (mode | (nb <= 4 ? (skipFlags >> 4) : 0x10u)) | 0x80u | 0x10u;     // :933-934
+    o[idx++] = (u8)copyMode;
+    if (nb > 4) { o[idx++] = (u8)skipFlags; hsf = skipFlags; } else hsf = ((copyMode << 4) | 0x0F) & 0xFF;
+    mode = copyMode;
+    written = 8LL * (F.hdrBytes[b] + postLen);
+  } else {
+    if ((mode & 0x80) || nb <= 4) {
+      mode |= (skipFlags >> 4);
+      hsf = (mode & 0x80) ? 0u : (((mode << 4) | 0x0F) & 0xFF);
+      o[idx++] = (u8)mode;
+    } else {
+      mode |= 0x10;
+      o[idx++] = (u8)mode; o[idx++] = (u8)skipFlags;
+    }
+    written = 8LL * F.hdrBytes[b] + F.bits[b];
+  }
+  for (int k = dataSize - 1; k >= 0; k--) o[idx++] = (u8)((u32)postLen >> (8 * k));
+  o[idx] = kz_block_cksum(mode & 0xFF, hsf, (u32)postLen, (u64)written);
+  res[b].bits = written; res[b].length = postLen; res[b].status = 0;
+  res[b].skipFlags = (u8)skipFlags; res[b].mode = (u8)mode;
+}
+
+// =================================================================================================
+// batch plumbing
+struct Pipe {
+  kz_batch bt;
+  int32_t* d_mask = nullptr;      // [B] stage applies to this block
+  int32_t* d_applied = nullptr;   // [B]
+  int32_t* d_lenSave = nullptr;   // [B]
+  int32_t* d_one = nullptr;       // [B] all ones
+};
+
+static int sync_lengths(kz_ctx* ctx, kz_batch& bt) {
+  KZ_HIP(hipMemcpyAsync(ctx->hpin, bt.d_len, (size_t)bt.B * 4, hipMemcpyDeviceToHost, ctx->stream));
+  KZ_HIP(hipStreamSynchronize(ctx->stream));
+  for (int b = 0; b < bt.B; b++) bt.h_len[b] = ctx->hpin[b];
+  return 0;
+}
+
+// run one stage on the blocks selected by h_mask; others (and blocks where the transform declines)
+// pass through unchanged.  On return h_applied[b] tells which blocks the transform was applied to.
+template <typename F>
+static int run_stage(kz_ctx* ctx, Pipe& P, const std::vector<int32_t>& h_mask, std::vector<int32_t>& h_applied, F stage) {
+  kz_batch& bt = P.bt;
+  const int B = bt.B;
+  hipStream_t st = ctx->stream;
+  KZ_HIP(hipMemcpyAsync(P.d_mask, h_mask.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+  // save true lengths, run on masked lengths
+  KZ_HIP(hipMemcpyAsync(P.d_lenSave, bt.d_len, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_mask_len, dim3((B + 255) / 256), dim3(256), 0, st, P.d_lenSave, P.d_mask, bt.d_len, B);
+  std::vector<int32_t> saved = bt.h_len;
+  for (int b = 0; b < B; b++) if (!h_mask[b]) bt.h_len[b] = 0;
+  const u8* srcBefore = bt.buf[bt.cur];
+  int rc = stage(bt);
+  if (rc) return rc;
+  u8* dstAfter = bt.buf[bt.cur];
+  hipLaunchKernelGGL(k_passthrough, dim3(64, B), dim3(256), 0, st, srcBefore, dstAfter, bt.stride, P.d_lenSave, bt.d_len,
+                     P.d_mask, bt.d_flag, P.d_applied);
+  KZ_HIP(hipMemcpyAsync(ctx->hpin + B, P.d_applied, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  rc = sync_lengths(ctx, bt);
+  if (rc) return rc;
+  h_applied.resize(B);
+  for (int b = 0; b < B; b++) h_applied[b] = ctx->hpin[B + b];
+  (void)saved;
+  return 0;
+}
+
+static size_t pipeline_scratch(int B, int maxLen) {
+  size_t s = 0;
+  s = std::max(s, kz_bwt_forward_scratch(B, maxLen));
+  s = std::max(s, kz_bwt_inverse_scratch(B, maxLen));
+  s = std::max(s, kz_sbrt_scratch(B, maxLen));
+  s = std::max(s, kz_zrlt_scratch(B, maxLen));
+  s = std::max(s, kz_ans_scratch(B, maxLen));
+  return s;
+}
+
+static int pipe_setup(kz_ctx* ctx, Pipe& P, int B, int maxLen, int64_t extraBytes) {
+  kz_batch& bt = P.bt;
+  bt.B = B; bt.maxN = maxLen;
+  bt.stride = (int64_t)kz_align((size_t)maxLen + 4096, 256);
+  const size_t fixed = (size_t)bt.stride * B * 2 + (size_t)B * 4 * 16 + 65536 + (size_t)extraBytes;
+  int rc = kz_arena_reserve(ctx, fixed + pipeline_scratch(B, maxLen) + (1 << 20));
+  if (rc) return rc;
+  bt.buf[0] = (u8*)kz_arena_alloc(ctx, (size_t)bt.stride * B);
+  bt.buf[1] = (u8*)kz_arena_alloc(ctx, (size_t)bt.stride * B);
+  bt.d_len = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  bt.d_len2 = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  bt.d_flag = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  P.d_mask = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  P.d_applied = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  P.d_lenSave = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  bt.cur = 0;
+  bt.h_len.assign(B, 0);
+  if (!P.d_lenSave) { snprintf(ctx->err, sizeof(ctx->err), "pipe_setup: arena overflow"); return -KZ_ERR_DEVICE; }
+  return 0;
+}
+
+static int run_transform_stage(kz_ctx* ctx, kz_batch& bt, int type, bool forward, int dstCap) {
+  switch (type) {
+    case KZ_T_BWT: return forward ? kz_stage_bwt_forward(ctx, bt) : kz_stage_bwt_inverse(ctx, bt);
+    case KZ_T_RANK: return forward ? kz_stage_sbrt_forward(ctx, bt, 2) : kz_stage_sbrt_inverse(ctx, bt, 2);
+    case KZ_T_MTFT: return forward ? kz_stage_sbrt_forward(ctx, bt, 1) : kz_stage_sbrt_inverse(ctx, bt, 1);
+    case KZ_T_ZRLT: return forward ? kz_stage_zrlt_forward(ctx, bt) : kz_stage_zrlt_inverse(ctx, bt, dstCap);
+    default: snprintf(ctx->err, sizeof(ctx->err), "transform %d has no HIP stage", type); return -KZ_ERR_INVALID_CODEC;
+  }
+}
+static int stage_id(int type, bool forward) {
+  switch (type) {
+    case KZ_T_BWT: return forward ? KZ_STAGE_BWT_FWD : KZ_STAGE_BWT_INV;
+    case KZ_T_RANK: case KZ_T_MTFT: return forward ? KZ_STAGE_SBRT_FWD : KZ_STAGE_SBRT_INV;
+    default: return forward ? KZ_STAGE_ZRLT_FWD : KZ_STAGE_ZRLT_INV;
+  }
+}
+
+// =================================================================================================
+// encode
+extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType,
+                                    const uint8_t* in, int64_t inStride, const int32_t* lengths, int32_t nBlocks,
+                                    uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind) {
+  if (!ctx) return -KZ_ERR_INVALID_PARAM;
+  if (nBlocks <= 0) return 0;
+  KZ_HIP(hipSetDevice(ctx->device));
+  int types[8];
+  const int nb = split_types(transformType, types);
+  for (int i = 0; i < nb; i++) if (!transform_supported(types[i])) { snprintf(ctx->err, sizeof(ctx->err), "unsupported transform id %d", types[i]); return -KZ_ERR_INVALID_CODEC; }
+  if (!entropy_supported((int)entropyType)) { snprintf(ctx->err, sizeof(ctx->err), "unsupported entropy id %u", entropyType); return -KZ_ERR_INVALID_CODEC; }
+  const int B = nBlocks;
+  int maxN = 0;
+  for (int b = 0; b < B; b++) { if (lengths[b] < 0) return -KZ_ERR_INVALID_PARAM; maxN = std::max(maxN, lengths[b]); }
+  const int maxLen = seq_max_len(types, nb, maxN);
+  const int64_t needOut = kz_max_block_stream_bytes(maxN);
+  if (outStride < needOut || (outStride & 3)) { snprintf(ctx->err, sizeof(ctx->err), "outStride %lld < %lld or not a multiple of 4", (long long)outStride, (long long)needOut); return -KZ_ERR_INVALID_PARAM; }
+  const bool host = memKind == KZ_MEM_HOST;
+  Pipe P;
+  const int64_t extra = (host ? (int64_t)outStride * B : 0) + (int64_t)B * (sizeof(kz_block_result) + 64) + (int64_t)B * 16;
+  int rc = pipe_setup(ctx, P, B, maxLen, extra);
+  if (rc) return rc;
+  kz_batch& bt = P.bt;
+  hipStream_t st = ctx->stream;
+  u8* d_out = host ? (u8*)kz_arena_alloc(ctx, (size_t)outStride * B) : out;
+  kz_block_result* d_res = (kz_block_result*)kz_arena_alloc(ctx, (size_t)B * sizeof(kz_block_result));
+  FrameEnc F;
+  F.skipFlags = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  F.hdrBytes = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  F.isCopy = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  F.fallback = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  F.bits = (int64_t*)kz_arena_alloc(ctx, (size_t)B * 8);
+  F.nbFunctions = nb;
+  if (!F.bits || !d_res || !d_out) { snprintf(ctx->err, sizeof(ctx->err), "encode: arena overflow"); return -KZ_ERR_DEVICE; }
+
+  // ---- load blocks into HBM ----
+  for (int b = 0; b < B; b++) {
+    if (lengths[b] == 0) continue;
+    KZ_HIP(hipMemcpyAsync(bt.buf[0] + (int64_t)b * bt.stride, in + (int64_t)b * inStride, (size_t)lengths[b],
+                          host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+  }
+  for (int b = 0; b < B; b++) bt.h_len[b] = lengths[b];
+  KZ_HIP(hipMemcpyAsync(bt.d_len, lengths, (size_t)B * 4, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemsetAsync(d_out, 0, (size_t)outStride * B, st));       // bit-concat ORs into zeroed words
+
+  // ---- transform chain (Sequence.forward, K/transform/Sequence.java:56-127) ----
+  std::vector<int32_t> h_copy(B), h_mask(B), h_applied, h_skip(B, 0xFF);
+  for (int b = 0; b < B; b++) h_copy[b] = (lengths[b] <= 15) ? 1 : 0;          // CompressedOutputStream.java:764-767
+  for (int i = 0; i < nb; i++) {
+    for (int b = 0; b < B; b++) h_mask[b] = (!h_copy[b] && bt.h_len[b] > 0) ? 1 : 0;
+    if (types[i] == KZ_T_NONE) { for (int b = 0; b < B; b++) if (h_mask[b]) h_skip[b] &= ~(1 << (7 - i)); continue; }
+    hipEvent_t e0; kz_stage_begin(ctx, &e0);
+    int64_t inBytes = 0; for (int b = 0; b < B; b++) if (h_mask[b]) inBytes += bt.h_len[b];
+    const int type = types[i];
+    rc = run_stage(ctx, P, h_mask, h_applied, [&](kz_batch& x) { return run_transform_stage(ctx, x, type, true, 0); });
+    if (rc) return rc;
+    kz_stage_end(ctx, e0, stage_id(type, true), inBytes);
+    for (int b = 0; b < B; b++) if (h_applied[b]) h_skip[b] &= ~(1 << (7 - i));
+  }
+  for (int b = 0; b < B; b++) if (h_copy[b]) h_skip[b] = 0x7F;                   // NullTransform applies (NONE_TYPE chain)
+  KZ_HIP(hipMemcpyAsync(F.skipFlags, h_skip.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemcpyAsync(F.isCopy, h_copy.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+  F.postLen = bt.d_len;
+  hipLaunchKernelGGL(k_frame_prepare, dim3((B + 255) / 256), dim3(256), 0, st, F, B);
+
+  // ---- entropy (EntropyEncoder.encode + dispose) ----
+  {
+    hipEvent_t e0; kz_stage_begin(ctx, &e0);
+    int64_t inBytes = 0; for (int b = 0; b < B; b++) inBytes += bt.h_len[b];
+    // copy blocks and NONE entropy: raw bytes (NullEntropyEncoder.java:66-81)
+    if (entropyType == KZ_E_ANS0) {
+      // small copy blocks use NONE: mask them out of the ANS stage by zero length, then copy raw
+      for (int b = 0; b < B; b++) h_mask[b] = h_copy[b] ? 0 : 1;
+      KZ_HIP(hipMemcpyAsync(P.d_mask, h_mask.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+      KZ_HIP(hipMemcpyAsync(P.d_lenSave, bt.d_len, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(k_mask_len, dim3((B + 255) / 256), dim3(256), 0, st, P.d_lenSave, P.d_mask, bt.d_len, B);
+      std::vector<int32_t> saved = bt.h_len;
+      for (int b = 0; b < B; b++) if (h_copy[b]) bt.h_len[b] = 0;
+      rc = kz_stage_ans0_encode(ctx, bt, d_out, outStride, F.hdrBytes, F.bits);
+      if (rc) return rc;
+      bt.h_len = saved;
+      KZ_HIP(hipMemcpyAsync(bt.d_len, P.d_lenSave, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    }
+    // raw payload for copy blocks (and all blocks when entropy is NONE)
+    {
+      for (int b = 0; b < B; b++) h_mask[b] = (entropyType == KZ_E_NONE || h_copy[b]) ? 1 : 0;
+      KZ_HIP(hipMemcpyAsync(P.d_mask, h_mask.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_copy_bytes, dim3(64, B), dim3(256), 0, st, bt.buf[bt.cur], bt.stride, d_out, outStride, bt.d_len, F.hdrBytes, P.d_mask);
+      // bits = 8*len for those blocks
+      std::vector<int64_t> hb(B);
+      if (entropyType == KZ_E_NONE) {
+        for (int b = 0; b < B; b++) hb[b] = 8LL * bt.h_len[b];
+        KZ_HIP(hipMemcpyAsync(F.bits, hb.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
+        KZ_HIP(hipStreamSynchronize(st));
+      } else {
+        for (int b = 0; b < B; b++) if (h_copy[b]) { int64_t v = 8LL * bt.h_len[b]; KZ_HIP(hipMemcpyAsync(F.bits + b, &v, 8, hipMemcpyHostToDevice, st)); KZ_HIP(hipStreamSynchronize(st)); }
+      }
+    }
+    kz_stage_end(ctx, e0, KZ_STAGE_ENTROPY_ENC, inBytes);
+  }
+  // ---- block header, raw fallback (CompressedOutputStream.java:861-985) ----
+  {
+    hipEvent_t e0; kz_stage_begin(ctx, &e0);
+    hipLaunchKernelGGL(k_frame_decide, dim3((B + 255) / 256), dim3(256), 0, st, F, B);
+    hipLaunchKernelGGL(k_copy_bytes, dim3(64, B), dim3(256), 0, st, bt.buf[bt.cur], bt.stride, d_out, outStride, bt.d_len, F.hdrBytes, F.fallback);
+    hipLaunchKernelGGL(k_frame_header, dim3((B + 255) / 256), dim3(256), 0, st, F, d_out, outStride, d_res, B);
+    kz_stage_end(ctx, e0, KZ_STAGE_FRAME_ENC, 0);
+  }
+  KZ_HIP(hipMemcpyAsync(results, d_res, (size_t)B * sizeof(kz_block_result), hipMemcpyDeviceToHost, st));
+  KZ_HIP(hipStreamSynchronize(st));
+  if (host) {
+    for (int b = 0; b < B; b++) {
+      const size_t nbytes = (size_t)((results[b].bits + 7) >> 3);
+      if (nbytes) KZ_HIP(hipMemcpyAsync(out + (int64_t)b * outStride, d_out + (int64_t)b * outStride, nbytes, hipMemcpyDeviceToHost, st));
+    }
+    KZ_HIP(hipStreamSynchronize(st));
+  }
+  KZ_HIP(hipGetLastError());
+  return 0;
+}
+
+// =================================================================================================
+// decode
+struct FrameDec {
+  int32_t* preLen; int32_t* skipFlags; int32_t* hdrBytes; int32_t* raw; int32_t* tcopy; int32_t* status;
+  int64_t* bitOff; int64_t* bitEnd;
+};
+// CompressedInputStream.java:1025-1095 readBlockHeader
+__global__ void k_frame_parse(const u8* __restrict__ in, int64_t inStride, const int64_t* __restrict__ bitLen, FrameDec F,
+                              int nbFunctions, int maxTransformLength, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const u8* p = in + (int64_t)b * inStride;
+  const int64_t W = bitLen[b];
+  int status = 0, preLen = 0, hdrBytes = 0, raw = 0, tcopy = 0;
+  u32 skipFlags = 0;
+  if (W == 0) { status = 0; }
+  else if (W < 8) status = -KZ_ERR_BLOCK_SIZE;
+  else {
+    const u32 mode = p[0];
+    bool hasSkip = false;
+    if (mode & 0x80) {
+      if (mode & 0x10) { tcopy = 1; if (nbFunctions > 4) hasSkip = true; else skipFlags = ((mode << 4) | 0x0F) & 0xFF; }
+      else raw = 1;
+    } else if (mode & 0x10) hasSkip = true;
+    else skipFlags = ((mode << 4) | 0x0F) & 0xFF;
+    const int dataSize = 1 + ((mode >> 5) & 3);
+    hdrBytes = 1 + (hasSkip ? 1 : 0) + dataSize + 1;
+    if (W < (int64_t)hdrBytes * 8) status = -KZ_ERR_BLOCK_SIZE;
+    else {
+      int idx = 1;
+      if (hasSkip) skipFlags = p[idx++];
+      for (int i = 0; i < dataSize; i++) preLen = (preLen << 8) | p[idx++];
+      const u8 ck = p[idx];
+      if (ck != kz_block_cksum(mode, skipFlags, (u32)preLen, (u64)W)) status = -KZ_ERR_CRC_CHECK;
+      else if (preLen < 0 || preLen > maxTransformLength) status = -KZ_ERR_READ_FILE;
+      else if (((W + 7) >> 3) > (int64_t)preLen + hdrBytes) status = -KZ_ERR_BLOCK_SIZE;     // :1158-1164
+    }
+  }
+  if (status) { preLen = 0; }
+  F.preLen[b] = preLen; F.skipFlags[b] = (int32_t)(raw ? 0xFF : skipFlags); F.hdrBytes[b] = hdrBytes;
+  F.raw[b] = raw; F.tcopy[b] = tcopy; F.status[b] = status;
+  F.bitOff[b] = 8LL * hdrBytes; F.bitEnd[b] = W;
+}
+__global__ void k_copy_payload(const u8* __restrict__ in, int64_t inStride, u8* __restrict__ dst, int64_t stride,
+                               const int32_t* __restrict__ len, const int32_t* __restrict__ hdrBytes, const int32_t* __restrict__ cond) {
+  const int b = blockIdx.y;
+  if (!cond[b]) return;
+  const int n = len[b];
+  const u8* s = in + (int64_t)b * inStride + hdrBytes[b];
+  u8* d = dst + (int64_t)b * stride;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
+                                    const uint8_t* in, int64_t inStride, const int64_t* bitLengths, int32_t nBlocks,
+                                    uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind) {
+  if (!ctx) return -KZ_ERR_INVALID_PARAM;
+  if (nBlocks <= 0) return 0;
+  KZ_HIP(hipSetDevice(ctx->device));
+  int types[8];
+  const int nb = split_types(transformType, types);
+  for (int i = 0; i < nb; i++) if (!transform_supported(types[i])) { snprintf(ctx->err, sizeof(ctx->err), "unsupported transform id %d", types[i]); return -KZ_ERR_INVALID_CODEC; }
+  if (!entropy_supported((int)entropyType)) { snprintf(ctx->err, sizeof(ctx->err), "unsupported entropy id %u", entropyType); return -KZ_ERR_INVALID_CODEC; }
+  const int B = nBlocks;
+  const bool host = memKind == KZ_MEM_HOST;
+  // decoder's working size: blockSize + max(512, blockSize/16) (CompressedInputStream.java:694-695)
+  const int dataCap = blockSize + std::max(512, blockSize >> 4);
+  const int maxTL = std::min(std::max(blockSize + blockSize / 2, 2048), 1 << 30);
+  int64_t maxInBytes = 0;
+  for (int b = 0; b < B; b++) maxInBytes = std::max(maxInBytes, (bitLengths[b] + 7) >> 3);
+  const int maxLen = std::max(dataCap, maxTL);
+  Pipe P;
+  const int64_t inS = host ? (int64_t)kz_align((size_t)maxInBytes + 64, 256) : inStride;
+  const int64_t extra = (host ? inS * B : 0) + (int64_t)B * (sizeof(kz_block_result) + 128);
+  int rc = pipe_setup(ctx, P, B, maxLen, extra);
+  if (rc) return rc;
+  kz_batch& bt = P.bt;
+  hipStream_t st = ctx->stream;
+  const u8* d_in = in;
+  if (host) {
+    u8* t = (u8*)kz_arena_alloc(ctx, (size_t)inS * B);
+    if (!t) { snprintf(ctx->err, sizeof(ctx->err), "decode: arena overflow"); return -KZ_ERR_DEVICE; }
+    for (int b = 0; b < B; b++) {
+      const size_t nbytes = (size_t)((bitLengths[b] + 7) >> 3);
+      if (nbytes) KZ_HIP(hipMemcpyAsync(t + (int64_t)b * inS, in + (int64_t)b * inStride, nbytes, hipMemcpyHostToDevice, st));
+    }
+    d_in = t;
+  }
+  FrameDec F;
+  F.preLen = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  F.skipFlags = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  F.hdrBytes = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  F.raw = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  F.tcopy = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  F.status = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  F.bitOff = (int64_t*)kz_arena_alloc(ctx, (size_t)B * 8);
+  F.bitEnd = (int64_t*)kz_arena_alloc(ctx, (size_t)B * 8);
+  int64_t* d_bitLen = (int64_t*)kz_arena_alloc(ctx, (size_t)B * 8);
+  if (!d_bitLen) { snprintf(ctx->err, sizeof(ctx->err), "decode: arena overflow"); return -KZ_ERR_DEVICE; }
+  KZ_HIP(hipMemcpyAsync(d_bitLen, bitLengths, (size_t)B * 8, hipMemcpyHostToDevice, st));
+  hipEvent_t e0; kz_stage_begin(ctx, &e0);
+  hipLaunchKernelGGL(k_frame_parse, dim3((B + 255) / 256), dim3(256), 0, st, d_in, inS, d_bitLen, F, nb, maxTL, B);
+  // read back descriptors
+  int32_t* hp = ctx->hpin + 4 * B;
+  KZ_HIP(hipMemcpyAsync(hp + 0 * B, F.preLen, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  KZ_HIP(hipMemcpyAsync(hp + 1 * B, F.skipFlags, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  KZ_HIP(hipMemcpyAsync(hp + 2 * B, F.raw, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  KZ_HIP(hipMemcpyAsync(hp + 3 * B, F.tcopy, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  KZ_HIP(hipMemcpyAsync(hp + 4 * B, F.status, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  KZ_HIP(hipStreamSynchronize(st));
+  kz_stage_end(ctx, e0, KZ_STAGE_FRAME_DEC, 0);
+  std::vector<int32_t> h_pre(hp, hp + B), h_skip(hp + B, hp + 2 * B), h_raw(hp + 2 * B, hp + 3 * B), h_tc(hp + 3 * B, hp + 4 * B), h_status(hp + 4 * B, hp + 5 * B);
+  for (int b = 0; b < B; b++) bt.h_len[b] = h_status[b] ? 0 : h_pre[b];
+  KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+
+  // ---- entropy decode into buf ----
+  std::vector<int32_t> h_mask(B), h_applied;
+  {
+    hipEvent_t e1; kz_stage_begin(ctx, &e1);
+    int64_t outBytes = 0; for (int b = 0; b < B; b++) outBytes += bt.h_len[b];
+    std::vector<int32_t> h_rawp(B);
+    for (int b = 0; b < B; b++) h_rawp[b] = (entropyType == KZ_E_NONE || h_raw[b] || h_tc[b]) ? 1 : 0;
+    if (entropyType == KZ_E_ANS0) {
+      for (int b = 0; b < B; b++) h_mask[b] = h_rawp[b] ? 0 : 1;
+      rc = run_stage(ctx, P, h_mask, h_applied, [&](kz_batch& x) { return kz_stage_ans0_decode(ctx, x, d_in, inS, F.bitOff, F.bitEnd); });
+      if (rc) return rc;
+      for (int b = 0; b < B; b++) if (h_mask[b] && !h_applied[b] && !h_status[b]) h_status[b] = -KZ_ERR_PROCESS_BLOCK;
+    } else {
+      bt.cur ^= 1;    // raw path writes into the "next" buffer below
+    }
+    KZ_HIP(hipMemcpyAsync(P.d_mask, h_rawp.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_copy_payload, dim3(64, B), dim3(256), 0, st, d_in, inS, bt.buf[bt.cur], bt.stride, bt.d_len, F.hdrBytes, P.d_mask);
+    kz_stage_end(ctx, e1, KZ_STAGE_ENTROPY_DEC, outBytes);
+  }
+  // ---- inverse chain (Sequence.inverse, K/transform/Sequence.java:137-207) ----
+  for (int i = nb - 1; i >= 0; i--) {
+    if (types[i] == KZ_T_NONE) continue;
+    bool any = false;
+    for (int b = 0; b < B; b++) { h_mask[b] = (!h_status[b] && !(h_skip[b] & (1 << (7 - i))) && bt.h_len[b] > 0) ? 1 : 0; any |= h_mask[b] != 0; }
+    if (!any) continue;
+    hipEvent_t e1; kz_stage_begin(ctx, &e1);
+    const int type = types[i];
+    rc = run_stage(ctx, P, h_mask, h_applied, [&](kz_batch& x) { return run_transform_stage(ctx, x, type, false, dataCap); });
+    if (rc) return rc;
+    int64_t outBytes = 0; for (int b = 0; b < B; b++) if (h_mask[b]) outBytes += bt.h_len[b];
+    kz_stage_end(ctx, e1, stage_id(type, false), outBytes);
+    for (int b = 0; b < B; b++) if (h_mask[b] && !h_applied[b]) { h_status[b] = -KZ_ERR_PROCESS_BLOCK; bt.h_len[b] = 0; }
+  }
+  // ---- results ----
+  for (int b = 0; b < B; b++) {
+    if (!h_status[b] && (bt.h_len[b] > blockSize || bt.h_len[b] > outStride)) h_status[b] = -KZ_ERR_PROCESS_BLOCK;
+    results[b].bits = bitLengths[b]; results[b].length = h_status[b] ? 0 : bt.h_len[b]; results[b].status = h_status[b];
+    results[b].skipFlags = (uint8_t)h_skip[b]; results[b].mode = 0;
+    if (!h_status[b] && bt.h_len[b] > 0)
+      KZ_HIP(hipMemcpyAsync(out + (int64_t)b * outStride, bt.buf[bt.cur] + (int64_t)b * bt.stride, (size_t)bt.h_len[b],
+                            host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+  }
+  KZ_HIP(hipStreamSynchronize(st));
+  KZ_HIP(hipGetLastError());
+  return 0;
+}
+
+// =================================================================================================
+// single-block mirrors of ByteTransform / EntropyEncoder / EntropyDecoder (host buffers)
+static int32_t transform_one(kz_ctx* ctx, uint32_t type, bool forward, const uint8_t* src, int32_t n, uint8_t* dst, int32_t dstCap, int32_t* produced) {
+  if (!ctx || !src || !dst || !produced || n < 0) return -KZ_ERR_INVALID_PARAM;
+  *produced = 0;
+  if (n == 0) return 1;                                             // every reference codec: length 0 -> true
+  if (!transform_supported((int)type) || type == KZ_T_NONE) { snprintf(ctx->err, sizeof(ctx->err), "transform %u has no HIP stage", type); return -KZ_ERR_INVALID_CODEC; }
+  KZ_HIP(hipSetDevice(ctx->device));
+  if (forward && dstCap < kz_transform_max_encoded_len(type, n)) return 0;   // e.g. ZRLT.java:68, BWTBlockCodec.java:84-86
+  Pipe P;
+  const int maxLen = std::max(kz_transform_max_encoded_len(type, n), std::max(dstCap, n));
+  int rc = pipe_setup(ctx, P, 1, maxLen, 0);
+  if (rc) return rc;
+  kz_batch& bt = P.bt;
+  hipStream_t st = ctx->stream;
+  KZ_HIP(hipMemcpyAsync(bt.buf[0], src, (size_t)n, hipMemcpyHostToDevice, st));
+  bt.h_len[0] = n;
+  KZ_HIP(hipMemcpyAsync(bt.d_len, &n, 4, hipMemcpyHostToDevice, st));
+  std::vector<int32_t> mask(1, 1), applied;
+  rc = run_stage(ctx, P, mask, applied, [&](kz_batch& x) { return run_transform_stage(ctx, x, (int)type, forward, dstCap); });
+  if (rc) return rc;
+  if (!applied[0]) return 0;
+  if (bt.h_len[0] > dstCap) return 0;
+  *produced = bt.h_len[0];
+  if (bt.h_len[0] > 0) KZ_HIP(hipMemcpyAsync(dst, bt.buf[bt.cur], (size_t)bt.h_len[0], hipMemcpyDeviceToHost, st));
+  KZ_HIP(hipStreamSynchronize(st));
+  return 1;
+}
+extern "C" int32_t kz_transform_forward(kz_ctx* ctx, uint32_t type, const uint8_t* src, int32_t n, uint8_t* dst, int32_t dstCap, int32_t* produced) {
+  return transform_one(ctx, type, true, src, n, dst, dstCap, produced);
+}
+extern "C" int32_t kz_transform_inverse(kz_ctx* ctx, uint32_t type, const uint8_t* src, int32_t n, uint8_t* dst, int32_t dstCap, int32_t* produced) {
+  return transform_one(ctx, type, false, src, n, dst, dstCap, produced);
+}
+
+extern "C" int64_t kz_entropy_encode(kz_ctx* ctx, uint32_t type, const uint8_t* src, int32_t n, uint8_t* out, int64_t outCapBytes) {
+  if (!ctx || !src || !out || n < 0) return -KZ_ERR_INVALID_PARAM;
+  if (!entropy_supported((int)type)) return -KZ_ERR_INVALID_CODEC;
+  if (n == 0) return 0;
+  KZ_HIP(hipSetDevice(ctx->device));
+  Pipe P;
+  const int64_t oS = kz_max_block_stream_bytes(n);
+  int rc = pipe_setup(ctx, P, 1, n, oS + 256);
+  if (rc) return rc;
+  kz_batch& bt = P.bt;
+  hipStream_t st = ctx->stream;
+  u8* d_out = (u8*)kz_arena_alloc(ctx, (size_t)oS);
+  int32_t* d_hdr = (int32_t*)kz_arena_alloc(ctx, 64);
+  int64_t* d_bits = (int64_t*)kz_arena_alloc(ctx, 64);
+  if (!d_bits) return -KZ_ERR_DEVICE;
+  KZ_HIP(hipMemcpyAsync(bt.buf[0], src, (size_t)n, hipMemcpyHostToDevice, st));
+  bt.h_len[0] = n;
+  KZ_HIP(hipMemcpyAsync(bt.d_len, &n, 4, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemsetAsync(d_out, 0, (size_t)oS, st));
+  KZ_HIP(hipMemsetAsync(d_hdr, 0, 64, st));
+  int64_t bits = 0;
+  if (type == KZ_E_ANS0) {
+    rc = kz_stage_ans0_encode(ctx, bt, d_out, oS, d_hdr, d_bits);
+    if (rc) return rc;
+    KZ_HIP(hipMemcpyAsync(&bits, d_bits, 8, hipMemcpyDeviceToHost, st));
+    KZ_HIP(hipStreamSynchronize(st));
+  } else {
+    KZ_HIP(hipMemcpyAsync(d_out, bt.buf[0], (size_t)n, hipMemcpyDeviceToDevice, st));
+    bits = 8LL * n;
+  }
+  const int64_t nbytes = (bits + 7) >> 3;
+  if (nbytes > outCapBytes) return -KZ_ERR_WRITE_FILE;
+  KZ_HIP(hipMemcpyAsync(out, d_out, (size_t)nbytes, hipMemcpyDeviceToHost, st));
+  KZ_HIP(hipStreamSynchronize(st));
+  return bits;
+}
+
+extern "C" int32_t kz_entropy_decode(kz_ctx* ctx, uint32_t type, const uint8_t* in, int64_t inBits, uint8_t* dst, int32_t count, int64_t* bitsConsumed) {
+  if (!ctx || !in || !dst || count < 0) return -KZ_ERR_INVALID_PARAM;
+  if (!entropy_supported((int)type)) return -KZ_ERR_INVALID_CODEC;
+  if (bitsConsumed) *bitsConsumed = 0;
+  if (count == 0) return 0;
+  KZ_HIP(hipSetDevice(ctx->device));
+  Pipe P;
+  const int64_t inBytes = (inBits + 7) >> 3;
+  const int64_t inS = (int64_t)kz_align((size_t)inBytes + 64, 256);
+  int rc = pipe_setup(ctx, P, 1, count, inS + 256);
+  if (rc) return rc;
+  kz_batch& bt = P.bt;
+  hipStream_t st = ctx->stream;
+  u8* d_in = (u8*)kz_arena_alloc(ctx, (size_t)inS);
+  int64_t* d_off = (int64_t*)kz_arena_alloc(ctx, 64);
+  if (!d_off) return -KZ_ERR_DEVICE;
+  KZ_HIP(hipMemsetAsync(d_in, 0, (size_t)inS, st));
+  KZ_HIP(hipMemcpyAsync(d_in, in, (size_t)inBytes, hipMemcpyHostToDevice, st));
+  int64_t h[2] = {0, inBits};
+  KZ_HIP(hipMemcpyAsync(d_off, h, 16, hipMemcpyHostToDevice, st));
+  bt.h_len[0] = count;
+  KZ_HIP(hipMemcpyAsync(bt.d_len, &count, 4, hipMemcpyHostToDevice, st));
+  if (type == KZ_E_ANS0) {
+    rc = kz_stage_ans0_decode(ctx, bt, d_in, inS, d_off, d_off + 1);
+    if (rc) return rc;
+    int32_t flag = 0;
+    KZ_HIP(hipMemcpyAsync(&flag, bt.d_flag, 4, hipMemcpyDeviceToHost, st));
+    KZ_HIP(hipStreamSynchronize(st));
+    if (!flag) return -KZ_ERR_PROCESS_BLOCK;
+    KZ_HIP(hipMemcpyAsync(dst, bt.buf[bt.cur], (size_t)count, hipMemcpyDeviceToHost, st));
+  } else {
+    if (inBits < 8LL * count) return -KZ_ERR_PROCESS_BLOCK;
+    KZ_HIP(hipMemcpyAsync(dst, d_in, (size_t)count, hipMemcpyDeviceToHost, st));
+    if (bitsConsumed) *bitsConsumed = 8LL * count;
+  }
+  KZ_HIP(hipStreamSynchronize(st));
+  return count;
+}

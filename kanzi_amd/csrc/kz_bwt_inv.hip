@@ -1,0 +1,219 @@
+// kz_bwt_inv.hip -- inverse BWT for a batch of blocks on gfx950.
+//
+// Replaces K/transform/BWTBlockCodec.java:138-213 (header parse + checks) and
+// K/transform/BWT.java:245-374 (inverseMergeTPSI).  Same data structure as the reference -- a packed
+// link array data[j] = (next << 8) | byte built by a stable counting sort of the BWT bytes
+// (BWT.java:264-293) -- but built in parallel: LDS tile histograms, a per-symbol scan over tiles,
+// and a ballot match-any stable scatter; then the 8 primary-index walkers of each block
+// (BWT.java:295-368) chase pointers concurrently, 8 lanes per block, all blocks of the batch at once.
+// Limit: n <= 2^24 (the packed form; the reference switches to biPSIv2 above 8 MiB with the same
+// output) -- larger blocks return -KZ_ERR_BLOCK_SIZE.
+#include "kz_device.h"
+#include "kz_internal.h"
+
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+#define BI_ITEMS 16
+#define BI_TILE (KZ_WG * BI_ITEMS)
+
+struct BwtInv {
+  u32* data;        // [B][NS]
+  u32* tileHist;    // [B][T][256]
+  u32* bucket;      // [B][256]
+  int32_t* n;       // [B] payload length
+  int32_t* hdr;     // [B] header size
+  int32_t* prim;    // [B][8] primary indexes (as stored + 1)
+  int32_t* status;  // [B]
+  int64_t NS; int T;
+};
+
+__global__ void k_bwti_parse(const u8* __restrict__ src, int64_t stride, const int32_t* __restrict__ d_len, BwtInv V, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int blockSize = d_len[b];
+  const u8* s = src + (int64_t)b * stride;
+  int status = 0, n = 0, headerSize = 0;
+  for (int k = 0; k < 8; k++) V.prim[b * 8 + k] = 0;
+  if (blockSize > 0) {
+    const u8 mode = s[0];
+    const int logNbChunks = (mode >> 2) & 7;
+    const int pIndexSize = (mode & 3) + 1;
+    const int chunks = 1 << logNbChunks;
+    headerSize = 1 + chunks * pIndexSize;
+    if (blockSize < headerSize || chunks > 8) status = -KZ_ERR_PROCESS_BLOCK;          // :155-156
+    else {
+      n = blockSize - headerSize;
+      if (chunks != ((n < 256) ? 1 : 8)) status = -KZ_ERR_PROCESS_BLOCK;               // :158-159
+      else if (n > (1 << 24)) status = -KZ_ERR_BLOCK_SIZE;
+      else {
+        int pos = 1;
+        for (int i = 0; i < chunks; i++) {
+          long long pi = 0;
+          for (int k = 0; k < pIndexSize; k++) pi = (pi << 8) | s[pos++];
+          if (pi >= 0x7FFFFFFFLL) { status = -KZ_ERR_PROCESS_BLOCK; break; }
+          V.prim[b * 8 + i] = (int32_t)pi + 1;
+        }
+        if (status == 0 && n >= 2) {
+          const int p0 = V.prim[b * 8];
+          if (p0 <= 0 || p0 > n) status = -KZ_ERR_PROCESS_BLOCK;                        // BWT.java:261
+          if (chunks == 8) for (int k = 0; k < 8; k++) { const int t = V.prim[b * 8 + k] - 1; if (t < 0 || t >= n) status = -KZ_ERR_PROCESS_BLOCK; }  // :305-311
+        }
+      }
+    }
+  }
+  V.n[b] = (status == 0) ? n : 0;
+  V.hdr[b] = headerSize;
+  V.status[b] = status;
+}
+
+__global__ __launch_bounds__(KZ_WG) void k_bwti_hist(const u8* __restrict__ src, int64_t stride, BwtInv V) {
+  const int b = blockIdx.y, tile = blockIdx.x;
+  const int n = V.n[b];
+  if ((int64_t)tile * BI_TILE >= n) return;
+  __shared__ u32 hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const u8* s = src + (int64_t)b * stride + V.hdr[b];
+  const int base = tile * BI_TILE;
+#pragma unroll 4
+  for (int r = 0; r < BI_ITEMS; r++) {
+    const int idx = base + r * KZ_WG + threadIdx.x;
+    const bool valid = idx < n;
+    const u32 d = valid ? s[idx] : 0;
+    const uint64_t peers = kz_match8(d, valid);
+    if (valid && (peers & kz_lanemask_lt()) == 0) atomicAdd(&hist[d], (u32)__popcll(peers));
+  }
+  __syncthreads();
+  V.tileHist[((int64_t)b * V.T + tile) * 256 + threadIdx.x] = hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_bwti_scan(BwtInv V) {
+  const int b = blockIdx.x;
+  const int n = V.n[b];
+  const int tiles = (n + BI_TILE - 1) / BI_TILE;
+  __shared__ u32 lds[32];
+  u32* h = V.tileHist + (int64_t)b * V.T * 256;
+  u32 run = 0;
+  for (int t = 0; t < tiles; t++) {
+    const u32 v = h[(int64_t)t * 256 + threadIdx.x];
+    h[(int64_t)t * 256 + threadIdx.x] = run;
+    run += v;
+  }
+  u32 total;
+  const u32 ex = kz_wg_excl_sum(run, lds, &total);
+  V.bucket[b * 256 + threadIdx.x] = ex;
+}
+
+__global__ __launch_bounds__(KZ_WG) void k_bwti_scatter(const u8* __restrict__ src, int64_t stride, BwtInv V) {
+  const int b = blockIdx.y, tile = blockIdx.x;
+  const int n = V.n[b];
+  if ((int64_t)tile * BI_TILE >= n) return;
+  __shared__ u32 cnt[4][256];
+  for (int i = threadIdx.x; i < 1024; i += KZ_WG) (&cnt[0][0])[i] = 0;
+  __syncthreads();
+  const u8* s = src + (int64_t)b * stride + V.hdr[b];
+  u32* data = V.data + (int64_t)b * V.NS;
+  const int pIdx = V.prim[b * 8];
+  const int wave = threadIdx.x >> 6, lane = kz_lane();
+  const int base = tile * BI_TILE + wave * (64 * BI_ITEMS);
+  const uint64_t lt = kz_lanemask_lt();
+  u32 dr[BI_ITEMS];
+#pragma unroll
+  for (int r = 0; r < BI_ITEMS; r++) {
+    const int idx = base + r * 64 + lane;
+    const bool valid = idx < n;
+    const u32 d = valid ? s[idx] : 0;
+    const uint64_t peers = kz_match8(d, valid);
+    u32 pre = 0;
+    if (valid) pre = cnt[wave][d];
+    const u32 rnk = pre + (u32)__popcll(peers & lt);
+    if (valid && (peers >> lane) == 1ULL) cnt[wave][d] = pre + (u32)__popcll(peers);
+    dr[r] = d | (rnk << 8);
+  }
+  __syncthreads();
+  {
+    const int d = threadIdx.x;
+    u32 runv = V.bucket[b * 256 + d] + V.tileHist[((int64_t)b * V.T + tile) * 256 + d];
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const u32 t = cnt[w][d]; cnt[w][d] = runv; runv += t; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < BI_ITEMS; r++) {
+    const int i = base + r * 64 + lane;
+    if (i < n) {
+      const u32 c = dr[r] & 0xFF;
+      const u32 pos = cnt[wave][c] + (dr[r] >> 8);
+      // BWT.java:273-293: i==0 -> 0xFF00|c ; i<pIdx -> (i-1)<<8|c ; else i<<8|c
+      const u32 v = (i == 0) ? (0xFF00u | c) : (((u32)(i < pIdx ? i - 1 : i) << 8) | c);
+      data[pos] = v;
+    }
+  }
+}
+
+// walkers: lane k of the wave follows primary index k (BWT.java:295-368)
+__global__ __launch_bounds__(64) void k_bwti_walk(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride, BwtInv V,
+                                                   int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag) {
+  const int b = blockIdx.x;
+  const int n = V.n[b];
+  const int lane = kz_lane();
+  u8* d = dst + (int64_t)b * stride;
+  if (V.status[b] != 0) { if (lane == 0) { d_len2[b] = 0; d_flag[b] = 0; } return; }
+  if (lane == 0) { d_len2[b] = n; d_flag[b] = 1; }
+  if (n == 0) return;
+  if (n == 1) { if (lane == 0) d[0] = src[(int64_t)b * stride + V.hdr[b]]; return; }     // BWT.java:174-177 mirror
+  const u32* data = V.data + (int64_t)b * V.NS;
+  const int chunks = (n < 256) ? 1 : 8;
+  if (lane >= chunks) return;
+  const int ckSize = (chunks == 1) ? n : (((n & 7) == 0) ? (n >> 3) : (n >> 3) + 1);
+  const int start = lane * ckSize;
+  const int end = min(n, start + ckSize);
+  u32 t = (u32)(V.prim[b * 8 + lane] - 1);
+  bool bad = false;
+  for (int i = start; i < end; i++) {
+    if (t >= (u32)n) { bad = true; break; }
+    const u32 ptr = data[t];
+    d[i] = (u8)ptr;
+    t = ptr >> 8;
+  }
+  if (bad) { atomicExch(&V.status[b], -KZ_ERR_PROCESS_BLOCK); d_flag[b] = 0; }
+}
+
+size_t kz_bwt_inverse_scratch(int B, int maxN) {
+  const int64_t NS = (int64_t)kz_align((size_t)maxN + 64, BI_TILE);
+  const int T = (int)(NS / BI_TILE);
+  return (size_t)B * ((size_t)NS * 4 + (size_t)T * 1024 + 1024 + 64 * 4) + 8192;
+}
+
+int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
+  const int B = bt.B;
+  int maxN = 0;
+  for (int b = 0; b < B; b++) if (bt.h_len[b] > maxN) maxN = bt.h_len[b];
+  BwtInv V;
+  V.NS = (int64_t)kz_align((size_t)(maxN > 0 ? maxN : 1), BI_TILE);
+  V.T = (int)(V.NS / BI_TILE);
+  V.data = (u32*)kz_arena_alloc(ctx, (size_t)V.NS * B * 4);
+  V.tileHist = (u32*)kz_arena_alloc(ctx, (size_t)V.T * B * 1024);
+  V.bucket = (u32*)kz_arena_alloc(ctx, (size_t)B * 1024);
+  V.n = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  V.hdr = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  V.prim = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 32);
+  V.status = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  if (!V.status || !V.data) { snprintf(ctx->err, sizeof(ctx->err), "bwt_inverse: arena overflow"); return -KZ_ERR_DEVICE; }
+  hipStream_t st = ctx->stream;
+  const u8* src = bt.buf[bt.cur];
+  u8* dst = bt.buf[bt.cur ^ 1];
+  hipLaunchKernelGGL(k_bwti_parse, dim3((B + 63) / 64), dim3(64), 0, st, src, bt.stride, bt.d_len, V, B);
+  const int tiles = (maxN + BI_TILE - 1) / BI_TILE;
+  if (tiles > 0) {
+    hipLaunchKernelGGL(k_bwti_hist, dim3(tiles, B), dim3(KZ_WG), 0, st, src, bt.stride, V);
+    hipLaunchKernelGGL(k_bwti_scan, dim3(B), dim3(256), 0, st, V);
+    hipLaunchKernelGGL(k_bwti_scatter, dim3(tiles, B), dim3(KZ_WG), 0, st, src, bt.stride, V);
+  }
+  hipLaunchKernelGGL(k_bwti_walk, dim3(B), dim3(64), 0, st, src, dst, bt.stride, V, bt.d_len2, bt.d_flag);
+  KZ_HIP(hipGetLastError());
+  bt.cur ^= 1;
+  { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }
+  return 0;
+}

@@ -1,0 +1,71 @@
+// kz_internal.h -- host-side context + stage interfaces (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "../../include/kanzi_hip.h"
+
+struct kz_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // grow-only device arena, bump-allocated per API call
+  uint8_t* arena = nullptr;
+  size_t arenaCap = 0, arenaTop = 0;
+  // pinned host staging for small read-backs
+  int32_t* hpin = nullptr;       // 64K ints
+  char err[512] = {0};
+  // last-call stage timings (ms) for bench/roofline (hipEvent based)
+  float stageMs[KZ_MAX_STAGES] = {0};
+  int64_t stageAlgBytes[KZ_MAX_STAGES] = {0};
+  int nStages = 0;
+  bool timing = false;
+};
+
+#define KZ_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  snprintf(ctx->err, sizeof(ctx->err), "%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+  return -KZ_ERR_DEVICE; } } while (0)
+
+static inline size_t kz_align(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Reserve `total` bytes of arena (may reallocate: only call before any sub-allocation).
+int kz_arena_reserve(kz_ctx* ctx, size_t total);
+void* kz_arena_alloc(kz_ctx* ctx, size_t bytes);   // 256-byte aligned; nullptr on overflow
+
+// A batch of independent blocks resident in HBM: block b lives at base + b*stride.
+struct kz_batch {
+  int B = 0;            // blocks in the batch
+  int maxN = 0;         // largest original block length
+  int64_t stride = 0;   // bytes between blocks in each ping-pong buffer
+  uint8_t* buf[2] = {nullptr, nullptr};
+  int cur = 0;          // which buffer holds the current data
+  int32_t* d_len = nullptr;     // [B] current length per block (device)
+  int32_t* d_len2 = nullptr;    // [B] next length (stages write here, then swap)
+  int32_t* d_flag = nullptr;    // [B] per-stage applied flag (device)
+  std::vector<int32_t> h_len;   // host mirror of d_len
+};
+
+// ---- stages (each works on the whole batch; returns 0 or -KZ_ERR_*) ----
+// forward: reads batch.buf[cur] / d_len, writes buf[cur^1] / d_len and d_flag[b]=1 applied, 0 declined
+int kz_stage_bwt_forward(kz_ctx*, kz_batch&);
+int kz_stage_bwt_inverse(kz_ctx*, kz_batch&);
+int kz_stage_sbrt_forward(kz_ctx*, kz_batch&, int mode);
+int kz_stage_sbrt_inverse(kz_ctx*, kz_batch&, int mode);
+int kz_stage_zrlt_forward(kz_ctx*, kz_batch&);
+int kz_stage_zrlt_inverse(kz_ctx*, kz_batch&, int dstCap);
+// entropy: reads buf[cur]; writes per-block bitstring at out + b*outStride starting at byte offset
+// d_hdrBytes[b]; d_bits[b] = payload bits produced
+int kz_stage_ans0_encode(kz_ctx*, kz_batch&, uint8_t* out, int64_t outStride, const int32_t* d_hdrBytes, int64_t* d_bits);
+// decode: in = bitstrings (payload starts at bit offset d_bitOff[b]); count d_len[b]; writes buf[cur^1]
+int kz_stage_ans0_decode(kz_ctx*, kz_batch&, const uint8_t* in, int64_t inStride, const int64_t* d_bitOff, const int64_t* d_bitEnd);
+
+size_t kz_bwt_forward_scratch(int B, int maxN);
+size_t kz_bwt_inverse_scratch(int B, int maxN);
+size_t kz_sbrt_scratch(int B, int maxN);
+size_t kz_zrlt_scratch(int B, int maxN);
+size_t kz_ans_scratch(int B, int maxN);
+
+// timing helpers
+void kz_stage_begin(kz_ctx*, hipEvent_t* e0);
+void kz_stage_end(kz_ctx*, hipEvent_t e0, int stageId, int64_t algBytes);

@@ -1,0 +1,257 @@
+// kz_sbrt.hip -- Sort-By-Rank transform (RANK = SBR(1/2), MTF = SBR(0), TIMESTAMP) on gfx950.
+//
+// Replaces K/transform/SBRT.java:87-151 (forward) and :154-214 (inverse).
+//
+// The reference keeps a 256-entry list ordered by q[] (descending), most recently moved first among
+// equal q, never-seen symbols at the bottom in symbol order.  That order is a pure function of, per
+// symbol, its last two occurrence positions:  key(s) = (q_s << 32) | (p_s + 256)  for a seen symbol,
+// 255 - s for a never-seen one, and   rank(c) = #{ s : key(s) > key(c) }.
+//
+// forward (parallel):  1) per 8 KiB tile, last two occurrences of every symbol  2) per block, an
+//   exclusive "last-two" scan over tiles (thread = symbol)  3) every tile replays independently:
+//   one wave64 per tile holds the 256 keys in 4 x u64 VGPRs (symbol s = reg s>>6, lane s&63);
+//   a rank is 4 v_cmp_gt_u64 ballots + s_bcnt1.
+// inverse (serial per block by nature: the list state depends on every decoded symbol): one wave
+//   per block; the rank->symbol list lives in ONE VGPR (position j = lane j>>2, byte j&3) and a
+//   move-up is a DPP wave shift + byte funnel; blocks of the batch decode concurrently.
+#include "kz_device.h"
+#include "kz_internal.h"
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+#define SB_TS 8192               // bytes per tile
+
+__device__ __forceinline__ u64 kz_readlane64(u64 v, int l) {
+  u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, l);
+  u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l);
+  return ((u64)hi << 32) | lo;
+}
+
+// ---- forward 1/3: last two occurrences per symbol in each tile -------------------------------
+// tab[b][t][s] = (p1,p2) absolute positions, -1 = none
+__global__ __launch_bounds__(64) void k_sbrt_last2(const u8* __restrict__ src, int64_t stride, const int32_t* __restrict__ d_len,
+                                                    int2* __restrict__ tab, int T) {
+  const int b = blockIdx.y, t = blockIdx.x;
+  const int n = d_len[b];
+  const int start = t * SB_TS;
+  if (start >= n) return;
+  const int end = min(n, start + SB_TS);
+  const u8* s = src + (int64_t)b * stride;
+  const int lane = kz_lane();
+  int p1[4] = {-1, -1, -1, -1}, p2[4] = {-1, -1, -1, -1};
+  for (int row = start; row < end; row += 256) {
+    const int wi = row + lane * 4;
+    u32 w = 0;
+    if (wi + 3 < end) w = *(const u32*)(s + wi);
+    else { for (int k = 0; k < 4; k++) if (wi + k < end) w |= (u32)s[wi + k] << (8 * k); }
+    const int cnt = min(256, end - row);
+    for (int j = 0; j < cnt; j++) {
+      const u32 ww = (u32)__builtin_amdgcn_readlane((int)w, j >> 2);
+      const int c = (ww >> (8 * (j & 3))) & 0xFF;
+      const int i = row + j;
+      const bool mine = lane == (c & 63);
+      switch (c >> 6) {
+        case 0: if (mine) { p2[0] = p1[0]; p1[0] = i; } break;
+        case 1: if (mine) { p2[1] = p1[1]; p1[1] = i; } break;
+        case 2: if (mine) { p2[2] = p1[2]; p1[2] = i; } break;
+        default: if (mine) { p2[3] = p1[3]; p1[3] = i; } break;
+      }
+    }
+  }
+  int2* o = tab + ((int64_t)b * T + t) * 256;
+#pragma unroll
+  for (int q = 0; q < 4; q++) o[q * 64 + lane] = make_int2(p1[q], p2[q]);
+}
+
+// ---- forward 2/3: exclusive scan over tiles (thread = symbol) --------------------------------
+__global__ __launch_bounds__(256) void k_sbrt_scan(const int32_t* __restrict__ d_len, int2* __restrict__ tab, int T) {
+  const int b = blockIdx.x;
+  const int n = d_len[b];
+  const int tiles = (n + SB_TS - 1) / SB_TS;
+  int a1 = -1, a2 = -1;
+  int2* base = tab + (int64_t)b * T * 256 + threadIdx.x;
+  for (int t = 0; t < tiles; t++) {
+    int2 v = base[(int64_t)t * 256];
+    base[(int64_t)t * 256] = make_int2(a1, a2);
+    if (v.x >= 0) { if (v.y >= 0) { a1 = v.x; a2 = v.y; } else { a2 = a1; a1 = v.x; } }
+  }
+}
+
+__device__ __forceinline__ u64 kz_sbrt_key(int mode, int a1, int a2, int sym) {
+  if (a1 < 0) return (u64)(255 - sym);
+  const u32 pprev = a2 < 0 ? 0u : (u32)a2;          // p[] starts at 0 (SBRT.java:113-118)
+  u32 q;
+  if (mode == 2) q = ((u32)a1 + pprev) >> 1;         // RANK: (i + p[c]) >> 1
+  else if (mode == 1) q = (u32)a1;                   // MTF : i
+  else q = pprev;                                    // TIMESTAMP: p[c]
+  return ((u64)q << 32) | (u64)((u32)a1 + 256u);
+}
+
+#define KZ_SBRT_RANK_AND_UPDATE(CASE_Q)                                         \
+  { const u64 kc = kz_readlane64(k##CASE_Q, c & 63);                            \
+    cnt = (int)(__popcll(kz_ballot(k0 > kc)) + __popcll(kz_ballot(k1 > kc)) +   \
+                __popcll(kz_ballot(k2 > kc)) + __popcll(kz_ballot(k3 > kc)));   \
+    const u32 lo = (u32)kc;                                                     \
+    const u32 pc = (lo >= 256u) ? lo - 256u : 0u;                               \
+    const u32 qc = (mode == 2) ? (((u32)i + pc) >> 1) : ((mode == 1) ? (u32)i : pc); \
+    const u64 nk = ((u64)qc << 32) | (u64)((u32)i + 256u);                      \
+    if (lane == (c & 63)) k##CASE_Q = nk; }
+
+// ---- forward 3/3: replay one tile per wave ----------------------------------------------------
+__global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                                                     const int32_t* __restrict__ d_len, const int2* __restrict__ tab, int T, int mode) {
+  const int b = blockIdx.y, t = blockIdx.x;
+  const int n = d_len[b];
+  const int start = t * SB_TS;
+  if (start >= n) return;
+  const int end = min(n, start + SB_TS);
+  const u8* s = src + (int64_t)b * stride;
+  u8* d = dst + (int64_t)b * stride;
+  const int lane = kz_lane();
+  const int2* pre = tab + ((int64_t)b * T + t) * 256;
+  int2 v0 = pre[lane], v1 = pre[64 + lane], v2 = pre[128 + lane], v3 = pre[192 + lane];
+  u64 k0 = kz_sbrt_key(mode, v0.x, v0.y, lane);
+  u64 k1 = kz_sbrt_key(mode, v1.x, v1.y, 64 + lane);
+  u64 k2 = kz_sbrt_key(mode, v2.x, v2.y, 128 + lane);
+  u64 k3 = kz_sbrt_key(mode, v3.x, v3.y, 192 + lane);
+  for (int row = start; row < end; row += 256) {
+    const int wi = row + lane * 4;
+    u32 w = 0;
+    if (wi + 3 < end) w = *(const u32*)(s + wi);
+    else { for (int k = 0; k < 4; k++) if (wi + k < end) w |= (u32)s[wi + k] << (8 * k); }
+    const int cntRow = min(256, end - row);
+    u32 outw = 0;
+    u32 acc = 0;
+    for (int j = 0; j < cntRow; j++) {
+      const u32 ww = (u32)__builtin_amdgcn_readlane((int)w, j >> 2);
+      const int c = (ww >> (8 * (j & 3))) & 0xFF;
+      const int i = row + j;
+      int cnt;
+      switch (c >> 6) {
+        case 0: KZ_SBRT_RANK_AND_UPDATE(0) break;
+        case 1: KZ_SBRT_RANK_AND_UPDATE(1) break;
+        case 2: KZ_SBRT_RANK_AND_UPDATE(2) break;
+        default: KZ_SBRT_RANK_AND_UPDATE(3) break;
+      }
+      acc |= (u32)cnt << (8 * (j & 3));
+      if ((j & 3) == 3 || j == cntRow - 1) { if (lane == (j >> 2)) outw = acc; acc = 0; }
+    }
+    if (wi + 3 < end) *(u32*)(d + wi) = outw;
+    else { for (int k = 0; k < 4; k++) if (wi + k < end) d[wi + k] = (u8)(outw >> (8 * k)); }
+  }
+}
+
+// ---- inverse: one wave per block ---------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_sbrt_inverse(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                                                      const int32_t* __restrict__ d_len, int mode) {
+  const int b = blockIdx.x;
+  const int n = d_len[b];
+  const u8* s = src + (int64_t)b * stride;
+  u8* d = dst + (int64_t)b * stride;
+  const int lane = kz_lane();
+  // list: position j -> lane j>>2, byte j&3 ; initially r2s[j] = j
+  u32 list = (u32)(4 * lane) | ((u32)(4 * lane + 1) << 8) | ((u32)(4 * lane + 2) << 16) | ((u32)(4 * lane + 3) << 24);
+  u64 k0 = (u64)(255 - lane), k1 = (u64)(255 - 64 - lane), k2 = (u64)(255 - 128 - lane), k3 = (u64)(255 - 192 - lane);
+  for (int row = 0; row < n; row += 256) {
+    const int wi = row + lane * 4;
+    u32 w = 0;
+    if (wi + 3 < n) w = *(const u32*)(s + wi);
+    else { for (int k = 0; k < 4; k++) if (wi + k < n) w |= (u32)s[wi + k] << (8 * k); }
+    const int cntRow = min(256, n - row);
+    u32 outw = 0, acc = 0;
+    for (int j = 0; j < cntRow; j++) {
+      const u32 ww = (u32)__builtin_amdgcn_readlane((int)w, j >> 2);
+      const int r = (ww >> (8 * (j & 3))) & 0xFF;
+      const int i = row + j;
+      const u32 lw = (u32)__builtin_amdgcn_readlane((int)list, r >> 2);
+      const int c = (lw >> (8 * (r & 3))) & 0xFF;
+      u64 kc;
+      switch (c >> 6) {
+        case 0: kc = kz_readlane64(k0, c & 63); break;
+        case 1: kc = kz_readlane64(k1, c & 63); break;
+        case 2: kc = kz_readlane64(k2, c & 63); break;
+        default: kc = kz_readlane64(k3, c & 63); break;
+      }
+      const u32 lo = (u32)kc;
+      const u32 pc = (lo >= 256u) ? lo - 256u : 0u;
+      const u32 qc = (mode == 2) ? (((u32)i + pc) >> 1) : ((mode == 1) ? (u32)i : pc);
+      const u64 nk = ((u64)qc << 32) | (u64)((u32)i + 256u);
+      if (r != 0) {
+        // new position = number of symbols whose key exceeds the new key (c's old key is smaller)
+        const int rp = (int)(__popcll(kz_ballot(k0 > nk)) + __popcll(kz_ballot(k1 > nk)) +
+                             __popcll(kz_ballot(k2 > nk)) + __popcll(kz_ballot(k3 > nk)));
+        if (rp != r) {
+          // positions (rp, r] take their predecessor, position rp takes c
+          const u32 prev = (u32)__builtin_amdgcn_update_dpp(0, (int)list, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+          const u32 shifted = (list << 8) | (prev >> 24);
+          const int jb = 4 * lane;
+          const int a = (rp + 1) - jb;                 // first shifted byte index within this lane
+          const int e = r - jb + 1;                    // number of leading bytes <= r
+          const u32 mlo = (a <= 0) ? 0xFFFFFFFFu : ((a >= 4) ? 0u : (0xFFFFFFFFu << (8 * a)));
+          const u32 mhi = (e <= 0) ? 0u : ((e >= 4) ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (8 * (4 - e))));
+          const u32 mask = mlo & mhi;
+          u32 nl = (shifted & mask) | (list & ~mask);
+          if (lane == (rp >> 2)) { const int sh = 8 * (rp & 3); nl = (nl & ~(0xFFu << sh)) | ((u32)c << sh); }
+          list = nl;
+        }
+      }
+      switch (c >> 6) {
+        case 0: if (lane == (c & 63)) k0 = nk; break;
+        case 1: if (lane == (c & 63)) k1 = nk; break;
+        case 2: if (lane == (c & 63)) k2 = nk; break;
+        default: if (lane == (c & 63)) k3 = nk; break;
+      }
+      acc |= (u32)c << (8 * (j & 3));
+      if ((j & 3) == 3 || j == cntRow - 1) { if (lane == (j >> 2)) outw = acc; acc = 0; }
+    }
+    if (wi + 3 < n) *(u32*)(d + wi) = outw;
+    else { for (int k = 0; k < 4; k++) if (wi + k < n) d[wi + k] = (u8)(outw >> (8 * k)); }
+  }
+}
+
+__global__ void k_copy_len(const int32_t* a, int32_t* o, int32_t* flag, int B) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) { o[b] = a[b]; flag[b] = 1; }
+}
+
+size_t kz_sbrt_scratch(int B, int maxN) {
+  const int T = (maxN + 64 + SB_TS - 1) / SB_TS + 1;
+  return (size_t)B * T * 256 * sizeof(int2) + 4096;
+}
+
+int kz_stage_sbrt_forward(kz_ctx* ctx, kz_batch& bt, int mode) {
+  const int B = bt.B;
+  int maxN = 0;
+  for (int b = 0; b < B; b++) if (bt.h_len[b] > maxN) maxN = bt.h_len[b];
+  const int T = (maxN + SB_TS - 1) / SB_TS + 1;
+  int2* tab = (int2*)kz_arena_alloc(ctx, (size_t)B * T * 256 * sizeof(int2));
+  if (!tab) { snprintf(ctx->err, sizeof(ctx->err), "sbrt_forward: arena overflow"); return -KZ_ERR_DEVICE; }
+  hipStream_t st = ctx->stream;
+  const u8* src = bt.buf[bt.cur];
+  u8* dst = bt.buf[bt.cur ^ 1];
+  if (maxN > 0) {
+    hipLaunchKernelGGL(k_sbrt_last2, dim3(T, B), dim3(64), 0, st, src, bt.stride, bt.d_len, tab, T);
+    hipLaunchKernelGGL(k_sbrt_scan, dim3(B), dim3(256), 0, st, bt.d_len, tab, T);
+    hipLaunchKernelGGL(k_sbrt_replay, dim3(T, B), dim3(64), 0, st, src, dst, bt.stride, bt.d_len, tab, T, mode);
+  }
+  hipLaunchKernelGGL(k_copy_len, dim3((B + 255) / 256), dim3(256), 0, st, bt.d_len, bt.d_len2, bt.d_flag, B);
+  KZ_HIP(hipGetLastError());
+  bt.cur ^= 1;
+  { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }
+  return 0;
+}
+
+int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
+  const int B = bt.B;
+  hipStream_t st = ctx->stream;
+  const u8* src = bt.buf[bt.cur];
+  u8* dst = bt.buf[bt.cur ^ 1];
+  hipLaunchKernelGGL(k_sbrt_inverse, dim3(B), dim3(64), 0, st, src, dst, bt.stride, bt.d_len, mode);
+  hipLaunchKernelGGL(k_copy_len, dim3((B + 255) / 256), dim3(256), 0, st, bt.d_len, bt.d_len2, bt.d_flag, B);
+  KZ_HIP(hipGetLastError());
+  bt.cur ^= 1;
+  { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }
+  return 0;
+}

@@ -1,0 +1,384 @@
+// kz_zrlt.hip -- Zero Run Length Transform on gfx950 (scan-based, tile-parallel).
+//
+// Replaces K/transform/ZRLT.java:54-136 (forward) and :146-233 (inverse).
+//  forward token rules (:80-130): zero run of length L -> bits of (L+1) below its MSB, one byte
+//  (0/1) each, MSB first; byte v>=0xFE -> 0xFF,(v-0xFE); else v+1.  dstEnd = dstIdx0 + n ("do not
+//  expand"): run needs dstIdx < dstEnd-log2 (:94), escape dstIdx < dstEnd-1 (:111), literal
+//  dstIdx < dstEnd (:120); any violation => forward returns false (transform skipped).
+//
+// Parallel form: a token is emitted by the thread that owns the byte where it ENDS.  The length of
+// a zero run reaching back across threads/tiles is (own start) - (position after the last non-zero
+// byte before it), which is an exclusive MAX-scan of "last non-zero position + 1" -- done per
+// workgroup with wave shuffles + LDS and per block over tile summaries.  Output offsets are an
+// exclusive SUM-scan of token sizes over the same hierarchy.
+#include "kz_device.h"
+#include "kz_internal.h"
+
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+#define ZR_PER 16
+#define ZR_TILE (KZ_WG * ZR_PER)      // 4096 bytes per workgroup
+
+struct ZrScratch {
+  u32* tLastNz;   // [B][T]  abs position+1 of the last non-zero byte of the tile (0 = none)
+  u32* tInner;    // [B][T]  tokens whose size is known inside the tile
+  u32* tLead;     // [B][T]  leading zeros of the tile (tile length when all zero)
+  u32* tP;        // [B][T]  exclusive max-scan of tLastNz
+  u32* tOff;      // [B][T]  exclusive sum-scan of tile output sizes
+  int32_t* fail;  // [B]
+  int32_t* total; // [B]
+  int T;
+};
+
+__device__ __forceinline__ void zr_load16(const u8* s, int pos, int n, u8* v) {
+  if (pos + 16 <= n) { uint4 q = *(const uint4*)(s + pos); memcpy(v, &q, 16); }
+  else { for (int k = 0; k < 16; k++) v[k] = (pos + k < n) ? s[pos + k] : 1; }   // pad non-zero (never emitted)
+}
+
+// size of the tokens a thread emits for its 16-byte chunk, given `carry` zeros pending before it.
+// firstKnown=false: the run ending at the first non-zero byte is NOT counted (size unknown yet).
+__device__ __forceinline__ u32 zr_chunk_size(const u8* v, int cnt, u32 carry, bool firstKnown, bool isBlockEnd) {
+  u32 out = 0, run = carry;
+  bool first = true;
+  for (int k = 0; k < cnt; k++) {
+    if (v[k] == 0) { run++; continue; }
+    if (run > 0) { if (!first || firstKnown) out += (u32)kz_ilog2(run + 1); run = 0; }
+    first = false;
+    out += (v[k] >= 0xFE) ? 2u : 1u;
+  }
+  if (isBlockEnd && run > 0 && (!first || firstKnown)) out += (u32)kz_ilog2(run + 1);
+  return out;
+}
+
+// ---- forward 1/3 ------------------------------------------------------------------------------
+__global__ __launch_bounds__(KZ_WG) void k_zrlt_f1(const u8* __restrict__ src, int64_t stride, const int32_t* __restrict__ d_len, ZrScratch S) {
+  const int b = blockIdx.y, t = blockIdx.x;
+  const int n = d_len[b];
+  const int tstart = t * ZR_TILE;
+  if (tstart >= n) return;
+  __shared__ u32 lds[32];
+  const u8* s = src + (int64_t)b * stride;
+  const int pos = tstart + threadIdx.x * ZR_PER;
+  u8 v[16];
+  int cnt = 0;
+  u32 lastnz = 0;
+  if (pos < n) { zr_load16(s, pos, n, v); cnt = min(16, n - pos); for (int k = 0; k < cnt; k++) if (v[k]) lastnz = (u32)(pos + k + 1); }
+  u32 tot;
+  u32 inc = kz_wg_incl_max(lastnz, lds, &tot);
+  // exclusive max over previous threads
+  __shared__ u32 wl[4];
+  u32 prev = __shfl_up(inc, 1, 64);
+  if (kz_lane() == 63) wl[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  if (kz_lane() == 0) prev = (threadIdx.x >> 6) ? wl[(threadIdx.x >> 6) - 1] : 0;
+  u32 sz = 0;
+  if (cnt > 0) {
+    const bool known = prev > 0;                       // a non-zero byte precedes us inside the tile
+    const u32 carry = known ? (u32)pos - prev : 0;
+    const bool blockEnd = (pos + cnt == n);
+    sz = zr_chunk_size(v, cnt, carry, known, blockEnd);
+    // a block-end trailing run whose start is unknown here (tile all zero) is added in f2
+  }
+  u32 total;
+  kz_wg_excl_sum(sz, lds, &total);
+  // leading zeros of the tile
+  if (threadIdx.x == 0) {
+    const int64_t o = (int64_t)b * S.T + t;
+    S.tLastNz[o] = tot;
+    S.tInner[o] = total;
+  }
+  // first non-zero position (min-reduce) -> tLead
+  u32 firstnz = 0xFFFFFFFFu;
+  if (cnt > 0) for (int k = cnt - 1; k >= 0; k--) if (v[k]) firstnz = (u32)(pos + k);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { u32 o = __shfl_xor(firstnz, d, 64); firstnz = o < firstnz ? o : firstnz; }
+  __shared__ u32 wf[4];
+  if (kz_lane() == 0) wf[threadIdx.x >> 6] = firstnz;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 f = min(min(wf[0], wf[1]), min(wf[2], wf[3]));
+    const int tlen = min(ZR_TILE, n - tstart);
+    S.tLead[(int64_t)b * S.T + t] = (f == 0xFFFFFFFFu) ? (u32)tlen : f - (u32)tstart;
+  }
+}
+
+// ---- forward 2/3: per block scan over tiles (one wave) ----------------------------------------
+__global__ __launch_bounds__(64) void k_zrlt_f2(const int32_t* __restrict__ d_len, ZrScratch S) {
+  const int b = blockIdx.x;
+  const int n = d_len[b];
+  const int tiles = (n + ZR_TILE - 1) / ZR_TILE;
+  const int64_t o = (int64_t)b * S.T;
+  const int lane = kz_lane();
+  u32 carryMax = 0, carrySum = 0;
+  for (int base = 0; base < tiles; base += 64) {
+    const int t = base + lane;
+    const bool ok = t < tiles;
+    const u32 ln = ok ? S.tLastNz[o + t] : 0;
+    u32 incm = kz_wave_incl_max(ln);
+    u32 P = __shfl_up(incm, 1, 64); if (lane == 0) P = 0;
+    P = P > carryMax ? P : carryMax;                       // abs pos+1 of last non-zero before the tile
+    u32 sz = 0;
+    if (ok) {
+      const u32 tstart = (u32)t * ZR_TILE;
+      const u32 tlen = (u32)min(ZR_TILE, n - (int)tstart);
+      const u32 lead = S.tLead[o + t];
+      const bool allzero = (ln == 0);
+      sz = S.tInner[o + t];
+      if (!allzero) { const u32 run = tstart - P + lead; if (run > 0) sz += (u32)kz_ilog2(run + 1); }
+      if (t == tiles - 1) {
+        // trailing run of the block whose start lies before the last non-zero of ... any tile
+        const u32 lastAll = ln > P ? ln : P;                // last non-zero over the whole block
+        const u32 R = (u32)n - lastAll;
+        // f1 already counted it when the owning thread knew its start (a non-zero precedes it in-tile)
+        const bool countedInF1 = (ln != 0);
+        if (R > 0 && !countedInF1) sz += (u32)kz_ilog2(R + 1);
+        (void)tlen;
+      }
+      S.tP[o + t] = P;
+    }
+    u32 incs = kz_wave_incl_sum(sz);
+    if (ok) S.tOff[o + t] = carrySum + incs - sz;
+    carrySum += __shfl(incs, 63, 64);
+    u32 lastm = __shfl(incm, 63, 64);
+    carryMax = carryMax > lastm ? carryMax : lastm;
+  }
+  if (lane == 0) { S.total[b] = (int32_t)carrySum; S.fail[b] = 0; }
+}
+
+// ---- forward 3/3: emit ----------------------------------------------------------------------------
+__global__ __launch_bounds__(KZ_WG) void k_zrlt_f3(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                                                    const int32_t* __restrict__ d_len, ZrScratch S) {
+  const int b = blockIdx.y, t = blockIdx.x;
+  const int n = d_len[b];
+  const int tstart = t * ZR_TILE;
+  if (tstart >= n) return;
+  __shared__ u32 lds[32];
+  __shared__ u32 wl[4];
+  const u8* s = src + (int64_t)b * stride;
+  u8* d = dst + (int64_t)b * stride;
+  const int pos = tstart + threadIdx.x * ZR_PER;
+  u8 v[16];
+  int cnt = 0;
+  u32 lastnz = 0;
+  if (pos < n) { zr_load16(s, pos, n, v); cnt = min(16, n - pos); for (int k = 0; k < cnt; k++) if (v[k]) lastnz = (u32)(pos + k + 1); }
+  u32 tot;
+  u32 inc = kz_wg_incl_max(lastnz, lds, &tot);
+  u32 prev = __shfl_up(inc, 1, 64);
+  if (kz_lane() == 63) wl[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  if (kz_lane() == 0) prev = (threadIdx.x >> 6) ? wl[(threadIdx.x >> 6) - 1] : 0;
+  const u32 tileP = S.tP[(int64_t)b * S.T + t];
+  const u32 P = prev > tileP ? prev : tileP;
+  const u32 carry = (cnt > 0) ? (u32)pos - P : 0;
+  const bool blockEnd = (cnt > 0) && (pos + cnt == n);
+  u32 sz = (cnt > 0) ? zr_chunk_size(v, cnt, carry, true, blockEnd) : 0;
+  u32 total;
+  u32 off = kz_wg_excl_sum(sz, lds, &total) + S.tOff[(int64_t)b * S.T + t];
+  if (cnt == 0) return;
+  // emit with the reference's bound checks; dstEnd = n
+  const u32 dstEnd = (u32)n;
+  u32 run = carry;
+  bool fail = false;
+  for (int k = 0; k <= cnt; k++) {
+    if (k < cnt && v[k] == 0) { run++; continue; }
+    if (k == cnt && !blockEnd) break;
+    if (run > 0) {
+      const u32 rl = run + 1;
+      int lg = kz_ilog2(rl);
+      if (off + (u32)lg >= dstEnd) { fail = true; off += (u32)lg; }      // ZRLT.java:94  dstIdx >= dstEnd - log2
+      else { while (lg > 0) { lg--; d[off++] = (u8)((rl >> lg) & 1); } }
+      run = 0;
+    }
+    if (k == cnt) break;
+    const u32 val = v[k];
+    if (val >= 0xFE) {
+      if (off + 1 >= dstEnd) fail = true;                        // :111
+      else { d[off] = 0xFF; d[off + 1] = (u8)(val - 0xFE); }
+      off += 2;
+    } else {
+      if (off >= dstEnd) fail = true;                            // :120
+      else d[off] = (u8)(val + 1);
+      off += 1;
+    }
+  }
+  if (fail) atomicOr(&S.fail[b], 1);
+}
+
+// finalize: applied -> length = total ; declined -> copy input through (Sequence.java:95-105)
+__global__ void k_zrlt_ffin(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                            const int32_t* __restrict__ d_len, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag, ZrScratch S) {
+  const int b = blockIdx.y;
+  const int n = d_len[b];
+  const bool fail = (S.fail[b] != 0);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { d_len2[b] = fail ? n : ((n == 0) ? 0 : S.total[b]); d_flag[b] = fail ? 0 : 1; }
+  if (!fail) return;
+  const u8* s = src + (int64_t)b * stride;
+  u8* d = dst + (int64_t)b * stride;
+  for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += gridDim.x * blockDim.x * 16) {
+    if (i + 16 <= n) *(uint4*)(d + i) = *(const uint4*)(s + i);
+    else for (int k = i; k < n; k++) d[k] = s[k];
+  }
+}
+
+// =================================================================================================
+// inverse
+// classification of input byte i (ZRLT.java:167-214): payload = byte following an escape 0xFF
+__device__ __forceinline__ bool zr_is_payload(const u8* s, int i) {
+  int k = 0;
+  while (i - 1 - k >= 0 && s[i - 1 - k] == 0xFF) k++;
+  return (k & 1) != 0;
+}
+
+// output bytes produced by the token STARTING at input byte i (0 if i is inside a token)
+__device__ __forceinline__ u32 zr_inv_token(const u8* s, int i, int n, bool* bad) {
+  const u32 v = s[i];
+  const bool payload = zr_is_payload(s, i);
+  if (payload) return 0;
+  if (v <= 1) {
+    if (i > 0 && s[i - 1] <= 1 && !zr_is_payload(s, i - 1)) return 0;     // not the head digit
+    u32 rl = 1;
+    int k = i, digits = 0;
+    while (k < n && s[k] <= 1) { rl = (rl << 1) | s[k]; k++; if (++digits > 30) { *bad = true; break; } }
+    return rl - 1;
+  }
+  if (v == 0xFF) return (i + 1 < n) ? 1u : 0u;
+  return 1u;
+}
+
+struct ZiScratch { u32* tSum; u32* tOff; int32_t* total; int32_t* fail; int T; };
+
+__global__ __launch_bounds__(KZ_WG) void k_zrlt_i1(const u8* __restrict__ src, int64_t stride, const int32_t* __restrict__ d_len, ZiScratch S) {
+  const int b = blockIdx.y, t = blockIdx.x;
+  const int n = d_len[b];
+  const int tstart = t * ZR_TILE;
+  if (tstart >= n) return;
+  __shared__ u32 lds[32];
+  const u8* s = src + (int64_t)b * stride;
+  const int pos = tstart + threadIdx.x * ZR_PER;
+  u32 sz = 0; bool bad = false;
+  for (int k = 0; k < ZR_PER; k++) if (pos + k < n) sz += zr_inv_token(s, pos + k, n, &bad);
+  if (bad) atomicOr(&S.fail[b], 1);
+  u32 total;
+  kz_wg_excl_sum(sz, lds, &total);
+  if (threadIdx.x == 0) S.tSum[(int64_t)b * S.T + t] = total;
+}
+
+__global__ __launch_bounds__(64) void k_zrlt_i2(const int32_t* __restrict__ d_len, ZiScratch S, int dstCap) {
+  const int b = blockIdx.x;
+  const int n = d_len[b];
+  const int tiles = (n + ZR_TILE - 1) / ZR_TILE;
+  const int64_t o = (int64_t)b * S.T;
+  const int lane = kz_lane();
+  unsigned long long carry = 0;
+  for (int base = 0; base < tiles; base += 64) {
+    const int t = base + lane;
+    const u32 v = (t < tiles) ? S.tSum[o + t] : 0;
+    u32 inc = kz_wave_incl_sum(v);
+    if (t < tiles) S.tOff[o + t] = (u32)carry + inc - v;
+    carry += __shfl(inc, 63, 64);
+  }
+  if (lane == 0) {
+    if (carry > (unsigned long long)dstCap) { S.fail[b] = 1; S.total[b] = 0; }
+    else S.total[b] = (int32_t)carry;
+  }
+}
+
+__global__ __launch_bounds__(KZ_WG) void k_zrlt_i3(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                                                    const int32_t* __restrict__ d_len, ZiScratch S) {
+  const int b = blockIdx.y, t = blockIdx.x;
+  const int n = d_len[b];
+  const int tstart = t * ZR_TILE;
+  if (tstart >= n || S.fail[b]) return;
+  __shared__ u32 lds[32];
+  const u8* s = src + (int64_t)b * stride;
+  u8* d = dst + (int64_t)b * stride;
+  const int pos = tstart + threadIdx.x * ZR_PER;
+  u32 sz[ZR_PER]; u32 sum = 0; bool bad = false;
+  for (int k = 0; k < ZR_PER; k++) { sz[k] = (pos + k < n) ? zr_inv_token(s, pos + k, n, &bad) : 0; sum += sz[k]; }
+  u32 total;
+  u32 off = kz_wg_excl_sum(sum, lds, &total) + S.tOff[(int64_t)b * S.T + t];
+  for (int k = 0; k < ZR_PER; k++) {
+    const int i = pos + k;
+    if (i >= n) break;
+    const u32 v = s[i];
+    if (sz[k] && v > 1) d[off] = (v == 0xFF) ? (u8)(0xFE + s[i + 1]) : (u8)(v - 1);   // zero runs: dst pre-zeroed
+    off += sz[k];
+  }
+}
+
+__global__ void k_zrlt_ifin(const int32_t* __restrict__ d_len, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag, ZiScratch S, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const bool fail = S.fail[b] != 0;
+  d_len2[b] = fail ? 0 : ((d_len[b] == 0) ? 0 : S.total[b]);
+  d_flag[b] = fail ? 0 : 1;
+}
+
+size_t kz_zrlt_scratch(int B, int maxN) {
+  const int T = (maxN + 64 + ZR_TILE - 1) / ZR_TILE + 1;
+  return (size_t)B * T * 4 * 6 + (size_t)B * 16 + 8192;
+}
+
+int kz_stage_zrlt_forward(kz_ctx* ctx, kz_batch& bt) {
+  const int B = bt.B;
+  int maxN = 0;
+  for (int b = 0; b < B; b++) if (bt.h_len[b] > maxN) maxN = bt.h_len[b];
+  ZrScratch S;
+  S.T = (maxN + ZR_TILE - 1) / ZR_TILE + 1;
+  S.tLastNz = (u32*)kz_arena_alloc(ctx, (size_t)B * S.T * 4);
+  S.tInner = (u32*)kz_arena_alloc(ctx, (size_t)B * S.T * 4);
+  S.tLead = (u32*)kz_arena_alloc(ctx, (size_t)B * S.T * 4);
+  S.tP = (u32*)kz_arena_alloc(ctx, (size_t)B * S.T * 4);
+  S.tOff = (u32*)kz_arena_alloc(ctx, (size_t)B * S.T * 4);
+  S.fail = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  S.total = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  if (!S.total) { snprintf(ctx->err, sizeof(ctx->err), "zrlt_forward: arena overflow"); return -KZ_ERR_DEVICE; }
+  hipStream_t st = ctx->stream;
+  const u8* src = bt.buf[bt.cur];
+  u8* dst = bt.buf[bt.cur ^ 1];
+  KZ_HIP(hipMemsetAsync(S.fail, 0, (size_t)B * 4, st));
+  KZ_HIP(hipMemsetAsync(S.total, 0, (size_t)B * 4, st));
+  if (maxN > 0) {
+    const int tiles = (maxN + ZR_TILE - 1) / ZR_TILE;
+    hipLaunchKernelGGL(k_zrlt_f1, dim3(tiles, B), dim3(KZ_WG), 0, st, src, bt.stride, bt.d_len, S);
+    hipLaunchKernelGGL(k_zrlt_f2, dim3(B), dim3(64), 0, st, bt.d_len, S);
+    hipLaunchKernelGGL(k_zrlt_f3, dim3(tiles, B), dim3(KZ_WG), 0, st, src, dst, bt.stride, bt.d_len, S);
+  }
+  hipLaunchKernelGGL(k_zrlt_ffin, dim3(64, B), dim3(256), 0, st, src, dst, bt.stride, bt.d_len, bt.d_len2, bt.d_flag, S);
+  KZ_HIP(hipGetLastError());
+  bt.cur ^= 1;
+  { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }
+  return 0;
+}
+
+int kz_stage_zrlt_inverse(kz_ctx* ctx, kz_batch& bt, int dstCap) {
+  const int B = bt.B;
+  int maxN = 0;
+  for (int b = 0; b < B; b++) if (bt.h_len[b] > maxN) maxN = bt.h_len[b];
+  ZiScratch S;
+  S.T = (maxN + ZR_TILE - 1) / ZR_TILE + 1;
+  S.tSum = (u32*)kz_arena_alloc(ctx, (size_t)B * S.T * 4);
+  S.tOff = (u32*)kz_arena_alloc(ctx, (size_t)B * S.T * 4);
+  S.fail = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  S.total = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  if (!S.total) { snprintf(ctx->err, sizeof(ctx->err), "zrlt_inverse: arena overflow"); return -KZ_ERR_DEVICE; }
+  hipStream_t st = ctx->stream;
+  const u8* src = bt.buf[bt.cur];
+  u8* dst = bt.buf[bt.cur ^ 1];
+  if ((int64_t)dstCap > bt.stride) dstCap = (int)bt.stride;
+  KZ_HIP(hipMemsetAsync(S.fail, 0, (size_t)B * 4, st));
+  KZ_HIP(hipMemsetAsync(S.total, 0, (size_t)B * 4, st));
+  KZ_HIP(hipMemsetAsync(dst, 0, (size_t)bt.stride * B, st));       // zero runs are "written" here
+  if (maxN > 0) {
+    const int tiles = (maxN + ZR_TILE - 1) / ZR_TILE;
+    hipLaunchKernelGGL(k_zrlt_i1, dim3(tiles, B), dim3(KZ_WG), 0, st, src, bt.stride, bt.d_len, S);
+    hipLaunchKernelGGL(k_zrlt_i2, dim3(B), dim3(64), 0, st, bt.d_len, S, dstCap);
+    hipLaunchKernelGGL(k_zrlt_i3, dim3(tiles, B), dim3(KZ_WG), 0, st, src, dst, bt.stride, bt.d_len, S);
+  }
+  hipLaunchKernelGGL(k_zrlt_ifin, dim3((B + 255) / 256), dim3(256), 0, st, bt.d_len, bt.d_len2, bt.d_flag, S, B);
+  KZ_HIP(hipGetLastError());
+  bt.cur ^= 1;
+  { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }
+  return 0;
+}
