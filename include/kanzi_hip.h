@@ -115,6 +115,14 @@ int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, i
                     const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstCap);
 int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstCap);
 uint64_t kz_transform_type(const int32_t* types, int32_t nb);
+/* host-only container helpers (no GPU touched): assemble a .knz from per-block streams gathered in
+ * block-id order (stream header :236-313, 5+lw bit length prefix + payload per block :1024-1035, end
+ * marker :491-492); index = the serial walk of block prefixes a decoder must do first (:1127-1129). */
+int64_t kz_knz_assemble(uint64_t transformType, uint32_t entropyType, int32_t blockSize, int64_t inputSize,
+                        const uint8_t* streams, int64_t stride, const int64_t* bits, int32_t nBlocks,
+                        uint8_t* dst, int64_t dstCap);
+int32_t kz_knz_index(const uint8_t* src, int64_t n, uint64_t* transformType, uint32_t* entropyType,
+                     int32_t* blockSize, int64_t* inputSize, int64_t* blockBitOff, int64_t* blockBits, int32_t cap);
 
 /* ---- instrumentation (bench.py / roofline) ----------------------------------------------------- */
 void    kz_set_timing(kz_ctx* ctx, int32_t enable);     /* hipEvent-bracket every stage of the next calls */
@@ -122,6 +130,13 @@ int32_t kz_get_stage_count(kz_ctx* ctx);
 float   kz_get_stage_ms(kz_ctx* ctx, int32_t stage);    /* accumulated since last kz_reset_timing */
 int64_t kz_get_stage_alg_bytes(kz_ctx* ctx, int32_t stage);
 void    kz_reset_timing(kz_ctx* ctx);
+/* per-kernel: HIP events recorded on the context's stream around every kernel launch */
+void        kz_set_kernel_timing(kz_ctx* ctx, int32_t enable);
+int32_t     kz_get_kernel_count(void);
+const char* kz_get_kernel_name(int32_t id);
+double      kz_get_kernel_ms(kz_ctx* ctx, int32_t id);        /* summed launch durations since reset */
+int64_t     kz_get_kernel_launches(kz_ctx* ctx, int32_t id);
+void        kz_reset_kernel_timing(kz_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -75,11 +75,19 @@ def load_library():
         "kz_compress": (c.c_int64, [vp, c.c_uint64, c.c_uint32, c.c_int32, u8p, c.c_int64, u8p, c.c_int64]),
         "kz_decompress": (c.c_int64, [vp, u8p, c.c_int64, u8p, c.c_int64]),
         "kz_transform_type": (c.c_uint64, [i32p, c.c_int32]),
+        "kz_knz_assemble": (c.c_int64, [c.c_uint64, c.c_uint32, c.c_int32, c.c_int64, u8p, c.c_int64, i64p, c.c_int32, u8p, c.c_int64]),
+        "kz_knz_index": (c.c_int32, [u8p, c.c_int64, vp, vp, vp, vp, i64p, i64p, c.c_int32]),
         "kz_set_timing": (None, [vp, c.c_int32]),
         "kz_get_stage_count": (c.c_int32, [vp]),
         "kz_get_stage_ms": (c.c_float, [vp, c.c_int32]),
         "kz_get_stage_alg_bytes": (c.c_int64, [vp, c.c_int32]),
         "kz_reset_timing": (None, [vp]),
+        "kz_set_kernel_timing": (None, [vp, c.c_int32]),
+        "kz_get_kernel_count": (c.c_int32, []),
+        "kz_get_kernel_name": (c.c_char_p, [c.c_int32]),
+        "kz_get_kernel_ms": (c.c_double, [vp, c.c_int32]),
+        "kz_get_kernel_launches": (c.c_int64, [vp, c.c_int32]),
+        "kz_reset_kernel_timing": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError if the .so does not export it
@@ -93,7 +101,10 @@ ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_err
                "kz_transform_forward", "kz_transform_inverse", "kz_transform_max_encoded_len",
                "kz_entropy_encode", "kz_entropy_decode", "kz_encode_blocks", "kz_decode_blocks",
                "kz_max_block_stream_bytes", "kz_compress", "kz_decompress", "kz_transform_type",
-               "kz_set_timing", "kz_get_stage_count", "kz_get_stage_ms", "kz_get_stage_alg_bytes", "kz_reset_timing"]
+               "kz_knz_assemble", "kz_knz_index",
+               "kz_set_timing", "kz_get_stage_count", "kz_get_stage_ms", "kz_get_stage_alg_bytes", "kz_reset_timing",
+               "kz_set_kernel_timing", "kz_get_kernel_count", "kz_get_kernel_name", "kz_get_kernel_ms",
+               "kz_get_kernel_launches", "kz_reset_kernel_timing"]
 
 
 def transform_type(names):
@@ -153,6 +164,21 @@ class Context:
 
     def reset_timing(self):
         self.lib.kz_reset_timing(self.h)
+
+    def set_kernel_timing(self, on):
+        self.lib.kz_set_kernel_timing(self.h, 1 if on else 0)
+
+    def reset_kernel_timing(self):
+        self.lib.kz_reset_kernel_timing(self.h)
+
+    def kernel_times(self):
+        """{kernel name: {"ms": summed launch durations, "launches": n}} since the last reset."""
+        out = {}
+        for i in range(self.lib.kz_get_kernel_count()):
+            n = int(self.lib.kz_get_kernel_launches(self.h, i))
+            if n:
+                out[self.lib.kz_get_kernel_name(i).decode()] = {"ms": float(self.lib.kz_get_kernel_ms(self.h, i)), "launches": n}
+        return out
 
     def stage_times(self):
         out = {}
@@ -373,3 +399,54 @@ class CompressedInputStream:
             return max(len(self.data) * 64, 1 << 20)
         size = (v >> (total - 121 - 16 * szmask)) & ((1 << (16 * szmask)) - 1)
         return int(size)
+
+
+def knz_assemble(transform, entropy, block_size, input_size, streams, bits):
+    """Host-only: build a .knz from per-block private streams (list of bytes) in block-id order."""
+    L = load_library()
+    tt = transform if isinstance(transform, int) else transform_type(transform)
+    et = entropy if isinstance(entropy, int) else ENTROPY_IDS[entropy.upper()]
+    nb = len(streams)
+    stride = max([len(s) for s in streams] + [8]) + 8
+    buf = np.zeros(nb * stride + 8, dtype=np.uint8)
+    for i, s in enumerate(streams):
+        buf[i * stride:i * stride + len(s)] = np.frombuffer(s, dtype=np.uint8)
+    b = np.ascontiguousarray(bits, dtype=np.int64)
+    cap = int(sum((int(x) + 7) // 8 + 8 for x in bits)) + 64
+    dst = np.zeros(cap, dtype=np.uint8)
+    rc = L.kz_knz_assemble(tt, et, int(block_size), int(input_size), buf.ctypes.data, stride, b.ctypes.data, nb, dst.ctypes.data, cap)
+    if rc < 0:
+        raise KanziError(-rc, "knz_assemble")
+    return dst[:rc].tobytes()
+
+
+def knz_index(data):
+    """Host-only: -> dict(transform, entropy, blockSize, inputSize, blocks=[(bitOffset, bits), ...])."""
+    L = load_library()
+    src = np.frombuffer(bytes(data) + b"\0" * 16, dtype=np.uint8)
+    tt, et, bs, isz = ctypes.c_uint64(0), ctypes.c_uint32(0), ctypes.c_int32(0), ctypes.c_int64(0)
+    cap = max(16, len(data) // 8 + 16)
+    off = np.zeros(cap, dtype=np.int64)
+    bits = np.zeros(cap, dtype=np.int64)
+    nb = L.kz_knz_index(src.ctypes.data, len(data), ctypes.addressof(tt), ctypes.addressof(et), ctypes.addressof(bs),
+                        ctypes.addressof(isz), off.ctypes.data, bits.ctypes.data, cap)
+    if nb < 0:
+        raise KanziError(-nb, "knz_index")
+    return {"transform": tt.value, "entropy": et.value, "blockSize": bs.value, "inputSize": isz.value,
+            "blocks": [(int(off[i]), int(bits[i])) for i in range(nb)]}
+
+
+def shard_blocks(n_blocks, world, rank):
+    """Round-robin block partition over GPUs: block i -> rank i mod world."""
+    return list(range(rank, n_blocks, world))
+
+
+def extract_bits(data, bit_off, nbits):
+    """Host helper: the nbits-long bit string starting at bit_off of `data`, left aligned (MSB first)."""
+    v = int.from_bytes(data[bit_off // 8:(bit_off + nbits + 7) // 8 + 1], "big")
+    total = ((bit_off + nbits + 7) // 8 + 1 - bit_off // 8) * 8
+    have = min(total, len(data) * 8 - (bit_off // 8) * 8)
+    v <<= (total - have)
+    v = (v >> (total - (bit_off % 8) - nbits)) & ((1 << nbits) - 1)
+    pad = (-nbits) % 8
+    return (v << pad).to_bytes((nbits + 7) // 8, "big")

@@ -374,9 +374,9 @@ int kz_stage_ans0_encode(kz_ctx* ctx, kz_batch& bt, uint8_t* out, int64_t outStr
   KZ_HIP(hipMemsetAsync(E.hdrBits, 0, (size_t)B * E.C * 4, st));
   KZ_HIP(hipMemsetAsync(E.tailBytes, 0, (size_t)B * E.C * 4, st));
   const int chunks = (maxN + ANS_CHUNK - 1) / ANS_CHUNK;
-  if (chunks > 0) hipLaunchKernelGGL(k_ans_enc_chunk, dim3(chunks, B), dim3(64), 0, st, src, bt.stride, bt.d_len, E);
-  hipLaunchKernelGGL(k_ans_enc_scan, dim3(B), dim3(64), 0, st, bt.d_len, E, d_bits);
-  if (chunks > 0) hipLaunchKernelGGL(k_ans_enc_concat, dim3(chunks, B), dim3(KZ_WG), 0, st, bt.d_len, E, out, outStride, d_hdrBytes);
+  if (chunks > 0) KZ_LAUNCH(ctx, KID_ANS_ENC_CHUNK, k_ans_enc_chunk, dim3(chunks, B), dim3(64), src, bt.stride, bt.d_len, E);
+  KZ_LAUNCH(ctx, KID_ANS_ENC_SCAN, k_ans_enc_scan, dim3(B), dim3(64), bt.d_len, E, d_bits);
+  if (chunks > 0) KZ_LAUNCH(ctx, KID_ANS_ENC_CONCAT, k_ans_enc_concat, dim3(chunks, B), dim3(KZ_WG), bt.d_len, E, out, outStride, d_hdrBytes);
   KZ_HIP(hipGetLastError());
   return 0;
 }
@@ -582,10 +582,10 @@ int kz_stage_ans0_decode(kz_ctx* ctx, kz_batch& bt, const uint8_t* in, int64_t i
   if (!D.status || !D.chunkBit) { snprintf(ctx->err, sizeof(ctx->err), "ans0_decode: arena overflow"); return -KZ_ERR_DEVICE; }
   hipStream_t st = ctx->stream;
   u8* dst = bt.buf[bt.cur ^ 1];
-  hipLaunchKernelGGL(k_ans_dec_index, dim3((B + 63) / 64), dim3(64), 0, st, in, inStride, d_bitOff, d_bitEnd, bt.d_len, D, B);
+  KZ_LAUNCH(ctx, KID_ANS_DEC_INDEX, k_ans_dec_index, dim3((B + 63) / 64), dim3(64), in, inStride, d_bitOff, d_bitEnd, bt.d_len, D, B);
   const int chunks = (maxN + ANS_CHUNK - 1) / ANS_CHUNK;
-  if (chunks > 0) hipLaunchKernelGGL(k_ans_dec_chunk, dim3(chunks, B), dim3(64), 0, st, in, inStride, d_bitOff, bt.d_len, D, dst, bt.stride);
-  hipLaunchKernelGGL(k_ans_dec_fin, dim3((B + 255) / 256), dim3(256), 0, st, bt.d_len, bt.d_len2, bt.d_flag, D, B);
+  if (chunks > 0) KZ_LAUNCH(ctx, KID_ANS_DEC_CHUNK, k_ans_dec_chunk, dim3(chunks, B), dim3(64), in, inStride, d_bitOff, bt.d_len, D, dst, bt.stride);
+  KZ_LAUNCH(ctx, KID_ANS_DEC_FIN, k_ans_dec_fin, dim3((B + 255) / 256), dim3(256), bt.d_len, bt.d_len2, bt.d_flag, D, B);
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
   { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }

@@ -59,6 +59,25 @@ extern "C" float kz_get_stage_ms(kz_ctx* ctx, int32_t s) { return (s >= 0 && s <
 extern "C" int64_t kz_get_stage_alg_bytes(kz_ctx* ctx, int32_t s) { return (s >= 0 && s < KZ_MAX_STAGES) ? ctx->stageAlgBytes[s] : 0; }
 extern "C" void kz_reset_timing(kz_ctx* ctx) { for (int i = 0; i < KZ_MAX_STAGES; i++) { ctx->stageMs[i] = 0; ctx->stageAlgBytes[i] = 0; } }
 
+hipEvent_t kz_ev(kz_ctx* ctx) {
+  if (!ctx->evPool.empty()) { hipEvent_t e = ctx->evPool.back(); ctx->evPool.pop_back(); return e; }
+  hipEvent_t e; hipEventCreate(&e); return e;
+}
+void kz_ktimer_flush(kz_ctx* ctx) {
+  for (auto& p : ctx->pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) { ctx->kMs[p.id] += ms; ctx->kLaunches[p.id]++; }
+    ctx->evPool.push_back(p.e0); ctx->evPool.push_back(p.e1);
+  }
+  ctx->pending.clear();
+}
+extern "C" void kz_set_kernel_timing(kz_ctx* ctx, int32_t enable) { ctx->ktiming = enable != 0; }
+extern "C" int32_t kz_get_kernel_count(void) { return KID_COUNT; }
+extern "C" const char* kz_get_kernel_name(int32_t id) { static const char* n[] = KZ_KERNEL_NAMES; return (id >= 0 && id < KID_COUNT) ? n[id] : ""; }
+extern "C" double kz_get_kernel_ms(kz_ctx* ctx, int32_t id) { return (id >= 0 && id < KID_COUNT) ? ctx->kMs[id] : 0.0; }
+extern "C" int64_t kz_get_kernel_launches(kz_ctx* ctx, int32_t id) { return (id >= 0 && id < KID_COUNT) ? ctx->kLaunches[id] : 0; }
+extern "C" void kz_reset_kernel_timing(kz_ctx* ctx) { for (int i = 0; i < KID_COUNT; i++) { ctx->kMs[i] = 0; ctx->kLaunches[i] = 0; } }
+
 void kz_stage_begin(kz_ctx* ctx, hipEvent_t* e0) {
   *e0 = nullptr;
   if (!ctx->timing) return;
@@ -247,15 +266,14 @@ static int run_stage(kz_ctx* ctx, Pipe& P, const std::vector<int32_t>& h_mask, s
   KZ_HIP(hipMemcpyAsync(P.d_mask, h_mask.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
   // save true lengths, run on masked lengths
   KZ_HIP(hipMemcpyAsync(P.d_lenSave, bt.d_len, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
-  hipLaunchKernelGGL(k_mask_len, dim3((B + 255) / 256), dim3(256), 0, st, P.d_lenSave, P.d_mask, bt.d_len, B);
+  KZ_LAUNCH(ctx, KID_MASK_LEN, k_mask_len, dim3((B + 255) / 256), dim3(256), P.d_lenSave, P.d_mask, bt.d_len, B);
   std::vector<int32_t> saved = bt.h_len;
   for (int b = 0; b < B; b++) if (!h_mask[b]) bt.h_len[b] = 0;
   const u8* srcBefore = bt.buf[bt.cur];
   int rc = stage(bt);
   if (rc) return rc;
   u8* dstAfter = bt.buf[bt.cur];
-  hipLaunchKernelGGL(k_passthrough, dim3(64, B), dim3(256), 0, st, srcBefore, dstAfter, bt.stride, P.d_lenSave, bt.d_len,
-                     P.d_mask, bt.d_flag, P.d_applied);
+  KZ_LAUNCH(ctx, KID_PASSTHROUGH, k_passthrough, dim3(64, B), dim3(256), srcBefore, dstAfter, bt.stride, P.d_lenSave, bt.d_len, P.d_mask, bt.d_flag, P.d_applied);
   KZ_HIP(hipMemcpyAsync(ctx->hpin + B, P.d_applied, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   rc = sync_lengths(ctx, bt);
   if (rc) return rc;
@@ -377,7 +395,7 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   KZ_HIP(hipMemcpyAsync(F.skipFlags, h_skip.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
   KZ_HIP(hipMemcpyAsync(F.isCopy, h_copy.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
   F.postLen = bt.d_len;
-  hipLaunchKernelGGL(k_frame_prepare, dim3((B + 255) / 256), dim3(256), 0, st, F, B);
+  KZ_LAUNCH(ctx, KID_FRAME_PREPARE, k_frame_prepare, dim3((B + 255) / 256), dim3(256), F, B);
 
   // ---- entropy (EntropyEncoder.encode + dispose) ----
   {
@@ -389,7 +407,7 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
       for (int b = 0; b < B; b++) h_mask[b] = h_copy[b] ? 0 : 1;
       KZ_HIP(hipMemcpyAsync(P.d_mask, h_mask.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
       KZ_HIP(hipMemcpyAsync(P.d_lenSave, bt.d_len, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
-      hipLaunchKernelGGL(k_mask_len, dim3((B + 255) / 256), dim3(256), 0, st, P.d_lenSave, P.d_mask, bt.d_len, B);
+      KZ_LAUNCH(ctx, KID_MASK_LEN, k_mask_len, dim3((B + 255) / 256), dim3(256), P.d_lenSave, P.d_mask, bt.d_len, B);
       std::vector<int32_t> saved = bt.h_len;
       for (int b = 0; b < B; b++) if (h_copy[b]) bt.h_len[b] = 0;
       rc = kz_stage_ans0_encode(ctx, bt, d_out, outStride, F.hdrBytes, F.bits);
@@ -401,7 +419,7 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     {
       for (int b = 0; b < B; b++) h_mask[b] = (entropyType == KZ_E_NONE || h_copy[b]) ? 1 : 0;
       KZ_HIP(hipMemcpyAsync(P.d_mask, h_mask.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(k_copy_bytes, dim3(64, B), dim3(256), 0, st, bt.buf[bt.cur], bt.stride, d_out, outStride, bt.d_len, F.hdrBytes, P.d_mask);
+      KZ_LAUNCH(ctx, KID_COPY_BYTES, k_copy_bytes, dim3(64, B), dim3(256), bt.buf[bt.cur], bt.stride, d_out, outStride, bt.d_len, F.hdrBytes, P.d_mask);
       // bits = 8*len for those blocks
       std::vector<int64_t> hb(B);
       if (entropyType == KZ_E_NONE) {
@@ -417,9 +435,9 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   // ---- block header, raw fallback (CompressedOutputStream.java:861-985) ----
   {
     hipEvent_t e0; kz_stage_begin(ctx, &e0);
-    hipLaunchKernelGGL(k_frame_decide, dim3((B + 255) / 256), dim3(256), 0, st, F, B);
-    hipLaunchKernelGGL(k_copy_bytes, dim3(64, B), dim3(256), 0, st, bt.buf[bt.cur], bt.stride, d_out, outStride, bt.d_len, F.hdrBytes, F.fallback);
-    hipLaunchKernelGGL(k_frame_header, dim3((B + 255) / 256), dim3(256), 0, st, F, d_out, outStride, d_res, B);
+    KZ_LAUNCH(ctx, KID_FRAME_DECIDE, k_frame_decide, dim3((B + 255) / 256), dim3(256), F, B);
+    KZ_LAUNCH(ctx, KID_COPY_BYTES, k_copy_bytes, dim3(64, B), dim3(256), bt.buf[bt.cur], bt.stride, d_out, outStride, bt.d_len, F.hdrBytes, F.fallback);
+    KZ_LAUNCH(ctx, KID_FRAME_HEADER, k_frame_header, dim3((B + 255) / 256), dim3(256), F, d_out, outStride, d_res, B);
     kz_stage_end(ctx, e0, KZ_STAGE_FRAME_ENC, 0);
   }
   KZ_HIP(hipMemcpyAsync(results, d_res, (size_t)B * sizeof(kz_block_result), hipMemcpyDeviceToHost, st));
@@ -432,6 +450,7 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     KZ_HIP(hipStreamSynchronize(st));
   }
   KZ_HIP(hipGetLastError());
+  kz_ktimer_flush(ctx);
   return 0;
 }
 
@@ -536,7 +555,7 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   if (!d_bitLen) { snprintf(ctx->err, sizeof(ctx->err), "decode: arena overflow"); return -KZ_ERR_DEVICE; }
   KZ_HIP(hipMemcpyAsync(d_bitLen, bitLengths, (size_t)B * 8, hipMemcpyHostToDevice, st));
   hipEvent_t e0; kz_stage_begin(ctx, &e0);
-  hipLaunchKernelGGL(k_frame_parse, dim3((B + 255) / 256), dim3(256), 0, st, d_in, inS, d_bitLen, F, nb, maxTL, B);
+  KZ_LAUNCH(ctx, KID_FRAME_PARSE, k_frame_parse, dim3((B + 255) / 256), dim3(256), d_in, inS, d_bitLen, F, nb, maxTL, B);
   // read back descriptors
   int32_t* hp = ctx->hpin + 4 * B;
   KZ_HIP(hipMemcpyAsync(hp + 0 * B, F.preLen, (size_t)B * 4, hipMemcpyDeviceToHost, st));
@@ -566,7 +585,7 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
       bt.cur ^= 1;    // raw path writes into the "next" buffer below
     }
     KZ_HIP(hipMemcpyAsync(P.d_mask, h_rawp.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_copy_payload, dim3(64, B), dim3(256), 0, st, d_in, inS, bt.buf[bt.cur], bt.stride, bt.d_len, F.hdrBytes, P.d_mask);
+    KZ_LAUNCH(ctx, KID_COPY_PAYLOAD, k_copy_payload, dim3(64, B), dim3(256), d_in, inS, bt.buf[bt.cur], bt.stride, bt.d_len, F.hdrBytes, P.d_mask);
     kz_stage_end(ctx, e1, KZ_STAGE_ENTROPY_DEC, outBytes);
   }
   // ---- inverse chain (Sequence.inverse, K/transform/Sequence.java:137-207) ----
@@ -594,6 +613,7 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   }
   KZ_HIP(hipStreamSynchronize(st));
   KZ_HIP(hipGetLastError());
+  kz_ktimer_flush(ctx);
   return 0;
 }
 

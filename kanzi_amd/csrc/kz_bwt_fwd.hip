@@ -425,7 +425,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
   u32 *vC = A.val[0], *vF = A.val[1];
   u32 *cposC = A.cpos[0], *cposF = A.cpos[1];
   u8 *headC = A.head[0], *headF = A.head[1];
-  hipLaunchKernelGGL(k_bwt_init, dim3(gridFor(maxN, 256 * 8), B), dim3(256), 0, st, src, bt.stride, kC, vC, cposC, headC, A);
+  KZ_LAUNCH(ctx, KID_BWT_INIT, k_bwt_init, dim3(gridFor(maxN, 256 * 8), B), dim3(256), src, bt.stride, kC, vC, cposC, headC, A);
   int mMax = maxN, gMax = 1;
   int h = 0;
   for (int round = 0; round < 64 && mMax > 0; round++) {
@@ -434,21 +434,21 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
     const int passes = (nbits + 7) / 8;
     const int tiles = gridFor(mMax, RS_TILE);
     for (int p = 0; p < passes; p++) {
-      hipLaunchKernelGGL(k_radix_hist, dim3(tiles, B), dim3(KZ_WG), 0, st, kC, A, p * 8);
-      hipLaunchKernelGGL(k_radix_scan, dim3(B), dim3(256), 0, st, A);
-      hipLaunchKernelGGL(k_radix_scatter, dim3(tiles, B), dim3(KZ_WG), 0, st, kC, vC, kF, vF, A, p * 8);
+      KZ_LAUNCH(ctx, KID_RADIX_HIST, k_radix_hist, dim3(tiles, B), dim3(KZ_WG), kC, A, p * 8);
+      KZ_LAUNCH(ctx, KID_RADIX_SCAN, k_radix_scan, dim3(B), dim3(256), A);
+      KZ_LAUNCH(ctx, KID_RADIX_SCATTER, k_radix_scatter, dim3(tiles, B), dim3(KZ_WG), kC, vC, kF, vF, A, p * 8);
       u64* tk = kC; kC = kF; kF = tk;
       u32* tv = vC; vC = vF; vF = tv;
     }
     // sorted data in (kC, vC); (kF, vF) is free
-    hipLaunchKernelGGL(k_bwt_newhead, dim3(gridFor(mMax, 256 * 8), B), dim3(256), 0, st, kC, headC, A);
-    hipLaunchKernelGGL(k_hp_reduce, dim3(tiles, B), dim3(KZ_WG), 0, st, A);
-    hipLaunchKernelGGL(k_hp_scan, dim3(B), dim3(64), 0, st, A);
-    hipLaunchKernelGGL(k_hp_apply, dim3(tiles, B), dim3(KZ_WG), 0, st, vC, cposC, A);
-    hipLaunchKernelGGL(k_flt_reduce, dim3(tiles, B), dim3(KZ_WG), 0, st, A);
-    hipLaunchKernelGGL(k_flt_scan, dim3(B), dim3(64), 0, st, A);
+    KZ_LAUNCH(ctx, KID_BWT_NEWHEAD, k_bwt_newhead, dim3(gridFor(mMax, 256 * 8), B), dim3(256), kC, headC, A);
+    KZ_LAUNCH(ctx, KID_HP_REDUCE, k_hp_reduce, dim3(tiles, B), dim3(KZ_WG), A);
+    KZ_LAUNCH(ctx, KID_HP_SCAN, k_hp_scan, dim3(B), dim3(64), A);
+    KZ_LAUNCH(ctx, KID_HP_APPLY, k_hp_apply, dim3(tiles, B), dim3(KZ_WG), vC, cposC, A);
+    KZ_LAUNCH(ctx, KID_FLT_REDUCE, k_flt_reduce, dim3(tiles, B), dim3(KZ_WG), A);
+    KZ_LAUNCH(ctx, KID_FLT_SCAN, k_flt_scan, dim3(B), dim3(64), A);
     h = (round == 0) ? 7 : h * 2;
-    hipLaunchKernelGGL(k_flt_apply, dim3(tiles, B), dim3(KZ_WG), 0, st, vC, cposC, kF, vF, cposF, headF, A, h, bitsR);
+    KZ_LAUNCH(ctx, KID_FLT_APPLY, k_flt_apply, dim3(tiles, B), dim3(KZ_WG), vC, cposC, kF, vF, cposF, headF, A, h, bitsR);
     { u64* tk = kC; kC = kF; kF = tk; u32* tv = vC; vC = vF; vF = tv; }
     { u32* tc = cposC; cposC = cposF; cposF = tc; u8* th = headC; headC = headF; headF = th; }
     // ---- read back sizes (next compact size / group count per block) ----
@@ -460,7 +460,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
     int32_t* tm = A.d_m; A.d_m = A.d_m2; A.d_m2 = tm;
   }
   if (mMax > 0) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: suffix sort did not converge"); return -KZ_ERR_PROCESS_BLOCK; }
-  hipLaunchKernelGGL(k_bwt_emit, dim3(gridFor(maxN, 256 * 8), B), dim3(256), 0, st, src, bt.stride, dst, bt.stride, A, bt.d_len2, bt.d_flag);
+  KZ_LAUNCH(ctx, KID_BWT_EMIT, k_bwt_emit, dim3(gridFor(maxN, 256 * 8), B), dim3(256), src, bt.stride, dst, bt.stride, A, bt.d_len2, bt.d_flag);
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
   { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }

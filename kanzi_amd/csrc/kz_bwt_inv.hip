@@ -204,14 +204,14 @@ int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
   hipStream_t st = ctx->stream;
   const u8* src = bt.buf[bt.cur];
   u8* dst = bt.buf[bt.cur ^ 1];
-  hipLaunchKernelGGL(k_bwti_parse, dim3((B + 63) / 64), dim3(64), 0, st, src, bt.stride, bt.d_len, V, B);
+  KZ_LAUNCH(ctx, KID_BWTI_PARSE, k_bwti_parse, dim3((B + 63) / 64), dim3(64), src, bt.stride, bt.d_len, V, B);
   const int tiles = (maxN + BI_TILE - 1) / BI_TILE;
   if (tiles > 0) {
-    hipLaunchKernelGGL(k_bwti_hist, dim3(tiles, B), dim3(KZ_WG), 0, st, src, bt.stride, V);
-    hipLaunchKernelGGL(k_bwti_scan, dim3(B), dim3(256), 0, st, V);
-    hipLaunchKernelGGL(k_bwti_scatter, dim3(tiles, B), dim3(KZ_WG), 0, st, src, bt.stride, V);
+    KZ_LAUNCH(ctx, KID_BWTI_HIST, k_bwti_hist, dim3(tiles, B), dim3(KZ_WG), src, bt.stride, V);
+    KZ_LAUNCH(ctx, KID_BWTI_SCAN, k_bwti_scan, dim3(B), dim3(256), V);
+    KZ_LAUNCH(ctx, KID_BWTI_SCATTER, k_bwti_scatter, dim3(tiles, B), dim3(KZ_WG), src, bt.stride, V);
   }
-  hipLaunchKernelGGL(k_bwti_walk, dim3(B), dim3(64), 0, st, src, dst, bt.stride, V, bt.d_len2, bt.d_flag);
+  KZ_LAUNCH(ctx, KID_BWTI_WALK, k_bwti_walk, dim3(B), dim3(64), src, dst, bt.stride, V, bt.d_len2, bt.d_flag);
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
   { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }

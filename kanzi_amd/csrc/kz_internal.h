@@ -7,6 +7,9 @@
 #include <vector>
 #include "../../include/kanzi_hip.h"
 
+enum KzKernelId { KID_ANS_ENC_CHUNK, KID_ANS_ENC_SCAN, KID_ANS_ENC_CONCAT, KID_ANS_DEC_INDEX, KID_ANS_DEC_CHUNK, KID_ANS_DEC_FIN, KID_MASK_LEN, KID_PASSTHROUGH, KID_FRAME_PREPARE, KID_COPY_BYTES, KID_FRAME_DECIDE, KID_FRAME_HEADER, KID_FRAME_PARSE, KID_COPY_PAYLOAD, KID_BWT_INIT, KID_RADIX_HIST, KID_RADIX_SCAN, KID_RADIX_SCATTER, KID_BWT_NEWHEAD, KID_HP_REDUCE, KID_HP_SCAN, KID_HP_APPLY, KID_FLT_REDUCE, KID_FLT_SCAN, KID_FLT_APPLY, KID_BWT_EMIT, KID_BWTI_PARSE, KID_BWTI_HIST, KID_BWTI_SCAN, KID_BWTI_SCATTER, KID_BWTI_WALK, KID_SBRT_LAST2, KID_SBRT_SCAN, KID_SBRT_REPLAY, KID_COPY_LEN, KID_SBRT_INVERSE, KID_ZRLT_F1, KID_ZRLT_F2, KID_ZRLT_F3, KID_ZRLT_FFIN, KID_ZRLT_I1, KID_ZRLT_I2, KID_ZRLT_I3, KID_ZRLT_IFIN, KID_COUNT };
+#define KZ_KERNEL_NAMES { "k_ans_enc_chunk", "k_ans_enc_scan", "k_ans_enc_concat", "k_ans_dec_index", "k_ans_dec_chunk", "k_ans_dec_fin", "k_mask_len", "k_passthrough", "k_frame_prepare", "k_copy_bytes", "k_frame_decide", "k_frame_header", "k_frame_parse", "k_copy_payload", "k_bwt_init", "k_radix_hist", "k_radix_scan", "k_radix_scatter", "k_bwt_newhead", "k_hp_reduce", "k_hp_scan", "k_hp_apply", "k_flt_reduce", "k_flt_scan", "k_flt_apply", "k_bwt_emit", "k_bwti_parse", "k_bwti_hist", "k_bwti_scan", "k_bwti_scatter", "k_bwti_walk", "k_sbrt_last2", "k_sbrt_scan", "k_sbrt_replay", "k_copy_len", "k_sbrt_inverse", "k_zrlt_f1", "k_zrlt_f2", "k_zrlt_f3", "k_zrlt_ffin", "k_zrlt_i1", "k_zrlt_i2", "k_zrlt_i3", "k_zrlt_ifin" }
+struct KzPending { hipEvent_t e0, e1; int id; };
 struct kz_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -21,6 +24,12 @@ struct kz_ctx {
   int64_t stageAlgBytes[KZ_MAX_STAGES] = {0};
   int nStages = 0;
   bool timing = false;
+  // per-kernel event timing (bench roofline): events recorded on ctx->stream around every launch
+  bool ktiming = false;
+  std::vector<KzPending> pending;
+  std::vector<hipEvent_t> evPool;
+  double kMs[KID_COUNT] = {0};
+  long long kLaunches[KID_COUNT] = {0};
 };
 
 #define KZ_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
@@ -65,6 +74,15 @@ size_t kz_bwt_inverse_scratch(int B, int maxN);
 size_t kz_sbrt_scratch(int B, int maxN);
 size_t kz_zrlt_scratch(int B, int maxN);
 size_t kz_ans_scratch(int B, int maxN);
+
+// per-kernel timing
+hipEvent_t kz_ev(kz_ctx* ctx);
+void kz_ktimer_flush(kz_ctx* ctx);     // call after the stream has been synchronized
+#define KZ_LAUNCH(ctx, kid, kernel, grid, block, ...) do { \
+  hipEvent_t a_ = nullptr, b_ = nullptr; \
+  if ((ctx)->ktiming) { a_ = kz_ev(ctx); b_ = kz_ev(ctx); (void)hipEventRecord(a_, (ctx)->stream); } \
+  hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__); \
+  if ((ctx)->ktiming) { (void)hipEventRecord(b_, (ctx)->stream); (ctx)->pending.push_back({a_, b_, kid}); } } while (0)
 
 // timing helpers
 void kz_stage_begin(kz_ctx*, hipEvent_t* e0);

@@ -232,11 +232,11 @@ int kz_stage_sbrt_forward(kz_ctx* ctx, kz_batch& bt, int mode) {
   const u8* src = bt.buf[bt.cur];
   u8* dst = bt.buf[bt.cur ^ 1];
   if (maxN > 0) {
-    hipLaunchKernelGGL(k_sbrt_last2, dim3(T, B), dim3(64), 0, st, src, bt.stride, bt.d_len, tab, T);
-    hipLaunchKernelGGL(k_sbrt_scan, dim3(B), dim3(256), 0, st, bt.d_len, tab, T);
-    hipLaunchKernelGGL(k_sbrt_replay, dim3(T, B), dim3(64), 0, st, src, dst, bt.stride, bt.d_len, tab, T, mode);
+    KZ_LAUNCH(ctx, KID_SBRT_LAST2, k_sbrt_last2, dim3(T, B), dim3(64), src, bt.stride, bt.d_len, tab, T);
+    KZ_LAUNCH(ctx, KID_SBRT_SCAN, k_sbrt_scan, dim3(B), dim3(256), bt.d_len, tab, T);
+    KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay, dim3(T, B), dim3(64), src, dst, bt.stride, bt.d_len, tab, T, mode);
   }
-  hipLaunchKernelGGL(k_copy_len, dim3((B + 255) / 256), dim3(256), 0, st, bt.d_len, bt.d_len2, bt.d_flag, B);
+  KZ_LAUNCH(ctx, KID_COPY_LEN, k_copy_len, dim3((B + 255) / 256), dim3(256), bt.d_len, bt.d_len2, bt.d_flag, B);
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
   { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }
@@ -248,8 +248,8 @@ int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
   hipStream_t st = ctx->stream;
   const u8* src = bt.buf[bt.cur];
   u8* dst = bt.buf[bt.cur ^ 1];
-  hipLaunchKernelGGL(k_sbrt_inverse, dim3(B), dim3(64), 0, st, src, dst, bt.stride, bt.d_len, mode);
-  hipLaunchKernelGGL(k_copy_len, dim3((B + 255) / 256), dim3(256), 0, st, bt.d_len, bt.d_len2, bt.d_flag, B);
+  KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse, dim3(B), dim3(64), src, dst, bt.stride, bt.d_len, mode);
+  KZ_LAUNCH(ctx, KID_COPY_LEN, k_copy_len, dim3((B + 255) / 256), dim3(256), bt.d_len, bt.d_len2, bt.d_flag, B);
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
   { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }

@@ -89,12 +89,8 @@ int batch_blocks(int blockSize) {
 }
 }  // namespace
 
-extern "C" int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
-                               const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstCap) {
-  if (!ctx || !src || !dst || n < 0) return -KZ_ERR_INVALID_PARAM;
-  if (blockSize < 1024 || blockSize > (1 << 30) || (blockSize & 15)) return -KZ_ERR_BLOCK_SIZE;   // :165-174
-  HostBits bs{dst, dstCap, 0, false};
-  // ---- stream header (CompressedOutputStream.java:236-313) ----
+// ---- host-only container helpers (no GPU needed): used by kz_compress and by multi-GPU gathers ----
+static int write_stream_header(HostBits& bs, uint64_t transformType, uint32_t entropyType, int32_t blockSize, int64_t n) {
   bs.put(0x4B414E5A, 32); bs.put(7, 4); bs.put(0, 2);
   bs.put(entropyType, 5); bs.put(transformType, 48); bs.put((uint32_t)blockSize >> 4, 28);
   int szMask = 0;
@@ -106,6 +102,73 @@ extern "C" int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t ent
   if (szMask > 0) bs.put((uint64_t)n, 16 * szMask);
   bs.put(0, 15);
   bs.put(header_cksum(0, (int)entropyType, transformType, blockSize, szMask, n), 24);
+  return szMask;
+}
+static void write_block(HostBits& bs, const uint8_t* stream, uint64_t written) {   // :1024-1035
+  const int lw = (written < 8) ? 3 : ilog2((uint32_t)(written >> 3)) + 4;
+  bs.put((uint64_t)(lw - 3), 5);
+  bs.put(written, lw);
+  bs.putBytes(stream, written);
+}
+
+// Assemble a complete .knz stream from per-block private streams (e.g. gathered from several GPUs
+// in block-id order).  Pure host code.
+extern "C" int64_t kz_knz_assemble(uint64_t transformType, uint32_t entropyType, int32_t blockSize, int64_t inputSize,
+                                   const uint8_t* streams, int64_t stride, const int64_t* bits, int32_t nBlocks,
+                                   uint8_t* dst, int64_t dstCap) {
+  if (!dst || nBlocks < 0 || (nBlocks > 0 && (!streams || !bits))) return -KZ_ERR_INVALID_PARAM;
+  HostBits bs{dst, dstCap, 0, false};
+  write_stream_header(bs, transformType, entropyType, blockSize, inputSize);
+  for (int i = 0; i < nBlocks; i++) if (bits[i] > 0) write_block(bs, streams + (int64_t)i * stride, (uint64_t)bits[i]);
+  bs.put(0, 5); bs.put(0, 3);
+  if (bs.overflow) return -KZ_ERR_WRITE_FILE;
+  return (int64_t)((bs.pos + 7) >> 3);
+}
+
+// Parse the stream header and walk the block length prefixes: blockBitOff[i] = bit offset of block
+// i's private stream inside src, blockBits[i] = its length W.  Returns the number of blocks or <0.
+extern "C" int32_t kz_knz_index(const uint8_t* src, int64_t n, uint64_t* transformType, uint32_t* entropyType,
+                                int32_t* blockSize, int64_t* inputSize, int64_t* blockBitOff, int64_t* blockBits, int32_t cap) {
+  if (!src || n < 20) return -KZ_ERR_INVALID_FILE;
+  HostBitsIn bs{src, (uint64_t)n * 8, 0, false};
+  if (bs.get(32) != 0x4B414E5A) return -KZ_ERR_INVALID_FILE;
+  if (bs.get(4) != 7) return -KZ_ERR_INVALID_FILE;
+  const int chkKind = (int)bs.get(2);
+  const int et = (int)bs.get(5);
+  const uint64_t tt = bs.get(48);
+  const int bsz = (int)(bs.get(28) << 4);
+  const int szMask = (int)bs.get(2);
+  int64_t isz = 0;
+  if (szMask) isz = (int64_t)bs.get(16 * szMask);
+  bs.get(15);
+  const uint32_t ck = (uint32_t)bs.get(24);
+  if (bs.error || ck != header_cksum(chkKind, et, tt, bsz, szMask, isz)) return -KZ_ERR_CRC_CHECK;
+  if (chkKind != 0) return -KZ_ERR_INVALID_CODEC;
+  if (transformType) *transformType = tt;
+  if (entropyType) *entropyType = (uint32_t)et;
+  if (blockSize) *blockSize = bsz;
+  if (inputSize) *inputSize = isz;
+  int nb = 0;
+  for (;;) {
+    const int lr = (int)bs.get(5) + 3;
+    const uint64_t rd = bs.get(lr);
+    if (bs.error) return -KZ_ERR_READ_FILE;
+    if (rd == 0) break;
+    if (nb < cap) { if (blockBitOff) blockBitOff[nb] = (int64_t)bs.pos; if (blockBits) blockBits[nb] = (int64_t)rd; }
+    nb++;
+    if (bs.pos + rd > bs.nbits) return -KZ_ERR_READ_FILE;
+    bs.pos += rd;
+  }
+  return nb;
+}
+
+extern "C" int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
+                               const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstCap) {
+  if (!ctx || !src || !dst || n < 0) return -KZ_ERR_INVALID_PARAM;
+  if (blockSize < 1024 || blockSize > (1 << 30) || (blockSize & 15)) return -KZ_ERR_BLOCK_SIZE;   // :165-174
+  HostBits bs{dst, dstCap, 0, false};
+  // ---- stream header (CompressedOutputStream.java:236-313) ----
+  write_stream_header(bs, transformType, entropyType, blockSize, n);
   // ---- blocks, in batches ----
   const int64_t nblocks = (n + blockSize - 1) / blockSize;
   const int NB = batch_blocks(blockSize);
@@ -121,11 +184,7 @@ extern "C" int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t ent
     if (rc) return rc;
     for (int i = 0; i < cnt; i++) {                             // ordered emission (:1024-1035)
       if (res[i].status) return res[i].status;
-      const uint64_t written = (uint64_t)res[i].bits;
-      const int lw = (written < 8) ? 3 : ilog2((uint32_t)(written >> 3)) + 4;
-      bs.put((uint64_t)(lw - 3), 5);
-      bs.put(written, lw);
-      bs.putBytes(outbuf.data() + (size_t)i * oS, written);
+      if (res[i].bits > 0) write_block(bs, outbuf.data() + (size_t)i * oS, (uint64_t)res[i].bits);
     }
   }
   bs.put(0, 5); bs.put(0, 3);                                   // end marker (:491-492)

@@ -341,11 +341,11 @@ int kz_stage_zrlt_forward(kz_ctx* ctx, kz_batch& bt) {
   KZ_HIP(hipMemsetAsync(S.total, 0, (size_t)B * 4, st));
   if (maxN > 0) {
     const int tiles = (maxN + ZR_TILE - 1) / ZR_TILE;
-    hipLaunchKernelGGL(k_zrlt_f1, dim3(tiles, B), dim3(KZ_WG), 0, st, src, bt.stride, bt.d_len, S);
-    hipLaunchKernelGGL(k_zrlt_f2, dim3(B), dim3(64), 0, st, bt.d_len, S);
-    hipLaunchKernelGGL(k_zrlt_f3, dim3(tiles, B), dim3(KZ_WG), 0, st, src, dst, bt.stride, bt.d_len, S);
+    KZ_LAUNCH(ctx, KID_ZRLT_F1, k_zrlt_f1, dim3(tiles, B), dim3(KZ_WG), src, bt.stride, bt.d_len, S);
+    KZ_LAUNCH(ctx, KID_ZRLT_F2, k_zrlt_f2, dim3(B), dim3(64), bt.d_len, S);
+    KZ_LAUNCH(ctx, KID_ZRLT_F3, k_zrlt_f3, dim3(tiles, B), dim3(KZ_WG), src, dst, bt.stride, bt.d_len, S);
   }
-  hipLaunchKernelGGL(k_zrlt_ffin, dim3(64, B), dim3(256), 0, st, src, dst, bt.stride, bt.d_len, bt.d_len2, bt.d_flag, S);
+  KZ_LAUNCH(ctx, KID_ZRLT_FFIN, k_zrlt_ffin, dim3(64, B), dim3(256), src, dst, bt.stride, bt.d_len, bt.d_len2, bt.d_flag, S);
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
   { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }
@@ -372,11 +372,11 @@ int kz_stage_zrlt_inverse(kz_ctx* ctx, kz_batch& bt, int dstCap) {
   KZ_HIP(hipMemsetAsync(dst, 0, (size_t)bt.stride * B, st));       // zero runs are "written" here
   if (maxN > 0) {
     const int tiles = (maxN + ZR_TILE - 1) / ZR_TILE;
-    hipLaunchKernelGGL(k_zrlt_i1, dim3(tiles, B), dim3(KZ_WG), 0, st, src, bt.stride, bt.d_len, S);
-    hipLaunchKernelGGL(k_zrlt_i2, dim3(B), dim3(64), 0, st, bt.d_len, S, dstCap);
-    hipLaunchKernelGGL(k_zrlt_i3, dim3(tiles, B), dim3(KZ_WG), 0, st, src, dst, bt.stride, bt.d_len, S);
+    KZ_LAUNCH(ctx, KID_ZRLT_I1, k_zrlt_i1, dim3(tiles, B), dim3(KZ_WG), src, bt.stride, bt.d_len, S);
+    KZ_LAUNCH(ctx, KID_ZRLT_I2, k_zrlt_i2, dim3(B), dim3(64), bt.d_len, S, dstCap);
+    KZ_LAUNCH(ctx, KID_ZRLT_I3, k_zrlt_i3, dim3(tiles, B), dim3(KZ_WG), src, dst, bt.stride, bt.d_len, S);
   }
-  hipLaunchKernelGGL(k_zrlt_ifin, dim3((B + 255) / 256), dim3(256), 0, st, bt.d_len, bt.d_len2, bt.d_flag, S, B);
+  KZ_LAUNCH(ctx, KID_ZRLT_IFIN, k_zrlt_ifin, dim3((B + 255) / 256), dim3(256), bt.d_len, bt.d_len2, bt.d_flag, S, B);
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
   { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }

@@ -1,0 +1,95 @@
+"""The reference's own test inputs, re-generated (no expected outputs exist upstream: round-trip only).
+  transforms : T/test/TestTransforms.java:183-254 (java.util.Random(Long.MAX_VALUE) LCG reproduced)
+  entropy    : T/test/TestEntropyCodec.java:219-244
+  bwt        : T/test/TestBWT.java:85-103
+"""
+import numpy as np
+
+from oracle import JavaRandom
+
+LONG_MAX = (1 << 63) - 1
+
+
+def transform_inputs():
+    rnd = JavaRandom(LONG_MAX)
+    out = []
+    for ii in range(0, 51):
+        if ii == 0:
+            arr = [0, 1, 2, 2, 2, 2, 7, 9, 9, 16, 16, 16, 1] + [3] * 19
+        elif ii < 10:
+            arr = [ii] * 80000
+        elif ii in (10, 11):
+            arr = [1] + [8] * 79999
+        elif ii == 12:
+            arr = [0, 0, 1, 1, 2, 2, 3, 3]
+        elif ii == 13:
+            arr = [0] * 512
+            for i in range(256):
+                arr[2 * i] = i
+                arr[2 * i + 1] = i
+            arr[1] = 255
+        elif ii < 16:
+            arr = []
+            for _ in range(1 << (ii + 6)):
+                v = rnd.next_int(100)
+                arr.append(0 if v >= 33 else v)
+        elif ii == 16:
+            arr = [0] * 20 + [rnd.next_int(256) for _ in range(20, 512)]
+        else:
+            arr = [0] * 1024
+            idx = 20
+            while idx < 1024:
+                ln = rnd.next_int(120)
+                if ln % 3 == 0:
+                    ln = 1
+                val = rnd.next_int(256)
+                end = min(idx + ln, 1024)
+                for j in range(idx, end):
+                    arr[j] = val
+                idx += ln
+        out.append(bytes(x & 0xFF for x in arr))
+    return out
+
+
+def entropy_inputs():
+    rnd = JavaRandom(LONG_MAX)
+    out = []
+    for ii in range(1, 20):
+        if ii == 3:
+            v = [0, 0, 32, 15, -4, 16, 0, 16, 0, 7, -1, -4, -32, 0, 31, -1]
+        elif ii == 2:
+            v = [61, 77, 84, 71, 90, 54, 57, 38, 114, 111, 108, 101, 61, 112, 114, 101]
+        elif ii == 1:
+            v = [2] * 40
+        elif ii == 4:
+            v = [2 + (i & 1) for i in range(40)]
+        elif ii == 5:
+            v = [42]
+        elif ii == 6:
+            v = [42, 42]
+        else:
+            v = [64 + 4 * ii + rnd.next_int(8 * ii + 1) for _ in range(256)]
+        out.append(bytes(x & 0xFF for x in v))
+    return out
+
+
+def bwt_inputs():
+    rnd = JavaRandom(LONG_MAX)
+    out = [b"mississippi", b"3.14159265358979323846264338327950288419716939937510", b"SIX.MIXED.PIXIES.SIFT.SIXTY.PIXIE.DUST.BOXES"]
+    out.append(bytes(65 + rnd.next_int(4 * 1) for _ in range(128)))
+    return out
+
+
+def edge_inputs():
+    """empty / ragged / threshold sizes: copy-block limit 15|16, ANS raw limit 32|33, BWT chunk switch 255|256|257."""
+    rng = np.random.default_rng(12345)
+    out = []
+    for n in (1, 2, 3, 15, 16, 17, 31, 32, 33, 34, 63, 64, 65, 255, 256, 257, 1000, 4095, 4096, 4097, 16383, 16384, 16385, 16417, 70001):
+        out.append(bytes(rng.integers(0, 4, n, dtype=np.uint8)))
+        out.append(bytes(np.minimum(rng.geometric(0.3, n) - 1, 255).astype(np.uint8)))
+    out.append(bytes([0xFF] * 300))
+    out.append(bytes([0xFE, 0xFF] * 200))
+    out.append(bytes(5000))
+    out.append(bytes([1] + [0] * 4999))
+    out.append(bytes([0] * 4999 + [1]))
+    return out

@@ -1,0 +1,103 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every symbol include/kanzi_hip.h
+declares (no compute without a GPU), host-only helpers agree with the oracle, and the product path
+fails loudly when no GPU is present."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import kanzi_amd as kz
+import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "kanzi_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(kz_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 25
+    L = ctypes.CDLL(kz.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), "libkanzi_hip.so does not export %s" % name
+    assert sorted(kz.ABI_SYMBOLS) == declared, "python binding list out of sync with the header"
+    assert kz.load_library().kz_abi_version() == 1
+
+
+def test_max_encoded_len_matches_reference_values(built):
+    L = kz.load_library()
+    O = oracle.lib()
+    for n in (0, 1, 100, 1024, 1025, 65536, 4 * 1024 * 1024):
+        # BWT n+33 (BWTBlockCodec.java:40,222); SRT n+1024 (SRT.java:30,365); LZ/LZX (LZCodec.java:961-964); ZRLT/SBRT n
+        assert L.kz_transform_max_encoded_len(kz.BWT_TYPE, n) == n + 33
+        assert L.kz_transform_max_encoded_len(kz.SRT_TYPE, n) == n + 1024
+        assert L.kz_transform_max_encoded_len(kz.LZ_TYPE, n) == ((n + 16) if n <= 1024 else n + n // 64) + 2
+        assert L.kz_transform_max_encoded_len(kz.ZRLT_TYPE, n) == n
+        for t in (kz.BWT_TYPE, kz.SRT_TYPE, kz.LZ_TYPE, kz.LZX_TYPE, kz.ZRLT_TYPE, kz.RANK_TYPE, kz.MTFT_TYPE):
+            assert L.kz_transform_max_encoded_len(t, n) == O.kzo_transform_max_encoded_len(t, n)
+
+
+def test_transform_type_word(built):
+    # TransformFactory.java:29-31,144-157: 8 slots x 6 bits, first transform in the top slot
+    assert kz.transform_type("BWT+RANK+ZRLT") == (1 << 42) | (8 << 36) | (6 << 30)
+    assert kz.transform_type("BWT+RANK+ZRLT") == oracle.ttype("BWT+RANK+ZRLT")
+    ids = (ctypes.c_int32 * 3)(1, 8, 6)
+    assert kz.load_library().kz_transform_type(ids, 3) == kz.transform_type("BWT+RANK+ZRLT")
+    with pytest.raises(ValueError):
+        kz.transform_type("+".join(["ZRLT"] * 9))
+
+
+def test_host_container_assembly_matches_oracle(built):
+    """kz_knz_assemble (product, host-only) over oracle-encoded block streams == oracle stream."""
+    rng = np.random.default_rng(11)
+    data = bytes(np.minimum(rng.geometric(0.08, 150000) - 1, 255).astype(np.uint8)) + bytes(10000) + b"xyz"
+    bs = 32768
+    chain, ent = "BWT+RANK+ZRLT", "ANS0"
+    blocks = [data[i:i + bs] for i in range(0, len(data), bs)]
+    streams, bits = [], []
+    for b in blocks:
+        s, w, _, _ = oracle.encode_block(chain, ent, b)
+        streams.append(s)
+        bits.append(w)
+    knz = kz.knz_assemble(chain, ent, bs, len(data), streams, bits)
+    assert knz == oracle.compress(chain, ent, bs, data, jobs=2)
+    idx = kz.knz_index(knz)
+    assert idx["blockSize"] == bs and idx["inputSize"] == len(data)
+    assert idx["transform"] == kz.transform_type(chain) and idx["entropy"] == kz.E_ANS0
+    assert [w for _, w in idx["blocks"]] == bits
+    for (off, w), s in zip(idx["blocks"], streams):
+        assert kz.extract_bits(knz, off, w) == s[:(w + 7) // 8]
+
+
+def test_stream_header_tamper_widths(built):
+    # T/test/TestCompressedStream.java:177-291 pins the header field widths 32/4/2/5/48/28/2/16k/15/24
+    knz = oracle.compress("ZRLT", "NONE", 1024, b"a" * 3000, jobs=1)
+    assert kz.knz_index(knz)["blockSize"] == 1024
+    bad = bytearray(knz)
+    bad[10] ^= 0x10            # flip a bit inside the transform word -> header checksum must fail
+    with pytest.raises(kz.KanziError) as e:
+        kz.knz_index(bytes(bad))
+    assert e.value.code == 19  # ERR_CRC_CHECK
+
+
+def test_product_path_fails_loudly_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        kz.Context(0)
+    assert kz.load_library().kz_ctx_create(0) is None
+
+
+def test_no_oracle_in_product_path():
+    """The product (kanzi_amd/, include/, bench timing path) must never import or link the oracle."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "kanzi_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                if re.search(r"kzo_|libkzo|import oracle|from oracle|oracle/", txt):
+                    bad.append(f)
+    assert not bad, bad
