@@ -1,0 +1,16 @@
+package io.github.flanglet.kanzi.hip;
+
+/** Native entry points of libkanzi_hip_jni.so (integration/jni/kanzi_hip_jni.c). */
+public final class KanziHip {
+  static { System.loadLibrary("kanzi_hip_jni"); }
+  public static final int DECLINED = -1000000;
+  public static native long ctxCreate(int device);
+  public static native void ctxDestroy(long ctx);
+  public static native int maxEncodedLength(int type, int n);
+  public static native int transform(long ctx, int type, boolean forward, byte[] src, int srcIdx, int n, byte[] dst, int dstIdx, int dstCap);
+  public static native long entropyEncode(long ctx, int type, byte[] block, int blkptr, int n, byte[] out);
+  public static native int entropyDecode(long ctx, int type, byte[] in, long inBits, byte[] block, int blkptr, int count);
+  public static native int encodeBlocks(long ctx, long transformType, int entropyType, java.nio.ByteBuffer in, long inStride,
+      int[] lengths, int nBlocks, java.nio.ByteBuffer out, long outStride, long[] bitsOut, int[] postLenOut, byte[] skipFlagsOut);
+  private KanziHip() {}
+}

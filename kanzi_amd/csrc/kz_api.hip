@@ -283,22 +283,33 @@ static int run_stage(kz_ctx* ctx, Pipe& P, const std::vector<int32_t>& h_mask, s
   return 0;
 }
 
-static size_t pipeline_scratch(int B, int maxLen) {
-  size_t s = 0;
-  s = std::max(s, kz_bwt_forward_scratch(B, maxLen));
-  s = std::max(s, kz_bwt_inverse_scratch(B, maxLen));
-  s = std::max(s, kz_sbrt_scratch(B, maxLen));
-  s = std::max(s, kz_zrlt_scratch(B, maxLen));
-  s = std::max(s, kz_ans_scratch(B, maxLen));
+static size_t kz_arena_budget() {
+  static size_t budget = 0;
+  if (!budget) {
+    const char* e = getenv("KZ_ARENA_BUDGET_GB");
+    double gb = e ? atof(e) : 96.0;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > 0) gb = std::min(gb, (double)freeB / (1 << 30) * 0.6);
+    if (gb < 1.0) gb = 1.0;
+    budget = (size_t)(gb * (double)(1 << 30));
+  }
+  return budget;
+}
+// stage scratch is bump-allocated after the ping-pong buffers; each stage allocates in turn, so the
+// arena must hold the SUM over the stages of a direction (they are small except the suffix sort)
+static size_t pipeline_scratch(int B, int maxLen, bool decode) {
+  size_t s = kz_sbrt_scratch(B, maxLen) + kz_zrlt_scratch(B, maxLen) * 2;
+  if (decode) s += kz_bwt_inverse_scratch(B, maxLen) + (size_t)B * ((size_t)(maxLen / 16384 + 4) * 8 + 64) + 65536;
+  else s += kz_bwt_forward_scratch(B, maxLen) + kz_ans_scratch(B, maxLen);
   return s;
 }
 
-static int pipe_setup(kz_ctx* ctx, Pipe& P, int B, int maxLen, int64_t extraBytes) {
+static int pipe_setup(kz_ctx* ctx, Pipe& P, int B, int maxLen, int64_t extraBytes, bool decode) {
   kz_batch& bt = P.bt;
   bt.B = B; bt.maxN = maxLen;
   bt.stride = (int64_t)kz_align((size_t)maxLen + 4096, 256);
   const size_t fixed = (size_t)bt.stride * B * 2 + (size_t)B * 4 * 16 + 65536 + (size_t)extraBytes;
-  int rc = kz_arena_reserve(ctx, fixed + pipeline_scratch(B, maxLen) + (1 << 20));
+  int rc = kz_arena_reserve(ctx, fixed + pipeline_scratch(B, maxLen, decode) + (1 << 20));
   if (rc) return rc;
   bt.buf[0] = (u8*)kz_arena_alloc(ctx, (size_t)bt.stride * B);
   bt.buf[1] = (u8*)kz_arena_alloc(ctx, (size_t)bt.stride * B);
@@ -347,12 +358,27 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   int maxN = 0;
   for (int b = 0; b < B; b++) { if (lengths[b] < 0) return -KZ_ERR_INVALID_PARAM; maxN = std::max(maxN, lengths[b]); }
   const int maxLen = seq_max_len(types, nb, maxN);
+  {
+    // bound the scratch arena: the suffix sort needs ~43 B per input byte, so very large batches are
+    // processed as consecutive sub-batches (blocks are independent; results are identical)
+    const size_t perBlock = pipeline_scratch(1, maxLen, false) + (size_t)maxLen * 2 + (size_t)outStride + (1 << 16);
+    const int maxB = (int)std::max<size_t>(1, kz_arena_budget() / perBlock);
+    if (B > maxB) {
+      for (int b0 = 0; b0 < B; b0 += maxB) {
+        const int cnt = std::min(maxB, B - b0);
+        int rc = kz_encode_blocks(ctx, transformType, entropyType, in + (int64_t)b0 * inStride, inStride, lengths + b0, cnt,
+                                  out + (int64_t)b0 * outStride, outStride, results + b0, memKind);
+        if (rc) return rc;
+      }
+      return 0;
+    }
+  }
   const int64_t needOut = kz_max_block_stream_bytes(maxN);
   if (outStride < needOut || (outStride & 3)) { snprintf(ctx->err, sizeof(ctx->err), "outStride %lld < %lld or not a multiple of 4", (long long)outStride, (long long)needOut); return -KZ_ERR_INVALID_PARAM; }
   const bool host = memKind == KZ_MEM_HOST;
   Pipe P;
   const int64_t extra = (host ? (int64_t)outStride * B : 0) + (int64_t)B * (sizeof(kz_block_result) + 64) + (int64_t)B * 16;
-  int rc = pipe_setup(ctx, P, B, maxLen, extra);
+  int rc = pipe_setup(ctx, P, B, maxLen, extra, false);
   if (rc) return rc;
   kz_batch& bt = P.bt;
   hipStream_t st = ctx->stream;
@@ -524,11 +550,27 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   const int maxTL = std::min(std::max(blockSize + blockSize / 2, 2048), 1 << 30);
   int64_t maxInBytes = 0;
   for (int b = 0; b < B; b++) maxInBytes = std::max(maxInBytes, (bitLengths[b] + 7) >> 3);
-  const int maxLen = std::max(dataCap, maxTL);
+  // The reference accepts preTransformLength up to 1.5 x blockSize (CompressedInputStream.java:1139-1140);
+  // no chain in scope expands a block by more than 1024 bytes, so buffers are sized dataCap+1024 and a
+  // larger (corrupt) length is rejected with the same error code.
+  const int maxLen = std::min(maxTL, dataCap + 1024);
+  {
+    const size_t perBlock = pipeline_scratch(1, maxLen, true) + (size_t)maxLen * 2 + (size_t)(host ? maxInBytes : 0) + (1 << 16);
+    const int maxB = (int)std::max<size_t>(1, kz_arena_budget() / perBlock);
+    if (B > maxB) {
+      for (int b0 = 0; b0 < B; b0 += maxB) {
+        const int cnt = std::min(maxB, B - b0);
+        int rc = kz_decode_blocks(ctx, transformType, entropyType, blockSize, in + (int64_t)b0 * inStride, inStride, bitLengths + b0, cnt,
+                                  out + (int64_t)b0 * outStride, outStride, results + b0, memKind);
+        if (rc) return rc;
+      }
+      return 0;
+    }
+  }
   Pipe P;
   const int64_t inS = host ? (int64_t)kz_align((size_t)maxInBytes + 64, 256) : inStride;
   const int64_t extra = (host ? inS * B : 0) + (int64_t)B * (sizeof(kz_block_result) + 128);
-  int rc = pipe_setup(ctx, P, B, maxLen, extra);
+  int rc = pipe_setup(ctx, P, B, maxLen, extra, true);
   if (rc) return rc;
   kz_batch& bt = P.bt;
   hipStream_t st = ctx->stream;
@@ -555,7 +597,7 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   if (!d_bitLen) { snprintf(ctx->err, sizeof(ctx->err), "decode: arena overflow"); return -KZ_ERR_DEVICE; }
   KZ_HIP(hipMemcpyAsync(d_bitLen, bitLengths, (size_t)B * 8, hipMemcpyHostToDevice, st));
   hipEvent_t e0; kz_stage_begin(ctx, &e0);
-  KZ_LAUNCH(ctx, KID_FRAME_PARSE, k_frame_parse, dim3((B + 255) / 256), dim3(256), d_in, inS, d_bitLen, F, nb, maxTL, B);
+  KZ_LAUNCH(ctx, KID_FRAME_PARSE, k_frame_parse, dim3((B + 255) / 256), dim3(256), d_in, inS, d_bitLen, F, nb, maxLen, B);
   // read back descriptors
   int32_t* hp = ctx->hpin + 4 * B;
   KZ_HIP(hipMemcpyAsync(hp + 0 * B, F.preLen, (size_t)B * 4, hipMemcpyDeviceToHost, st));
@@ -628,7 +670,7 @@ static int32_t transform_one(kz_ctx* ctx, uint32_t type, bool forward, const uin
   if (forward && dstCap < kz_transform_max_encoded_len(type, n)) return 0;   // e.g. ZRLT.java:68, BWTBlockCodec.java:84-86
   Pipe P;
   const int maxLen = std::max(kz_transform_max_encoded_len(type, n), std::max(dstCap, n));
-  int rc = pipe_setup(ctx, P, 1, maxLen, 0);
+  int rc = pipe_setup(ctx, P, 1, maxLen, 0, !forward);
   if (rc) return rc;
   kz_batch& bt = P.bt;
   hipStream_t st = ctx->stream;
@@ -659,7 +701,7 @@ extern "C" int64_t kz_entropy_encode(kz_ctx* ctx, uint32_t type, const uint8_t* 
   KZ_HIP(hipSetDevice(ctx->device));
   Pipe P;
   const int64_t oS = kz_max_block_stream_bytes(n);
-  int rc = pipe_setup(ctx, P, 1, n, oS + 256);
+  int rc = pipe_setup(ctx, P, 1, n, oS + 256, false);
   if (rc) return rc;
   kz_batch& bt = P.bt;
   hipStream_t st = ctx->stream;
@@ -698,7 +740,7 @@ extern "C" int32_t kz_entropy_decode(kz_ctx* ctx, uint32_t type, const uint8_t* 
   Pipe P;
   const int64_t inBytes = (inBits + 7) >> 3;
   const int64_t inS = (int64_t)kz_align((size_t)inBytes + 64, 256);
-  int rc = pipe_setup(ctx, P, 1, count, inS + 256);
+  int rc = pipe_setup(ctx, P, 1, count, inS + 256, true);
   if (rc) return rc;
   kz_batch& bt = P.bt;
   hipStream_t st = ctx->stream;

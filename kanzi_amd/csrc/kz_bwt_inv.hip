@@ -4,9 +4,13 @@
 // K/transform/BWT.java:245-374 (inverseMergeTPSI).  Same data structure as the reference -- a packed
 // link array data[j] = (next << 8) | byte built by a stable counting sort of the BWT bytes
 // (BWT.java:264-293) -- but built in parallel: LDS tile histograms, a per-symbol scan over tiles,
-// and a ballot match-any stable scatter; then the 8 primary-index walkers of each block
-// (BWT.java:295-368) chase pointers concurrently, 8 lanes per block, all blocks of the batch at once.
-// Limit: n <= 2^24 (the packed form; the reference switches to biPSIv2 above 8 MiB with the same
+// and a ballot match-any stable scatter.  The reference then runs 8 pointer-chasing walkers from the
+// 8 primary indexes (BWT.java:295-368); a pointer chase is latency bound (one HBM round trip per
+// byte), so here every block gets THOUSANDS of walkers: one per grid point j*S of the link array plus
+// the text head.  Pass 1 measures each segment (walk until the next grid point), a per-block LDS
+// pointer-jumping pass turns segment lengths into text offsets, pass 2 re-walks and writes the bytes.
+// The output is the same text; only the primary index 0 is needed (the others are validated).
+// Limit: n < 2^24-1 (the packed form; the reference switches to biPSIv2 above 8 MiB with the same
 // output) -- larger blocks return -KZ_ERR_BLOCK_SIZE.
 #include "kz_device.h"
 #include "kz_internal.h"
@@ -25,8 +29,14 @@ struct BwtInv {
   int32_t* hdr;     // [B] header size
   int32_t* prim;    // [B][8] primary indexes (as stored + 1)
   int32_t* status;  // [B]
+  u32* segLen;      // [B][GS]  walker segment lengths
+  int32_t* segNext; // [B][GS]  next segment id on the text path, -1 = end of text
+  u32* segOff;      // [B][GS]  text offset of each segment
   int64_t NS; int T;
+  int logS;         // grid spacing = 1 << logS
+  int GS;           // walker stride per block (grid points + 1)
 };
+#define BI_END 0xFFFFFFu
 
 __global__ void k_bwti_parse(const u8* __restrict__ src, int64_t stride, const int32_t* __restrict__ d_len, BwtInv V, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,7 +55,7 @@ __global__ void k_bwti_parse(const u8* __restrict__ src, int64_t stride, const i
     else {
       n = blockSize - headerSize;
       if (chunks != ((n < 256) ? 1 : 8)) status = -KZ_ERR_PROCESS_BLOCK;               // :158-159
-      else if (n > (1 << 24)) status = -KZ_ERR_BLOCK_SIZE;
+      else if (n >= (1 << 24) - 1) status = -KZ_ERR_BLOCK_SIZE;
       else {
         int pos = 1;
         for (int i = 0; i < chunks; i++) {
@@ -145,45 +155,110 @@ __global__ __launch_bounds__(KZ_WG) void k_bwti_scatter(const u8* __restrict__ s
     if (i < n) {
       const u32 c = dr[r] & 0xFF;
       const u32 pos = cnt[wave][c] + (dr[r] >> 8);
-      // BWT.java:273-293: i==0 -> 0xFF00|c ; i<pIdx -> (i-1)<<8|c ; else i<<8|c
-      const u32 v = (i == 0) ? (0xFF00u | c) : (((u32)(i < pIdx ? i - 1 : i) << 8) | c);
+      // BWT.java:273-293: i<pIdx -> (i-1)<<8|c ; else i<<8|c.  i==0 is the row of the last text byte:
+      // the reference stores a dummy link (0xFF00|c); an explicit END marker is stored here instead.
+      const u32 v = (i == 0) ? ((BI_END << 8) | c) : (((u32)(i < pIdx ? i - 1 : i) << 8) | c);
       data[pos] = v;
     }
   }
 }
 
-// walkers: lane k of the wave follows primary index k (BWT.java:295-368)
-__global__ __launch_bounds__(64) void k_bwti_walk(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride, BwtInv V,
-                                                   int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag) {
+// pass 1: walker w starts at grid point w*S (w < G) or at the text head t0 (w == G) and counts the
+// steps to the next grid point / END.
+__global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V) {
+  const int b = blockIdx.y;
+  const int n = V.n[b];
+  if (n < 2 || V.status[b] != 0) return;
+  const int S = 1 << V.logS;
+  const int G = (n + S - 1) >> V.logS;
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  if (w > G) return;
+  const u32* data = V.data + (int64_t)b * V.NS;
+  u32 t = (w < G) ? (u32)w << V.logS : (u32)(V.prim[b * 8] - 1);
+  u32 steps = 0;
+  int nxt = -2;
+  while (steps <= (u32)n) {
+    if (t >= (u32)n) break;                                   // corrupt link
+    const u32 ptr = data[t];
+    steps++;
+    t = ptr >> 8;
+    if (t == BI_END) { nxt = -1; break; }
+    if ((t & (u32)(S - 1)) == 0) { nxt = (int)(t >> V.logS); break; }
+  }
+  if (nxt == -2) { atomicExch(&V.status[b], -KZ_ERR_PROCESS_BLOCK); nxt = -1; }
+  V.segLen[(int64_t)b * V.GS + w] = steps;
+  V.segNext[(int64_t)b * V.GS + w] = nxt;
+}
+
+// per block: suffix sums along the segment chain by pointer jumping in LDS -> text offsets
+#define BI_MAXSEG 4100
+__global__ __launch_bounds__(256) void k_bwti_resolve(BwtInv V) {
   const int b = blockIdx.x;
   const int n = V.n[b];
-  const int lane = kz_lane();
-  u8* d = dst + (int64_t)b * stride;
-  if (V.status[b] != 0) { if (lane == 0) { d_len2[b] = 0; d_flag[b] = 0; } return; }
-  if (lane == 0) { d_len2[b] = n; d_flag[b] = 1; }
-  if (n == 0) return;
-  if (n == 1) { if (lane == 0) d[0] = src[(int64_t)b * stride + V.hdr[b]]; return; }     // BWT.java:174-177 mirror
+  if (n < 2 || V.status[b] != 0) return;
+  const int S = 1 << V.logS;
+  const int G = (n + S - 1) >> V.logS;
+  const int M = G + 1;
+  __shared__ u32 R[BI_MAXSEG];
+  __shared__ int NX[BI_MAXSEG];
+  const int64_t o = (int64_t)b * V.GS;
+  for (int i = threadIdx.x; i < M; i += 256) { R[i] = V.segLen[o + i]; NX[i] = V.segNext[o + i]; }
+  __syncthreads();
+  for (int round = 0; round < 13; round++) {
+    u32 r2[17]; int n2[17];
+    int k = 0;
+    for (int i = threadIdx.x; i < M; i += 256, k++) {
+      const int nx = NX[i];
+      r2[k] = (nx >= 0) ? R[i] + R[nx] : R[i];
+      n2[k] = (nx >= 0) ? NX[nx] : -1;
+    }
+    __syncthreads();
+    k = 0;
+    for (int i = threadIdx.x; i < M; i += 256, k++) { R[i] = r2[k]; NX[i] = n2[k]; }
+    __syncthreads();
+  }
+  // R[i] = bytes from the start of segment i to the end of the text
+  if (threadIdx.x == 0 && (R[G] != (u32)n || NX[G] != -1)) atomicExch(&V.status[b], -KZ_ERR_PROCESS_BLOCK);
+  for (int i = threadIdx.x; i < M; i += 256) V.segOff[o + i] = (R[i] <= (u32)n) ? (u32)n - R[i] : 0xFFFFFFFFu;
+}
+
+// pass 2: re-walk every segment and write its bytes at the resolved text offset
+__global__ __launch_bounds__(64) void k_bwti_walk2(u8* __restrict__ dst, int64_t stride, BwtInv V) {
+  const int b = blockIdx.y;
+  const int n = V.n[b];
+  if (n < 2 || V.status[b] != 0) return;
+  const int S = 1 << V.logS;
+  const int G = (n + S - 1) >> V.logS;
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  if (w > G) return;
   const u32* data = V.data + (int64_t)b * V.NS;
-  const int chunks = (n < 256) ? 1 : 8;
-  if (lane >= chunks) return;
-  const int ckSize = (chunks == 1) ? n : (((n & 7) == 0) ? (n >> 3) : (n >> 3) + 1);
-  const int start = lane * ckSize;
-  const int end = min(n, start + ckSize);
-  u32 t = (u32)(V.prim[b * 8 + lane] - 1);
-  bool bad = false;
-  for (int i = start; i < end; i++) {
-    if (t >= (u32)n) { bad = true; break; }
+  u8* d = dst + (int64_t)b * stride;
+  u32 t = (w < G) ? (u32)w << V.logS : (u32)(V.prim[b * 8] - 1);
+  const u32 len = V.segLen[(int64_t)b * V.GS + w];
+  u32 off = V.segOff[(int64_t)b * V.GS + w];
+  if (off == 0xFFFFFFFFu || (unsigned long long)off + len > (unsigned long long)n) return;   // not on the text path
+  for (u32 k = 0; k < len; k++) {
     const u32 ptr = data[t];
-    d[i] = (u8)ptr;
+    d[off + k] = (u8)ptr;
     t = ptr >> 8;
   }
-  if (bad) { atomicExch(&V.status[b], -KZ_ERR_PROCESS_BLOCK); d_flag[b] = 0; }
+}
+
+__global__ void k_bwti_fin(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride, BwtInv V,
+                           int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int n = V.n[b];
+  const bool ok = V.status[b] == 0;
+  d_len2[b] = ok ? n : 0;
+  d_flag[b] = ok ? 1 : 0;
+  if (ok && n == 1) dst[(int64_t)b * stride] = src[(int64_t)b * stride + V.hdr[b]];      // BWT.java:174-177 mirror
 }
 
 size_t kz_bwt_inverse_scratch(int B, int maxN) {
   const int64_t NS = (int64_t)kz_align((size_t)maxN + 64, BI_TILE);
   const int T = (int)(NS / BI_TILE);
-  return (size_t)B * ((size_t)NS * 4 + (size_t)T * 1024 + 1024 + 64 * 4) + 8192;
+  return (size_t)B * ((size_t)NS * 4 + (size_t)T * 1024 + 1024 + 64 * 4 + (size_t)BI_MAXSEG * 12) + 16384;
 }
 
 int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
@@ -200,7 +275,13 @@ int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
   V.hdr = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   V.prim = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 32);
   V.status = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
-  if (!V.status || !V.data) { snprintf(ctx->err, sizeof(ctx->err), "bwt_inverse: arena overflow"); return -KZ_ERR_DEVICE; }
+  V.logS = 6;
+  while (((maxN + (1 << V.logS) - 1) >> V.logS) > 4096) V.logS++;
+  V.GS = ((maxN + (1 << V.logS) - 1) >> V.logS) + 1;
+  V.segLen = (u32*)kz_arena_alloc(ctx, (size_t)B * V.GS * 4);
+  V.segNext = (int32_t*)kz_arena_alloc(ctx, (size_t)B * V.GS * 4);
+  V.segOff = (u32*)kz_arena_alloc(ctx, (size_t)B * V.GS * 4);
+  if (!V.status || !V.data || !V.segOff) { snprintf(ctx->err, sizeof(ctx->err), "bwt_inverse: arena overflow"); return -KZ_ERR_DEVICE; }
   hipStream_t st = ctx->stream;
   const u8* src = bt.buf[bt.cur];
   u8* dst = bt.buf[bt.cur ^ 1];
@@ -211,7 +292,12 @@ int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
     KZ_LAUNCH(ctx, KID_BWTI_SCAN, k_bwti_scan, dim3(B), dim3(256), V);
     KZ_LAUNCH(ctx, KID_BWTI_SCATTER, k_bwti_scatter, dim3(tiles, B), dim3(KZ_WG), src, bt.stride, V);
   }
-  KZ_LAUNCH(ctx, KID_BWTI_WALK, k_bwti_walk, dim3(B), dim3(64), src, dst, bt.stride, V, bt.d_len2, bt.d_flag);
+  if (maxN >= 2) {
+    KZ_LAUNCH(ctx, KID_BWTI_WALK1, k_bwti_walk1, dim3((V.GS + 63) / 64, B), dim3(64), V);
+    KZ_LAUNCH(ctx, KID_BWTI_RESOLVE, k_bwti_resolve, dim3(B), dim3(256), V);
+    KZ_LAUNCH(ctx, KID_BWTI_WALK2, k_bwti_walk2, dim3((V.GS + 63) / 64, B), dim3(64), dst, bt.stride, V);
+  }
+  KZ_LAUNCH(ctx, KID_BWTI_FIN, k_bwti_fin, dim3((B + 255) / 256), dim3(256), src, dst, bt.stride, V, bt.d_len2, bt.d_flag, B);
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
   { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }

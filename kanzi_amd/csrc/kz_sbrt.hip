@@ -144,6 +144,31 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
 }
 
 // ---- inverse: one wave per block ---------------------------------------------------------------
+// State: the rank->symbol list kept sorted by position: position j lives in register j>>6, lane j&63
+// as ONE 64-bit value  key' = (q << 40) | ((p + 256) << 8) | symbol  (never seen: ((255-s) << 8) | s).
+// (q,p) is unique per symbol so the extra low byte never changes the order, and symbol + key move
+// together: a step costs two readlanes, one v_cmp_gt_u64 ballot per register up to r>>6 (new position
+// = number of keys above the new key) and one DPP wave_shr:1 per touched register half.  Zero ranks
+// never move the list: runs of zeros are skipped in O(1) with a ballot of the non-zero lanes of each
+// 64-byte row (after BWT most ranks are zero).  Valid for n < 2^24 - 256.
+#define KZ_DPP_SHR1(x) ((u32)__builtin_amdgcn_update_dpp(0, (int)(x), 0x138 /*wave_shr:1*/, 0xF, 0xF, false))
+#define KZ_K64(k) (((u64)hi##k << 32) | (u64)lo##k)
+
+// shift register k (positions 64k..64k+63) for a move of position r up to rp; K1 = k-1 (carry source)
+#define KZ_SBRT_SHIFT(k, K1, HAS_PREV)                                                     \
+  if ((k) <= R && (k) >= RP) {                                                             \
+    u32 slo = KZ_DPP_SHR1(lo##k), shi = KZ_DPP_SHR1(hi##k);                                \
+    if (HAS_PREV && (k) > RP) {                                                            \
+      const u32 clo = (u32)__builtin_amdgcn_readlane((int)lo##K1, 63);                     \
+      const u32 chi = (u32)__builtin_amdgcn_readlane((int)hi##K1, 63);                     \
+      if (lane == 0) { slo = clo; shi = chi; }                                             \
+    }                                                                                      \
+    const int pos = 64 * (k) + lane;                                                       \
+    const bool in = (pos > rp) && (pos <= r);                                              \
+    lo##k = in ? slo : lo##k; hi##k = in ? shi : hi##k;                                    \
+    if (pos == rp) { lo##k = nlo; hi##k = nhi; }                                           \
+  }
+
 __global__ __launch_bounds__(64) void k_sbrt_inverse(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
                                                       const int32_t* __restrict__ d_len, int mode) {
   const int b = blockIdx.x;
@@ -151,63 +176,67 @@ __global__ __launch_bounds__(64) void k_sbrt_inverse(const u8* __restrict__ src,
   const u8* s = src + (int64_t)b * stride;
   u8* d = dst + (int64_t)b * stride;
   const int lane = kz_lane();
-  // list: position j -> lane j>>2, byte j&3 ; initially r2s[j] = j
-  u32 list = (u32)(4 * lane) | ((u32)(4 * lane + 1) << 8) | ((u32)(4 * lane + 2) << 16) | ((u32)(4 * lane + 3) << 24);
-  u64 k0 = (u64)(255 - lane), k1 = (u64)(255 - 64 - lane), k2 = (u64)(255 - 128 - lane), k3 = (u64)(255 - 192 - lane);
-  for (int row = 0; row < n; row += 256) {
-    const int wi = row + lane * 4;
-    u32 w = 0;
-    if (wi + 3 < n) w = *(const u32*)(s + wi);
-    else { for (int k = 0; k < 4; k++) if (wi + k < n) w |= (u32)s[wi + k] << (8 * k); }
-    const int cntRow = min(256, n - row);
-    u32 outw = 0, acc = 0;
-    for (int j = 0; j < cntRow; j++) {
-      const u32 ww = (u32)__builtin_amdgcn_readlane((int)w, j >> 2);
-      const int r = (ww >> (8 * (j & 3))) & 0xFF;
+  // r2s[j] = j, all symbols never seen
+  u32 lo0 = ((u32)(255 - lane) << 8) | (u32)lane, lo1 = ((u32)(191 - lane) << 8) | (u32)(64 + lane);
+  u32 lo2 = ((u32)(127 - lane) << 8) | (u32)(128 + lane), lo3 = ((u32)(63 - lane) << 8) | (u32)(192 + lane);
+  u32 hi0 = 0, hi1 = 0, hi2 = 0, hi3 = 0;
+  u32 flo = (255u << 8) | 0u, fhi = 0;      // authoritative copy of position 0 (synced into lane 0 on demand)
+  u32 cur = (lane < n) ? (u32)s[lane] : 0u;
+  for (int row = 0; row < n; row += 64) {
+    const int cnt = min(64, n - row);
+    const int nrow = row + 64;
+    const u32 nxt = (nrow + lane < n) ? (u32)s[nrow + lane] : 0u;  // prefetch the next row
+    uint64_t nz = kz_ballot(cur != 0 && lane < cnt);
+    u32 outv = 0;
+    int prev = -1;
+    for (;;) {
+      const int j = nz ? (int)__builtin_ctzll(nz) : cnt;
+      const int zr = j - prev - 1;
+      if (zr > 0) {
+        // zero run [prev+1, j): the front symbol repeats; only its (q,p) change (SBRT.java:194-201)
+        const u32 pk = flo >> 8;
+        const u32 pold = (pk >= 256u) ? pk - 256u : 0u;
+        const u32 pl = (u32)(row + prev + zr);                     // last index of the run
+        const u32 pp = (zr >= 2) ? pl - 1u : pold;
+        const u32 q = (mode == 2) ? ((pl + pp) >> 1) : ((mode == 1) ? pl : pp);
+        fhi = q << 8;
+        flo = ((pl + 256u) << 8) | (flo & 0xFFu);
+        if (lane > prev && lane < j) outv = flo & 0xFFu;
+      }
+      if (j >= cnt) break;
+      nz &= nz - 1;
+      const int r = __builtin_amdgcn_readlane((int)cur, j);
       const int i = row + j;
-      const u32 lw = (u32)__builtin_amdgcn_readlane((int)list, r >> 2);
-      const int c = (lw >> (8 * (r & 3))) & 0xFF;
-      u64 kc;
-      switch (c >> 6) {
-        case 0: kc = kz_readlane64(k0, c & 63); break;
-        case 1: kc = kz_readlane64(k1, c & 63); break;
-        case 2: kc = kz_readlane64(k2, c & 63); break;
-        default: kc = kz_readlane64(k3, c & 63); break;
-      }
-      const u32 lo = (u32)kc;
-      const u32 pc = (lo >= 256u) ? lo - 256u : 0u;
+      if (lane == 0) { lo0 = flo; hi0 = fhi; }                     // sync the cached front entry
+      const int R = r >> 6, rl = r & 63;
+      u32 clo;
+      if (R == 0) clo = (u32)__builtin_amdgcn_readlane((int)lo0, rl);
+      else if (R == 1) clo = (u32)__builtin_amdgcn_readlane((int)lo1, rl);
+      else if (R == 2) clo = (u32)__builtin_amdgcn_readlane((int)lo2, rl);
+      else clo = (u32)__builtin_amdgcn_readlane((int)lo3, rl);
+      const u32 c = clo & 0xFFu;
+      const u32 pk = clo >> 8;
+      const u32 pc = (pk >= 256u) ? pk - 256u : 0u;
       const u32 qc = (mode == 2) ? (((u32)i + pc) >> 1) : ((mode == 1) ? (u32)i : pc);
-      const u64 nk = ((u64)qc << 32) | (u64)((u32)i + 256u);
-      if (r != 0) {
-        // new position = number of symbols whose key exceeds the new key (c's old key is smaller)
-        const int rp = (int)(__popcll(kz_ballot(k0 > nk)) + __popcll(kz_ballot(k1 > nk)) +
-                             __popcll(kz_ballot(k2 > nk)) + __popcll(kz_ballot(k3 > nk)));
-        if (rp != r) {
-          // positions (rp, r] take their predecessor, position rp takes c
-          const u32 prev = (u32)__builtin_amdgcn_update_dpp(0, (int)list, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
-          const u32 shifted = (list << 8) | (prev >> 24);
-          const int jb = 4 * lane;
-          const int a = (rp + 1) - jb;                 // first shifted byte index within this lane
-          const int e = r - jb + 1;                    // number of leading bytes <= r
-          const u32 mlo = (a <= 0) ? 0xFFFFFFFFu : ((a >= 4) ? 0u : (0xFFFFFFFFu << (8 * a)));
-          const u32 mhi = (e <= 0) ? 0u : ((e >= 4) ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (8 * (4 - e))));
-          const u32 mask = mlo & mhi;
-          u32 nl = (shifted & mask) | (list & ~mask);
-          if (lane == (rp >> 2)) { const int sh = 8 * (rp & 3); nl = (nl & ~(0xFFu << sh)) | ((u32)c << sh); }
-          list = nl;
-        }
-      }
-      switch (c >> 6) {
-        case 0: if (lane == (c & 63)) k0 = nk; break;
-        case 1: if (lane == (c & 63)) k1 = nk; break;
-        case 2: if (lane == (c & 63)) k2 = nk; break;
-        default: if (lane == (c & 63)) k3 = nk; break;
-      }
-      acc |= (u32)c << (8 * (j & 3));
-      if ((j & 3) == 3 || j == cntRow - 1) { if (lane == (j >> 2)) outw = acc; acc = 0; }
+      const u32 nlo = (((u32)i + 256u) << 8) | c, nhi = qc << 8;
+      const u64 nk = ((u64)nhi << 32) | (u64)nlo;
+      // new position = number of entries above the new key (entries below r are smaller than the old key)
+      int rp = (int)__popcll(kz_ballot(KZ_K64(0) > nk));
+      if (R >= 1) rp += (int)__popcll(kz_ballot(KZ_K64(1) > nk));
+      if (R >= 2) rp += (int)__popcll(kz_ballot(KZ_K64(2) > nk));
+      if (R >= 3) rp += (int)__popcll(kz_ballot(KZ_K64(3) > nk));
+      const int RP = rp >> 6;
+      // descending order: register k reads its carry from the still unmodified register k-1
+      KZ_SBRT_SHIFT(3, 2, true)
+      KZ_SBRT_SHIFT(2, 1, true)
+      KZ_SBRT_SHIFT(1, 0, true)
+      KZ_SBRT_SHIFT(0, 0, false)
+      if (rp == 0) { flo = nlo; fhi = nhi; }                       // else position 0 is untouched
+      if (lane == j) outv = c;
+      prev = j;
     }
-    if (wi + 3 < n) *(u32*)(d + wi) = outw;
-    else { for (int k = 0; k < 4; k++) if (wi + k < n) d[wi + k] = (u8)(outw >> (8 * k)); }
+    if (lane < cnt) d[row + lane] = (u8)outv;
+    cur = nxt;
   }
 }
 
@@ -245,6 +274,10 @@ int kz_stage_sbrt_forward(kz_ctx* ctx, kz_batch& bt, int mode) {
 
 int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
   const int B = bt.B;
+  for (int b = 0; b < B; b++) if (bt.h_len[b] >= (1 << 24) - 256) {
+    snprintf(ctx->err, sizeof(ctx->err), "sbrt_inverse: block of %d bytes exceeds the packed-key limit 2^24-256", bt.h_len[b]);
+    return -KZ_ERR_BLOCK_SIZE;
+  }
   hipStream_t st = ctx->stream;
   const u8* src = bt.buf[bt.cur];
   u8* dst = bt.buf[bt.cur ^ 1];

@@ -149,9 +149,10 @@ int kzo_bwt_forward_raw(const uint8_t* src, int n, uint8_t* dst, int32_t primary
   return 1;
 }
 
-/* K/transform/BWT.java:245-374 (inverseMergeTPSI); blocks > 8 MiB use biPSIv2 in the reference with
- * the same result, so one restatement serves both as long as n < 2^24 ... the packed form needs
- * n <= 2^24; larger blocks use a 64-bit unpacked walk here (same output). */
+/* K/transform/BWT.java:245-374 (inverseMergeTPSI): packed link array data[j] = (next << 8) | byte built by a
+ * counting sort, then 8 interleaved walkers (one per primary index) for memory-level parallelism, exactly
+ * the reference's loop structure.  Blocks > 2^24 (the reference switches to biPSIv2 above 8 MiB, same
+ * output) use an unpacked 64-bit walk. */
 int kzo_bwt_inverse_raw(const uint8_t* src, int n, uint8_t* dst, const int32_t primary[8]) {
   if (n <= 0) return 1;
   if (n == 1) { dst[0] = src[0]; return 1; }
@@ -160,27 +161,58 @@ int kzo_bwt_inverse_raw(const uint8_t* src, int n, uint8_t* dst, const int32_t p
   uint32_t b[256]; memset(b, 0, sizeof(b));
   for (int i = 0; i < n; i++) b[src[i]]++;
   for (int i = 0, sum = 0; i < 256; i++) { int t = (int)b[i]; b[i] = (uint32_t)sum; sum += t; }
+  int ok = 1;
+  if (n < (1 << 24)) {
+    uint32_t* data = (uint32_t*)malloc(((size_t)n + 64) * sizeof(uint32_t));
+    if (!data) return 0;
+    { int v = src[0]; data[b[v]] = 0xFF00u | (uint32_t)v; b[v]++; }                               /* :273-275 */
+    for (int i = 1; i < pIdx; i++) { int v = src[i]; data[b[v]] = ((uint32_t)(i - 1) << 8) | (uint32_t)v; b[v]++; }
+    for (int i = pIdx; i < n; i++) { int v = src[i]; data[b[v]] = ((uint32_t)i << 8) | (uint32_t)v; b[v]++; }
+    if (bwt_chunks(n) != 8) {
+      uint32_t t = (uint32_t)(pIdx - 1);
+      for (int i = 0; i < n; i++) { if (t >= (uint32_t)n) { ok = 0; break; } uint32_t ptr = data[t]; dst[i] = (uint8_t)ptr; t = ptr >> 8; }
+    } else {
+      const int ckSize = ((n & 7) == 0) ? (n >> 3) : (n >> 3) + 1;
+      uint32_t t[8];
+      for (int k = 0; k < 8; k++) {
+        int64_t tk = (int64_t)primary[k] - 1;
+        if (tk < 0 || tk >= n) { ok = 0; break; }          /* :305-311 */
+        t[k] = (uint32_t)tk;
+      }
+      if (ok) {
+        const int end = n - ckSize * 7;                    /* :313-314 */
+        int i = 0;
+        for (; i < end && ok; i++) {
+          for (int k = 0; k < 8; k++) {
+            if (t[k] >= (uint32_t)n) { ok = 0; break; }    /* corrupt stream (Java would throw) */
+            uint32_t ptr = data[t[k]]; dst[i + k * ckSize] = (uint8_t)ptr; t[k] = ptr >> 8;
+          }
+        }
+        for (; i < ckSize && ok; i++) {
+          for (int k = 0; k < 7; k++) {
+            if (t[k] >= (uint32_t)n) { ok = 0; break; }
+            uint32_t ptr = data[t[k]]; dst[i + k * ckSize] = (uint8_t)ptr; t[k] = ptr >> 8;
+          }
+        }
+      }
+    }
+    free(data);
+    return ok;
+  }
   uint32_t* nxt = (uint32_t*)malloc((size_t)n * sizeof(uint32_t));
   uint8_t* fch = (uint8_t*)malloc((size_t)n);
   if (!nxt || !fch) { free(nxt); free(fch); return 0; }
-  { int v = src[0]; fch[b[v]] = (uint8_t)v; nxt[b[v]] = 0xFF; b[v]++; }      /* :273-275 */
+  { int v = src[0]; fch[b[v]] = (uint8_t)v; nxt[b[v]] = 0xFF; b[v]++; }
   for (int i = 1; i < pIdx; i++) { int v = src[i]; fch[b[v]] = (uint8_t)v; nxt[b[v]] = (uint32_t)(i - 1); b[v]++; }
   for (int i = pIdx; i < n; i++) { int v = src[i]; fch[b[v]] = (uint8_t)v; nxt[b[v]] = (uint32_t)i; b[v]++; }
-  int ok = 1;
-  if (bwt_chunks(n) != 8) {
-    uint32_t t = (uint32_t)(pIdx - 1);
-    for (int i = 0; i < n; i++) { if (t >= (uint32_t)n) { ok = 0; break; } dst[i] = fch[t]; t = nxt[t]; }
-  } else {
+  {
     const int ckSize = ((n & 7) == 0) ? (n >> 3) : (n >> 3) + 1;
     for (int k = 0; k < 8 && ok; k++) {
       int64_t t = (int64_t)primary[k] - 1;
-      if (t < 0 || t >= n) { ok = 0; break; }              /* :305-311 */
+      if (t < 0 || t >= n) { ok = 0; break; }
       int start = k * ckSize;
       int end = start + ckSize < n ? start + ckSize : n;
-      for (int i = start; i < end; i++) {
-        if (t >= n) { ok = 0; break; }                     /* corrupt stream (Java would throw) */
-        dst[i] = fch[t]; t = nxt[t];
-      }
+      for (int i = start; i < end; i++) { if (t >= n) { ok = 0; break; } dst[i] = fch[t]; t = nxt[t]; }
     }
   }
   free(nxt); free(fch);
