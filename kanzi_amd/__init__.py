@@ -7,7 +7,7 @@ there is NO CPU fallback: importing works everywhere (so the ABI can be inspecte
 
 Reference interfaces mirrored (K/ = java/src/main/java/io/github/flanglet/kanzi/):
   * ``ByteTransform``  K/ByteTransform.java:36,48,56      -> :class:`BWTBlockCodec`, :class:`SBRT`, :class:`ZRLT`
-  * ``EntropyEncoder`` K/EntropyEncoder.java:34,41,48     -> :class:`ANSRangeEncoder`, :class:`NullEntropyEncoder`
+  * ``EntropyEncoder`` K/EntropyEncoder.java:34,41,48     -> :class:`ANSRangeEncoder`, :class:`HuffmanEncoder`, :class:`NullEntropyEncoder`
   * ``EntropyDecoder`` K/EntropyDecoder.java:33           -> :class:`ANSRangeDecoder`, :class:`NullEntropyDecoder`
   * ``Sequence`` / block span of EncodingTask.encodeBlock -> :func:`encode_blocks` / :func:`decode_blocks`
   * ``CompressedOutputStream`` / ``CompressedInputStream`` -> same-named classes (whole .knz stream)
@@ -300,6 +300,14 @@ class ANSRangeEncoder(_EntropyEncoder):
 
 class ANSRangeDecoder(_EntropyDecoder):
     TYPE = E_ANS0
+
+
+class HuffmanEncoder(_EntropyEncoder):
+    TYPE = E_HUFFMAN           # K/entropy/HuffmanEncoder.java
+
+
+class HuffmanDecoder(_EntropyDecoder):
+    TYPE = E_HUFFMAN
 
 
 class NullEntropyEncoder(_EntropyEncoder):

@@ -14,27 +14,13 @@
 // concatenated at bit granularity by a scan + funnel-shift kernel (the .knz payload is bit packed).
 #include "kz_device.h"
 #include "kz_internal.h"
+#include "kz_chunk.h"
 
-typedef unsigned long long u64;
-typedef uint32_t u32;
 typedef uint16_t u16;
-typedef uint8_t u8;
 
 #define ANS_TOP (1u << 15)
-#define ANS_CHUNK 16384
 #define ANS_LR 12
-#define ANS_HDR_BYTES 512            // per-chunk header bit buffer
-#define ANS_SCRATCH (32 * 1024)      // per-chunk rANS output buffer (worst case 12 bit/sym * 16384 + 19)
 
-struct AnsEnc {
-  u8* hdr;          // [B][C][ANS_HDR_BYTES]
-  u8* scr;          // [B][C][ANS_SCRATCH]
-  u32* hdrBits;     // [B][C]
-  u32* tailOff;     // [B][C] offset inside the chunk scratch where varint|states|payload start
-  u32* tailBytes;   // [B][C]
-  u64* bitOff;      // [B][C] exclusive scan of chunk bit lengths
-  int C;            // chunk stride per block
-};
 
 // ---- single-lane MSB-first bit writer into a zeroed buffer ------------------------------------
 struct BitW { u8* p; u32 pos; };
@@ -63,7 +49,7 @@ __global__ __launch_bounds__(64) void k_ans_enc_chunk(const u8* __restrict__ src
   if (count <= 32) {                                            // ANSRangeEncoder.java:267-270 raw
     if (ck != 0) return;
     if (lane < count) scr[lane] = blk[lane];
-    if (lane == 0) { E.hdrBits[ci] = 0; E.tailOff[ci] = 0; E.tailBytes[ci] = (u32)count; }
+    if (lane == 0) { E.hdrBits[ci] = 0; E.tailOff[ci] = 0; E.tailBits[ci] = 8u * (u32)count; }
     return;
   }
   const int start = ck * ANS_CHUNK;
@@ -245,7 +231,7 @@ __global__ __launch_bounds__(64) void k_ans_enc_chunk(const u8* __restrict__ src
   __syncthreads();
   for (int i = lane; i < ANS_HDR_BYTES / 4; i += 64) ((u32*)hdr)[i] = hbuf[i];
   if (alphabetSize <= 1) {                                        // :295-298 no payload
-    if (lane == 0) { E.tailOff[ci] = 0; E.tailBytes[ci] = 0; }
+    if (lane == 0) { E.tailOff[ci] = 0; E.tailBits[ci] = 0; }
     return;
   }
   // ---- encodeChunk (:337-407): 4 lanes = st0..st3, walking backwards ----
@@ -279,7 +265,7 @@ __global__ __launch_bounds__(64) void k_ans_enc_chunk(const u8* __restrict__ src
     u32 v = payload; int p = tail;
     while (v >= 128) { scr[p++] = (u8)(0x80 | (v & 0x7F)); v >>= 7; }     // EntropyUtils.java:259-276
     scr[p++] = (u8)v;
-    E.tailOff[ci] = (u32)tail; E.tailBytes[ci] = payload + 16 + vlen;
+    E.tailOff[ci] = (u32)tail; E.tailBits[ci] = 8u * (payload + 16 + vlen);
   }
   if (lane < 4) {
     u8* p = scr + tail + vlen + 4 * lane;
@@ -288,16 +274,16 @@ __global__ __launch_bounds__(64) void k_ans_enc_chunk(const u8* __restrict__ src
 }
 
 // per block: exclusive scan of chunk bit lengths (<= 257 chunks) -> bitOff, total payload bits
-__global__ __launch_bounds__(64) void k_ans_enc_scan(const int32_t* __restrict__ d_len, AnsEnc E, int64_t* __restrict__ d_bits) {
+__global__ __launch_bounds__(64) void k_ans_enc_scan(const int32_t* __restrict__ d_len, AnsEnc E, int64_t* __restrict__ d_bits, int rawLimit) {
   const int b = blockIdx.x;
   const int count = d_len[b];
-  const int chunks = (count <= 32) ? (count > 0 ? 1 : 0) : (count + ANS_CHUNK - 1) / ANS_CHUNK;
+  const int chunks = (count <= rawLimit) ? (count > 0 ? 1 : 0) : (count + ANS_CHUNK - 1) / ANS_CHUNK;
   const int lane = kz_lane();
   u64 carry = 0;
   for (int base = 0; base < chunks; base += 64) {
     const int c = base + lane;
     const int64_t ci = (int64_t)b * E.C + c;
-    const u32 v = (c < chunks) ? E.hdrBits[ci] + 8u * E.tailBytes[ci] : 0;
+    const u32 v = (c < chunks) ? E.hdrBits[ci] + E.tailBits[ci] : 0;
     const u32 inc = kz_wave_incl_sum(v);
     if (c < chunks) E.bitOff[ci] = carry + inc - v;
     carry += __shfl(inc, 63, 64);
@@ -328,15 +314,15 @@ __device__ __forceinline__ u32 kz_fetch32(const u8* __restrict__ p, int64_t nbit
 
 // concatenate chunk bit strings into out[b] at bit offset 8*hdrBytes[b] + bitOff (out pre-zeroed)
 __global__ __launch_bounds__(KZ_WG) void k_ans_enc_concat(const int32_t* __restrict__ d_len, AnsEnc E, u8* __restrict__ out,
-                                                           int64_t outStride, const int32_t* __restrict__ d_hdrBytes) {
+                                                           int64_t outStride, const int32_t* __restrict__ d_hdrBytes, int rawLimit) {
   const int b = blockIdx.y, ck = blockIdx.x;
   const int count = d_len[b];
-  const int chunks = (count <= 32) ? (count > 0 ? 1 : 0) : (count + ANS_CHUNK - 1) / ANS_CHUNK;
+  const int chunks = (count <= rawLimit) ? (count > 0 ? 1 : 0) : (count + ANS_CHUNK - 1) / ANS_CHUNK;
   if (ck >= chunks) return;
   const int64_t ci = (int64_t)b * E.C + ck;
   const u8* hdr = E.hdr + ci * ANS_HDR_BYTES;
   const int64_t hb = E.hdrBits[ci];
-  const int64_t tb = 8LL * E.tailBytes[ci];
+  const int64_t tb = (int64_t)E.tailBits[ci];
   const u8* tail = E.scr + ci * ANS_SCRATCH + E.tailOff[ci];
   const int64_t len = hb + tb;
   if (len == 0) return;
@@ -356,29 +342,38 @@ size_t kz_ans_scratch(int B, int maxN) {
   return (size_t)B * C * (ANS_HDR_BYTES + ANS_SCRATCH + 32) + (size_t)B * 64 + 8192;
 }
 
-int kz_stage_ans0_encode(kz_ctx* ctx, kz_batch& bt, uint8_t* out, int64_t outStride, const int32_t* d_hdrBytes, int64_t* d_bits) {
+int kz_chunk_enc_alloc(kz_ctx* ctx, kz_batch& bt, AnsEnc& E, int* chunksOut) {
   const int B = bt.B;
   int maxN = 0;
   for (int b = 0; b < B; b++) if (bt.h_len[b] > maxN) maxN = bt.h_len[b];
-  AnsEnc E;
   E.C = (maxN + ANS_CHUNK - 1) / ANS_CHUNK + 1;
   E.hdr = (u8*)kz_arena_alloc(ctx, (size_t)B * E.C * ANS_HDR_BYTES);
   E.scr = (u8*)kz_arena_alloc(ctx, (size_t)B * E.C * ANS_SCRATCH);
   E.hdrBits = (u32*)kz_arena_alloc(ctx, (size_t)B * E.C * 4);
   E.tailOff = (u32*)kz_arena_alloc(ctx, (size_t)B * E.C * 4);
-  E.tailBytes = (u32*)kz_arena_alloc(ctx, (size_t)B * E.C * 4);
+  E.tailBits = (u32*)kz_arena_alloc(ctx, (size_t)B * E.C * 4);
   E.bitOff = (u64*)kz_arena_alloc(ctx, (size_t)B * E.C * 8);
-  if (!E.bitOff || !E.scr) { snprintf(ctx->err, sizeof(ctx->err), "ans0_encode: arena overflow"); return -KZ_ERR_DEVICE; }
-  hipStream_t st = ctx->stream;
-  const u8* src = bt.buf[bt.cur];
-  KZ_HIP(hipMemsetAsync(E.hdrBits, 0, (size_t)B * E.C * 4, st));
-  KZ_HIP(hipMemsetAsync(E.tailBytes, 0, (size_t)B * E.C * 4, st));
-  const int chunks = (maxN + ANS_CHUNK - 1) / ANS_CHUNK;
-  if (chunks > 0) KZ_LAUNCH(ctx, KID_ANS_ENC_CHUNK, k_ans_enc_chunk, dim3(chunks, B), dim3(64), src, bt.stride, bt.d_len, E);
-  KZ_LAUNCH(ctx, KID_ANS_ENC_SCAN, k_ans_enc_scan, dim3(B), dim3(64), bt.d_len, E, d_bits);
-  if (chunks > 0) KZ_LAUNCH(ctx, KID_ANS_ENC_CONCAT, k_ans_enc_concat, dim3(chunks, B), dim3(KZ_WG), bt.d_len, E, out, outStride, d_hdrBytes);
+  if (!E.bitOff || !E.scr) { snprintf(ctx->err, sizeof(ctx->err), "entropy encode: arena overflow"); return -KZ_ERR_DEVICE; }
+  KZ_HIP(hipMemsetAsync(E.hdrBits, 0, (size_t)B * E.C * 4, ctx->stream));
+  KZ_HIP(hipMemsetAsync(E.tailBits, 0, (size_t)B * E.C * 4, ctx->stream));
+  *chunksOut = (maxN + ANS_CHUNK - 1) / ANS_CHUNK;
+  return 0;
+}
+int kz_chunk_enc_finish(kz_ctx* ctx, kz_batch& bt, AnsEnc& E, int chunks, uint8_t* out, int64_t outStride,
+                        const int32_t* d_hdrBytes, int64_t* d_bits, int rawLimit) {
+  const int B = bt.B;
+  KZ_LAUNCH(ctx, KID_ANS_ENC_SCAN, k_ans_enc_scan, dim3(B), dim3(64), bt.d_len, E, d_bits, rawLimit);
+  if (chunks > 0) KZ_LAUNCH(ctx, KID_ANS_ENC_CONCAT, k_ans_enc_concat, dim3(chunks, B), dim3(KZ_WG), bt.d_len, E, out, outStride, d_hdrBytes, rawLimit);
   KZ_HIP(hipGetLastError());
   return 0;
+}
+
+int kz_stage_ans0_encode(kz_ctx* ctx, kz_batch& bt, uint8_t* out, int64_t outStride, const int32_t* d_hdrBytes, int64_t* d_bits) {
+  AnsEnc E; int chunks = 0;
+  int rc = kz_chunk_enc_alloc(ctx, bt, E, &chunks);
+  if (rc) return rc;
+  if (chunks > 0) KZ_LAUNCH(ctx, KID_ANS_ENC_CHUNK, k_ans_enc_chunk, dim3(chunks, bt.B), dim3(64), bt.buf[bt.cur], bt.stride, bt.d_len, E);
+  return kz_chunk_enc_finish(ctx, bt, E, chunks, out, outStride, d_hdrBytes, d_bits, 32);
 }
 
 // =================================================================================================

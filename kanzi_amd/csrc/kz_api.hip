@@ -118,7 +118,7 @@ static int split_types(uint64_t tt, int* types) {                    // Transfor
   return k;
 }
 static bool transform_supported(int t) { return t == KZ_T_NONE || t == KZ_T_BWT || t == KZ_T_RANK || t == KZ_T_MTFT || t == KZ_T_ZRLT; }
-static bool entropy_supported(int e) { return e == KZ_E_NONE || e == KZ_E_ANS0; }
+static bool entropy_supported(int e) { return e == KZ_E_NONE || e == KZ_E_ANS0 || e == KZ_E_HUFFMAN; }
 static int seq_max_len(const int* types, int nb, int n) {             // Sequence.java:215-226
   int req = n;
   for (int i = 0; i < nb; i++) req = std::max(req, kz_transform_max_encoded_len((uint32_t)types[i], req));
@@ -428,7 +428,7 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     hipEvent_t e0; kz_stage_begin(ctx, &e0);
     int64_t inBytes = 0; for (int b = 0; b < B; b++) inBytes += bt.h_len[b];
     // copy blocks and NONE entropy: raw bytes (NullEntropyEncoder.java:66-81)
-    if (entropyType == KZ_E_ANS0) {
+    if (entropyType == KZ_E_ANS0 || entropyType == KZ_E_HUFFMAN) {
       // small copy blocks use NONE: mask them out of the ANS stage by zero length, then copy raw
       for (int b = 0; b < B; b++) h_mask[b] = h_copy[b] ? 0 : 1;
       KZ_HIP(hipMemcpyAsync(P.d_mask, h_mask.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
@@ -436,7 +436,8 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
       KZ_LAUNCH(ctx, KID_MASK_LEN, k_mask_len, dim3((B + 255) / 256), dim3(256), P.d_lenSave, P.d_mask, bt.d_len, B);
       std::vector<int32_t> saved = bt.h_len;
       for (int b = 0; b < B; b++) if (h_copy[b]) bt.h_len[b] = 0;
-      rc = kz_stage_ans0_encode(ctx, bt, d_out, outStride, F.hdrBytes, F.bits);
+      rc = (entropyType == KZ_E_ANS0) ? kz_stage_ans0_encode(ctx, bt, d_out, outStride, F.hdrBytes, F.bits)
+                                      : kz_stage_huffman_encode(ctx, bt, d_out, outStride, F.hdrBytes, F.bits);
       if (rc) return rc;
       bt.h_len = saved;
       KZ_HIP(hipMemcpyAsync(bt.d_len, P.d_lenSave, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
@@ -618,9 +619,11 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     int64_t outBytes = 0; for (int b = 0; b < B; b++) outBytes += bt.h_len[b];
     std::vector<int32_t> h_rawp(B);
     for (int b = 0; b < B; b++) h_rawp[b] = (entropyType == KZ_E_NONE || h_raw[b] || h_tc[b]) ? 1 : 0;
-    if (entropyType == KZ_E_ANS0) {
+    if (entropyType == KZ_E_ANS0 || entropyType == KZ_E_HUFFMAN) {
       for (int b = 0; b < B; b++) h_mask[b] = h_rawp[b] ? 0 : 1;
-      rc = run_stage(ctx, P, h_mask, h_applied, [&](kz_batch& x) { return kz_stage_ans0_decode(ctx, x, d_in, inS, F.bitOff, F.bitEnd); });
+      rc = run_stage(ctx, P, h_mask, h_applied, [&](kz_batch& x) {
+        return (entropyType == KZ_E_ANS0) ? kz_stage_ans0_decode(ctx, x, d_in, inS, F.bitOff, F.bitEnd)
+                                          : kz_stage_huffman_decode(ctx, x, d_in, inS, F.bitOff, F.bitEnd); });
       if (rc) return rc;
       for (int b = 0; b < B; b++) if (h_mask[b] && !h_applied[b] && !h_status[b]) h_status[b] = -KZ_ERR_PROCESS_BLOCK;
     } else {
@@ -715,8 +718,8 @@ extern "C" int64_t kz_entropy_encode(kz_ctx* ctx, uint32_t type, const uint8_t* 
   KZ_HIP(hipMemsetAsync(d_out, 0, (size_t)oS, st));
   KZ_HIP(hipMemsetAsync(d_hdr, 0, 64, st));
   int64_t bits = 0;
-  if (type == KZ_E_ANS0) {
-    rc = kz_stage_ans0_encode(ctx, bt, d_out, oS, d_hdr, d_bits);
+  if (type == KZ_E_ANS0 || type == KZ_E_HUFFMAN) {
+    rc = (type == KZ_E_ANS0) ? kz_stage_ans0_encode(ctx, bt, d_out, oS, d_hdr, d_bits) : kz_stage_huffman_encode(ctx, bt, d_out, oS, d_hdr, d_bits);
     if (rc) return rc;
     KZ_HIP(hipMemcpyAsync(&bits, d_bits, 8, hipMemcpyDeviceToHost, st));
     KZ_HIP(hipStreamSynchronize(st));
@@ -753,8 +756,8 @@ extern "C" int32_t kz_entropy_decode(kz_ctx* ctx, uint32_t type, const uint8_t* 
   KZ_HIP(hipMemcpyAsync(d_off, h, 16, hipMemcpyHostToDevice, st));
   bt.h_len[0] = count;
   KZ_HIP(hipMemcpyAsync(bt.d_len, &count, 4, hipMemcpyHostToDevice, st));
-  if (type == KZ_E_ANS0) {
-    rc = kz_stage_ans0_decode(ctx, bt, d_in, inS, d_off, d_off + 1);
+  if (type == KZ_E_ANS0 || type == KZ_E_HUFFMAN) {
+    rc = (type == KZ_E_ANS0) ? kz_stage_ans0_decode(ctx, bt, d_in, inS, d_off, d_off + 1) : kz_stage_huffman_decode(ctx, bt, d_in, inS, d_off, d_off + 1);
     if (rc) return rc;
     int32_t flag = 0;
     KZ_HIP(hipMemcpyAsync(&flag, bt.d_flag, 4, hipMemcpyDeviceToHost, st));

@@ -79,23 +79,35 @@ def test_python_mirror_slice_semantics(ctx):
     assert r.forward(s3, d3) and list(d3.array) == [97, 98, 99, 2]
 
 
-def test_ans0_encode_decode_match_oracle(ctx):
-    for data in _all_inputs():
+def _huffman_limit_input():
+    # Fibonacci-like frequencies force code lengths > 12 -> limitCodeLengths (HuffmanEncoder.java:191-273)
+    fib = [1, 1]
+    while len(fib) < 24:
+        fib.append(fib[-1] + fib[-2])
+    d = b"".join(bytes([i]) * f for i, f in enumerate(fib))[:16384]
+    return bytes(np.random.default_rng(0).permutation(np.frombuffer(d, dtype=np.uint8)))
+
+
+@pytest.mark.parametrize("ent", ["ANS0", "HUFFMAN"])
+def test_entropy_encode_decode_match_oracle(ctx, ent):
+    Enc, Dec = (kz.ANSRangeEncoder, kz.ANSRangeDecoder) if ent == "ANS0" else (kz.HuffmanEncoder, kz.HuffmanDecoder)
+    for data in _all_inputs() + [_huffman_limit_input(), _huffman_limit_input()[:5000] + bytes(range(256)) * 4]:
         if len(data) == 0:
             continue
-        bits_o, nb_o = oracle.entropy_encode("ANS0", data)
-        enc = kz.ANSRangeEncoder(ctx)
+        bits_o, nb_o = oracle.entropy_encode(ent, data)
+        enc = Enc(ctx)
         assert enc.encode(np.frombuffer(data, dtype=np.uint8), 0, len(data)) == len(data)
         bits_g, nb_g = enc.bits[0]
         assert nb_g == nb_o and bits_g == bits_o, len(data)
-        dec = kz.ANSRangeDecoder(ctx, bits_o, nb_o)
+        dec = Dec(ctx, bits_o, nb_o)
         out = np.zeros(len(data), dtype=np.uint8)
         assert dec.decode(out, 0, len(data)) == len(data)
         assert out.tobytes() == data
 
 
 @pytest.mark.parametrize("chain,ent", [("BWT+RANK+ZRLT", "ANS0"), ("BWT+MTFT+ZRLT", "ANS0"), ("ZRLT", "NONE"),
-                                        ("BWT", "ANS0"), ("RANK+ZRLT", "ANS0"), ("NONE", "ANS0")])
+                                        ("BWT", "ANS0"), ("RANK+ZRLT", "ANS0"), ("NONE", "ANS0"),
+                                        ("BWT+RANK+ZRLT", "HUFFMAN"), ("NONE", "HUFFMAN")])
 def test_block_streams_match_oracle(ctx, chain, ent):
     """kz_encode_blocks output == oracle encode_block (header, skip flags, raw fallback, copy blocks)."""
     bs = 40000

@@ -83,14 +83,14 @@ def test_transform_roundtrip_reference_inputs(name):
 
 def test_entropy_roundtrip_reference_inputs():
     # T/test/TestEntropyCodec.java:203-290
-    for ent in ("ANS0", "NONE"):
+    for ent in ("ANS0", "HUFFMAN", "NONE"):
         for data in refinputs.entropy_inputs() + refinputs.edge_inputs():
             bits, nb = oracle.entropy_encode(ent, data)
             r, back, used = oracle.entropy_decode(ent, bits, nb, len(data))
             assert r == len(data) and back == data and used == nb
 
 
-@pytest.mark.parametrize("chain,ent", [("BWT+RANK+ZRLT", "ANS0"), ("BWT+MTFT+ZRLT", "ANS0"), ("ZRLT", "NONE"), ("NONE", "ANS0")])
+@pytest.mark.parametrize("chain,ent", [("BWT+RANK+ZRLT", "ANS0"), ("BWT+MTFT+ZRLT", "ANS0"), ("ZRLT", "NONE"), ("NONE", "ANS0"), ("BWT+RANK+ZRLT", "HUFFMAN")])
 def test_stream_roundtrip(chain, ent):
     rng = np.random.default_rng(5)
     data = bytes(np.minimum(rng.geometric(0.05, 200000) - 1, 255).astype(np.uint8)) + b"abc" * 1000 + bytes(3000)
