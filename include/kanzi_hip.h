@@ -7,10 +7,12 @@
  *   kz_transform_forward / _inverse / _max_encoded_len
  *       K/ByteTransform.java:36,48,56  (boolean forward(SliceByteArray,SliceByteArray), inverse, getMaxEncodedLength)
  *       for the codecs K/transform/BWTBlockCodec.java:71-213, K/transform/SBRT.java:87-214 (RANK, MTFT),
- *       K/transform/ZRLT.java:54-233.   "false" is a normal outcome (Sequence.java:95-105) -> return 0.
+ *       K/transform/ZRLT.java:54-233, K/transform/SRT.java:66-257, K/transform/LZCodec.java:299-756 (LZ, LZX).   "false" is a normal outcome (Sequence.java:95-105) -> return 0.
  *   kz_entropy_encode / kz_entropy_decode
  *       K/EntropyEncoder.java:34 (int encode(byte[],int,int)) + dispose(), K/EntropyDecoder.java:33
  *       for K/entropy/ANSRangeEncoder.java:263-305, K/entropy/ANSRangeDecoder.java:189-236,
+ *       K/entropy/HuffmanEncoder.java:380-416, K/entropy/HuffmanDecoder.java:353-390,
+ *       K/entropy/FPAQEncoder.java:128-238, K/entropy/FPAQDecoder.java:161-335,
  *       K/entropy/NullEntropyEncoder.java:66-81.  The codec's output is a bit string (MSB first,
  *       K/bitstream/DefaultOutputBitStream.java:103-123): the Java adapter calls
  *       obs.writeBits(out, 0, nbits) once.
@@ -53,7 +55,8 @@ enum { KZ_MEM_HOST = 0, KZ_MEM_DEVICE = 1 };
 #define KZ_MAX_STAGES 16
 enum { KZ_STAGE_BWT_FWD = 0, KZ_STAGE_SBRT_FWD = 1, KZ_STAGE_ZRLT_FWD = 2, KZ_STAGE_ENTROPY_ENC = 3,
        KZ_STAGE_FRAME_ENC = 4, KZ_STAGE_ENTROPY_DEC = 5, KZ_STAGE_ZRLT_INV = 6, KZ_STAGE_SBRT_INV = 7,
-       KZ_STAGE_BWT_INV = 8, KZ_STAGE_FRAME_DEC = 9 };
+       KZ_STAGE_BWT_INV = 8, KZ_STAGE_FRAME_DEC = 9, KZ_STAGE_LZ_FWD = 10, KZ_STAGE_LZ_INV = 11,
+       KZ_STAGE_SRT_FWD = 12, KZ_STAGE_SRT_INV = 13 };
 
 typedef struct kz_ctx kz_ctx;
 

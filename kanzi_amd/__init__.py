@@ -28,7 +28,7 @@ ENTROPY_IDS = {"NONE": 0, "HUFFMAN": 1, "FPAQ": 2, "ANS0": 5}
 MEM_HOST, MEM_DEVICE = 0, 1
 
 STAGE_NAMES = ["bwt_fwd", "sbrt_fwd", "zrlt_fwd", "entropy_enc", "frame_enc",
-               "entropy_dec", "zrlt_inv", "sbrt_inv", "bwt_inv", "frame_dec"]
+               "entropy_dec", "zrlt_inv", "sbrt_inv", "bwt_inv", "frame_dec", "lz_fwd", "lz_inv", "srt_fwd", "srt_inv"]
 
 
 class KanziError(RuntimeError):
@@ -242,6 +242,18 @@ class ZRLT(_Transform):
     TYPE = ZRLT_TYPE           # K/transform/ZRLT.java
 
 
+class SRT(_Transform):
+    TYPE = SRT_TYPE            # K/transform/SRT.java
+
+
+class LZCodec(_Transform):
+    """K/transform/LZCodec.java (LZXCodec): lz=LZ_TYPE or LZX_TYPE."""
+
+    def __init__(self, ctx, lz=LZ_TYPE):
+        super().__init__(ctx)
+        self.TYPE = lz
+
+
 class SBRT(_Transform):
     MODE_MTF, MODE_RANK, MODE_TIMESTAMP = 1, 2, 3   # K/transform/SBRT.java:35-37
 
@@ -308,6 +320,14 @@ class HuffmanEncoder(_EntropyEncoder):
 
 class HuffmanDecoder(_EntropyDecoder):
     TYPE = E_HUFFMAN
+
+
+class FPAQEncoder(_EntropyEncoder):
+    TYPE = E_FPAQ              # K/entropy/FPAQEncoder.java (encode + dispose)
+
+
+class FPAQDecoder(_EntropyDecoder):
+    TYPE = E_FPAQ
 
 
 class NullEntropyEncoder(_EntropyEncoder):

@@ -117,8 +117,8 @@ static int split_types(uint64_t tt, int* types) {                    // Transfor
   for (int i = 0; i < nbtr; i++) { int t = (int)((tt >> (42 - 6 * i)) & 0x3F); if (t != KZ_T_NONE || i == 0) types[k++] = t; }
   return k;
 }
-static bool transform_supported(int t) { return t == KZ_T_NONE || t == KZ_T_BWT || t == KZ_T_RANK || t == KZ_T_MTFT || t == KZ_T_ZRLT; }
-static bool entropy_supported(int e) { return e == KZ_E_NONE || e == KZ_E_ANS0 || e == KZ_E_HUFFMAN; }
+static bool transform_supported(int t) { return t == KZ_T_NONE || t == KZ_T_BWT || t == KZ_T_RANK || t == KZ_T_MTFT || t == KZ_T_ZRLT || t == KZ_T_SRT || t == KZ_T_LZ || t == KZ_T_LZX; }
+static bool entropy_supported(int e) { return e == KZ_E_NONE || e == KZ_E_ANS0 || e == KZ_E_HUFFMAN || e == KZ_E_FPAQ; }
 static int seq_max_len(const int* types, int nb, int n) {             // Sequence.java:215-226
   int req = n;
   for (int i = 0; i < nb; i++) req = std::max(req, kz_transform_max_encoded_len((uint32_t)types[i], req));
@@ -296,20 +296,33 @@ static size_t kz_arena_budget() {
   return budget;
 }
 // stage scratch is bump-allocated after the ping-pong buffers; each stage allocates in turn, so the
-// arena must hold the SUM over the stages of a direction (they are small except the suffix sort)
-static size_t pipeline_scratch(int B, int maxLen, bool decode) {
-  size_t s = kz_sbrt_scratch(B, maxLen) + kz_zrlt_scratch(B, maxLen) * 2;
-  if (decode) s += kz_bwt_inverse_scratch(B, maxLen) + (size_t)B * ((size_t)(maxLen / 16384 + 4) * 8 + 64) + 65536;
-  else s += kz_bwt_forward_scratch(B, maxLen) + kz_ans_scratch(B, maxLen);
+// arena must hold the SUM over the stages the chain actually runs
+struct ChainSpec { int types[8]; int nb; int entropy; };
+static size_t pipeline_scratch(int B, int maxLen, bool decode, const ChainSpec& C) {
+  size_t s = 65536;
+  for (int i = 0; i < C.nb; i++) {
+    switch (C.types[i]) {
+      case KZ_T_BWT: s += decode ? kz_bwt_inverse_scratch(B, maxLen) : kz_bwt_forward_scratch(B, maxLen); break;
+      case KZ_T_RANK: case KZ_T_MTFT: s += kz_sbrt_scratch(B, maxLen); break;
+      case KZ_T_ZRLT: s += kz_zrlt_scratch(B, maxLen); break;
+      case KZ_T_SRT: s += decode ? 4096 : kz_srt_scratch(B, maxLen); break;
+      case KZ_T_LZ: case KZ_T_LZX: s += decode ? 4096 : kz_lz_scratch(B, maxLen); break;
+      default: break;
+    }
+  }
+  if (C.entropy == KZ_E_ANS0 || C.entropy == KZ_E_HUFFMAN)
+    s += decode ? (size_t)B * ((size_t)(maxLen / 16384 + 4) * 8 + 64) + 65536 : kz_ans_scratch(B, maxLen);
+  else if (C.entropy == KZ_E_FPAQ)
+    s += decode ? 4096 : (size_t)B * kz_align((size_t)maxLen + (size_t)(maxLen >> 3) + 64, 256) + 4096;
   return s;
 }
 
-static int pipe_setup(kz_ctx* ctx, Pipe& P, int B, int maxLen, int64_t extraBytes, bool decode) {
+static int pipe_setup(kz_ctx* ctx, Pipe& P, int B, int maxLen, int64_t extraBytes, bool decode, const ChainSpec& C) {
   kz_batch& bt = P.bt;
   bt.B = B; bt.maxN = maxLen;
   bt.stride = (int64_t)kz_align((size_t)maxLen + 4096, 256);
   const size_t fixed = (size_t)bt.stride * B * 2 + (size_t)B * 4 * 16 + 65536 + (size_t)extraBytes;
-  int rc = kz_arena_reserve(ctx, fixed + pipeline_scratch(B, maxLen, decode) + (1 << 20));
+  int rc = kz_arena_reserve(ctx, fixed + pipeline_scratch(B, maxLen, decode, C) + (1 << 20));
   if (rc) return rc;
   bt.buf[0] = (u8*)kz_arena_alloc(ctx, (size_t)bt.stride * B);
   bt.buf[1] = (u8*)kz_arena_alloc(ctx, (size_t)bt.stride * B);
@@ -331,6 +344,9 @@ static int run_transform_stage(kz_ctx* ctx, kz_batch& bt, int type, bool forward
     case KZ_T_RANK: return forward ? kz_stage_sbrt_forward(ctx, bt, 2) : kz_stage_sbrt_inverse(ctx, bt, 2);
     case KZ_T_MTFT: return forward ? kz_stage_sbrt_forward(ctx, bt, 1) : kz_stage_sbrt_inverse(ctx, bt, 1);
     case KZ_T_ZRLT: return forward ? kz_stage_zrlt_forward(ctx, bt) : kz_stage_zrlt_inverse(ctx, bt, dstCap);
+    case KZ_T_SRT: return forward ? kz_stage_srt_forward(ctx, bt) : kz_stage_srt_inverse(ctx, bt);
+    case KZ_T_LZ: return forward ? kz_stage_lz_forward(ctx, bt, 0) : kz_stage_lz_inverse(ctx, bt, 0, dstCap);
+    case KZ_T_LZX: return forward ? kz_stage_lz_forward(ctx, bt, 1) : kz_stage_lz_inverse(ctx, bt, 1, dstCap);
     default: snprintf(ctx->err, sizeof(ctx->err), "transform %d has no HIP stage", type); return -KZ_ERR_INVALID_CODEC;
   }
 }
@@ -338,6 +354,8 @@ static int stage_id(int type, bool forward) {
   switch (type) {
     case KZ_T_BWT: return forward ? KZ_STAGE_BWT_FWD : KZ_STAGE_BWT_INV;
     case KZ_T_RANK: case KZ_T_MTFT: return forward ? KZ_STAGE_SBRT_FWD : KZ_STAGE_SBRT_INV;
+    case KZ_T_SRT: return forward ? KZ_STAGE_SRT_FWD : KZ_STAGE_SRT_INV;
+    case KZ_T_LZ: case KZ_T_LZX: return forward ? KZ_STAGE_LZ_FWD : KZ_STAGE_LZ_INV;
     default: return forward ? KZ_STAGE_ZRLT_FWD : KZ_STAGE_ZRLT_INV;
   }
 }
@@ -358,10 +376,11 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   int maxN = 0;
   for (int b = 0; b < B; b++) { if (lengths[b] < 0) return -KZ_ERR_INVALID_PARAM; maxN = std::max(maxN, lengths[b]); }
   const int maxLen = seq_max_len(types, nb, maxN);
+  ChainSpec CS; CS.nb = nb; CS.entropy = (int)entropyType; for (int i = 0; i < nb; i++) CS.types[i] = types[i];
   {
     // bound the scratch arena: the suffix sort needs ~43 B per input byte, so very large batches are
     // processed as consecutive sub-batches (blocks are independent; results are identical)
-    const size_t perBlock = pipeline_scratch(1, maxLen, false) + (size_t)maxLen * 2 + (size_t)outStride + (1 << 16);
+    const size_t perBlock = pipeline_scratch(1, maxLen, false, CS) + (size_t)maxLen * 2 + (size_t)outStride + (1 << 16);
     const int maxB = (int)std::max<size_t>(1, kz_arena_budget() / perBlock);
     if (B > maxB) {
       for (int b0 = 0; b0 < B; b0 += maxB) {
@@ -378,7 +397,7 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   const bool host = memKind == KZ_MEM_HOST;
   Pipe P;
   const int64_t extra = (host ? (int64_t)outStride * B : 0) + (int64_t)B * (sizeof(kz_block_result) + 64) + (int64_t)B * 16;
-  int rc = pipe_setup(ctx, P, B, maxLen, extra, false);
+  int rc = pipe_setup(ctx, P, B, maxLen, extra, false, CS);
   if (rc) return rc;
   kz_batch& bt = P.bt;
   hipStream_t st = ctx->stream;
@@ -428,7 +447,7 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     hipEvent_t e0; kz_stage_begin(ctx, &e0);
     int64_t inBytes = 0; for (int b = 0; b < B; b++) inBytes += bt.h_len[b];
     // copy blocks and NONE entropy: raw bytes (NullEntropyEncoder.java:66-81)
-    if (entropyType == KZ_E_ANS0 || entropyType == KZ_E_HUFFMAN) {
+    if (entropyType == KZ_E_ANS0 || entropyType == KZ_E_HUFFMAN || entropyType == KZ_E_FPAQ) {
       // small copy blocks use NONE: mask them out of the ANS stage by zero length, then copy raw
       for (int b = 0; b < B; b++) h_mask[b] = h_copy[b] ? 0 : 1;
       KZ_HIP(hipMemcpyAsync(P.d_mask, h_mask.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
@@ -437,7 +456,8 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
       std::vector<int32_t> saved = bt.h_len;
       for (int b = 0; b < B; b++) if (h_copy[b]) bt.h_len[b] = 0;
       rc = (entropyType == KZ_E_ANS0) ? kz_stage_ans0_encode(ctx, bt, d_out, outStride, F.hdrBytes, F.bits)
-                                      : kz_stage_huffman_encode(ctx, bt, d_out, outStride, F.hdrBytes, F.bits);
+         : (entropyType == KZ_E_HUFFMAN) ? kz_stage_huffman_encode(ctx, bt, d_out, outStride, F.hdrBytes, F.bits)
+                                         : kz_stage_fpaq_encode(ctx, bt, d_out, outStride, F.hdrBytes, F.bits);
       if (rc) return rc;
       bt.h_len = saved;
       KZ_HIP(hipMemcpyAsync(bt.d_len, P.d_lenSave, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
@@ -555,8 +575,9 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   // no chain in scope expands a block by more than 1024 bytes, so buffers are sized dataCap+1024 and a
   // larger (corrupt) length is rejected with the same error code.
   const int maxLen = std::min(maxTL, dataCap + 1024);
+  ChainSpec CS; CS.nb = nb; CS.entropy = (int)entropyType; for (int i = 0; i < nb; i++) CS.types[i] = types[i];
   {
-    const size_t perBlock = pipeline_scratch(1, maxLen, true) + (size_t)maxLen * 2 + (size_t)(host ? maxInBytes : 0) + (1 << 16);
+    const size_t perBlock = pipeline_scratch(1, maxLen, true, CS) + (size_t)maxLen * 2 + (size_t)(host ? maxInBytes : 0) + (1 << 16);
     const int maxB = (int)std::max<size_t>(1, kz_arena_budget() / perBlock);
     if (B > maxB) {
       for (int b0 = 0; b0 < B; b0 += maxB) {
@@ -571,7 +592,7 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   Pipe P;
   const int64_t inS = host ? (int64_t)kz_align((size_t)maxInBytes + 64, 256) : inStride;
   const int64_t extra = (host ? inS * B : 0) + (int64_t)B * (sizeof(kz_block_result) + 128);
-  int rc = pipe_setup(ctx, P, B, maxLen, extra, true);
+  int rc = pipe_setup(ctx, P, B, maxLen, extra, true, CS);
   if (rc) return rc;
   kz_batch& bt = P.bt;
   hipStream_t st = ctx->stream;
@@ -619,11 +640,12 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     int64_t outBytes = 0; for (int b = 0; b < B; b++) outBytes += bt.h_len[b];
     std::vector<int32_t> h_rawp(B);
     for (int b = 0; b < B; b++) h_rawp[b] = (entropyType == KZ_E_NONE || h_raw[b] || h_tc[b]) ? 1 : 0;
-    if (entropyType == KZ_E_ANS0 || entropyType == KZ_E_HUFFMAN) {
+    if (entropyType == KZ_E_ANS0 || entropyType == KZ_E_HUFFMAN || entropyType == KZ_E_FPAQ) {
       for (int b = 0; b < B; b++) h_mask[b] = h_rawp[b] ? 0 : 1;
       rc = run_stage(ctx, P, h_mask, h_applied, [&](kz_batch& x) {
         return (entropyType == KZ_E_ANS0) ? kz_stage_ans0_decode(ctx, x, d_in, inS, F.bitOff, F.bitEnd)
-                                          : kz_stage_huffman_decode(ctx, x, d_in, inS, F.bitOff, F.bitEnd); });
+             : (entropyType == KZ_E_HUFFMAN) ? kz_stage_huffman_decode(ctx, x, d_in, inS, F.bitOff, F.bitEnd)
+                                             : kz_stage_fpaq_decode(ctx, x, d_in, inS, F.bitOff, F.bitEnd); });
       if (rc) return rc;
       for (int b = 0; b < B; b++) if (h_mask[b] && !h_applied[b] && !h_status[b]) h_status[b] = -KZ_ERR_PROCESS_BLOCK;
     } else {
@@ -673,7 +695,8 @@ static int32_t transform_one(kz_ctx* ctx, uint32_t type, bool forward, const uin
   if (forward && dstCap < kz_transform_max_encoded_len(type, n)) return 0;   // e.g. ZRLT.java:68, BWTBlockCodec.java:84-86
   Pipe P;
   const int maxLen = std::max(kz_transform_max_encoded_len(type, n), std::max(dstCap, n));
-  int rc = pipe_setup(ctx, P, 1, maxLen, 0, !forward);
+  ChainSpec CS; CS.nb = 1; CS.types[0] = (int)type; CS.entropy = KZ_E_NONE;
+  int rc = pipe_setup(ctx, P, 1, maxLen, 0, !forward, CS);
   if (rc) return rc;
   kz_batch& bt = P.bt;
   hipStream_t st = ctx->stream;
@@ -704,7 +727,8 @@ extern "C" int64_t kz_entropy_encode(kz_ctx* ctx, uint32_t type, const uint8_t* 
   KZ_HIP(hipSetDevice(ctx->device));
   Pipe P;
   const int64_t oS = kz_max_block_stream_bytes(n);
-  int rc = pipe_setup(ctx, P, 1, n, oS + 256, false);
+  ChainSpec CS; CS.nb = 0; CS.entropy = (int)type;
+  int rc = pipe_setup(ctx, P, 1, n, oS + 256, false, CS);
   if (rc) return rc;
   kz_batch& bt = P.bt;
   hipStream_t st = ctx->stream;
@@ -718,8 +742,8 @@ extern "C" int64_t kz_entropy_encode(kz_ctx* ctx, uint32_t type, const uint8_t* 
   KZ_HIP(hipMemsetAsync(d_out, 0, (size_t)oS, st));
   KZ_HIP(hipMemsetAsync(d_hdr, 0, 64, st));
   int64_t bits = 0;
-  if (type == KZ_E_ANS0 || type == KZ_E_HUFFMAN) {
-    rc = (type == KZ_E_ANS0) ? kz_stage_ans0_encode(ctx, bt, d_out, oS, d_hdr, d_bits) : kz_stage_huffman_encode(ctx, bt, d_out, oS, d_hdr, d_bits);
+  if (type == KZ_E_ANS0 || type == KZ_E_HUFFMAN || type == KZ_E_FPAQ) {
+    rc = (type == KZ_E_ANS0) ? kz_stage_ans0_encode(ctx, bt, d_out, oS, d_hdr, d_bits) : (type == KZ_E_HUFFMAN) ? kz_stage_huffman_encode(ctx, bt, d_out, oS, d_hdr, d_bits) : kz_stage_fpaq_encode(ctx, bt, d_out, oS, d_hdr, d_bits);
     if (rc) return rc;
     KZ_HIP(hipMemcpyAsync(&bits, d_bits, 8, hipMemcpyDeviceToHost, st));
     KZ_HIP(hipStreamSynchronize(st));
@@ -743,7 +767,8 @@ extern "C" int32_t kz_entropy_decode(kz_ctx* ctx, uint32_t type, const uint8_t* 
   Pipe P;
   const int64_t inBytes = (inBits + 7) >> 3;
   const int64_t inS = (int64_t)kz_align((size_t)inBytes + 64, 256);
-  int rc = pipe_setup(ctx, P, 1, count, inS + 256, true);
+  ChainSpec CS; CS.nb = 0; CS.entropy = (int)type;
+  int rc = pipe_setup(ctx, P, 1, count, inS + 256, true, CS);
   if (rc) return rc;
   kz_batch& bt = P.bt;
   hipStream_t st = ctx->stream;
@@ -756,8 +781,8 @@ extern "C" int32_t kz_entropy_decode(kz_ctx* ctx, uint32_t type, const uint8_t* 
   KZ_HIP(hipMemcpyAsync(d_off, h, 16, hipMemcpyHostToDevice, st));
   bt.h_len[0] = count;
   KZ_HIP(hipMemcpyAsync(bt.d_len, &count, 4, hipMemcpyHostToDevice, st));
-  if (type == KZ_E_ANS0 || type == KZ_E_HUFFMAN) {
-    rc = (type == KZ_E_ANS0) ? kz_stage_ans0_decode(ctx, bt, d_in, inS, d_off, d_off + 1) : kz_stage_huffman_decode(ctx, bt, d_in, inS, d_off, d_off + 1);
+  if (type == KZ_E_ANS0 || type == KZ_E_HUFFMAN || type == KZ_E_FPAQ) {
+    rc = (type == KZ_E_ANS0) ? kz_stage_ans0_decode(ctx, bt, d_in, inS, d_off, d_off + 1) : (type == KZ_E_HUFFMAN) ? kz_stage_huffman_decode(ctx, bt, d_in, inS, d_off, d_off + 1) : kz_stage_fpaq_decode(ctx, bt, d_in, inS, d_off, d_off + 1);
     if (rc) return rc;
     int32_t flag = 0;
     KZ_HIP(hipMemcpyAsync(&flag, bt.d_flag, 4, hipMemcpyDeviceToHost, st));

@@ -1,0 +1,310 @@
+// kz_lz.hip -- LZ / LZX (LZXCodec) on gfx950, first correct version.
+//
+// Replaces K/transform/LZCodec.java:299-597 (forward), :904-911 (hash), :271-287 (findMatch),
+// :211-231 (emitLength), :626-756 (inverseV6).
+//
+// The parse is a sequential state machine (hash-table last-writer, 2 repeat distances, lazy +1/+2
+// evaluation, skip acceleration srcInc>>6: SURVEY F6), and bit-exactness needs the exact visiting
+// order.  This version runs it as one wave per block with wave-uniform control flow: every lane
+// executes the same scalar logic (loads of one address broadcast), lane 0 performs the stores, and the
+// bulk copies (literals, final section assembly, match copies in the inverse) use all 64 lanes.  The hash
+// table (2^16 / 2^19 ints) lives in HBM/L2.  Throughput comes from blocks in flight; a wave-speculative
+// parse is the planned replacement.
+#include "kz_device.h"
+#include "kz_internal.h"
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+#define LZ_SEED 0x1E35A7BDULL
+#define LZ_MAXD1 ((1 << 16) - 2)
+#define LZ_MAXD2 ((1 << 24) - 2)
+#define LZ_MAX_MATCH (65535 + 254 + 4)
+#define LZ_MIN_BLOCK 24
+
+__device__ __forceinline__ u64 lz_le64(const u8* p) {
+  u64 v = 0;
+#pragma unroll
+  for (int k = 7; k >= 0; k--) v = (v << 8) | (u64)p[k];
+  return v;
+}
+__device__ __forceinline__ u32 lz_le32(const u8* p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
+__device__ __forceinline__ int lz_hash(const u8* p, int extra) { return (int)(((lz_le64(p) << 24) * LZ_SEED) >> (extra ? 45 : 48)); }
+__device__ __forceinline__ bool lz_diff4(const u8* a, int i, int j) { return lz_le32(a + i) != lz_le32(a + j); }
+__device__ __forceinline__ int lz_find_match(const u8* src, int srcIdx, int ref, int maxMatch) {
+  int bestLen = 0;
+  while (bestLen + 8 <= maxMatch) {
+    const u64 diff = lz_le64(src + srcIdx + bestLen) ^ lz_le64(src + ref + bestLen);
+    if (diff != 0) { bestLen += (__builtin_ctzll(diff) >> 3); break; }
+    bestLen += 8;
+  }
+  return bestLen;
+}
+// lane-0 stores with uniform index arithmetic
+__device__ __forceinline__ int lz_emit_length(u8* block, int idx, int length, bool w) {
+  if (length < 254) { if (w) block[idx] = (u8)length; return idx + 1; }
+  if (length < 65536 + 254) { length -= 254; if (w) { block[idx] = 254; block[idx + 1] = (u8)(length >> 8); block[idx + 2] = (u8)length; } return idx + 3; }
+  length -= 255;
+  if (w) { block[idx] = 255; block[idx + 1] = (u8)(length >> 16); block[idx + 2] = (u8)(length >> 8); block[idx + 3] = (u8)length; }
+  return idx + 4;
+}
+__device__ __forceinline__ void lz_copy(u8* d, const u8* s, int n) { for (int i = kz_lane(); i < n; i += 64) d[i] = s[i]; }
+
+__global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8* __restrict__ dstAll, int64_t stride,
+                                                const int32_t* __restrict__ d_len, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag,
+                                                int32_t* __restrict__ hashAll, u8* __restrict__ tmpAll, int64_t tmpStride, int extra) {
+  const int b = blockIdx.x;
+  const int count = d_len[b];
+  const int lane = kz_lane();
+  const bool w = lane == 0;
+  const u8* src = srcAll + (int64_t)b * stride;
+  u8* dst = dstAll + (int64_t)b * stride;
+  if (count < LZ_MIN_BLOCK) { if (w) { d_len2[b] = count; d_flag[b] = 0; } return; }      // :313-315 (count==0 handled by caller)
+  const int hsize = extra ? (1 << 19) : (1 << 16);
+  int32_t* hashes = hashAll + (int64_t)b * hsize;
+  for (int i = lane; i < hsize; i += 64) hashes[i] = 0;
+  u8* tkBuf = tmpAll + (int64_t)b * tmpStride;
+  u8* mBuf = tkBuf + tmpStride / 3;
+  u8* mLenBuf = mBuf + tmpStride / 3;
+  __syncthreads();
+  const int minMatch = 4;                                            // dataType UNDEFINED (:342-353)
+  const int srcEnd = count - 16 - 2;
+  const int maxDist = (srcEnd < 4 * LZ_MAXD1) ? LZ_MAXD1 : LZ_MAXD2;
+  if (w) dst[12] = (u8)(((maxDist == LZ_MAXD1) ? 0 : 1) | (((minMatch - 2) & 7) << 1));
+  int srcIdx = 0, anchor = 0, dstIdx = 13, mIdx = 0, mLenIdx = 0, tkIdx = 0;
+  int repd0 = count, repd1 = count;
+  int repIdx = 0, srcInc = 0;
+  bool ok = true;
+  while (srcIdx < srcEnd) {
+    int bestLen = 0;
+    const int h0 = lz_hash(src + srcIdx, extra);
+    const int ref0 = hashes[h0];
+    __syncthreads();
+    if (w) hashes[h0] = srcIdx;
+    const int srcIdx1 = srcIdx + 1;
+    int ref = srcIdx1 - (repIdx ? repd1 : repd0);
+    const int minRef = max(srcIdx - maxDist, 0);
+    if ((ref > minRef) && !lz_diff4(src, ref, srcIdx1)) {
+      bestLen = lz_find_match(src, srcIdx1, ref, min(srcEnd - srcIdx1, LZ_MAX_MATCH));
+    } else {
+      ref = srcIdx1 - (repIdx ? repd0 : repd1);
+      if ((ref > minRef) && !lz_diff4(src, ref, srcIdx1)) bestLen = lz_find_match(src, srcIdx1, ref, min(srcEnd - srcIdx1, LZ_MAX_MATCH));
+    }
+    if (bestLen < minMatch) {
+      ref = ref0;
+      if ((ref > minRef) && !lz_diff4(src, ref, srcIdx)) bestLen = lz_find_match(src, srcIdx, ref, min(srcEnd - srcIdx, LZ_MAX_MATCH));
+      if (bestLen < minMatch) { srcIdx = srcIdx1 + (srcInc >> 6); srcInc++; repIdx = 0; __syncthreads(); continue; }
+      if ((ref != srcIdx - repd0) && (ref != srcIdx - repd1)) {
+        const int h1 = lz_hash(src + srcIdx1, extra);
+        const int ref1 = hashes[h1];
+        __syncthreads();
+        if (w) hashes[h1] = srcIdx1;
+        if ((ref1 > minRef + 1) && !lz_diff4(src, ref1 + bestLen - 3, srcIdx1 + bestLen - 3)) {
+          const int bestLen1 = lz_find_match(src, srcIdx1, ref1, min(srcEnd - srcIdx1, LZ_MAX_MATCH));
+          if (bestLen1 >= bestLen) { ref = ref1; bestLen = bestLen1; srcIdx = srcIdx1; }
+        }
+        if (extra) {
+          const int srcIdx2 = srcIdx1 + 1;
+          const int h2 = lz_hash(src + srcIdx2, extra);
+          __syncthreads();
+          const int ref2 = hashes[h2];
+          __syncthreads();
+          if (w) hashes[h2] = srcIdx2;
+          if ((ref2 > minRef + 2) && !lz_diff4(src, ref2 + bestLen - 3, srcIdx2 + bestLen - 3)) {
+            const int bestLen2 = lz_find_match(src, srcIdx2, ref2, min(srcEnd - srcIdx2, LZ_MAX_MATCH));
+            if (bestLen2 >= bestLen) { ref = ref2; bestLen = bestLen2; srcIdx = srcIdx2; }
+          }
+        }
+      }
+      while ((srcIdx > anchor) && (ref > minRef) && (src[srcIdx - 1] == src[ref - 1])) { bestLen++; ref--; srcIdx--; }
+      if (bestLen > LZ_MAX_MATCH) { ref += (bestLen - LZ_MAX_MATCH); srcIdx += (bestLen - LZ_MAX_MATCH); bestLen = LZ_MAX_MATCH; }
+    } else {
+      if ((bestLen >= LZ_MAX_MATCH) || (src[srcIdx] != src[ref - 1])) {
+        srcIdx++;
+        const int h1 = lz_hash(src + srcIdx, extra);
+        __syncthreads();
+        if (w) hashes[h1] = srcIdx;
+      } else { bestLen++; ref--; }
+    }
+    srcInc = 0;
+    const int dist = srcIdx - ref;
+    int token, mLenTh;
+    if (dist == repd0) { token = 0x00; mLenTh = 3; }
+    else if (dist == repd1) { token = 0x04; mLenTh = 3; }
+    else {
+      if (w) mBuf[mIdx] = (u8)(dist >> 16);
+      const int inc1 = dist >= 65536 ? 1 : 0; mIdx += inc1;
+      if (w) mBuf[mIdx] = (u8)(dist >> 8);
+      const int inc2 = dist >= 256 ? 1 : 0; mIdx += inc2;
+      if (w) mBuf[mIdx] = (u8)dist;
+      mIdx++;
+      token = (inc1 + inc2 + 1) << 3;
+      mLenTh = 7;
+    }
+    const int mLen = bestLen - minMatch;
+    if (mLen >= mLenTh) { token += mLenTh; mLenIdx = lz_emit_length(mLenBuf, mLenIdx, mLen - mLenTh, w); }
+    else token += mLen;
+    repd1 = repd0; repd0 = dist; repIdx = 1;
+    const int litLen = srcIdx - anchor;
+    if (litLen == 0) { if (w) tkBuf[tkIdx] = (u8)token; tkIdx++; }
+    else {
+      if (litLen >= 7) {
+        if (litLen >= (1 << 24)) { ok = false; break; }
+        if (w) tkBuf[tkIdx] = (u8)((7 << 5) | token);
+        tkIdx++;
+        dstIdx = lz_emit_length(dst, dstIdx, litLen - 7, w);
+      } else { if (w) tkBuf[tkIdx] = (u8)((litLen << 5) | token); tkIdx++; }
+      lz_copy(dst + dstIdx, src + anchor, litLen);
+      dstIdx += litLen;
+    }
+    anchor = srcIdx + bestLen;
+    __syncthreads();
+    // hash fill of the covered positions (:554-565): position-monotone, last writer = highest position
+    for (int p0 = srcIdx + 1; p0 < anchor; p0 += 64) {
+      const int pp = p0 + lane;
+      int hh = 0; bool act = pp < anchor;
+      if (act) hh = lz_hash(src + pp, extra);
+      // within the wave several positions may share a slot: only the highest position may win
+      for (int l = 0; l < 64; l++) {
+        const int hl = __shfl(hh, l, 64);
+        const bool al = __shfl(act ? 1 : 0, l, 64) != 0;
+        if (al && act && l > lane && hl == hh) act = false;
+      }
+      if (act) hashes[hh] = pp;
+      __syncthreads();
+    }
+    srcIdx = anchor;
+  }
+  int res = 0, produced = 0;
+  if (ok) {
+    const int litLen = count - anchor;
+    if (dstIdx + litLen + tkIdx + mIdx + mLenIdx >= count) ok = false;                    // :571-572
+    else {
+      if (litLen >= 7) { if (w) tkBuf[tkIdx] = (u8)(7 << 5); tkIdx++; dstIdx = lz_emit_length(dst, dstIdx, litLen - 7, w); }
+      else { if (w) tkBuf[tkIdx] = (u8)(litLen << 5); tkIdx++; }
+      lz_copy(dst + dstIdx, src + anchor, litLen);
+      dstIdx += litLen;
+      if (w) {
+        dst[0] = (u8)dstIdx; dst[1] = (u8)(dstIdx >> 8); dst[2] = (u8)(dstIdx >> 16); dst[3] = (u8)(dstIdx >> 24);
+        dst[4] = (u8)tkIdx; dst[5] = (u8)(tkIdx >> 8); dst[6] = (u8)(tkIdx >> 16); dst[7] = (u8)(tkIdx >> 24);
+        dst[8] = (u8)mIdx; dst[9] = (u8)(mIdx >> 8); dst[10] = (u8)(mIdx >> 16); dst[11] = (u8)(mIdx >> 24);
+      }
+      __syncthreads();
+      lz_copy(dst + dstIdx, tkBuf, tkIdx); dstIdx += tkIdx;
+      lz_copy(dst + dstIdx, mBuf, mIdx); dstIdx += mIdx;
+      lz_copy(dst + dstIdx, mLenBuf, mLenIdx); dstIdx += mLenIdx;
+      produced = dstIdx;
+      res = (dstIdx <= count - (count / 100)) ? 1 : 0;                                     // :596
+    }
+  }
+  if (w) { d_flag[b] = (ok && res) ? 1 : 0; d_len2[b] = (ok && res) ? produced : count; }
+}
+
+__device__ __forceinline__ int lz_read_length(const u8* a, int& idx) {
+  int res = a[idx++];
+  if (res < 254) return res;
+  if (res == 254) { res += (a[idx] << 8); res += a[idx + 1]; idx += 2; return res; }
+  res += (a[idx] << 16); res += (a[idx + 1] << 8); res += a[idx + 2];
+  idx += 3;
+  return res;
+}
+
+__global__ __launch_bounds__(64) void k_lz_inv(const u8* __restrict__ srcAll, u8* __restrict__ dstAll, int64_t stride,
+                                                const int32_t* __restrict__ d_len, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag, int dstCap) {
+  const int b = blockIdx.x;
+  const int count = d_len[b];
+  const int lane = kz_lane();
+  const u8* src = srcAll + (int64_t)b * stride;
+  u8* dst = dstAll + (int64_t)b * stride;
+  bool ok = true;
+  int dstIdx = 0;
+  if (count == 0) { if (lane == 0) { d_len2[b] = 0; d_flag[b] = 1; } return; }
+  if (count < 13) ok = false;
+  if (ok) {
+    const int dstEnd = dstCap;
+    const int tkLen = (int)lz_le32(src), mIdxLen = (int)lz_le32(src + 4), mLenLen = (int)lz_le32(src + 8);
+    if ((tkLen < 0) || (mIdxLen < 0) || (mLenLen < 0)) ok = false;
+    else if ((tkLen < 13) || (tkLen > count) || (mIdxLen > count - tkLen) || (mLenLen > count - tkLen - mIdxLen)) ok = false;
+    if (ok) {
+      int tkIdx = tkLen, mIdx = tkIdx + mIdxLen, mLenIdx = mIdx + mLenLen;
+      const int srcEnd = tkIdx - 13, litEnd = tkIdx;
+      const int maxDist = ((src[12] & 1) == 0) ? LZ_MAXD1 : LZ_MAXD2;
+      const int minMatch = ((src[12] >> 1) & 7) + 2;
+      int srcIdx = 13, repd0 = count, repd1 = count;
+      for (;;) {
+        if (tkIdx >= count) { ok = false; break; }
+        const int token = src[tkIdx++];
+        if (token >= 32) {
+          const int litLen = (token >= 0xE0) ? 7 + lz_read_length(src, srcIdx) : token >> 5;
+          if ((litLen > dstEnd - dstIdx) || (litLen > litEnd - srcIdx)) { ok = false; break; }
+          lz_copy(dst + dstIdx, src + srcIdx, litLen);
+          srcIdx += litLen; dstIdx += litLen;
+          if (srcIdx >= srcEnd) { ok = (srcIdx == srcEnd + 13); break; }
+        }
+        int mLen, dist;
+        const int f = token & 0x18;
+        if (f == 0) {
+          mLen = token & 3;
+          mLen += (mLen == 3) ? minMatch + lz_read_length(src, mLenIdx) : minMatch;
+          dist = ((token & 4) == 0) ? repd0 : repd1;
+        } else {
+          mLen = token & 7;
+          mLen += (mLen == 7) ? minMatch + lz_read_length(src, mLenIdx) : minMatch;
+          dist = src[mIdx++];
+          if (f == 0x18) { dist = (dist << 8) | src[mIdx]; dist = (dist << 8) | src[mIdx + 1]; mIdx += 2; }
+          else if (f == 0x10) { dist = (dist << 8) | src[mIdx]; mIdx++; }
+        }
+        repd1 = repd0; repd0 = dist;
+        const int mEnd = dstIdx + mLen;
+        const int ref = dstIdx - dist;
+        if ((ref < 0) || (dist > maxDist) || (mEnd > dstEnd) || dist <= 0) { ok = false; break; }
+        // make the preceding stores of this wave visible to the copy below
+        __syncthreads();
+        __threadfence_block();
+        if (dist >= 64) {
+          for (int k = 0; k < mLen; k += 64) { const int i = k + lane; u8 v = 0; if (i < mLen) v = dst[ref + i]; __syncthreads(); if (i < mLen) dst[dstIdx + i] = v; __syncthreads(); }
+        } else {
+          // overlapping copy: the output is periodic with period dist over already written bytes
+          for (int i = lane; i < mLen; i += 64) dst[dstIdx + i] = dst[ref + (i % dist)];
+        }
+        __syncthreads();
+        dstIdx = mEnd;
+      }
+    }
+  }
+  if (lane == 0) { d_flag[b] = ok ? 1 : 0; d_len2[b] = ok ? dstIdx : 0; }
+}
+
+size_t kz_lz_scratch(int B, int maxN) {
+  const size_t tmpStride = kz_align((size_t)maxN * 3 + 3072, 256);
+  return (size_t)B * (((size_t)1 << 19) * 4 + tmpStride) + 16384;
+}
+
+int kz_stage_lz_forward(kz_ctx* ctx, kz_batch& bt, int extra) {
+  const int B = bt.B;
+  int maxN = 0;
+  for (int b = 0; b < B; b++) if (bt.h_len[b] > maxN) maxN = bt.h_len[b];
+  const int hsize = extra ? (1 << 19) : (1 << 16);
+  int32_t* hashes = (int32_t*)kz_arena_alloc(ctx, (size_t)B * hsize * 4);
+  const int64_t tmpStride = (int64_t)kz_align((size_t)maxN * 3 + 3072, 256) / 3 * 3;
+  u8* tmp = (u8*)kz_arena_alloc(ctx, (size_t)tmpStride * B + 256);
+  if (!hashes || !tmp) { snprintf(ctx->err, sizeof(ctx->err), "lz_forward: arena overflow"); return -KZ_ERR_DEVICE; }
+  KZ_LAUNCH(ctx, KID_LZ_FWD, k_lz_fwd, dim3(B), dim3(64), bt.buf[bt.cur], bt.buf[bt.cur ^ 1], bt.stride, bt.d_len, bt.d_len2, bt.d_flag,
+            hashes, tmp, tmpStride, extra);
+  KZ_HIP(hipGetLastError());
+  bt.cur ^= 1;
+  { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }
+  return 0;
+}
+
+int kz_stage_lz_inverse(kz_ctx* ctx, kz_batch& bt, int extra, int dstCap) {
+  (void)extra;
+  const int B = bt.B;
+  if ((int64_t)dstCap > bt.stride) dstCap = (int)bt.stride;
+  KZ_LAUNCH(ctx, KID_LZ_INV, k_lz_inv, dim3(B), dim3(64), bt.buf[bt.cur], bt.buf[bt.cur ^ 1], bt.stride, bt.d_len, bt.d_len2, bt.d_flag, dstCap);
+  KZ_HIP(hipGetLastError());
+  bt.cur ^= 1;
+  { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }
+  return 0;
+}

@@ -79,12 +79,15 @@ __global__ __launch_bounds__(256) void k_sbrt_scan(const int32_t* __restrict__ d
   }
 }
 
+// mode 4 = SRT's move-to-front (K/transform/SRT.java:131-150): plain MTF whose initial list is the order
+// of first appearance, i.e. a never-seen symbol ranks after every seen one and never-seen symbols do not
+// count each other: key 0.
 __device__ __forceinline__ u64 kz_sbrt_key(int mode, int a1, int a2, int sym) {
-  if (a1 < 0) return (u64)(255 - sym);
+  if (a1 < 0) return (mode == 4) ? 0ULL : (u64)(255 - sym);
   const u32 pprev = a2 < 0 ? 0u : (u32)a2;          // p[] starts at 0 (SBRT.java:113-118)
   u32 q;
   if (mode == 2) q = ((u32)a1 + pprev) >> 1;         // RANK: (i + p[c]) >> 1
-  else if (mode == 1) q = (u32)a1;                   // MTF : i
+  else if (mode == 1 || mode == 4) q = (u32)a1;      // MTF : i
   else q = pprev;                                    // TIMESTAMP: p[c]
   return ((u64)q << 32) | (u64)((u32)a1 + 256u);
 }
@@ -95,7 +98,7 @@ __device__ __forceinline__ u64 kz_sbrt_key(int mode, int a1, int a2, int sym) {
                 __popcll(kz_ballot(k2 > kc)) + __popcll(kz_ballot(k3 > kc)));   \
     const u32 lo = (u32)kc;                                                     \
     const u32 pc = (lo >= 256u) ? lo - 256u : 0u;                               \
-    const u32 qc = (mode == 2) ? (((u32)i + pc) >> 1) : ((mode == 1) ? (u32)i : pc); \
+    const u32 qc = (mode == 2) ? (((u32)i + pc) >> 1) : ((mode == 1 || mode == 4) ? (u32)i : pc); \
     const u64 nk = ((u64)qc << 32) | (u64)((u32)i + 256u);                      \
     if (lane == (c & 63)) k##CASE_Q = nk; }
 
@@ -269,6 +272,20 @@ int kz_stage_sbrt_forward(kz_ctx* ctx, kz_batch& bt, int mode) {
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
   { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }
+  return 0;
+}
+
+// ranks only (no length/flag bookkeeping): used by the SRT stage (mode 4)
+int kz_sbrt_ranks(kz_ctx* ctx, const uint8_t* src, uint8_t* dst, int64_t stride, const int32_t* d_len, int B, int maxN, int mode) {
+  const int T = (maxN + SB_TS - 1) / SB_TS + 1;
+  int2* tab = (int2*)kz_arena_alloc(ctx, (size_t)B * T * 256 * sizeof(int2));
+  if (!tab) { snprintf(ctx->err, sizeof(ctx->err), "sbrt_ranks: arena overflow"); return -KZ_ERR_DEVICE; }
+  if (maxN > 0) {
+    KZ_LAUNCH(ctx, KID_SBRT_LAST2, k_sbrt_last2, dim3(T, B), dim3(64), src, stride, d_len, tab, T);
+    KZ_LAUNCH(ctx, KID_SBRT_SCAN, k_sbrt_scan, dim3(B), dim3(256), d_len, tab, T);
+    KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay, dim3(T, B), dim3(64), src, dst, stride, d_len, tab, T, mode);
+  }
+  KZ_HIP(hipGetLastError());
   return 0;
 }
 

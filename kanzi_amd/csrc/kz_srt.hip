@@ -1,0 +1,303 @@
+// kz_srt.hip -- Sorted Rank Transform (level-6 chain) on gfx950.
+//
+// Replaces K/transform/SRT.java:66-168 (forward), :171-257 (inverse), :259-302 (preprocess: symbols by
+// (frequency desc, symbol asc) -- a total order, so any sort gives the reference's shell-sort result),
+// :304-346 (header = 256 LEB128-style frequencies).
+//
+// forward = three data-parallel pieces: (1) byte histogram; (2) move-to-front ranks -- SRT's list starts
+//   as the order of first appearance, so rank(c) = #symbols whose last occurrence is later than c's
+//   (never seen: number of symbols seen so far); zero inside a run falls out naturally.  This is the
+//   SBRT tile machinery with key 0 for never-seen symbols (kz_sbrt.hip mode 4);  (3) a STABLE scatter of
+//   the ranks into per-symbol buckets laid out in (freq desc, symbol asc) order: LDS tile histograms,
+//   per-symbol scan over tiles, ballot match-any ranking.
+// inverse: the list is ordered by NEXT occurrence and every step needs the next rank of the symbol just
+//   emitted (a dependent load), so it is serial per block: one wave per block, list in one VGPR,
+//   64-byte windows of the current symbol's bucket fetched per event, zero ranks (runs) consumed in O(1).
+#include "kz_device.h"
+#include "kz_internal.h"
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+#define SR_ITEMS 16
+#define SR_TILE (KZ_WG * SR_ITEMS)
+
+struct SrtFwd {
+  u32* tileHist;    // [B][T][256]
+  u32* bucket;      // [B][256] bucket start (in output order) per symbol
+  int32_t* hdrLen;  // [B]
+  u8* ranks;        // [B][stride] MTF ranks
+  int T;
+};
+
+__global__ __launch_bounds__(KZ_WG) void k_srt_hist(const u8* __restrict__ src, int64_t stride, const int32_t* __restrict__ d_len, SrtFwd S) {
+  const int b = blockIdx.y, tile = blockIdx.x;
+  const int n = d_len[b];
+  if ((int64_t)tile * SR_TILE >= n) return;
+  __shared__ u32 hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const u8* s = src + (int64_t)b * stride;
+  const int base = tile * SR_TILE;
+#pragma unroll 4
+  for (int r = 0; r < SR_ITEMS; r++) {
+    const int idx = base + r * KZ_WG + threadIdx.x;
+    const bool valid = idx < n;
+    const u32 d = valid ? s[idx] : 0;
+    const uint64_t peers = kz_match8(d, valid);
+    if (valid && (peers & kz_lanemask_lt()) == 0) atomicAdd(&hist[d], (u32)__popcll(peers));
+  }
+  __syncthreads();
+  S.tileHist[((int64_t)b * S.T + tile) * 256 + threadIdx.x] = hist[threadIdx.x];
+}
+
+// per block: per-symbol tile offsets, frequencies, bucket order, header (thread = symbol)
+__global__ __launch_bounds__(256) void k_srt_prep(const int32_t* __restrict__ d_len, SrtFwd S, u8* __restrict__ dst, int64_t stride) {
+  const int b = blockIdx.x;
+  const int n = d_len[b];
+  if (n <= 0) { if (threadIdx.x == 0) S.hdrLen[b] = 0; return; }
+  const int tiles = (n + SR_TILE - 1) / SR_TILE;
+  __shared__ u32 freq[256];
+  __shared__ u32 start[256];
+  __shared__ u8 order[256];
+  u32* h = S.tileHist + (int64_t)b * S.T * 256;
+  const int sym = threadIdx.x;
+  u32 run = 0;
+  for (int t = 0; t < tiles; t++) { const u32 v = h[(int64_t)t * 256 + sym]; h[(int64_t)t * 256 + sym] = run; run += v; }
+  freq[sym] = run;
+  __syncthreads();
+  // position in (freq desc, symbol asc) order (SRT.java:259-302)
+  u32 pos = 0;
+  for (int t = 0; t < 256; t++) { const u32 ft = freq[t]; if (ft > run || (ft == run && t < sym)) pos++; }
+  order[pos] = (u8)sym;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 acc = 0;
+    for (int i = 0; i < 256; i++) { const int c = order[i]; start[c] = acc; acc += freq[c]; }
+    // header (SRT.java:304-319)
+    u8* d = dst + (int64_t)b * stride;
+    int hl = 0;
+    for (int i = 0; i < 256; i++) { u32 f = freq[i]; while (f >= 128) { d[hl++] = (u8)(0x80 | f); f >>= 7; } d[hl++] = (u8)f; }
+    S.hdrLen[b] = hl;
+  }
+  __syncthreads();
+  S.bucket[b * 256 + sym] = start[sym];
+}
+
+// stable scatter of rank bytes into the symbol buckets
+__global__ __launch_bounds__(KZ_WG) void k_srt_scatter(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                                                        const int32_t* __restrict__ d_len, SrtFwd S) {
+  const int b = blockIdx.y, tile = blockIdx.x;
+  const int n = d_len[b];
+  if ((int64_t)tile * SR_TILE >= n) return;
+  __shared__ u32 cnt[4][256];
+  for (int i = threadIdx.x; i < 1024; i += KZ_WG) (&cnt[0][0])[i] = 0;
+  __syncthreads();
+  const u8* s = src + (int64_t)b * stride;
+  const u8* rk = S.ranks + (int64_t)b * stride;
+  u8* d = dst + (int64_t)b * stride + S.hdrLen[b];
+  const int wave = threadIdx.x >> 6, lane = kz_lane();
+  const int base = tile * SR_TILE + wave * (64 * SR_ITEMS);
+  const uint64_t lt = kz_lanemask_lt();
+  u32 dr[SR_ITEMS];
+#pragma unroll
+  for (int r = 0; r < SR_ITEMS; r++) {
+    const int idx = base + r * 64 + lane;
+    const bool valid = idx < n;
+    const u32 c = valid ? s[idx] : 0;
+    const uint64_t peers = kz_match8(c, valid);
+    u32 pre = 0;
+    if (valid) pre = cnt[wave][c];
+    const u32 rnk = pre + (u32)__popcll(peers & lt);
+    if (valid && (peers >> lane) == 1ULL) cnt[wave][c] = pre + (u32)__popcll(peers);
+    dr[r] = c | (rnk << 8);
+  }
+  __syncthreads();
+  {
+    const int c = threadIdx.x;
+    u32 runv = S.bucket[b * 256 + c] + S.tileHist[((int64_t)b * S.T + tile) * 256 + c];
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const u32 t = cnt[w][c]; cnt[w][c] = runv; runv += t; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < SR_ITEMS; r++) {
+    const int i = base + r * 64 + lane;
+    if (i < n) d[cnt[wave][dr[r] & 0xFF] + (dr[r] >> 8)] = rk[i];
+  }
+}
+
+__global__ void k_srt_ffin(const int32_t* __restrict__ d_len, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag, SrtFwd S, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int n = d_len[b];
+  d_len2[b] = (n > 0) ? n + S.hdrLen[b] : 0;
+  d_flag[b] = 1;
+}
+
+// =================================================================================================
+// inverse: one wave per block
+#define KZ_DPP_SHL1(x) ((u32)__builtin_amdgcn_update_dpp(0, (int)(x), 0x130 /*wave_shl:1*/, 0xF, 0xF, false))
+
+__global__ __launch_bounds__(64) void k_srt_inv(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                                                 const int32_t* __restrict__ d_len, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag) {
+  const int b = blockIdx.x;
+  const int length = d_len[b];
+  const int lane = kz_lane();
+  const u8* in = src + (int64_t)b * stride;
+  u8* o = dst + (int64_t)b * stride;
+  if (length <= 0) { if (lane == 0) { d_len2[b] = 0; d_flag[b] = 1; } return; }
+  __shared__ u32 freq[256];
+  __shared__ u32 bstart[256];
+  __shared__ u32 bend[256];
+  __shared__ u8 order[256];
+  __shared__ u8 r2s0[256];
+  __shared__ int sh_h, sh_bad;
+  // ---- header (SRT.java:321-346) ----
+  if (lane == 0) {
+    int h = 0, bad = 0;
+    for (int i = 0; i < 256 && !bad; i++) {
+      if (h >= length) { bad = 1; break; }
+      int val = in[h++];
+      int res = val & 0x7F, shift = 7;
+      while (val >= 128) {
+        if (h >= length) { bad = 1; break; }
+        val = in[h++];
+        res |= ((val & 0x7F) << shift);
+        if (shift > 21) break;
+        shift += 7;
+      }
+      freq[i] = (u32)res;
+    }
+    sh_h = h; sh_bad = bad;
+  }
+  for (int i = lane; i < 256; i += 64) r2s0[i] = 0;
+  __syncthreads();
+  const int H = sh_h;
+  const int count = length - H;
+  if (sh_bad || count < 0) { if (lane == 0) { d_len2[b] = 0; d_flag[b] = 0; } return; }
+  const u8* s = in + H;
+  // ---- bucket order (freq desc, symbol asc), bucket ranges ----
+  int nbSymbols = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int sym = q * 64 + lane;
+    const u32 f = freq[sym];
+    u32 pos = 0;
+    for (int t = 0; t < 256; t++) { const u32 ft = freq[t]; if (ft > f || (ft == f && t < sym)) pos++; }
+    order[pos] = (u8)sym;
+    nbSymbols += (int)__popcll(kz_ballot(f > 0));
+  }
+  __syncthreads();
+  int bad = 0;
+  {
+    u32 acc = 0;
+    for (int i = 0; i < nbSymbols; i++) {                           // :204-215 (uniform across lanes)
+      const int c = order[i];
+      if ((int)acc >= count) { bad = 1; break; }
+      const int first = s[acc];
+      if (lane == 0) { r2s0[first] = (u8)c; bstart[c] = acc + 1; }
+      acc += freq[c];
+      if (lane == 0) bend[c] = acc;
+    }
+    if ((int)acc != count) bad = 1;                                  // frequencies must cover the payload
+  }
+  __syncthreads();
+  if (bad) { if (lane == 0) { d_len2[b] = 0; d_flag[b] = 0; } return; }
+  // list: position j -> lane j>>2, byte j&3
+  u32 list = (u32)r2s0[4 * lane] | ((u32)r2s0[4 * lane + 1] << 8) | ((u32)r2s0[4 * lane + 2] << 16) | ((u32)r2s0[4 * lane + 3] << 24);
+  int i = 0;
+  int c = (int)(__builtin_amdgcn_readfirstlane((int)list) & 0xFF);
+  while (i < count) {
+    const u32 cur = bstart[c], end = bend[c];
+    __syncthreads();
+    const int vc = (int)min(64u, end - cur);                          // ranks of c still available in this window
+    const u32 v = (lane < vc) ? (u32)s[cur + lane] : 0u;
+    const uint64_t nz = kz_ballot(v != 0 && lane < vc);
+    const int z = nz ? (int)__builtin_ctzll(nz) : vc;                 // leading zero ranks = c repeats
+    int r = 0;
+    int emit, consumed;
+    bool moveC = false, removeC = false;
+    if (nz) { emit = z + 1; consumed = z + 1; r = __builtin_amdgcn_readlane((int)v, z); moveC = true; }
+    else if (cur + (u32)vc == end) { emit = vc + 1; consumed = vc; removeC = true; }      // bucket exhausted (:239-248)
+    else { emit = vc; consumed = vc; }                                 // 64 zeros, more to come
+    if (emit > count - i) { emit = count - i; moveC = false; removeC = false; }
+    if (lane < emit) o[i + lane] = (u8)c;
+    if (emit > 64 && lane == 0) o[i + 64] = (u8)c;
+    i += emit;
+    if (lane == 0) bstart[c] = cur + (u32)consumed;
+    if (moveC) {
+      // positions 0..r-1 <- 1..r ; position r <- c   (SRT.java:233-237)
+      const u32 nxt = KZ_DPP_SHL1(list);
+      const u32 shifted = (list >> 8) | (nxt << 24);
+      const int jb = 4 * lane;
+      const int e = r - jb;                                            // bytes with position < r in this lane
+      const u32 mask = (e <= 0) ? 0u : ((e >= 4) ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (8 * (4 - e))));
+      u32 nl = (shifted & mask) | (list & ~mask);
+      if (lane == (r >> 2)) { const int sh = 8 * (r & 3); nl = (nl & ~(0xFFu << sh)) | ((u32)c << sh); }
+      list = nl;
+      c = (int)(__builtin_amdgcn_readfirstlane((int)list) & 0xFF);
+    } else if (removeC) {
+      if (nbSymbols > 1) {                                             // :242-248
+        nbSymbols--;
+        const u32 nxt = KZ_DPP_SHL1(list);
+        list = (list >> 8) | (nxt << 24);
+        c = (int)(__builtin_amdgcn_readfirstlane((int)list) & 0xFF);
+      } else {
+        // single symbol left: it repeats to the end (:239-240)
+        for (int k = i + lane; k < count; k += 64) o[k] = (u8)c;
+        i = count;
+      }
+    }
+    __syncthreads();
+  }
+  if (lane == 0) { d_len2[b] = count; d_flag[b] = 1; }
+}
+
+size_t kz_srt_scratch(int B, int maxN) {
+  const int T = (maxN + SR_TILE - 1) / SR_TILE + 1;
+  const int64_t stride = (int64_t)kz_align((size_t)maxN + 4096 + 1024, 256);
+  return (size_t)B * ((size_t)T * 1024 + 1024 + 64 + (size_t)stride) + kz_sbrt_scratch(B, maxN) + 16384;
+}
+
+int kz_stage_srt_forward(kz_ctx* ctx, kz_batch& bt) {
+  const int B = bt.B;
+  int maxN = 0;
+  for (int b = 0; b < B; b++) if (bt.h_len[b] > maxN) maxN = bt.h_len[b];
+  SrtFwd S;
+  S.T = (maxN + SR_TILE - 1) / SR_TILE + 1;
+  S.tileHist = (u32*)kz_arena_alloc(ctx, (size_t)B * S.T * 1024);
+  S.bucket = (u32*)kz_arena_alloc(ctx, (size_t)B * 1024);
+  S.hdrLen = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  S.ranks = (u8*)kz_arena_alloc(ctx, (size_t)bt.stride * B);
+  if (!S.ranks || !S.hdrLen) { snprintf(ctx->err, sizeof(ctx->err), "srt_forward: arena overflow"); return -KZ_ERR_DEVICE; }
+  const u8* src = bt.buf[bt.cur];
+  u8* dst = bt.buf[bt.cur ^ 1];
+  const int tiles = (maxN + SR_TILE - 1) / SR_TILE;
+  if (tiles > 0) {
+    KZ_LAUNCH(ctx, KID_SRT_HIST, k_srt_hist, dim3(tiles, B), dim3(KZ_WG), src, bt.stride, bt.d_len, S);
+    KZ_LAUNCH(ctx, KID_SRT_PREP, k_srt_prep, dim3(B), dim3(256), bt.d_len, S, dst, bt.stride);
+    int rc = kz_sbrt_ranks(ctx, src, S.ranks, bt.stride, bt.d_len, B, maxN, 4);
+    if (rc) return rc;
+    KZ_LAUNCH(ctx, KID_SRT_SCATTER, k_srt_scatter, dim3(tiles, B), dim3(KZ_WG), src, dst, bt.stride, bt.d_len, S);
+  } else {
+    KZ_HIP(hipMemsetAsync(S.hdrLen, 0, (size_t)B * 4, ctx->stream));
+  }
+  KZ_LAUNCH(ctx, KID_COPY_LEN, k_srt_ffin, dim3((B + 255) / 256), dim3(256), bt.d_len, bt.d_len2, bt.d_flag, S, B);
+  KZ_HIP(hipGetLastError());
+  bt.cur ^= 1;
+  { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }
+  return 0;
+}
+
+int kz_stage_srt_inverse(kz_ctx* ctx, kz_batch& bt) {
+  const int B = bt.B;
+  const u8* src = bt.buf[bt.cur];
+  u8* dst = bt.buf[bt.cur ^ 1];
+  KZ_LAUNCH(ctx, KID_SRT_INV, k_srt_inv, dim3(B), dim3(64), src, dst, bt.stride, bt.d_len, bt.d_len2, bt.d_flag);
+  KZ_HIP(hipGetLastError());
+  bt.cur ^= 1;
+  { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }
+  return 0;
+}

@@ -44,10 +44,11 @@ def _all_inputs():
     return ins
 
 
-TIDS = {"BWT": kz.BWT_TYPE, "RANK": kz.RANK_TYPE, "MTFT": kz.MTFT_TYPE, "ZRLT": kz.ZRLT_TYPE}
+TIDS = {"BWT": kz.BWT_TYPE, "RANK": kz.RANK_TYPE, "MTFT": kz.MTFT_TYPE, "ZRLT": kz.ZRLT_TYPE,
+        "SRT": kz.SRT_TYPE, "LZ": kz.LZ_TYPE, "LZX": kz.LZX_TYPE}
 
 
-@pytest.mark.parametrize("name", ["BWT", "RANK", "MTFT", "ZRLT"])
+@pytest.mark.parametrize("name", ["BWT", "RANK", "MTFT", "ZRLT", "SRT", "LZ", "LZX"])
 def test_transform_forward_and_inverse_match_oracle(ctx, name):
     for data in _all_inputs():
         ok_o, enc_o = oracle.transform_forward(name, data)
@@ -88,9 +89,10 @@ def _huffman_limit_input():
     return bytes(np.random.default_rng(0).permutation(np.frombuffer(d, dtype=np.uint8)))
 
 
-@pytest.mark.parametrize("ent", ["ANS0", "HUFFMAN"])
+@pytest.mark.parametrize("ent", ["ANS0", "HUFFMAN", "FPAQ"])
 def test_entropy_encode_decode_match_oracle(ctx, ent):
-    Enc, Dec = (kz.ANSRangeEncoder, kz.ANSRangeDecoder) if ent == "ANS0" else (kz.HuffmanEncoder, kz.HuffmanDecoder)
+    Enc, Dec = {"ANS0": (kz.ANSRangeEncoder, kz.ANSRangeDecoder), "HUFFMAN": (kz.HuffmanEncoder, kz.HuffmanDecoder),
+                "FPAQ": (kz.FPAQEncoder, kz.FPAQDecoder)}[ent]
     for data in _all_inputs() + [_huffman_limit_input(), _huffman_limit_input()[:5000] + bytes(range(256)) * 4]:
         if len(data) == 0:
             continue
@@ -107,7 +109,8 @@ def test_entropy_encode_decode_match_oracle(ctx, ent):
 
 @pytest.mark.parametrize("chain,ent", [("BWT+RANK+ZRLT", "ANS0"), ("BWT+MTFT+ZRLT", "ANS0"), ("ZRLT", "NONE"),
                                         ("BWT", "ANS0"), ("RANK+ZRLT", "ANS0"), ("NONE", "ANS0"),
-                                        ("BWT+RANK+ZRLT", "HUFFMAN"), ("NONE", "HUFFMAN")])
+                                        ("BWT+RANK+ZRLT", "HUFFMAN"), ("NONE", "HUFFMAN"),
+                                        ("BWT+SRT+ZRLT", "FPAQ"), ("LZ", "HUFFMAN"), ("LZ", "ANS0"), ("LZX", "NONE")])
 def test_block_streams_match_oracle(ctx, chain, ent):
     """kz_encode_blocks output == oracle encode_block (header, skip flags, raw fallback, copy blocks)."""
     bs = 40000
