@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--chain", default="BWT+RANK+ZRLT")
     ap.add_argument("--entropy", default="ANS0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"),
+                    help="per-kernel HBM bytes from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)")
     ap.add_argument("--cpu-sample-blocks", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     args = ap.parse_args()
 
@@ -167,8 +169,16 @@ def main():
         launches = max(dom["launches_per_step"], 1.0)
         avg_ms = dom["ms_per_step"] / launches
         achieved = (alg / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        try:
+            with open(args.traffic_json) as f:
+                tj = json.load(f)
+            if tj.get("blocks_per_gpu_per_step") == B and dom["kernel"] in tj["kernels"]:
+                traffic = tj["kernels"][dom["kernel"]]["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "kernel": dom["kernel"], "stage": st, "launches_per_step": launches, "avg_launch_ms": avg_ms,
                     "alg_bytes_per_launch": alg / launches,
                     "stage_achieved_GBs": (alg / (stage_ms[st] * 1e-3) / 1e9) if stage_ms.get(st) else None,

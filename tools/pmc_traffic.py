@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc counter_collection CSVs (one pass per counter) into per-kernel HBM traffic.
+Usage: tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <blocks> > profiles/rNN_pmc_traffic.json
+Units/corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KiB
+(hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024); on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide
+coalesced streaming read (TCC_EA0_RDREQ x 64 B with 128-B requests) -> doubled here; other access widths and
+WRITE_SIZE are uncalibrated (reported as measured)."""
+import csv
+import json
+import re
+import sys
+
+
+def agg(path, counter):
+    out = {}
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            name = re.sub(r"\(.*", "", row["Kernel_Name"]).strip()
+            d = out.setdefault(name, {"launches": 0, "sum": 0.0})
+            d["launches"] += 1
+            d["sum"] += float(row["Counter_Value"])
+    return out
+
+
+def main():
+    fetch = agg(sys.argv[1], "FETCH_SIZE")
+    write = agg(sys.argv[2], "WRITE_SIZE")
+    blocks = int(sys.argv[3])
+    res = {"blocks_per_gpu_per_step": blocks, "steps_profiled": 1,
+           "note": "FETCH_SIZE doubled (gfx950 correction), KiB -> bytes; WRITE_SIZE as measured", "kernels": {}}
+    for k in sorted(set(fetch) | set(write)):
+        if not k.startswith("k_"):
+            continue
+        f = fetch.get(k, {"launches": 0, "sum": 0.0})
+        w = write.get(k, {"launches": 0, "sum": 0.0})
+        n = max(f["launches"], w["launches"], 1)
+        res["kernels"][k] = {"launches": n,
+                             "fetch_bytes_per_launch": 2.0 * f["sum"] * 1024.0 / n,
+                             "write_bytes_per_launch": w["sum"] * 1024.0 / n,
+                             "hbm_bytes_per_launch": (2.0 * f["sum"] + w["sum"]) * 1024.0 / n}
+    json.dump(res, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
