@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=1024, help="4 MiB blocks per GPU per step (one wave per block in the serial kernels: throughput comes from blocks in flight)")
+    ap.add_argument("--blocks", type=int, default=2048, help="4 MiB blocks per GPU per step (one wave per block in the serial kernels: throughput comes from blocks in flight)")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic blocks generated per GPU; the step's blocks tile them (blocks are coded independently)")
     ap.add_argument("--block-size", type=int, default=4 * 1024 * 1024)
     ap.add_argument("--chain", default="BWT+RANK+ZRLT")

@@ -150,27 +150,36 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
 // State: the rank->symbol list kept sorted by position: position j lives in register j>>6, lane j&63
 // as ONE 64-bit value  key' = (q << 40) | ((p + 256) << 8) | symbol  (never seen: ((255-s) << 8) | s).
 // (q,p) is unique per symbol so the extra low byte never changes the order, and symbol + key move
-// together: a step costs two readlanes, one v_cmp_gt_u64 ballot per register up to r>>6 (new position
-// = number of keys above the new key) and one DPP wave_shr:1 per touched register half.  Zero ranks
-// never move the list: runs of zeros are skipped in O(1) with a ballot of the non-zero lanes of each
-// 64-byte row (after BWT most ranks are zero).  Valid for n < 2^24 - 256.
+// together.  Zero ranks never move the list: runs of zeros are skipped in O(1) with a ballot of the
+// non-zero lanes of each 64-byte row (after BWT most ranks are zero).  Valid for n < 2^24 - 256.
+//
+// Cost model (tools/ubench_lonewave.hip, one wave per CU): a dependent VALU op costs 4 cycles, but every
+// VALU->SALU hand-off (v_readlane / v_cmp result consumed by s_* ops) costs ~30 and every scalar branch
+// ~40.  The step is therefore written to STAY ON THE VALU: wave-uniform quantities (symbol, new key, new
+// position) are kept in VGPRs (forced with v_mov / v_bcnt inline asm so the compiler does not scalarise
+// them), selections are v_cndmask instead of branches, and the only branch per non-zero rank is r < 64.
 #define KZ_DPP_SHR1(x) ((u32)__builtin_amdgcn_update_dpp(0, (int)(x), 0x138 /*wave_shr:1*/, 0xF, 0xF, false))
 #define KZ_K64(k) (((u64)hi##k << 32) | (u64)lo##k)
 
-// shift register k (positions 64k..64k+63) for a move of position r up to rp; K1 = k-1 (carry source)
-#define KZ_SBRT_SHIFT(k, K1, HAS_PREV)                                                     \
-  if ((k) <= R && (k) >= RP) {                                                             \
-    u32 slo = KZ_DPP_SHR1(lo##k), shi = KZ_DPP_SHR1(hi##k);                                \
-    if (HAS_PREV && (k) > RP) {                                                            \
-      const u32 clo = (u32)__builtin_amdgcn_readlane((int)lo##K1, 63);                     \
-      const u32 chi = (u32)__builtin_amdgcn_readlane((int)hi##K1, 63);                     \
-      if (lane == 0) { slo = clo; shi = chi; }                                             \
-    }                                                                                      \
-    const int pos = 64 * (k) + lane;                                                       \
-    const bool in = (pos > rp) && (pos <= r);                                              \
-    lo##k = in ? slo : lo##k; hi##k = in ? shi : hi##k;                                    \
-    if (pos == rp) { lo##k = nlo; hi##k = nhi; }                                           \
-  }
+// NOTE gfx940+ hazard: 2 wait states between a VALU writing an SGPR/VCC (v_readlane, v_cmp) and a VALU
+// reading it; the compiler's hazard recognizer does not look inside inline asm, hence the s_nop 1.
+__device__ __forceinline__ u32 kz_v_from_s(u32 s) { u32 v; asm volatile("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
+// acc + popcount(mask) computed on the VALU (mask is a ballot in an SGPR pair)
+__device__ __forceinline__ u32 kz_v_bcnt64(uint64_t m, u32 acc) {
+  const u32 mlo = (u32)m, mhi = (u32)(m >> 32);
+  u32 r;
+  asm volatile("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %2\n\tv_bcnt_u32_b32 %0, %3, %0" : "=&v"(r) : "s"(mlo), "v"(acc), "s"(mhi));
+  return r;
+}
+
+// One list slot (position 4*lane + S): positions (rp, r] take their predecessor, position rp the new entry.
+// rel = pos - (rp+1) ; span = r - rp  (unsigned: in range iff rel < span; pos == rp iff rel == ~0)
+#define KZ_SBRT_SLOT(S, SRC_LO, SRC_HI)                                                   \
+  { const u32 rel = relBase + (u32)(S);                                                    \
+    const bool in = rel < span;                                                            \
+    const bool at = rel == 0xFFFFFFFFu;                /* pos == rp */                     \
+    u32 tl = in ? (SRC_LO) : l##S, th = in ? (SRC_HI) : h##S;                              \
+    l##S = at ? nlo : tl; h##S = at ? nhi : th; }
 
 __global__ __launch_bounds__(64) void k_sbrt_inverse(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
                                                       const int32_t* __restrict__ d_len, int mode) {
@@ -179,63 +188,70 @@ __global__ __launch_bounds__(64) void k_sbrt_inverse(const u8* __restrict__ src,
   const u8* s = src + (int64_t)b * stride;
   u8* d = dst + (int64_t)b * stride;
   const int lane = kz_lane();
-  // r2s[j] = j, all symbols never seen
-  u32 lo0 = ((u32)(255 - lane) << 8) | (u32)lane, lo1 = ((u32)(191 - lane) << 8) | (u32)(64 + lane);
-  u32 lo2 = ((u32)(127 - lane) << 8) | (u32)(128 + lane), lo3 = ((u32)(63 - lane) << 8) | (u32)(192 + lane);
-  u32 hi0 = 0, hi1 = 0, hi2 = 0, hi3 = 0;
-  u32 flo = (255u << 8) | 0u, fhi = 0;      // authoritative copy of position 0 (synced into lane 0 on demand)
+  // list position j = 4*lane + slot ; r2s[j] = j, all symbols never seen: lo = ((255-j) << 8) | j, hi = 0
+  const u32 p0 = 4u * (u32)lane;
+  u32 l0 = ((255u - p0) << 8) | p0, l1 = ((254u - p0) << 8) | (p0 + 1u), l2 = ((253u - p0) << 8) | (p0 + 2u), l3 = ((252u - p0) << 8) | (p0 + 3u);
+  u32 h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+  // authoritative copy of position 0 (lane 0, slot 0): uniform, kept in VGPRs, synced before each use
+  u32 flo = kz_v_from_s((255u << 8) | 0u), fhi = kz_v_from_s(0u);
+  const bool mRank = (mode == 2), mMtf = (mode == 1);
   u32 cur = (lane < n) ? (u32)s[lane] : 0u;
   for (int row = 0; row < n; row += 64) {
     const int cnt = min(64, n - row);
     const int nrow = row + 64;
     const u32 nxt = (nrow + lane < n) ? (u32)s[nrow + lane] : 0u;  // prefetch the next row
     uint64_t nz = kz_ballot(cur != 0 && lane < cnt);
+    const u32 curL = cur >> 2, curS = cur & 3u;                       // lane / slot of each rank, split on the VALU
     u32 outv = 0;
     int prev = -1;
     for (;;) {
       const int j = nz ? (int)__builtin_ctzll(nz) : cnt;
       const int zr = j - prev - 1;
-      if (zr > 0) {
-        // zero run [prev+1, j): the front symbol repeats; only its (q,p) change (SBRT.java:194-201)
+      {
+        // zero run [prev+1, j): the front symbol repeats; only its (q,p) change (SBRT.java:194-201).
+        // Evaluated unconditionally and selected (no branch).
         const u32 pk = flo >> 8;
-        const u32 pold = (pk >= 256u) ? pk - 256u : 0u;
+        const u32 pold = max(pk, 256u) - 256u;
         const u32 pl = (u32)(row + prev + zr);                     // last index of the run
         const u32 pp = (zr >= 2) ? pl - 1u : pold;
-        const u32 q = (mode == 2) ? ((pl + pp) >> 1) : ((mode == 1) ? pl : pp);
-        fhi = q << 8;
-        flo = ((pl + 256u) << 8) | (flo & 0xFFu);
-        if (lane > prev && lane < j) outv = flo & 0xFFu;
+        const u32 q = mRank ? ((pl + pp) >> 1) : (mMtf ? pl : pp);
+        const bool has = zr > 0;
+        fhi = has ? (q << 8) : fhi;
+        flo = has ? (((pl + 256u) << 8) | (flo & 0xFFu)) : flo;
+        outv = (has && lane > prev && lane < j) ? (flo & 0xFFu) : outv;
       }
       if (j >= cnt) break;
       nz &= nz - 1;
-      const int r = __builtin_amdgcn_readlane((int)cur, j);
-      const int i = row + j;
-      if (lane == 0) { lo0 = flo; hi0 = fhi; }                     // sync the cached front entry
-      const int R = r >> 6, rl = r & 63;
-      u32 clo;
-      if (R == 0) clo = (u32)__builtin_amdgcn_readlane((int)lo0, rl);
-      else if (R == 1) clo = (u32)__builtin_amdgcn_readlane((int)lo1, rl);
-      else if (R == 2) clo = (u32)__builtin_amdgcn_readlane((int)lo2, rl);
-      else clo = (u32)__builtin_amdgcn_readlane((int)lo3, rl);
+      const int L = __builtin_amdgcn_readlane((int)curL, j);       // SGPRs used only as lane selects / v_mov sources
+      const u32 vsel = kz_v_from_s((u32)__builtin_amdgcn_readlane((int)curS, j));
+      const u32 vr = (kz_v_from_s((u32)L) << 2) | vsel;
+      const u32 iv = (u32)(row + j);
+      l0 = (lane == 0) ? flo : l0; h0 = (lane == 0) ? fhi : h0;    // sync the cached front entry
+      // entry at position r = slot vsel of lane L: every lane picks its own slot vsel, then ONE readlane
+      u32 cand = (vsel == 1u) ? l1 : l0;
+      cand = (vsel == 2u) ? l2 : cand;
+      cand = (vsel == 3u) ? l3 : cand;
+      const u32 clo = kz_v_from_s((u32)__builtin_amdgcn_readlane((int)cand, L));
       const u32 c = clo & 0xFFu;
-      const u32 pk = clo >> 8;
-      const u32 pc = (pk >= 256u) ? pk - 256u : 0u;
-      const u32 qc = (mode == 2) ? (((u32)i + pc) >> 1) : ((mode == 1) ? (u32)i : pc);
-      const u32 nlo = (((u32)i + 256u) << 8) | c, nhi = qc << 8;
+      const u32 pc = max(clo >> 8, 256u) - 256u;
+      const u32 qc = mRank ? ((iv + pc) >> 1) : (mMtf ? iv : pc);
+      const u32 nlo = ((iv + 256u) << 8) | c, nhi = qc << 8;
       const u64 nk = ((u64)nhi << 32) | (u64)nlo;
       // new position = number of entries above the new key (entries below r are smaller than the old key)
-      int rp = (int)__popcll(kz_ballot(KZ_K64(0) > nk));
-      if (R >= 1) rp += (int)__popcll(kz_ballot(KZ_K64(1) > nk));
-      if (R >= 2) rp += (int)__popcll(kz_ballot(KZ_K64(2) > nk));
-      if (R >= 3) rp += (int)__popcll(kz_ballot(KZ_K64(3) > nk));
-      const int RP = rp >> 6;
-      // descending order: register k reads its carry from the still unmodified register k-1
-      KZ_SBRT_SHIFT(3, 2, true)
-      KZ_SBRT_SHIFT(2, 1, true)
-      KZ_SBRT_SHIFT(1, 0, true)
-      KZ_SBRT_SHIFT(0, 0, false)
-      if (rp == 0) { flo = nlo; fhi = nhi; }                       // else position 0 is untouched
-      if (lane == j) outv = c;
+      u32 vrp = kz_v_bcnt64(kz_ballot((((u64)h0 << 32) | l0) > nk), 0u);
+      vrp = kz_v_bcnt64(kz_ballot((((u64)h1 << 32) | l1) > nk), vrp);
+      vrp = kz_v_bcnt64(kz_ballot((((u64)h2 << 32) | l2) > nk), vrp);
+      vrp = kz_v_bcnt64(kz_ballot((((u64)h3 << 32) | l3) > nk), vrp);
+      const u32 relBase = p0 - (vrp + 1u);
+      const u32 span = vr - vrp;                                     // r >= rp always
+      const u32 pl3 = KZ_DPP_SHR1(l3), ph3 = KZ_DPP_SHR1(h3);        // slot 0 of lane l takes slot 3 of lane l-1
+      // descending slots: each reads the still unmodified lower slot
+      KZ_SBRT_SLOT(3, l2, h2)
+      KZ_SBRT_SLOT(2, l1, h1)
+      KZ_SBRT_SLOT(1, l0, h0)
+      KZ_SBRT_SLOT(0, pl3, ph3)
+      fhi = (vrp == 0u) ? nhi : fhi; flo = (vrp == 0u) ? nlo : flo;
+      outv = (lane == j) ? c : outv;
       prev = j;
     }
     if (lane < cnt) d[row + lane] = (u8)outv;
