@@ -64,6 +64,10 @@ int32_t     kz_abi_version(void);
 kz_ctx*     kz_ctx_create(int32_t deviceId);          /* NULL if no HIP device / out of memory */
 void        kz_ctx_destroy(kz_ctx* ctx);
 const char* kz_last_error(kz_ctx* ctx);
+/* per-block checksum of the original data: bits = 0 (none), 32 (XXHash32) or 64 (XXHash64): the "checksum" key of
+ * the reference's context map (K/io/CompressedOutputStream.java:190-204, :749-755, :887-891). Applies to the
+ * following kz_encode_blocks / kz_decode_blocks / kz_compress calls (kz_decompress reads it from the stream). */
+int32_t     kz_ctx_set_checksum(kz_ctx* ctx, int32_t bits);
 /* HIP stream the context launches on (as void* = hipStream_t) so callers can bracket it with events */
 void*       kz_ctx_stream(kz_ctx* ctx);
 

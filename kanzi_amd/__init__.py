@@ -64,6 +64,7 @@ def load_library():
         "kz_ctx_destroy": (None, [vp]),
         "kz_last_error": (c.c_char_p, [vp]),
         "kz_ctx_stream": (vp, [vp]),
+        "kz_ctx_set_checksum": (c.c_int32, [vp, c.c_int32]),
         "kz_transform_forward": (c.c_int32, [vp, c.c_uint32, u8p, c.c_int32, u8p, c.c_int32, i32p]),
         "kz_transform_inverse": (c.c_int32, [vp, c.c_uint32, u8p, c.c_int32, u8p, c.c_int32, i32p]),
         "kz_transform_max_encoded_len": (c.c_int32, [c.c_uint32, c.c_int32]),
@@ -97,7 +98,7 @@ def load_library():
     return L
 
 
-ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_error", "kz_ctx_stream",
+ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_error", "kz_ctx_stream", "kz_ctx_set_checksum",
                "kz_transform_forward", "kz_transform_inverse", "kz_transform_max_encoded_len",
                "kz_entropy_encode", "kz_entropy_decode", "kz_encode_blocks", "kz_decode_blocks",
                "kz_max_block_stream_bytes", "kz_compress", "kz_decompress", "kz_transform_type",
@@ -153,6 +154,10 @@ class Context:
         if rc < 0:
             raise KanziError(-rc, self.error())
         return rc
+
+    def set_checksum(self, bits):
+        """0, 32 or 64: block checksum kind (the reference's -x32 / -x64)."""
+        self.check(self.lib.kz_ctx_set_checksum(self.h, int(bits)))
 
     @property
     def stream(self):
@@ -370,7 +375,7 @@ class CompressedOutputStream:
     """K/io/CompressedOutputStream.java: write() bytes, close() -> .knz bytes in self.output.
     ctx keys mirror the reference's Map (transform, entropy, blockSize)."""
 
-    def __init__(self, ctx, transform="BWT+RANK+ZRLT", entropy="ANS0", blockSize=4 * 1024 * 1024):
+    def __init__(self, ctx, transform="BWT+RANK+ZRLT", entropy="ANS0", blockSize=4 * 1024 * 1024, checksum=0):
         if blockSize > 1024 * 1024 * 1024:
             raise ValueError("The block size must be at most 1 GB")              # CompressedOutputStream.java:165-174
         if blockSize < 1024:
@@ -381,6 +386,7 @@ class CompressedOutputStream:
         self.tt = transform_type(transform)
         self.et = ENTROPY_IDS[entropy.upper()]
         self.blockSize = blockSize
+        self.checksum = checksum
         self._chunks = []
         self.closed = False
         self.output = None
@@ -399,7 +405,11 @@ class CompressedOutputStream:
         cap = n + n // 4 + 65536
         dst = np.empty(cap, dtype=np.uint8)
         sp = src.ctypes.data if n else dst.ctypes.data
-        rc = self.ctx.lib.kz_compress(self.ctx.h, self.tt, self.et, self.blockSize, sp, n, dst.ctypes.data, cap)
+        self.ctx.set_checksum(self.checksum)
+        try:
+            rc = self.ctx.lib.kz_compress(self.ctx.h, self.tt, self.et, self.blockSize, sp, n, dst.ctypes.data, cap)
+        finally:
+            self.ctx.set_checksum(0)
         self.ctx.check(rc)
         self.output = dst[:rc].tobytes()
 

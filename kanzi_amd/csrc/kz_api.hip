@@ -33,6 +33,11 @@ extern "C" void kz_ctx_destroy(kz_ctx* ctx) {
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
+extern "C" int32_t kz_ctx_set_checksum(kz_ctx* ctx, int32_t bits) {
+  if (!ctx || (bits != 0 && bits != 32 && bits != 64)) return -KZ_ERR_INVALID_PARAM;
+  ctx->checksum = bits == 32 ? 1 : (bits == 64 ? 2 : 0);
+  return 0;
+}
 extern "C" const char* kz_last_error(kz_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 extern "C" void* kz_ctx_stream(kz_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
@@ -182,6 +187,8 @@ struct FrameEnc {
   int32_t* isCopy;       // [B] small block (<= 15 bytes): raw copy block
   int32_t* fallback;     // [B]
   int64_t* bits;         // [B] entropy payload bits -> final W
+  u64* hash;             // [B] block checksum (XXHash32/64 of the original block)
+  int chk;               // 0 none, 1 = 32 bit, 2 = 64 bit
   int nbFunctions;
 };
 
@@ -192,7 +199,7 @@ __global__ void k_frame_prepare(FrameEnc F, int B) {
   const int postLen = F.postLen[b];
   const int dataSize = (postLen < 256) ? 1 : (kz_ilog2((u32)postLen) >> 3) + 1;
   const bool two = !F.isCopy[b] && F.nbFunctions > 4;
-  F.hdrBytes[b] = 1 + (two ? 1 : 0) + dataSize + 1;
+  F.hdrBytes[b] = 1 + (two ? 1 : 0) + dataSize + 1 + (F.chk == 1 ? 4 : (F.chk == 2 ? 8 : 0));
 }
 // after entropy: decide the raw "transformed copy" fallback (:926-973)
 __global__ void k_frame_decide(FrameEnc F, int B) {
@@ -234,7 +241,12 @@ __global__ void k_frame_header(FrameEnc F, u8* __restrict__ out, int64_t outStri
     written = 8LL * F.hdrBytes[b] + F.bits[b];
   }
   for (int k = dataSize - 1; k >= 0; k--) o[idx++] = (u8)((u32)postLen >> (8 * k));
-  o[idx] = kz_block_cksum(mode & 0xFF, hsf, (u32)postLen, (u64)written);
+  o[idx++] = kz_block_cksum(mode & 0xFF, hsf, (u32)postLen, (u64)written);
+  if (F.chk) {                                               // CompressedOutputStream.java:887-891
+    const int nby = (F.chk == 1) ? 4 : 8;
+    const u64 hv = F.hash[b];
+    for (int k = nby - 1; k >= 0; k--) o[idx++] = (u8)(hv >> (8 * k));
+  }
   res[b].bits = written; res[b].length = postLen; res[b].status = 0;
   res[b].skipFlags = (u8)skipFlags; res[b].mode = (u8)mode;
 }
@@ -409,8 +421,10 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   F.isCopy = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   F.fallback = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   F.bits = (int64_t*)kz_arena_alloc(ctx, (size_t)B * 8);
+  F.hash = (u64*)kz_arena_alloc(ctx, (size_t)B * 8);
+  F.chk = ctx->checksum;
   F.nbFunctions = nb;
-  if (!F.bits || !d_res || !d_out) { snprintf(ctx->err, sizeof(ctx->err), "encode: arena overflow"); return -KZ_ERR_DEVICE; }
+  if (!F.bits || !d_res || !d_out || !F.hash) { snprintf(ctx->err, sizeof(ctx->err), "encode: arena overflow"); return -KZ_ERR_DEVICE; }
 
   // ---- load blocks into HBM ----
   for (int b = 0; b < B; b++) {
@@ -421,6 +435,7 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   for (int b = 0; b < B; b++) bt.h_len[b] = lengths[b];
   KZ_HIP(hipMemcpyAsync(bt.d_len, lengths, (size_t)B * 4, hipMemcpyHostToDevice, st));
   KZ_HIP(hipMemsetAsync(d_out, 0, (size_t)outStride * B, st));       // bit-concat ORs into zeroed words
+  if (F.chk) { rc = kz_block_hashes(ctx, bt.buf[0], bt.stride, bt.d_len, B, F.chk, F.hash); if (rc) return rc; }
 
   // ---- transform chain (Sequence.forward, K/transform/Sequence.java:56-127) ----
   std::vector<int32_t> h_copy(B), h_mask(B), h_applied, h_skip(B, 0xFF);
@@ -506,6 +521,8 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
 struct FrameDec {
   int32_t* preLen; int32_t* skipFlags; int32_t* hdrBytes; int32_t* raw; int32_t* tcopy; int32_t* status;
   int64_t* bitOff; int64_t* bitEnd;
+  u64* hashRef;          // [B] checksum stored in the block header
+  int chk;
 };
 // CompressedInputStream.java:1025-1095 readBlockHeader
 __global__ void k_frame_parse(const u8* __restrict__ in, int64_t inStride, const int64_t* __restrict__ bitLen, FrameDec F,
@@ -533,8 +550,12 @@ __global__ void k_frame_parse(const u8* __restrict__ in, int64_t inStride, const
       int idx = 1;
       if (hasSkip) skipFlags = p[idx++];
       for (int i = 0; i < dataSize; i++) preLen = (preLen << 8) | p[idx++];
-      const u8 ck = p[idx];
+      const u8 ck = p[idx++];
+      const int cbytes = (F.chk == 1) ? 4 : (F.chk == 2 ? 8 : 0);
+      if (cbytes && W >= (int64_t)(hdrBytes + cbytes) * 8) { u64 hv = 0; for (int k = 0; k < cbytes; k++) hv = (hv << 8) | p[idx++]; F.hashRef[b] = hv; }
+      hdrBytes += cbytes;
       if (ck != kz_block_cksum(mode, skipFlags, (u32)preLen, (u64)W)) status = -KZ_ERR_CRC_CHECK;
+      else if (W < (int64_t)hdrBytes * 8) status = -KZ_ERR_BLOCK_SIZE;
       else if (preLen < 0 || preLen > maxTransformLength) status = -KZ_ERR_READ_FILE;
       else if (((W + 7) >> 3) > (int64_t)preLen + hdrBytes) status = -KZ_ERR_BLOCK_SIZE;     // :1158-1164
     }
@@ -615,6 +636,9 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   F.status = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   F.bitOff = (int64_t*)kz_arena_alloc(ctx, (size_t)B * 8);
   F.bitEnd = (int64_t*)kz_arena_alloc(ctx, (size_t)B * 8);
+  F.hashRef = (u64*)kz_arena_alloc(ctx, (size_t)B * 8);
+  F.chk = ctx->checksum;
+  u64* d_hashOut = (u64*)kz_arena_alloc(ctx, (size_t)B * 8);
   int64_t* d_bitLen = (int64_t*)kz_arena_alloc(ctx, (size_t)B * 8);
   if (!d_bitLen) { snprintf(ctx->err, sizeof(ctx->err), "decode: arena overflow"); return -KZ_ERR_DEVICE; }
   KZ_HIP(hipMemcpyAsync(d_bitLen, bitLengths, (size_t)B * 8, hipMemcpyHostToDevice, st));
@@ -668,6 +692,16 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     int64_t outBytes = 0; for (int b = 0; b < B; b++) if (h_mask[b]) outBytes += bt.h_len[b];
     kz_stage_end(ctx, e1, stage_id(type, false), outBytes);
     for (int b = 0; b < B; b++) if (h_mask[b] && !h_applied[b]) { h_status[b] = -KZ_ERR_PROCESS_BLOCK; bt.h_len[b] = 0; }
+  }
+  // ---- checksum verification (CompressedInputStream.java:1349-1363) ----
+  if (F.chk) {
+    rc = kz_block_hashes(ctx, bt.buf[bt.cur], bt.stride, bt.d_len, B, F.chk, d_hashOut);
+    if (rc) return rc;
+    std::vector<u64> h1(B), h2(B);
+    KZ_HIP(hipMemcpyAsync(h1.data(), F.hashRef, (size_t)B * 8, hipMemcpyDeviceToHost, st));
+    KZ_HIP(hipMemcpyAsync(h2.data(), d_hashOut, (size_t)B * 8, hipMemcpyDeviceToHost, st));
+    KZ_HIP(hipStreamSynchronize(st));
+    for (int b = 0; b < B; b++) if (!h_status[b] && bt.h_len[b] > 0 && h1[b] != h2[b]) h_status[b] = -KZ_ERR_CRC_CHECK;
   }
   // ---- results ----
   for (int b = 0; b < B; b++) {

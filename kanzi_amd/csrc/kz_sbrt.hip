@@ -30,7 +30,9 @@ __device__ __forceinline__ u64 kz_readlane64(u64 v, int l) {
 }
 
 // ---- forward 1/3: last two occurrences per symbol in each tile -------------------------------
-// tab[b][t][s] = (p1,p2) absolute positions, -1 = none
+// tab[b][t][s] = (p1,p2) absolute positions, -1 = none.  64 bytes per step: one ballot match-any groups
+// the lanes holding the same symbol; the highest lane of each group (distinct symbols -> distinct LDS
+// slots, no atomics) merges the group's two highest positions into the running table.
 __global__ __launch_bounds__(64) void k_sbrt_last2(const u8* __restrict__ src, int64_t stride, const int32_t* __restrict__ d_len,
                                                     int2* __restrict__ tab, int T) {
   const int b = blockIdx.y, t = blockIdx.x;
@@ -40,29 +42,26 @@ __global__ __launch_bounds__(64) void k_sbrt_last2(const u8* __restrict__ src, i
   const int end = min(n, start + SB_TS);
   const u8* s = src + (int64_t)b * stride;
   const int lane = kz_lane();
-  int p1[4] = {-1, -1, -1, -1}, p2[4] = {-1, -1, -1, -1};
-  for (int row = start; row < end; row += 256) {
-    const int wi = row + lane * 4;
-    u32 w = 0;
-    if (wi + 3 < end) w = *(const u32*)(s + wi);
-    else { for (int k = 0; k < 4; k++) if (wi + k < end) w |= (u32)s[wi + k] << (8 * k); }
-    const int cnt = min(256, end - row);
-    for (int j = 0; j < cnt; j++) {
-      const u32 ww = (u32)__builtin_amdgcn_readlane((int)w, j >> 2);
-      const int c = (ww >> (8 * (j & 3))) & 0xFF;
-      const int i = row + j;
-      const bool mine = lane == (c & 63);
-      switch (c >> 6) {
-        case 0: if (mine) { p2[0] = p1[0]; p1[0] = i; } break;
-        case 1: if (mine) { p2[1] = p1[1]; p1[1] = i; } break;
-        case 2: if (mine) { p2[2] = p1[2]; p1[2] = i; } break;
-        default: if (mine) { p2[3] = p1[3]; p1[3] = i; } break;
-      }
+  __shared__ int2 last[256];
+  for (int i = lane; i < 256; i += 64) last[i] = make_int2(-1, -1);
+  __syncthreads();
+  for (int row = start; row < end; row += 64) {
+    const int i = row + lane;
+    const bool valid = i < end;
+    const u32 c = valid ? (u32)s[i] : 0u;
+    const uint64_t peers = kz_match8(c, valid);
+    if (valid && (peers >> lane) == 1ULL) {                         // highest lane of its group
+      const uint64_t rest = peers & ~(1ULL << lane);
+      int2 v = last[c];
+      if (rest) { v.y = row + (63 - (int)__builtin_clzll(rest)); } else { v.y = v.x; }
+      v.x = i;
+      last[c] = v;
     }
   }
+  __syncthreads();
   int2* o = tab + ((int64_t)b * T + t) * 256;
 #pragma unroll
-  for (int q = 0; q < 4; q++) o[q * 64 + lane] = make_int2(p1[q], p2[q]);
+  for (int q = 0; q < 4; q++) o[q * 64 + lane] = last[q * 64 + lane];
 }
 
 // ---- forward 2/3: exclusive scan over tiles (thread = symbol) --------------------------------

@@ -90,8 +90,8 @@ int batch_blocks(int blockSize) {
 }  // namespace
 
 // ---- host-only container helpers (no GPU needed): used by kz_compress and by multi-GPU gathers ----
-static int write_stream_header(HostBits& bs, uint64_t transformType, uint32_t entropyType, int32_t blockSize, int64_t n) {
-  bs.put(0x4B414E5A, 32); bs.put(7, 4); bs.put(0, 2);
+static int write_stream_header(HostBits& bs, uint64_t transformType, uint32_t entropyType, int32_t blockSize, int64_t n, int chkKind = 0) {
+  bs.put(0x4B414E5A, 32); bs.put(7, 4); bs.put((uint64_t)chkKind, 2);
   bs.put(entropyType, 5); bs.put(transformType, 48); bs.put((uint32_t)blockSize >> 4, 28);
   int szMask = 0;
   if (n != 0 && n < (1LL << 48)) {
@@ -101,7 +101,7 @@ static int write_stream_header(HostBits& bs, uint64_t transformType, uint32_t en
   bs.put((uint64_t)szMask, 2);
   if (szMask > 0) bs.put((uint64_t)n, 16 * szMask);
   bs.put(0, 15);
-  bs.put(header_cksum(0, (int)entropyType, transformType, blockSize, szMask, n), 24);
+  bs.put(header_cksum(chkKind, (int)entropyType, transformType, blockSize, szMask, n), 24);
   return szMask;
 }
 static void write_block(HostBits& bs, const uint8_t* stream, uint64_t written) {   // :1024-1035
@@ -143,7 +143,7 @@ extern "C" int32_t kz_knz_index(const uint8_t* src, int64_t n, uint64_t* transfo
   bs.get(15);
   const uint32_t ck = (uint32_t)bs.get(24);
   if (bs.error || ck != header_cksum(chkKind, et, tt, bsz, szMask, isz)) return -KZ_ERR_CRC_CHECK;
-  if (chkKind != 0) return -KZ_ERR_INVALID_CODEC;
+  if (chkKind > 2) return -KZ_ERR_INVALID_FILE;
   if (transformType) *transformType = tt;
   if (entropyType) *entropyType = (uint32_t)et;
   if (blockSize) *blockSize = bsz;
@@ -168,7 +168,7 @@ extern "C" int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t ent
   if (blockSize < 1024 || blockSize > (1 << 30) || (blockSize & 15)) return -KZ_ERR_BLOCK_SIZE;   // :165-174
   HostBits bs{dst, dstCap, 0, false};
   // ---- stream header (CompressedOutputStream.java:236-313) ----
-  write_stream_header(bs, transformType, entropyType, blockSize, n);
+  write_stream_header(bs, transformType, entropyType, blockSize, n, ctx->checksum);
   // ---- blocks, in batches ----
   const int64_t nblocks = (n + blockSize - 1) / blockSize;
   const int NB = batch_blocks(blockSize);
@@ -207,7 +207,10 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
   bs.get(15);
   const uint32_t ck = (uint32_t)bs.get(24);
   if (bs.error || ck != header_cksum(chkKind, entropyType, tt, blockSize, szMask, inputSize)) return -KZ_ERR_CRC_CHECK;
-  if (chkKind != 0) { snprintf(ctx->err, sizeof(ctx->err), "block checksums (-x) are not supported by the HIP path"); return -KZ_ERR_INVALID_CODEC; }
+  if (chkKind > 2) return -KZ_ERR_INVALID_FILE;
+  const int savedChk = ctx->checksum;
+  ctx->checksum = chkKind;
+  struct Restore { kz_ctx* c; int v; ~Restore() { c->checksum = v; } } restore_{ctx, savedChk};
   if (blockSize < 1024 || blockSize > (1 << 30)) return -KZ_ERR_BLOCK_SIZE;
   const int NB = batch_blocks(blockSize);
   const int64_t iS = (int64_t)kz_align((size_t)blockSize + (size_t)(blockSize >> 3) + 1024 + 64, 256);

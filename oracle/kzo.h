@@ -99,6 +99,15 @@ int64_t kzo_encode_block(uint64_t transformType, int entropyType, const uint8_t*
                          uint8_t* out, size_t outCap, uint8_t* skipFlagsOut, int* postLenOut);
 int     kzo_decode_block(uint64_t transformType, int entropyType, int blockSize, const uint8_t* in,
                          int64_t nbits, uint8_t* out, int outCap);
+/* _x variants: chkKind 0 none / 1 XXHash32 / 2 XXHash64 block checksum (-x32 / -x64) */
+int64_t kzo_encode_block_x(uint64_t transformType, int entropyType, int chkKind, const uint8_t* data, int n,
+                           uint8_t* out, size_t outCap, uint8_t* skipFlagsOut, int* postLenOut);
+int     kzo_decode_block_x(uint64_t transformType, int entropyType, int chkKind, int blockSize, const uint8_t* in,
+                           int64_t nbits, uint8_t* out, int outCap);
+int64_t kzo_compress_x(uint64_t transformType, int entropyType, int blockSize, int chkKind, const uint8_t* src,
+                       int64_t n, uint8_t* dst, int64_t dstCap, int jobs);
+uint32_t kzo_xxhash32(const uint8_t* data, int length, uint32_t seed);
+uint64_t kzo_xxhash64(const uint8_t* data, int length, uint64_t seed);
 /* whole stream, `jobs` threads over blocks; returns bytes written or <0 */
 int64_t kzo_compress(uint64_t transformType, int entropyType, int blockSize, const uint8_t* src,
                      int64_t n, uint8_t* dst, int64_t dstCap, int jobs);

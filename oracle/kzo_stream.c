@@ -187,7 +187,16 @@ static uint8_t block_hdr_cksum(uint8_t mode, uint8_t headerSkipFlags, uint32_t p
  * dataType 0 = UNDEFINED is passed (documented limitation; chains in scope ignore it except LZ). */
 int64_t kzo_encode_block(uint64_t transformType, int entropyType, const uint8_t* data, int n,
                          uint8_t* out, size_t outCap, uint8_t* skipFlagsOut, int* postLenOut) {
+  return kzo_encode_block_x(transformType, entropyType, 0, data, n, out, outCap, skipFlagsOut, postLenOut);
+}
+
+/* chkKind: 0 none, 1 XXHash32, 2 XXHash64 of the ORIGINAL block (CompressedOutputStream.java:749-755,887-891) */
+int64_t kzo_encode_block_x(uint64_t transformType, int entropyType, int chkKind, const uint8_t* data, int n,
+                           uint8_t* out, size_t outCap, uint8_t* skipFlagsOut, int* postLenOut) {
   if (n == 0) return 0;
+  uint64_t checksum = 0;
+  if (chkKind == 1) checksum = kzo_xxhash32(data, n, 0x4B414E5Au);
+  else if (chkKind == 2) checksum = kzo_xxhash64(data, n, 0x4B414E5AULL);
   uint8_t mode = 0;
   int types[8];
   if (n <= 15) { transformType = 0; entropyType = KZO_E_NONE; mode |= 0x80; }   /* :764-767 */
@@ -214,6 +223,7 @@ int64_t kzo_encode_block(uint64_t transformType, int entropyType, const uint8_t*
   int headerChecksumIndex = 1 + dataSize;
   if (!(mode & 0x80) && (nb > 4)) headerChecksumIndex++;
   kzo_obs_write(&os, 0, 8);
+  if (chkKind == 1) kzo_obs_write(&os, checksum, 32); else if (chkKind == 2) kzo_obs_write(&os, checksum, 64);
   if (kzo_entropy_encode(entropyType, &os, buffer, postLen) != postLen) { kzo_obs_free(&os); free(buffer); return -1; }
   uint64_t written = os.nbits;
   if (!(mode & 0x80)) {                                                           /* :926-973 raw fallback */
@@ -228,6 +238,7 @@ int64_t kzo_encode_block(uint64_t transformType, int entropyType, const uint8_t*
       if (nb > 4) { headerChecksumIndex++; headerSkipFlags = skipFlags; }
       else headerSkipFlags = (uint8_t)(((copyMode << 4) | 0x0F) & 0xFF);
       kzo_obs_write(&os, 0, 8);
+      if (chkKind == 1) kzo_obs_write(&os, checksum, 32); else if (chkKind == 2) kzo_obs_write(&os, checksum, 64);
       kzo_obs_write_bytes(&os, buffer, (uint64_t)postLen * 8);
       written = os.nbits;
       mode = copyMode;
@@ -246,6 +257,11 @@ int64_t kzo_encode_block(uint64_t transformType, int entropyType, const uint8_t*
 /* in = the block's private stream (header included), nbits = W. Returns decoded length or <0. */
 int kzo_decode_block(uint64_t transformType, int entropyType, int blockSize, const uint8_t* in,
                      int64_t nbits, uint8_t* out, int outCap) {
+  return kzo_decode_block_x(transformType, entropyType, 0, blockSize, in, nbits, out, outCap);
+}
+
+int kzo_decode_block_x(uint64_t transformType, int entropyType, int chkKind, int blockSize, const uint8_t* in,
+                       int64_t nbits, uint8_t* out, int outCap) {
   if (nbits < 8) return -1;
   kzo_ibs is; kzo_ibs_init(&is, in, (uint64_t)nbits);
   int types[8];
@@ -272,6 +288,8 @@ int kzo_decode_block(uint64_t transformType, int entropyType, int blockSize, con
   int maxTL = blockSize + blockSize / 2; if (maxTL < 2048) maxTL = 2048;
   if ((int)preLen < 0 || (int)preLen > maxTL) return -1;
   if (preLen == 0) return 0;
+  uint64_t checksum1 = 0;
+  if (chkKind == 1) checksum1 = kzo_ibs_read(&is, 32); else if (chkKind == 2) checksum1 = kzo_ibs_read(&is, 64);   /* :1256-1262 */
   if (rawCopy) { transformType = 0; entropyType = KZO_E_NONE; skipFlags = 0xFF; }
   else if (transformedCopy) entropyType = KZO_E_NONE;
   uint8_t* buffer = (uint8_t*)malloc((size_t)preLen + 1024);
@@ -282,7 +300,11 @@ int kzo_decode_block(uint64_t transformType, int entropyType, int blockSize, con
     int cap = blockSize + ((blockSize >> 4) > 512 ? (blockSize >> 4) : 512);
     uint8_t* tmp = (uint8_t*)malloc((size_t)cap + 64);
     int r = kzo_sequence_inverse(types, nb, skipFlags, buffer, (int)preLen, tmp, cap);
-    if (r >= 0 && r <= outCap) { memcpy(out, tmp, (size_t)r); ret = r; }
+    if (r >= 0 && r <= outCap) {
+      memcpy(out, tmp, (size_t)r); ret = r;
+      if (chkKind == 1 && (uint32_t)checksum1 != kzo_xxhash32(tmp, r, 0x4B414E5Au)) ret = -19;      /* ERR_CRC_CHECK :1349-1363 */
+      if (chkKind == 2 && checksum1 != kzo_xxhash64(tmp, r, 0x4B414E5AULL)) ret = -19;
+    }
     free(tmp);
   }
   free(buffer);
@@ -325,7 +347,7 @@ int kzo_stream_header(uint64_t transformType, int entropyType, int blockSize, in
 }
 
 typedef struct {
-  uint64_t transformType; int entropyType; int blockSize;
+  uint64_t transformType; int entropyType; int blockSize; int chkKind;
   const uint8_t* src; int64_t n; int nblocks;
   uint8_t** outs; int64_t* bits; int* next; pthread_mutex_t* mu; int fail;
 } enc_job;
@@ -341,7 +363,7 @@ static void* enc_worker(void* arg) {
     int len = (int)((j->n - off) < j->blockSize ? (j->n - off) : j->blockSize);
     size_t cap = (size_t)len + (len >> 3) + 1024;
     j->outs[b] = (uint8_t*)malloc(cap);
-    j->bits[b] = kzo_encode_block(j->transformType, j->entropyType, j->src + off, len, j->outs[b], cap, NULL, NULL);
+    j->bits[b] = kzo_encode_block_x(j->transformType, j->entropyType, j->chkKind, j->src + off, len, j->outs[b], cap, NULL, NULL);
     if (j->bits[b] < 0) j->fail = 1;
   }
   return NULL;
@@ -349,13 +371,18 @@ static void* enc_worker(void* arg) {
 
 int64_t kzo_compress(uint64_t transformType, int entropyType, int blockSize, const uint8_t* src,
                      int64_t n, uint8_t* dst, int64_t dstCap, int jobs) {
+  return kzo_compress_x(transformType, entropyType, blockSize, 0, src, n, dst, dstCap, jobs);
+}
+
+int64_t kzo_compress_x(uint64_t transformType, int entropyType, int blockSize, int chkKind, const uint8_t* src,
+                       int64_t n, uint8_t* dst, int64_t dstCap, int jobs) {
   tune_malloc();
   int nblocks = (int)((n + blockSize - 1) / blockSize);
   uint8_t** outs = (uint8_t**)calloc((size_t)nblocks + 1, sizeof(uint8_t*));
   int64_t* bits = (int64_t*)calloc((size_t)nblocks + 1, sizeof(int64_t));
   pthread_mutex_t mu; pthread_mutex_init(&mu, NULL);
   int next = 0;
-  enc_job job = { transformType, entropyType, blockSize, src, n, nblocks, outs, bits, &next, &mu, 0 };
+  enc_job job = { transformType, entropyType, blockSize, chkKind, src, n, nblocks, outs, bits, &next, &mu, 0 };
   if (jobs < 1) jobs = 1;
   if (jobs > 256) jobs = 256;
   pthread_t th[256];
@@ -365,7 +392,7 @@ int64_t kzo_compress(uint64_t transformType, int entropyType, int blockSize, con
   if (!job.fail) {
     kzo_obs s; kzo_obs_init(&s, (size_t)(n / 2) + 4096);
     uint8_t hdr[40];
-    int hl = kzo_stream_header(transformType, entropyType, blockSize, 0, n, hdr);
+    int hl = kzo_stream_header(transformType, entropyType, blockSize, chkKind, n, hdr);
     kzo_obs_write_bytes(&s, hdr, (uint64_t)hl * 8);
     for (int b = 0; b < nblocks; b++) {                            /* :1024-1035 */
       uint64_t written = (uint64_t)bits[b];
@@ -385,7 +412,7 @@ int64_t kzo_compress(uint64_t transformType, int entropyType, int blockSize, con
 }
 
 typedef struct {
-  uint64_t transformType; int entropyType; int blockSize; int nblocks;
+  uint64_t transformType; int entropyType; int blockSize; int chkKind; int nblocks;
   uint8_t** ins; int64_t* bits; uint8_t* dst; int64_t dstCap; int* lens;
   int* next; pthread_mutex_t* mu; int fail;
 } dec_job;
@@ -400,7 +427,7 @@ static void* dec_worker(void* arg) {
     int64_t off = (int64_t)b * j->blockSize;
     int64_t cap = j->dstCap - off; if (cap > j->blockSize) cap = j->blockSize;
     if (cap < 0) { j->fail = 1; continue; }
-    int r = kzo_decode_block(j->transformType, j->entropyType, j->blockSize, j->ins[b], j->bits[b], j->dst + off, (int)cap);
+    int r = kzo_decode_block_x(j->transformType, j->entropyType, j->chkKind, j->blockSize, j->ins[b], j->bits[b], j->dst + off, (int)cap);
     j->lens[b] = r;
     if (r < 0) j->fail = 1;
   }
@@ -425,7 +452,7 @@ int64_t kzo_decompress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstC
   uint8_t hdr[40];
   int hl = kzo_stream_header(transformType, entropyType, blockSize, chkKind, inputSize, hdr);
   uint32_t ck2 = ((uint32_t)hdr[hl - 3] << 16) | ((uint32_t)hdr[hl - 2] << 8) | hdr[hl - 1];
-  if (ck != ck2 || chkKind != 0 || s.error) return -3;
+  if (ck != ck2 || chkKind > 2 || s.error) return -3;
   /* serial index pass over block length prefixes (decodeBlock :1127-1129) */
   int capBlocks = 1024, nblocks = 0;
   uint8_t** ins = (uint8_t**)malloc(sizeof(uint8_t*) * (size_t)capBlocks);
@@ -452,7 +479,7 @@ int64_t kzo_decompress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstC
     int* lens = (int*)calloc((size_t)nblocks + 1, sizeof(int));
     pthread_mutex_t mu; pthread_mutex_init(&mu, NULL);
     int next = 0;
-    dec_job job = { transformType, entropyType, blockSize, nblocks, ins, bits, dst, dstCap, lens, &next, &mu, 0 };
+    dec_job job = { transformType, entropyType, blockSize, chkKind, nblocks, ins, bits, dst, dstCap, lens, &next, &mu, 0 };
     if (jobs < 1) jobs = 1;
     if (jobs > 256) jobs = 256;
     pthread_t th[256];

@@ -33,6 +33,14 @@ def lib():
         c = ctypes
         L.kzo_compress.restype = c.c_int64
         L.kzo_compress.argtypes = [c.c_uint64, c.c_int, c.c_int, c.c_void_p, c.c_int64, c.c_void_p, c.c_int64, c.c_int]
+        L.kzo_compress_x.restype = c.c_int64
+        L.kzo_compress_x.argtypes = [c.c_uint64, c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_int64, c.c_void_p, c.c_int64, c.c_int]
+        L.kzo_encode_block_x.restype = c.c_int64
+        L.kzo_encode_block_x.argtypes = [c.c_uint64, c.c_int, c.c_int, c.c_void_p, c.c_int, c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p]
+        L.kzo_xxhash32.restype = c.c_uint32
+        L.kzo_xxhash32.argtypes = [c.c_void_p, c.c_int, c.c_uint32]
+        L.kzo_xxhash64.restype = c.c_uint64
+        L.kzo_xxhash64.argtypes = [c.c_void_p, c.c_int, c.c_uint64]
         L.kzo_decompress.restype = c.c_int64
         L.kzo_decompress.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_int64, c.c_int]
         L.kzo_encode_block.restype = c.c_int64
@@ -125,14 +133,14 @@ def entropy_decode(name, data, nbits, count):
     return r, out[:count].tobytes(), int(s.pos)
 
 
-def encode_block(chain, entropy, data):
-    """-> (stream bytes, W bits, skipFlags, postLen)"""
+def encode_block(chain, entropy, data, checksum=0):
+    """-> (stream bytes, W bits, skipFlags, postLen); checksum 0 / 32 / 64"""
     a = _u8(data)
     cap = len(a) + len(a) // 8 + 2048
     out = np.zeros(cap, dtype=np.uint8)
     sf = ctypes.c_uint8(0)
     pl = ctypes.c_int(0)
-    w = lib().kzo_encode_block(ttype(chain), E[entropy.upper()], a.ctypes.data, len(a), out.ctypes.data, cap, ctypes.byref(sf), ctypes.byref(pl))
+    w = lib().kzo_encode_block_x(ttype(chain), E[entropy.upper()], {0: 0, 32: 1, 64: 2}[checksum], a.ctypes.data, len(a), out.ctypes.data, cap, ctypes.byref(sf), ctypes.byref(pl))
     if w < 0:
         raise RuntimeError("oracle encode_block failed")
     return out[:(w + 7) // 8].tobytes(), int(w), sf.value, pl.value
@@ -145,11 +153,11 @@ def decode_block(chain, entropy, block_size, stream, nbits, cap):
     return r, out[:max(r, 0)].tobytes()
 
 
-def compress(chain, entropy, block_size, data, jobs=1):
+def compress(chain, entropy, block_size, data, jobs=1, checksum=0):
     a = _u8(data)
     cap = len(a) + len(a) // 4 + 65536
     out = np.zeros(cap, dtype=np.uint8)
-    r = lib().kzo_compress(ttype(chain), E[entropy.upper()], block_size, a.ctypes.data if len(a) else out.ctypes.data, len(a), out.ctypes.data, cap, jobs)
+    r = lib().kzo_compress_x(ttype(chain), E[entropy.upper()], block_size, {0: 0, 32: 1, 64: 2}[checksum], a.ctypes.data if len(a) else out.ctypes.data, len(a), out.ctypes.data, cap, jobs)
     if r < 0:
         raise RuntimeError("oracle compress failed %d" % r)
     return out[:r].tobytes()
@@ -162,6 +170,16 @@ def decompress(data, cap, jobs=1):
     if r < 0:
         raise RuntimeError("oracle decompress failed %d" % r)
     return out[:r].tobytes()
+
+
+def xxhash32(data, seed=0x4B414E5A):
+    a = _u8(data)
+    return int(lib().kzo_xxhash32(a.ctypes.data if len(a) else None, len(a), seed))
+
+
+def xxhash64(data, seed=0x4B414E5A):
+    a = _u8(data)
+    return int(lib().kzo_xxhash64(a.ctypes.data if len(a) else None, len(a), seed))
 
 
 class JavaRandom:

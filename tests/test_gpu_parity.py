@@ -183,3 +183,23 @@ def test_full_size_blocks_properties(ctx):
     for i in (0, 4):
         s, w, sf, pl = oracle.encode_block("BWT+RANK+ZRLT", "ANS0", inp[i])
         assert res[i].bits == w and out[i, :(w + 7) // 8].tobytes() == s
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_block_checksums_match_oracle(ctx, bits):
+    """-x32 / -x64: XXHash32 (standard) and the reference's XXHash64 variant of the original block in the block
+    header (CompressedOutputStream.java:749-755,887-891); corrupted payload must be reported as ERR_CRC_CHECK or
+    a decode error (CompressedInputStream.java:1349-1363)."""
+    data = datagen.stream(5, 32768).tobytes() + b"0123456789abcdefXYZ" + bytes(37)
+    ref = oracle.compress("BWT+RANK+ZRLT", "ANS0", 32768, data, jobs=2, checksum=bits)
+    cos = kz.CompressedOutputStream(ctx, "BWT+RANK+ZRLT", "ANS0", 32768, checksum=bits)
+    cos.write(data)
+    cos.close()
+    assert cos.output == ref
+    assert kz.CompressedInputStream(ctx, ref).read() == data
+    raw = oracle.compress("NONE", "NONE", 32768, data, jobs=1, checksum=bits)     # payload = plain bytes: flip one
+    bad = bytearray(raw)
+    bad[len(bad) // 2] ^= 0x01
+    with pytest.raises(kz.KanziError) as e:
+        kz.CompressedInputStream(ctx, bytes(bad)).read(len(data))
+    assert e.value.code == 19

@@ -113,3 +113,26 @@ def test_golden_fixtures():
         got = oracle.compress(e["chain"], e["entropy"], e["blockSize"], inp, jobs=2)
         assert got == exp, e
         assert oracle.decompress(exp, len(inp), jobs=2) == inp
+
+
+def test_xxhash32_is_standard_xxh32_and_xxhash64_quirks():
+    """External pin: K/util/hash/XXHash32.java is the standard XXH32 (checked against the `xxhash` package).
+    XXHash64 deviates from XXH64 (32-bit rotate amounts in the lane merge, sign-extended 4-byte tail): it equals
+    the standard only where neither quirk triggers (< 32 bytes and no 4-byte tail with the top bit set)."""
+    xxhash = pytest.importorskip("xxhash")
+    rng = np.random.default_rng(9)
+    for n in (0, 1, 3, 4, 15, 16, 17, 31, 32, 33, 100, 1000, 65536):
+        d = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        assert oracle.xxhash32(d) == xxhash.xxh32(d, seed=0x4B414E5A).intdigest()
+    for n in (0, 1, 3, 8, 9, 16, 24):
+        d = bytes(rng.integers(0, 128, n, dtype=np.uint8))
+        assert oracle.xxhash64(d) == xxhash.xxh64(d, seed=0x4B414E5A).intdigest()
+    d = bytes(rng.integers(0, 256, 1000, dtype=np.uint8))
+    assert oracle.xxhash64(d) != xxhash.xxh64(d, seed=0x4B414E5A).intdigest()
+
+
+def test_checksummed_stream_roundtrip():
+    data = bytes(np.random.default_rng(2).integers(0, 7, 100000, dtype=np.uint8))
+    for bits in (32, 64):
+        knz = oracle.compress("BWT+RANK+ZRLT", "ANS0", 32768, data, jobs=2, checksum=bits)
+        assert oracle.decompress(knz, len(data), jobs=2) == data
