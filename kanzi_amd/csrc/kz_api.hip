@@ -408,7 +408,7 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   if (outStride < needOut || (outStride & 3)) { snprintf(ctx->err, sizeof(ctx->err), "outStride %lld < %lld or not a multiple of 4", (long long)outStride, (long long)needOut); return -KZ_ERR_INVALID_PARAM; }
   const bool host = memKind == KZ_MEM_HOST;
   Pipe P;
-  const int64_t extra = (host ? (int64_t)outStride * B : 0) + (int64_t)B * (sizeof(kz_block_result) + 64) + (int64_t)B * 16;
+  const int64_t extra = (host ? (int64_t)outStride * B : 0) + (int64_t)B * (sizeof(kz_block_result) + 64) + (int64_t)B * 32 + 8192;
   int rc = pipe_setup(ctx, P, B, maxLen, extra, false, CS);
   if (rc) return rc;
   kz_batch& bt = P.bt;
@@ -612,7 +612,7 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   }
   Pipe P;
   const int64_t inS = host ? (int64_t)kz_align((size_t)maxInBytes + 64, 256) : inStride;
-  const int64_t extra = (host ? inS * B : 0) + (int64_t)B * (sizeof(kz_block_result) + 128);
+  const int64_t extra = (host ? inS * B : 0) + (int64_t)B * (sizeof(kz_block_result) + 128) + (int64_t)B * 32 + 8192;
   int rc = pipe_setup(ctx, P, B, maxLen, extra, true, CS);
   if (rc) return rc;
   kz_batch& bt = P.bt;
