@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--chain", default="BWT+RANK+ZRLT")
     ap.add_argument("--entropy", default="ANS0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--data-class", type=int, default=-1, help="diagnostic: force one class of the synthetic generator (0..4) instead of the mix")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"),
                     help="per-kernel HBM bytes from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)")
     ap.add_argument("--cpu-sample-blocks", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
@@ -89,7 +90,7 @@ def main():
     D = min(args.distinct, B)
     host = np.empty((D, bs), dtype=np.uint8)
     for i in range(D):
-        host[i] = datagen.block(i * world + rank, bs)
+        host[i] = datagen.block(i * world + rank, bs, None if args.data_class < 0 else args.data_class)
     d_host = torch.from_numpy(host).to(dev)
     d_in = d_host.repeat((B + D - 1) // D, 1)[:B].contiguous()
     del d_host

@@ -180,8 +180,8 @@ __device__ __forceinline__ u32 kz_v_bcnt64(uint64_t m, u32 acc) {
     u32 tl = in ? (SRC_LO) : l##S, th = in ? (SRC_HI) : h##S;                              \
     l##S = at ? nlo : tl; h##S = at ? nhi : th; }
 
-__global__ __launch_bounds__(64) void k_sbrt_inverse(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
-                                                      const int32_t* __restrict__ d_len, int mode) {
+__global__ __launch_bounds__(64) void k_sbrt_inverse_v4(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                                                         const int32_t* __restrict__ d_len, int mode) {
   const int b = blockIdx.x;
   const int n = d_len[b];
   const u8* s = src + (int64_t)b * stride;
@@ -258,6 +258,93 @@ __global__ __launch_bounds__(64) void k_sbrt_inverse(const u8* __restrict__ src,
   }
 }
 
+// ---- inverse, v5: symbol order in ONE VGPR, keys per symbol --------------------------------------
+// ord : byte k of lane l = symbol at list position 4l+k.  A move of position r up to rp is a rotation of
+//       [rp, r]: one DPP wave_shr + one v_perm_b32 whose per-lane byte selector is built from two clamped
+//       shifts of 0x01010101 (bytes <= r minus bytes <= rp select "predecessor"), then a v_bfi for byte rp.
+// K   : keys stay with their SYMBOL (symbol s = lane s&63, element pair 2*(s>>6)), so nothing but the moved
+//       symbol's key ever changes: an indexed-VGPR write (s_set_gpr_idx) under a single-lane select.
+//       new position rp = #keys above the new key = 4 v_cmp_gt_u64 ballots + s_bcnt1 (order-free count).
+// Uniform values (rank, symbol, new key, rp) live in SGPRs; per non-zero rank the step has ~36 VALU and
+// ~50 SALU instructions, 4 VALU->SALU hand-offs and 2 branches (v4: ~110 VALU, all lanes redundantly).
+typedef u64 kz_u64x8 __attribute__((ext_vector_type(8)));
+#define KZ_DPP_SHR1_Z(x) ((u32)__builtin_amdgcn_update_dpp(0, (int)(x), 0x138 /*wave_shr:1*/, 0xF, 0xF, true))
+
+// zero run of zr ranks ending at index pl: the front symbol repeats, only its (q,p) change (SBRT.java:194-201)
+#define KZ_SBRT_ZERO_RUN(zr, plv)                                                              \
+  { const u32 pold = max(fplo, 256u) - 256u;                                                   \
+    const u32 pl = (u32)(plv);                                                                 \
+    const u32 pp = ((zr) >= 2) ? pl - 1u : pold;                                               \
+    const u32 fq = (MODE == 2) ? ((pl + pp) >> 1) : ((MODE == 1) ? pl : pp);                   \
+    fplo = pl + 256u;                                                                          \
+    const int fs = (int)(f >> 6);                                                              \
+    const u64 ok = K[fs];                                                                      \
+    K[fs] = (lane == (int)(f & 63u)) ? (((u64)fq << 32) | (u64)fplo) : ok; }
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_sbrt_inverse(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                                                      const int32_t* __restrict__ d_len) {
+  const int b = blockIdx.x;
+  const int n = d_len[b];
+  const u8* s = src + (int64_t)b * stride;
+  u8* d = dst + (int64_t)b * stride;
+  const int lane = kz_lane();
+  const u32 p0 = 4u * (u32)lane;
+  u32 ord = p0 | ((p0 + 1u) << 8) | ((p0 + 2u) << 16) | ((p0 + 3u) << 24);
+  // 8 elements (4 used) so that the compiler keeps the uniform-index accesses as VGPR-indexed moves
+  kz_u64x8 K = (kz_u64x8)(0ULL);
+  K[0] = (u64)(255 - lane); K[1] = (u64)(191 - lane); K[2] = (u64)(127 - lane); K[3] = (u64)(63 - lane);   // never seen: 255 - s
+  u32 f = 0, fplo = 255u;                      // front symbol and the low half (p + 256) of its key
+  const int v32l = 32 * lane;
+  u32 cur = (lane < n) ? (u32)s[lane] : 0u;
+  for (int row = 0; row < n; row += 64) {
+    const int cnt = min(64, n - row);
+    const int nrow = row + 64;
+    const u32 nxt = (nrow + lane < n) ? (u32)s[nrow + lane] : 0u;  // prefetch the next row
+    uint64_t nz = kz_ballot(cur != 0 && lane < cnt);
+    // zero ranks output the front symbol of their time: every lane starts with the current front, a new
+    // front is filled forward over the lanes behind it, non-zero lanes are overwritten with v_writelane
+    u32 outv = f;
+    int prev = -1;
+    while (nz) {
+      const int j = (int)__builtin_ctzll(nz);
+      nz &= nz - 1;
+      const int zr = j - prev - 1;
+      if (zr > 0) KZ_SBRT_ZERO_RUN(zr, row + j - 1)
+      const u32 r = (u32)__builtin_amdgcn_readlane((int)cur, j);
+      const u32 w = (u32)__builtin_amdgcn_readlane((int)ord, (int)(r >> 2));
+      const u32 c = (w >> ((r & 3u) * 8u)) & 0xFFu;
+      const int cl = (int)(c & 63u), cs = (int)(c >> 6);
+      const u64 ok = K[cs];
+      const u32 plo = (u32)__builtin_amdgcn_readlane((int)(u32)ok, cl);
+      const u32 pc = max(plo, 256u) - 256u;
+      const u32 iv = (u32)(row + j);
+      const u32 nhi = (MODE == 2) ? ((iv + pc) >> 1) : ((MODE == 1) ? iv : pc);
+      const u32 nlo = iv + 256u;
+      const u64 nk = ((u64)nhi << 32) | (u64)nlo;
+      // new position = number of keys above the new key (the moved symbol's old key is below it)
+      const u32 rp = (u32)(__builtin_popcountll(kz_ballot(K[0] > nk)) + __builtin_popcountll(kz_ballot(K[1] > nk)) +
+                           __builtin_popcountll(kz_ballot(K[2] > nk)) + __builtin_popcountll(kz_ballot(K[3] > nk)));
+      K[cs] = (lane == cl) ? nk : ok;
+      // rotate list positions [rp, r]: (rp, r] take their predecessor, rp takes c
+      const u32 prevw = KZ_DPP_SHR1_Z(ord);
+      const int sx = (24 - 8 * (int)r) + v32l, sy = (24 - 8 * (int)rp) + v32l;
+      const u32 lmx = 0x01010101u >> (u32)min(max(sx, 0), 31);     // 0x01 in bytes at positions <= r
+      const u32 lmy = 0x01010101u >> (u32)min(max(sy, 0), 31);     //                          <= rp
+      const u32 sel = 0x07060504u - lmx + lmy;                      // keep: 4+k (ord byte k) ; shift: 3+k (byte k-1 / prevw byte 3)
+      const u32 res = __builtin_amdgcn_perm(ord, prevw, sel);
+      const u32 am = (lane == (int)(rp >> 2)) ? (0xFFu << ((rp & 3u) * 8u)) : 0u;
+      ord = (am & (c * 0x01010101u)) | (~am & res);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(c), "s"(j) : "m0");   // outv[lane j] = c
+      if (rp == 0) { f = c; fplo = nlo; outv = (lane > j) ? c : outv; }
+      prev = j;
+    }
+    { const int zr = cnt - prev - 1; if (zr > 0) KZ_SBRT_ZERO_RUN(zr, row + cnt - 1) }
+    if (lane < cnt) d[row + lane] = (u8)outv;
+    cur = nxt;
+  }
+}
+
 __global__ void k_copy_len(const int32_t* a, int32_t* o, int32_t* flag, int B) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) { o[b] = a[b]; flag[b] = 1; }
@@ -313,7 +400,11 @@ int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
   hipStream_t st = ctx->stream;
   const u8* src = bt.buf[bt.cur];
   u8* dst = bt.buf[bt.cur ^ 1];
-  KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse, dim3(B), dim3(64), src, dst, bt.stride, bt.d_len, mode);
+  static const bool useV4 = getenv("KZ_SBRT_INV_V4") != nullptr;
+  if (useV4) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse_v4, dim3(B), dim3(64), src, dst, bt.stride, bt.d_len, mode); }
+  else if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<2>, dim3(B), dim3(64), src, dst, bt.stride, bt.d_len); }
+  else if (mode == 1) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<1>, dim3(B), dim3(64), src, dst, bt.stride, bt.d_len); }
+  else { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<3>, dim3(B), dim3(64), src, dst, bt.stride, bt.d_len); }
   KZ_LAUNCH(ctx, KID_COPY_LEN, k_copy_len, dim3((B + 255) / 256), dim3(256), bt.d_len, bt.d_len2, bt.d_flag, B);
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
