@@ -105,7 +105,10 @@ __global__ __launch_bounds__(256) void k_radix_scan(BwtArrays A) {
 }
 
 // radix pass 3/3: stable scatter.  Wave w owns the contiguous sub-tile [w*1024, (w+1)*1024);
-// rows of 64 keys are ranked with ballot match-any against per-wave LDS digit counters.
+// rows of 64 keys are ranked with ballot match-any against per-wave LDS digit counters.  The tile is
+// then reordered IN LDS (keys, then values through the same 32 KiB buffer) so that consecutive threads
+// store consecutive elements of each digit run: a wave store touches a few 128 B lines instead of up
+// to 64 scattered 8 B / 4 B segments (the pass is bound by memory transactions, not bytes).
 __global__ __launch_bounds__(KZ_WG) void k_radix_scatter(const u64* __restrict__ keyIn, const u32* __restrict__ valIn,
                                                           u64* __restrict__ keyOut, u32* __restrict__ valOut,
                                                           BwtArrays A, int shift) {
@@ -114,14 +117,19 @@ __global__ __launch_bounds__(KZ_WG) void k_radix_scatter(const u64* __restrict__
   const int tile = blockIdx.x;
   if ((int64_t)tile * RS_TILE >= m) return;
   __shared__ u32 cnt[4][256];
+  __shared__ u32 gdelta[256];        // global slot of the digit's first element of this tile - its tile-local slot
+  __shared__ u32 scan[32];
+  __shared__ u64 stage[RS_TILE];     // 32 KiB: keys, then values
   for (int i = threadIdx.x; i < 1024; i += KZ_WG) (&cnt[0][0])[i] = 0;
   __syncthreads();
   const int64_t off = (int64_t)b * A.NS;
   const int wave = threadIdx.x >> 6;
   const int lane = kz_lane();
-  const int base = tile * RS_TILE + wave * (64 * RS_ITEMS);
+  const int tbase = tile * RS_TILE;
+  const int base = tbase + wave * (64 * RS_ITEMS);
+  const int tcount = min(RS_TILE, m - tbase);
   const uint64_t lt = kz_lanemask_lt();
-  u64 k[RS_ITEMS]; u32 v[RS_ITEMS]; u32 dr[RS_ITEMS];   // dr = digit | (rank<<8)
+  u64 k[RS_ITEMS]; u32 v[RS_ITEMS]; u32 dr[RS_ITEMS];   // dr = digit | (rank<<8), later the tile-local slot
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
     const int idx = base + r * 64 + lane;
@@ -145,19 +153,41 @@ __global__ __launch_bounds__(KZ_WG) void k_radix_scatter(const u64* __restrict__
   __syncthreads();
   {
     const int d = threadIdx.x;
-    u32 runv = A.digitBase[b * 256 + d] + A.tileHist[((int64_t)b * A.T + tile) * 256 + d];
-#pragma unroll
-    for (int w = 0; w < 4; w++) { u32 t = cnt[w][d]; cnt[w][d] = runv; runv += t; }
+    const u32 c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+    u32 total;
+    const u32 ts = kz_wg_excl_sum(c0 + c1 + c2 + c3, scan, &total);
+    gdelta[d] = A.digitBase[b * 256 + d] + A.tileHist[((int64_t)b * A.T + tile) * 256 + d] - ts;
+    cnt[0][d] = ts; cnt[1][d] = ts + c0; cnt[2][d] = ts + c0 + c1; cnt[3][d] = ts + c0 + c1 + c2;
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
     const int idx = base + r * 64 + lane;
-    if (idx < m) {
-      const u32 pos = cnt[wave][dr[r] & 0xFF] + (dr[r] >> 8);
-      keyOut[off + pos] = k[r];
-      valOut[off + pos] = v[r];
+    if (idx < m) { const u32 slot = cnt[wave][dr[r] & 0xFF] + (dr[r] >> 8); dr[r] = slot; stage[slot] = k[r]; }
+  }
+  __syncthreads();
+  u32 gp[RS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    const int slot = r * KZ_WG + threadIdx.x;
+    if (slot < tcount) {
+      const u64 kk = stage[slot];
+      gp[r] = gdelta[(u32)((kk >> shift) & 0xFF)] + (u32)slot;
+      keyOut[off + gp[r]] = kk;
     }
+  }
+  __syncthreads();
+  u32* stageV = (u32*)stage;
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    const int idx = base + r * 64 + lane;
+    if (idx < m) stageV[dr[r]] = v[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    const int slot = r * KZ_WG + threadIdx.x;
+    if (slot < tcount) valOut[off + gp[r]] = stageV[slot];
   }
 }
 

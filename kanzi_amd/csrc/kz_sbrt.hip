@@ -91,19 +91,25 @@ __device__ __forceinline__ u64 kz_sbrt_key(int mode, int a1, int a2, int sym) {
   return ((u64)q << 32) | (u64)((u32)a1 + 256u);
 }
 
-#define KZ_SBRT_RANK_AND_UPDATE(CASE_Q)                                         \
-  { const u64 kc = kz_readlane64(k##CASE_Q, c & 63);                            \
-    cnt = (int)(__popcll(kz_ballot(k0 > kc)) + __popcll(kz_ballot(k1 > kc)) +   \
-                __popcll(kz_ballot(k2 > kc)) + __popcll(kz_ballot(k3 > kc)));   \
-    const u32 lo = (u32)kc;                                                     \
-    const u32 pc = (lo >= 256u) ? lo - 256u : 0u;                               \
-    const u32 qc = (mode == 2) ? (((u32)i + pc) >> 1) : ((mode == 1 || mode == 4) ? (u32)i : pc); \
-    const u64 nk = ((u64)qc << 32) | (u64)((u32)i + 256u);                      \
-    if (lane == (c & 63)) k##CASE_Q = nk; }
+typedef u64 kz_u64x8 __attribute__((ext_vector_type(8)));
 
 // ---- forward 3/3: replay one tile per wave ----------------------------------------------------
+// Keys per symbol (symbol s = lane s&63, element s>>6 of K; 8 elements so that uniform-index accesses stay
+// VGPR-indexed moves).  A rank is 4 v_cmp_gt_u64 ballots + s_bcnt1.  From the third equal byte in a row on,
+// the rank is 0 in every mode (after two consecutive occurrences the symbol is at the front) and only the
+// symbol's own (q,p) change, in closed form: those positions are skipped with a ballot mask
+// R[j] = byte[j]==byte[j-1]==byte[j-2] and the key is repaired before the next ranked symbol (after BWT
+// most bytes sit in such runs).
+#define KZ_SBRT_FIX_RUN(sym, plv)                                                              \
+  { const u32 pl = (u32)(plv), pp = pl - 1u;                                                   \
+    const u32 fq = (MODE == 2) ? ((pl + pp) >> 1) : ((MODE == 1 || MODE == 4) ? pl : pp);      \
+    const int fs = (int)((sym) >> 6);                                                          \
+    const u64 ok = K[fs];                                                                      \
+    K[fs] = (lane == (int)((sym) & 63u)) ? (((u64)fq << 32) | (u64)(pl + 256u)) : ok; }
+
+template <int MODE>
 __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
-                                                     const int32_t* __restrict__ d_len, const int2* __restrict__ tab, int T, int mode) {
+                                                     const int32_t* __restrict__ d_len, const int2* __restrict__ tab, int T) {
   const int b = blockIdx.y, t = blockIdx.x;
   const int n = d_len[b];
   const int start = t * SB_TS;
@@ -113,35 +119,52 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
   u8* d = dst + (int64_t)b * stride;
   const int lane = kz_lane();
   const int2* pre = tab + ((int64_t)b * T + t) * 256;
-  int2 v0 = pre[lane], v1 = pre[64 + lane], v2 = pre[128 + lane], v3 = pre[192 + lane];
-  u64 k0 = kz_sbrt_key(mode, v0.x, v0.y, lane);
-  u64 k1 = kz_sbrt_key(mode, v1.x, v1.y, 64 + lane);
-  u64 k2 = kz_sbrt_key(mode, v2.x, v2.y, 128 + lane);
-  u64 k3 = kz_sbrt_key(mode, v3.x, v3.y, 192 + lane);
-  for (int row = start; row < end; row += 256) {
-    const int wi = row + lane * 4;
-    u32 w = 0;
-    if (wi + 3 < end) w = *(const u32*)(s + wi);
-    else { for (int k = 0; k < 4; k++) if (wi + k < end) w |= (u32)s[wi + k] << (8 * k); }
-    const int cntRow = min(256, end - row);
-    u32 outw = 0;
-    u32 acc = 0;
-    for (int j = 0; j < cntRow; j++) {
-      const u32 ww = (u32)__builtin_amdgcn_readlane((int)w, j >> 2);
-      const int c = (ww >> (8 * (j & 3))) & 0xFF;
-      const int i = row + j;
-      int cnt;
-      switch (c >> 6) {
-        case 0: KZ_SBRT_RANK_AND_UPDATE(0) break;
-        case 1: KZ_SBRT_RANK_AND_UPDATE(1) break;
-        case 2: KZ_SBRT_RANK_AND_UPDATE(2) break;
-        default: KZ_SBRT_RANK_AND_UPDATE(3) break;
-      }
-      acc |= (u32)cnt << (8 * (j & 3));
-      if ((j & 3) == 3 || j == cntRow - 1) { if (lane == (j >> 2)) outw = acc; acc = 0; }
+  const int2 v0 = pre[lane], v1 = pre[64 + lane], v2 = pre[128 + lane], v3 = pre[192 + lane];
+  kz_u64x8 K = (kz_u64x8)(0ULL);
+  K[0] = kz_sbrt_key(MODE, v0.x, v0.y, lane);
+  K[1] = kz_sbrt_key(MODE, v1.x, v1.y, 64 + lane);
+  K[2] = kz_sbrt_key(MODE, v2.x, v2.y, 128 + lane);
+  K[3] = kz_sbrt_key(MODE, v3.x, v3.y, 192 + lane);
+  // bytes before the tile (run detection across the tile boundary)
+  u32 cp = (start >= 1) ? (u32)s[start - 1] : 0x100u;            // symbol at the previous position (0x100: none)
+  uint64_t carryE = (start >= 2 && s[start - 1] == s[start - 2]) ? 1ULL : 0ULL;
+  u32 cur = (start + lane < end) ? (u32)s[start + lane] : 0u;
+  for (int row = start; row < end; row += 64) {
+    const int cnt = min(64, end - row);
+    const int nrow = row + 64;
+    const u32 nxt = (nrow + lane < end) ? (u32)s[nrow + lane] : 0u;  // prefetch the next row
+    u32 prevb = (u32)__builtin_amdgcn_update_dpp(0, (int)cur, 0x138 /*wave_shr:1*/, 0xF, 0xF, true);
+    if (lane == 0) prevb = cp;
+    const uint64_t valid = (cnt == 64) ? ~0ULL : ((1ULL << cnt) - 1ULL);
+    const uint64_t E = kz_ballot(cur == prevb) & valid;
+    const uint64_t R = E & ((E << 1) | carryE);
+    carryE = E >> 63;
+    uint64_t N = valid & ~R;
+    u32 outv = 0;
+    int prev = -1;
+    while (N) {
+      const int j = (int)__builtin_ctzll(N);
+      N &= N - 1;
+      if (j - prev - 1 > 0) KZ_SBRT_FIX_RUN(cp, row + j - 1)
+      const u32 c = (u32)__builtin_amdgcn_readlane((int)cur, j);
+      const int cl = (int)(c & 63u), cs = (int)(c >> 6);
+      const u64 ok = K[cs];
+      const u64 kc = kz_readlane64(ok, cl);
+      const u32 cntv = (u32)(__builtin_popcountll(kz_ballot(K[0] > kc)) + __builtin_popcountll(kz_ballot(K[1] > kc)) +
+                             __builtin_popcountll(kz_ballot(K[2] > kc)) + __builtin_popcountll(kz_ballot(K[3] > kc)));
+      const u32 lo = (u32)kc;
+      const u32 pc = max(lo, 256u) - 256u;
+      const u32 iv = (u32)(row + j);
+      const u32 qc = (MODE == 2) ? ((iv + pc) >> 1) : ((MODE == 1 || MODE == 4) ? iv : pc);
+      const u64 nk = ((u64)qc << 32) | (u64)(iv + 256u);
+      K[cs] = (lane == cl) ? nk : ok;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(cntv), "s"(j) : "m0");   // outv[lane j] = rank
+      cp = c;
+      prev = j;
     }
-    if (wi + 3 < end) *(u32*)(d + wi) = outw;
-    else { for (int k = 0; k < 4; k++) if (wi + k < end) d[wi + k] = (u8)(outw >> (8 * k)); }
+    if (cnt - prev - 1 > 0) KZ_SBRT_FIX_RUN(cp, row + cnt - 1)
+    if (lane < cnt) d[row + lane] = (u8)outv;
+    cur = nxt;
   }
 }
 
@@ -267,7 +290,6 @@ __global__ __launch_bounds__(64) void k_sbrt_inverse_v4(const u8* __restrict__ s
 //       new position rp = #keys above the new key = 4 v_cmp_gt_u64 ballots + s_bcnt1 (order-free count).
 // Uniform values (rank, symbol, new key, rp) live in SGPRs; per non-zero rank the step has ~36 VALU and
 // ~50 SALU instructions, 4 VALU->SALU hand-offs and 2 branches (v4: ~110 VALU, all lanes redundantly).
-typedef u64 kz_u64x8 __attribute__((ext_vector_type(8)));
 #define KZ_DPP_SHR1_Z(x) ((u32)__builtin_amdgcn_update_dpp(0, (int)(x), 0x138 /*wave_shr:1*/, 0xF, 0xF, true))
 
 // zero run of zr ranks ending at index pl: the front symbol repeats, only its (q,p) change (SBRT.java:194-201)
@@ -368,7 +390,12 @@ int kz_stage_sbrt_forward(kz_ctx* ctx, kz_batch& bt, int mode) {
   if (maxN > 0) {
     KZ_LAUNCH(ctx, KID_SBRT_LAST2, k_sbrt_last2, dim3(T, B), dim3(64), src, bt.stride, bt.d_len, tab, T);
     KZ_LAUNCH(ctx, KID_SBRT_SCAN, k_sbrt_scan, dim3(B), dim3(256), bt.d_len, tab, T);
-    KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay, dim3(T, B), dim3(64), src, dst, bt.stride, bt.d_len, tab, T, mode);
+    switch (mode) {
+      case 1: KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay<1>, dim3(T, B), dim3(64), src, dst, bt.stride, bt.d_len, tab, T); break;
+      case 2: KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay<2>, dim3(T, B), dim3(64), src, dst, bt.stride, bt.d_len, tab, T); break;
+      case 4: KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay<4>, dim3(T, B), dim3(64), src, dst, bt.stride, bt.d_len, tab, T); break;
+      default: KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay<3>, dim3(T, B), dim3(64), src, dst, bt.stride, bt.d_len, tab, T); break;
+    }
   }
   KZ_LAUNCH(ctx, KID_COPY_LEN, k_copy_len, dim3((B + 255) / 256), dim3(256), bt.d_len, bt.d_len2, bt.d_flag, B);
   KZ_HIP(hipGetLastError());
@@ -385,7 +412,12 @@ int kz_sbrt_ranks(kz_ctx* ctx, const uint8_t* src, uint8_t* dst, int64_t stride,
   if (maxN > 0) {
     KZ_LAUNCH(ctx, KID_SBRT_LAST2, k_sbrt_last2, dim3(T, B), dim3(64), src, stride, d_len, tab, T);
     KZ_LAUNCH(ctx, KID_SBRT_SCAN, k_sbrt_scan, dim3(B), dim3(256), d_len, tab, T);
-    KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay, dim3(T, B), dim3(64), src, dst, stride, d_len, tab, T, mode);
+    switch (mode) {
+      case 1: KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay<1>, dim3(T, B), dim3(64), src, dst, stride, d_len, tab, T); break;
+      case 2: KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay<2>, dim3(T, B), dim3(64), src, dst, stride, d_len, tab, T); break;
+      case 4: KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay<4>, dim3(T, B), dim3(64), src, dst, stride, d_len, tab, T); break;
+      default: KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay<3>, dim3(T, B), dim3(64), src, dst, stride, d_len, tab, T); break;
+    }
   }
   KZ_HIP(hipGetLastError());
   return 0;
