@@ -147,6 +147,17 @@ def main():
     if not ok:
         raise SystemExit("round trip mismatch: decoded blocks differ from the input")
 
+    # ---- measured stream-copy rate of this GPU, printed next to the 8 TB/s spec peak ----
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    d_dec.copy_(d_in)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(3):
+        d_dec.copy_(d_in)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 3 * 2.0 * B * bs / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
     # ---- ratios + roofline ----
     step_bytes = float(B) * bs
     comp_bytes = float(sum((r.bits + 7) // 8 for r in res))
@@ -179,7 +190,7 @@ def main():
         except (OSError, ValueError, KeyError):
             traffic = None
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "measured_copy_GBs": copy_gbs,
                     "kernel": dom["kernel"], "stage": st, "launches_per_step": launches, "avg_launch_ms": avg_ms,
                     "alg_bytes_per_launch": alg / launches,
                     "stage_achieved_GBs": (alg / (stage_ms[st] * 1e-3) / 1e9) if stage_ms.get(st) else None,

@@ -20,6 +20,12 @@ JNIEXPORT void JNICALL CLS(ctxDestroy)(JNIEnv* env, jclass c, jlong ctx) {
   (void)env; (void)c;
   kz_ctx_destroy((kz_ctx*)(intptr_t)ctx);
 }
+/* context map key "checksum": 0 / 32 / 64 (CompressedOutputStream.java:190-204) */
+JNIEXPORT jint JNICALL CLS(ctxSetChecksum)(JNIEnv* env, jclass c, jlong ctx, jint bits) {
+  (void)env; (void)c;
+  return kz_ctx_set_checksum((kz_ctx*)(intptr_t)ctx, bits);
+}
+
 JNIEXPORT jint JNICALL CLS(maxEncodedLength)(JNIEnv* env, jclass c, jint type, jint n) {
   (void)env; (void)c;
   return kz_transform_max_encoded_len((uint32_t)type, n);

@@ -14,6 +14,7 @@
 // output) -- larger blocks return -KZ_ERR_BLOCK_SIZE.
 #include "kz_device.h"
 #include "kz_internal.h"
+#define BI_LD(p) __builtin_nontemporal_load(p)   // link loads: every line is used for one 4-byte link per visit
 
 typedef uint32_t u32;
 typedef uint8_t u8;
@@ -165,8 +166,8 @@ __global__ __launch_bounds__(KZ_WG) void k_bwti_scatter(const u8* __restrict__ s
 
 // pass 1: walker w starts at grid point w*S (w < G) or at the text head t0 (w == G) and counts the
 // steps to the next grid point / END.
-__global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V) {
-  const int b = blockIdx.y;
+__global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V, int b0) {
+  const int b = blockIdx.y + b0;
   const int n = V.n[b];
   if (n < 2 || V.status[b] != 0) return;
   const int S = 1 << V.logS;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V) {
   int nxt = -2;
   while (steps <= (u32)n) {
     if (t >= (u32)n) break;                                   // corrupt link
-    const u32 ptr = data[t];
+    const u32 ptr = BI_LD(&data[t]);
     steps++;
     t = ptr >> 8;
     if (t == BI_END) { nxt = -1; break; }
@@ -192,8 +193,8 @@ __global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V) {
 
 // per block: suffix sums along the segment chain by pointer jumping in LDS -> text offsets
 #define BI_MAXSEG 4100
-__global__ __launch_bounds__(256) void k_bwti_resolve(BwtInv V) {
-  const int b = blockIdx.x;
+__global__ __launch_bounds__(256) void k_bwti_resolve(BwtInv V, int b0) {
+  const int b = blockIdx.x + b0;
   const int n = V.n[b];
   if (n < 2 || V.status[b] != 0) return;
   const int S = 1 << V.logS;
@@ -223,8 +224,8 @@ __global__ __launch_bounds__(256) void k_bwti_resolve(BwtInv V) {
 }
 
 // pass 2: re-walk every segment and write its bytes at the resolved text offset
-__global__ __launch_bounds__(64) void k_bwti_walk2(u8* __restrict__ dst, int64_t stride, BwtInv V) {
-  const int b = blockIdx.y;
+__global__ __launch_bounds__(64) void k_bwti_walk2(u8* __restrict__ dst, int64_t stride, BwtInv V, int b0) {
+  const int b = blockIdx.y + b0;
   const int n = V.n[b];
   if (n < 2 || V.status[b] != 0) return;
   const int S = 1 << V.logS;
@@ -237,8 +238,27 @@ __global__ __launch_bounds__(64) void k_bwti_walk2(u8* __restrict__ dst, int64_t
   const u32 len = V.segLen[(int64_t)b * V.GS + w];
   u32 off = V.segOff[(int64_t)b * V.GS + w];
   if (off == 0xFFFFFFFFu || (unsigned long long)off + len > (unsigned long long)n) return;   // not on the text path
-  for (u32 k = 0; k < len; k++) {
-    const u32 ptr = data[t];
+  // bytes are packed into aligned 8-byte stores: a 1-byte store to a line nobody else is writing costs a
+  // whole 32 B write transaction
+  u32 k = 0;
+  while (k < len && ((off + k) & 7u)) {
+    const u32 ptr = BI_LD(&data[t]);
+    d[off + k] = (u8)ptr;
+    t = ptr >> 8;
+    k++;
+  }
+  for (; k + 8 <= len; k += 8) {
+    unsigned long long w = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const u32 ptr = BI_LD(&data[t]);
+      w |= (unsigned long long)(ptr & 0xFFu) << (8 * q);
+      t = ptr >> 8;
+    }
+    *(unsigned long long*)(d + off + k) = w;
+  }
+  for (; k < len; k++) {
+    const u32 ptr = BI_LD(&data[t]);
     d[off + k] = (u8)ptr;
     t = ptr >> 8;
   }
@@ -293,9 +313,20 @@ int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
     KZ_LAUNCH(ctx, KID_BWTI_SCATTER, k_bwti_scatter, dim3(tiles, B), dim3(KZ_WG), src, bt.stride, V);
   }
   if (maxN >= 2) {
-    KZ_LAUNCH(ctx, KID_BWTI_WALK1, k_bwti_walk1, dim3((V.GS + 63) / 64, B), dim3(64), V);
-    KZ_LAUNCH(ctx, KID_BWTI_RESOLVE, k_bwti_resolve, dim3(B), dim3(256), V);
-    KZ_LAUNCH(ctx, KID_BWTI_WALK2, k_bwti_walk2, dim3((V.GS + 63) / 64, B), dim3(64), dst, bt.stride, V);
+    // The walks are dependent random 4-byte loads over a 4n-byte link array per block: bandwidth bound at one
+    // cache line per step once enough walkers are in flight.  Walking the batch in small groups (so that the
+    // group's link arrays stay in the 256 MB Infinity Cache) was measured 4-7x SLOWER: fewer walkers in
+    // flight (and segment lengths are geometric, so most lanes of a wave idle behind its longest segment).
+    // KZ_BWTI_GROUP is kept for experiments; the default walks the whole batch at once.
+    static const int groupEnv = getenv("KZ_BWTI_GROUP") ? atoi(getenv("KZ_BWTI_GROUP")) : 0;
+    int group = groupEnv > 0 ? groupEnv : B;
+    if (group > B) group = B;
+    for (int b0 = 0; b0 < B; b0 += group) {
+      const int nb = (B - b0 < group) ? B - b0 : group;
+      KZ_LAUNCH(ctx, KID_BWTI_WALK1, k_bwti_walk1, dim3((V.GS + 63) / 64, nb), dim3(64), V, b0);
+      KZ_LAUNCH(ctx, KID_BWTI_RESOLVE, k_bwti_resolve, dim3(nb), dim3(256), V, b0);
+      KZ_LAUNCH(ctx, KID_BWTI_WALK2, k_bwti_walk2, dim3((V.GS + 63) / 64, nb), dim3(64), dst, bt.stride, V, b0);
+    }
   }
   KZ_LAUNCH(ctx, KID_BWTI_FIN, k_bwti_fin, dim3((B + 255) / 256), dim3(256), src, dst, bt.stride, V, bt.d_len2, bt.d_flag, B);
   KZ_HIP(hipGetLastError());

@@ -18,6 +18,7 @@ def agg(path, counter):
             if row["Counter_Name"] != counter:
                 continue
             name = re.sub(r"\(.*", "", row["Kernel_Name"]).strip()
+            name = re.sub(r"<.*", "", name.replace("void ", "")).strip()      # templated kernels: "void k_x<2>"
             d = out.setdefault(name, {"launches": 0, "sum": 0.0})
             d["launches"] += 1
             d["sum"] += float(row["Counter_Value"])
