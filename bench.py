@@ -242,6 +242,19 @@ def main():
                                "knz_identical_to_hip": bool(cos.output == pref)}
         if cos.output != pref:
             raise SystemExit("PARITY FAILURE: HIP .knz differs from the oracle on the cpu_baseline sample")
+        # second row: the reference's default job count min(logical CPUs / 2, 64), on a smaller sample
+        jobs2 = max(1, min(jobs // 2, 64))
+        if jobs2 != jobs:
+            ns2 = int(min(ns, max(D, 2 * jobs2)))
+            sample2 = sample[:ns2 * bs]
+            t0 = time.perf_counter()
+            knz2 = oracle.compress(args.chain, args.entropy, bs, sample2, jobs=jobs2)
+            t1 = time.perf_counter()
+            back2 = oracle.decompress(knz2, len(sample2), jobs=jobs2)
+            t2 = time.perf_counter()
+            assert back2 == sample2.tobytes()
+            out["cpu_baseline"]["default_jobs_row"] = {"value": len(sample2) / (t2 - t0) / 1e6, "unit": "MB/s", "cores": jobs2,
+                                                       "sample": "%d blocks; enc %.2f s dec %.2f s" % (ns2, t1 - t0, t2 - t1)}
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -28,6 +28,24 @@ __device__ __forceinline__ void fp_copy(u8* __restrict__ d, const u8* __restrict
   for (int i = kz_lane(); i < n; i += 64) d[i] = s[i];
 }
 
+// One range-coder step (FPAQEncoder.java:182-199 encodeBit + :208-213 flush), all operands wave-uniform.
+// Written branch-free (selects) except for the rare flush: a taken scalar branch costs a lone wave ~40 cycles.
+#define FP_ENC_BIT(PP, BIT)                                                                    \
+  { const u64 split = (((high - low) >> 8) * (u64)(u32)(PP)) >> 8;                             \
+    const bool one = (BIT) != 0;                                                               \
+    const u64 nh = low + split, nl = nh + 1;                                                   \
+    high = one ? nh : high; low = one ? low : nl;                                              \
+    while (__builtin_expect(((low ^ high) & FP_M2456) == 0, 0)) {                              \
+      if (lane == 0) { const u32 w = (u32)(high >> 24); sba[idx] = (u8)(w >> 24); sba[idx + 1] = (u8)(w >> 16); sba[idx + 2] = (u8)(w >> 8); sba[idx + 3] = (u8)w; } \
+      idx += 4;                                                                                \
+      low <<= 32;                                                                              \
+      high = (high << 32) | FP_M032;                                                           \
+    } }
+
+// Encoder: the 8 contexts of a byte are known up front (the byte is known) and are 8 distinct table entries,
+// and the probability update does not depend on the coder state: lanes 0..7 gather, update and write back the
+// 8 probabilities of a byte with ONE LDS read and ONE LDS write; the gather for the next byte is issued before
+// the 8 sequential range-coder steps of the current one, which run on the scalar unit.
 __global__ __launch_bounds__(64) void k_fpaq_enc(const u8* __restrict__ src, int64_t stride, const int32_t* __restrict__ d_len,
                                                   u8* __restrict__ scr, int64_t scrStride, u8* __restrict__ out, int64_t outStride,
                                                   const int32_t* __restrict__ d_hdrBytes, int64_t* __restrict__ d_bits) {
@@ -44,33 +62,35 @@ __global__ __launch_bounds__(64) void k_fpaq_enc(const u8* __restrict__ src, int
   int opos = 0;
   u64 low = 0, high = FP_TOP;
   int startChunk = 0;
+  const int kbit = 7 - (lane & 7);                                // lane k codes bit 7-k (MSB first)
   while (startChunk < count) {
     const int chunkSize = min(FP_CHUNK, count - startChunk);
+    const int chunkEnd = startChunk + chunkSize;
     int idx = 0;
-    int tb = 0;                                                   // this.p = this.probs[0] (:148)
-    u32 rowv = (startChunk + lane < startChunk + chunkSize) ? (u32)blk[startChunk + lane] : 0u;
-    for (int i = startChunk; i < startChunk + chunkSize; i++) {
-      const int j = (i - startChunk) & 63;
-      if (j == 0 && i != startChunk) rowv = (i + lane < startChunk + chunkSize) ? (u32)blk[i + lane] : 0u;   // 64 bytes per load
-      const int val = __builtin_amdgcn_readlane((int)rowv, j);
-      const int bits = val + 256;
-#pragma unroll
-      for (int k = 7; k >= 0; k--) {
-        const int pIdx = tb + ((k == 7) ? 1 : (bits >> (k + 1)));
-        const int bit = (val >> k) & 1;
-        int pp = probs[pIdx];
-        const u64 split = (((high - low) >> 8) * (u64)(u32)pp) >> 8;  // :185
-        if (bit == 0) { low += (split + 1); pp -= (pp >> 6); }
-        else { high = low + split; pp -= ((pp - FP_PSCALE + 64) >> 6); }
-        probs[pIdx] = pp;
-        while (((low ^ high) & FP_M2456) == 0) {                    // flush :208-213
-          if (lane == 0) { const u32 w = (u32)(high >> 24); sba[idx] = (u8)(w >> 24); sba[idx + 1] = (u8)(w >> 16); sba[idx + 2] = (u8)(w >> 8); sba[idx + 3] = (u8)w; }
-          idx += 4;
-          low <<= 32;
-          high = (high << 32) | FP_M032;
-        }
+    u32 rowv = (startChunk + lane < chunkEnd) ? (u32)blk[startChunk + lane] : 0u;
+    // contexts of the first byte: this.p = this.probs[0] (:148)
+    int val = __builtin_amdgcn_readlane((int)rowv, 0);
+    int pIdx = 0 + ((kbit == 7) ? 1 : ((val + 256) >> (kbit + 1)));
+    int pp = probs[pIdx];
+    for (int i = startChunk; i < chunkEnd; i++) {
+      // update and write back this byte's 8 probabilities (lanes 0..7), fetch the next byte's
+      const int bit = (val >> kbit) & 1;
+      const int np = bit ? pp - ((pp - FP_PSCALE + 64) >> 6) : pp - (pp >> 6);
+      if (lane < 8) probs[pIdx] = np;
+      const int cur = pp;
+      const int curVal = val;
+      const int j1 = (i + 1 - startChunk) & 63;
+      if (i + 1 < chunkEnd) {
+        if (j1 == 0) rowv = (i + 1 + lane < chunkEnd) ? (u32)blk[i + 1 + lane] : 0u;   // 64 bytes per load
+        val = __builtin_amdgcn_readlane((int)rowv, j1);
+        pIdx = ((curVal >> 6) << 8) + ((kbit == 7) ? 1 : ((val + 256) >> (kbit + 1)));    // :161
+        pp = probs[pIdx];
       }
-      tb = (val >> 6) << 8;                                         // :161
+      const int p7 = __builtin_amdgcn_readlane(cur, 0), p6 = __builtin_amdgcn_readlane(cur, 1), p5 = __builtin_amdgcn_readlane(cur, 2),
+                p4 = __builtin_amdgcn_readlane(cur, 3), p3 = __builtin_amdgcn_readlane(cur, 4), p2 = __builtin_amdgcn_readlane(cur, 5),
+                p1 = __builtin_amdgcn_readlane(cur, 6), p0 = __builtin_amdgcn_readlane(cur, 7);
+      FP_ENC_BIT(p7, curVal & 0x80) FP_ENC_BIT(p6, curVal & 0x40) FP_ENC_BIT(p5, curVal & 0x20) FP_ENC_BIT(p4, curVal & 0x10)
+      FP_ENC_BIT(p3, curVal & 0x08) FP_ENC_BIT(p2, curVal & 0x04) FP_ENC_BIT(p1, curVal & 0x02) FP_ENC_BIT(p0, curVal & 0x01)
     }
     // varint(idx) | bytes   (EntropyUtils.writeVarInt; :164-165)
     { u32 v = (u32)idx; while (v >= 128) { if (lane == 0) o[opos] = (u8)(0x80 | (v & 0x7F)); opos++; v >>= 7; } if (lane == 0) o[opos] = (u8)v; opos++; }
@@ -89,6 +109,34 @@ __global__ __launch_bounds__(64) void k_fpaq_enc(const u8* __restrict__ src, int
   if (lane == 0) d_bits[b] = 8LL * opos;
 }
 
+// One decoder step (FPAQDecoder.java:290-314 decodeBitV2 + :322-335 read).  PR = probability of the current
+// context (scalar); the two children of the context were fetched from LDS one level earlier.
+#define FP_DEC_BIT(LEVEL)                                                                      \
+  { int2 ch = make_int2(0, 0);                                                                 \
+    if (LEVEL < 7) ch = *(const int2*)&probs[tb + 2 * ctx];        /* children of ctx: used at the next level */ \
+    const u64 split = ((((high - low) >> 8) * (u64)(u32)pr) >> 8) + low;                       \
+    const bool one = (int)((split - current) >> 32) >= 0;           /* split >= current (both < 2^56): sign of a scalar subtract */ \
+    const int np = one ? pr - ((pr - FP_PSCALE + 64) >> 6) : pr - (pr >> 6);                   \
+    high = one ? split : high; low = one ? low : split + 1;                                    \
+    probs[tb + ctx] = np;                                                                      \
+    ctx = (ctx << 1) + (one ? 1 : 0);                                                          \
+    if (LEVEL == 1) rootNext = probs[((ctx & 3) << 8) + 1];        /* next byte's first context (:233-239) */ \
+    while (__builtin_expect(((low ^ high) & FP_M2456) == 0, 0)) {                              \
+      low = (low << 32) & FP_M056;                                                             \
+      high = ((high << 32) | FP_M032) & FP_M056;                                               \
+      if (idx + 4 > bufLimit) { current = (current << 32) & FP_M056; idx = bufLimit + 1; continue; } \
+      if (idx >= wbase + 256) { wbase = idx; const u8* q = buf + wbase + 4 * lane; win = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3]; } \
+      const u64 val = (u64)(u32)__builtin_amdgcn_readlane((int)win, (idx - wbase) >> 2);       \
+      current = ((current << 32) | val) & FP_M056;                                             \
+      idx += 4;                                                                                \
+    }                                                                                          \
+    if (LEVEL < 7) pr = __builtin_amdgcn_readfirstlane(one ? ch.y : ch.x); }
+
+// Decoder: every bit's context depends on the previous bit, so the chain is serial; what can be hidden is the
+// LDS latency of the probability: both children of the current context (adjacent ints) are fetched with one
+// 8-byte LDS read while the current bit is decoded, the next byte's first context after its top two bits are
+// known.  Range arithmetic runs on the scalar unit; output bytes are collected with v_writelane and stored
+// 64 at a time.
 __global__ __launch_bounds__(64) void k_fpaq_dec(const u8* __restrict__ in, int64_t inStride, const int64_t* __restrict__ d_bitOff,
                                                   const int64_t* __restrict__ d_bitEnd, const int32_t* __restrict__ d_len,
                                                   u8* __restrict__ dst, int64_t stride, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag) {
@@ -97,7 +145,7 @@ __global__ __launch_bounds__(64) void k_fpaq_dec(const u8* __restrict__ in, int6
   const int lane = kz_lane();
   if (lane == 0) { d_len2[b] = count; d_flag[b] = 1; }
   if (count <= 0) return;
-  __shared__ int probs[1024];
+  __shared__ __attribute__((aligned(8))) int probs[1024];
   for (int i = lane; i < 1024; i += 64) probs[i] = FP_PSCALE >> 1;
   __syncthreads();
   const u8* p = in + (int64_t)b * inStride + (d_bitOff[b] >> 3);   // payload is byte aligned behind the block header
@@ -125,25 +173,15 @@ __global__ __launch_bounds__(64) void k_fpaq_dec(const u8* __restrict__ in, int6
     { const u8* q = buf + 4 * lane; win = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3]; }
     const int chunkSize = min(FP_CHUNK, count - startChunk);
     int tb = 0;
+    int rootNext = probs[1];
+    u32 outv = 0;
     for (int i = startChunk; i < startChunk + chunkSize; i++) {
       int ctx = 1;
-#pragma unroll
-      for (int k = 0; k < 8; k++) {                                  // decodeBitV2 :290-314
-        int pp = probs[tb + ctx];
-        const u64 split = ((((high - low) >> 8) * (u64)(u32)pp) >> 8) + low;
-        if (split >= current) { high = split; pp -= ((pp - FP_PSCALE + 64) >> 6); probs[tb + ctx] = pp; ctx = (ctx << 1) + 1; }
-        else { low = split + 1; pp -= (pp >> 6); probs[tb + ctx] = pp; ctx = ctx << 1; }
-        while (((low ^ high) & FP_M2456) == 0) {                     // read :322-335
-          low = (low << 32) & FP_M056;
-          high = ((high << 32) | FP_M032) & FP_M056;
-          if (idx + 4 > bufLimit) { current = (current << 32) & FP_M056; idx = bufLimit + 1; continue; }
-          if (idx >= wbase + 256) { wbase = idx; const u8* q = buf + wbase + 4 * lane; win = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3]; }
-          const u64 val = (u64)(u32)__builtin_amdgcn_readlane((int)win, (idx - wbase) >> 2);
-          current = ((current << 32) | val) & FP_M056;
-          idx += 4;
-        }
-      }
-      if (lane == 0) o[i] = (u8)ctx;
+      int pr = __builtin_amdgcn_readfirstlane(rootNext);
+      FP_DEC_BIT(0) FP_DEC_BIT(1) FP_DEC_BIT(2) FP_DEC_BIT(3) FP_DEC_BIT(4) FP_DEC_BIT(5) FP_DEC_BIT(6) FP_DEC_BIT(7)
+      const int j = (i - startChunk) & 63;
+      { const u32 cb = (u32)__builtin_amdgcn_readfirstlane(ctx & 0xFF); asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(cb), "s"(j) : "m0"); }
+      if (j == 63 || i + 1 == startChunk + chunkSize) { if (lane <= j) o[i - j + lane] = (u8)outv; }
       if (idx > szBytes) { bad = true; break; }                      // :231-232
       tb = ((ctx & 0xFF) >> 6) << 8;
     }

@@ -205,15 +205,33 @@ __global__ __launch_bounds__(64) void k_srt_inv(const u8* __restrict__ src, u8* 
   }
   __syncthreads();
   if (bad) { if (lane == 0) { d_len2[b] = 0; d_flag[b] = 0; } return; }
+  // Every step needs the next rank of the symbol that just became current: a dependent load.  Each symbol's
+  // next 64 ranks are therefore cached in LDS (16 KiB): a step is an LDS read, global memory is touched once
+  // per 64 ranks of a symbol.
+  __shared__ u32 wbase[256];
+  __shared__ u8 win[256][64];
+  for (int sym = 0; sym < 256; sym++) {
+    const u32 bs = bstart[sym], be = bend[sym];
+    const bool present = freq[sym] > 0;
+    win[sym][lane] = (present && bs + (u32)lane < be) ? s[bs + lane] : (u8)0;
+    if (lane == 0) wbase[sym] = bs;
+  }
+  __syncthreads();
   // list: position j -> lane j>>2, byte j&3
   u32 list = (u32)r2s0[4 * lane] | ((u32)r2s0[4 * lane + 1] << 8) | ((u32)r2s0[4 * lane + 2] << 16) | ((u32)r2s0[4 * lane + 3] << 24);
   int i = 0;
   int c = (int)(__builtin_amdgcn_readfirstlane((int)list) & 0xFF);
   while (i < count) {
     const u32 cur = bstart[c], end = bend[c];
-    __syncthreads();
-    const int vc = (int)min(64u, end - cur);                          // ranks of c still available in this window
-    const u32 v = (lane < vc) ? (u32)s[cur + lane] : 0u;
+    u32 wb = wbase[c];
+    int vc = (int)(min(end, wb + 64u) - cur);                         // ranks of c available in the cached window
+    if (vc == 0 && cur < end) {                                       // window used up: fetch the next 64 ranks
+      wb = cur;
+      win[c][lane] = (cur + (u32)lane < end) ? s[cur + lane] : (u8)0;
+      if (lane == 0) wbase[c] = wb;
+      vc = (int)min(64u, end - cur);
+    }
+    const u32 v = (lane < vc) ? (u32)win[c][(cur - wb) + (u32)lane] : 0u;
     const uint64_t nz = kz_ballot(v != 0 && lane < vc);
     const int z = nz ? (int)__builtin_ctzll(nz) : vc;                 // leading zero ranks = c repeats
     int r = 0;
@@ -221,7 +239,7 @@ __global__ __launch_bounds__(64) void k_srt_inv(const u8* __restrict__ src, u8* 
     bool moveC = false, removeC = false;
     if (nz) { emit = z + 1; consumed = z + 1; r = __builtin_amdgcn_readlane((int)v, z); moveC = true; }
     else if (cur + (u32)vc == end) { emit = vc + 1; consumed = vc; removeC = true; }      // bucket exhausted (:239-248)
-    else { emit = vc; consumed = vc; }                                 // 64 zeros, more to come
+    else { emit = vc; consumed = vc; }                                 // only zeros in the window, more to come
     if (emit > count - i) { emit = count - i; moveC = false; removeC = false; }
     if (lane < emit) o[i + lane] = (u8)c;
     if (emit > 64 && lane == 0) o[i + 64] = (u8)c;
@@ -250,7 +268,6 @@ __global__ __launch_bounds__(64) void k_srt_inv(const u8* __restrict__ src, u8* 
         i = count;
       }
     }
-    __syncthreads();
   }
   if (lane == 0) { d_len2[b] = count; d_flag[b] = 1; }
 }
