@@ -6,6 +6,7 @@
 #include "kz_internal.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <memory>
 
 namespace {
 struct HostBits {            // MSB-first writer (DefaultOutputBitStream.java:103-205)
@@ -31,9 +32,12 @@ struct HostBits {            // MSB-first writer (DefaultOutputBitStream.java:10
     if (sh == 0) { memcpy(p + (pos >> 3), s, (size_t)full); pos += full << 3; }
     else {
       uint8_t* d = p + (pos >> 3);
-      uint32_t acc = d[0] >> (8 - sh);                      // bits already in the partial byte
-      for (uint64_t i = 0; i < full; i++) { acc = (acc << 8) | s[i]; d[i] = (uint8_t)(acc >> sh); }
-      d[full] = (uint8_t)(acc << (8 - sh));
+      const int up = 8 - sh;
+      if (full) {
+        d[0] = (uint8_t)((d[0] & (0xFF << up)) | (s[0] >> sh));         // keep the bits already in the partial byte
+        for (uint64_t i = 1; i < full; i++) d[i] = (uint8_t)((s[i - 1] << up) | (s[i] >> sh));   // no carried dependency: vectorises
+        d[full] = (uint8_t)(s[full - 1] << up);
+      }
       pos += full << 3;
     }
     const int r = (int)(nbits & 7);
@@ -81,11 +85,11 @@ uint32_t header_cksum(int chkKind, int entropyType, uint64_t tt, int blockSize, 
   return ((c >> 23) ^ (c >> 3)) & 0xFFFFFF;
 }
 int batch_blocks(int blockSize) {
-  // bound device memory per batch (~140 B of scratch per input byte for the BWT stage)
-  int64_t budget = 48LL << 30;
-  int64_t per = (int64_t)blockSize * 160 + (64 << 20);
-  int nb = (int)std::max<int64_t>(1, std::min<int64_t>(256, budget / per));
-  return nb;
+  // blocks per kz_encode_blocks / kz_decode_blocks call of the host-buffer entry points: 8 GiB of input per call
+  // (device scratch is bounded separately by the arena budget, which splits a call into sub-batches); the
+  // serial kernels want a thousand blocks or more in flight.  The strided host staging buffers are allocated
+  // uninitialised, so only the bytes actually produced/consumed are ever touched.
+  return (int)std::max<int64_t>(1, std::min<int64_t>(2048, (8LL << 30) / blockSize));
 }
 }  // namespace
 
@@ -173,18 +177,18 @@ extern "C" int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t ent
   const int64_t nblocks = (n + blockSize - 1) / blockSize;
   const int NB = batch_blocks(blockSize);
   const int64_t oS = kz_max_block_stream_bytes(blockSize);
-  std::vector<uint8_t> outbuf((size_t)oS * (size_t)std::min<int64_t>(NB, std::max<int64_t>(nblocks, 1)));
+  std::unique_ptr<uint8_t[]> outbuf(new uint8_t[(size_t)oS * (size_t)std::min<int64_t>(NB, std::max<int64_t>(nblocks, 1))]);
   std::vector<int32_t> lens(NB);
   std::vector<kz_block_result> res(NB);
   for (int64_t b0 = 0; b0 < nblocks; b0 += NB) {
     const int cnt = (int)std::min<int64_t>(NB, nblocks - b0);
     for (int i = 0; i < cnt; i++) lens[i] = (int32_t)std::min<int64_t>(blockSize, n - (b0 + i) * blockSize);
     int rc = kz_encode_blocks(ctx, transformType, entropyType, src + b0 * blockSize, blockSize, lens.data(), cnt,
-                              outbuf.data(), oS, res.data(), KZ_MEM_HOST);
+                              outbuf.get(), oS, res.data(), KZ_MEM_HOST);
     if (rc) return rc;
     for (int i = 0; i < cnt; i++) {                             // ordered emission (:1024-1035)
       if (res[i].status) return res[i].status;
-      if (res[i].bits > 0) write_block(bs, outbuf.data() + (size_t)i * oS, (uint64_t)res[i].bits);
+      if (res[i].bits > 0) write_block(bs, outbuf.get() + (size_t)i * oS, (uint64_t)res[i].bits);
     }
   }
   bs.put(0, 5); bs.put(0, 3);                                   // end marker (:491-492)
@@ -212,9 +216,12 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
   ctx->checksum = chkKind;
   struct Restore { kz_ctx* c; int v; ~Restore() { c->checksum = v; } } restore_{ctx, savedChk};
   if (blockSize < 1024 || blockSize > (1 << 30)) return -KZ_ERR_BLOCK_SIZE;
-  const int NB = batch_blocks(blockSize);
+  int NB = batch_blocks(blockSize);
+  // no more staging than the stream can need: declared size if present, else >= 8 bytes of stream per block
+  if (szMask && inputSize > 0) NB = (int)std::min<int64_t>(NB, (inputSize + blockSize - 1) / blockSize);
+  else NB = (int)std::min<int64_t>(NB, n / 8 + 1);
   const int64_t iS = (int64_t)kz_align((size_t)blockSize + (size_t)(blockSize >> 3) + 1024 + 64, 256);
-  std::vector<uint8_t> inbuf((size_t)iS * NB);
+  std::unique_ptr<uint8_t[]> inbuf(new uint8_t[(size_t)iS * NB]);
   std::vector<int64_t> bits(NB);
   std::vector<kz_block_result> res(NB);
   int64_t produced = 0;
@@ -227,7 +234,7 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
       if (bs.error) return -KZ_ERR_READ_FILE;
       if (rd == 0) { done = true; break; }
       if ((int64_t)((rd + 7) >> 3) > iS - 64) return -KZ_ERR_BLOCK_SIZE;
-      bs.getBytes(inbuf.data() + (size_t)cnt * iS, rd);
+      bs.getBytes(inbuf.get() + (size_t)cnt * iS, rd);
       if (bs.error) return -KZ_ERR_READ_FILE;
       bits[cnt++] = (int64_t)rd;
     }
@@ -236,7 +243,7 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
     // decode into a temporary when the tail would overflow dst
     const int64_t room = dstCap - produced;
     if (room >= (int64_t)cnt * blockSize) {
-      int rc = kz_decode_blocks(ctx, tt, (uint32_t)entropyType, blockSize, inbuf.data(), iS, bits.data(), cnt,
+      int rc = kz_decode_blocks(ctx, tt, (uint32_t)entropyType, blockSize, inbuf.get(), iS, bits.data(), cnt,
                                 dst + produced, blockSize, res.data(), KZ_MEM_HOST);
       if (rc) return rc;
       for (int i = 0; i < cnt; i++) {
@@ -246,7 +253,7 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
       }
     } else {
       std::vector<uint8_t> tmp((size_t)cnt * blockSize);
-      int rc = kz_decode_blocks(ctx, tt, (uint32_t)entropyType, blockSize, inbuf.data(), iS, bits.data(), cnt,
+      int rc = kz_decode_blocks(ctx, tt, (uint32_t)entropyType, blockSize, inbuf.get(), iS, bits.data(), cnt,
                                 tmp.data(), blockSize, res.data(), KZ_MEM_HOST);
       if (rc) return rc;
       for (int i = 0; i < cnt; i++) {
