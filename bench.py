@@ -39,7 +39,7 @@ for k in ("k_ans_dec_index", "k_ans_dec_chunk", "k_ans_dec_fin"):
 for k in ("k_zrlt_i1", "k_zrlt_i2", "k_zrlt_i3", "k_zrlt_ifin"):
     KERNEL_STAGE[k] = "zrlt_inv"
 KERNEL_STAGE["k_sbrt_inverse"] = "sbrt_inv"
-for k in ("k_bwti_parse", "k_bwti_hist", "k_bwti_scan", "k_bwti_scatter", "k_bwti_walk1", "k_bwti_resolve", "k_bwti_walk2", "k_bwti_fin"):
+for k in ("k_bwti_parse", "k_bwti_hist", "k_bwti_scan", "k_bwti_scatter", "k_bwti_walk1", "k_bwti_resolve", "k_bwti_copy", "k_bwti_fin"):
     KERNEL_STAGE[k] = "bwt_inv"
 
 
@@ -174,6 +174,20 @@ def main():
     stage_ms = {}
     for k in kernels:
         stage_ms[k["stage"]] = stage_ms.get(k["stage"], 0.0) + k["ms_per_step"]
+    # measured HBM traffic per kernel (separate rocprofv3 --pmc passes, tools/pmc_traffic.py), if it matches this workload
+    tj = None
+    try:
+        with open(args.traffic_json) as f:
+            tj = json.load(f)
+        if tj.get("blocks_per_gpu_per_step") != B or args.chain != "BWT+RANK+ZRLT" or args.entropy != "ANS0" or args.data_class >= 0:
+            tj = None
+    except (OSError, ValueError):
+        tj = None
+    if tj:
+        for k in kernels:
+            t = tj["kernels"].get(k["kernel"])
+            if t and k["ms_per_step"] > 0:
+                k["hbm_traffic_GBs"] = t["hbm_bytes_per_launch"] * k["launches_per_step"] / (k["ms_per_step"] * 1e-3) / 1e9
     if kernels:
         dom = kernels[0]
         st = dom["stage"]
@@ -182,13 +196,8 @@ def main():
         avg_ms = dom["ms_per_step"] / launches
         achieved = (alg / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
-        try:
-            with open(args.traffic_json) as f:
-                tj = json.load(f)
-            if tj.get("blocks_per_gpu_per_step") == B and dom["kernel"] in tj["kernels"]:
-                traffic = tj["kernels"][dom["kernel"]]["hbm_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            traffic = None
+        if tj and dom["kernel"] in tj["kernels"]:
+            traffic = tj["kernels"][dom["kernel"]]["hbm_bytes_per_launch"]
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "measured_copy_GBs": copy_gbs,
                     "kernel": dom["kernel"], "stage": st, "launches_per_step": launches, "avg_launch_ms": avg_ms,

@@ -33,11 +33,16 @@ struct BwtInv {
   u32* segLen;      // [B][GS]  walker segment lengths
   int32_t* segNext; // [B][GS]  next segment id on the text path, -1 = end of text
   u32* segOff;      // [B][GS]  text offset of each segment
+  u8* pool;         // [B][maxChunks * BI_CH] bytes recorded by the walkers, in chunks of BI_CH bytes
+  uint2* chunkMeta; // [B][maxChunks] (walker, sequence number inside its segment)
+  u32* chunkCount;  // [B] chunks handed out
+  int maxChunks;
   int64_t NS; int T;
   int logS;         // grid spacing = 1 << logS
   int GS;           // walker stride per block (grid points + 1)
 };
 #define BI_END 0xFFFFFFu
+#define BI_CH 256          // bytes per recording chunk
 
 __global__ void k_bwti_parse(const u8* __restrict__ src, int64_t stride, const int32_t* __restrict__ d_len, BwtInv V, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -164,8 +169,11 @@ __global__ __launch_bounds__(KZ_WG) void k_bwti_scatter(const u8* __restrict__ s
   }
 }
 
-// pass 1: walker w starts at grid point w*S (w < G) or at the text head t0 (w == G) and counts the
-// steps to the next grid point / END.
+// The walk (done ONCE): walker w starts at grid point w*S (w < G) or at the text head t0 (w == G) and follows
+// the links to the next grid point / END, counting its steps.  Where its bytes belong in the text is only known
+// after k_bwti_resolve, so they are recorded into chunks of BI_CH bytes taken from a per-block pool (8 bytes
+// per store; chunkMeta = (walker, sequence number)); k_bwti_copy then moves every chunk to its place with
+// coalesced accesses.  A second walk would cost another cache line per byte.
 __global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V, int b0) {
   const int b = blockIdx.y + b0;
   const int n = V.n[b];
@@ -175,18 +183,44 @@ __global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V, int b0) {
   const int w = blockIdx.x * 64 + threadIdx.x;
   if (w > G) return;
   const u32* data = V.data + (int64_t)b * V.NS;
+  u8* pool = V.pool + (int64_t)b * V.maxChunks * BI_CH;
+  uint2* meta = V.chunkMeta + (int64_t)b * V.maxChunks;
   u32 t = (w < G) ? (u32)w << V.logS : (u32)(V.prim[b * 8] - 1);
   u32 steps = 0;
   int nxt = -2;
+  unsigned long long acc = 0;
+  u32 fill = BI_CH, seq = 0;              // bytes stored in the current chunk (BI_CH: none allocated yet)
+  u8* cp = nullptr;
+  bool full = false;
   while (steps <= (u32)n) {
     if (t >= (u32)n) break;                                   // corrupt link
     const u32 ptr = BI_LD(&data[t]);
+    acc |= (unsigned long long)(ptr & 0xFFu) << (8 * (steps & 7u));
     steps++;
+    if ((steps & 7u) == 0) {
+      if (fill == BI_CH) {
+        const u32 id = atomicAdd(&V.chunkCount[b], 1u);
+        if (id >= (u32)V.maxChunks) { full = true; break; }
+        meta[id] = make_uint2((u32)w, seq++);
+        cp = pool + (size_t)id * BI_CH;
+        fill = 0;
+      }
+      *(unsigned long long*)(cp + fill) = acc;
+      fill += 8; acc = 0;
+    }
     t = ptr >> 8;
     if (t == BI_END) { nxt = -1; break; }
     if ((t & (u32)(S - 1)) == 0) { nxt = (int)(t >> V.logS); break; }
   }
-  if (nxt == -2) { atomicExch(&V.status[b], -KZ_ERR_PROCESS_BLOCK); nxt = -1; }
+  if ((steps & 7u) != 0 && !full && nxt != -2) {              // partial tail
+    if (fill == BI_CH) {
+      const u32 id = atomicAdd(&V.chunkCount[b], 1u);
+      if (id >= (u32)V.maxChunks) full = true;
+      else { meta[id] = make_uint2((u32)w, seq++); cp = pool + (size_t)id * BI_CH; fill = 0; }
+    }
+    if (!full) *(unsigned long long*)(cp + fill) = acc;
+  }
+  if (nxt == -2 || full) { atomicExch(&V.status[b], -KZ_ERR_PROCESS_BLOCK); nxt = -1; }
   V.segLen[(int64_t)b * V.GS + w] = steps;
   V.segNext[(int64_t)b * V.GS + w] = nxt;
 }
@@ -223,45 +257,27 @@ __global__ __launch_bounds__(256) void k_bwti_resolve(BwtInv V, int b0) {
   for (int i = threadIdx.x; i < M; i += 256) V.segOff[o + i] = (R[i] <= (u32)n) ? (u32)n - R[i] : 0xFFFFFFFFu;
 }
 
-// pass 2: re-walk every segment and write its bytes at the resolved text offset
-__global__ __launch_bounds__(64) void k_bwti_walk2(u8* __restrict__ dst, int64_t stride, BwtInv V, int b0) {
+// move every recorded chunk to its place in the text: one wave per chunk, 4 bytes per lane
+typedef u32 __attribute__((aligned(1))) bi_u32_unaligned;
+__global__ __launch_bounds__(256) void k_bwti_copy(u8* __restrict__ dst, int64_t stride, BwtInv V, int b0) {
   const int b = blockIdx.y + b0;
   const int n = V.n[b];
   if (n < 2 || V.status[b] != 0) return;
-  const int S = 1 << V.logS;
-  const int G = (n + S - 1) >> V.logS;
-  const int w = blockIdx.x * 64 + threadIdx.x;
-  if (w > G) return;
-  const u32* data = V.data + (int64_t)b * V.NS;
-  u8* d = dst + (int64_t)b * stride;
-  u32 t = (w < G) ? (u32)w << V.logS : (u32)(V.prim[b * 8] - 1);
-  const u32 len = V.segLen[(int64_t)b * V.GS + w];
-  u32 off = V.segOff[(int64_t)b * V.GS + w];
+  const u32 id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (id >= V.chunkCount[b] || id >= (u32)V.maxChunks) return;
+  const int lane = threadIdx.x & 63;
+  const uint2 m = V.chunkMeta[(int64_t)b * V.maxChunks + id];
+  const u32 len = V.segLen[(int64_t)b * V.GS + m.x];
+  const u32 off = V.segOff[(int64_t)b * V.GS + m.x];
   if (off == 0xFFFFFFFFu || (unsigned long long)off + len > (unsigned long long)n) return;   // not on the text path
-  // bytes are packed into aligned 8-byte stores: a 1-byte store to a line nobody else is writing costs a
-  // whole 32 B write transaction
-  u32 k = 0;
-  while (k < len && ((off + k) & 7u)) {
-    const u32 ptr = BI_LD(&data[t]);
-    d[off + k] = (u8)ptr;
-    t = ptr >> 8;
-    k++;
-  }
-  for (; k + 8 <= len; k += 8) {
-    unsigned long long w = 0;
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const u32 ptr = BI_LD(&data[t]);
-      w |= (unsigned long long)(ptr & 0xFFu) << (8 * q);
-      t = ptr >> 8;
-    }
-    *(unsigned long long*)(d + off + k) = w;
-  }
-  for (; k < len; k++) {
-    const u32 ptr = BI_LD(&data[t]);
-    d[off + k] = (u8)ptr;
-    t = ptr >> 8;
-  }
+  const u32 start = m.y * BI_CH;
+  if (start >= len) return;
+  const u32 cnt = min((u32)BI_CH, len - start);
+  const u8* src = V.pool + ((int64_t)b * V.maxChunks + id) * BI_CH;
+  u8* d = dst + (int64_t)b * stride + off + start;
+  const u32 k = 4u * (u32)lane;
+  if (k + 4 <= cnt) *(bi_u32_unaligned*)(d + k) = *(const u32*)(src + k);
+  else for (u32 q = k; q < cnt; q++) d[q] = src[q];
 }
 
 __global__ void k_bwti_fin(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride, BwtInv V,
@@ -278,7 +294,8 @@ __global__ void k_bwti_fin(const u8* __restrict__ src, u8* __restrict__ dst, int
 size_t kz_bwt_inverse_scratch(int B, int maxN) {
   const int64_t NS = (int64_t)kz_align((size_t)maxN + 64, BI_TILE);
   const int T = (int)(NS / BI_TILE);
-  return (size_t)B * ((size_t)NS * 4 + (size_t)T * 1024 + 1024 + 64 * 4 + (size_t)BI_MAXSEG * 12) + 16384;
+  const size_t maxChunks = (size_t)NS / BI_CH + BI_MAXSEG + 8;
+  return (size_t)B * ((size_t)NS * 4 + (size_t)T * 1024 + 1024 + 64 * 4 + (size_t)BI_MAXSEG * 12 + maxChunks * (BI_CH + 8) + 512) + 16384;
 }
 
 int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
@@ -301,10 +318,15 @@ int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
   V.segLen = (u32*)kz_arena_alloc(ctx, (size_t)B * V.GS * 4);
   V.segNext = (int32_t*)kz_arena_alloc(ctx, (size_t)B * V.GS * 4);
   V.segOff = (u32*)kz_arena_alloc(ctx, (size_t)B * V.GS * 4);
-  if (!V.status || !V.data || !V.segOff) { snprintf(ctx->err, sizeof(ctx->err), "bwt_inverse: arena overflow"); return -KZ_ERR_DEVICE; }
+  V.maxChunks = (int)(V.NS / BI_CH) + V.GS + 4;
+  V.pool = (u8*)kz_arena_alloc(ctx, (size_t)B * V.maxChunks * BI_CH);
+  V.chunkMeta = (uint2*)kz_arena_alloc(ctx, (size_t)B * V.maxChunks * sizeof(uint2));
+  V.chunkCount = (u32*)kz_arena_alloc(ctx, (size_t)B * 4);
+  if (!V.status || !V.data || !V.segOff || !V.chunkCount || !V.pool || !V.chunkMeta) { snprintf(ctx->err, sizeof(ctx->err), "bwt_inverse: arena overflow"); return -KZ_ERR_DEVICE; }
   hipStream_t st = ctx->stream;
   const u8* src = bt.buf[bt.cur];
   u8* dst = bt.buf[bt.cur ^ 1];
+  KZ_HIP(hipMemsetAsync(V.chunkCount, 0, (size_t)B * 4, st));
   KZ_LAUNCH(ctx, KID_BWTI_PARSE, k_bwti_parse, dim3((B + 63) / 64), dim3(64), src, bt.stride, bt.d_len, V, B);
   const int tiles = (maxN + BI_TILE - 1) / BI_TILE;
   if (tiles > 0) {
@@ -325,7 +347,7 @@ int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
       const int nb = (B - b0 < group) ? B - b0 : group;
       KZ_LAUNCH(ctx, KID_BWTI_WALK1, k_bwti_walk1, dim3((V.GS + 63) / 64, nb), dim3(64), V, b0);
       KZ_LAUNCH(ctx, KID_BWTI_RESOLVE, k_bwti_resolve, dim3(nb), dim3(256), V, b0);
-      KZ_LAUNCH(ctx, KID_BWTI_WALK2, k_bwti_walk2, dim3((V.GS + 63) / 64, nb), dim3(64), dst, bt.stride, V, b0);
+      KZ_LAUNCH(ctx, KID_BWTI_COPY, k_bwti_copy, dim3((V.maxChunks + 3) / 4, nb), dim3(256), dst, bt.stride, V, b0);
     }
   }
   KZ_LAUNCH(ctx, KID_BWTI_FIN, k_bwti_fin, dim3((B + 255) / 256), dim3(256), src, dst, bt.stride, V, bt.d_len2, bt.d_flag, B);
