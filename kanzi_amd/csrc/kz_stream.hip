@@ -196,6 +196,44 @@ extern "C" int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t ent
   return (int64_t)((bs.pos + 7) >> 3);
 }
 
+
+// Host restatement of DecodingTask.readBlockHeader + the two checks that follow it
+// (CompressedInputStream.java:1025-1095, :1145-1164): the reference validates a block's header on the shared
+// bit stream BEFORE it reads the payload, so a truncated or tampered stream is reported with the header's error
+// (ERR_CRC_CHECK / ERR_BLOCK_SIZE / ERR_READ_FILE), not as a short read.  Returns 0 or -(error code).
+static int precheck_block_header(HostBitsIn bs /* by value: peek */, uint64_t W, int nbFunctions, int blockSize, int chkKind) {
+  if (W < 8) return -KZ_ERR_BLOCK_SIZE;
+  const uint32_t mode = (uint32_t)bs.get(8);
+  uint32_t skipFlags = 0;
+  bool hasSkip = false;
+  if (mode & 0x80) {
+    if (mode & 0x10) { if (nbFunctions > 4) hasSkip = true; else skipFlags = ((mode << 4) | 0x0F) & 0xFF; }
+  } else if (mode & 0x10) hasSkip = true;
+  else skipFlags = ((mode << 4) | 0x0F) & 0xFF;
+  const int dataSize = 1 + (int)((mode >> 5) & 3);
+  const int headerSize = 1 + (hasSkip ? 1 : 0) + dataSize + 1;
+  if (W < (uint64_t)headerSize * 8) return -KZ_ERR_BLOCK_SIZE;
+  if (hasSkip) skipFlags = (uint32_t)bs.get(8);
+  uint32_t preLen = 0;
+  for (int i = 0; i < dataSize; i++) preLen = (preLen << 8) | (uint32_t)bs.get(8);
+  const uint32_t ck = (uint32_t)bs.get(8);
+  if (bs.error) return -KZ_ERR_READ_FILE;
+  const uint32_t HASH = 0x1E35A7BDu;
+  uint32_t c = HASH * 0x01030507u;
+  c = mix32(c, HASH, mode & 0xFF);
+  c = mix32(c, HASH, skipFlags & 0xFF);
+  c = mix32(c, HASH, preLen);
+  c = mix32(c, HASH, (uint32_t)(W >> 32));
+  c = mix32(c, HASH, (uint32_t)W);
+  c = (c >> 23) ^ (c >> 3);
+  if (ck != (c & 0xFF)) return -KZ_ERR_CRC_CHECK;
+  const int64_t maxTL = std::min<int64_t>(std::max<int64_t>((int64_t)blockSize + blockSize / 2, 2048), 1LL << 30);
+  if ((int32_t)preLen < 0 || (int64_t)preLen > maxTL) return -KZ_ERR_READ_FILE;
+  const int checksumSize = (chkKind == 2) ? 8 : (chkKind == 1 ? 4 : 0);
+  if ((int64_t)((W + 7) >> 3) > (int64_t)preLen + headerSize + checksumSize) return -KZ_ERR_BLOCK_SIZE;
+  return 0;
+}
+
 extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstCap) {
   if (!ctx || !src || !dst || n < 0) return -KZ_ERR_INVALID_PARAM;
   HostBitsIn bs{src, (uint64_t)n * 8, 0, false};
@@ -216,6 +254,9 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
   ctx->checksum = chkKind;
   struct Restore { kz_ctx* c; int v; ~Restore() { c->checksum = v; } } restore_{ctx, savedChk};
   if (blockSize < 1024 || blockSize > (1 << 30)) return -KZ_ERR_BLOCK_SIZE;
+  int nbFunctions = 0;
+  for (int i = 0; i < 8; i++) if (((tt >> (42 - 6 * i)) & 0x3F) != 0) nbFunctions++;         // Sequence length (TransformFactory.java:240-266)
+  if (nbFunctions == 0) nbFunctions = 1;
   int NB = batch_blocks(blockSize);
   // no more staging than the stream can need: declared size if present, else >= 8 bytes of stream per block
   if (szMask && inputSize > 0) NB = (int)std::min<int64_t>(NB, (inputSize + blockSize - 1) / blockSize);
@@ -233,6 +274,7 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
       const uint64_t rd = bs.get(lr);
       if (bs.error) return -KZ_ERR_READ_FILE;
       if (rd == 0) { done = true; break; }
+      { const int hrc = precheck_block_header(bs, rd, nbFunctions, blockSize, chkKind); if (hrc) return hrc; }
       if ((int64_t)((rd + 7) >> 3) > iS - 64) return -KZ_ERR_BLOCK_SIZE;
       bs.getBytes(inbuf.get() + (size_t)cnt * iS, rd);
       if (bs.error) return -KZ_ERR_READ_FILE;

@@ -203,3 +203,96 @@ def test_block_checksums_match_oracle(ctx, bits):
     with pytest.raises(kz.KanziError) as e:
         kz.CompressedInputStream(ctx, bytes(bad)).read(len(data))
     assert e.value.code == 19
+
+
+# ---- mirrors of the reference's own stream tests (T = java/src/test/java/io/github/flanglet/kanzi/test) ----
+def _mix32(c, h, v):
+    c ^= (h * (~v & 0xFFFFFFFF)) & 0xFFFFFFFF
+    c = ((c << 13) | (c >> 19)) & 0xFFFFFFFF
+    return (c * 5 + 0x52DCE729) & 0xFFFFFFFF
+
+
+def _block_header_checksum(mode, skip_flags, length, encoded_block_length):      # T/TestCompressedStream.java:488-498
+    h = 0x1E35A7BD
+    c = (h * 0x01030507) & 0xFFFFFFFF
+    for v in (mode, skip_flags, length, encoded_block_length >> 32, encoded_block_length & 0xFFFFFFFF):
+        c = _mix32(c, h, v)
+    return ((c >> 23) ^ (c >> 3)) & 0xFF
+
+
+def _write_bits(buf, off, value, count):
+    for k in range(count):
+        bit = (value >> (count - 1 - k)) & 1
+        byte, sh = (off + k) >> 3, 7 - ((off + k) & 7)
+        buf[byte] = (buf[byte] & ~(1 << sh)) | (bit << sh)
+
+
+def _small_copy_stream(ctx):
+    cos = kz.CompressedOutputStream(ctx, "NONE", "NONE", 1024)
+    cos.write(bytes([1, 2, 3, 4, 5, 6, 7, 8]))
+    cos.close()
+    enc = cos.output
+    assert enc == oracle.compress("NONE", "NONE", 1024, bytes([1, 2, 3, 4, 5, 6, 7, 8]), jobs=1)
+    idx = kz.knz_index(enc)
+    boff, w = idx["blocks"][0]
+    lr = 3 if w < 8 else (w >> 3).bit_length() - 1 + 4
+    mode = kz.extract_bits(enc, boff, 8)[0]
+    assert mode & 0x80                                               # small blocks are copied
+    data_size = 1 + ((mode >> 5) & 3)
+    pre = int.from_bytes(kz.extract_bits(enc, boff + 8, 8 * data_size), "big")
+    return bytearray(enc), boff, w, lr, mode, data_size, pre
+
+
+def test_ref_bulk_read_end_of_stream(ctx):
+    """T/TestCompressedStream.java:98-120: 3 bytes, NONE/NONE, block size 1024."""
+    cos = kz.CompressedOutputStream(ctx, "NONE", "NONE", 1024)
+    cos.write(bytes([1, 2, 3]))
+    cos.close()
+    assert cos.output == oracle.compress("NONE", "NONE", 1024, bytes([1, 2, 3]), jobs=1)
+    assert kz.CompressedInputStream(ctx, cos.output).read() == bytes([1, 2, 3])
+
+
+def test_ref_block_header_checksum_checked_before_payload_read(ctx):
+    """T/TestCompressedStream.java:177-229: flip one bit of the block header checksum and cut the stream right
+    behind it: the decoder must report ERR_CRC_CHECK (19), not a short read."""
+    enc, boff, w, lr, mode, data_size, pre = _small_copy_stream(ctx)
+    ck_off = boff + 8 + 8 * data_size
+    enc[ck_off >> 3] ^= 1 << (7 - (ck_off & 7))
+    cut = bytes(enc[:(ck_off + 15) >> 3])
+    with pytest.raises(kz.KanziError) as e:
+        kz.CompressedInputStream(ctx, cut).read(16)
+    assert e.value.code == 19
+
+
+def test_ref_encoded_block_length_bound_checked_before_payload_read(ctx):
+    """T/TestCompressedStream.java:231-291: encoded block length + 8 with a matching header checksum, stream cut
+    behind the header: ERR_BLOCK_SIZE (2)."""
+    enc, boff, w, lr, mode, data_size, pre = _small_copy_stream(ctx)
+    assert w + 8 < (1 << lr)
+    _write_bits(enc, boff - lr, w + 8, lr)
+    ck_off = boff + 8 + 8 * data_size
+    _write_bits(enc, ck_off, _block_header_checksum(mode, 0, pre, w + 8), 8)
+    cut = bytes(enc[:(ck_off + 15) >> 3])
+    with pytest.raises(kz.KanziError) as e:
+        kz.CompressedInputStream(ctx, cut).read(16)
+    assert e.value.code == 2
+
+
+def test_ref_correctness_matrix(ctx):
+    """T/TestCompressedStream.java:57-96 testCorrectness: sizes 65536 << (test % 7), values from
+    java.util.Random(Long.MAX_VALUE).nextInt(4*test+1); compress1 = NONE & HUFFMAN, compress2 = LZX & FPAQ with a
+    random checksum kind; block size (length / (1 + nextInt(3))) & -16.  Every stream must equal the oracle's
+    (where the oracle is fast enough) and decode back to the input."""
+    rng = oracle.JavaRandom((1 << 63) - 1)
+    for test in (1, 2, 3, 6, 7, 13):
+        length = 65536 << (test % 7)
+        values = bytes(rng.next_int(4 * test + 1) for _ in range(min(length, 1 << 18)))
+        values = (values * (length // len(values) + 1))[:length]
+        for chain, ent, chk in (("NONE", "HUFFMAN", 0), ("LZX", "FPAQ", rng.next_int(3) * 32)):
+            bs = (length // (1 + rng.next_int(3))) & -16
+            cos = kz.CompressedOutputStream(ctx, chain, ent, bs, checksum=chk)
+            cos.write(values)
+            cos.close()
+            if length <= (1 << 20):
+                assert cos.output == oracle.compress(chain, ent, bs, values, jobs=4, checksum=chk), (test, chain, bs, chk)
+            assert kz.CompressedInputStream(ctx, cos.output).read() == values, (test, chain, bs, chk)
