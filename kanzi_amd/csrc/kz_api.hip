@@ -310,11 +310,19 @@ static size_t kz_arena_budget() {
 // stage scratch is bump-allocated after the ping-pong buffers; each stage allocates in turn, so the
 // arena must hold the SUM over the stages the chain actually runs
 struct ChainSpec { int types[8]; int nb; int entropy; };
+// The forward BWT (suffix sort) needs ~43 B of scratch per input byte, an order of magnitude more than any
+// other stage.  It therefore sorts the batch in groups that fit half the arena budget and reuses the scratch,
+// while every other stage (and the serial-per-block entropy coders in particular) sees the whole batch.
+static int bwt_group_blocks(int B, int maxLen) {
+  const size_t per = kz_bwt_forward_scratch(1, maxLen);
+  const int g = (int)std::max<size_t>(1, (kz_arena_budget() / 2) / per);
+  return std::min(g, B);
+}
 static size_t pipeline_scratch(int B, int maxLen, bool decode, const ChainSpec& C) {
   size_t s = 65536;
   for (int i = 0; i < C.nb; i++) {
     switch (C.types[i]) {
-      case KZ_T_BWT: s += decode ? kz_bwt_inverse_scratch(B, maxLen) : kz_bwt_forward_scratch(B, maxLen); break;
+      case KZ_T_BWT: s += decode ? kz_bwt_inverse_scratch(B, maxLen) : kz_bwt_forward_scratch(bwt_group_blocks(B, maxLen), maxLen); break;
       case KZ_T_RANK: case KZ_T_MTFT: s += kz_sbrt_scratch(B, maxLen); break;
       case KZ_T_ZRLT: s += kz_zrlt_scratch(B, maxLen); break;
       case KZ_T_SRT: s += decode ? 4096 : kz_srt_scratch(B, maxLen); break;
@@ -350,9 +358,30 @@ static int pipe_setup(kz_ctx* ctx, Pipe& P, int B, int maxLen, int64_t extraByte
   return 0;
 }
 
+static int bwt_forward_grouped(kz_ctx* ctx, kz_batch& bt) {
+  const int B = bt.B;
+  const int G = bwt_group_blocks(B, bt.maxN);
+  if (G >= B) return kz_stage_bwt_forward(ctx, bt);
+  const size_t mark = ctx->arenaTop;
+  for (int b0 = 0; b0 < B; b0 += G) {
+    const int cnt = std::min(G, B - b0);
+    kz_batch v;                                   // a view of blocks [b0, b0+cnt)
+    v.B = cnt; v.maxN = bt.maxN; v.stride = bt.stride; v.cur = bt.cur;
+    v.buf[0] = bt.buf[0] + (int64_t)b0 * bt.stride; v.buf[1] = bt.buf[1] + (int64_t)b0 * bt.stride;
+    v.d_len = bt.d_len + b0; v.d_len2 = bt.d_len2 + b0; v.d_flag = bt.d_flag + b0;
+    v.h_len.assign(bt.h_len.begin() + b0, bt.h_len.begin() + b0 + cnt);
+    ctx->arenaTop = mark;                         // the groups run back to back on one stream: reuse the scratch
+    const int rc = kz_stage_bwt_forward(ctx, v);
+    if (rc) return rc;
+  }
+  bt.cur ^= 1;
+  { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }
+  return 0;
+}
+
 static int run_transform_stage(kz_ctx* ctx, kz_batch& bt, int type, bool forward, int dstCap) {
   switch (type) {
-    case KZ_T_BWT: return forward ? kz_stage_bwt_forward(ctx, bt) : kz_stage_bwt_inverse(ctx, bt);
+    case KZ_T_BWT: return forward ? bwt_forward_grouped(ctx, bt) : kz_stage_bwt_inverse(ctx, bt);
     case KZ_T_RANK: return forward ? kz_stage_sbrt_forward(ctx, bt, 2) : kz_stage_sbrt_inverse(ctx, bt, 2);
     case KZ_T_MTFT: return forward ? kz_stage_sbrt_forward(ctx, bt, 1) : kz_stage_sbrt_inverse(ctx, bt, 1);
     case KZ_T_ZRLT: return forward ? kz_stage_zrlt_forward(ctx, bt) : kz_stage_zrlt_inverse(ctx, bt, dstCap);
@@ -392,8 +421,13 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   {
     // bound the scratch arena: the suffix sort needs ~43 B per input byte, so very large batches are
     // processed as consecutive sub-batches (blocks are independent; results are identical)
-    const size_t perBlock = pipeline_scratch(1, maxLen, false, CS) + (size_t)maxLen * 2 + (size_t)outStride + (1 << 16);
-    const int maxB = (int)std::max<size_t>(1, kz_arena_budget() / perBlock);
+    bool hasBwt = false;
+    for (int i = 0; i < nb; i++) hasBwt |= (types[i] == KZ_T_BWT);
+    ChainSpec noBwt = CS;
+    for (int i = 0; i < noBwt.nb; i++) if (noBwt.types[i] == KZ_T_BWT) noBwt.types[i] = KZ_T_NONE;
+    const size_t perBlock = pipeline_scratch(1, maxLen, false, noBwt) + (size_t)maxLen * 2 + 8192 + (size_t)(memKind == KZ_MEM_HOST ? outStride : 0) + (1 << 16);
+    const size_t avail = hasBwt ? kz_arena_budget() / 2 : kz_arena_budget();      // the other half: suffix-sort groups
+    const int maxB = (int)std::max<size_t>(1, avail / perBlock);
     if (B > maxB) {
       for (int b0 = 0; b0 < B; b0 += maxB) {
         const int cnt = std::min(maxB, B - b0);
