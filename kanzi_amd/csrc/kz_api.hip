@@ -333,7 +333,7 @@ static size_t pipeline_scratch(int B, int maxLen, bool decode, const ChainSpec& 
   if (C.entropy == KZ_E_ANS0 || C.entropy == KZ_E_HUFFMAN)
     s += decode ? (size_t)B * ((size_t)(maxLen / 16384 + 4) * 8 + 64) + 65536 : kz_ans_scratch(B, maxLen);
   else if (C.entropy == KZ_E_FPAQ)
-    s += decode ? 4096 : (size_t)B * kz_align((size_t)maxLen + (size_t)(maxLen >> 3) + 64, 256) + 4096;
+    s += decode ? 4096 : kz_fpaq_scratch(B, maxLen);
   return s;
 }
 
