@@ -25,8 +25,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 
 # kernel -> pipeline stage (for the algorithmic-byte attribution of SURVEY.md 8d)
 KERNEL_STAGE = {}
-for k in ("k_bwt_init", "k_radix_hist", "k_radix_scan", "k_radix_scatter", "k_bwt_newhead", "k_hp_reduce",
-          "k_hp_scan", "k_hp_apply", "k_flt_reduce", "k_flt_scan", "k_flt_apply", "k_bwt_emit"):
+for k in ("k_bwt_init", "k_radix_hist", "k_radix_scan", "k_radix_scatter", "k_seg_reduce", "k_seg_scan",
+          "k_seg_apply", "k_live_count", "k_live_scan", "k_live_emit", "k_bwt_emit"):
     KERNEL_STAGE[k] = "bwt_fwd"
 for k in ("k_sbrt_last2", "k_sbrt_scan", "k_sbrt_replay"):
     KERNEL_STAGE[k] = "sbrt_fwd"

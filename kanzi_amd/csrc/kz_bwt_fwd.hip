@@ -9,21 +9,31 @@
 // DivSufSort.java:217-224 and :233-325 (primary[k] = ISA[k*step] + 1).
 //
 // Per block b (n bytes), arrays live in HBM with stride NS elements:
-//   key[2] u64, val[2] u32 (suffix index), cpos[2] u32 (SA slot of the compact element),
-//   head[2] u8, rank u32 (= ISA as "group head slot"), sa u32.
-// Round r keeps only suffixes whose group is not yet a singleton ("compact" arrays of size m_b).
+//   key[2] u64, val[2] u32 (suffix index): the compact (still unsorted) suffixes, ping-pong for the radix passes
+//   rank u32: ISA as "head slot of the suffix's group", bit 31 = LIVE (group not yet a singleton);  sa u32.
+// A round with step h:
+//   1. text order (coalesced): every LIVE suffix s emits key = (rank[s] << bitsR) | (rank[s+h] + 1), val = s.
+//      Reading rank[s+h] in TEXT order makes both reads sequential; gathering it in SA order (the textbook
+//      formulation, and the first version of this file) costs a 128 B line per 4-byte rank and was the largest
+//      HBM consumer of the whole encoder (114 GB fetched per launch).  Scanning all n ranks each round costs less
+//      than gathering for n/16 live suffixes.
+//   2. radix sort of the compact pairs (old group = high key bits, so groups stay contiguous).
+//   3. SA order: the members of an old group g occupy the slots g, g+1, ... in sorted order; a new group starts
+//      wherever the key changes; rank[val] = new head slot | LIVE, and suffixes whose new group is a singleton are
+//      final: sa[slot] = val.  Two max-scans (old-group start index, new-group start index) give the slots.
 #include "kz_device.h"
 #include "kz_internal.h"
 
 #define RS_ITEMS 16
 #define RS_TILE (KZ_WG * RS_ITEMS)   // 4096 elements per workgroup
+#define BW_LIVE 0x80000000u
 
 typedef unsigned long long u64;
 typedef uint32_t u32;
 typedef uint8_t u8;
 
 struct BwtArrays {
-  u64* key[2]; u32* val[2]; u32* cpos[2]; u8* head[2]; u8* nhead;
+  u64* key[2]; u32* val[2];
   u32* rank; u32* sa;
   u32* tileHist;     // [B][T][256]
   u32* digitBase;    // [B][256]
@@ -32,7 +42,6 @@ struct BwtArrays {
   int32_t* d_n;      // [B] block length
   int32_t* d_m;      // [B] compact size (current)
   int32_t* d_m2;     // [B] compact size (next)
-  int32_t* d_g;      // [B] group count among compact (next)
   int64_t NS;        // element stride per block
   int T;             // tile stride per block
 };
@@ -40,21 +49,19 @@ struct BwtArrays {
 // ---------------------------------------------------------------------------------------------
 // round 0 keys: 7 data bytes (zero padded) + min(n-i,7): ties between a truncated suffix and a
 // longer one resolve "shorter first" exactly like plain string comparison.
-__global__ void k_bwt_init(const u8* __restrict__ src, int64_t srcStride, u64* keyC, u32* valC, u32* cposC, u8* headC, BwtArrays A) {
+__global__ void k_bwt_init(const u8* __restrict__ src, int64_t srcStride, u64* keyC, u32* valC, BwtArrays A) {
   const int b = blockIdx.y;
   const int n = A.d_n[b];
   const u8* s = src + (int64_t)b * srcStride;
   u64* key = keyC + (int64_t)b * A.NS;
   u32* val = valC + (int64_t)b * A.NS;
-  u32* cpos = cposC + (int64_t)b * A.NS;
-  u8* head = headC + (int64_t)b * A.NS;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     u64 k = 0;
     const int rem = n - i;
 #pragma unroll
     for (int j = 0; j < 7; j++) k = (k << 8) | (u64)((j < rem) ? s[i + j] : 0);
     k = (k << 8) | (u64)(rem < 7 ? rem : 7);
-    key[i] = k; val[i] = (u32)i; cpos[i] = (u32)i; head[i] = (i == 0) ? 1 : 0;
+    key[i] = k; val[i] = (u32)i;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { A.d_m[b] = n; }
 }
@@ -192,114 +199,36 @@ __global__ __launch_bounds__(KZ_WG) void k_radix_scatter(const u64* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// new group heads after a sort: old head (positional) or key differs from the predecessor
-__global__ void k_bwt_newhead(const u64* __restrict__ keyS, const u8* __restrict__ headOld, BwtArrays A) {
-  const int b = blockIdx.y;
-  const int m = A.d_m[b];
-  const int64_t off = (int64_t)b * A.NS;
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < m; c += gridDim.x * blockDim.x) {
-    u8 h = headOld[off + c];
-    if (!h && c > 0) h = (keyS[off + c] != keyS[off + c - 1]) ? 1 : 0;
-    if (c == 0) h = 1;
-    A.nhead[off + c] = h;
-  }
-}
+// step 3 (SA order, after the sort).  g(c) = old group head slot = key >> gshift (gshift >= 64: one group, slot 0).
+__device__ __forceinline__ u32 bw_group(u64 k, int gshift) { return gshift >= 64 ? 0u : (u32)(k >> gshift); }
 
-// scan A (max): per tile, the last head slot (c+1) in the tile
-__global__ __launch_bounds__(KZ_WG) void k_hp_reduce(BwtArrays A) {
+// per tile: (last index+1 where the old group changes, last index+1 where the key changes)
+__global__ __launch_bounds__(KZ_WG) void k_seg_reduce(const u64* __restrict__ keyS, BwtArrays A, int gshift) {
   const int b = blockIdx.y;
   const int m = A.d_m[b];
   const int tile = blockIdx.x;
   if ((int64_t)tile * RS_TILE >= m) return;
   __shared__ u32 lds[32];
-  const int64_t off = (int64_t)b * A.NS;
+  const u64* key = keyS + (int64_t)b * A.NS;
   const int base = tile * RS_TILE + threadIdx.x * RS_ITEMS;
-  u32 mx = 0;
-#pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) { const int c = base + r; if (c < m && A.nhead[off + c]) mx = (u32)c + 1; }
-  u32 total; kz_wg_incl_max(mx, lds, &total);
-  if (threadIdx.x == 0) A.tileA[(int64_t)b * A.T + tile] = total;
-}
-// per block: exclusive max-scan over tiles (serial per block: <= 1024 tiles) -- one wave per block
-__global__ void k_hp_scan(BwtArrays A) {
-  const int b = blockIdx.x;
-  const int m = A.d_m[b];
-  const int tiles = (m + RS_TILE - 1) / RS_TILE;
-  u32* t = A.tileA + (int64_t)b * A.T;
-  u32 carry = 0;
-  for (int base = 0; base < tiles; base += 64) {
-    const int i = base + threadIdx.x;
-    u32 v = (i < tiles) ? t[i] : 0;
-    u32 inc = kz_wave_incl_max(v);
-    u32 exc = __shfl_up(inc, 1, 64); if (threadIdx.x == 0) exc = 0;
-    exc = exc > carry ? exc : carry;
-    if (i < tiles) t[i] = exc;
-    u32 last = __shfl(inc, 63, 64);
-    carry = carry > last ? carry : last;
-  }
-}
-// apply: rank[val[c]] = cpos[headslot]
-__global__ __launch_bounds__(KZ_WG) void k_hp_apply(const u32* __restrict__ valS, const u32* __restrict__ cposOld, BwtArrays A) {
-  const int b = blockIdx.y;
-  const int m = A.d_m[b];
-  const int tile = blockIdx.x;
-  if ((int64_t)tile * RS_TILE >= m) return;
-  __shared__ u32 lds[32];
-  const int64_t off = (int64_t)b * A.NS;
-  const int base = tile * RS_TILE + threadIdx.x * RS_ITEMS;
-  u32 loc[RS_ITEMS];
-  u32 mx = 0;
-#pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) { const int c = base + r; if (c < m && A.nhead[off + c]) mx = (u32)c + 1; loc[r] = mx; }
-  u32 total;
-  u32 inc = kz_wg_incl_max(mx, lds, &total);
-  // exclusive prefix for this thread = max over previous threads
-  u32 prevT = __shfl_up(inc, 1, 64);
-  __shared__ u32 wlast[4];
-  if (kz_lane() == 63) wlast[threadIdx.x >> 6] = inc;
-  __syncthreads();
-  if (kz_lane() == 0) prevT = (threadIdx.x >> 6) ? wlast[(threadIdx.x >> 6) - 1] : 0;
-  const u32 carry = A.tileA[(int64_t)b * A.T + tile];
-  u32 pre = prevT > carry ? prevT : carry;
-  u32* rank = A.rank + off;
+  u32 ms = 0, mh = 0;
+  u64 prev = (base > 0 && base <= m) ? key[base - 1] : 0;
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
     const int c = base + r;
     if (c < m) {
-      u32 hs = loc[r] > pre ? loc[r] : pre;     // head slot + 1 (always >= 1 since c==0 is a head)
-      rank[valS[off + c]] = cposOld[off + hs - 1];
+      const u64 k = key[c];
+      if (c == 0 || k != prev) { mh = (u32)c + 1; if (c == 0 || bw_group(k, gshift) != bw_group(prev, gshift)) ms = (u32)c + 1; }
+      prev = k;
     }
   }
+  u32 ts, th;
+  kz_wg_incl_max(ms, lds, &ts);
+  kz_wg_incl_max(mh, lds, &th);
+  if (threadIdx.x == 0) { A.tileA[(int64_t)b * A.T + tile] = ts; A.tileB[(int64_t)b * A.T + tile] = th; }
 }
-
-// ---------------------------------------------------------------------------------------------
-// filter: keep[c] = element's new group is not a singleton.  Two counts are scanned together:
-// kept elements and kept heads (-> group ordinal).  Dropped elements are final: write SA.
-__device__ __forceinline__ bool kz_keep(const u8* nh, int c, int m) {
-  const bool h0 = nh[c] != 0;
-  const bool h1 = (c + 1 >= m) ? true : (nh[c + 1] != 0);
-  return !(h0 && h1);
-}
-__global__ __launch_bounds__(KZ_WG) void k_flt_reduce(BwtArrays A) {
-  const int b = blockIdx.y;
-  const int m = A.d_m[b];
-  const int tile = blockIdx.x;
-  if ((int64_t)tile * RS_TILE >= m) return;
-  __shared__ u32 lds[32];
-  const u8* nh = A.nhead + (int64_t)b * A.NS;
-  const int base = tile * RS_TILE + threadIdx.x * RS_ITEMS;
-  u32 ck = 0, ch = 0;
-#pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
-    const int c = base + r;
-    if (c < m && kz_keep(nh, c, m)) { ck++; if (nh[c]) ch++; }
-  }
-  u32 tk, th;
-  kz_wg_excl_sum(ck, lds, &tk);
-  kz_wg_excl_sum(ch, lds, &th);
-  if (threadIdx.x == 0) { A.tileA[(int64_t)b * A.T + tile] = tk; A.tileB[(int64_t)b * A.T + tile] = th; }
-}
-__global__ void k_flt_scan(BwtArrays A) {
+// per block: exclusive max-scans over the tiles -- one wave per block
+__global__ void k_seg_scan(BwtArrays A) {
   const int b = blockIdx.x;
   const int m = A.d_m[b];
   const int tiles = (m + RS_TILE - 1) / RS_TILE;
@@ -308,59 +237,134 @@ __global__ void k_flt_scan(BwtArrays A) {
   u32 ca = 0, cb = 0;
   for (int base = 0; base < tiles; base += 64) {
     const int i = base + threadIdx.x;
-    u32 va = (i < tiles) ? ta[i] : 0, vb = (i < tiles) ? tb[i] : 0;
-    u32 ia = kz_wave_incl_sum(va), ib = kz_wave_incl_sum(vb);
-    if (i < tiles) { ta[i] = ca + ia - va; tb[i] = cb + ib - vb; }
-    ca += __shfl(ia, 63, 64); cb += __shfl(ib, 63, 64);
+    const u32 va = (i < tiles) ? ta[i] : 0, vb = (i < tiles) ? tb[i] : 0;
+    const u32 ia = kz_wave_incl_max(va), ib = kz_wave_incl_max(vb);
+    u32 ea = __shfl_up(ia, 1, 64), eb = __shfl_up(ib, 1, 64);
+    if (threadIdx.x == 0) { ea = 0; eb = 0; }
+    ea = ea > ca ? ea : ca; eb = eb > cb ? eb : cb;
+    if (i < tiles) { ta[i] = ea; tb[i] = eb; }
+    const u32 la = __shfl(ia, 63, 64), lb = __shfl(ib, 63, 64);
+    ca = ca > la ? ca : la; cb = cb > lb ? cb : lb;
   }
-  if (threadIdx.x == 0) { A.d_m2[b] = (int32_t)ca; A.d_g[b] = (int32_t)cb; }
 }
-// apply: compaction + next-round key gather (rank[] is final for this round: k_hp_apply ran before)
-__global__ __launch_bounds__(KZ_WG) void k_flt_apply(const u32* __restrict__ valS, const u32* __restrict__ cposOld,
-                                                      u64* __restrict__ keyN, u32* __restrict__ valN,
-                                                      u32* __restrict__ cposN, u8* __restrict__ headN,
-                                                      BwtArrays A, int hNext, int bitsR) {
+// apply: slot = g + (c - segment start); new rank = g + (new-group start - segment start); LIVE unless the new
+// group is a singleton, in which case the suffix is final
+__global__ __launch_bounds__(KZ_WG) void k_seg_apply(const u64* __restrict__ keyS, const u32* __restrict__ valS, BwtArrays A, int gshift) {
   const int b = blockIdx.y;
   const int m = A.d_m[b];
-  const int n = A.d_n[b];
   const int tile = blockIdx.x;
   if ((int64_t)tile * RS_TILE >= m) return;
   __shared__ u32 lds[32];
+  __shared__ u32 wlastS[4], wlastH[4];
   const int64_t off = (int64_t)b * A.NS;
-  const u8* nh = A.nhead + off;
+  const u64* key = keyS + off;
   const int base = tile * RS_TILE + threadIdx.x * RS_ITEMS;
-  u32 ck = 0, ch = 0;
+  u64 k[RS_ITEMS + 1];
+  u32 locS[RS_ITEMS], locH[RS_ITEMS];
+  u32 ms = 0, mh = 0;
+  u64 prev = (base > 0 && base <= m) ? key[base - 1] : 0;
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
     const int c = base + r;
-    if (c < m && kz_keep(nh, c, m)) { ck++; if (nh[c]) ch++; }
+    k[r] = (c < m) ? key[c] : 0;
+    if (c < m) {
+      if (c == 0 || k[r] != prev) { mh = (u32)c + 1; if (c == 0 || bw_group(k[r], gshift) != bw_group(prev, gshift)) ms = (u32)c + 1; }
+      prev = k[r];
+    }
+    locS[r] = ms; locH[r] = mh;
   }
-  u32 tk, th;
-  u32 ek = kz_wg_excl_sum(ck, lds, &tk);
-  u32 eh = kz_wg_excl_sum(ch, lds, &th);
-  ek += A.tileA[(int64_t)b * A.T + tile];
-  eh += A.tileB[(int64_t)b * A.T + tile];
-  const u32* rank = A.rank + off;
+  k[RS_ITEMS] = (base + RS_ITEMS < m) ? key[base + RS_ITEMS] : 0;
+  u32 tot;
+  const u32 incS = kz_wg_incl_max(ms, lds, &tot);
+  const u32 incH = kz_wg_incl_max(mh, lds, &tot);
+  // exclusive prefix for this thread = max over the previous threads of the tile
+  u32 preS = __shfl_up(incS, 1, 64), preH = __shfl_up(incH, 1, 64);
+  if (kz_lane() == 63) { wlastS[threadIdx.x >> 6] = incS; wlastH[threadIdx.x >> 6] = incH; }
+  __syncthreads();
+  if (kz_lane() == 0) {
+    const int w = threadIdx.x >> 6;
+    preS = w ? wlastS[w - 1] : 0; preH = w ? wlastH[w - 1] : 0;
+  }
+  const u32 carS = A.tileA[(int64_t)b * A.T + tile], carH = A.tileB[(int64_t)b * A.T + tile];
+  preS = preS > carS ? preS : carS; preH = preH > carH ? preH : carH;
+  u32* rank = A.rank + off;
   u32* sa = A.sa + off;
+  const u32* val = valS + off;
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
     const int c = base + r;
-    if (c >= m) break;
-    const u32 sv = valS[off + c];
-    const u32 cp = cposOld[off + c];
-    if (kz_keep(nh, c, m)) {
-      const bool hd = nh[c] != 0;
-      if (hd) eh++;
-      const u32 gord = eh - 1;               // ordinal of this element's group among kept groups
-      const int64_t j = (int64_t)sv + hNext;
-      const u64 r2 = (j < n) ? (u64)rank[j] + 1ULL : 0ULL;
-      keyN[off + ek] = ((u64)gord << bitsR) | r2;
-      valN[off + ek] = sv;
-      cposN[off + ek] = cp;
-      headN[off + ek] = hd ? 1 : 0;
-      ek++;
-    } else {
-      sa[cp] = sv;                           // singleton group: final position
+    if (c < m) {
+      const u32 ss = (locS[r] > preS ? locS[r] : preS) - 1;          // index of the old group's first element (c = 0 starts one)
+      const u32 hh = (locH[r] > preH ? locH[r] : preH) - 1;          // index of the new group's first element
+      const u32 g = bw_group(k[r], gshift);
+      const bool headC = hh == (u32)c;
+      const bool headN = (c + 1 >= m) || (k[r + 1] != k[r]);
+      const u32 sv = val[c];
+      const bool live = !(headC && headN);
+      rank[sv] = (g + (hh - ss)) | (live ? BW_LIVE : 0u);
+      if (!live) sa[g + ((u32)c - ss)] = sv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// step 1 (text order): compact the LIVE suffixes and build their keys from sequential rank reads
+__global__ __launch_bounds__(KZ_WG) void k_live_count(BwtArrays A) {
+  const int b = blockIdx.y;
+  const int n = A.d_n[b];
+  const int tile = blockIdx.x;
+  if ((int64_t)tile * RS_TILE >= n) return;
+  __shared__ u32 lds[32];
+  const u32* rank = A.rank + (int64_t)b * A.NS;
+  u32 cnt = 0;
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    const int s = tile * RS_TILE + r * KZ_WG + threadIdx.x;          // coalesced
+    if (s < n && (rank[s] & BW_LIVE)) cnt++;
+  }
+  u32 tot;
+  kz_wg_excl_sum(cnt, lds, &tot);
+  if (threadIdx.x == 0) A.tileA[(int64_t)b * A.T + tile] = tot;
+}
+__global__ void k_live_scan(BwtArrays A) {
+  const int b = blockIdx.x;
+  const int n = A.d_n[b];
+  const int tiles = (n + RS_TILE - 1) / RS_TILE;
+  u32* ta = A.tileA + (int64_t)b * A.T;
+  u32 ca = 0;
+  for (int base = 0; base < tiles; base += 64) {
+    const int i = base + threadIdx.x;
+    const u32 va = (i < tiles) ? ta[i] : 0;
+    const u32 ia = kz_wave_incl_sum(va);
+    if (i < tiles) ta[i] = ca + ia - va;
+    ca += __shfl(ia, 63, 64);
+  }
+  if (threadIdx.x == 0) A.d_m2[b] = (int32_t)ca;
+}
+__global__ __launch_bounds__(KZ_WG) void k_live_emit(u64* __restrict__ keyN, u32* __restrict__ valN, BwtArrays A, int h, int bitsR) {
+  const int b = blockIdx.y;
+  const int n = A.d_n[b];
+  const int tile = blockIdx.x;
+  if ((int64_t)tile * RS_TILE >= n) return;
+  __shared__ u32 lds[32];
+  const int64_t off = (int64_t)b * A.NS;
+  const u32* rank = A.rank + off;
+  const int base = tile * RS_TILE + threadIdx.x * RS_ITEMS;          // 16 consecutive suffixes per thread: text order kept
+  u32 rk[RS_ITEMS];
+  u32 cnt = 0;
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) { const int s = base + r; rk[r] = (s < n) ? rank[s] : 0u; cnt += (rk[r] & BW_LIVE) ? 1u : 0u; }
+  u32 tot;
+  u32 pos = kz_wg_excl_sum(cnt, lds, &tot) + A.tileA[(int64_t)b * A.T + tile];
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    if (rk[r] & BW_LIVE) {
+      const int s = base + r;
+      const int64_t j = (int64_t)s + h;
+      const u64 r2 = (j < n) ? (u64)(rank[j] & ~BW_LIVE) + 1ULL : 0ULL;
+      keyN[off + pos] = ((u64)(rk[r] & ~BW_LIVE) << bitsR) | r2;
+      valN[off + pos] = (u32)s;
+      pos++;
     }
   }
 }
@@ -412,7 +416,7 @@ __global__ void k_bwt_emit(const u8* __restrict__ src, int64_t srcStride, u8* __
 size_t kz_bwt_forward_scratch(int B, int maxN) {
   const int64_t NS = (int64_t)kz_align((size_t)maxN, RS_TILE);
   const int T = (int)(NS / RS_TILE);
-  size_t per = (size_t)NS * (8 * 2 + 4 * 2 + 4 * 2 + 1 * 3 + 4 + 4) + (size_t)T * (256 * 4 + 8) + 256 * 4 + 64;
+  size_t per = (size_t)NS * (8 * 2 + 4 * 2 + 4 + 4) + (size_t)T * (256 * 4 + 8) + 256 * 4 + 64 + 8 * 256;
   return kz_align(per * (size_t)B + 4096 * 16, 4096) + (1 << 20);
 }
 
@@ -429,10 +433,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
   for (int i = 0; i < 2; i++) {
     A.key[i] = (u64*)kz_arena_alloc(ctx, (size_t)NS * B * 8);
     A.val[i] = (u32*)kz_arena_alloc(ctx, (size_t)NS * B * 4);
-    A.cpos[i] = (u32*)kz_arena_alloc(ctx, (size_t)NS * B * 4);
-    A.head[i] = (u8*)kz_arena_alloc(ctx, (size_t)NS * B);
   }
-  A.nhead = (u8*)kz_arena_alloc(ctx, (size_t)NS * B);
   A.rank = (u32*)kz_arena_alloc(ctx, (size_t)NS * B * 4);
   A.sa = (u32*)kz_arena_alloc(ctx, (size_t)NS * B * 4);
   A.tileHist = (u32*)kz_arena_alloc(ctx, (size_t)T * B * 256 * 4);
@@ -441,8 +442,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
   A.tileB = (u32*)kz_arena_alloc(ctx, (size_t)T * B * 4);
   A.d_m = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   A.d_m2 = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
-  A.d_g = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
-  if (!A.d_g || !A.tileB || !A.sa) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: arena overflow"); return -KZ_ERR_DEVICE; }
+  if (!A.d_m2 || !A.tileB || !A.sa) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: arena overflow"); return -KZ_ERR_DEVICE; }
   A.d_n = bt.d_len;
   hipStream_t st = ctx->stream;
   const u8* src = bt.buf[bt.cur];
@@ -450,17 +450,18 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
 
   int bitsR = 1;
   while ((1LL << bitsR) < (int64_t)maxN + 2) bitsR++;
+  int bitsG = 1;
+  while ((1LL << bitsG) < (int64_t)maxN) bitsG++;
 
   u64 *kC = A.key[0], *kF = A.key[1];
   u32 *vC = A.val[0], *vF = A.val[1];
-  u32 *cposC = A.cpos[0], *cposF = A.cpos[1];
-  u8 *headC = A.head[0], *headF = A.head[1];
-  KZ_LAUNCH(ctx, KID_BWT_INIT, k_bwt_init, dim3(gridFor(maxN, 256 * 8), B), dim3(256), src, bt.stride, kC, vC, cposC, headC, A);
-  int mMax = maxN, gMax = 1;
+  KZ_LAUNCH(ctx, KID_BWT_INIT, k_bwt_init, dim3(gridFor(maxN, 256 * 8), B), dim3(256), src, bt.stride, kC, vC, A);
+  int mMax = maxN;
   int h = 0;
+  const int tilesN = gridFor(maxN, RS_TILE);
   for (int round = 0; round < 64 && mMax > 0; round++) {
     // ---- sort (kC,vC): LSD radix, 8-bit digits, ping-pong with the free pair ----
-    const int nbits = (round == 0) ? 64 : bitsR + (gMax > 1 ? (32 - __builtin_clz((unsigned)(gMax - 1))) : 0);
+    const int nbits = (round == 0) ? 64 : bitsR + bitsG;
     const int passes = (nbits + 7) / 8;
     const int tiles = gridFor(mMax, RS_TILE);
     for (int p = 0; p < passes; p++) {
@@ -470,23 +471,22 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
       u64* tk = kC; kC = kF; kF = tk;
       u32* tv = vC; vC = vF; vF = tv;
     }
-    // sorted data in (kC, vC); (kF, vF) is free
-    KZ_LAUNCH(ctx, KID_BWT_NEWHEAD, k_bwt_newhead, dim3(gridFor(mMax, 256 * 8), B), dim3(256), kC, headC, A);
-    KZ_LAUNCH(ctx, KID_HP_REDUCE, k_hp_reduce, dim3(tiles, B), dim3(KZ_WG), A);
-    KZ_LAUNCH(ctx, KID_HP_SCAN, k_hp_scan, dim3(B), dim3(64), A);
-    KZ_LAUNCH(ctx, KID_HP_APPLY, k_hp_apply, dim3(tiles, B), dim3(KZ_WG), vC, cposC, A);
-    KZ_LAUNCH(ctx, KID_FLT_REDUCE, k_flt_reduce, dim3(tiles, B), dim3(KZ_WG), A);
-    KZ_LAUNCH(ctx, KID_FLT_SCAN, k_flt_scan, dim3(B), dim3(64), A);
+    // ---- SA order: new groups, ranks, final suffixes ----
+    const int gshift = (round == 0) ? 64 : bitsR;
+    KZ_LAUNCH(ctx, KID_SEG_REDUCE, k_seg_reduce, dim3(tiles, B), dim3(KZ_WG), kC, A, gshift);
+    KZ_LAUNCH(ctx, KID_SEG_SCAN, k_seg_scan, dim3(B), dim3(64), A);
+    KZ_LAUNCH(ctx, KID_SEG_APPLY, k_seg_apply, dim3(tiles, B), dim3(KZ_WG), kC, vC, A, gshift);
+    // ---- text order: compact the live suffixes, keys for the next round ----
     h = (round == 0) ? 7 : h * 2;
-    KZ_LAUNCH(ctx, KID_FLT_APPLY, k_flt_apply, dim3(tiles, B), dim3(KZ_WG), vC, cposC, kF, vF, cposF, headF, A, h, bitsR);
+    KZ_LAUNCH(ctx, KID_LIVE_COUNT, k_live_count, dim3(tilesN, B), dim3(KZ_WG), A);
+    KZ_LAUNCH(ctx, KID_LIVE_SCAN, k_live_scan, dim3(B), dim3(64), A);
+    KZ_LAUNCH(ctx, KID_LIVE_EMIT, k_live_emit, dim3(tilesN, B), dim3(KZ_WG), kF, vF, A, h, bitsR);
     { u64* tk = kC; kC = kF; kF = tk; u32* tv = vC; vC = vF; vF = tv; }
-    { u32* tc = cposC; cposC = cposF; cposF = tc; u8* th = headC; headC = headF; headF = th; }
-    // ---- read back sizes (next compact size / group count per block) ----
+    // ---- read back the next compact sizes ----
     KZ_HIP(hipMemcpyAsync(ctx->hpin, A.d_m2, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    KZ_HIP(hipMemcpyAsync(ctx->hpin + B, A.d_g, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     KZ_HIP(hipStreamSynchronize(st));
-    mMax = 0; gMax = 1;
-    for (int b = 0; b < B; b++) { if (ctx->hpin[b] > mMax) mMax = ctx->hpin[b]; if (ctx->hpin[B + b] > gMax) gMax = ctx->hpin[B + b]; }
+    mMax = 0;
+    for (int b = 0; b < B; b++) if (ctx->hpin[b] > mMax) mMax = ctx->hpin[b];
     int32_t* tm = A.d_m; A.d_m = A.d_m2; A.d_m2 = tm;
   }
   if (mMax > 0) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: suffix sort did not converge"); return -KZ_ERR_PROCESS_BLOCK; }
