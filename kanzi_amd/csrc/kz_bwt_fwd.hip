@@ -47,8 +47,9 @@ struct BwtArrays {
 };
 
 // ---------------------------------------------------------------------------------------------
-// round 0 keys: 7 data bytes (zero padded) + min(n-i,7): ties between a truncated suffix and a
-// longer one resolve "shorter first" exactly like plain string comparison.
+// round 0 keys: the first 7 bytes, zero padded at the end of the text.  A truncated suffix can therefore share a
+// group with suffixes that continue with real zero bytes; it is a prefix of all of them, must sort first, and
+// does: k_live_emit gives positions past the end of the text the smallest, distinct secondary keys.
 __global__ void k_bwt_init(const u8* __restrict__ src, int64_t srcStride, u64* keyC, u32* valC, BwtArrays A) {
   const int b = blockIdx.y;
   const int n = A.d_n[b];
@@ -60,8 +61,7 @@ __global__ void k_bwt_init(const u8* __restrict__ src, int64_t srcStride, u64* k
     const int rem = n - i;
 #pragma unroll
     for (int j = 0; j < 7; j++) k = (k << 8) | (u64)((j < rem) ? s[i + j] : 0);
-    k = (k << 8) | (u64)(rem < 7 ? rem : 7);
-    key[i] = k; val[i] = (u32)i;
+    key[i] = k; val[i] = (u32)i;                                    // 56 bits: 7 radix passes
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { A.d_m[b] = n; }
 }
@@ -361,7 +361,8 @@ __global__ __launch_bounds__(KZ_WG) void k_live_emit(u64* __restrict__ keyN, u32
     if (rk[r] & BW_LIVE) {
       const int s = base + r;
       const int64_t j = (int64_t)s + h;
-      const u64 r2 = (j < n) ? (u64)(rank[j] & ~BW_LIVE) + 1ULL : 0ULL;
+      // positions past the end (s + h >= n): n - s in [1, min(h, n)], smaller for the shorter suffix and below every real rank
+      const u64 r2 = (j < n) ? (u64)(rank[j] & ~BW_LIVE) + (u64)min(h, n) + 1ULL : (u64)(n - s);
       keyN[off + pos] = ((u64)(rk[r] & ~BW_LIVE) << bitsR) | r2;
       valN[off + pos] = (u32)s;
       pos++;
@@ -449,7 +450,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
   u8* dst = bt.buf[bt.cur ^ 1];
 
   int bitsR = 1;
-  while ((1LL << bitsR) < (int64_t)maxN + 2) bitsR++;
+  while ((1LL << bitsR) < 2 * (int64_t)maxN + 2) bitsR++;         // secondary key < n + h + 1 <= 2n + 1
   int bitsG = 1;
   while ((1LL << bitsG) < (int64_t)maxN) bitsG++;
 
@@ -461,7 +462,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
   const int tilesN = gridFor(maxN, RS_TILE);
   for (int round = 0; round < 64 && mMax > 0; round++) {
     // ---- sort (kC,vC): LSD radix, 8-bit digits, ping-pong with the free pair ----
-    const int nbits = (round == 0) ? 64 : bitsR + bitsG;
+    const int nbits = (round == 0) ? 56 : bitsR + bitsG;
     const int passes = (nbits + 7) / 8;
     const int tiles = gridFor(mMax, RS_TILE);
     for (int p = 0; p < passes; p++) {
