@@ -116,36 +116,39 @@ __global__ __launch_bounds__(256) void k_radix_scan(BwtArrays A) {
 // then reordered IN LDS (keys, then values through the same 32 KiB buffer) so that consecutive threads
 // store consecutive elements of each digit run: a wave store touches a few 128 B lines instead of up
 // to 64 scattered 8 B / 4 B segments (the pass is bound by memory transactions, not bytes).
-__global__ __launch_bounds__(KZ_WG) void k_radix_scatter(const u64* __restrict__ keyIn, const u32* __restrict__ valIn,
-                                                          u64* __restrict__ keyOut, u32* __restrict__ valOut,
-                                                          BwtArrays A, int shift) {
+#define RSC_WAVES 8                       // scatter workgroup: 8 waves x 8 rows of 64 keys = the same 4096-key tile
+#define RSC_ITEMS (RS_TILE / (64 * RSC_WAVES))
+#define RSC_WG (64 * RSC_WAVES)
+__global__ __launch_bounds__(RSC_WG) void k_radix_scatter(const u64* __restrict__ keyIn, const u32* __restrict__ valIn,
+                                                           u64* __restrict__ keyOut, u32* __restrict__ valOut,
+                                                           BwtArrays A, int shift) {
   const int b = blockIdx.y;
   const int m = A.d_m[b];
   const int tile = blockIdx.x;
   if ((int64_t)tile * RS_TILE >= m) return;
-  __shared__ u32 cnt[4][256];
+  __shared__ u32 cnt[RSC_WAVES][256];
   __shared__ u32 gdelta[256];        // global slot of the digit's first element of this tile - its tile-local slot
   __shared__ u32 scan[32];
   __shared__ u64 stage[RS_TILE];     // 32 KiB: keys, then values
-  for (int i = threadIdx.x; i < 1024; i += KZ_WG) (&cnt[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < RSC_WAVES * 256; i += RSC_WG) (&cnt[0][0])[i] = 0;
   __syncthreads();
   const int64_t off = (int64_t)b * A.NS;
   const int wave = threadIdx.x >> 6;
   const int lane = kz_lane();
   const int tbase = tile * RS_TILE;
-  const int base = tbase + wave * (64 * RS_ITEMS);
+  const int base = tbase + wave * (64 * RSC_ITEMS);
   const int tcount = min(RS_TILE, m - tbase);
   const uint64_t lt = kz_lanemask_lt();
-  u64 k[RS_ITEMS]; u32 v[RS_ITEMS]; u32 dr[RS_ITEMS];   // dr = digit | (rank<<8), later the tile-local slot
+  u64 k[RSC_ITEMS]; u32 v[RSC_ITEMS]; u32 dr[RSC_ITEMS];   // dr = digit | (rank<<8), later the tile-local slot
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
+  for (int r = 0; r < RSC_ITEMS; r++) {
     const int idx = base + r * 64 + lane;
     const bool valid = idx < m;
     k[r] = valid ? keyIn[off + idx] : 0;
     v[r] = valid ? valIn[off + idx] : 0;
   }
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
+  for (int r = 0; r < RSC_ITEMS; r++) {
     const int idx = base + r * 64 + lane;
     const bool valid = idx < m;
     const u32 d = (u32)((k[r] >> shift) & 0xFF);
@@ -159,24 +162,32 @@ __global__ __launch_bounds__(KZ_WG) void k_radix_scatter(const u64* __restrict__
   }
   __syncthreads();
   {
-    const int d = threadIdx.x;
-    const u32 c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
+    u32 tot = 0;
+    u32 c[RSC_WAVES];
+    const int d = threadIdx.x & 255;
+#pragma unroll
+    for (int w = 0; w < RSC_WAVES; w++) { c[w] = cnt[w][d]; tot += c[w]; }
     u32 total;
-    const u32 ts = kz_wg_excl_sum(c0 + c1 + c2 + c3, scan, &total);
-    gdelta[d] = A.digitBase[b * 256 + d] + A.tileHist[((int64_t)b * A.T + tile) * 256 + d] - ts;
-    cnt[0][d] = ts; cnt[1][d] = ts + c0; cnt[2][d] = ts + c0 + c1; cnt[3][d] = ts + c0 + c1 + c2;
+    // exclusive scan over the 256 digits (threads 256..511 carry zero and are ignored)
+    const u32 ts = kz_wg_excl_sum(threadIdx.x < 256 ? tot : 0u, scan, &total);
+    if (threadIdx.x < 256) {
+      gdelta[d] = A.digitBase[b * 256 + d] + A.tileHist[((int64_t)b * A.T + tile) * 256 + d] - ts;
+      u32 run = ts;
+#pragma unroll
+      for (int w = 0; w < RSC_WAVES; w++) { cnt[w][d] = run; run += c[w]; }
+    }
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
+  for (int r = 0; r < RSC_ITEMS; r++) {
     const int idx = base + r * 64 + lane;
     if (idx < m) { const u32 slot = cnt[wave][dr[r] & 0xFF] + (dr[r] >> 8); dr[r] = slot; stage[slot] = k[r]; }
   }
   __syncthreads();
-  u32 gp[RS_ITEMS];
+  u32 gp[RSC_ITEMS];
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
-    const int slot = r * KZ_WG + threadIdx.x;
+  for (int r = 0; r < RSC_ITEMS; r++) {
+    const int slot = r * RSC_WG + threadIdx.x;
     if (slot < tcount) {
       const u64 kk = stage[slot];
       gp[r] = gdelta[(u32)((kk >> shift) & 0xFF)] + (u32)slot;
@@ -186,14 +197,14 @@ __global__ __launch_bounds__(KZ_WG) void k_radix_scatter(const u64* __restrict__
   __syncthreads();
   u32* stageV = (u32*)stage;
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
+  for (int r = 0; r < RSC_ITEMS; r++) {
     const int idx = base + r * 64 + lane;
     if (idx < m) stageV[dr[r]] = v[r];
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
-    const int slot = r * KZ_WG + threadIdx.x;
+  for (int r = 0; r < RSC_ITEMS; r++) {
+    const int slot = r * RSC_WG + threadIdx.x;
     if (slot < tcount) valOut[off + gp[r]] = stageV[slot];
   }
 }
@@ -468,7 +479,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
     for (int p = 0; p < passes; p++) {
       KZ_LAUNCH(ctx, KID_RADIX_HIST, k_radix_hist, dim3(tiles, B), dim3(KZ_WG), kC, A, p * 8);
       KZ_LAUNCH(ctx, KID_RADIX_SCAN, k_radix_scan, dim3(B), dim3(256), A);
-      KZ_LAUNCH(ctx, KID_RADIX_SCATTER, k_radix_scatter, dim3(tiles, B), dim3(KZ_WG), kC, vC, kF, vF, A, p * 8);
+      KZ_LAUNCH(ctx, KID_RADIX_SCATTER, k_radix_scatter, dim3(tiles, B), dim3(RSC_WG), kC, vC, kF, vF, A, p * 8);
       u64* tk = kC; kC = kF; kF = tk;
       u32* tv = vC; vC = vF; vF = tv;
     }
