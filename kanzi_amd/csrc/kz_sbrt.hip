@@ -303,6 +303,47 @@ __global__ __launch_bounds__(64) void k_sbrt_inverse_v4(const u8* __restrict__ s
     const u64 ok = K[fs];                                                                      \
     K[fs] = (lane == (int)(f & 63u)) ? (((u64)fq << 32) | (u64)fplo) : ok; }
 
+// One non-zero rank at row position JV (iv = row + JV).  WRITE_OUT stores the decoded symbol c in lane JV of outv.
+#define KZ_SBRT_NZ_STEP(JV, WRITE_OUT)                                                         \
+  { const u32 r = (u32)__builtin_amdgcn_readlane((int)cur, (JV));                              \
+    const u32 w = (u32)__builtin_amdgcn_readlane((int)ord, (int)(r >> 2));                     \
+    const u32 c = (w >> ((r & 3u) * 8u)) & 0xFFu;                                              \
+    const int cl = (int)(c & 63u), cs = (int)(c >> 6);                                         \
+    const u64 ok = K[cs];                                                                      \
+    const u32 plo = (u32)__builtin_amdgcn_readlane((int)(u32)ok, cl);                          \
+    const u32 pc = max(plo, 256u) - 256u;                                                      \
+    const u32 iv = (u32)(row + (JV));                                                          \
+    const u32 nhi = (MODE == 2) ? ((iv + pc) >> 1) : ((MODE == 1) ? iv : pc);                  \
+    const u32 nlo = iv + 256u;                                                                 \
+    const u64 nk = ((u64)nhi << 32) | (u64)nlo;                                                \
+    /* new position = number of keys above the new key (the moved symbol's old key is below it) */ \
+    const u32 rp = (u32)(__builtin_popcountll(kz_ballot(K[0] > nk)) + __builtin_popcountll(kz_ballot(K[1] > nk)) + \
+                         __builtin_popcountll(kz_ballot(K[2] > nk)) + __builtin_popcountll(kz_ballot(K[3] > nk))); \
+    K[cs] = (lane == cl) ? nk : ok;                                                            \
+    /* rotate list positions [rp, r]: (rp, r] take their predecessor, rp takes c */            \
+    const u32 prevw = KZ_DPP_SHR1_Z(ord);                                                      \
+    const int sx = (24 - 8 * (int)r) + v32l, sy = (24 - 8 * (int)rp) + v32l;                   \
+    const u32 lmx = 0x01010101u >> (u32)min(max(sx, 0), 31);     /* 0x01 in bytes at positions <= r  */ \
+    const u32 lmy = 0x01010101u >> (u32)min(max(sy, 0), 31);     /*                          <= rp */ \
+    const u32 sel = 0x07060504u - lmx + lmy;                      /* keep: 4+k (ord byte k) ; shift: 3+k (byte k-1 / prevw byte 3) */ \
+    const u32 res = __builtin_amdgcn_perm(ord, prevw, sel);                                    \
+    const u32 am = (lane == (int)(rp >> 2)) ? (0xFFu << ((rp & 3u) * 8u)) : 0u;                \
+    ord = (am & (c * 0x01010101u)) | (~am & res);                                              \
+    WRITE_OUT                                                                                  \
+    if (rp == 0) { f = c; fplo = nlo; outv = (lane > (JV)) ? c : outv; } }
+
+// unrolled row position J: skipped when its rank is zero; zeros right before it repair the front key first
+#define KZ_SBRT_STEP_CONST(J)                                                                  \
+  if ((nz >> J) & 1ULL) {                                                                      \
+    if (J > 0 && !((nz >> (J > 0 ? J - 1 : 0)) & 1ULL)) {                                      \
+      const uint64_t below = nz & ((1ULL << J) - 1ULL);                                        \
+      const int pz = below ? 63 - (int)__builtin_clzll(below) : -1;                            \
+      KZ_SBRT_ZERO_RUN(J - pz - 1, row + J - 1)                                                \
+    }                                                                                          \
+    KZ_SBRT_NZ_STEP(J, asm volatile("v_writelane_b32 %0, %1, " #J : "+v"(outv) : "s"(c));)    \
+  }
+#define KZ_SBRT_STEP4(A, B, C, D) KZ_SBRT_STEP_CONST(A) KZ_SBRT_STEP_CONST(B) KZ_SBRT_STEP_CONST(C) KZ_SBRT_STEP_CONST(D)
+
 template <int MODE>
 __global__ __launch_bounds__(64) void k_sbrt_inverse(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
                                                       const int32_t* __restrict__ d_len) {
@@ -327,41 +368,26 @@ __global__ __launch_bounds__(64) void k_sbrt_inverse(const u8* __restrict__ src,
     // zero ranks output the front symbol of their time: every lane starts with the current front, a new
     // front is filled forward over the lanes behind it, non-zero lanes are overwritten with v_writelane
     u32 outv = f;
-    int prev = -1;
-    while (nz) {
-      const int j = (int)__builtin_ctzll(nz);
-      nz &= nz - 1;
-      const int zr = j - prev - 1;
-      if (zr > 0) KZ_SBRT_ZERO_RUN(zr, row + j - 1)
-      const u32 r = (u32)__builtin_amdgcn_readlane((int)cur, j);
-      const u32 w = (u32)__builtin_amdgcn_readlane((int)ord, (int)(r >> 2));
-      const u32 c = (w >> ((r & 3u) * 8u)) & 0xFFu;
-      const int cl = (int)(c & 63u), cs = (int)(c >> 6);
-      const u64 ok = K[cs];
-      const u32 plo = (u32)__builtin_amdgcn_readlane((int)(u32)ok, cl);
-      const u32 pc = max(plo, 256u) - 256u;
-      const u32 iv = (u32)(row + j);
-      const u32 nhi = (MODE == 2) ? ((iv + pc) >> 1) : ((MODE == 1) ? iv : pc);
-      const u32 nlo = iv + 256u;
-      const u64 nk = ((u64)nhi << 32) | (u64)nlo;
-      // new position = number of keys above the new key (the moved symbol's old key is below it)
-      const u32 rp = (u32)(__builtin_popcountll(kz_ballot(K[0] > nk)) + __builtin_popcountll(kz_ballot(K[1] > nk)) +
-                           __builtin_popcountll(kz_ballot(K[2] > nk)) + __builtin_popcountll(kz_ballot(K[3] > nk)));
-      K[cs] = (lane == cl) ? nk : ok;
-      // rotate list positions [rp, r]: (rp, r] take their predecessor, rp takes c
-      const u32 prevw = KZ_DPP_SHR1_Z(ord);
-      const int sx = (24 - 8 * (int)r) + v32l, sy = (24 - 8 * (int)rp) + v32l;
-      const u32 lmx = 0x01010101u >> (u32)min(max(sx, 0), 31);     // 0x01 in bytes at positions <= r
-      const u32 lmy = 0x01010101u >> (u32)min(max(sy, 0), 31);     //                          <= rp
-      const u32 sel = 0x07060504u - lmx + lmy;                      // keep: 4+k (ord byte k) ; shift: 3+k (byte k-1 / prevw byte 3)
-      const u32 res = __builtin_amdgcn_perm(ord, prevw, sel);
-      const u32 am = (lane == (int)(rp >> 2)) ? (0xFFu << ((rp & 3u) * 8u)) : 0u;
-      ord = (am & (c * 0x01010101u)) | (~am & res);
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(c), "s"(j) : "m0");   // outv[lane j] = c
-      if (rp == 0) { f = c; fplo = nlo; outv = (lane > j) ? c : outv; }
-      prev = j;
+    if (cnt == 64 && __builtin_popcountll(nz) >= 40) {
+      // most ranks of the row are non-zero (poorly compressible data: the blocks that set the kernel's run time):
+      // straight-line code with constant lane numbers, no loop control; zero ranks are skipped with a bit test
+      KZ_SBRT_STEP4(0, 1, 2, 3) KZ_SBRT_STEP4(4, 5, 6, 7) KZ_SBRT_STEP4(8, 9, 10, 11) KZ_SBRT_STEP4(12, 13, 14, 15)
+      KZ_SBRT_STEP4(16, 17, 18, 19) KZ_SBRT_STEP4(20, 21, 22, 23) KZ_SBRT_STEP4(24, 25, 26, 27) KZ_SBRT_STEP4(28, 29, 30, 31)
+      KZ_SBRT_STEP4(32, 33, 34, 35) KZ_SBRT_STEP4(36, 37, 38, 39) KZ_SBRT_STEP4(40, 41, 42, 43) KZ_SBRT_STEP4(44, 45, 46, 47)
+      KZ_SBRT_STEP4(48, 49, 50, 51) KZ_SBRT_STEP4(52, 53, 54, 55) KZ_SBRT_STEP4(56, 57, 58, 59) KZ_SBRT_STEP4(60, 61, 62, 63)
+      { const int pz = 63 - (int)__builtin_clzll(nz); if (pz < 63) KZ_SBRT_ZERO_RUN(63 - pz, row + 63) }      // trailing zeros
+    } else {
+      int prev = -1;
+      while (nz) {
+        const int j = (int)__builtin_ctzll(nz);
+        nz &= nz - 1;
+        const int zr = j - prev - 1;
+        if (zr > 0) KZ_SBRT_ZERO_RUN(zr, row + j - 1)
+        KZ_SBRT_NZ_STEP(j, asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(c), "s"(j) : "m0");)
+        prev = j;
+      }
+      { const int zr = cnt - prev - 1; if (zr > 0) KZ_SBRT_ZERO_RUN(zr, row + cnt - 1) }
     }
-    { const int zr = cnt - prev - 1; if (zr > 0) KZ_SBRT_ZERO_RUN(zr, row + cnt - 1) }
     if (lane < cnt) d[row + lane] = (u8)outv;
     cur = nxt;
   }
