@@ -357,26 +357,42 @@ __global__ __launch_bounds__(KZ_WG) void k_live_emit(u64* __restrict__ keyN, u32
   const int n = A.d_n[b];
   const int tile = blockIdx.x;
   if ((int64_t)tile * RS_TILE >= n) return;
-  __shared__ u32 lds[32];
+  __shared__ u32 rowCnt[RS_ITEMS * 4 + 1];   // live suffixes per (wave, row), then exclusive prefix
   const int64_t off = (int64_t)b * A.NS;
   const u32* rank = A.rank + off;
-  const int base = tile * RS_TILE + threadIdx.x * RS_ITEMS;          // 16 consecutive suffixes per thread: text order kept
+  const int wave = threadIdx.x >> 6, lane = kz_lane();
+  // wave w owns the 1024 consecutive suffixes [w*1024, (w+1)*1024): rows of 64 -> every access is coalesced and the
+  // compact order stays the text order
+  const int base = tile * RS_TILE + wave * (64 * RS_ITEMS);
   u32 rk[RS_ITEMS];
-  u32 cnt = 0;
+  uint64_t bal[RS_ITEMS];
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) { const int s = base + r; rk[r] = (s < n) ? rank[s] : 0u; cnt += (rk[r] & BW_LIVE) ? 1u : 0u; }
-  u32 tot;
-  u32 pos = kz_wg_excl_sum(cnt, lds, &tot) + A.tileA[(int64_t)b * A.T + tile];
+  for (int r = 0; r < RS_ITEMS; r++) {
+    const int s = base + r * 64 + lane;
+    rk[r] = (s < n) ? rank[s] : 0u;
+    bal[r] = kz_ballot((rk[r] & BW_LIVE) != 0);
+    if (lane == 0) rowCnt[wave * RS_ITEMS + r] = (u32)__popcll(bal[r]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {                      // exclusive scan of the 64 (wave,row) counts by one wave
+    const u32 v = rowCnt[threadIdx.x];
+    const u32 inc = kz_wave_incl_sum(v);
+    rowCnt[threadIdx.x] = inc - v;
+  }
+  __syncthreads();
+  const u32 tbase = A.tileA[(int64_t)b * A.T + tile];
+  const uint64_t lt = kz_lanemask_lt();
+  const u32 hcap = (u32)min(h, n);
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
     if (rk[r] & BW_LIVE) {
-      const int s = base + r;
+      const int s = base + r * 64 + lane;
       const int64_t j = (int64_t)s + h;
       // positions past the end (s + h >= n): n - s in [1, min(h, n)], smaller for the shorter suffix and below every real rank
-      const u64 r2 = (j < n) ? (u64)(rank[j] & ~BW_LIVE) + (u64)min(h, n) + 1ULL : (u64)(n - s);
+      const u64 r2 = (j < n) ? (u64)(rank[j] & ~BW_LIVE) + (u64)hcap + 1ULL : (u64)(n - s);
+      const u32 pos = tbase + rowCnt[wave * RS_ITEMS + r] + (u32)__popcll(bal[r] & lt);
       keyN[off + pos] = ((u64)(rk[r] & ~BW_LIVE) << bitsR) | r2;
       valN[off + pos] = (u32)s;
-      pos++;
     }
   }
 }
