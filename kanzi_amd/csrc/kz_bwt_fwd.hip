@@ -213,30 +213,50 @@ __global__ __launch_bounds__(RSC_WG) void k_radix_scatter(const u64* __restrict_
 // step 3 (SA order, after the sort).  g(c) = old group head slot = key >> gshift (gshift >= 64: one group, slot 0).
 __device__ __forceinline__ u32 bw_group(u64 k, int gshift) { return gshift >= 64 ? 0u : (u32)(k >> gshift); }
 
+// Wave w of a tile owns the 1024 consecutive sorted elements [w*1024, (w+1)*1024) as 16 rows of 64 (coalesced).
+// Loads the keys, returns per row the ballots "key differs from its predecessor" (hb) and "old group differs" (sb).
+__device__ __forceinline__ void bw_row_flags(const u64* __restrict__ key, int base, int m, int gshift, int lane,
+                                             u64 (&k)[RS_ITEMS], uint64_t (&hb)[RS_ITEMS], uint64_t (&sb)[RS_ITEMS]) {
+  u64 prevRowLast = (base > 0 && base <= m) ? key[base - 1] : 0;      // uniform
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    const int c = base + r * 64 + lane;
+    k[r] = (c < m) ? key[c] : 0;
+    u64 prev = __shfl_up(k[r], 1, 64);
+    if (lane == 0) prev = prevRowLast;
+    const bool valid = c < m;
+    const bool head = valid && (c == 0 || k[r] != prev);
+    const bool seg = head && (c == 0 || bw_group(k[r], gshift) != bw_group(prev, gshift));
+    hb[r] = kz_ballot(head);
+    sb[r] = kz_ballot(seg);
+    prevRowLast = __shfl(k[r], 63, 64);
+  }
+}
+
 // per tile: (last index+1 where the old group changes, last index+1 where the key changes)
 __global__ __launch_bounds__(KZ_WG) void k_seg_reduce(const u64* __restrict__ keyS, BwtArrays A, int gshift) {
   const int b = blockIdx.y;
   const int m = A.d_m[b];
   const int tile = blockIdx.x;
   if ((int64_t)tile * RS_TILE >= m) return;
-  __shared__ u32 lds[32];
+  __shared__ u32 wS[4], wH[4];
   const u64* key = keyS + (int64_t)b * A.NS;
-  const int base = tile * RS_TILE + threadIdx.x * RS_ITEMS;
+  const int wave = threadIdx.x >> 6, lane = kz_lane();
+  const int base = tile * RS_TILE + wave * (64 * RS_ITEMS);
+  u64 k[RS_ITEMS]; uint64_t hb[RS_ITEMS], sb[RS_ITEMS];
+  bw_row_flags(key, base, m, gshift, lane, k, hb, sb);
   u32 ms = 0, mh = 0;
-  u64 prev = (base > 0 && base <= m) ? key[base - 1] : 0;
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
-    const int c = base + r;
-    if (c < m) {
-      const u64 k = key[c];
-      if (c == 0 || k != prev) { mh = (u32)c + 1; if (c == 0 || bw_group(k, gshift) != bw_group(prev, gshift)) ms = (u32)c + 1; }
-      prev = k;
-    }
+    if (hb[r]) mh = (u32)(base + r * 64 + 63 - (int)__builtin_clzll(hb[r])) + 1;
+    if (sb[r]) ms = (u32)(base + r * 64 + 63 - (int)__builtin_clzll(sb[r])) + 1;
   }
-  u32 ts, th;
-  kz_wg_incl_max(ms, lds, &ts);
-  kz_wg_incl_max(mh, lds, &th);
-  if (threadIdx.x == 0) { A.tileA[(int64_t)b * A.T + tile] = ts; A.tileB[(int64_t)b * A.T + tile] = th; }
+  if (lane == 0) { wS[wave] = ms; wH[wave] = mh; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    A.tileA[(int64_t)b * A.T + tile] = max(max(wS[0], wS[1]), max(wS[2], wS[3]));
+    A.tileB[(int64_t)b * A.T + tile] = max(max(wH[0], wH[1]), max(wH[2], wH[3]));
+  }
 }
 // per block: exclusive max-scans over the tiles -- one wave per block
 __global__ void k_seg_scan(BwtArrays A) {
@@ -265,56 +285,51 @@ __global__ __launch_bounds__(KZ_WG) void k_seg_apply(const u64* __restrict__ key
   const int m = A.d_m[b];
   const int tile = blockIdx.x;
   if ((int64_t)tile * RS_TILE >= m) return;
-  __shared__ u32 lds[32];
-  __shared__ u32 wlastS[4], wlastH[4];
+  __shared__ u32 wS[4], wH[4];
   const int64_t off = (int64_t)b * A.NS;
   const u64* key = keyS + off;
-  const int base = tile * RS_TILE + threadIdx.x * RS_ITEMS;
-  u64 k[RS_ITEMS + 1];
-  u32 locS[RS_ITEMS], locH[RS_ITEMS];
+  const int wave = threadIdx.x >> 6, lane = kz_lane();
+  const int base = tile * RS_TILE + wave * (64 * RS_ITEMS);
+  u64 k[RS_ITEMS]; uint64_t hb[RS_ITEMS], sb[RS_ITEMS];
+  bw_row_flags(key, base, m, gshift, lane, k, hb, sb);
   u32 ms = 0, mh = 0;
-  u64 prev = (base > 0 && base <= m) ? key[base - 1] : 0;
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
-    const int c = base + r;
-    k[r] = (c < m) ? key[c] : 0;
-    if (c < m) {
-      if (c == 0 || k[r] != prev) { mh = (u32)c + 1; if (c == 0 || bw_group(k[r], gshift) != bw_group(prev, gshift)) ms = (u32)c + 1; }
-      prev = k[r];
-    }
-    locS[r] = ms; locH[r] = mh;
+    if (hb[r]) mh = (u32)(base + r * 64 + 63 - (int)__builtin_clzll(hb[r])) + 1;
+    if (sb[r]) ms = (u32)(base + r * 64 + 63 - (int)__builtin_clzll(sb[r])) + 1;
   }
-  k[RS_ITEMS] = (base + RS_ITEMS < m) ? key[base + RS_ITEMS] : 0;
-  u32 tot;
-  const u32 incS = kz_wg_incl_max(ms, lds, &tot);
-  const u32 incH = kz_wg_incl_max(mh, lds, &tot);
-  // exclusive prefix for this thread = max over the previous threads of the tile
-  u32 preS = __shfl_up(incS, 1, 64), preH = __shfl_up(incH, 1, 64);
-  if (kz_lane() == 63) { wlastS[threadIdx.x >> 6] = incS; wlastH[threadIdx.x >> 6] = incH; }
+  if (lane == 0) { wS[wave] = ms; wH[wave] = mh; }
   __syncthreads();
-  if (kz_lane() == 0) {
-    const int w = threadIdx.x >> 6;
-    preS = w ? wlastS[w - 1] : 0; preH = w ? wlastH[w - 1] : 0;
-  }
-  const u32 carS = A.tileA[(int64_t)b * A.T + tile], carH = A.tileB[(int64_t)b * A.T + tile];
-  preS = preS > carS ? preS : carS; preH = preH > carH ? preH : carH;
+  // carry into this wave: the tile's carry and the previous waves of the tile ("index + 1", 0 = none)
+  u32 carS = A.tileA[(int64_t)b * A.T + tile], carH = A.tileB[(int64_t)b * A.T + tile];
+  for (int w = 0; w < wave; w++) { carS = max(carS, wS[w]); carH = max(carH, wH[w]); }
   u32* rank = A.rank + off;
   u32* sa = A.sa + off;
   const u32* val = valS + off;
+  const uint64_t le = kz_lanemask_lt() | (1ULL << lane);
+  const u64 afterLast = (base + 64 * RS_ITEMS < m) ? key[base + 64 * RS_ITEMS] : 0;   // uniform
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; r++) {
-    const int c = base + r;
+    const int rowBase = base + r * 64;
+    const int c = rowBase + lane;
+    const uint64_t hbl = hb[r] & le, sbl = sb[r] & le;
+    const u32 hh = hbl ? (u32)(rowBase + 63 - (int)__builtin_clzll(hbl)) : carH - 1;   // index of the new group's first element
+    const u32 ss = sbl ? (u32)(rowBase + 63 - (int)__builtin_clzll(sbl)) : carS - 1;   // index of the old group's first element
+    // key of the next element: next lane / first lane of the next row / first key behind the wave's chunk
+    u64 nextk = __shfl_down(k[r], 1, 64);
+    const u64 nextRowFirst = (r + 1 < RS_ITEMS) ? __shfl(k[(r + 1 < RS_ITEMS) ? r + 1 : r], 0, 64) : afterLast;
+    if (lane == 63) nextk = nextRowFirst;
     if (c < m) {
-      const u32 ss = (locS[r] > preS ? locS[r] : preS) - 1;          // index of the old group's first element (c = 0 starts one)
-      const u32 hh = (locH[r] > preH ? locH[r] : preH) - 1;          // index of the new group's first element
       const u32 g = bw_group(k[r], gshift);
       const bool headC = hh == (u32)c;
-      const bool headN = (c + 1 >= m) || (k[r + 1] != k[r]);
+      const bool headN = (c + 1 >= m) || (nextk != k[r]);
       const u32 sv = val[c];
       const bool live = !(headC && headN);
       rank[sv] = (g + (hh - ss)) | (live ? BW_LIVE : 0u);
       if (!live) sa[g + ((u32)c - ss)] = sv;
     }
+    if (hb[r]) carH = (u32)(rowBase + 63 - (int)__builtin_clzll(hb[r])) + 1;
+    if (sb[r]) carS = (u32)(rowBase + 63 - (int)__builtin_clzll(sb[r])) + 1;
   }
 }
 
