@@ -262,8 +262,15 @@ def main():
             back2 = oracle.decompress(knz2, len(sample2), jobs=jobs2)
             t2 = time.perf_counter()
             assert back2 == sample2.tobytes()
-            out["cpu_baseline"]["default_jobs_row"] = {"value": len(sample2) / (t2 - t0) / 1e6, "unit": "MB/s", "cores": jobs2,
-                                                       "sample": "%d blocks; enc %.2f s dec %.2f s" % (ns2, t1 - t0, t2 - t1)}
+            row2 = {"value": len(sample2) / (t2 - t0) / 1e6, "unit": "MB/s", "cores": jobs2,
+                    "encode_MBps": len(sample2) / (t1 - t0) / 1e6, "decode_MBps": len(sample2) / (t2 - t1) / 1e6,
+                    "sample": "%d blocks (%d B) of the same stream; oracle/libkzo.so (C restatement, SA-IS BWT), %d threads over blocks; enc %.2f s dec %.2f s" % (ns2, len(sample2), jobs2, t1 - t0, t2 - t1)}
+            cb = out["cpu_baseline"]
+            row1 = {k: cb[k] for k in ("value", "unit", "cores", "encode_MBps", "decode_MBps", "sample")}
+            # the headline CPU figure is the better of the two thread counts (oversubscribing SMT threads can lose)
+            best, other = (row2, row1) if row2["value"] > row1["value"] else (row1, row2)
+            cb.update(best)
+            cb["other_thread_count_row"] = other
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

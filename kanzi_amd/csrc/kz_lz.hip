@@ -76,7 +76,23 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
   int repd0 = count, repd1 = count;
   int repIdx = 0, srcInc = 0;
   bool ok = true;
+  // Assist prefetch: the parse itself is one dependent chain (hash entry -> candidate bytes -> decision) with two
+  // cache misses per literal position.  The 64 lanes, which otherwise all execute the same scalar step, touch the
+  // hash-table lines and the candidate lines of the next 64..128 positions ahead of time.  Touching lines never
+  // changes what the parse reads (values are always loaded at their proper time), it only turns HBM misses into
+  // cache hits.
+  int pfPos = 0;
+  u32 pfSink = 0;
   while (srcIdx < srcEnd) {
+    if (srcIdx + 64 > pfPos) {
+      const int q = max(pfPos, srcIdx) + lane;
+      if (q < srcEnd) {
+        const int rq = hashes[lz_hash(src + q, extra)];
+        pfSink ^= (u32)rq;
+        if (rq > 0 && rq < q) pfSink ^= (u32)src[rq];
+      }
+      pfPos = max(pfPos, srcIdx) + 64;
+    }
     int bestLen = 0;
     const int h0 = lz_hash(src + srcIdx, extra);
     const int ref0 = hashes[h0];
@@ -198,6 +214,7 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
       res = (dstIdx <= count - (count / 100)) ? 1 : 0;                                     // :596
     }
   }
+  asm volatile("" :: "v"(pfSink));                               // keep the prefetch loads alive
   if (w) { d_flag[b] = (ok && res) ? 1 : 0; d_len2[b] = (ok && res) ? produced : count; }
 }
 
