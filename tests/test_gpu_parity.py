@@ -296,3 +296,48 @@ def test_ref_correctness_matrix(ctx):
             if length <= (1 << 20):
                 assert cos.output == oracle.compress(chain, ent, bs, values, jobs=4, checksum=chk), (test, chain, bs, chk)
             assert kz.CompressedInputStream(ctx, cos.output).read() == values, (test, chain, bs, chk)
+
+
+def _fuzz_input(rng, n):
+    kind = rng.integers(0, 8)
+    if kind == 0:
+        return rng.integers(0, 256, n, dtype=np.uint8)
+    if kind == 1:
+        return rng.integers(0, int(rng.integers(1, 5)), n, dtype=np.uint8)                 # tiny alphabet
+    if kind == 2:
+        return np.repeat(rng.integers(0, 256, max(1, n // 37 + 1), dtype=np.uint8), 37)[:n]   # long runs
+    if kind == 3:
+        period = int(rng.integers(1, 300))
+        return np.resize(rng.integers(0, 256, period, dtype=np.uint8), n)                  # periodic: deep suffix sort rounds
+    if kind == 4:
+        a = rng.integers(0, 256, n, dtype=np.uint8)
+        a[rng.random(n) < 0.9] = 0                                                         # sparse
+        return a
+    if kind == 5:
+        return np.zeros(n, dtype=np.uint8)
+    if kind == 6:
+        words = [bytes(rng.integers(97, 123, int(rng.integers(2, 9)), dtype=np.uint8)) for _ in range(40)]
+        out = b" ".join(words[int(i)] for i in rng.integers(0, 40, n // 4 + 1))
+        return np.frombuffer(out[:n].ljust(n, b"."), dtype=np.uint8)
+    return (np.arange(n) * int(rng.integers(1, 7)) % 251).astype(np.uint8)                 # ramps
+
+
+def test_fuzz_streams_match_oracle(ctx):
+    """Randomised parity: lengths, contents, chains, entropy coders, block sizes and checksum kinds drawn from a fixed
+    seed; every HIP stream must equal the oracle's and decode back (through both decoders)."""
+    rng = np.random.default_rng(20260928)
+    chains = ["BWT+RANK+ZRLT", "BWT+MTFT+ZRLT", "BWT+SRT+ZRLT", "BWT", "RANK", "ZRLT", "SRT", "LZ", "LZX", "RANK+ZRLT", "BWT+RANK", "LZ+ZRLT", "NONE"]
+    ents = ["ANS0", "HUFFMAN", "FPAQ", "NONE"]
+    for case in range(160):
+        n = int(rng.choice([0, 1, 15, 16, 17, 255, 1023, 1024, 4096, int(rng.integers(1, 70000)), int(rng.integers(1, 200000))]))
+        data = _fuzz_input(rng, n).tobytes()
+        chain, ent = chains[int(rng.integers(0, len(chains)))], ents[int(rng.integers(0, len(ents)))]
+        bs = int(rng.choice([1024, 4096, 16384, 65536, 1 << 20]))
+        chk = int(rng.choice([0, 0, 32, 64]))
+        ref = oracle.compress(chain, ent, bs, data, jobs=4, checksum=chk)
+        cos = kz.CompressedOutputStream(ctx, chain, ent, bs, checksum=chk)
+        cos.write(data)
+        cos.close()
+        assert cos.output == ref, (case, n, chain, ent, bs, chk)
+        assert kz.CompressedInputStream(ctx, ref).read(max(n, 1)) == data, (case, n, chain, ent, bs, chk)
+        assert oracle.decompress(cos.output, n, jobs=2) == data
