@@ -84,8 +84,12 @@ __global__ __launch_bounds__(KZ_WG) void k_radix_hist(const u64* __restrict__ ke
     const int idx = base + r * KZ_WG + threadIdx.x;
     const bool valid = idx < m;
     const u32 d = valid ? (u32)((key[idx] >> shift) & 0xFF) : 0;
-    const uint64_t peers = kz_match8(d, valid);
-    if (valid && (peers & kz_lanemask_lt()) == 0) atomicAdd(&hist[d], (u32)__popcll(peers));
+    // skewed digits (one value for the whole row: high key bytes, runs) would serialise 64 LDS atomics on one
+    // address: those rows add once; rows with mixed digits use plain LDS atomics (conflicts only on equal digits)
+    const uint64_t vm = kz_ballot(valid);
+    const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
+    if (vm != 0 && kz_ballot(valid && d == d0) == vm) { if (lane == (int)__builtin_ctzll(vm)) atomicAdd(&hist[d0], (u32)__popcll(vm)); }
+    else if (valid) atomicAdd(&hist[d], 1u);
   }
   (void)lane;
   __syncthreads();
