@@ -156,7 +156,11 @@ __global__ __launch_bounds__(RSC_WG) void k_radix_scatter(const u64* __restrict_
     const int idx = base + r * 64 + lane;
     const bool valid = idx < m;
     const u32 d = (u32)((k[r] >> shift) & 0xFF);
-    const uint64_t peers = kz_match8(d, valid);
+    // rows holding a single digit value (high key bytes, runs) skip the 8-ballot match-any
+    const uint64_t vm = kz_ballot(valid);
+    const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
+    const bool uni = (vm != 0) && (kz_ballot(valid && d == d0) == vm);
+    const uint64_t peers = uni ? (valid ? vm : 0ULL) : kz_match8(d, valid);
     u32 pre = 0;
     if (valid) pre = cnt[wave][d];
     const u32 rnk = pre + (u32)__popcll(peers & lt);
