@@ -27,6 +27,8 @@
 #define RS_ITEMS 16
 #define RS_TILE (KZ_WG * RS_ITEMS)   // 4096 elements per workgroup
 #define BW_LIVE 0x80000000u
+#define RSORT_TILE 8192                // keys per radix tile: a digit run of a tile averages 32 keys = 256 B
+#define RSORT_ITEMS (RSORT_TILE / KZ_WG)
 
 typedef unsigned long long u64;
 typedef uint32_t u32;
@@ -72,15 +74,15 @@ __global__ __launch_bounds__(KZ_WG) void k_radix_hist(const u64* __restrict__ ke
   const int b = blockIdx.y;
   const int m = A.d_m[b];
   const int tile = blockIdx.x;
-  if ((int64_t)tile * RS_TILE >= m) return;
+  if ((int64_t)tile * RSORT_TILE >= m) return;
   __shared__ u32 hist[256];
   hist[threadIdx.x] = 0;
   __syncthreads();
   const u64* key = keyIn + (int64_t)b * A.NS;
-  const int base = tile * RS_TILE;
+  const int base = tile * RSORT_TILE;
   const int lane = kz_lane();
 #pragma unroll 4
-  for (int r = 0; r < RS_ITEMS; r++) {
+  for (int r = 0; r < RSORT_ITEMS; r++) {
     const int idx = base + r * KZ_WG + threadIdx.x;
     const bool valid = idx < m;
     const u32 d = valid ? (u32)((key[idx] >> shift) & 0xFF) : 0;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(KZ_WG) void k_radix_hist(const u64* __restrict__ ke
 __global__ __launch_bounds__(256) void k_radix_scan(BwtArrays A) {
   const int b = blockIdx.x;
   const int m = A.d_m[b];
-  const int tiles = (m + RS_TILE - 1) / RS_TILE;
+  const int tiles = (m + RSORT_TILE - 1) / RSORT_TILE;
   __shared__ u32 lds[32];
   u32* h = A.tileHist + (int64_t)b * A.T * 256;
   u32 run = 0;
@@ -120,8 +122,8 @@ __global__ __launch_bounds__(256) void k_radix_scan(BwtArrays A) {
 // then reordered IN LDS (keys, then values through the same 32 KiB buffer) so that consecutive threads
 // store consecutive elements of each digit run: a wave store touches a few 128 B lines instead of up
 // to 64 scattered 8 B / 4 B segments (the pass is bound by memory transactions, not bytes).
-#define RSC_WAVES 8                       // scatter workgroup: 8 waves x 8 rows of 64 keys = the same 4096-key tile
-#define RSC_ITEMS (RS_TILE / (64 * RSC_WAVES))
+#define RSC_WAVES 8                       // scatter workgroup: 8 waves x 16 rows of 64 keys = one radix tile
+#define RSC_ITEMS (RSORT_TILE / (64 * RSC_WAVES))
 #define RSC_WG (64 * RSC_WAVES)
 __global__ __launch_bounds__(RSC_WG) void k_radix_scatter(const u64* __restrict__ keyIn, const u32* __restrict__ valIn,
                                                            u64* __restrict__ keyOut, u32* __restrict__ valOut,
@@ -129,19 +131,19 @@ __global__ __launch_bounds__(RSC_WG) void k_radix_scatter(const u64* __restrict_
   const int b = blockIdx.y;
   const int m = A.d_m[b];
   const int tile = blockIdx.x;
-  if ((int64_t)tile * RS_TILE >= m) return;
+  if ((int64_t)tile * RSORT_TILE >= m) return;
   __shared__ u32 cnt[RSC_WAVES][256];
   __shared__ u32 gdelta[256];        // global slot of the digit's first element of this tile - its tile-local slot
   __shared__ u32 scan[32];
-  __shared__ u64 stage[RS_TILE];     // 32 KiB: keys, then values
+  __shared__ u64 stage[RSORT_TILE];  // 64 KiB: keys, then values
   for (int i = threadIdx.x; i < RSC_WAVES * 256; i += RSC_WG) (&cnt[0][0])[i] = 0;
   __syncthreads();
   const int64_t off = (int64_t)b * A.NS;
   const int wave = threadIdx.x >> 6;
   const int lane = kz_lane();
-  const int tbase = tile * RS_TILE;
+  const int tbase = tile * RSORT_TILE;
   const int base = tbase + wave * (64 * RSC_ITEMS);
-  const int tcount = min(RS_TILE, m - tbase);
+  const int tcount = min(RSORT_TILE, m - tbase);
   const uint64_t lt = kz_lanemask_lt();
   u64 k[RSC_ITEMS]; u32 v[RSC_ITEMS]; u32 dr[RSC_ITEMS];   // dr = digit | (rank<<8), later the tile-local slot
 #pragma unroll
@@ -515,10 +517,11 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
     const int nbits = (round == 0) ? 56 : bitsR + bitsG;
     const int passes = (nbits + 7) / 8;
     const int tiles = gridFor(mMax, RS_TILE);
+    const int rtiles = gridFor(mMax, RSORT_TILE);
     for (int p = 0; p < passes; p++) {
-      KZ_LAUNCH(ctx, KID_RADIX_HIST, k_radix_hist, dim3(tiles, B), dim3(KZ_WG), kC, A, p * 8);
+      KZ_LAUNCH(ctx, KID_RADIX_HIST, k_radix_hist, dim3(rtiles, B), dim3(KZ_WG), kC, A, p * 8);
       KZ_LAUNCH(ctx, KID_RADIX_SCAN, k_radix_scan, dim3(B), dim3(256), A);
-      KZ_LAUNCH(ctx, KID_RADIX_SCATTER, k_radix_scatter, dim3(tiles, B), dim3(RSC_WG), kC, vC, kF, vF, A, p * 8);
+      KZ_LAUNCH(ctx, KID_RADIX_SCATTER, k_radix_scatter, dim3(rtiles, B), dim3(RSC_WG), kC, vC, kF, vF, A, p * 8);
       u64* tk = kC; kC = kF; kF = tk;
       u32* tv = vC; vC = vF; vF = tv;
     }
