@@ -27,7 +27,7 @@
 #define RS_ITEMS 16
 #define RS_TILE (KZ_WG * RS_ITEMS)   // 4096 elements per workgroup
 #define BW_LIVE 0x80000000u
-#define RSORT_TILE 8192                // keys per radix tile: a digit run of a tile averages 32 keys = 256 B
+#define RSORT_TILE 16384               // keys per radix tile: a digit run of a tile averages 64 keys = 512 B
 #define RSORT_ITEMS (RSORT_TILE / KZ_WG)
 
 typedef unsigned long long u64;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_radix_scan(BwtArrays A) {
 // then reordered IN LDS (keys, then values through the same 32 KiB buffer) so that consecutive threads
 // store consecutive elements of each digit run: a wave store touches a few 128 B lines instead of up
 // to 64 scattered 8 B / 4 B segments (the pass is bound by memory transactions, not bytes).
-#define RSC_WAVES 8                       // scatter workgroup: 8 waves x 16 rows of 64 keys = one radix tile
+#define RSC_WAVES 16                      // scatter workgroup: 16 waves x 16 rows of 64 keys = one radix tile
 #define RSC_ITEMS (RSORT_TILE / (64 * RSC_WAVES))
 #define RSC_WG (64 * RSC_WAVES)
 __global__ __launch_bounds__(RSC_WG) void k_radix_scatter(const u64* __restrict__ keyIn, const u32* __restrict__ valIn,
