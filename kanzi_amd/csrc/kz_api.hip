@@ -714,8 +714,14 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     kz_stage_end(ctx, e1, KZ_STAGE_ENTROPY_DEC, outBytes);
   }
   // ---- inverse chain (Sequence.inverse, K/transform/Sequence.java:137-207) ----
+  // cost hint for the serial-per-block inverse stages: the length a block had at the input of the previous stage
+  // (for RANK behind ZRLT that is the ZRLT-coded length ~ the number of non-zero ranks)
+  std::vector<int32_t> prevIn(B);
+  for (int b = 0; b < B; b++) prevIn[b] = (int32_t)std::min<int64_t>((bitLengths[b] + 7) >> 3, 0x7FFFFFFF);
   for (int i = nb - 1; i >= 0; i--) {
     if (types[i] == KZ_T_NONE) continue;
+    bt.h_cost = prevIn;
+    prevIn = bt.h_len;
     bool any = false;
     for (int b = 0; b < B; b++) { h_mask[b] = (!h_status[b] && !(h_skip[b] & (1 << (7 - i))) && bt.h_len[b] > 0) ? 1 : 0; any |= h_mask[b] != 0; }
     if (!any) continue;

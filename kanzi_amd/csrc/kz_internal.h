@@ -54,6 +54,7 @@ struct kz_batch {
   int32_t* d_len2 = nullptr;    // [B] next length (stages write here, then swap)
   int32_t* d_flag = nullptr;    // [B] per-stage applied flag (device)
   std::vector<int32_t> h_len;   // host mirror of d_len
+  std::vector<int32_t> h_cost;  // optional per-block cost hint for serial-per-block stages (length at the previous stage's input)
 };
 
 // ---- stages (each works on the whole batch; returns 0 or -KZ_ERR_*) ----

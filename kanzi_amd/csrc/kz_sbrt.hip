@@ -16,6 +16,8 @@
 //   move-up is a DPP wave shift + byte funnel; blocks of the batch decode concurrently.
 #include "kz_device.h"
 #include "kz_internal.h"
+#include <algorithm>
+#include <vector>
 
 typedef unsigned long long u64;
 typedef uint32_t u32;
@@ -168,128 +170,17 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
   }
 }
 
-// ---- inverse: one wave per block ---------------------------------------------------------------
-// State: the rank->symbol list kept sorted by position: position j lives in register j>>6, lane j&63
-// as ONE 64-bit value  key' = (q << 40) | ((p + 256) << 8) | symbol  (never seen: ((255-s) << 8) | s).
-// (q,p) is unique per symbol so the extra low byte never changes the order, and symbol + key move
-// together.  Zero ranks never move the list: runs of zeros are skipped in O(1) with a ballot of the
-// non-zero lanes of each 64-byte row (after BWT most ranks are zero).  Valid for n < 2^24 - 256.
-//
-// Cost model (tools/ubench_lonewave.hip, one wave per CU): a dependent VALU op costs 4 cycles, but every
-// VALU->SALU hand-off (v_readlane / v_cmp result consumed by s_* ops) costs ~30 and every scalar branch
-// ~40.  The step is therefore written to STAY ON THE VALU: wave-uniform quantities (symbol, new key, new
-// position) are kept in VGPRs (forced with v_mov / v_bcnt inline asm so the compiler does not scalarise
-// them), selections are v_cndmask instead of branches, and the only branch per non-zero rank is r < 64.
-#define KZ_DPP_SHR1(x) ((u32)__builtin_amdgcn_update_dpp(0, (int)(x), 0x138 /*wave_shr:1*/, 0xF, 0xF, false))
-#define KZ_K64(k) (((u64)hi##k << 32) | (u64)lo##k)
-
-// NOTE gfx940+ hazard: 2 wait states between a VALU writing an SGPR/VCC (v_readlane, v_cmp) and a VALU
-// reading it; the compiler's hazard recognizer does not look inside inline asm, hence the s_nop 1.
-__device__ __forceinline__ u32 kz_v_from_s(u32 s) { u32 v; asm volatile("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
-// acc + popcount(mask) computed on the VALU (mask is a ballot in an SGPR pair)
-__device__ __forceinline__ u32 kz_v_bcnt64(uint64_t m, u32 acc) {
-  const u32 mlo = (u32)m, mhi = (u32)(m >> 32);
-  u32 r;
-  asm volatile("s_nop 1\n\tv_bcnt_u32_b32 %0, %1, %2\n\tv_bcnt_u32_b32 %0, %3, %0" : "=&v"(r) : "s"(mlo), "v"(acc), "s"(mhi));
-  return r;
-}
-
-// One list slot (position 4*lane + S): positions (rp, r] take their predecessor, position rp the new entry.
-// rel = pos - (rp+1) ; span = r - rp  (unsigned: in range iff rel < span; pos == rp iff rel == ~0)
-#define KZ_SBRT_SLOT(S, SRC_LO, SRC_HI)                                                   \
-  { const u32 rel = relBase + (u32)(S);                                                    \
-    const bool in = rel < span;                                                            \
-    const bool at = rel == 0xFFFFFFFFu;                /* pos == rp */                     \
-    u32 tl = in ? (SRC_LO) : l##S, th = in ? (SRC_HI) : h##S;                              \
-    l##S = at ? nlo : tl; h##S = at ? nhi : th; }
-
-__global__ __launch_bounds__(64) void k_sbrt_inverse_v4(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
-                                                         const int32_t* __restrict__ d_len, int mode) {
-  const int b = blockIdx.x;
-  const int n = d_len[b];
-  const u8* s = src + (int64_t)b * stride;
-  u8* d = dst + (int64_t)b * stride;
-  const int lane = kz_lane();
-  // list position j = 4*lane + slot ; r2s[j] = j, all symbols never seen: lo = ((255-j) << 8) | j, hi = 0
-  const u32 p0 = 4u * (u32)lane;
-  u32 l0 = ((255u - p0) << 8) | p0, l1 = ((254u - p0) << 8) | (p0 + 1u), l2 = ((253u - p0) << 8) | (p0 + 2u), l3 = ((252u - p0) << 8) | (p0 + 3u);
-  u32 h0 = 0, h1 = 0, h2 = 0, h3 = 0;
-  // authoritative copy of position 0 (lane 0, slot 0): uniform, kept in VGPRs, synced before each use
-  u32 flo = kz_v_from_s((255u << 8) | 0u), fhi = kz_v_from_s(0u);
-  const bool mRank = (mode == 2), mMtf = (mode == 1);
-  u32 cur = (lane < n) ? (u32)s[lane] : 0u;
-  for (int row = 0; row < n; row += 64) {
-    const int cnt = min(64, n - row);
-    const int nrow = row + 64;
-    const u32 nxt = (nrow + lane < n) ? (u32)s[nrow + lane] : 0u;  // prefetch the next row
-    uint64_t nz = kz_ballot(cur != 0 && lane < cnt);
-    const u32 curL = cur >> 2, curS = cur & 3u;                       // lane / slot of each rank, split on the VALU
-    u32 outv = 0;
-    int prev = -1;
-    for (;;) {
-      const int j = nz ? (int)__builtin_ctzll(nz) : cnt;
-      const int zr = j - prev - 1;
-      {
-        // zero run [prev+1, j): the front symbol repeats; only its (q,p) change (SBRT.java:194-201).
-        // Evaluated unconditionally and selected (no branch).
-        const u32 pk = flo >> 8;
-        const u32 pold = max(pk, 256u) - 256u;
-        const u32 pl = (u32)(row + prev + zr);                     // last index of the run
-        const u32 pp = (zr >= 2) ? pl - 1u : pold;
-        const u32 q = mRank ? ((pl + pp) >> 1) : (mMtf ? pl : pp);
-        const bool has = zr > 0;
-        fhi = has ? (q << 8) : fhi;
-        flo = has ? (((pl + 256u) << 8) | (flo & 0xFFu)) : flo;
-        outv = (has && lane > prev && lane < j) ? (flo & 0xFFu) : outv;
-      }
-      if (j >= cnt) break;
-      nz &= nz - 1;
-      const int L = __builtin_amdgcn_readlane((int)curL, j);       // SGPRs used only as lane selects / v_mov sources
-      const u32 vsel = kz_v_from_s((u32)__builtin_amdgcn_readlane((int)curS, j));
-      const u32 vr = (kz_v_from_s((u32)L) << 2) | vsel;
-      const u32 iv = (u32)(row + j);
-      l0 = (lane == 0) ? flo : l0; h0 = (lane == 0) ? fhi : h0;    // sync the cached front entry
-      // entry at position r = slot vsel of lane L: every lane picks its own slot vsel, then ONE readlane
-      u32 cand = (vsel == 1u) ? l1 : l0;
-      cand = (vsel == 2u) ? l2 : cand;
-      cand = (vsel == 3u) ? l3 : cand;
-      const u32 clo = kz_v_from_s((u32)__builtin_amdgcn_readlane((int)cand, L));
-      const u32 c = clo & 0xFFu;
-      const u32 pc = max(clo >> 8, 256u) - 256u;
-      const u32 qc = mRank ? ((iv + pc) >> 1) : (mMtf ? iv : pc);
-      const u32 nlo = ((iv + 256u) << 8) | c, nhi = qc << 8;
-      const u64 nk = ((u64)nhi << 32) | (u64)nlo;
-      // new position = number of entries above the new key (entries below r are smaller than the old key)
-      u32 vrp = kz_v_bcnt64(kz_ballot((((u64)h0 << 32) | l0) > nk), 0u);
-      vrp = kz_v_bcnt64(kz_ballot((((u64)h1 << 32) | l1) > nk), vrp);
-      vrp = kz_v_bcnt64(kz_ballot((((u64)h2 << 32) | l2) > nk), vrp);
-      vrp = kz_v_bcnt64(kz_ballot((((u64)h3 << 32) | l3) > nk), vrp);
-      const u32 relBase = p0 - (vrp + 1u);
-      const u32 span = vr - vrp;                                     // r >= rp always
-      const u32 pl3 = KZ_DPP_SHR1(l3), ph3 = KZ_DPP_SHR1(h3);        // slot 0 of lane l takes slot 3 of lane l-1
-      // descending slots: each reads the still unmodified lower slot
-      KZ_SBRT_SLOT(3, l2, h2)
-      KZ_SBRT_SLOT(2, l1, h1)
-      KZ_SBRT_SLOT(1, l0, h0)
-      KZ_SBRT_SLOT(0, pl3, ph3)
-      fhi = (vrp == 0u) ? nhi : fhi; flo = (vrp == 0u) ? nlo : flo;
-      outv = (lane == j) ? c : outv;
-      prev = j;
-    }
-    if (lane < cnt) d[row + lane] = (u8)outv;
-    cur = nxt;
-  }
-}
-
-// ---- inverse, v5: symbol order in ONE VGPR, keys per symbol --------------------------------------
+// ---- inverse: one wave per block; symbol order in ONE VGPR, keys per symbol ---------------------
+// (v4 kept the list as 256 (key,symbol) pairs in 8 VGPRs and shifted all of them per symbol: ~110 VALU per rank)
 // ord : byte k of lane l = symbol at list position 4l+k.  A move of position r up to rp is a rotation of
 //       [rp, r]: one DPP wave_shr + one v_perm_b32 whose per-lane byte selector is built from two clamped
 //       shifts of 0x01010101 (bytes <= r minus bytes <= rp select "predecessor"), then a v_bfi for byte rp.
 // K   : keys stay with their SYMBOL (symbol s = lane s&63, element pair 2*(s>>6)), so nothing but the moved
 //       symbol's key ever changes: an indexed-VGPR write (s_set_gpr_idx) under a single-lane select.
 //       new position rp = #keys above the new key = 4 v_cmp_gt_u64 ballots + s_bcnt1 (order-free count).
-// Uniform values (rank, symbol, new key, rp) live in SGPRs; per non-zero rank the step has ~36 VALU and
-// ~50 SALU instructions, 4 VALU->SALU hand-offs and 2 branches (v4: ~110 VALU, all lanes redundantly).
+// Uniform values (rank, symbol, new key, rp) live in SGPRs; per non-zero rank the step has ~33 VALU and
+// ~38 SALU instructions and 4 VALU->SALU hand-offs.  Cost model (tools/ubench_lonewave.hip): a lone wave issues
+// one instruction per 4 cycles whatever its type, a VALU->SALU hand-off costs ~30 cycles, a taken branch ~40.
 #define KZ_DPP_SHR1_Z(x) ((u32)__builtin_amdgcn_update_dpp(0, (int)(x), 0x138 /*wave_shr:1*/, 0xF, 0xF, true))
 
 // zero run of zr ranks ending at index pl: the front symbol repeats, only its (q,p) change (SBRT.java:194-201)
@@ -344,10 +235,13 @@ __global__ __launch_bounds__(64) void k_sbrt_inverse_v4(const u8* __restrict__ s
   }
 #define KZ_SBRT_STEP4(A, B, C, D) KZ_SBRT_STEP_CONST(A) KZ_SBRT_STEP_CONST(B) KZ_SBRT_STEP_CONST(C) KZ_SBRT_STEP_CONST(D)
 
+// One wave per block, up to 8 blocks per workgroup: the waves of a workgroup are spread over the 4 SIMDs of one
+// CU (wave w and wave w+4 share a SIMD), so the host can pair an expensive block with a cheap one (order[]).
 template <int MODE>
-__global__ __launch_bounds__(64) void k_sbrt_inverse(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
-                                                      const int32_t* __restrict__ d_len) {
-  const int b = blockIdx.x;
+__global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                                                       const int32_t* __restrict__ d_len, const int32_t* __restrict__ order, int wavesPerGroup) {
+  const int b = order[blockIdx.x * wavesPerGroup + (int)(threadIdx.x >> 6)];
+  if (b < 0) return;
   const int n = d_len[b];
   const u8* s = src + (int64_t)b * stride;
   u8* d = dst + (int64_t)b * stride;
@@ -458,11 +352,34 @@ int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
   hipStream_t st = ctx->stream;
   const u8* src = bt.buf[bt.cur];
   u8* dst = bt.buf[bt.cur ^ 1];
-  static const bool useV4 = getenv("KZ_SBRT_INV_V4") != nullptr;
-  if (useV4) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse_v4, dim3(B), dim3(64), src, dst, bt.stride, bt.d_len, mode); }
-  else if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<2>, dim3(B), dim3(64), src, dst, bt.stride, bt.d_len); }
-  else if (mode == 1) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<1>, dim3(B), dim3(64), src, dst, bt.stride, bt.d_len); }
-  else { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<3>, dim3(B), dim3(64), src, dst, bt.stride, bt.d_len); }
+  // ---- placement: the decode time of a block is proportional to its non-zero ranks, and two waves on one SIMD
+  // slow each other down.  Small batches get one wave per workgroup (spread over all CUs); large batches get 8
+  // blocks per workgroup = per CU, sorted so that every SIMD pairs an expensive block with a cheap one. ----
+  const int wpg = B > 1024 ? 8 : (B > 512 ? 4 : (B > 256 ? 2 : 1));
+  const int G = (B + wpg - 1) / wpg;
+  std::vector<int32_t> order((size_t)G * wpg, -1);
+  if (wpg == 8 && (int)bt.h_cost.size() == B) {
+    std::vector<int32_t> idx(B);
+    for (int b = 0; b < B; b++) idx[b] = b;
+    std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) {
+      const int64_t cx = bt.h_len[x] > 0 ? bt.h_cost[x] : -1, cy = bt.h_len[y] > 0 ? bt.h_cost[y] : -1;
+      return cx > cy; });
+    for (int k = 0; k < B; k++) {
+      const int p = k / G, q = k % G;
+      const int wg = (p & 1) ? G - 1 - q : q;                      // snake over the workgroups
+      const int slot = p < 4 ? p : 11 - p;                          // 4 most expensive on waves 0..3, the cheapest facing them
+      order[(size_t)wg * 8 + slot] = idx[k];
+    }
+  } else {
+    for (int b = 0; b < B; b++) order[b] = b;
+  }
+  int32_t* d_order = (int32_t*)kz_arena_alloc(ctx, order.size() * 4);
+  if (!d_order) { snprintf(ctx->err, sizeof(ctx->err), "sbrt_inverse: arena overflow"); return -KZ_ERR_DEVICE; }
+  KZ_HIP(hipMemcpyAsync(d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipStreamSynchronize(st));                                 // order[] is a local
+  if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<2>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, d_order, wpg); }
+  else if (mode == 1) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<1>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, d_order, wpg); }
+  else { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<3>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, d_order, wpg); }
   KZ_LAUNCH(ctx, KID_COPY_LEN, k_copy_len, dim3((B + 255) / 256), dim3(256), bt.d_len, bt.d_len2, bt.d_flag, B);
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
