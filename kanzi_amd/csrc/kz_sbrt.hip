@@ -207,9 +207,10 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
     const u32 nhi = (MODE == 2) ? ((iv + pc) >> 1) : ((MODE == 1) ? iv : pc);                  \
     const u32 nlo = iv + 256u;                                                                 \
     const u64 nk = ((u64)nhi << 32) | (u64)nlo;                                                \
-    /* new position = number of keys above the new key (the moved symbol's old key is below it) */ \
-    const u32 rp = (u32)(__builtin_popcountll(kz_ballot(K[0] > nk)) + __builtin_popcountll(kz_ballot(K[1] > nk)) + \
-                         __builtin_popcountll(kz_ballot(K[2] > nk)) + __builtin_popcountll(kz_ballot(K[3] > nk))); \
+    /* new position = number of keys above the new key.  The new key's low half (iv + 256) exceeds every existing \
+       one, so key > nk <=> q > nhi: 32-bit compares of the high halves (never-seen symbols have q = 0) */ \
+    const u32 rp = (u32)(__builtin_popcountll(kz_ballot((u32)(K[0] >> 32) > nhi)) + __builtin_popcountll(kz_ballot((u32)(K[1] >> 32) > nhi)) + \
+                         __builtin_popcountll(kz_ballot((u32)(K[2] >> 32) > nhi)) + __builtin_popcountll(kz_ballot((u32)(K[3] >> 32) > nhi))); \
     K[cs] = (lane == cl) ? nk : ok;                                                            \
     /* rotate list positions [rp, r]: (rp, r] take their predecessor, rp takes c */            \
     const u32 prevw = KZ_DPP_SHR1_Z(ord);                                                      \
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
     const u32 am = (lane == (int)(rp >> 2)) ? (0xFFu << ((rp & 3u) * 8u)) : 0u;                \
     ord = (am & (c * 0x01010101u)) | (~am & res);                                              \
     WRITE_OUT                                                                                  \
-    if (rp == 0) { f = c; fplo = nlo; outv = (lane > (JV)) ? c : outv; } }
+    if (rp == 0) { f = c; fplo = nlo; fm |= 1ULL << (JV); } }     /* front changed here: resolved at the end of the row */
 
 // unrolled row position J: skipped when its rank is zero; zeros right before it repair the front key first
 #define KZ_SBRT_STEP_CONST(J)                                                                  \
@@ -259,9 +260,12 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
     const int nrow = row + 64;
     const u32 nxt = (nrow + lane < n) ? (u32)s[nrow + lane] : 0u;  // prefetch the next row
     uint64_t nz = kz_ballot(cur != 0 && lane < cnt);
-    // zero ranks output the front symbol of their time: every lane starts with the current front, a new
-    // front is filled forward over the lanes behind it, non-zero lanes are overwritten with v_writelane
-    u32 outv = f;
+    // non-zero lanes receive their symbol with v_writelane; zero ranks output the front symbol of their time: the
+    // positions where the front changed are collected in the scalar mask fm and resolved once per row
+    u32 outv = 0;
+    uint64_t fm = 0;
+    const u32 f0 = f;
+    const uint64_t nzRow = nz;
     if (cnt == 64 && __builtin_popcountll(nz) >= 40) {
       // most ranks of the row are non-zero (poorly compressible data: the blocks that set the kernel's run time):
       // straight-line code with constant lane numbers, no loop control; zero ranks are skipped with a bit test
@@ -281,6 +285,13 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
         prev = j;
       }
       { const int zr = cnt - prev - 1; if (zr > 0) KZ_SBRT_ZERO_RUN(zr, row + cnt - 1) }
+    }
+    {
+      // zero-rank lane l: symbol of the last front change before l (held by that lane), else the front at row start
+      const uint64_t below = fm & kz_lanemask_lt();
+      const int srcLane = below ? 63 - (int)__builtin_clzll(below) : 0;
+      const u32 fv = (u32)__shfl((int)outv, srcLane, 64);
+      if (!((nzRow >> lane) & 1ULL)) outv = below ? fv : f0;
     }
     if (lane < cnt) d[row + lane] = (u8)outv;
     cur = nxt;
