@@ -307,6 +307,7 @@ class _EntropyDecoder:
         rc = self.ctx.lib.kz_entropy_decode(self.ctx.h, self.TYPE, s.ctypes.data, self.nbits, out.ctypes.data, count, ctypes.addressof(used))
         if rc < 0:
             return -1
+        self.bits_consumed = used.value          # the Java adapter advances the shared InputBitStream by this many bits
         block[blkptr:blkptr + count] = out
         return count
 

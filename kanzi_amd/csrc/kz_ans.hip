@@ -393,7 +393,7 @@ __device__ __forceinline__ u32 kz_peek(const u8* __restrict__ p, u64 pos, int co
 
 // index pass: one lane per block walks the chunk headers (sizes are only known by parsing)
 __global__ void k_ans_dec_index(const u8* __restrict__ in, int64_t inStride, const int64_t* __restrict__ d_bitOff,
-                                const int64_t* __restrict__ d_bitEnd, const int32_t* __restrict__ d_len, AnsDec D, int B) {
+                                const int64_t* __restrict__ d_bitEnd, const int32_t* __restrict__ d_len, AnsDec D, int B, long long* __restrict__ endOut) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int count = d_len[b];
@@ -431,7 +431,8 @@ __global__ void k_ans_dec_index(const u8* __restrict__ in, int64_t inStride, con
       pos += 128 + 8ULL * sz;
       if (pos > endBits) { status = -KZ_ERR_PROCESS_BLOCK; break; }
     }
-  }
+  } else pos += 8ULL * (u64)(count > 0 ? count : 0);
+  if (endOut) endOut[b] = (long long)pos;                          // bits consumed (EntropyDecoder contract)
   D.status[b] = status;
 }
 
@@ -577,7 +578,7 @@ int kz_stage_ans0_decode(kz_ctx* ctx, kz_batch& bt, const uint8_t* in, int64_t i
   if (!D.status || !D.chunkBit) { snprintf(ctx->err, sizeof(ctx->err), "ans0_decode: arena overflow"); return -KZ_ERR_DEVICE; }
   hipStream_t st = ctx->stream;
   u8* dst = bt.buf[bt.cur ^ 1];
-  KZ_LAUNCH(ctx, KID_ANS_DEC_INDEX, k_ans_dec_index, dim3((B + 63) / 64), dim3(64), in, inStride, d_bitOff, d_bitEnd, bt.d_len, D, B);
+  KZ_LAUNCH(ctx, KID_ANS_DEC_INDEX, k_ans_dec_index, dim3((B + 63) / 64), dim3(64), in, inStride, d_bitOff, d_bitEnd, bt.d_len, D, B, ctx->d_endBits);
   const int chunks = (maxN + ANS_CHUNK - 1) / ANS_CHUNK;
   if (chunks > 0) KZ_LAUNCH(ctx, KID_ANS_DEC_CHUNK, k_ans_dec_chunk, dim3(chunks, B), dim3(64), in, inStride, d_bitOff, bt.d_len, D, dst, bt.stride);
   KZ_LAUNCH(ctx, KID_ANS_DEC_FIN, k_ans_dec_fin, dim3((B + 255) / 256), dim3(256), bt.d_len, bt.d_len2, bt.d_flag, D, B);

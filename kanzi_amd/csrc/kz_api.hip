@@ -856,12 +856,17 @@ extern "C" int32_t kz_entropy_decode(kz_ctx* ctx, uint32_t type, const uint8_t* 
   bt.h_len[0] = count;
   KZ_HIP(hipMemcpyAsync(bt.d_len, &count, 4, hipMemcpyHostToDevice, st));
   if (type == KZ_E_ANS0 || type == KZ_E_HUFFMAN || type == KZ_E_FPAQ) {
+    ctx->d_endBits = (long long*)(d_off + 2);
     rc = (type == KZ_E_ANS0) ? kz_stage_ans0_decode(ctx, bt, d_in, inS, d_off, d_off + 1) : (type == KZ_E_HUFFMAN) ? kz_stage_huffman_decode(ctx, bt, d_in, inS, d_off, d_off + 1) : kz_stage_fpaq_decode(ctx, bt, d_in, inS, d_off, d_off + 1);
+    ctx->d_endBits = nullptr;
     if (rc) return rc;
     int32_t flag = 0;
+    long long used = 0;
     KZ_HIP(hipMemcpyAsync(&flag, bt.d_flag, 4, hipMemcpyDeviceToHost, st));
+    KZ_HIP(hipMemcpyAsync(&used, d_off + 2, 8, hipMemcpyDeviceToHost, st));
     KZ_HIP(hipStreamSynchronize(st));
     if (!flag) return -KZ_ERR_PROCESS_BLOCK;
+    if (bitsConsumed) *bitsConsumed = (int64_t)used;
     KZ_HIP(hipMemcpyAsync(dst, bt.buf[bt.cur], (size_t)count, hipMemcpyDeviceToHost, st));
   } else {
     if (inBits < 8LL * count) return -KZ_ERR_PROCESS_BLOCK;

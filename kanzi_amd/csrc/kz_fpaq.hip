@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_fpaq_pack(const int32_t* __restrict__ d
 
 __global__ __launch_bounds__(64) void k_fpaq_dec(const u8* __restrict__ in, int64_t inStride, const int64_t* __restrict__ d_bitOff,
                                                   const int64_t* __restrict__ d_bitEnd, const int32_t* __restrict__ d_len,
-                                                  u8* __restrict__ dst, int64_t stride, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag, int B) {
+                                                  u8* __restrict__ dst, int64_t stride, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag, int B, long long* __restrict__ endOut) {
   __shared__ u16 probs[1024][64];
   // input ring: the next 64 dwords of this lane's chunk, [slot][lane].  A global load issued when a lane consumes a
   // word would be waited for by whichever lane flushes next (one VGPR, in-order vmcnt): every bit step would pay a
@@ -205,6 +205,7 @@ __global__ __launch_bounds__(64) void k_fpaq_dec(const u8* __restrict__ in, int6
     i++;
   }
   if (!bad) for (int k = 0; k < (count & 3); k++) o[(count & ~3) + k] = (u8)(outw >> (8 * k));
+  if (endOut) endOut[b] = (long long)(d_bitOff[b] + 8LL * ipos);     // bits consumed (EntropyDecoder contract)
   if (bad) d_flag[b] = 0;
 }
 
@@ -233,7 +234,7 @@ int kz_stage_fpaq_encode(kz_ctx* ctx, kz_batch& bt, uint8_t* out, int64_t outStr
 int kz_stage_fpaq_decode(kz_ctx* ctx, kz_batch& bt, const uint8_t* in, int64_t inStride, const int64_t* d_bitOff, const int64_t* d_bitEnd) {
   const int B = bt.B;
   u8* dst = bt.buf[bt.cur ^ 1];
-  KZ_LAUNCH(ctx, KID_FPAQ_DEC, k_fpaq_dec, dim3((B + 63) / 64), dim3(64), in, inStride, d_bitOff, d_bitEnd, bt.d_len, dst, bt.stride, bt.d_len2, bt.d_flag, B);
+  KZ_LAUNCH(ctx, KID_FPAQ_DEC, k_fpaq_dec, dim3((B + 63) / 64), dim3(64), in, inStride, d_bitOff, d_bitEnd, bt.d_len, dst, bt.stride, bt.d_len2, bt.d_flag, B, ctx->d_endBits);
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
   { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }

@@ -427,7 +427,7 @@ __device__ __forceinline__ u32 huf_varint(const u8* __restrict__ p, u64& pos) {
 
 // index pass: one lane per block walks the chunk headers
 __global__ void k_huf_dec_index(const u8* __restrict__ in, int64_t inStride, const int64_t* __restrict__ d_bitOff,
-                                const int64_t* __restrict__ d_bitEnd, const int32_t* __restrict__ d_len, HufDec D, int B) {
+                                const int64_t* __restrict__ d_bitEnd, const int32_t* __restrict__ d_len, HufDec D, int B, long long* __restrict__ endOut) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int count = d_len[b];
@@ -459,6 +459,7 @@ __global__ void k_huf_dec_index(const u8* __restrict__ in, int64_t inStride, con
     }
     if (pos > endBits) status = -KZ_ERR_PROCESS_BLOCK;
   }
+  if (endOut) endOut[b] = (long long)pos;                          // bits consumed (EntropyDecoder contract)
   D.status[b] = status;
 }
 
@@ -561,7 +562,7 @@ int kz_stage_huffman_decode(kz_ctx* ctx, kz_batch& bt, const uint8_t* in, int64_
   D.status = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   if (!D.status || !D.chunkBit) { snprintf(ctx->err, sizeof(ctx->err), "huffman_decode: arena overflow"); return -KZ_ERR_DEVICE; }
   u8* dst = bt.buf[bt.cur ^ 1];
-  KZ_LAUNCH(ctx, KID_HUF_DEC_INDEX, k_huf_dec_index, dim3((B + 63) / 64), dim3(64), in, inStride, d_bitOff, d_bitEnd, bt.d_len, D, B);
+  KZ_LAUNCH(ctx, KID_HUF_DEC_INDEX, k_huf_dec_index, dim3((B + 63) / 64), dim3(64), in, inStride, d_bitOff, d_bitEnd, bt.d_len, D, B, ctx->d_endBits);
   const int chunks = (maxN + ANS_CHUNK - 1) / ANS_CHUNK;
   if (chunks > 0) KZ_LAUNCH(ctx, KID_HUF_DEC_CHUNK, k_huf_dec_chunk, dim3(chunks, B), dim3(64), in, inStride, bt.d_len, D, dst, bt.stride, d_bitEnd);
   KZ_LAUNCH(ctx, KID_HUF_DEC_FIN, k_huf_dec_fin, dim3((B + 255) / 256), dim3(256), bt.d_len, bt.d_len2, bt.d_flag, D, B);

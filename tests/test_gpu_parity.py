@@ -105,6 +105,7 @@ def test_entropy_encode_decode_match_oracle(ctx, ent):
         out = np.zeros(len(data), dtype=np.uint8)
         assert dec.decode(out, 0, len(data)) == len(data)
         assert out.tobytes() == data
+        assert dec.bits_consumed == nb_o, (ent, len(data))          # EntropyDecoder contract: exactly the encoder's bits
 
 
 @pytest.mark.parametrize("chain,ent", [("BWT+RANK+ZRLT", "ANS0"), ("BWT+MTFT+ZRLT", "ANS0"), ("ZRLT", "NONE"),
