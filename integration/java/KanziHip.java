@@ -10,7 +10,7 @@ public final class KanziHip {
   public static native int maxEncodedLength(int type, int n);
   public static native int transform(long ctx, int type, boolean forward, byte[] src, int srcIdx, int n, byte[] dst, int dstIdx, int dstCap);
   public static native long entropyEncode(long ctx, int type, byte[] block, int blkptr, int n, byte[] out);
-  public static native int entropyDecode(long ctx, int type, byte[] in, long inBits, byte[] block, int blkptr, int count);
+  public static native int entropyDecode(long ctx, int type, byte[] in, int inOff, long inBits, byte[] block, int blkptr, int count, long[] bitsUsed);
   public static native int encodeBlocks(long ctx, long transformType, int entropyType, java.nio.ByteBuffer in, long inStride,
       int[] lengths, int nBlocks, java.nio.ByteBuffer out, long outStride, long[] bitsOut, int[] postLenOut, byte[] skipFlagsOut);
   private KanziHip() {}

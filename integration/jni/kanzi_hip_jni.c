@@ -57,15 +57,17 @@ JNIEXPORT jlong JNICALL CLS(entropyEncode)(JNIEnv* env, jclass c, jlong ctx, jin
   (*env)->ReleasePrimitiveArrayCritical(env, block, s, JNI_ABORT);
   return bits;
 }
-JNIEXPORT jint JNICALL CLS(entropyDecode)(JNIEnv* env, jclass c, jlong ctx, jint type, jbyteArray in, jlong inBits,
-                                          jbyteArray block, jint blkptr, jint count) {
+/* returns count or -(Error code); bitsUsed[0] = bits the codec consumed from in[inOff..] (EntropyDecoder contract) */
+JNIEXPORT jint JNICALL CLS(entropyDecode)(JNIEnv* env, jclass c, jlong ctx, jint type, jbyteArray in, jint inOff, jlong inBits,
+                                          jbyteArray block, jint blkptr, jint count, jlongArray bitsUsed) {
   (void)c;
   jbyte* s = (*env)->GetPrimitiveArrayCritical(env, in, NULL);
   jbyte* d = (*env)->GetPrimitiveArrayCritical(env, block, NULL);
   int64_t used = 0;
-  int32_t rc = kz_entropy_decode((kz_ctx*)(intptr_t)ctx, (uint32_t)type, (const uint8_t*)s, inBits, (uint8_t*)d + blkptr, count, &used);
+  int32_t rc = kz_entropy_decode((kz_ctx*)(intptr_t)ctx, (uint32_t)type, (const uint8_t*)s + inOff, inBits, (uint8_t*)d + blkptr, count, &used);
   (*env)->ReleasePrimitiveArrayCritical(env, block, d, 0);
   (*env)->ReleasePrimitiveArrayCritical(env, in, s, JNI_ABORT);
+  if (bitsUsed != NULL) { jlong u = (jlong)used; (*env)->SetLongArrayRegion(env, bitsUsed, 0, 1, &u); }
   return rc;
 }
 /* Fused batched path over direct ByteBuffers (pinned host memory owned by Java): the form that pays. */
