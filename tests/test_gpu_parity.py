@@ -342,3 +342,37 @@ def test_fuzz_streams_match_oracle(ctx):
         assert cos.output == ref, (case, n, chain, ent, bs, chk)
         assert kz.CompressedInputStream(ctx, ref).read(max(n, 1)) == data, (case, n, chain, ent, bs, chk)
         assert oracle.decompress(cos.output, n, jobs=2) == data
+
+
+@pytest.mark.parametrize("chain,ent", [("BWT+RANK+ZRLT", "ANS0"), ("LZ", "HUFFMAN"), ("BWT+SRT+ZRLT", "FPAQ"), ("LZX", "NONE")])
+def test_corrupted_streams_never_hang_or_crash(ctx, chain, ent):
+    """Bit flips, truncations and garbage payloads: the decoder must return (an error code or some bytes) -- no hang,
+    no fault -- and a context must stay usable afterwards.  Block checksums (-x64) must flag every payload
+    corruption that still decodes."""
+    rng = np.random.default_rng(77)
+    data = datagen.stream(3, 32768).tobytes()
+    good = oracle.compress(chain, ent, 32768, data, jobs=2, checksum=64)
+    hdr = 24                                                   # leave the stream header alone: those checks run on the host
+    for trial in range(40):
+        bad = bytearray(good)
+        kind = trial % 4
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                pos = int(rng.integers(hdr, len(bad)))
+                bad[pos] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            bad = bad[:int(rng.integers(hdr, len(bad)))]
+        elif kind == 2:
+            a = int(rng.integers(hdr, len(bad) - 64))
+            bad[a:a + 64] = bytes(rng.integers(0, 256, 64, dtype=np.uint8))
+        else:
+            a = int(rng.integers(hdr, len(bad) - 8))
+            del bad[a:a + int(rng.integers(1, 8))]
+        try:
+            out = kz.CompressedInputStream(ctx, bytes(bad)).read(len(data))
+            assert out == data or len(out) <= len(data)       # undetected only if nothing that matters changed
+            if bytes(bad) != good:
+                assert out == data or len(out) < len(data), "payload corruption slipped through the block checksum"
+        except kz.KanziError as e:
+            assert e.code > 0
+    assert kz.CompressedInputStream(ctx, good).read(len(data)) == data
