@@ -17,6 +17,11 @@ typedef unsigned long long u64;
 typedef uint32_t u32;
 typedef uint8_t u8;
 
+// The workgroup is ONE wave: vector memory operations of a wave are issued and performed in program order (and the
+// per-CU L1 is write-through), so a load that follows a store to the same address sees it without s_barrier; a
+// real barrier would also drain every outstanding store (s_waitcnt vmcnt(0)) at each parse step.  Only the compiler
+// has to be kept from reordering.
+#define LZ_ORDER() __builtin_amdgcn_wave_barrier()
 #define LZ_SEED 0x1E35A7BDULL
 #define LZ_MAXD1 ((1 << 16) - 2)
 #define LZ_MAXD2 ((1 << 24) - 2)
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
   u8* tkBuf = tmpAll + (int64_t)b * tmpStride;
   u8* mBuf = tkBuf + tmpStride / 3;
   u8* mLenBuf = mBuf + tmpStride / 3;
-  __syncthreads();
+  LZ_ORDER();
   const int minMatch = 4;                                            // dataType UNDEFINED (:342-353)
   const int srcEnd = count - 16 - 2;
   const int maxDist = (srcEnd < 4 * LZ_MAXD1) ? LZ_MAXD1 : LZ_MAXD2;
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
     int bestLen = 0;
     const int h0 = lz_hash(src + srcIdx, extra);
     const int ref0 = hashes[h0];
-    __syncthreads();
+    LZ_ORDER();
     if (w) hashes[h0] = srcIdx;
     const int srcIdx1 = srcIdx + 1;
     int ref = srcIdx1 - (repIdx ? repd1 : repd0);
@@ -110,11 +115,11 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
     if (bestLen < minMatch) {
       ref = ref0;
       if ((ref > minRef) && !lz_diff4(src, ref, srcIdx)) bestLen = lz_find_match(src, srcIdx, ref, min(srcEnd - srcIdx, LZ_MAX_MATCH));
-      if (bestLen < minMatch) { srcIdx = srcIdx1 + (srcInc >> 6); srcInc++; repIdx = 0; __syncthreads(); continue; }
+      if (bestLen < minMatch) { srcIdx = srcIdx1 + (srcInc >> 6); srcInc++; repIdx = 0; LZ_ORDER(); continue; }
       if ((ref != srcIdx - repd0) && (ref != srcIdx - repd1)) {
         const int h1 = lz_hash(src + srcIdx1, extra);
         const int ref1 = hashes[h1];
-        __syncthreads();
+        LZ_ORDER();
         if (w) hashes[h1] = srcIdx1;
         if ((ref1 > minRef + 1) && !lz_diff4(src, ref1 + bestLen - 3, srcIdx1 + bestLen - 3)) {
           const int bestLen1 = lz_find_match(src, srcIdx1, ref1, min(srcEnd - srcIdx1, LZ_MAX_MATCH));
@@ -123,9 +128,9 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
         if (extra) {
           const int srcIdx2 = srcIdx1 + 1;
           const int h2 = lz_hash(src + srcIdx2, extra);
-          __syncthreads();
+          LZ_ORDER();
           const int ref2 = hashes[h2];
-          __syncthreads();
+          LZ_ORDER();
           if (w) hashes[h2] = srcIdx2;
           if ((ref2 > minRef + 2) && !lz_diff4(src, ref2 + bestLen - 3, srcIdx2 + bestLen - 3)) {
             const int bestLen2 = lz_find_match(src, srcIdx2, ref2, min(srcEnd - srcIdx2, LZ_MAX_MATCH));
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
       if ((bestLen >= LZ_MAX_MATCH) || (src[srcIdx] != src[ref - 1])) {
         srcIdx++;
         const int h1 = lz_hash(src + srcIdx, extra);
-        __syncthreads();
+        LZ_ORDER();
         if (w) hashes[h1] = srcIdx;
       } else { bestLen++; ref--; }
     }
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
       dstIdx += litLen;
     }
     anchor = srcIdx + bestLen;
-    __syncthreads();
+    LZ_ORDER();
     // hash fill of the covered positions (:554-565): position-monotone, last writer = highest position
     for (int p0 = srcIdx + 1; p0 < anchor; p0 += 64) {
       const int pp = p0 + lane;
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
         if (al && act && l > lane && hl == hh) act = false;
       }
       if (act) hashes[hh] = pp;
-      __syncthreads();
+      LZ_ORDER();
     }
     srcIdx = anchor;
   }
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
         dst[4] = (u8)tkIdx; dst[5] = (u8)(tkIdx >> 8); dst[6] = (u8)(tkIdx >> 16); dst[7] = (u8)(tkIdx >> 24);
         dst[8] = (u8)mIdx; dst[9] = (u8)(mIdx >> 8); dst[10] = (u8)(mIdx >> 16); dst[11] = (u8)(mIdx >> 24);
       }
-      __syncthreads();
+      LZ_ORDER();
       lz_copy(dst + dstIdx, tkBuf, tkIdx); dstIdx += tkIdx;
       lz_copy(dst + dstIdx, mBuf, mIdx); dstIdx += mIdx;
       lz_copy(dst + dstIdx, mLenBuf, mLenIdx); dstIdx += mLenIdx;
@@ -277,15 +282,15 @@ __global__ __launch_bounds__(64) void k_lz_inv(const u8* __restrict__ srcAll, u8
         const int ref = dstIdx - dist;
         if ((ref < 0) || (dist > maxDist) || (mEnd > dstEnd) || dist <= 0) { ok = false; break; }
         // make the preceding stores of this wave visible to the copy below
-        __syncthreads();
+        LZ_ORDER();
         __threadfence_block();
         if (dist >= 64) {
-          for (int k = 0; k < mLen; k += 64) { const int i = k + lane; u8 v = 0; if (i < mLen) v = dst[ref + i]; __syncthreads(); if (i < mLen) dst[dstIdx + i] = v; __syncthreads(); }
+          for (int k = 0; k < mLen; k += 64) { const int i = k + lane; u8 v = 0; if (i < mLen) v = dst[ref + i]; LZ_ORDER(); if (i < mLen) dst[dstIdx + i] = v; LZ_ORDER(); }
         } else {
           // overlapping copy: the output is periodic with period dist over already written bytes
           for (int i = lane; i < mLen; i += 64) dst[dstIdx + i] = dst[ref + (i % dist)];
         }
-        __syncthreads();
+        LZ_ORDER();
         dstIdx = mEnd;
       }
     }
