@@ -376,3 +376,19 @@ def test_corrupted_streams_never_hang_or_crash(ctx, chain, ent):
         except kz.KanziError as e:
             assert e.code > 0
     assert kz.CompressedInputStream(ctx, good).read(len(data)) == data
+
+
+def test_large_blocks_match_oracle(ctx):
+    """Blocks above the 4 MiB default: 8 MiB blocks (the reference's -l 6 default, BlockCompressor.java:143-145) and a
+    ragged 12 MiB block, against the oracle."""
+    rng = np.random.default_rng(5)
+    words = [bytes(rng.integers(97, 123, int(rng.integers(2, 10)), dtype=np.uint8)) for _ in range(500)]
+    text = b" ".join(words[int(i)] for i in rng.integers(0, 500, 2_600_000))
+    data = text[:8 * 1024 * 1024 + 12345] + bytes(rng.integers(0, 256, 300000, dtype=np.uint8)) + bytes(500000)
+    for bs, chain, ent in ((8 * 1024 * 1024, "BWT+RANK+ZRLT", "ANS0"), (12 * 1024 * 1024, "BWT+SRT+ZRLT", "HUFFMAN")):
+        ref = oracle.compress(chain, ent, bs, data, jobs=2)
+        cos = kz.CompressedOutputStream(ctx, chain, ent, bs)
+        cos.write(data)
+        cos.close()
+        assert cos.output == ref, (bs, chain)
+        assert kz.CompressedInputStream(ctx, ref).read() == data
