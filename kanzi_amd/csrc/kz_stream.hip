@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <memory>
+#include <thread>
+#include <atomic>
 
 namespace {
 struct HostBits {            // MSB-first writer (DefaultOutputBitStream.java:103-205)
@@ -166,6 +168,56 @@ extern "C" int32_t kz_knz_index(const uint8_t* src, int64_t n, uint64_t* transfo
   return nb;
 }
 
+
+// run fn(i) for i in [0, n) on a few host threads (blocks are independent)
+template <typename F>
+static void parallel_blocks(int n, F fn) {
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int T = std::max(1, std::min(std::min(n, 16), hw > 0 ? hw : 1));
+  if (T == 1) { for (int i = 0; i < n; i++) fn(i); return; }
+  std::atomic<int> next(0);
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; t++) th.emplace_back([&]() { for (;;) { const int i = next.fetch_add(1); if (i >= n) break; fn(i); } });
+  for (auto& x : th) x.join();
+}
+
+// Ordered emission of a batch (CompressedOutputStream.java:1024-1035) at bit granularity.  The serial pass writes,
+// per block, the 5-bit / lw-bit length prefix and the (at most 7 + 7) payload bits that share a byte with a
+// neighbour, skipping the bytes that belong to one payload only; those interiors are then copied (shifted) by a
+// few threads.
+static void emit_blocks(HostBits& bs, const uint8_t* streams, int64_t stride, const kz_block_result* res, int cnt) {
+  struct Job { const uint8_t* s; uint8_t* d; uint64_t nbytes; int e; };
+  std::vector<Job> jobs;
+  jobs.reserve(cnt);
+  for (int i = 0; i < cnt; i++) {
+    const uint64_t W = (uint64_t)res[i].bits;
+    if (W == 0) continue;
+    const uint8_t* s = streams + (size_t)i * stride;
+    const int lw = (W < 8) ? 3 : ilog2((uint32_t)(W >> 3)) + 4;
+    bs.put((uint64_t)(lw - 3), 5);
+    bs.put(W, lw);
+    if (bs.overflow || (int64_t)((bs.pos + W + 7) >> 3) > bs.cap) { bs.overflow = true; return; }
+    const int e = (int)((8 - (bs.pos & 7)) & 7);                  // payload bits that complete the current byte
+    if (W < (uint64_t)e + 16) { bs.putBytes(s, W); continue; }    // tiny block: all serial
+    if (e) bs.put((uint64_t)(s[0] >> (8 - e)), e);
+    const uint64_t nbytes = (W - (uint64_t)e) >> 3;               // whole bytes owned by this payload alone
+    jobs.push_back({s, bs.p + (bs.pos >> 3), nbytes, e});
+    bs.pos += nbytes << 3;
+    const int r = (int)((W - (uint64_t)e) & 7);                   // trailing bits
+    if (r) {
+      const uint64_t bitoff = (uint64_t)e + (nbytes << 3);
+      const uint32_t two = ((uint32_t)s[bitoff >> 3] << 8) | (uint32_t)s[(bitoff >> 3) + 1];
+      bs.put((uint64_t)((two >> (16 - (int)(bitoff & 7) - r)) & ((1u << r) - 1)), r);
+    }
+  }
+  parallel_blocks((int)jobs.size(), [&](int k) {
+    const Job& j = jobs[k];
+    if (j.e == 0) { memcpy(j.d, j.s, (size_t)j.nbytes); return; }
+    const int e = j.e, up = 8 - e;
+    for (uint64_t i = 0; i < j.nbytes; i++) j.d[i] = (uint8_t)((j.s[i] << e) | (j.s[i + 1] >> up));
+  });
+}
+
 extern "C" int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
                                const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstCap) {
   if (!ctx || !src || !dst || n < 0) return -KZ_ERR_INVALID_PARAM;
@@ -186,10 +238,9 @@ extern "C" int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t ent
     int rc = kz_encode_blocks(ctx, transformType, entropyType, src + b0 * blockSize, blockSize, lens.data(), cnt,
                               outbuf.get(), oS, res.data(), KZ_MEM_HOST);
     if (rc) return rc;
-    for (int i = 0; i < cnt; i++) {                             // ordered emission (:1024-1035)
-      if (res[i].status) return res[i].status;
-      if (res[i].bits > 0) write_block(bs, outbuf.get() + (size_t)i * oS, (uint64_t)res[i].bits);
-    }
+    for (int i = 0; i < cnt; i++) if (res[i].status) return res[i].status;
+    emit_blocks(bs, outbuf.get(), oS, res.data(), cnt);           // ordered emission (:1024-1035)
+    if (bs.overflow) break;
   }
   bs.put(0, 5); bs.put(0, 3);                                   // end marker (:491-492)
   if (bs.overflow) { snprintf(ctx->err, sizeof(ctx->err), "kz_compress: destination too small"); return -KZ_ERR_WRITE_FILE; }
@@ -264,6 +315,7 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
   const int64_t iS = (int64_t)kz_align((size_t)blockSize + (size_t)(blockSize >> 3) + 1024 + 64, 256);
   std::unique_ptr<uint8_t[]> inbuf(new uint8_t[(size_t)iS * NB]);
   std::vector<int64_t> bits(NB);
+  std::vector<uint64_t> starts(NB);
   std::vector<kz_block_result> res(NB);
   int64_t produced = 0;
   bool done = false;
@@ -276,11 +328,13 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
       if (rd == 0) { done = true; break; }
       { const int hrc = precheck_block_header(bs, rd, nbFunctions, blockSize, chkKind); if (hrc) return hrc; }
       if ((int64_t)((rd + 7) >> 3) > iS - 64) return -KZ_ERR_BLOCK_SIZE;
-      bs.getBytes(inbuf.get() + (size_t)cnt * iS, rd);
-      if (bs.error) return -KZ_ERR_READ_FILE;
+      if (bs.pos + rd > bs.nbits) return -KZ_ERR_READ_FILE;
+      starts[cnt] = bs.pos;                                     // the payload is extracted below, by several threads
+      bs.pos += rd;
       bits[cnt++] = (int64_t)rd;
     }
     if (cnt == 0) break;
+    parallel_blocks(cnt, [&](int i) { HostBitsIn t = bs; t.pos = starts[i]; t.error = false; t.getBytes(inbuf.get() + (size_t)i * iS, (uint64_t)bits[i]); });
     if (produced + (int64_t)cnt * blockSize > dstCap + blockSize) return -KZ_ERR_WRITE_FILE;
     // decode into a temporary when the tail would overflow dst
     const int64_t room = dstCap - produced;
