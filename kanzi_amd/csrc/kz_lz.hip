@@ -28,13 +28,11 @@ typedef uint8_t u8;
 #define LZ_MAX_MATCH (65535 + 254 + 4)
 #define LZ_MIN_BLOCK 24
 
-__device__ __forceinline__ u64 lz_le64(const u8* p) {
-  u64 v = 0;
-#pragma unroll
-  for (int k = 7; k >= 0; k--) v = (v << 8) | (u64)p[k];
-  return v;
-}
-__device__ __forceinline__ u32 lz_le32(const u8* p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
+// little-endian loads at arbitrary byte addresses: global memory supports unaligned accesses, one load each
+typedef u64 __attribute__((aligned(1))) lz_u64_unaligned;
+typedef u32 __attribute__((aligned(1))) lz_u32_unaligned;
+__device__ __forceinline__ u64 lz_le64(const u8* p) { return *(const lz_u64_unaligned*)p; }
+__device__ __forceinline__ u32 lz_le32(const u8* p) { return *(const lz_u32_unaligned*)p; }
 __device__ __forceinline__ int lz_hash(const u8* p, int extra) { return (int)(((lz_le64(p) << 24) * LZ_SEED) >> (extra ? 45 : 48)); }
 __device__ __forceinline__ bool lz_diff4(const u8* a, int i, int j) { return lz_le32(a + i) != lz_le32(a + j); }
 __device__ __forceinline__ int lz_find_match(const u8* src, int srcIdx, int ref, int maxMatch) {
@@ -187,10 +185,10 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
       int hh = 0; bool act = pp < anchor;
       if (act) hh = lz_hash(src + pp, extra);
       // within the wave several positions may share a slot: only the highest position may win
-      for (int l = 0; l < 64; l++) {
+      for (uint64_t am = kz_ballot(act) & ~1ULL; am; am &= am - 1) {
+        const int l = (int)__builtin_ctzll(am);                    // an active lane above lane 0
         const int hl = __shfl(hh, l, 64);
-        const bool al = __shfl(act ? 1 : 0, l, 64) != 0;
-        if (al && act && l > lane && hl == hh) act = false;
+        if (act && l > lane && hl == hh) act = false;
       }
       if (act) hashes[hh] = pp;
       LZ_ORDER();
