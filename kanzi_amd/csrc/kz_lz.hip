@@ -97,22 +97,28 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
       pfPos = max(pfPos, srcIdx) + 64;
     }
     int bestLen = 0;
-    const int h0 = lz_hash(src + srcIdx, extra);
+    // every load whose address is known up front is issued before the dependent hash-table access: the two repeat
+    // candidates and the current bytes travel together, the chain is then bytes -> table entry -> candidate
+    const int srcIdx1 = srcIdx + 1;
+    const int minRef = max(srcIdx - maxDist, 0);
+    const int refA = srcIdx1 - (repIdx ? repd1 : repd0), refB = srcIdx1 - (repIdx ? repd0 : repd1);
+    const u64 own = lz_le64(src + srcIdx);
+    const u32 own1 = lz_le32(src + srcIdx1);
+    const u32 wA = lz_le32(src + max(refA, 0)), wB = lz_le32(src + max(refB, 0));
+    const int h0 = (int)(((own << 24) * LZ_SEED) >> (extra ? 45 : 48));
     const int ref0 = hashes[h0];
     LZ_ORDER();
     if (w) hashes[h0] = srcIdx;
-    const int srcIdx1 = srcIdx + 1;
-    int ref = srcIdx1 - (repIdx ? repd1 : repd0);
-    const int minRef = max(srcIdx - maxDist, 0);
-    if ((ref > minRef) && !lz_diff4(src, ref, srcIdx1)) {
+    int ref = refA;
+    if ((ref > minRef) && (wA == own1)) {
       bestLen = lz_find_match(src, srcIdx1, ref, min(srcEnd - srcIdx1, LZ_MAX_MATCH));
     } else {
-      ref = srcIdx1 - (repIdx ? repd0 : repd1);
-      if ((ref > minRef) && !lz_diff4(src, ref, srcIdx1)) bestLen = lz_find_match(src, srcIdx1, ref, min(srcEnd - srcIdx1, LZ_MAX_MATCH));
+      ref = refB;
+      if ((ref > minRef) && (wB == own1)) bestLen = lz_find_match(src, srcIdx1, ref, min(srcEnd - srcIdx1, LZ_MAX_MATCH));
     }
     if (bestLen < minMatch) {
       ref = ref0;
-      if ((ref > minRef) && !lz_diff4(src, ref, srcIdx)) bestLen = lz_find_match(src, srcIdx, ref, min(srcEnd - srcIdx, LZ_MAX_MATCH));
+      if ((ref > minRef) && (lz_le32(src + ref) == (u32)own)) bestLen = lz_find_match(src, srcIdx, ref, min(srcEnd - srcIdx, LZ_MAX_MATCH));
       if (bestLen < minMatch) { srcIdx = srcIdx1 + (srcInc >> 6); srcInc++; repIdx = 0; LZ_ORDER(); continue; }
       if ((ref != srcIdx - repd0) && (ref != srcIdx - repd1)) {
         const int h1 = lz_hash(src + srcIdx1, extra);
