@@ -35,12 +35,24 @@ __device__ __forceinline__ u64 lz_le64(const u8* p) { return *(const lz_u64_unal
 __device__ __forceinline__ u32 lz_le32(const u8* p) { return *(const lz_u32_unaligned*)p; }
 __device__ __forceinline__ int lz_hash(const u8* p, int extra) { return (int)(((lz_le64(p) << 24) * LZ_SEED) >> (extra ? 45 : 48)); }
 __device__ __forceinline__ bool lz_diff4(const u8* a, int i, int j) { return lz_le32(a + i) != lz_le32(a + j); }
+// match length (LZCodec.java:271-287: 8 bytes per step, same result): all arguments are wave-uniform; the 64 lanes
+// compare 512 bytes per round trip instead of 8
 __device__ __forceinline__ int lz_find_match(const u8* src, int srcIdx, int ref, int maxMatch) {
+  const int lane = kz_lane();
   int bestLen = 0;
   while (bestLen + 8 <= maxMatch) {
-    const u64 diff = lz_le64(src + srcIdx + bestLen) ^ lz_le64(src + ref + bestLen);
-    if (diff != 0) { bestLen += (__builtin_ctzll(diff) >> 3); break; }
-    bestLen += 8;
+    const int off = bestLen + 8 * lane;
+    const bool in = off + 8 <= maxMatch;
+    const u64 diff = in ? (lz_le64(src + srcIdx + off) ^ lz_le64(src + ref + off)) : 0ULL;
+    const uint64_t inMask = kz_ballot(in);
+    const uint64_t dm = kz_ballot(in && diff != 0);
+    if (dm) {
+      const int l = (int)__builtin_ctzll(dm);
+      const u32 dlo = (u32)__builtin_amdgcn_readlane((int)(u32)diff, l), dhi = (u32)__builtin_amdgcn_readlane((int)(u32)(diff >> 32), l);
+      const u64 dd = ((u64)dhi << 32) | dlo;
+      return bestLen + 8 * l + (int)(__builtin_ctzll(dd) >> 3);
+    }
+    bestLen += 8 * (int)__builtin_popcountll(inMask);
   }
   return bestLen;
 }
@@ -142,7 +154,21 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
           }
         }
       }
-      while ((srcIdx > anchor) && (ref > minRef) && (src[srcIdx - 1] == src[ref - 1])) { bestLen++; ref--; srcIdx--; }
+      // backward extension (:527-531): up to 8 bytes per round trip instead of one
+      while ((srcIdx > anchor) && (ref > minRef)) {
+        int ext;
+        if (ref >= 8) {
+          const u64 x = lz_le64(src + srcIdx - 8) ^ lz_le64(src + ref - 8);      // byte k-1 back = bits 63-8(k-1)..
+          ext = x ? (int)(__builtin_clzll(x) >> 3) : 8;
+        } else {                                                     // first 8 bytes of the block: byte by byte
+          while ((srcIdx > anchor) && (ref > minRef) && (src[srcIdx - 1] == src[ref - 1])) { bestLen++; ref--; srcIdx--; }
+          break;
+        }
+        ext = min(ext, min(srcIdx - anchor, ref - minRef));
+        if (ext == 0) break;
+        bestLen += ext; ref -= ext; srcIdx -= ext;
+        if (ext < 8) break;
+      }
       if (bestLen > LZ_MAX_MATCH) { ref += (bestLen - LZ_MAX_MATCH); srcIdx += (bestLen - LZ_MAX_MATCH); bestLen = LZ_MAX_MATCH; }
     } else {
       if ((bestLen >= LZ_MAX_MATCH) || (src[srcIdx] != src[ref - 1])) {
