@@ -195,8 +195,8 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
     K[fs] = (lane == (int)(f & 63u)) ? (((u64)fq << 32) | (u64)fplo) : ok; }
 
 // One non-zero rank at row position JV (iv = row + JV).  WRITE_OUT stores the decoded symbol c in lane JV of outv.
-#define KZ_SBRT_NZ_STEP(JV, WRITE_OUT)                                                         \
-  { const u32 r = (u32)__builtin_amdgcn_readlane((int)cur, (JV));                              \
+#define KZ_SBRT_NZ_STEP(JV, RVAL, WRITE_OUT)                                                   \
+  { const u32 r = (RVAL);                                                                      \
     const u32 w = (u32)__builtin_amdgcn_readlane((int)ord, (int)(r >> 2));                     \
     const u32 c = (w >> ((r & 3u) * 8u)) & 0xFFu;                                              \
     const int cl = (int)(c & 63u), cs = (int)(c >> 6);                                         \
@@ -226,13 +226,14 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
 
 // unrolled row position J: skipped when its rank is zero; zeros right before it repair the front key first
 #define KZ_SBRT_STEP_CONST(J)                                                                  \
+  rq0 = rq1; rq1 = (u32)__builtin_amdgcn_readlane((int)cur, (J + 1) & 63);   /* rank of the next position: off the critical chain */ \
   if ((nz >> J) & 1ULL) {                                                                      \
     if (J > 0 && !((nz >> (J > 0 ? J - 1 : 0)) & 1ULL)) {                                      \
       const uint64_t below = nz & ((1ULL << J) - 1ULL);                                        \
       const int pz = below ? 63 - (int)__builtin_clzll(below) : -1;                            \
       KZ_SBRT_ZERO_RUN(J - pz - 1, row + J - 1)                                                \
     }                                                                                          \
-    KZ_SBRT_NZ_STEP(J, asm volatile("v_writelane_b32 %0, %1, " #J : "+v"(outv) : "s"(c));)    \
+    KZ_SBRT_NZ_STEP(J, rq0, asm volatile("v_writelane_b32 %0, %1, " #J : "+v"(outv) : "s"(c));)  \
   }
 #define KZ_SBRT_STEP4(A, B, C, D) KZ_SBRT_STEP_CONST(A) KZ_SBRT_STEP_CONST(B) KZ_SBRT_STEP_CONST(C) KZ_SBRT_STEP_CONST(D)
 
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
     if (cnt == 64 && __builtin_popcountll(nz) >= 40) {
       // most ranks of the row are non-zero (poorly compressible data: the blocks that set the kernel's run time):
       // straight-line code with constant lane numbers, no loop control; zero ranks are skipped with a bit test
+      u32 rq0 = 0, rq1 = (u32)__builtin_amdgcn_readlane((int)cur, 0);
       KZ_SBRT_STEP4(0, 1, 2, 3) KZ_SBRT_STEP4(4, 5, 6, 7) KZ_SBRT_STEP4(8, 9, 10, 11) KZ_SBRT_STEP4(12, 13, 14, 15)
       KZ_SBRT_STEP4(16, 17, 18, 19) KZ_SBRT_STEP4(20, 21, 22, 23) KZ_SBRT_STEP4(24, 25, 26, 27) KZ_SBRT_STEP4(28, 29, 30, 31)
       KZ_SBRT_STEP4(32, 33, 34, 35) KZ_SBRT_STEP4(36, 37, 38, 39) KZ_SBRT_STEP4(40, 41, 42, 43) KZ_SBRT_STEP4(44, 45, 46, 47)
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
         nz &= nz - 1;
         const int zr = j - prev - 1;
         if (zr > 0) KZ_SBRT_ZERO_RUN(zr, row + j - 1)
-        KZ_SBRT_NZ_STEP(j, asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(c), "s"(j) : "m0");)
+        KZ_SBRT_NZ_STEP(j, (u32)__builtin_amdgcn_readlane((int)cur, j), asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(c), "s"(j) : "m0");)
         prev = j;
       }
       { const int zr = cnt - prev - 1; if (zr > 0) KZ_SBRT_ZERO_RUN(zr, row + cnt - 1) }
