@@ -33,6 +33,7 @@
 typedef unsigned long long u64;
 typedef uint32_t u32;
 typedef uint8_t u8;
+typedef u64 __attribute__((aligned(1))) bw_u64_unaligned;
 
 struct BwtArrays {
   u64* key[2]; u32* val[2];
@@ -59,10 +60,10 @@ __global__ void k_bwt_init(const u8* __restrict__ src, int64_t srcStride, u64* k
   u64* key = keyC + (int64_t)b * A.NS;
   u32* val = valC + (int64_t)b * A.NS;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    u64 k = 0;
     const int rem = n - i;
-#pragma unroll
-    for (int j = 0; j < 7; j++) k = (k << 8) | (u64)((j < rem) ? s[i + j] : 0);
+    // first 7 bytes as a big-endian number: one unaligned 8-byte load (blocks have >= 4 KiB of slack behind them)
+    u64 k = __builtin_bswap64(*(const bw_u64_unaligned*)(s + i)) >> 8;
+    if (rem < 7) k &= ~0ULL << (8 * (7 - rem));                     // zero padding at the end of the text
     key[i] = k; val[i] = (u32)i;                                    // 56 bits: 7 radix passes
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { A.d_m[b] = n; }
