@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
 
 // zero run of zr ranks ending at index pl: the front symbol repeats, only its (q,p) change (SBRT.java:194-201)
 #define KZ_SBRT_ZERO_RUN(zr, plv)                                                              \
-  { const u32 pold = max(fplo, 256u) - 256u;                                                   \
+  if (MODE != 1) { const u32 pold = max(fplo, 256u) - 256u;                                                   \
     const u32 pl = (u32)(plv);                                                                 \
     const u32 pp = ((zr) >= 2) ? pl - 1u : pold;                                               \
     const u32 fq = (MODE == 2) ? ((pl + pp) >> 1) : ((MODE == 1) ? pl : pp);                   \
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
     const u32 w = (u32)__builtin_amdgcn_readlane((int)ord, (int)(r >> 2));                     \
     const u32 c = (w >> ((r & 3u) * 8u)) & 0xFFu;                                              \
     const int cl = (int)(c & 63u), cs = (int)(c >> 6);                                         \
-    const u64 ok = K[cs];                                                                      \
-    const u32 plo = (u32)__builtin_amdgcn_readlane((int)(u32)ok, cl);                          \
+    const u64 ok = (MODE == 1) ? 0ULL : K[cs];                  /* MTF: always to the front, no keys needed */ \
+    const u32 plo = (MODE == 1) ? 0u : (u32)__builtin_amdgcn_readlane((int)(u32)ok, cl);       \
     const u32 pc = max(plo, 256u) - 256u;                                                      \
     const u32 iv = (u32)(row + (JV));                                                          \
     const u32 nhi = (MODE == 2) ? ((iv + pc) >> 1) : ((MODE == 1) ? iv : pc);                  \
@@ -209,9 +209,10 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
     const u64 nk = ((u64)nhi << 32) | (u64)nlo;                                                \
     /* new position = number of keys above the new key.  The new key's low half (iv + 256) exceeds every existing \
        one, so key > nk <=> q > nhi: 32-bit compares of the high halves (never-seen symbols have q = 0) */ \
-    const u32 rp = (u32)(__builtin_popcountll(kz_ballot((u32)(K[0] >> 32) > nhi)) + __builtin_popcountll(kz_ballot((u32)(K[1] >> 32) > nhi)) + \
+    const u32 rp = (MODE == 1) ? 0u :                                                          \
+                   (u32)(__builtin_popcountll(kz_ballot((u32)(K[0] >> 32) > nhi)) + __builtin_popcountll(kz_ballot((u32)(K[1] >> 32) > nhi)) + \
                          __builtin_popcountll(kz_ballot((u32)(K[2] >> 32) > nhi)) + __builtin_popcountll(kz_ballot((u32)(K[3] >> 32) > nhi))); \
-    K[cs] = (lane == cl) ? nk : ok;                                                            \
+    if (MODE != 1) K[cs] = (lane == cl) ? nk : ok;                                             \
     /* rotate list positions [rp, r]: (rp, r] take their predecessor, rp takes c */            \
     const u32 prevw = KZ_DPP_SHR1_Z(ord);                                                      \
     const int sx = (24 - 8 * (int)r) + v32l, sy = (24 - 8 * (int)rp) + v32l;                   \
