@@ -21,6 +21,7 @@ extern "C" kz_ctx* kz_ctx_create(int32_t deviceId) {
   if (hipSetDevice(deviceId) != hipSuccess) return nullptr;
   kz_ctx* ctx = new kz_ctx();
   ctx->device = deviceId;
+  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, deviceId) == hipSuccess && cus > 0) ctx->numCUs = cus; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
   if (hipHostMalloc((void**)&ctx->hpin, 1 << 20, hipHostMallocDefault) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return nullptr; }
   return ctx;
@@ -633,7 +634,10 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   ChainSpec CS; CS.nb = nb; CS.entropy = (int)entropyType; for (int i = 0; i < nb; i++) CS.types[i] = types[i];
   {
     const size_t perBlock = pipeline_scratch(1, maxLen, true, CS) + (size_t)maxLen * 2 + (size_t)(host ? maxInBytes : 0) + (1 << 16);
-    const int maxB = (int)std::max<size_t>(1, kz_arena_budget() / perBlock);
+    int maxB = (int)std::max<size_t>(1, kz_arena_budget() / perBlock);
+    // the serial-per-block inverse stages like whole multiples of 8 blocks per CU (one wave per block, two per SIMD)
+    const int unit = 8 * (ctx->numCUs > 0 ? ctx->numCUs : 256);
+    if (B > maxB && maxB > unit) maxB = (maxB / unit) * unit;       // only when the batch has to be split anyway
     if (B > maxB) {
       for (int b0 = 0; b0 < B; b0 += maxB) {
         const int cnt = std::min(maxB, B - b0);

@@ -24,6 +24,7 @@ struct kz_ctx {
   int64_t stageAlgBytes[KZ_MAX_STAGES] = {0};
   int nStages = 0;
   int checksum = 0;              // 0 none, 1 XXHash32, 2 XXHash64 (ctx map key "checksum")
+  int numCUs = 256;              // compute units of the device (placement of the serial-per-block kernels)
   long long* d_endBits = nullptr; // optional [B] device array: bit position behind each block's entropy payload (kz_entropy_decode)
   bool timing = false;
   // per-kernel event timing (bench roofline): events recorded on ctx->stream around every launch
