@@ -59,6 +59,9 @@ struct kz_batch {
   std::vector<int32_t> h_cost;  // optional per-block cost hint for serial-per-block stages (length at the previous stage's input)
 };
 
+struct KzPlacement { int wpg = 1; int R = 1; std::vector<int> G, off; const int32_t* d_order = nullptr; };
+int kz_place_blocks(kz_ctx*, const kz_batch&, KzPlacement&);     // kz_sbrt.hip: cost-aware placement of one-wave-per-block kernels
+
 // ---- stages (each works on the whole batch; returns 0 or -KZ_ERR_*) ----
 // forward: reads batch.buf[cur] / d_len, writes buf[cur^1] / d_len and d_flag[b]=1 applied, 0 declined
 int kz_stage_bwt_forward(kz_ctx*, kz_batch&);

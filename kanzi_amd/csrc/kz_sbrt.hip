@@ -357,22 +357,17 @@ int kz_sbrt_ranks(kz_ctx* ctx, const uint8_t* src, uint8_t* dst, int64_t stride,
   return 0;
 }
 
-int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
+
+// ---- placement of one-wave-per-block kernels ------------------------------------------------------
+// The run time of a serial-per-block stage is proportional to a per-block cost the host knows (bt.h_cost: the length at
+// the previous stage's input, e.g. the ZRLT-coded length ~ non-zero ranks), and two waves on one SIMD slow each other
+// down.  Small batches get one wave per workgroup (spread over all CUs); large batches get 8 blocks per workgroup =
+// per CU (wave w and w+4 share a SIMD), sorted so that every SIMD pairs an expensive block with a cheap one; 16 blocks
+// per CU and more run as consecutive launches of 8 x CUs blocks (1.78 s vs 1.99 s for 4096 blocks).
+int kz_place_blocks(kz_ctx* ctx, const kz_batch& bt, KzPlacement& PL) {
   const int B = bt.B;
-  for (int b = 0; b < B; b++) if (bt.h_len[b] >= (1 << 24) - 256) {
-    snprintf(ctx->err, sizeof(ctx->err), "sbrt_inverse: block of %d bytes exceeds the packed-key limit 2^24-256", bt.h_len[b]);
-    return -KZ_ERR_BLOCK_SIZE;
-  }
-  hipStream_t st = ctx->stream;
-  const u8* src = bt.buf[bt.cur];
-  u8* dst = bt.buf[bt.cur ^ 1];
-  // ---- placement: the decode time of a block is proportional to its non-zero ranks, and two waves on one SIMD
-  // slow each other down.  Small batches get one wave per workgroup (spread over all CUs); large batches get 8
-  // blocks per workgroup = per CU, sorted so that every SIMD pairs an expensive block with a cheap one. ----
   const int cus = ctx->numCUs > 0 ? ctx->numCUs : 256;
   const int wpg = B > 4 * cus ? 8 : (B > 2 * cus ? 4 : (B > cus ? 2 : 1));
-  // 16 blocks per CU and more: consecutive launches of 8 x CUs blocks each beat 4 waves per SIMD (1.78 s vs 1.99 s
-  // for 4096 blocks); the sorted blocks are dealt round-robin so that every launch gets the same mix
   const int perLaunch = 8 * cus;
   const int R = (wpg == 8) ? std::max(1, B / perLaunch) : 1;       // only whole multiples pay: 1.5 x 8 x CUs is faster in one launch
   std::vector<int32_t> idx(B);
@@ -383,13 +378,13 @@ int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
       const int64_t cx = bt.h_len[x] > 0 ? bt.h_cost[x] : -1, cy = bt.h_len[y] > 0 ? bt.h_cost[y] : -1;
       return cx > cy; });
   std::vector<int32_t> order;
-  std::vector<int> launchG(R), launchOff(R);
+  PL.wpg = wpg; PL.R = R; PL.G.assign(R, 0); PL.off.assign(R, 0);
   for (int rr = 0; rr < R; rr++) {
     const int nb = (B - rr + R - 1) / R;                            // blocks idx[rr], idx[rr + R], ... of this launch
     const int G = (nb + wpg - 1) / wpg;
-    launchG[rr] = G; launchOff[rr] = (int)order.size();
+    PL.G[rr] = G; PL.off[rr] = (int)order.size();
     order.resize(order.size() + (size_t)G * wpg, -1);
-    int32_t* o = order.data() + launchOff[rr];
+    int32_t* o = order.data() + PL.off[rr];
     for (int k = 0; k < nb; k++) {
       const int blk = idx[rr + k * R];
       if (haveCost) {
@@ -400,10 +395,29 @@ int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
       } else o[k] = blk;
     }
   }
-  int32_t* d_order = (int32_t*)kz_arena_alloc(ctx, order.size() * 4);
-  if (!d_order) { snprintf(ctx->err, sizeof(ctx->err), "sbrt_inverse: arena overflow"); return -KZ_ERR_DEVICE; }
-  KZ_HIP(hipMemcpyAsync(d_order, order.data(), order.size() * 4, hipMemcpyHostToDevice, st));
-  KZ_HIP(hipStreamSynchronize(st));                                 // order[] is a local
+  int32_t* d = (int32_t*)kz_arena_alloc(ctx, order.size() * 4);
+  if (!d) { snprintf(ctx->err, sizeof(ctx->err), "placement: arena overflow"); return -KZ_ERR_DEVICE; }
+  KZ_HIP(hipMemcpyAsync(d, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  KZ_HIP(hipStreamSynchronize(ctx->stream));                        // order[] is a local
+  PL.d_order = d;
+  return 0;
+}
+
+int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
+  const int B = bt.B;
+  for (int b = 0; b < B; b++) if (bt.h_len[b] >= (1 << 24) - 256) {
+    snprintf(ctx->err, sizeof(ctx->err), "sbrt_inverse: block of %d bytes exceeds the packed-key limit 2^24-256", bt.h_len[b]);
+    return -KZ_ERR_BLOCK_SIZE;
+  }
+  hipStream_t st = ctx->stream;
+  const u8* src = bt.buf[bt.cur];
+  u8* dst = bt.buf[bt.cur ^ 1];
+  KzPlacement PL;
+  { const int prc = kz_place_blocks(ctx, bt, PL); if (prc) return prc; }
+  const int wpg = PL.wpg, R = PL.R;
+  const std::vector<int>& launchG = PL.G;
+  const std::vector<int>& launchOff = PL.off;
+  const int32_t* d_order = PL.d_order;
   for (int rr = 0; rr < R; rr++) {
     const int G = launchG[rr];
     const int32_t* ord = d_order + launchOff[rr];

@@ -140,20 +140,31 @@ __global__ void k_srt_ffin(const int32_t* __restrict__ d_len, int32_t* __restric
 // inverse: one wave per block
 #define KZ_DPP_SHL1(x) ((u32)__builtin_amdgcn_update_dpp(0, (int)(x), 0x130 /*wave_shl:1*/, 0xF, 0xF, false))
 
-__global__ __launch_bounds__(64) void k_srt_inv(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
-                                                 const int32_t* __restrict__ d_len, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag) {
-  const int b = blockIdx.x;
+// per-wave working set of k_srt_inv (up to 8 waves = 8 blocks per workgroup, see kz_place_blocks)
+struct SrtInvLds {
+  u32 freq[256]; u32 bstart[256]; u32 bend[256]; u32 wbase[256];
+  u8 order[256]; u8 r2s0[256];
+  u8 win[256][32];                   // next 32 ranks of every symbol
+  int h, bad;
+};
+#define SRT_SYNC() __builtin_amdgcn_wave_barrier()   /* one wave per block: program order suffices, keep the compiler in line */
+
+__global__ __launch_bounds__(512) void k_srt_inv(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                                                  const int32_t* __restrict__ d_len, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag,
+                                                  const int32_t* __restrict__ orderIdx, int wavesPerGroup) {
+  __shared__ SrtInvLds LDS[8];
+  const int wv = (int)(threadIdx.x >> 6);
+  const int b = orderIdx[blockIdx.x * wavesPerGroup + wv];
+  if (b < 0) return;
+  SrtInvLds& L = LDS[wv];
+  u32* freq = L.freq; u32* bstart = L.bstart; u32* bend = L.bend; u32* wbase = L.wbase;
+  u8* order = L.order; u8* r2s0 = L.r2s0;
+  u8 (*win)[32] = L.win;
   const int length = d_len[b];
   const int lane = kz_lane();
   const u8* in = src + (int64_t)b * stride;
   u8* o = dst + (int64_t)b * stride;
   if (length <= 0) { if (lane == 0) { d_len2[b] = 0; d_flag[b] = 1; } return; }
-  __shared__ u32 freq[256];
-  __shared__ u32 bstart[256];
-  __shared__ u32 bend[256];
-  __shared__ u8 order[256];
-  __shared__ u8 r2s0[256];
-  __shared__ int sh_h, sh_bad;
   // ---- header (SRT.java:321-346) ----
   if (lane == 0) {
     int h = 0, bad = 0;
@@ -170,13 +181,13 @@ __global__ __launch_bounds__(64) void k_srt_inv(const u8* __restrict__ src, u8* 
       }
       freq[i] = (u32)res;
     }
-    sh_h = h; sh_bad = bad;
+    L.h = h; L.bad = bad;
   }
   for (int i = lane; i < 256; i += 64) r2s0[i] = 0;
-  __syncthreads();
-  const int H = sh_h;
+  SRT_SYNC();
+  const int H = L.h;
   const int count = length - H;
-  if (sh_bad || count < 0) { if (lane == 0) { d_len2[b] = 0; d_flag[b] = 0; } return; }
+  if (L.bad || count < 0) { if (lane == 0) { d_len2[b] = 0; d_flag[b] = 0; } return; }
   const u8* s = in + H;
   // ---- bucket order (freq desc, symbol asc), bucket ranges ----
   int nbSymbols = 0;
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(64) void k_srt_inv(const u8* __restrict__ src, u8* 
     order[pos] = (u8)sym;
     nbSymbols += (int)__popcll(kz_ballot(f > 0));
   }
-  __syncthreads();
+  SRT_SYNC();
   int bad = 0;
   {
     u32 acc = 0;
@@ -203,20 +214,18 @@ __global__ __launch_bounds__(64) void k_srt_inv(const u8* __restrict__ src, u8* 
     }
     if ((int)acc != count) bad = 1;                                  // frequencies must cover the payload
   }
-  __syncthreads();
+  SRT_SYNC();
   if (bad) { if (lane == 0) { d_len2[b] = 0; d_flag[b] = 0; } return; }
   // Every step needs the next rank of the symbol that just became current: a dependent load.  Each symbol's
-  // next 64 ranks are therefore cached in LDS (16 KiB): a step is an LDS read, global memory is touched once
-  // per 64 ranks of a symbol.
-  __shared__ u32 wbase[256];
-  __shared__ u8 win[256][64];
+  // next 32 ranks are therefore cached in LDS (8 KiB per block): a step is an LDS read, global memory is touched once
+  // per 32 ranks of a symbol.
   for (int sym = 0; sym < 256; sym++) {
     const u32 bs = bstart[sym], be = bend[sym];
     const bool present = freq[sym] > 0;
-    win[sym][lane] = (present && bs + (u32)lane < be) ? s[bs + lane] : (u8)0;
+    if (lane < 32) win[sym][lane] = (present && bs + (u32)lane < be) ? s[bs + lane] : (u8)0;
     if (lane == 0) wbase[sym] = bs;
   }
-  __syncthreads();
+  SRT_SYNC();
   // list: position j -> lane j>>2, byte j&3
   u32 list = (u32)r2s0[4 * lane] | ((u32)r2s0[4 * lane + 1] << 8) | ((u32)r2s0[4 * lane + 2] << 16) | ((u32)r2s0[4 * lane + 3] << 24);
   int i = 0;
@@ -224,14 +233,14 @@ __global__ __launch_bounds__(64) void k_srt_inv(const u8* __restrict__ src, u8* 
   while (i < count) {
     const u32 cur = bstart[c], end = bend[c];
     u32 wb = wbase[c];
-    int vc = (int)(min(end, wb + 64u) - cur);                         // ranks of c available in the cached window
-    if (vc == 0 && cur < end) {                                       // window used up: fetch the next 64 ranks
+    int vc = (int)(min(end, wb + 32u) - cur);                         // ranks of c available in the cached window
+    if (vc == 0 && cur < end) {                                       // window used up: fetch the next 32 ranks
       wb = cur;
-      win[c][lane] = (cur + (u32)lane < end) ? s[cur + lane] : (u8)0;
+      if (lane < 32) win[c][lane] = (cur + (u32)lane < end) ? s[cur + lane] : (u8)0;
       if (lane == 0) wbase[c] = wb;
-      vc = (int)min(64u, end - cur);
+      vc = (int)min(32u, end - cur);
     }
-    const u32 v = (lane < vc) ? (u32)win[c][(cur - wb) + (u32)lane] : 0u;
+    const u32 v = (lane < vc) ? (u32)win[c][((cur - wb) + (u32)lane) & 31u] : 0u;
     const uint64_t nz = kz_ballot(v != 0 && lane < vc);
     const int z = nz ? (int)__builtin_ctzll(nz) : vc;                 // leading zero ranks = c repeats
     int r = 0;
@@ -312,7 +321,10 @@ int kz_stage_srt_inverse(kz_ctx* ctx, kz_batch& bt) {
   const int B = bt.B;
   const u8* src = bt.buf[bt.cur];
   u8* dst = bt.buf[bt.cur ^ 1];
-  KZ_LAUNCH(ctx, KID_SRT_INV, k_srt_inv, dim3(B), dim3(64), src, dst, bt.stride, bt.d_len, bt.d_len2, bt.d_flag);
+  KzPlacement PL;
+  { const int prc = kz_place_blocks(ctx, bt, PL); if (prc) return prc; }
+  for (int rr = 0; rr < PL.R; rr++)
+    KZ_LAUNCH(ctx, KID_SRT_INV, k_srt_inv, dim3(PL.G[rr]), dim3(64 * PL.wpg), src, dst, bt.stride, bt.d_len, bt.d_len2, bt.d_flag, PL.d_order + PL.off[rr], PL.wpg);
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
   { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }
