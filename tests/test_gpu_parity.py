@@ -392,3 +392,25 @@ def test_large_blocks_match_oracle(ctx):
         cos.close()
         assert cos.output == ref, (bs, chain)
         assert kz.CompressedInputStream(ctx, ref).read() == data
+
+
+@pytest.mark.parametrize("force", ["lanes", "waves"])
+def test_fpaq_both_arrangements(ctx, force, monkeypatch):
+    """FPAQ has two kernel arrangements (one wave per block for batches up to 8 blocks per CU, one lane per block above):
+    both must produce the oracle's bits."""
+    monkeypatch.setenv("KZ_FPAQ_FORCE", force)
+    data = datagen.stream(6, 65536).tobytes() + bytes(300) + bytes(range(256)) * 3
+    for chain, bs in (("BWT+SRT+ZRLT", 65536), ("NONE", 16384), ("LZ", 1 << 20)):
+        ref = oracle.compress(chain, "FPAQ", bs, data, jobs=2)
+        cos = kz.CompressedOutputStream(ctx, chain, "FPAQ", bs)
+        cos.write(data)
+        cos.close()
+        assert cos.output == ref, (force, chain)
+        assert kz.CompressedInputStream(ctx, ref).read() == data
+    big = (datagen.block(1, 4 * 1024 * 1024 + 4096).tobytes())          # > 4 MiB of FPAQ input: two coder chunks
+    ref = oracle.compress("NONE", "FPAQ", 8 * 1024 * 1024, big, jobs=1)
+    cos = kz.CompressedOutputStream(ctx, "NONE", "FPAQ", 8 * 1024 * 1024)
+    cos.write(big)
+    cos.close()
+    assert cos.output == ref, force
+    assert kz.CompressedInputStream(ctx, ref).read() == big
