@@ -7,9 +7,11 @@
 // and a ballot match-any stable scatter.  The reference then runs 8 pointer-chasing walkers from the
 // 8 primary indexes (BWT.java:295-368); a pointer chase is latency bound (one HBM round trip per
 // byte), so here every block gets THOUSANDS of walkers: one per grid point j*S of the link array plus
-// the text head.  Pass 1 measures each segment (walk until the next grid point), a per-block LDS
-// pointer-jumping pass turns segment lengths into text offsets, pass 2 re-walks and writes the bytes.
-// The output is the same text; only the primary index 0 is needed (the others are validated).
+// the text head.  Every walker follows its segment ONCE (until the next grid point), counting its steps and
+// recording its bytes into pooled 256-byte chunks; a per-block LDS pointer-jumping pass turns the segment
+// lengths into text offsets and a copy kernel moves the chunks to their place (a second walk would cost
+// another cache line per byte).  The output is the same text; only the primary index 0 is needed (the
+// others are validated).
 // Limit: n < 2^24-1 (the packed form; the reference switches to biPSIv2 above 8 MiB with the same
 // output) -- larger blocks return -KZ_ERR_BLOCK_SIZE.
 #include "kz_device.h"

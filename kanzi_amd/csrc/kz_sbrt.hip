@@ -9,11 +9,12 @@
 //
 // forward (parallel):  1) per 8 KiB tile, last two occurrences of every symbol  2) per block, an
 //   exclusive "last-two" scan over tiles (thread = symbol)  3) every tile replays independently:
-//   one wave64 per tile holds the 256 keys in 4 x u64 VGPRs (symbol s = reg s>>6, lane s&63);
-//   a rank is 4 v_cmp_gt_u64 ballots + s_bcnt1.
+//   one wave64 per tile holds the 256 keys in VGPRs (symbol s = element s>>6, lane s&63);
+//   a rank is 4 v_cmp_gt_u64 ballots + s_bcnt1; runs of equal bytes are skipped from the third byte on.
 // inverse (serial per block by nature: the list state depends on every decoded symbol): one wave
-//   per block; the rank->symbol list lives in ONE VGPR (position j = lane j>>2, byte j&3) and a
-//   move-up is a DPP wave shift + byte funnel; blocks of the batch decode concurrently.
+//   per block; the rank->symbol list lives in ONE VGPR (position j = lane j>>2, byte j&3), a move-up
+//   is a DPP wave shift + v_perm; keys stay with their symbol; blocks of the batch decode concurrently,
+//   placed on the SIMDs by cost (kz_place_blocks).
 #include "kz_device.h"
 #include "kz_internal.h"
 #include <algorithm>
