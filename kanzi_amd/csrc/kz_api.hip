@@ -461,14 +461,17 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   F.nbFunctions = nb;
   if (!F.bits || !d_res || !d_out || !F.hash) { snprintf(ctx->err, sizeof(ctx->err), "encode: arena overflow"); return -KZ_ERR_DEVICE; }
 
-  // ---- load blocks into HBM ----
-  for (int b = 0; b < B; b++) {
-    if (lengths[b] == 0) continue;
-    KZ_HIP(hipMemcpyAsync(bt.buf[0] + (int64_t)b * bt.stride, in + (int64_t)b * inStride, (size_t)lengths[b],
-                          host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
-  }
+  // ---- load blocks into HBM (device input: one strided copy kernel instead of one memcpy per block) ----
   for (int b = 0; b < B; b++) bt.h_len[b] = lengths[b];
   KZ_HIP(hipMemcpyAsync(bt.d_len, lengths, (size_t)B * 4, hipMemcpyHostToDevice, st));
+  if (host) {
+    for (int b = 0; b < B; b++) {
+      if (lengths[b] == 0) continue;
+      KZ_HIP(hipMemcpyAsync(bt.buf[0] + (int64_t)b * bt.stride, in + (int64_t)b * inStride, (size_t)lengths[b], hipMemcpyHostToDevice, st));
+    }
+  } else {
+    KZ_LAUNCH(ctx, KID_COPY_BYTES, k_copy_bytes, dim3(64, B), dim3(256), in, inStride, bt.buf[0], bt.stride, bt.d_len, (const int32_t*)nullptr, (const int32_t*)nullptr);
+  }
   KZ_HIP(hipMemsetAsync(d_out, 0, (size_t)outStride * B, st));       // bit-concat ORs into zeroed words
   if (F.chk) { rc = kz_block_hashes(ctx, bt.buf[0], bt.stride, bt.d_len, B, F.chk, F.hash); if (rc) return rc; }
 
@@ -752,9 +755,13 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     if (!h_status[b] && (bt.h_len[b] > blockSize || bt.h_len[b] > outStride)) h_status[b] = -KZ_ERR_PROCESS_BLOCK;
     results[b].bits = bitLengths[b]; results[b].length = h_status[b] ? 0 : bt.h_len[b]; results[b].status = h_status[b];
     results[b].skipFlags = (uint8_t)h_skip[b]; results[b].mode = 0;
-    if (!h_status[b] && bt.h_len[b] > 0)
-      KZ_HIP(hipMemcpyAsync(out + (int64_t)b * outStride, bt.buf[bt.cur] + (int64_t)b * bt.stride, (size_t)bt.h_len[b],
-                            host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, st));
+    if (host && !h_status[b] && bt.h_len[b] > 0)
+      KZ_HIP(hipMemcpyAsync(out + (int64_t)b * outStride, bt.buf[bt.cur] + (int64_t)b * bt.stride, (size_t)bt.h_len[b], hipMemcpyDeviceToHost, st));
+  }
+  if (!host) {                                                   // device output: one strided copy kernel (failed blocks: length 0)
+    for (int b = 0; b < B; b++) ctx->hpin[b] = h_status[b] ? 0 : bt.h_len[b];
+    KZ_HIP(hipMemcpyAsync(bt.d_len, ctx->hpin, (size_t)B * 4, hipMemcpyHostToDevice, st));
+    KZ_LAUNCH(ctx, KID_COPY_BYTES, k_copy_bytes, dim3(64, B), dim3(256), bt.buf[bt.cur], bt.stride, out, outStride, bt.d_len, (const int32_t*)nullptr, (const int32_t*)nullptr);
   }
   KZ_HIP(hipStreamSynchronize(st));
   KZ_HIP(hipGetLastError());
