@@ -414,3 +414,30 @@ def test_fpaq_both_arrangements(ctx, force, monkeypatch):
     cos.close()
     assert cos.output == ref, force
     assert kz.CompressedInputStream(ctx, ref).read() == big
+
+
+def test_device_resident_buffers_match_host_buffers(ctx):
+    """memKind = KZ_MEM_DEVICE (what bench.py times): same streams as with host buffers, and the decoder restores the input."""
+    torch = pytest.importorskip("torch")
+    bs, B = 65536, 24
+    inp = np.stack([datagen.block(i, bs) for i in range(B)])
+    lens = np.full(B, bs, dtype=np.int32)
+    lens[5], lens[7] = 12, 0                                         # a copy block and an empty one
+    ostride = kz.max_block_stream_bytes(bs)
+    out_h = np.zeros((B, ostride), dtype=np.uint8)
+    res_h = kz.encode_blocks(ctx, "BWT+RANK+ZRLT", "ANS0", inp, bs, lens, out_h, ostride)
+    d_in = torch.from_numpy(inp).cuda()
+    d_out = torch.zeros((B, ostride), dtype=torch.uint8, device="cuda")
+    res_d = kz.encode_blocks(ctx, "BWT+RANK+ZRLT", "ANS0", d_in.data_ptr(), bs, lens, d_out.data_ptr(), ostride, kz.MEM_DEVICE)
+    out_d = d_out.cpu().numpy()
+    for i in range(B):
+        assert (res_d[i].bits, res_d[i].length, res_d[i].status) == (res_h[i].bits, res_h[i].length, res_h[i].status)
+        nby = (res_h[i].bits + 7) // 8
+        assert out_d[i, :nby].tobytes() == out_h[i, :nby].tobytes()
+    bits = np.array([r.bits for r in res_d], dtype=np.int64)
+    d_dec = torch.zeros((B, bs), dtype=torch.uint8, device="cuda")
+    res2 = kz.decode_blocks(ctx, "BWT+RANK+ZRLT", "ANS0", bs, d_out.data_ptr(), ostride, bits, d_dec.data_ptr(), bs, kz.MEM_DEVICE)
+    dec = d_dec.cpu().numpy()
+    for i in range(B):
+        assert res2[i].status == 0 and res2[i].length == lens[i]
+        assert dec[i, :lens[i]].tobytes() == inp[i, :lens[i]].tobytes()
