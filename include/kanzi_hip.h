@@ -44,10 +44,10 @@ enum { KZ_T_NONE = 0, KZ_T_BWT = 1, KZ_T_LZ = 3, KZ_T_ZRLT = 6, KZ_T_MTFT = 7, K
        KZ_T_SRT = 13, KZ_T_LZX = 16 };
 /* entropy ids: K/entropy/EntropyCodecFactory.java */
 enum { KZ_E_NONE = 0, KZ_E_HUFFMAN = 1, KZ_E_FPAQ = 2, KZ_E_ANS0 = 5 };
-/* error codes: K/Error.java (returned negated) */
-enum { KZ_ERR_MISSING_PARAM = 1, KZ_ERR_BLOCK_SIZE = 2, KZ_ERR_INVALID_CODEC = 3, KZ_ERR_INVALID_PARAM = 10,
-       KZ_ERR_PROCESS_BLOCK = 13, KZ_ERR_READ_FILE = 15, KZ_ERR_WRITE_FILE = 16, KZ_ERR_CRC_CHECK = 19,
-       KZ_ERR_INVALID_FILE = 21, KZ_ERR_DEVICE = 126, KZ_ERR_UNKNOWN = 127 };
+/* error codes: K/Error.java:24-43 (returned negated); KZ_ERR_DEVICE is the one code the reference has no equivalent for */
+enum { KZ_ERR_MISSING_PARAM = 1, KZ_ERR_BLOCK_SIZE = 2, KZ_ERR_INVALID_CODEC = 3, KZ_ERR_READ_FILE = 11,
+       KZ_ERR_WRITE_FILE = 12, KZ_ERR_PROCESS_BLOCK = 13, KZ_ERR_INVALID_FILE = 15, KZ_ERR_STREAM_VERSION = 16,
+       KZ_ERR_INVALID_PARAM = 18, KZ_ERR_CRC_CHECK = 19, KZ_ERR_DEVICE = 126, KZ_ERR_UNKNOWN = 127 };
 
 /* pointer location flags for the batched calls */
 enum { KZ_MEM_HOST = 0, KZ_MEM_DEVICE = 1 };

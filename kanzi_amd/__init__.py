@@ -394,7 +394,7 @@ class CompressedOutputStream:
 
     def write(self, data):
         if self.closed:
-            raise KanziError(16, "Stream closed")                                # ERR_WRITE_FILE
+            raise KanziError(12, "Stream closed")                                # ERR_WRITE_FILE
         self._chunks.append(bytes(data))
 
     def close(self):

@@ -133,23 +133,42 @@ extern "C" int64_t kz_knz_assemble(uint64_t transformType, uint32_t entropyType,
 
 // Parse the stream header and walk the block length prefixes: blockBitOff[i] = bit offset of block
 // i's private stream inside src, blockBits[i] = its length W.  Returns the number of blocks or <0.
+// Stream header, checked in the reference's order and with its codes (CompressedInputStream.java:359-478).
+struct KnzHeader { int chkKind, entropyType, blockSize, szMask; uint64_t transformType; int64_t inputSize; };
+static int read_stream_header(HostBitsIn& bs, KnzHeader& h, char* err, size_t errCap) {
+  if (bs.get(32) != 0x4B414E5A) return -KZ_ERR_INVALID_FILE;                                    // :367-368
+  const int bsVersion = (int)bs.get(4);
+  if (bsVersion != 7) {                                                                            // :374-377; older layouts are not built here
+    if (err) snprintf(err, errCap, "cannot read this version of the stream: %d (only 7 is built)", bsVersion);
+    return -KZ_ERR_STREAM_VERSION;
+  }
+  h.chkKind = (int)bs.get(2);
+  if (h.chkKind > 2) return -KZ_ERR_INVALID_FILE;                                               // :390-392
+  h.entropyType = (int)bs.get(5);
+  if (h.entropyType == 3 || h.entropyType > 9) return -KZ_ERR_INVALID_CODEC;                     // EntropyCodecFactory.getName :212-243
+  h.transformType = bs.get(48);
+  for (int i = 0; i < 8; i++) {                                                                  // TransformFactory.getName :368-449
+    const int t = (int)((h.transformType >> (42 - 6 * i)) & 0x3F);
+    if (t == 4 || t > 19) return -KZ_ERR_INVALID_CODEC;
+  }
+  h.blockSize = (int)(bs.get(28) << 4);
+  if (h.blockSize < 1024 || h.blockSize > (1 << 30)) return -KZ_ERR_BLOCK_SIZE;                  // :419-422
+  h.szMask = (int)bs.get(2);
+  h.inputSize = h.szMask ? (int64_t)bs.get(16 * h.szMask) : 0;
+  bs.get(15);
+  const uint32_t ck = (uint32_t)bs.get(24);
+  if (bs.error || ck != header_cksum(h.chkKind, h.entropyType, h.transformType, h.blockSize, h.szMask, h.inputSize))
+    return -KZ_ERR_CRC_CHECK;                                                                    // :477-478
+  return 0;
+}
+
 extern "C" int32_t kz_knz_index(const uint8_t* src, int64_t n, uint64_t* transformType, uint32_t* entropyType,
                                 int32_t* blockSize, int64_t* inputSize, int64_t* blockBitOff, int64_t* blockBits, int32_t cap) {
   if (!src || n < 20) return -KZ_ERR_INVALID_FILE;
   HostBitsIn bs{src, (uint64_t)n * 8, 0, false};
-  if (bs.get(32) != 0x4B414E5A) return -KZ_ERR_INVALID_FILE;
-  if (bs.get(4) != 7) return -KZ_ERR_INVALID_FILE;
-  const int chkKind = (int)bs.get(2);
-  const int et = (int)bs.get(5);
-  const uint64_t tt = bs.get(48);
-  const int bsz = (int)(bs.get(28) << 4);
-  const int szMask = (int)bs.get(2);
-  int64_t isz = 0;
-  if (szMask) isz = (int64_t)bs.get(16 * szMask);
-  bs.get(15);
-  const uint32_t ck = (uint32_t)bs.get(24);
-  if (bs.error || ck != header_cksum(chkKind, et, tt, bsz, szMask, isz)) return -KZ_ERR_CRC_CHECK;
-  if (chkKind > 2) return -KZ_ERR_INVALID_FILE;
+  KnzHeader h;
+  { const int hrc = read_stream_header(bs, h, nullptr, 0); if (hrc) return hrc; }
+  const uint64_t tt = h.transformType; const int et = h.entropyType, bsz = h.blockSize; const int64_t isz = h.inputSize;
   if (transformType) *transformType = tt;
   if (entropyType) *entropyType = (uint32_t)et;
   if (blockSize) *blockSize = bsz;
@@ -288,23 +307,13 @@ static int precheck_block_header(HostBitsIn bs /* by value: peek */, uint64_t W,
 extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstCap) {
   if (!ctx || !src || !dst || n < 0) return -KZ_ERR_INVALID_PARAM;
   HostBitsIn bs{src, (uint64_t)n * 8, 0, false};
-  if (bs.get(32) != 0x4B414E5A) return -KZ_ERR_INVALID_FILE;    // CompressedInputStream.java:359-515
-  if (bs.get(4) != 7) { snprintf(ctx->err, sizeof(ctx->err), "only bitstream version 7 is supported"); return -KZ_ERR_INVALID_FILE; }
-  const int chkKind = (int)bs.get(2);
-  const int entropyType = (int)bs.get(5);
-  const uint64_t tt = bs.get(48);
-  const int blockSize = (int)(bs.get(28) << 4);
-  const int szMask = (int)bs.get(2);
-  int64_t inputSize = 0;
-  if (szMask) inputSize = (int64_t)bs.get(16 * szMask);
-  bs.get(15);
-  const uint32_t ck = (uint32_t)bs.get(24);
-  if (bs.error || ck != header_cksum(chkKind, entropyType, tt, blockSize, szMask, inputSize)) return -KZ_ERR_CRC_CHECK;
-  if (chkKind > 2) return -KZ_ERR_INVALID_FILE;
+  KnzHeader h;
+  { const int hrc = read_stream_header(bs, h, ctx->err, sizeof(ctx->err)); if (hrc) return hrc; }
+  const int chkKind = h.chkKind, entropyType = h.entropyType, blockSize = h.blockSize, szMask = h.szMask;
+  const uint64_t tt = h.transformType; const int64_t inputSize = h.inputSize;
   const int savedChk = ctx->checksum;
   ctx->checksum = chkKind;
   struct Restore { kz_ctx* c; int v; ~Restore() { c->checksum = v; } } restore_{ctx, savedChk};
-  if (blockSize < 1024 || blockSize > (1 << 30)) return -KZ_ERR_BLOCK_SIZE;
   int nbFunctions = 0;
   for (int i = 0; i < 8; i++) if (((tt >> (42 - 6 * i)) & 0x3F) != 0) nbFunctions++;         // Sequence length (TransformFactory.java:240-266)
   if (nbFunctions == 0) nbFunctions = 1;
@@ -319,20 +328,25 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
   std::vector<kz_block_result> res(NB);
   int64_t produced = 0;
   bool done = false;
+  int pending = 0;
   while (!done) {
     int cnt = 0;
+    // A fault met while walking the length prefixes is held back until the blocks before it have been decoded:
+    // the reference reports the FIRST failing block in stream order (processedBlockId ordering, :1127-1170).
     while (cnt < NB) {                                          // serial walk of block length prefixes (:1127-1129)
       const int lr = (int)bs.get(5) + 3;
       const uint64_t rd = bs.get(lr);
-      if (bs.error) return -KZ_ERR_READ_FILE;
+      if (bs.error) { pending = -KZ_ERR_READ_FILE; break; }
       if (rd == 0) { done = true; break; }
-      { const int hrc = precheck_block_header(bs, rd, nbFunctions, blockSize, chkKind); if (hrc) return hrc; }
-      if ((int64_t)((rd + 7) >> 3) > iS - 64) return -KZ_ERR_BLOCK_SIZE;
-      if (bs.pos + rd > bs.nbits) return -KZ_ERR_READ_FILE;
+      pending = precheck_block_header(bs, rd, nbFunctions, blockSize, chkKind);
+      if (!pending && (int64_t)((rd + 7) >> 3) > iS - 64) pending = -KZ_ERR_BLOCK_SIZE;
+      if (!pending && bs.pos + rd > bs.nbits) pending = -KZ_ERR_READ_FILE;
+      if (pending) break;
       starts[cnt] = bs.pos;                                     // the payload is extracted below, by several threads
       bs.pos += rd;
       bits[cnt++] = (int64_t)rd;
     }
+    if (pending) done = true;
     if (cnt == 0) break;
     parallel_blocks(cnt, [&](int i) { HostBitsIn t = bs; t.pos = starts[i]; t.error = false; t.getBytes(inbuf.get() + (size_t)i * iS, (uint64_t)bits[i]); });
     if (produced + (int64_t)cnt * blockSize > dstCap + blockSize) return -KZ_ERR_WRITE_FILE;
@@ -360,5 +374,5 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
       }
     }
   }
-  return produced;
+  return pending ? pending : produced;
 }

@@ -262,7 +262,7 @@ int kzo_decode_block(uint64_t transformType, int entropyType, int blockSize, con
 
 int kzo_decode_block_x(uint64_t transformType, int entropyType, int chkKind, int blockSize, const uint8_t* in,
                        int64_t nbits, uint8_t* out, int outCap) {
-  if (nbits < 8) return -1;
+  if (nbits < 8) return -2;                                      /* ERR_BLOCK_SIZE :1027-1028 */
   kzo_ibs is; kzo_ibs_init(&is, in, (uint64_t)nbits);
   int types[8];
   uint8_t mode = (uint8_t)kzo_ibs_read(&is, 8);
@@ -279,14 +279,18 @@ int kzo_decode_block_x(uint64_t transformType, int entropyType, int chkKind, int
   else skipFlags = (uint8_t)((mode << 4) | 0x0F);
   const int dataSize = 1 + ((mode >> 5) & 3);
   const int headerSize = 1 + hasSkipFlags + dataSize + 1;
-  if (nbits < (headerSize << 3)) return -1;
+  if (nbits < (headerSize << 3)) return -2;                      /* ERR_BLOCK_SIZE :1056-1057 */
   if (hasSkipFlags) skipFlags = (uint8_t)kzo_ibs_read(&is, 8);
   uint32_t preLen = (uint32_t)kzo_ibs_read(&is, 8 * dataSize);
   uint8_t ck = (uint8_t)kzo_ibs_read(&is, 8);
   uint8_t hsf = hasSkipFlags ? skipFlags : (rawCopy ? 0 : (uint8_t)(((mode << 4) | 0x0F) & 0xFF));
   if (ck != block_hdr_cksum(mode, hsf, preLen, (uint64_t)nbits)) return -19;   /* ERR_CRC_CHECK */
   int maxTL = blockSize + blockSize / 2; if (maxTL < 2048) maxTL = 2048;
-  if ((int)preLen < 0 || (int)preLen > maxTL) return -1;
+  if ((int)preLen < 0 || (int)preLen > maxTL) return -11;        /* ERR_READ_FILE :1151-1156 */
+  {                                                              /* ERR_BLOCK_SIZE :1158-1165 */
+    const int64_t checksumSize = chkKind == 2 ? 8 : (chkKind == 1 ? 4 : 0);
+    if ((nbits + 7) >> 3 > (int64_t)preLen + headerSize + checksumSize) return -2;
+  }
   if (preLen == 0) return 0;
   uint64_t checksum1 = 0;
   if (chkKind == 1) checksum1 = kzo_ibs_read(&is, 32); else if (chkKind == 2) checksum1 = kzo_ibs_read(&is, 64);   /* :1256-1262 */
@@ -437,13 +441,21 @@ static void* dec_worker(void* arg) {
 int64_t kzo_decompress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstCap, int jobs) {
   tune_malloc();
   kzo_ibs s; kzo_ibs_init(&s, src, (uint64_t)n * 8);
-  if (kzo_ibs_read(&s, 32) != 0x4B414E5A) return -1;               /* CompressedInputStream.java:359-515 */
+  /* header checks in the reference's order, returning -(Error.java code) (CompressedInputStream.java:359-478) */
+  if (kzo_ibs_read(&s, 32) != 0x4B414E5A) return -15;              /* ERR_INVALID_FILE :367-368 */
   int version = (int)kzo_ibs_read(&s, 4);
-  if (version != 7) return -2;
+  if (version != 7) return -16;                                    /* ERR_STREAM_VERSION :374-377 (older layouts not restated) */
   int chkKind = (int)kzo_ibs_read(&s, 2);
+  if (chkKind > 2) return -15;                                     /* :390-392 */
   int entropyType = (int)kzo_ibs_read(&s, 5);
+  if (entropyType == 3 || entropyType > 9) return -3;              /* ERR_INVALID_CODEC, EntropyCodecFactory.getName :212-243 */
   uint64_t transformType = kzo_ibs_read(&s, 48);
+  for (int i = 0; i < 8; i++) {                                    /* TransformFactory.getName :368-449 */
+    int t = (int)((transformType >> (42 - 6 * i)) & 0x3F);
+    if (t == 4 || t > 19) return -3;
+  }
   int blockSize = (int)(kzo_ibs_read(&s, 28) << 4);
+  if (blockSize < 1024 || blockSize > (1 << 30)) return -2;        /* ERR_BLOCK_SIZE :419-422 */
   int szMask = (int)kzo_ibs_read(&s, 2);
   int64_t inputSize = 0;
   if (szMask) inputSize = (int64_t)kzo_ibs_read(&s, 16 * szMask);
@@ -452,7 +464,7 @@ int64_t kzo_decompress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstC
   uint8_t hdr[40];
   int hl = kzo_stream_header(transformType, entropyType, blockSize, chkKind, inputSize, hdr);
   uint32_t ck2 = ((uint32_t)hdr[hl - 3] << 16) | ((uint32_t)hdr[hl - 2] << 8) | hdr[hl - 1];
-  if (ck != ck2 || chkKind > 2 || s.error) return -3;
+  if (ck != ck2 || s.error) return -19;                            /* ERR_CRC_CHECK :477-478 */
   /* serial index pass over block length prefixes (decodeBlock :1127-1129) */
   int capBlocks = 1024, nblocks = 0;
   uint8_t** ins = (uint8_t**)malloc(sizeof(uint8_t*) * (size_t)capBlocks);
@@ -470,12 +482,12 @@ int64_t kzo_decompress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstC
     }
     ins[nblocks] = (uint8_t*)malloc((size_t)((read + 7) >> 3) + 8);
     kzo_ibs_read_bytes(&s, ins[nblocks], read);
+    if (s.error) { free(ins[nblocks]); bad = 1; break; }           /* stream ends inside this block: it is not decoded */
     bits[nblocks] = (int64_t)read;
     nblocks++;
-    if (s.error) { bad = 1; break; }
   }
-  int64_t ret = -4;
-  if (!bad) {
+  int64_t ret = -11;                                               /* ERR_READ_FILE: stream ends inside a block */
+  {
     int* lens = (int*)calloc((size_t)nblocks + 1, sizeof(int));
     pthread_mutex_t mu; pthread_mutex_init(&mu, NULL);
     int next = 0;
@@ -488,10 +500,14 @@ int64_t kzo_decompress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstC
     if (!job.fail) {
       ret = 0;
       for (int b = 0; b < nblocks; b++) {
-        if (b < nblocks - 1 && lens[b] != blockSize) { ret = -5; break; }
+        if (b < nblocks - 1 && lens[b] != blockSize) { ret = -13; break; }
         ret += lens[b];
       }
-    } else ret = -13;
+      if (bad && ret >= 0) ret = -11;                              /* every whole block decoded; the fault is the truncated one after them */
+    } else {                                                       /* code of the first failing block, as the reader would surface it */
+      ret = -13;
+      for (int b = 0; b < nblocks; b++) if (lens[b] < 0) { ret = lens[b]; break; }
+    }
     free(lens); pthread_mutex_destroy(&mu);
   }
   for (int b = 0; b < nblocks; b++) free(ins[b]);

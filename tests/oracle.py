@@ -163,12 +163,20 @@ def compress(chain, entropy, block_size, data, jobs=1, checksum=0):
     return out[:r].tobytes()
 
 
+class OracleError(RuntimeError):
+    """kzo_decompress failure; code = the K/Error.java value the reference reader would throw."""
+
+    def __init__(self, code):
+        super().__init__("oracle decompress failed: Error code %d" % code)
+        self.code = code
+
+
 def decompress(data, cap, jobs=1):
     a = _u8(bytes(data) + b"\0" * 16)
     out = np.zeros(max(cap, 1), dtype=np.uint8)
     r = lib().kzo_decompress(a.ctypes.data, len(data), out.ctypes.data, cap, jobs)
     if r < 0:
-        raise RuntimeError("oracle decompress failed %d" % r)
+        raise OracleError(int(-r))
     return out[:r].tobytes()
 
 

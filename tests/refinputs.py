@@ -93,3 +93,39 @@ def edge_inputs():
     out.append(bytes([1] + [0] * 4999))
     out.append(bytes([0] * 4999 + [1]))
     return out
+
+
+def set_bits(buf, bitoff, nbits, value):
+    """Overwrite nbits (MSB first, the bitstream's order) at bit offset bitoff of bytearray buf."""
+    for i in range(nbits):
+        bit = (value >> (nbits - 1 - i)) & 1
+        pos = bitoff + i
+        if bit:
+            buf[pos >> 3] |= 0x80 >> (pos & 7)
+        else:
+            buf[pos >> 3] &= ~(0x80 >> (pos & 7)) & 0xFF
+
+
+def header_faults(good):
+    """Stream-header faults and the K/Error.java code CompressedInputStream.readHeader throws for each, in the order it
+    checks them (CompressedInputStream.java:363-478).  Field offsets in bits: magic 0, version 32, checksum kind 36,
+    entropy 38, transforms 43, block size 91, size mask 119."""
+    cases = []
+
+    def mk(off, nbits, value, code, what):
+        b = bytearray(good)
+        set_bits(b, off, nbits, value)
+        cases.append((what, bytes(b), code))
+
+    mk(0, 32, 0x4B414E5B, 15, "magic")                 # ERR_INVALID_FILE :367-368
+    mk(32, 4, 8, 16, "version")                        # ERR_STREAM_VERSION :374-377
+    mk(36, 2, 3, 15, "checksum kind 3")                # ERR_INVALID_FILE :390-392
+    mk(38, 5, 3, 3, "entropy id 3 (obsolete PAQ)")     # ERR_INVALID_CODEC :399-406
+    mk(38, 5, 31, 3, "entropy id 31")
+    mk(43, 6, 4, 3, "transform id 4 (SNAPPY, removed)")  # ERR_INVALID_CODEC :408-415
+    mk(43 + 42, 6, 63, 3, "transform id 63 in slot 8")
+    mk(91, 28, 1, 2, "block size 16")                  # ERR_BLOCK_SIZE :419-422
+    mk(91, 28, (1 << 26) + 1, 2, "block size > 1 GiB")
+    mk(119, 2, 0, 19, "size mask cleared")             # ERR_CRC_CHECK :477-478
+    mk(38, 5, 1, 19, "entropy id changed to a valid one")
+    return cases

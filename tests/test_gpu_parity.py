@@ -344,6 +344,22 @@ def test_fuzz_streams_match_oracle(ctx):
         assert oracle.decompress(cos.output, n, jobs=2) == data
 
 
+def test_stream_header_faults_report_reference_codes(ctx):
+    """Stream-header faults surface with the code and in the order of CompressedInputStream.readHeader
+    (CompressedInputStream.java:363-478, Error.java:24-43), the same as the oracle reports."""
+    data = datagen.stream(5, 20000).tobytes()
+    good = oracle.compress("BWT+RANK+ZRLT", "ANS0", 4096, data, checksum=32)
+    assert kz.CompressedInputStream(ctx, good).read(len(data)) == data
+    for what, bad, code in refinputs.header_faults(good):
+        with pytest.raises(kz.KanziError) as e:
+            kz.CompressedInputStream(ctx, bad).read(len(data))
+        assert e.value.code == code, what
+        with pytest.raises(oracle.OracleError) as eo:
+            oracle.decompress(bad, len(data))
+        assert eo.value.code == code, what
+    assert kz.CompressedInputStream(ctx, good).read(len(data)) == data
+
+
 @pytest.mark.parametrize("chain,ent", [("BWT+RANK+ZRLT", "ANS0"), ("LZ", "HUFFMAN"), ("BWT+SRT+ZRLT", "FPAQ"), ("LZX", "NONE")])
 def test_corrupted_streams_never_hang_or_crash(ctx, chain, ent):
     """Bit flips, truncations and garbage payloads: the decoder must return (an error code or some bytes) -- no hang,

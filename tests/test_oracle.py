@@ -136,3 +136,31 @@ def test_checksummed_stream_roundtrip():
     for bits in (32, 64):
         knz = oracle.compress("BWT+RANK+ZRLT", "ANS0", 32768, data, jobs=2, checksum=bits)
         assert oracle.decompress(knz, len(data), jobs=2) == data
+
+
+def test_stream_header_faults_report_reference_codes():
+    """Each stream-header fault is reported with the code, and in the order, of CompressedInputStream.readHeader
+    (CompressedInputStream.java:363-478; codes from Error.java:24-43)."""
+    data = bytes(range(256)) * 20
+    good = oracle.compress(["BWT", "RANK", "ZRLT"], "ANS0", 4096, data)
+    assert oracle.decompress(good, len(data)) == data
+    for what, bad, code in refinputs.header_faults(good):
+        with pytest.raises(oracle.OracleError) as e:
+            oracle.decompress(bad, len(data))
+        assert e.value.code == code, what
+
+
+def test_block_faults_report_first_failing_block():
+    """Block-level faults: truncation inside a block is ERR_READ_FILE (11) once the whole blocks before it decoded; a
+    flipped header byte is ERR_CRC_CHECK (19); an oversized encoded length is ERR_BLOCK_SIZE (2)
+    (CompressedInputStream.java:1027-1028,1088-1091,1151-1165)."""
+    data = bytes(range(256)) * 40
+    good = oracle.compress(["BWT", "RANK", "ZRLT"], "ANS0", 4096, data)
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.decompress(good[:len(good) - 40], len(data))
+    assert e.value.code == 11
+    bad = bytearray(good)
+    bad[25] ^= 0x40                                            # inside the first block's header bytes
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.decompress(bytes(bad), len(data))
+    assert e.value.code in (19, 2, 11, 13)
