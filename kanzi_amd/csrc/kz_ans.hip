@@ -378,9 +378,22 @@ int kz_stage_ans0_encode(kz_ctx* ctx, kz_batch& bt, uint8_t* out, int64_t outStr
 
 // =================================================================================================
 // decode
+// What ends a block's decode early, keyed so that the event of the lowest chunk wins (the reference decodes chunks in
+// order and stops at the first one, ANSRangeDecoder.java:210-233): key = chunk*4 + kind.
+//   ANS_EV_FAIL  header rejected / bits exhausted / empty alphabet -> decode() != count -> ERR_PROCESS_BLOCK
+//   ANS_EV_SKIP  chunk size >= MAX_CHUNK_SIZE: decodeChunkV2 returns false before writing (:360-361) -> decode() breaks, returns count
+//   ANS_EV_STOP  consumed bytes != chunk size after the chunk was written (:439)              -> decode() breaks, returns count
+// After SKIP/STOP the reference hands the caller `count` bytes whose tail it never wrote (stale buffer contents there);
+// here that tail is zero-filled, as the oracle does.
+#define ANS_EV_NONE 0x7FFFFFFF
+#define ANS_EV_FAIL 0
+#define ANS_EV_SKIP 1
+#define ANS_EV_STOP 2
+#define ANS_MAX_CHUNK_SIZE (1u << 27)
 struct AnsDec {
   u64* chunkBit;     // [B][C] absolute bit offset (in the block stream) of each chunk header
-  int32_t* status;   // [B] 0 ok
+  int32_t* event;    // [B] ANS_EV_NONE or chunk*4+kind
+  int32_t* nIdx;     // [B] chunks whose chunkBit is valid
   int C;
 };
 
@@ -400,12 +413,12 @@ __global__ void k_ans_dec_index(const u8* __restrict__ in, int64_t inStride, con
   const u8* p = in + (int64_t)b * inStride;
   u64 pos = (u64)d_bitOff[b];
   const u64 endBits = (u64)d_bitEnd[b];
-  int status = 0;
+  int event = ANS_EV_NONE, nIdx = 0, bufLen = 0;
   if (count > 32) {
     const int chunks = (count + ANS_CHUNK - 1) / ANS_CHUNK;
     for (int c = 0; c < chunks; c++) {
       D.chunkBit[(int64_t)b * D.C + c] = pos;
-      if (pos + 5 > endBits) { status = -KZ_ERR_PROCESS_BLOCK; break; }
+      if (pos + 5 > endBits) { event = c * 4 + ANS_EV_FAIL; break; }
       const int lr = 8 + (int)kz_peek(p, pos, 3); pos += 3;
       int asz;
       if (kz_peek(p, pos, 1) == 0) { asz = (kz_peek(p, pos + 1, 1) == 1) ? 0 : 256; pos += 2; }
@@ -414,26 +427,35 @@ __global__ void k_ans_dec_index(const u8* __restrict__ in, int64_t inStride, con
         asz = 0;
         for (int i = 0; i <= lastMask; i++) { asz += __popc(kz_peek(p, pos, 8)); pos += 8; }
       }
-      if (asz == 0) { status = -KZ_ERR_PROCESS_BLOCK; break; }       // ANSRangeDecoder.java:214-215
-      if (asz == 1) continue;
-      const int chkSize = (asz >= 64) ? 8 : 6;
-      int llr = 3;
-      while ((1 << llr) <= lr) llr++;
-      for (int i = 1; i < asz; i += chkSize) {
-        const int logMax = (int)kz_peek(p, pos, llr); pos += llr;
-        const int endj = (i + chkSize < asz) ? i + chkSize : asz;
-        pos += (u64)logMax * (u64)(endj - i);
+      if (asz == 0) { event = c * 4 + ANS_EV_FAIL; break; }          // ANSRangeDecoder.java:214-215 returns startChunk != count
+      {
+        const int chkSize = (asz >= 64) ? 8 : 6;
+        int llr = 3;
+        while ((1 << llr) <= lr) llr++;
+        for (int i = 1; i < asz; i += chkSize) {
+          const int logMax = (int)kz_peek(p, pos, llr); pos += llr;
+          const int endj = (i + chkSize < asz) ? i + chkSize : asz;
+          pos += (u64)logMax * (u64)(endj - i);
+        }
       }
+      if (pos > endBits) { event = c * 4 + ANS_EV_FAIL; break; }
+      nIdx = c + 1;
+      if (asz == 1) continue;
       // varint (EntropyUtils.java:284-300)
       u32 v = kz_peek(p, pos, 8); pos += 8;
       u32 sz = v & 0x7F; int shift = 7;
       while (v >= 128) { v = kz_peek(p, pos, 8); pos += 8; sz |= (v & 0x7F) << shift; if (shift == 28) break; shift += 7; }
+      if (sz >= ANS_MAX_CHUNK_SIZE) { nIdx = c; event = c * 4 + ANS_EV_SKIP; break; }    // :360-361
+      const int clen = min(count - c * ANS_CHUNK, ANS_CHUNK);
+      bufLen = max(bufLen, max(2 * clen, 256));                       // this.buffer only grows (:371-374)
+      if (sz > (u32)bufLen) { nIdx = c; event = c * 4 + ANS_EV_FAIL; break; }          // readBits past the array end throws (:379)
       pos += 128 + 8ULL * sz;
-      if (pos > endBits) { status = -KZ_ERR_PROCESS_BLOCK; break; }
+      if (pos > endBits) { nIdx = c; event = c * 4 + ANS_EV_FAIL; break; }
     }
   } else pos += 8ULL * (u64)(count > 0 ? count : 0);
   if (endOut) endOut[b] = (long long)pos;                          // bits consumed (EntropyDecoder contract)
-  D.status[b] = status;
+  D.event[b] = event;
+  D.nIdx[b] = nIdx;
 }
 
 // chunk decode: one wave per chunk
@@ -450,7 +472,7 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
     return;
   }
   const int start = ck * ANS_CHUNK;
-  if (start >= count || D.status[b] != 0) return;
+  if (start >= count || ck >= D.nIdx[b]) return;
   const int end = min(count, start + ANS_CHUNK);
   __shared__ u16 freq[256];
   __shared__ u16 cumf[256];
@@ -476,8 +498,7 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
         for (int j = 0; j < 8; j++) if (m & (1u << j)) alpha[asz++] = (u8)((i << 3) + j);
       }
     }
-    if (lr > 12) bad = 1;                                        // table sized for the encoder's logRange 12
-    if (asz > 0 && !bad) {
+    if (asz > 0) {
       int llr = 3;
       while ((1 << llr) <= lr) llr++;
       const int chkSize = (asz >= 64) ? 8 : 6;
@@ -500,7 +521,7 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
   }
   __syncthreads();
   const int asz = sh_asz, lr = sh_lr;
-  if (sh_bad || asz == 0) { if (lane == 0) atomicExch(&D.status[b], -KZ_ERR_PROCESS_BLOCK); return; }
+  if (sh_bad || asz == 0) { if (lane == 0) atomicMin(&D.event[b], ck * 4 + ANS_EV_FAIL); return; }
   if (asz == 1) {                                                 // :217-220
     const u8 c = alpha[0];
     for (int i = start + lane; i < end; i += 64) o[i] = c;
@@ -516,11 +537,16 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
     cum += __shfl(inc, 63, 64);
   }
   __syncthreads();
+  // the encoder never goes above logRange 12 (ANSRangeEncoder.java:38); a header may still say up to 15, which the
+  // reference accepts (:453-458): those chunks look symbols up by searching the cumulative table instead of f2s
+  const bool wide = lr > 12;
+  if (!wide) {
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int s = q * 64 + lane;
-    const int fv = freq[s], c0 = cumf[s];
-    for (int j = 0; j < fv; j++) f2s[c0 + j] = (u8)s;
+    for (int q = 0; q < 4; q++) {
+      const int s = q * 64 + lane;
+      const int fv = freq[s], c0 = cumf[s];
+      for (int j = 0; j < fv; j++) f2s[c0 + j] = (u8)s;
+    }
   }
   __syncthreads();
   // decodeChunkV2 :357-440
@@ -539,7 +565,14 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
   u32 n = 0;
   if (lane < 4) {
     for (int i = 0; i < end4; i += 4) {
-      const u32 cur = f2s[st & mask];
+      u32 cur;
+      if (!wide) cur = f2s[st & mask];
+      else {                                                      // last symbol whose cumulative frequency is <= the slot
+        const u32 x = st & mask;
+        int lo = 0, hi = 256;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((u32)cumf[mid] <= x) lo = mid; else hi = mid; }
+        cur = (u32)lo;
+      }
       o[start + i + lane] = (u8)cur;
       u32 fq = freq[cur]; if (fq >= (1u << lr)) fq = (1u << lr) - 1u;         // Symbol.reset mirror :576-579
       st = fq * (st >> lr) + (st & mask) - (u32)cumf[cur];
@@ -557,14 +590,20 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
   n = __shfl(n, 0, 64);
   if (lane < len - end4) { const u32 at = n + (u32)lane; o[start + end4 + lane] = (at < sz) ? (u8)kz_peek(p, payloadBit + 8ULL * at, 8) : 0; }
   n += (u32)(len - end4);
-  if (lane == 0 && n != sz) atomicExch(&D.status[b], -KZ_ERR_PROCESS_BLOCK);
+  if (lane == 0 && n != sz) atomicMin(&D.event[b], ck * 4 + ANS_EV_STOP);          // :439
 }
 
-__global__ void k_ans_dec_fin(const int32_t* __restrict__ d_len, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag, AnsDec D, int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  d_len2[b] = d_len[b];
-  d_flag[b] = (D.status[b] == 0) ? 1 : 0;
+// one wave per block: verdict of the lowest-chunk event, zero fill of what the reference leaves unwritten
+__global__ __launch_bounds__(64) void k_ans_dec_fin(const int32_t* __restrict__ d_len, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag,
+                                                     AnsDec D, u8* __restrict__ dst, int64_t stride) {
+  const int b = blockIdx.x, lane = kz_lane();
+  const int count = d_len[b];
+  const int ev = D.event[b];
+  if (lane == 0) { d_len2[b] = count; d_flag[b] = (ev == ANS_EV_NONE || (ev & 3) != ANS_EV_FAIL) ? 1 : 0; }
+  if (ev == ANS_EV_NONE || (ev & 3) == ANS_EV_FAIL) return;
+  const int64_t from = (int64_t)((ev >> 2) + ((ev & 3) == ANS_EV_STOP ? 1 : 0)) * ANS_CHUNK;
+  u8* o = dst + (int64_t)b * stride;
+  for (int64_t i = from + lane; i < count; i += 64) o[i] = 0;
 }
 
 int kz_stage_ans0_decode(kz_ctx* ctx, kz_batch& bt, const uint8_t* in, int64_t inStride, const int64_t* d_bitOff, const int64_t* d_bitEnd) {
@@ -574,14 +613,15 @@ int kz_stage_ans0_decode(kz_ctx* ctx, kz_batch& bt, const uint8_t* in, int64_t i
   AnsDec D;
   D.C = (maxN + ANS_CHUNK - 1) / ANS_CHUNK + 1;
   D.chunkBit = (u64*)kz_arena_alloc(ctx, (size_t)B * D.C * 8);
-  D.status = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
-  if (!D.status || !D.chunkBit) { snprintf(ctx->err, sizeof(ctx->err), "ans0_decode: arena overflow"); return -KZ_ERR_DEVICE; }
+  D.event = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  D.nIdx = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  if (!D.event || !D.nIdx || !D.chunkBit) { snprintf(ctx->err, sizeof(ctx->err), "ans0_decode: arena overflow"); return -KZ_ERR_DEVICE; }
   hipStream_t st = ctx->stream;
   u8* dst = bt.buf[bt.cur ^ 1];
   KZ_LAUNCH(ctx, KID_ANS_DEC_INDEX, k_ans_dec_index, dim3((B + 63) / 64), dim3(64), in, inStride, d_bitOff, d_bitEnd, bt.d_len, D, B, ctx->d_endBits);
   const int chunks = (maxN + ANS_CHUNK - 1) / ANS_CHUNK;
   if (chunks > 0) KZ_LAUNCH(ctx, KID_ANS_DEC_CHUNK, k_ans_dec_chunk, dim3(chunks, B), dim3(64), in, inStride, d_bitOff, bt.d_len, D, dst, bt.stride);
-  KZ_LAUNCH(ctx, KID_ANS_DEC_FIN, k_ans_dec_fin, dim3((B + 255) / 256), dim3(256), bt.d_len, bt.d_len2, bt.d_flag, D, B);
+  KZ_LAUNCH(ctx, KID_ANS_DEC_FIN, k_ans_dec_fin, dim3(B), dim3(64), bt.d_len, bt.d_len2, bt.d_flag, D, dst, bt.stride);
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
   { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }

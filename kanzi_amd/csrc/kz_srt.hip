@@ -142,13 +142,18 @@ __global__ void k_srt_ffin(const int32_t* __restrict__ d_len, int32_t* __restric
 
 // per-wave working set of k_srt_inv (up to 8 waves = 8 blocks per workgroup, see kz_place_blocks)
 struct SrtInvLds {
-  u32 freq[256]; u32 bstart[256]; u32 bend[256]; u32 wbase[256];
+  int32_t freq[256]; int32_t bstart[256]; int32_t bend[256]; int32_t wbase[256];
   u8 order[256]; u8 r2s0[256];
   u8 win[256][32];                   // next 32 ranks of every symbol
   int h, bad;
 };
 #define SRT_SYNC() __builtin_amdgcn_wave_barrier()   /* one wave per block: program order suffices, keep the compiler in line */
 
+// One wave per block replays SRT.java:178-257 step by step.  It follows the reference on ANY input, not only on
+// well-formed ones: frequencies are Java ints (a 5-byte varint can wrap negative; only freq > 0 counts, :268-273), the
+// three tables start zeroed like the fields of a fresh SRT (absent symbols have an empty bucket at 0), a removal shifts
+// only the first nbSymbols entries of r2s (:245-246), and a bucket running past the payload fails at the step that
+// would read there (the oracle's reading of the out-of-range access).
 __global__ __launch_bounds__(512) void k_srt_inv(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
                                                   const int32_t* __restrict__ d_len, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag,
                                                   const int32_t* __restrict__ orderIdx, int wavesPerGroup) {
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(512) void k_srt_inv(const u8* __restrict__ src, u8*
   const int b = orderIdx[blockIdx.x * wavesPerGroup + wv];
   if (b < 0) return;
   SrtInvLds& L = LDS[wv];
-  u32* freq = L.freq; u32* bstart = L.bstart; u32* bend = L.bend; u32* wbase = L.wbase;
+  int32_t* freq = L.freq; int32_t* bstart = L.bstart; int32_t* bend = L.bend; int32_t* wbase = L.wbase;
   u8* order = L.order; u8* r2s0 = L.r2s0;
   u8 (*win)[32] = L.win;
   const int length = d_len[b];
@@ -170,59 +175,59 @@ __global__ __launch_bounds__(512) void k_srt_inv(const u8* __restrict__ src, u8*
     int h = 0, bad = 0;
     for (int i = 0; i < 256 && !bad; i++) {
       if (h >= length) { bad = 1; break; }
-      int val = in[h++];
-      int res = val & 0x7F, shift = 7;
+      u32 val = in[h++];
+      u32 res = val & 0x7F; int shift = 7;
       while (val >= 128) {
         if (h >= length) { bad = 1; break; }
         val = in[h++];
-        res |= ((val & 0x7F) << shift);
+        res |= ((val & 0x7F) << shift);                               // wraps like the Java int
         if (shift > 21) break;
         shift += 7;
       }
-      freq[i] = (u32)res;
+      freq[i] = (int32_t)res;
     }
     L.h = h; L.bad = bad;
   }
-  for (int i = lane; i < 256; i += 64) r2s0[i] = 0;
+  for (int i = lane; i < 256; i += 64) { r2s0[i] = 0; bstart[i] = 0; bend[i] = 0; }
   SRT_SYNC();
   const int H = L.h;
   const int count = length - H;
   if (L.bad || count < 0) { if (lane == 0) { d_len2[b] = 0; d_flag[b] = 0; } return; }
   const u8* s = in + H;
-  // ---- bucket order (freq desc, symbol asc), bucket ranges ----
+  // ---- bucket order of the present symbols (freq desc, symbol asc :259-302), bucket ranges ----
   int nbSymbols = 0;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int sym = q * 64 + lane;
-    const u32 f = freq[sym];
+    const int32_t f = freq[sym];
     u32 pos = 0;
-    for (int t = 0; t < 256; t++) { const u32 ft = freq[t]; if (ft > f || (ft == f && t < sym)) pos++; }
-    order[pos] = (u8)sym;
+    for (int t = 0; t < 256; t++) { const int32_t ft = freq[t]; if (ft > 0 && (ft > f || (ft == f && t < sym))) pos++; }
+    if (f > 0) order[pos] = (u8)sym;
     nbSymbols += (int)__popcll(kz_ballot(f > 0));
   }
   SRT_SYNC();
   int bad = 0;
   {
-    u32 acc = 0;
+    int32_t acc = 0;
     for (int i = 0; i < nbSymbols; i++) {                           // :204-215 (uniform across lanes)
       const int c = order[i];
-      if ((int)acc >= count) { bad = 1; break; }
-      const int first = s[acc];
+      const int32_t at = (int32_t)((u32)H + (u32)acc);               // srcIdx + bucketPos, Java int arithmetic
+      if (at < 0 || at >= length) { bad = 1; break; }
+      const int first = in[at];
       if (lane == 0) { r2s0[first] = (u8)c; bstart[c] = acc + 1; }
-      acc += freq[c];
+      acc = (int32_t)((u32)acc + (u32)freq[c]);
       if (lane == 0) bend[c] = acc;
     }
-    if ((int)acc != count) bad = 1;                                  // frequencies must cover the payload
   }
   SRT_SYNC();
   if (bad) { if (lane == 0) { d_len2[b] = 0; d_flag[b] = 0; } return; }
   // Every step needs the next rank of the symbol that just became current: a dependent load.  Each symbol's
   // next 32 ranks are therefore cached in LDS (8 KiB per block): a step is an LDS read, global memory is touched once
-  // per 32 ranks of a symbol.
+  // per 32 ranks of a symbol.  Ranks are readable below `count` only (s[-H..-1] is the header, still inside the block).
   for (int sym = 0; sym < 256; sym++) {
-    const u32 bs = bstart[sym], be = bend[sym];
-    const bool present = freq[sym] > 0;
-    if (lane < 32) win[sym][lane] = (present && bs + (u32)lane < be) ? s[bs + lane] : (u8)0;
+    const int32_t bs = bstart[sym];
+    const int32_t lim = min(bend[sym], count);
+    if (lane < 32) win[sym][lane] = (bs + lane < lim) ? s[bs + lane] : (u8)0;
     if (lane == 0) wbase[sym] = bs;
   }
   SRT_SYNC();
@@ -231,54 +236,51 @@ __global__ __launch_bounds__(512) void k_srt_inv(const u8* __restrict__ src, u8*
   int i = 0;
   int c = (int)(__builtin_amdgcn_readfirstlane((int)list) & 0xFF);
   while (i < count) {
-    const u32 cur = bstart[c], end = bend[c];
-    u32 wb = wbase[c];
-    int vc = (int)(min(end, wb + 32u) - cur);                         // ranks of c available in the cached window
-    if (vc == 0 && cur < end) {                                       // window used up: fetch the next 32 ranks
+    const int32_t cur = bstart[c], end = bend[c];
+    const int32_t lim = min(end, count);
+    int32_t wb = wbase[c];
+    int vc = min(lim, wb + 32) - cur;                                 // ranks of c available in the cached window
+    if (vc <= 0 && cur < lim) {                                       // window used up: fetch the next 32 ranks
       wb = cur;
-      if (lane < 32) win[c][lane] = (cur + (u32)lane < end) ? s[cur + lane] : (u8)0;
+      if (lane < 32) win[c][lane] = (cur + lane < lim) ? s[cur + lane] : (u8)0;
       if (lane == 0) wbase[c] = wb;
-      vc = (int)min(32u, end - cur);
+      vc = min(32, lim - cur);
     }
-    const u32 v = (lane < vc) ? (u32)win[c][((cur - wb) + (u32)lane) & 31u] : 0u;
+    if (vc < 0) vc = 0;
+    if (vc == 0 && cur < end) { bad = 1; break; }                     // the next rank of c lies past the payload
+    const u32 v = (lane < vc) ? (u32)win[c][((u32)(cur - wb) + (u32)lane) & 31u] : 0u;
     const uint64_t nz = kz_ballot(v != 0 && lane < vc);
     const int z = nz ? (int)__builtin_ctzll(nz) : vc;                 // leading zero ranks = c repeats
     int r = 0;
     int emit, consumed;
     bool moveC = false, removeC = false;
     if (nz) { emit = z + 1; consumed = z + 1; r = __builtin_amdgcn_readlane((int)v, z); moveC = true; }
-    else if (cur + (u32)vc == end) { emit = vc + 1; consumed = vc; removeC = true; }      // bucket exhausted (:239-248)
+    else if (cur + vc >= end) { emit = vc + 1; consumed = vc; removeC = true; }           // bucket exhausted (:239-248)
     else { emit = vc; consumed = vc; }                                 // only zeros in the window, more to come
     if (emit > count - i) { emit = count - i; moveC = false; removeC = false; }
     if (lane < emit) o[i + lane] = (u8)c;
-    if (emit > 64 && lane == 0) o[i + 64] = (u8)c;
     i += emit;
-    if (lane == 0) bstart[c] = cur + (u32)consumed;
-    if (moveC) {
-      // positions 0..r-1 <- 1..r ; position r <- c   (SRT.java:233-237)
+    if (lane == 0) bstart[c] = cur + consumed;
+    if (moveC || (removeC && nbSymbols > 1)) {
+      // moveC:   positions 0..r-1 <- 1..r, position r <- c                        (SRT.java:233-237)
+      // removeC: positions 0..nbSymbols-1 <- 1..nbSymbols, the rest stays          (:242-248)
+      if (removeC) { nbSymbols--; r = nbSymbols; }
       const u32 nxt = KZ_DPP_SHL1(list);
       const u32 shifted = (list >> 8) | (nxt << 24);
       const int jb = 4 * lane;
       const int e = r - jb;                                            // bytes with position < r in this lane
       const u32 mask = (e <= 0) ? 0u : ((e >= 4) ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (8 * (4 - e))));
       u32 nl = (shifted & mask) | (list & ~mask);
-      if (lane == (r >> 2)) { const int sh = 8 * (r & 3); nl = (nl & ~(0xFFu << sh)) | ((u32)c << sh); }
+      if (moveC && lane == (r >> 2)) { const int sh = 8 * (r & 3); nl = (nl & ~(0xFFu << sh)) | ((u32)c << sh); }
       list = nl;
       c = (int)(__builtin_amdgcn_readfirstlane((int)list) & 0xFF);
     } else if (removeC) {
-      if (nbSymbols > 1) {                                             // :242-248
-        nbSymbols--;
-        const u32 nxt = KZ_DPP_SHL1(list);
-        list = (list >> 8) | (nxt << 24);
-        c = (int)(__builtin_amdgcn_readfirstlane((int)list) & 0xFF);
-      } else {
-        // single symbol left: it repeats to the end (:239-240)
-        for (int k = i + lane; k < count; k += 64) o[k] = (u8)c;
-        i = count;
-      }
+      // single symbol left with an empty bucket: it repeats to the end (:239-240)
+      for (int k = i + lane; k < count; k += 64) o[k] = (u8)c;
+      i = count;
     }
   }
-  if (lane == 0) { d_len2[b] = count; d_flag[b] = 1; }
+  if (lane == 0) { d_len2[b] = bad ? 0 : count; d_flag[b] = bad ? 0 : 1; }
 }
 
 size_t kz_srt_scratch(int B, int maxN) {

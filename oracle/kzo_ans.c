@@ -116,9 +116,11 @@ int kzo_ans0_decode(kzo_ibs* bs, uint8_t* block, int count) {
   int sizeChunk = ANS_CHUNK;
   int freqs[256], alphabet[256], dfreq[256], dcum[256];
   uint8_t* f2s = (uint8_t*)malloc(1 << 15);
-  int bufLen = 2 * sizeChunk > 256 ? 2 * sizeChunk : 256;
-  uint8_t* buffer = (uint8_t*)malloc((size_t)bufLen);
+  int bufLen = 0;                                               /* this.buffer starts empty and only grows (:371-374) */
+  uint8_t* buffer = NULL;
   int startChunk = 0, ret = count;
+  /* When decodeChunkV2 returns false the reference breaks and still returns count (:229-231): the bytes it never wrote
+     keep whatever the caller's array held.  Callers here pass a zeroed array, which is what the HIP path produces too. */
   while (startChunk < count) {
     int endChunk = startChunk + sizeChunk < count ? startChunk + sizeChunk : count;
     /* decodeHeader :452-544 */
@@ -164,7 +166,8 @@ int kzo_ans0_decode(kzo_ibs* bs, uint8_t* block, int count) {
     int32_t st2 = (int32_t)kzo_ibs_read(bs, 32), st3 = (int32_t)kzo_ibs_read(bs, 32);
     int start = startChunk, end = endChunk;
     int minBuf = 2 * (end - start) > 256 ? 2 * (end - start) : 256;
-    if (bufLen < minBuf || (uint32_t)bufLen < sz) { ret = -1; break; }
+    if (bufLen < minBuf) { free(buffer); bufLen = minBuf; buffer = (uint8_t*)malloc((size_t)bufLen); }
+    if ((uint32_t)bufLen < sz) { ret = -1; break; }              /* readBits past the array end throws */
     memset(buffer, 0, (size_t)bufLen);
     kzo_ibs_read_bytes(bs, buffer, (uint64_t)sz * 8);
     if (bs->error) { ret = -1; break; }

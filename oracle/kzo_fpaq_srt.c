@@ -191,7 +191,7 @@ int kzo_srt_inverse(const uint8_t* src, int length, uint8_t* dst, int dstCap, in
     while (val >= 128) {
       if (h >= length) return 0;
       val = src[h++];
-      res |= ((val & 0x7F) << shift);
+      res = (int)((uint32_t)res | ((uint32_t)(val & 0x7F) << shift));   /* wraps like the Java int */
       if (shift > 21) break;
       shift += 7;
     }
@@ -201,14 +201,15 @@ int kzo_srt_inverse(const uint8_t* src, int length, uint8_t* dst, int dstCap, in
   if (count > dstCap) return 0;
   const uint8_t* s = src + h;
   int nbSymbols = srt_preprocess(freqs, symbols);
-  memset(r2s, 0, sizeof(r2s));
+  /* fields of a fresh SRT instance (one per block, TransformFactory.newFunction): all zero */
+  memset(r2s, 0, sizeof(r2s)); memset(buckets, 0, sizeof(buckets)); memset(bucketEnds, 0, sizeof(bucketEnds));
   for (int i = 0, bucketPos = 0; i < nbSymbols; i++) {                  /* :204-215 */
     const int c = symbols[i];
     /* the reference tests (srcIdx+bucketPos >= input.length) with srcIdx already past the header */
-    if ((h + bucketPos < 0) || (h + bucketPos >= length)) return 0;
+    { const int at = (int)((uint32_t)h + (uint32_t)bucketPos); if ((at < 0) || (at >= length)) return 0; }
     r2s[s[bucketPos]] = c;
     buckets[c] = bucketPos + 1;
-    bucketPos += freqs[c];
+    bucketPos = (int)((uint32_t)bucketPos + (uint32_t)freqs[c]);       /* Java int wrap */
     bucketEnds[c] = bucketPos;
   }
   int c = r2s[0];

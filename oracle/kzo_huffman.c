@@ -257,8 +257,10 @@ int kzo_huffman_decode(kzo_ibs* bs, uint8_t* block, int count) {
       const int len = sizes[s];
       int idx = (int)(codes[s] << (HUF_MAXLEN - len));
       const int end = idx + (1 << (HUF_MAXLEN - len));
+      if (end > (1 << HUF_MAXLEN)) { bad = 1; break; }            /* over-subscribed lengths: Java throws on table[idx] */
       while (idx < end) table[idx++] = (uint16_t)((len << 8) | s);
     }
+    if (bad) { ret = -1; break; }
     uint32_t szBits[4];
     for (int j = 0; j < 4; j++) szBits[j] = kzo_read_varint(bs);
     const int szFrag = sizeChunk / 4;

@@ -296,7 +296,7 @@ int kzo_decode_block_x(uint64_t transformType, int entropyType, int chkKind, int
   if (chkKind == 1) checksum1 = kzo_ibs_read(&is, 32); else if (chkKind == 2) checksum1 = kzo_ibs_read(&is, 64);   /* :1256-1262 */
   if (rawCopy) { transformType = 0; entropyType = KZO_E_NONE; skipFlags = 0xFF; }
   else if (transformedCopy) entropyType = KZO_E_NONE;
-  uint8_t* buffer = (uint8_t*)malloc((size_t)preLen + 1024);
+  uint8_t* buffer = (uint8_t*)calloc((size_t)preLen + 1024, 1);   /* zeroed: see kzo_ans0_decode on unwritten tails */
   int ret = -13;                                                  /* ERR_PROCESS_BLOCK */
   if (kzo_entropy_decode(entropyType, &is, buffer, (int)preLen) == (int)preLen && !is.error) {
     int nb = split_types(transformType, types);

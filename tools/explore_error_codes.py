@@ -22,5 +22,6 @@ for chain, ent in [("BWT+RANK+ZRLT","ANS0"),("LZ","HUFFMAN"),("BWT+SRT+ZRLT","FP
         except kz.KanziError as e: p = ("err", e.code)
         try: o = ("ok", len(oracle.decompress(bytes(bad), len(data))))
         except oracle.OracleError as e: o = ("err", e.code)
+        if p != o: print('MISMATCH', chain, ent, 'trial', trial, 'kind', kind, p, o)
         stats[(kind, p == o, p if p[0]=="err" else "ok", o if o[0]=="err" else "ok")] += 1
 for k, v in sorted(stats.items(), key=str): print(k, v)
