@@ -39,7 +39,7 @@ for k in ("k_ans_dec_index", "k_ans_dec_chunk", "k_ans_dec_fin"):
 for k in ("k_zrlt_i1", "k_zrlt_i2", "k_zrlt_i3", "k_zrlt_ifin"):
     KERNEL_STAGE[k] = "zrlt_inv"
 KERNEL_STAGE["k_sbrt_inverse"] = "sbrt_inv"
-for k in ("k_bwti_parse", "k_bwti_hist", "k_bwti_scan", "k_bwti_scatter", "k_bwti_walk1", "k_bwti_resolve", "k_bwti_copy", "k_bwti_fin"):
+for k in ("k_bwti_parse", "k_bwti_hist", "k_bwti_scan", "k_bwti_scatter", "k_bwti_walk1", "k_bwti_resolve", "k_bwti_copy", "k_bwti_literal", "k_bwti_fin"):
     KERNEL_STAGE[k] = "bwt_inv"
 
 

@@ -394,6 +394,7 @@ struct AnsDec {
   u64* chunkBit;     // [B][C] absolute bit offset (in the block stream) of each chunk header
   int32_t* event;    // [B] ANS_EV_NONE or chunk*4+kind
   int32_t* nIdx;     // [B] chunks whose chunkBit is valid
+  int32_t* hdrOnly;  // [B] chunk whose header must still be validated although its payload is skipped (ANS_EV_SKIP), or -1
   int C;
 };
 
@@ -413,7 +414,7 @@ __global__ void k_ans_dec_index(const u8* __restrict__ in, int64_t inStride, con
   const u8* p = in + (int64_t)b * inStride;
   u64 pos = (u64)d_bitOff[b];
   const u64 endBits = (u64)d_bitEnd[b];
-  int event = ANS_EV_NONE, nIdx = 0, bufLen = 0;
+  int event = ANS_EV_NONE, nIdx = 0, bufLen = 0, hdrOnly = -1;
   if (count > 32) {
     const int chunks = (count + ANS_CHUNK - 1) / ANS_CHUNK;
     for (int c = 0; c < chunks; c++) {
@@ -445,7 +446,8 @@ __global__ void k_ans_dec_index(const u8* __restrict__ in, int64_t inStride, con
       u32 v = kz_peek(p, pos, 8); pos += 8;
       u32 sz = v & 0x7F; int shift = 7;
       while (v >= 128) { v = kz_peek(p, pos, 8); pos += 8; sz |= (v & 0x7F) << shift; if (shift == 28) break; shift += 7; }
-      if (sz >= ANS_MAX_CHUNK_SIZE) { nIdx = c; event = c * 4 + ANS_EV_SKIP; break; }    // :360-361
+      // :360-361 -- decodeHeader ran before this and throws on a bad table (:213): the chunk kernel still checks it
+      if (sz >= ANS_MAX_CHUNK_SIZE) { hdrOnly = c; event = c * 4 + ANS_EV_SKIP; break; }
       const int clen = min(count - c * ANS_CHUNK, ANS_CHUNK);
       bufLen = max(bufLen, max(2 * clen, 256));                       // this.buffer only grows (:371-374)
       if (sz > (u32)bufLen) { nIdx = c; event = c * 4 + ANS_EV_FAIL; break; }          // readBits past the array end throws (:379)
@@ -456,6 +458,7 @@ __global__ void k_ans_dec_index(const u8* __restrict__ in, int64_t inStride, con
   if (endOut) endOut[b] = (long long)pos;                          // bits consumed (EntropyDecoder contract)
   D.event[b] = event;
   D.nIdx[b] = nIdx;
+  D.hdrOnly[b] = hdrOnly;
 }
 
 // chunk decode: one wave per chunk
@@ -522,6 +525,7 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
   __syncthreads();
   const int asz = sh_asz, lr = sh_lr;
   if (sh_bad || asz == 0) { if (lane == 0) atomicMin(&D.event[b], ck * 4 + ANS_EV_FAIL); return; }
+  if (ck == D.hdrOnly[b]) return;                                 // header was all that had to be checked
   if (asz == 1) {                                                 // :217-220
     const u8 c = alpha[0];
     for (int i = start + lane; i < end; i += 64) o[i] = c;
@@ -615,7 +619,8 @@ int kz_stage_ans0_decode(kz_ctx* ctx, kz_batch& bt, const uint8_t* in, int64_t i
   D.chunkBit = (u64*)kz_arena_alloc(ctx, (size_t)B * D.C * 8);
   D.event = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   D.nIdx = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
-  if (!D.event || !D.nIdx || !D.chunkBit) { snprintf(ctx->err, sizeof(ctx->err), "ans0_decode: arena overflow"); return -KZ_ERR_DEVICE; }
+  D.hdrOnly = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  if (!D.event || !D.nIdx || !D.hdrOnly || !D.chunkBit) { snprintf(ctx->err, sizeof(ctx->err), "ans0_decode: arena overflow"); return -KZ_ERR_DEVICE; }
   hipStream_t st = ctx->stream;
   u8* dst = bt.buf[bt.cur ^ 1];
   KZ_LAUNCH(ctx, KID_ANS_DEC_INDEX, k_ans_dec_index, dim3((B + 63) / 64), dim3(64), in, inStride, d_bitOff, d_bitEnd, bt.d_len, D, B, ctx->d_endBits);

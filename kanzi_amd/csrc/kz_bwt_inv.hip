@@ -10,8 +10,11 @@
 // the text head.  Every walker follows its segment ONCE (until the next grid point), counting its steps and
 // recording its bytes into pooled 256-byte chunks; a per-block LDS pointer-jumping pass turns the segment
 // lengths into text offsets and a copy kernel moves the chunks to their place (a second walk would cost
-// another cache line per byte).  The output is the same text; only the primary index 0 is needed (the
-// others are validated).
+// another cache line per byte).  That stitching needs what every well-formed block has: one path from the text head
+// through all n links, with the 8 primary indexes sitting ckSize steps apart on it.  k_bwti_resolve checks exactly
+// that; a block that fails the check (corrupted input) is marked BI_SUSPECT and redone by k_bwti_literal, which runs
+// the reference's 8 walkers literally (BWT.java:295-368, including its dummy link 0xFF behind row 0), so the bytes
+// and the verdict match the reference on ANY input -- slowly, but only for blocks no encoder produced.
 // Limit: n < 2^24-1 (the packed form; the reference switches to biPSIv2 above 8 MiB with the same
 // output) -- larger blocks return -KZ_ERR_BLOCK_SIZE.
 #include "kz_device.h"
@@ -45,6 +48,8 @@ struct BwtInv {
 };
 #define BI_END 0xFFFFFFu
 #define BI_CH 256          // bytes per recording chunk
+#define BI_SUSPECT 1       // status: not stitched, k_bwti_literal decides
+#define BI_HEADS 8         // walkers G..G+7 start at the primary indexes (only head 0 records bytes)
 
 __global__ void k_bwti_parse(const u8* __restrict__ src, int64_t stride, const int32_t* __restrict__ d_len, BwtInv V, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -183,23 +188,28 @@ __global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V, int b0) {
   const int S = 1 << V.logS;
   const int G = (n + S - 1) >> V.logS;
   const int w = blockIdx.x * 64 + threadIdx.x;
-  if (w > G) return;
+  if (w >= G + BI_HEADS) return;
+  const int head = w - G;                                       // >= 0: starts at primary index `head`
+  if (head > 0 && n < 256) { V.segLen[(int64_t)b * V.GS + w] = 0; V.segNext[(int64_t)b * V.GS + w] = -1; return; }   // one primary index only
+  const bool rec = head <= 0;
   const u32* data = V.data + (int64_t)b * V.NS;
   u8* pool = V.pool + (int64_t)b * V.maxChunks * BI_CH;
   uint2* meta = V.chunkMeta + (int64_t)b * V.maxChunks;
-  u32 t = (w < G) ? (u32)w << V.logS : (u32)(V.prim[b * 8] - 1);
+  u32 t = (head < 0) ? (u32)w << V.logS : (u32)(V.prim[b * 8 + head] - 1);
   u32 steps = 0;
   int nxt = -2;
   unsigned long long acc = 0;
   u32 fill = BI_CH, seq = 0;              // bytes stored in the current chunk (BI_CH: none allocated yet)
   u8* cp = nullptr;
   bool full = false;
-  while (steps <= (u32)n) {
+  // Segment lengths are geometric with mean S; a walk this long without meeting a grid point is not a text path.
+  const u32 cap = min((u32)n, 1u << 20);
+  while (steps <= cap) {
     if (t >= (u32)n) break;                                   // corrupt link
     const u32 ptr = BI_LD(&data[t]);
     acc |= (unsigned long long)(ptr & 0xFFu) << (8 * (steps & 7u));
     steps++;
-    if ((steps & 7u) == 0) {
+    if (rec && (steps & 7u) == 0) {
       if (fill == BI_CH) {
         const u32 id = atomicAdd(&V.chunkCount[b], 1u);
         if (id >= (u32)V.maxChunks) { full = true; break; }
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V, int b0) {
     if (t == BI_END) { nxt = -1; break; }
     if ((t & (u32)(S - 1)) == 0) { nxt = (int)(t >> V.logS); break; }
   }
-  if ((steps & 7u) != 0 && !full && nxt != -2) {              // partial tail
+  if (rec && (steps & 7u) != 0 && !full && nxt != -2) {       // partial tail
     if (fill == BI_CH) {
       const u32 id = atomicAdd(&V.chunkCount[b], 1u);
       if (id >= (u32)V.maxChunks) full = true;
@@ -222,20 +232,20 @@ __global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V, int b0) {
     }
     if (!full) *(unsigned long long*)(cp + fill) = acc;
   }
-  if (nxt == -2 || full) { atomicExch(&V.status[b], -KZ_ERR_PROCESS_BLOCK); nxt = -1; }
+  if (nxt == -2 || full) { atomicCAS(&V.status[b], 0, BI_SUSPECT); nxt = -1; }
   V.segLen[(int64_t)b * V.GS + w] = steps;
   V.segNext[(int64_t)b * V.GS + w] = nxt;
 }
 
 // per block: suffix sums along the segment chain by pointer jumping in LDS -> text offsets
-#define BI_MAXSEG 4100
+#define BI_MAXSEG 4112
 __global__ __launch_bounds__(256) void k_bwti_resolve(BwtInv V, int b0) {
   const int b = blockIdx.x + b0;
   const int n = V.n[b];
   if (n < 2 || V.status[b] != 0) return;
   const int S = 1 << V.logS;
   const int G = (n + S - 1) >> V.logS;
-  const int M = G + 1;
+  const int M = G + BI_HEADS;
   __shared__ u32 R[BI_MAXSEG];
   __shared__ int NX[BI_MAXSEG];
   const int64_t o = (int64_t)b * V.GS;
@@ -254,8 +264,19 @@ __global__ __launch_bounds__(256) void k_bwti_resolve(BwtInv V, int b0) {
     for (int i = threadIdx.x; i < M; i += 256, k++) { R[i] = r2[k]; NX[i] = n2[k]; }
     __syncthreads();
   }
-  // R[i] = bytes from the start of segment i to the end of the text
-  if (threadIdx.x == 0 && (R[G] != (u32)n || NX[G] != -1)) atomicExch(&V.status[b], -KZ_ERR_PROCESS_BLOCK);
+  // R[i] = bytes from the start of segment i to the end of the text.  Stitching is right when head 0 reaches END
+  // after exactly n steps (then every link is on that path) and, with 8 primary indexes, head k sits k*ckSize steps
+  // into it (BWT.java:296-314); otherwise the literal walkers take over.
+  if (threadIdx.x < BI_HEADS) {
+    const int k = threadIdx.x;
+    bool good = true;
+    if (k == 0) good = (R[G] == (u32)n && NX[G] == -1);
+    else if (n >= 256) {
+      const u32 ckSize = (u32)(((n & 7) == 0) ? (n >> 3) : (n >> 3) + 1);
+      good = (NX[G + k] == -1 && R[G + k] <= (u32)n && (u32)n - R[G + k] == (u32)k * ckSize);
+    }
+    if (!good) atomicCAS(&V.status[b], 0, BI_SUSPECT);
+  }
   for (int i = threadIdx.x; i < M; i += 256) V.segOff[o + i] = (R[i] <= (u32)n) ? (u32)n - R[i] : 0xFFFFFFFFu;
 }
 
@@ -280,6 +301,35 @@ __global__ __launch_bounds__(256) void k_bwti_copy(u8* __restrict__ dst, int64_t
   const u32 k = 4u * (u32)lane;
   if (k + 4 <= cnt) *(bi_u32_unaligned*)(d + k) = *(const u32*)(src + k);
   else for (u32 q = k; q < cnt; q++) d[q] = src[q];
+}
+
+// The reference's walkers, literally (BWT.java:295-368): lane k follows the links from primary index k for its
+// share of the text; the link behind row 0 is the reference's dummy 0xFF (stored as BI_END here).  Only for blocks
+// k_bwti_resolve would not stitch.
+__global__ __launch_bounds__(64) void k_bwti_literal(u8* __restrict__ dst, int64_t stride, BwtInv V) {
+  const int b = blockIdx.x;
+  if (V.status[b] != BI_SUSPECT) return;
+  const int n = V.n[b];
+  const int lane = threadIdx.x;
+  const u32* data = V.data + (int64_t)b * V.NS;
+  u8* o = dst + (int64_t)b * stride;
+  bool fail = false;
+  const int walkers = (n < 256) ? 1 : 8;
+  if (lane < walkers) {
+    const int ckSize = (walkers == 1) ? n : (((n & 7) == 0) ? (n >> 3) : (n >> 3) + 1);
+    const int steps = (lane < 7) ? ckSize : n - 7 * ckSize;
+    u32 t = (u32)(V.prim[b * 8 + lane] - 1);
+    u8* q = o + (int64_t)lane * ckSize;
+    for (int i = 0; i < steps; i++) {
+      if (t >= (u32)n) { fail = true; break; }                 // Java: data[t] out of range throws
+      const u32 ptr = data[t];
+      q[i] = (u8)ptr;
+      t = ptr >> 8;
+      if (t == BI_END) t = 0xFF;
+    }
+  }
+  const bool anyFail = kz_ballot(fail) != 0;
+  if (lane == 0) V.status[b] = anyFail ? -KZ_ERR_PROCESS_BLOCK : 0;
 }
 
 __global__ void k_bwti_fin(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride, BwtInv V,
@@ -316,7 +366,7 @@ int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
   V.status = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   V.logS = 6;
   while (((maxN + (1 << V.logS) - 1) >> V.logS) > 4096) V.logS++;
-  V.GS = ((maxN + (1 << V.logS) - 1) >> V.logS) + 1;
+  V.GS = ((maxN + (1 << V.logS) - 1) >> V.logS) + BI_HEADS;
   V.segLen = (u32*)kz_arena_alloc(ctx, (size_t)B * V.GS * 4);
   V.segNext = (int32_t*)kz_arena_alloc(ctx, (size_t)B * V.GS * 4);
   V.segOff = (u32*)kz_arena_alloc(ctx, (size_t)B * V.GS * 4);
@@ -351,6 +401,7 @@ int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
       KZ_LAUNCH(ctx, KID_BWTI_RESOLVE, k_bwti_resolve, dim3(nb), dim3(256), V, b0);
       KZ_LAUNCH(ctx, KID_BWTI_COPY, k_bwti_copy, dim3((V.maxChunks + 3) / 4, nb), dim3(256), dst, bt.stride, V, b0);
     }
+    KZ_LAUNCH(ctx, KID_BWTI_LITERAL, k_bwti_literal, dim3(B), dim3(64), dst, bt.stride, V);
   }
   KZ_LAUNCH(ctx, KID_BWTI_FIN, k_bwti_fin, dim3((B + 255) / 256), dim3(256), src, dst, bt.stride, V, bt.d_len2, bt.d_flag, B);
   KZ_HIP(hipGetLastError());

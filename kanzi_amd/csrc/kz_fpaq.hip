@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64) void k_fpaq_dec(const u8* __restrict__ in, int6
       u32 v = p[ipos++]; u32 sz = v & 0x7F; int shift = 7;         // EntropyUtils.readVarInt
       while (v >= 128) { v = p[ipos++]; sz |= (v & 0x7F) << shift; if (shift == 28) break; shift += 7; }
       const int szBytes = (int)sz;
-      if (szBytes < 0 || szBytes >= 2 * count || ipos + 7 + szBytes > avail + 8) { bad = true; break; }   // :176-177
+      if (szBytes < 0 || szBytes >= 2 * count || ipos + 7 + szBytes > avail) { bad = true; break; }   // :176-177
       current = 0;
       for (int k = 0; k < 7; k++) current = (current << 8) | (u64)p[ipos + k];
       ipos += 7;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(512) void k_fpaq_dec_wave(const u8* __restrict__ in
     u32 v = p[ipos++]; u32 sz = v & 0x7F; int shift = 7;
     while (v >= 128) { v = p[ipos++]; sz |= (v & 0x7F) << shift; if (shift == 28) break; shift += 7; }
     const int szBytes = (int)sz;
-    if (szBytes < 0 || szBytes >= 2 * count || ipos + 7 + szBytes > avail + 8) { bad = true; break; }   // :176-177
+    if (szBytes < 0 || szBytes >= 2 * count || ipos + 7 + szBytes > avail) { bad = true; break; }   // :176-177
     current = 0;
     for (int k = 0; k < 7; k++) current = (current << 8) | (u64)p[ipos + k];
     ipos += 7;

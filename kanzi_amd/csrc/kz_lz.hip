@@ -253,7 +253,13 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
   if (w) { d_flag[b] = (ok && res) ? 1 : 0; d_len2[b] = (ok && res) ? produced : count; }
 }
 
-__device__ __forceinline__ int lz_read_length(const u8* a, int& idx) {
+// readLength; reads are bounded by the block length (past it the Java code throws or sees stale bytes: failure)
+__device__ __forceinline__ int lz_read_length(const u8* a, int& idx, int count, bool& bad) {
+  if (idx + 4 > count) {
+    int need = 1;
+    if (idx < count) need = (a[idx] < 254) ? 1 : (a[idx] == 254 ? 3 : 4);
+    if (idx + need > count) { bad = true; return 0; }
+  }
   int res = a[idx++];
   if (res < 254) return res;
   if (res == 254) { res += (a[idx] << 8); res += a[idx + 1]; idx += 2; return res; }
@@ -284,11 +290,13 @@ __global__ __launch_bounds__(64) void k_lz_inv(const u8* __restrict__ srcAll, u8
       const int maxDist = ((src[12] & 1) == 0) ? LZ_MAXD1 : LZ_MAXD2;
       const int minMatch = ((src[12] >> 1) & 7) + 2;
       int srcIdx = 13, repd0 = count, repd1 = count;
+      bool bad = false;
       for (;;) {
         if (tkIdx >= count) { ok = false; break; }
         const int token = src[tkIdx++];
         if (token >= 32) {
-          const int litLen = (token >= 0xE0) ? 7 + lz_read_length(src, srcIdx) : token >> 5;
+          const int litLen = (token >= 0xE0) ? 7 + lz_read_length(src, srcIdx, count, bad) : token >> 5;
+          if (bad) { ok = false; break; }
           if ((litLen > dstEnd - dstIdx) || (litLen > litEnd - srcIdx)) { ok = false; break; }
           lz_copy(dst + dstIdx, src + srcIdx, litLen);
           srcIdx += litLen; dstIdx += litLen;
@@ -298,15 +306,17 @@ __global__ __launch_bounds__(64) void k_lz_inv(const u8* __restrict__ srcAll, u8
         const int f = token & 0x18;
         if (f == 0) {
           mLen = token & 3;
-          mLen += (mLen == 3) ? minMatch + lz_read_length(src, mLenIdx) : minMatch;
+          mLen += (mLen == 3) ? minMatch + lz_read_length(src, mLenIdx, count, bad) : minMatch;
           dist = ((token & 4) == 0) ? repd0 : repd1;
         } else {
           mLen = token & 7;
-          mLen += (mLen == 7) ? minMatch + lz_read_length(src, mLenIdx) : minMatch;
+          mLen += (mLen == 7) ? minMatch + lz_read_length(src, mLenIdx, count, bad) : minMatch;
+          if (mIdx + ((f == 0x18) ? 3 : (f == 0x10) ? 2 : 1) > count) { ok = false; break; }
           dist = src[mIdx++];
           if (f == 0x18) { dist = (dist << 8) | src[mIdx]; dist = (dist << 8) | src[mIdx + 1]; mIdx += 2; }
           else if (f == 0x10) { dist = (dist << 8) | src[mIdx]; mIdx++; }
         }
+        if (bad) { ok = false; break; }
         repd1 = repd0; repd0 = dist;
         const int mEnd = dstIdx + mLen;
         const int ref = dstIdx - dist;

@@ -356,9 +356,13 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
       int rc = kz_decode_blocks(ctx, tt, (uint32_t)entropyType, blockSize, inbuf.get(), iS, bits.data(), cnt,
                                 dst + produced, blockSize, res.data(), KZ_MEM_HOST);
       if (rc) return rc;
+      const int64_t base = produced;
       for (int i = 0; i < cnt; i++) {
         if (res[i].status) return res[i].status;
-        if (i < cnt - 1 && res[i].length != blockSize) return -KZ_ERR_PROCESS_BLOCK;
+        if (res[i].length > blockSize) return -KZ_ERR_PROCESS_BLOCK;                  // "incorrectly decompressed" (:756-759)
+        // the reader appends whatever a block produced (:783-785): close up behind a short block (corrupted streams only)
+        if (produced != base + (int64_t)i * blockSize && res[i].length > 0)
+          memmove(dst + produced, dst + base + (int64_t)i * blockSize, (size_t)res[i].length);
         produced += res[i].length;
       }
     } else {
@@ -368,6 +372,7 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
       if (rc) return rc;
       for (int i = 0; i < cnt; i++) {
         if (res[i].status) return res[i].status;
+        if (res[i].length > blockSize) return -KZ_ERR_PROCESS_BLOCK;
         if (produced + res[i].length > dstCap) return -KZ_ERR_WRITE_FILE;
         memcpy(dst + produced, tmp.data() + (size_t)i * blockSize, (size_t)res[i].length);
         produced += res[i].length;

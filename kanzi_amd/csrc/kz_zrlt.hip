@@ -231,16 +231,33 @@ __device__ __forceinline__ bool zr_is_payload(const u8* s, int i) {
 }
 
 // output bytes produced by the token STARTING at input byte i (0 if i is inside a token)
+// Output bytes produced by the token starting at i (0 for bytes that continue a token).  A zero run of k digits has
+// the value (1 << k | digits) - 1 in Java int arithmetic (ZRLT.java:172-188): runs of more than 30 digits -- which no
+// encoder writes -- wrap, and the reference then emits the wrapped count (or nothing when it is <= 0).  A run that
+// reaches the end of the input goes through the trailing branch (:217-228), whose test differs at INT_MIN only.
+// A count that cannot fit fails later through the total (every such case dies in the reference as well).
 __device__ __forceinline__ u32 zr_inv_token(const u8* s, int i, int n, bool* bad) {
+  (void)bad;
   const u32 v = s[i];
   const bool payload = zr_is_payload(s, i);
   if (payload) return 0;
   if (v <= 1) {
     if (i > 0 && s[i - 1] <= 1 && !zr_is_payload(s, i - 1)) return 0;     // not the head digit
     u32 rl = 1;
-    int k = i, digits = 0;
-    while (k < n && s[k] <= 1) { rl = (rl << 1) | s[k]; k++; if (++digits > 30) { *bad = true; break; } }
-    return rl - 1;
+    int k = i;
+    while (k < n && s[k] <= 1) {
+      rl = (rl << 1) | s[k]; k++;
+      // long runs (corrupted input only): 8 digits per step; blocks start 256-byte aligned
+      while ((k & 7) == 0 && k + 8 <= n) {
+        const unsigned long long w = *(const unsigned long long*)(s + k);
+        if (w & 0xFEFEFEFEFEFEFEFEull) break;
+        rl = (rl << 8) | (u32)((w * 0x8040201008040201ull) >> 56);         // byte j of w -> bit 7-j
+        k += 8;
+      }
+    }
+    if (k >= n) return ((int32_t)rl > 0) ? rl - 1u : 0u;
+    const int32_t r = (int32_t)(rl - 1u);
+    return (r > 0) ? (u32)r : 0u;
   }
   if (v == 0xFF) return (i + 1 < n) ? 1u : 0u;
   return 1u;
@@ -253,15 +270,21 @@ __global__ __launch_bounds__(KZ_WG) void k_zrlt_i1(const u8* __restrict__ src, i
   const int n = d_len[b];
   const int tstart = t * ZR_TILE;
   if (tstart >= n) return;
-  __shared__ u32 lds[32];
+  __shared__ __attribute__((aligned(8))) u32 lds[32];
   const u8* s = src + (int64_t)b * stride;
   const int pos = tstart + threadIdx.x * ZR_PER;
-  u32 sz = 0; bool bad = false;
+  unsigned long long sz = 0; bool bad = false;
   for (int k = 0; k < ZR_PER; k++) if (pos + k < n) sz += zr_inv_token(s, pos + k, n, &bad);
-  if (bad) atomicOr(&S.fail[b], 1);
-  u32 total;
-  kz_wg_excl_sum(sz, lds, &total);
-  if (threadIdx.x == 0) S.tSum[(int64_t)b * S.T + t] = total;
+  // tile total, saturated: wrapped run counts can be anything below 2^31
+  for (int d = 1; d < 64; d <<= 1) sz += __shfl_xor(sz, d, 64);
+  unsigned long long* l64 = (unsigned long long*)lds;
+  if ((threadIdx.x & 63) == 0) l64[threadIdx.x >> 6] = sz;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long total = 0;
+    for (int w = 0; w < KZ_WG / 64; w++) total += l64[w];
+    S.tSum[(int64_t)b * S.T + t] = (total > 0xFFFFFFFFull) ? 0xFFFFFFFFu : (u32)total;
+  }
 }
 
 __global__ __launch_bounds__(64) void k_zrlt_i2(const int32_t* __restrict__ d_len, ZiScratch S, int dstCap) {
@@ -274,8 +297,9 @@ __global__ __launch_bounds__(64) void k_zrlt_i2(const int32_t* __restrict__ d_le
   for (int base = 0; base < tiles; base += 64) {
     const int t = base + lane;
     const u32 v = (t < tiles) ? S.tSum[o + t] : 0;
-    u32 inc = kz_wave_incl_sum(v);
-    if (t < tiles) S.tOff[o + t] = (u32)carry + inc - v;
+    unsigned long long inc = v;                                     // 64-bit: tile totals may be saturated
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long up = __shfl_up(inc, d, 64); if (lane >= d) inc += up; }
+    if (t < tiles) S.tOff[o + t] = (u32)(carry + inc - v);          // only used when the total fits
     carry += __shfl(inc, 63, 64);
   }
   if (lane == 0) {

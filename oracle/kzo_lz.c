@@ -175,7 +175,14 @@ int kzo_lz_forward(int extra, int dataType, const uint8_t* src, int count, uint8
   return ok ? res : 0;
 }
 
-static int read_length(const uint8_t* a, int* idx) {
+/* readLength (LZCodec.java).  Every read of the inverse is bounded by the block length `count`: past it the Java code
+ * either throws (end of the array) or picks up stale bytes of a reused buffer; both are restated as failure (*bad). */
+static int read_length(const uint8_t* a, int* idx, int count, int* bad) {
+  if (*idx + 4 > count) {
+    int need = 1;
+    if (*idx < count) need = (a[*idx] < 254) ? 1 : (a[*idx] == 254 ? 3 : 4);
+    if (*idx + need > count) { *bad = 1; return 0; }
+  }
   int res = a[(*idx)++];
   if (res < 254) return res;
   if (res == 254) { res += (a[(*idx)++] << 8); res += a[(*idx)++]; return res; }
@@ -198,12 +205,13 @@ int kzo_lz_inverse(int extra, const uint8_t* src, int count, uint8_t* dst, int d
   const int srcEnd = tkIdx - 13, litEnd = tkIdx;
   const int maxDist = ((src[12] & 1) == 0) ? MAX_DISTANCE1 : MAX_DISTANCE2;
   const int minMatch = ((src[12] >> 1) & 0x07) + 2;
-  int srcIdx = 13, dstIdx = 0, repd0 = count, repd1 = count;
+  int srcIdx = 13, dstIdx = 0, repd0 = count, repd1 = count, bad = 0;
   for (;;) {
     if (tkIdx >= count) return 0;                                            /* Java: AIOOBE on corrupt data */
     const int token = src[tkIdx++];
     if (token >= 32) {
-      const int litLen = (token >= 0xE0) ? 7 + read_length(src, &srcIdx) : token >> 5;
+      const int litLen = (token >= 0xE0) ? 7 + read_length(src, &srcIdx, count, &bad) : token >> 5;
+      if (bad) return 0;
       if ((litLen > dstEnd - dstIdx) || (litLen > litEnd - srcIdx)) return 0;
       memcpy(dst + dstIdx, src + srcIdx, (size_t)litLen);
       srcIdx += litLen; dstIdx += litLen;
@@ -213,19 +221,22 @@ int kzo_lz_inverse(int extra, const uint8_t* src, int count, uint8_t* dst, int d
     const int f = token & 0x18;
     if (f == 0) {
       mLen = token & 0x03;
-      mLen += (mLen == 3) ? minMatch + read_length(src, &mLenIdx) : minMatch;
+      mLen += (mLen == 3) ? minMatch + read_length(src, &mLenIdx, count, &bad) : minMatch;
       dist = ((token & 0x04) == 0) ? repd0 : repd1;
     } else {
       mLen = token & 0x07;
-      mLen += (mLen == 7) ? minMatch + read_length(src, &mLenIdx) : minMatch;
+      mLen += (mLen == 7) ? minMatch + read_length(src, &mLenIdx, count, &bad) : minMatch;
+      if (mIdx + ((f == 0x18) ? 3 : (f == 0x10) ? 2 : 1) > count) return 0;
       dist = src[mIdx++];
       if (f == 0x18) { dist = (dist << 8) | src[mIdx++]; dist = (dist << 8) | src[mIdx++]; }
       else if (f == 0x10) dist = (dist << 8) | src[mIdx++];
     }
+    if (bad) return 0;
     repd1 = repd0; repd0 = dist;
     const int mEnd = dstIdx + mLen;
     const int ref = dstIdx - dist;
     if ((ref < 0) || (dist > maxDist) || (mEnd > dstEnd)) return 0;
+    if (dist == 0) return 0;   /* the reference copies the region onto itself here, exposing stale buffer bytes: rejected */
     for (int i = 0; i < mLen; i++) dst[dstIdx + i] = dst[ref + i];
     dstIdx = mEnd;
   }

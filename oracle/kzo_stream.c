@@ -304,10 +304,12 @@ int kzo_decode_block_x(uint64_t transformType, int entropyType, int chkKind, int
     int cap = blockSize + ((blockSize >> 4) > 512 ? (blockSize >> 4) : 512);
     uint8_t* tmp = (uint8_t*)malloc((size_t)cap + 64);
     int r = kzo_sequence_inverse(types, nb, skipFlags, buffer, (int)preLen, tmp, cap);
-    if (r >= 0 && r <= outCap) {
-      memcpy(out, tmp, (size_t)r); ret = r;
-      if (chkKind == 1 && (uint32_t)checksum1 != kzo_xxhash32(tmp, r, 0x4B414E5Au)) ret = -19;      /* ERR_CRC_CHECK :1349-1363 */
-      if (chkKind == 2 && checksum1 != kzo_xxhash64(tmp, r, 0x4B414E5AULL)) ret = -19;
+    if (r >= 0) {
+      /* checksum first (:1349-1363), then the reader's "decoded > blockSize" test (:756-759) */
+      if (chkKind == 1 && (uint32_t)checksum1 != kzo_xxhash32(tmp, r, 0x4B414E5Au)) ret = -19;      /* ERR_CRC_CHECK */
+      else if (chkKind == 2 && checksum1 != kzo_xxhash64(tmp, r, 0x4B414E5AULL)) ret = -19;
+      else if (r > blockSize || r > outCap) ret = -13;                                            /* ERR_PROCESS_BLOCK */
+      else { memcpy(out, tmp, (size_t)r); ret = r; }
     }
     free(tmp);
   }
@@ -498,9 +500,11 @@ int64_t kzo_decompress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstC
     for (int t = 0; t < jobs; t++) pthread_create(&th[t], NULL, dec_worker, &job);
     for (int t = 0; t < jobs; t++) pthread_join(th[t], NULL);
     if (!job.fail) {
+      /* blocks were decoded at blockSize strides; the reader simply appends what each block produced (:783-785), so
+         a block that came out short (possible only for corrupted streams without checksums) is closed up */
       ret = 0;
       for (int b = 0; b < nblocks; b++) {
-        if (b < nblocks - 1 && lens[b] != blockSize) { ret = -13; break; }
+        if (ret != (int64_t)b * blockSize && lens[b] > 0) memmove(dst + ret, dst + (int64_t)b * blockSize, (size_t)lens[b]);
         ret += lens[b];
       }
       if (bad && ret >= 0) ret = -11;                              /* every whole block decoded; the fault is the truncated one after them */

@@ -49,23 +49,26 @@ int kzo_zrlt_inverse(const uint8_t* src, int count, uint8_t* dst, int dstCap, in
   if (count == 0) return 1;
   int srcIdx = 0, dstIdx = 0;
   const int srcEnd = count, dstEnd = dstCap;          /* :162 dstEnd = output.length */
-  int runLength = 0;
+  /* runLength is a Java int: a run of more than 30 digits wraps (ZRLT.java:172-176), and so do the sums it is tested
+     with.  A write past dstEnd is the ArrayIndexOutOfBounds the Java loop would die of: failure. */
+  int32_t runLength = 0;
+#define WRAP_ADD(a, b) ((int32_t)((uint32_t)(a) + (uint32_t)(b)))
   for (;;) {
     int val = src[srcIdx];
     if (val <= 1) {
       runLength = 1;
       int ended = 0;
       do {
-        runLength += (runLength + val);
+        runLength = WRAP_ADD(runLength, WRAP_ADD(runLength, val));
         srcIdx++;
         if (srcIdx >= srcEnd) { ended = 1; break; }
         val = src[srcIdx];
       } while (val <= 1);
       if (ended) break;                               /* break mainLoop */
-      runLength--;
+      runLength = WRAP_ADD(runLength, -1);
       if (runLength > 0) {
-        if (dstIdx + runLength >= dstEnd) break;
-        while (runLength > 0) { runLength--; dst[dstIdx++] = 0; }
+        if (WRAP_ADD(dstIdx, runLength) >= dstEnd) break;
+        while (runLength > 0) { runLength--; if (dstIdx >= dstEnd) return 0; dst[dstIdx++] = 0; }
       }
     }
     if (val == 0xFF) {
@@ -80,9 +83,10 @@ int kzo_zrlt_inverse(const uint8_t* src, int count, uint8_t* dst, int dstCap, in
   }
   if (runLength > 0) {                                /* :217-228 trailing zeros */
     runLength--;
-    if (dstIdx + runLength > dstEnd) return 0;
-    while (runLength > 0) { runLength--; dst[dstIdx++] = 0; }
+    if (WRAP_ADD(dstIdx, runLength) > dstEnd) return 0;
+    while (runLength > 0) { runLength--; if (dstIdx >= dstEnd) return 0; dst[dstIdx++] = 0; }
   }
+#undef WRAP_ADD
   *produced = dstIdx;
   return srcIdx == srcEnd;
 }

@@ -130,6 +130,8 @@ def entropy_decode(name, data, nbits, count):
     lib().kzo_ibs_init(ctypes.byref(s), a.ctypes.data, nbits)
     out = np.zeros(max(count, 1), dtype=np.uint8)
     r = lib().kzo_entropy_decode(E[name.upper()], ctypes.byref(s), out.ctypes.data, count)
+    if s.error:                                  # ran past the end of the block's bits: the Java bitstream throws
+        r = -1
     return r, out[:count].tobytes(), int(s.pos)
 
 

@@ -129,3 +129,37 @@ def header_faults(good):
     mk(119, 2, 0, 19, "size mask cleared")             # ERR_CRC_CHECK :477-478
     mk(38, 5, 1, 19, "entropy id changed to a valid one")
     return cases
+
+
+def corrupt(rng, good, kind):
+    """One corruption of a well-formed buffer: 0 bit flips, 1 truncation, 2 a 64-byte garbage splice, 3 deleted bytes,
+    4 bit flips in the first 300 bytes (headers), 5 all garbage, 6 zeroed tail (what a stopped entropy decode leaves),
+    7 a long run of 0/1 bytes (ZRLT digits, wraps the Java int run length)."""
+    import numpy as np
+    bad = bytearray(good)
+    if kind == 0:
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0, len(bad)))
+            bad[pos] ^= 1 << int(rng.integers(0, 8))
+    elif kind == 1:
+        bad = bad[:int(rng.integers(1, len(bad)))]
+    elif kind == 2:
+        a = int(rng.integers(0, max(1, len(bad) - 64)))
+        bad[a:a + 64] = bytes(rng.integers(0, 256, 64, dtype=np.uint8))
+    elif kind == 3:
+        a = int(rng.integers(0, max(1, len(bad) - 8)))
+        del bad[a:a + int(rng.integers(1, 8))]
+    elif kind == 4:
+        for _ in range(int(rng.integers(1, 3))):
+            pos = int(rng.integers(0, min(len(bad), 300)))
+            bad[pos] ^= 1 << int(rng.integers(0, 8))
+    elif kind == 5:
+        bad = bytearray(rng.integers(0, 256, len(bad), dtype=np.uint8).tobytes())
+    elif kind == 6:
+        a = int(rng.integers(0, len(bad)))
+        bad[a:] = bytes(len(bad) - a)
+    else:
+        a = int(rng.integers(0, max(1, len(bad) - 80)))
+        k = int(rng.integers(28, 70))
+        bad[a:a + k] = bytes(rng.integers(0, 2, k, dtype=np.uint8))
+    return bytes(bad)

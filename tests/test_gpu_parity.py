@@ -344,6 +344,71 @@ def test_fuzz_streams_match_oracle(ctx):
         assert oracle.decompress(cos.output, n, jobs=2) == data
 
 
+def _codec(ctx, name):
+    if name == "RANK":
+        return kz.SBRT(ctx, 2)
+    if name == "MTFT":
+        return kz.SBRT(ctx, 1)
+    if name == "LZ":
+        return kz.LZCodec(ctx, kz.LZ_TYPE)
+    if name == "LZX":
+        return kz.LZCodec(ctx, kz.LZX_TYPE)
+    return {"BWT": kz.BWTBlockCodec, "ZRLT": kz.ZRLT, "SRT": kz.SRT}[name](ctx)
+
+
+@pytest.mark.parametrize("name", ["BWT", "SRT", "ZRLT", "RANK", "MTFT", "LZ", "LZX"])
+def test_inverse_transforms_follow_the_reference_on_corrupted_input(ctx, name):
+    """Malformed input to an inverse transform: the verdict (applied / failed) AND, when it applies, every output byte
+    must be what the reference's code path yields (the oracle restates it, Java int wrap-around included): BWT's 8
+    literal walkers (BWT.java:295-368), SRT's stale rank table (SRT.java:204-250), ZRLT's wrapped run lengths
+    (ZRLT.java:166-228), LZ's bounded reads (LZCodec.java:626-747)."""
+    rng = np.random.default_rng(123)
+    n = 20000
+    cap = n + max(512, n >> 4)
+    compared = 0
+    for src_kind in range(8):
+        pre = datagen.block(src_kind, n).tobytes()
+        if name in ("SRT", "RANK", "MTFT", "ZRLT"):
+            pre = oracle.transform_forward("BWT", pre)[1]
+            if name == "ZRLT":
+                pre = oracle.transform_forward("RANK", pre)[1]
+        ok, good = oracle.transform_forward(name, pre)
+        if not ok:
+            continue
+        for trial in range(24):
+            bad = refinputs.corrupt(rng, good, trial % 8)
+            ok_o, o = oracle.transform_inverse(name, bad, cap)
+            src = kz.SliceByteArray(np.frombuffer(bad, dtype=np.uint8).copy(), len(bad), 0)
+            dst = kz.SliceByteArray(np.zeros(cap, dtype=np.uint8), cap, 0)
+            ok_p = _codec(ctx, name).inverse(src, dst)
+            assert bool(ok_p) == bool(ok_o), (name, src_kind, trial)
+            if ok_o:
+                assert bytes(dst.array[:dst.index]) == o, (name, src_kind, trial)
+            compared += 1
+    assert compared >= 72
+
+
+@pytest.mark.parametrize("ent", ["ANS0", "HUFFMAN", "FPAQ"])
+def test_entropy_decoders_follow_the_reference_on_corrupted_input(ctx, ent):
+    """Malformed entropy payloads: same verdict and same bytes as the reference's decoder, including its quirk of
+    returning `count` after a chunk whose size does not add up (ANSRangeDecoder.java:229-231; the unwritten tail is
+    zero on both sides) and FPAQ's over-read test (FPAQDecoder.java:231-232)."""
+    dec = {"ANS0": kz.ANSRangeDecoder, "HUFFMAN": kz.HuffmanDecoder, "FPAQ": kz.FPAQDecoder}[ent]
+    rng = np.random.default_rng(321)
+    for src_kind in (3, 1, 6, 0):
+        data = datagen.block(src_kind, 40000).tobytes()
+        good, nbits = oracle.entropy_encode(ent, data)
+        for trial in range(32):
+            bad = refinputs.corrupt(rng, good, trial % 8)
+            nb = min(nbits, len(bad) * 8)
+            r, o, _ = oracle.entropy_decode(ent, bad, nb, len(data))
+            buf = np.zeros(len(data), dtype=np.uint8)
+            ok_p = dec(ctx, bad, nb).decode(buf, 0, len(data)) == len(data)
+            assert ok_p == (r == len(data)), (ent, src_kind, trial)
+            if ok_p:
+                assert bytes(buf) == o, (ent, src_kind, trial)
+
+
 def test_stream_header_faults_report_reference_codes(ctx):
     """Stream-header faults surface with the code and in the order of CompressedInputStream.readHeader
     (CompressedInputStream.java:363-478, Error.java:24-43), the same as the oracle reports."""
@@ -389,8 +454,15 @@ def test_corrupted_streams_never_hang_or_crash(ctx, chain, ent):
             assert out == data or len(out) <= len(data)       # undetected only if nothing that matters changed
             if bytes(bad) != good:
                 assert out == data or len(out) < len(data), "payload corruption slipped through the block checksum"
+            got = ("ok", out)
         except kz.KanziError as e:
             assert e.code > 0
+            got = ("err", e.code)
+        try:                                                   # and the same outcome as the reference's reader
+            want = ("ok", oracle.decompress(bytes(bad), len(data)))
+        except oracle.OracleError as e:
+            want = ("err", e.code)
+        assert got == want, (chain, ent, trial)
     assert kz.CompressedInputStream(ctx, good).read(len(data)) == data
 
 

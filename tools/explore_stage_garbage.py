@@ -29,8 +29,13 @@ def mutate(rng, good, kind):
     elif kind == 4:   # header-weighted flips
         for _ in range(int(rng.integers(1, 3))):
             pos = int(rng.integers(0, min(len(bad), 300))); bad[pos] ^= 1 << int(rng.integers(0, 8))
-    else:
+    elif kind == 5:
         bad = bytearray(rng.integers(0, 256, len(bad), dtype=np.uint8).tobytes())
+    elif kind == 6:   # zeroed tail (what a stopped entropy decode leaves behind)
+        a = int(rng.integers(0, len(bad))); bad[a:] = bytes(len(bad) - a)
+    else:             # a long run of 0/1 digits somewhere
+        a = int(rng.integers(0, max(1, len(bad) - 80))); k = int(rng.integers(28, 70))
+        bad[a:a + k] = bytes(rng.integers(0, 2, k, dtype=np.uint8))
     return bytes(bad)
 
 stats = collections.Counter()
@@ -46,8 +51,8 @@ for name in ["SRT", "ZRLT", "RANK", "MTFT", "BWT", "LZ", "LZX"]:
         ok, good = oracle.transform_forward(name, pre)
         if not ok: continue
         cap = N + max(512, N >> 4)
-        for trial in range(30):
-            bad = mutate(rng, good, trial % 6)
+        for trial in range(40):
+            bad = mutate(rng, good, trial % 8)
             ok_o, o = oracle.transform_inverse(name, bad, cap)
             src = kz.SliceByteArray(np.frombuffer(bad, dtype=np.uint8).copy(), len(bad), 0)
             dst = kz.SliceByteArray(np.zeros(cap, dtype=np.uint8), cap, 0)
@@ -58,13 +63,13 @@ for name in ["SRT", "ZRLT", "RANK", "MTFT", "BWT", "LZ", "LZX"]:
             else: verdict = "same"
             stats[(name, verdict)] += 1
             if verdict != "same" and stats[(name, verdict)] <= 3:
-                print("DIFF", name, "src", src_kind, "trial", trial, "kind", trial % 6, verdict)
+                print("DIFF", name, "src", src_kind, "trial", trial, "kind", trial % 8, verdict)
 for ent in ["ANS0", "HUFFMAN", "FPAQ"]:
     for src_kind in (3, 1, 6):
         data = datagen.block(src_kind, 40000).tobytes()
         good, nbits = oracle.entropy_encode(ent, data)
         for trial in range(60):
-            bad = mutate(rng, good, trial % 6)
+            bad = mutate(rng, good, trial % 8)
             nb = min(nbits, len(bad) * 8)
             r, o, used = oracle.entropy_decode(ent, bad, nb, len(data))
             ok_o = (r == len(data))
@@ -77,5 +82,8 @@ for ent in ["ANS0", "HUFFMAN", "FPAQ"]:
             else: verdict = "same"
             stats[(ent, verdict)] += 1
             if verdict != "same" and stats[(ent, verdict)] <= 3:
-                print("DIFF", ent, "src", src_kind, "trial", trial, "kind", trial % 6, verdict)
+                print("DIFF", ent, "src", src_kind, "trial", trial, "kind", trial % 8, verdict)
+                os.makedirs("gpurun_out", exist_ok=True)
+                open("gpurun_out/diff_%s_%d_%d.bin" % (ent, src_kind, trial), "wb").write(bad)
+                print("   nb", nb, "count", len(data), "oracle r", r, "used", used)
 for k, v in sorted(stats.items()): print(k, v)
