@@ -296,16 +296,16 @@ static int run_stage(kz_ctx* ctx, Pipe& P, const std::vector<int32_t>& h_mask, s
   return 0;
 }
 
+static size_t kz_arena_budget_probe() {
+  const char* e = getenv("KZ_ARENA_BUDGET_GB");
+  double gb = e ? atof(e) : 96.0;
+  size_t freeB = 0, totalB = 0;
+  if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > 0) gb = std::min(gb, (double)freeB / (1 << 30) * 0.6);
+  if (gb < 1.0) gb = 1.0;
+  return (size_t)(gb * (double)(1 << 30));
+}
 static size_t kz_arena_budget() {
-  static size_t budget = 0;
-  if (!budget) {
-    const char* e = getenv("KZ_ARENA_BUDGET_GB");
-    double gb = e ? atof(e) : 96.0;
-    size_t freeB = 0, totalB = 0;
-    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > 0) gb = std::min(gb, (double)freeB / (1 << 30) * 0.6);
-    if (gb < 1.0) gb = 1.0;
-    budget = (size_t)(gb * (double)(1 << 30));
-  }
+  static const size_t budget = kz_arena_budget_probe();      // initialised once, also when contexts live on several threads
   return budget;
 }
 // stage scratch is bump-allocated after the ping-pong buffers; each stage allocates in turn, so the

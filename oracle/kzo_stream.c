@@ -183,8 +183,11 @@ static uint8_t block_hdr_cksum(uint8_t mode, uint8_t headerSkipFlags, uint32_t p
   return (uint8_t)c;
 }
 
-/* Data-type sniff used by LZ only (K/Magic.java, CompressedOutputStream.java:795-804) is not modelled:
- * dataType 0 = UNDEFINED is passed (documented limitation; chains in scope ignore it except LZ). */
+/* Data-type side channel.  The writer tags a block BIN / MULTIMEDIA / EXE from its first four bytes (K/Magic.java,
+ * CompressedOutputStream.java:795-804).  Of the stages restated here only LZ/LZX reads the tag, and it reacts to
+ * DNA and SMALL_ALPHABET alone (LZCodec.java:343-352) -- values that only TextCodec / AliasCodec / UTFCodec can
+ * set (Global.detectSimpleType), none of which is in scope.  So for every chain built here the tag cannot change a
+ * byte and UNDEFINED (0) is passed; kzo_lz_forward keeps the parameter for when those stages arrive. */
 int64_t kzo_encode_block(uint64_t transformType, int entropyType, const uint8_t* data, int n,
                          uint8_t* out, size_t outCap, uint8_t* skipFlagsOut, int* postLenOut) {
   return kzo_encode_block_x(transformType, entropyType, 0, data, n, out, outCap, skipFlagsOut, postLenOut);
