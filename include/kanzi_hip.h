@@ -41,7 +41,11 @@ extern "C" {
 
 /* transform ids: K/transform/TransformFactory.java:36-60 */
 enum { KZ_T_NONE = 0, KZ_T_BWT = 1, KZ_T_LZ = 3, KZ_T_ZRLT = 6, KZ_T_MTFT = 7, KZ_T_RANK = 8,
-       KZ_T_SRT = 13, KZ_T_LZX = 16 };
+       KZ_T_SRT = 13, KZ_T_MM = 15, KZ_T_LZX = 16 };
+/* Global.DataType (K/Global.java:40-80): the per-block context entry "dataType" that MM (FSDCodec.java:78-85,160-168)
+   and LZ/LZX (LZCodec.java:343-352) read and write */
+enum { KZ_DT_UNDEFINED = 0, KZ_DT_DNA = 1, KZ_DT_SMALL_ALPHABET = 2, KZ_DT_TEXT = 3, KZ_DT_MULTIMEDIA = 4, KZ_DT_EXE = 5,
+       KZ_DT_NUMERIC = 6, KZ_DT_BASE64 = 7, KZ_DT_BIN = 8, KZ_DT_UTF8 = 9 };
 /* entropy ids: K/entropy/EntropyCodecFactory.java */
 enum { KZ_E_NONE = 0, KZ_E_HUFFMAN = 1, KZ_E_FPAQ = 2, KZ_E_ANS0 = 5 };
 /* error codes: K/Error.java:24-43 (returned negated); KZ_ERR_DEVICE is the one code the reference has no equivalent for */
@@ -68,6 +72,12 @@ const char* kz_last_error(kz_ctx* ctx);
  * the reference's context map (K/io/CompressedOutputStream.java:190-204, :749-755, :887-891). Applies to the
  * following kz_encode_blocks / kz_decode_blocks / kz_compress calls (kz_decompress reads it from the stream). */
 int32_t     kz_ctx_set_checksum(kz_ctx* ctx, int32_t bits);
+/* the "dataType" key of the context map a transform instance is built with (KZ_DT_*): kz_transform_forward reads it
+ * the way FSDCodec.forward / LZCodec.forward do (FSDCodec.java:78-85, LZCodec.java:343-352) and stores back what the
+ * reference would store (FSDCodec.java:160-168).  The batched calls tag every block themselves, like the writer does
+ * from the block's first four bytes (K/Magic.java, K/io/CompressedOutputStream.java:795-804). */
+int32_t     kz_ctx_set_data_type(kz_ctx* ctx, int32_t dataType);
+int32_t     kz_ctx_get_data_type(kz_ctx* ctx);
 /* HIP stream the context launches on (as void* = hipStream_t) so callers can bracket it with events */
 void*       kz_ctx_stream(kz_ctx* ctx);
 

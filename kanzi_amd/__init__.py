@@ -21,9 +21,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkanzi_hip.so")
 
 # transform ids (K/transform/TransformFactory.java:36-60) and entropy ids (K/entropy/EntropyCodecFactory.java)
-NONE_TYPE, BWT_TYPE, LZ_TYPE, ZRLT_TYPE, MTFT_TYPE, RANK_TYPE, SRT_TYPE, LZX_TYPE = 0, 1, 3, 6, 7, 8, 13, 16
+NONE_TYPE, BWT_TYPE, LZ_TYPE, ZRLT_TYPE, MTFT_TYPE, RANK_TYPE, SRT_TYPE, MM_TYPE, LZX_TYPE = 0, 1, 3, 6, 7, 8, 13, 15, 16
 E_NONE, E_HUFFMAN, E_FPAQ, E_ANS0 = 0, 1, 2, 5
-TRANSFORM_IDS = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "LZX": 16}
+TRANSFORM_IDS = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "MM": 15, "LZX": 16}
+# Global.DataType (K/Global.java:40-80), numbered as KZ_DT_* in include/kanzi_hip.h
+DATA_TYPES = {"UNDEFINED": 0, "DNA": 1, "SMALL_ALPHABET": 2, "TEXT": 3, "MULTIMEDIA": 4, "EXE": 5, "NUMERIC": 6, "BASE64": 7, "BIN": 8, "UTF8": 9}
 ENTROPY_IDS = {"NONE": 0, "HUFFMAN": 1, "FPAQ": 2, "ANS0": 5}
 MEM_HOST, MEM_DEVICE = 0, 1
 
@@ -65,6 +67,8 @@ def load_library():
         "kz_last_error": (c.c_char_p, [vp]),
         "kz_ctx_stream": (vp, [vp]),
         "kz_ctx_set_checksum": (c.c_int32, [vp, c.c_int32]),
+        "kz_ctx_set_data_type": (c.c_int32, [vp, c.c_int32]),
+        "kz_ctx_get_data_type": (c.c_int32, [vp]),
         "kz_transform_forward": (c.c_int32, [vp, c.c_uint32, u8p, c.c_int32, u8p, c.c_int32, i32p]),
         "kz_transform_inverse": (c.c_int32, [vp, c.c_uint32, u8p, c.c_int32, u8p, c.c_int32, i32p]),
         "kz_transform_max_encoded_len": (c.c_int32, [c.c_uint32, c.c_int32]),
@@ -99,6 +103,7 @@ def load_library():
 
 
 ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_error", "kz_ctx_stream", "kz_ctx_set_checksum",
+               "kz_ctx_set_data_type", "kz_ctx_get_data_type",
                "kz_transform_forward", "kz_transform_inverse", "kz_transform_max_encoded_len",
                "kz_entropy_encode", "kz_entropy_decode", "kz_encode_blocks", "kz_decode_blocks",
                "kz_max_block_stream_bytes", "kz_compress", "kz_decompress", "kz_transform_type",
@@ -158,6 +163,15 @@ class Context:
     def set_checksum(self, bits):
         """0, 32 or 64: block checksum kind (the reference's -x32 / -x64)."""
         self.check(self.lib.kz_ctx_set_checksum(self.h, int(bits)))
+
+    def set_data_type(self, data_type):
+        """The context map's "dataType" entry (a DATA_TYPES name or value) that the next transform instance will see."""
+        dt = DATA_TYPES[data_type.upper()] if isinstance(data_type, str) else int(data_type)
+        self.check(self.lib.kz_ctx_set_data_type(self.h, dt))
+
+    def get_data_type(self):
+        """What the last forward transform left in the context's "dataType" entry (DATA_TYPES value)."""
+        return int(self.lib.kz_ctx_get_data_type(self.h))
 
     @property
     def stream(self):
@@ -249,6 +263,10 @@ class ZRLT(_Transform):
 
 class SRT(_Transform):
     TYPE = SRT_TYPE            # K/transform/SRT.java
+
+
+class FSDCodec(_Transform):
+    TYPE = MM_TYPE             # K/transform/FSDCodec.java (transform name "MM")
 
 
 class LZCodec(_Transform):

@@ -39,6 +39,13 @@ extern "C" int32_t kz_ctx_set_checksum(kz_ctx* ctx, int32_t bits) {
   ctx->checksum = bits == 32 ? 1 : (bits == 64 ? 2 : 0);
   return 0;
 }
+// ctx map key "dataType" (Global.DataType): what a transform instance built with this context would find / leave there
+extern "C" int32_t kz_ctx_set_data_type(kz_ctx* ctx, int32_t dataType) {
+  if (!ctx || dataType < KZ_DT_UNDEFINED || dataType > KZ_DT_UTF8) return -KZ_ERR_INVALID_PARAM;
+  ctx->dataType = dataType;
+  return 0;
+}
+extern "C" int32_t kz_ctx_get_data_type(kz_ctx* ctx) { return ctx ? ctx->dataType : -KZ_ERR_INVALID_PARAM; }
 extern "C" const char* kz_last_error(kz_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 extern "C" void* kz_ctx_stream(kz_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
@@ -107,6 +114,7 @@ extern "C" int32_t kz_transform_max_encoded_len(uint32_t type, int32_t n) {
     case KZ_T_BWT: return n + 33;                                    // BWTBlockCodec.java:40,222
     case KZ_T_SRT: return n + 1024;                                  // SRT.java:30,365
     case KZ_T_LZ: case KZ_T_LZX: return ((n <= 1024) ? n + 16 : n + (n / 64)) + 2;   // LZCodec.java:961-964
+    case KZ_T_MM: return n + std::max(64, n >> 4);                   // FSDCodec.java:320-323
     default: return n;                                               // ZRLT.java:243, SBRT.java:224
   }
 }
@@ -123,7 +131,7 @@ static int split_types(uint64_t tt, int* types) {                    // Transfor
   for (int i = 0; i < nbtr; i++) { int t = (int)((tt >> (42 - 6 * i)) & 0x3F); if (t != KZ_T_NONE || i == 0) types[k++] = t; }
   return k;
 }
-static bool transform_supported(int t) { return t == KZ_T_NONE || t == KZ_T_BWT || t == KZ_T_RANK || t == KZ_T_MTFT || t == KZ_T_ZRLT || t == KZ_T_SRT || t == KZ_T_LZ || t == KZ_T_LZX; }
+static bool transform_supported(int t) { return t == KZ_T_NONE || t == KZ_T_BWT || t == KZ_T_RANK || t == KZ_T_MTFT || t == KZ_T_ZRLT || t == KZ_T_SRT || t == KZ_T_LZ || t == KZ_T_LZX || t == KZ_T_MM; }
 static bool entropy_supported(int e) { return e == KZ_E_NONE || e == KZ_E_ANS0 || e == KZ_E_HUFFMAN || e == KZ_E_FPAQ; }
 static int seq_max_len(const int* types, int nb, int n) {             // Sequence.java:215-226
   int req = n;
@@ -328,6 +336,7 @@ static size_t pipeline_scratch(int B, int maxLen, bool decode, const ChainSpec& 
       case KZ_T_ZRLT: s += kz_zrlt_scratch(B, maxLen); break;
       case KZ_T_SRT: s += decode ? 4096 : kz_srt_scratch(B, maxLen); break;
       case KZ_T_LZ: case KZ_T_LZX: s += decode ? 4096 : kz_lz_scratch(B, maxLen); break;
+      case KZ_T_MM: s += kz_mm_scratch(B, maxLen); break;
       default: break;
     }
   }
@@ -350,12 +359,14 @@ static int pipe_setup(kz_ctx* ctx, Pipe& P, int B, int maxLen, int64_t extraByte
   bt.d_len = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   bt.d_len2 = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   bt.d_flag = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  bt.d_dtype = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   P.d_mask = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   P.d_applied = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   P.d_lenSave = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   bt.cur = 0;
   bt.h_len.assign(B, 0);
-  if (!P.d_lenSave) { snprintf(ctx->err, sizeof(ctx->err), "pipe_setup: arena overflow"); return -KZ_ERR_DEVICE; }
+  if (!P.d_lenSave || !bt.d_dtype) { snprintf(ctx->err, sizeof(ctx->err), "pipe_setup: arena overflow"); return -KZ_ERR_DEVICE; }
+  KZ_HIP(hipMemsetAsync(bt.d_dtype, 0, (size_t)B * 4, ctx->stream));      // Global.DataType.UNDEFINED
   return 0;
 }
 
@@ -389,6 +400,7 @@ static int run_transform_stage(kz_ctx* ctx, kz_batch& bt, int type, bool forward
     case KZ_T_SRT: return forward ? kz_stage_srt_forward(ctx, bt) : kz_stage_srt_inverse(ctx, bt);
     case KZ_T_LZ: return forward ? kz_stage_lz_forward(ctx, bt, 0) : kz_stage_lz_inverse(ctx, bt, 0, dstCap);
     case KZ_T_LZX: return forward ? kz_stage_lz_forward(ctx, bt, 1) : kz_stage_lz_inverse(ctx, bt, 1, dstCap);
+    case KZ_T_MM: return forward ? kz_stage_mm_forward(ctx, bt) : kz_stage_mm_inverse(ctx, bt, dstCap);
     default: snprintf(ctx->err, sizeof(ctx->err), "transform %d has no HIP stage", type); return -KZ_ERR_INVALID_CODEC;
   }
 }
@@ -473,6 +485,10 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     KZ_LAUNCH(ctx, KID_COPY_BYTES, k_copy_bytes, dim3(64, B), dim3(256), in, inStride, bt.buf[0], bt.stride, bt.d_len, (const int32_t*)nullptr, (const int32_t*)nullptr);
   }
   KZ_HIP(hipMemsetAsync(d_out, 0, (size_t)outStride * B, st));       // bit-concat ORs into zeroed words
+  // the writer's per-block "dataType" tag from the first four bytes (CompressedOutputStream.java:795-804); the stages
+  // that care (MM, LZ/LZX) read and update it on the device
+  rc = kz_block_data_types(ctx, bt, KZ_DT_UNDEFINED, true);
+  if (rc) return rc;
   if (F.chk) { rc = kz_block_hashes(ctx, bt.buf[0], bt.stride, bt.d_len, B, F.chk, F.hash); if (rc) return rc; }
 
   // ---- transform chain (Sequence.forward, K/transform/Sequence.java:56-127) ----
@@ -788,9 +804,18 @@ static int32_t transform_one(kz_ctx* ctx, uint32_t type, bool forward, const uin
   KZ_HIP(hipMemcpyAsync(bt.buf[0], src, (size_t)n, hipMemcpyHostToDevice, st));
   bt.h_len[0] = n;
   KZ_HIP(hipMemcpyAsync(bt.d_len, &n, 4, hipMemcpyHostToDevice, st));
+  // the instance's context entry "dataType" (kz_ctx_set_data_type): read by MM and LZ/LZX forward, rewritten by MM
+  rc = kz_block_data_types(ctx, bt, ctx->dataType, false);
+  if (rc) return rc;
   std::vector<int32_t> mask(1, 1), applied;
   rc = run_stage(ctx, P, mask, applied, [&](kz_batch& x) { return run_transform_stage(ctx, x, (int)type, forward, dstCap); });
   if (rc) return rc;
+  if (forward) {
+    int32_t dt = 0;
+    KZ_HIP(hipMemcpyAsync(&dt, bt.d_dtype, 4, hipMemcpyDeviceToHost, st));
+    KZ_HIP(hipStreamSynchronize(st));
+    ctx->dataType = dt;
+  }
   if (!applied[0]) return 0;
   if (bt.h_len[0] > dstCap) return 0;
   *produced = bt.h_len[0];

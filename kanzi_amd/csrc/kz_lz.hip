@@ -68,7 +68,8 @@ __device__ __forceinline__ void lz_copy(u8* d, const u8* s, int n) { for (int i 
 
 __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8* __restrict__ dstAll, int64_t stride,
                                                 const int32_t* __restrict__ d_len, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag,
-                                                int32_t* __restrict__ hashAll, u8* __restrict__ tmpAll, int64_t tmpStride, int extra) {
+                                                int32_t* __restrict__ hashAll, u8* __restrict__ tmpAll, int64_t tmpStride, int extra,
+                                                const int32_t* __restrict__ d_dtype) {
   const int b = blockIdx.x;
   const int count = d_len[b];
   const int lane = kz_lane();
@@ -83,7 +84,10 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
   u8* mBuf = tkBuf + tmpStride / 3;
   u8* mLenBuf = mBuf + tmpStride / 3;
   LZ_ORDER();
-  const int minMatch = 4;                                            // dataType UNDEFINED (:342-353)
+  // the block's "dataType" context entry (:342-353): DNA -> minMatch 6, SMALL_ALPHABET -> not for LZ
+  const int dtype = d_dtype ? __builtin_amdgcn_readfirstlane(d_dtype[b]) : 0;
+  if (dtype == 2 /* SMALL_ALPHABET */) { if (w) { d_len2[b] = count; d_flag[b] = 0; } return; }
+  const int minMatch = (dtype == 1 /* DNA */) ? 6 : 4;
   const int srcEnd = count - 16 - 2;
   const int maxDist = (srcEnd < 4 * LZ_MAXD1) ? LZ_MAXD1 : LZ_MAXD2;
   if (w) dst[12] = (u8)(((maxDist == LZ_MAXD1) ? 0 : 1) | (((minMatch - 2) & 7) << 1));
@@ -353,7 +357,7 @@ int kz_stage_lz_forward(kz_ctx* ctx, kz_batch& bt, int extra) {
   u8* tmp = (u8*)kz_arena_alloc(ctx, (size_t)tmpStride * B + 256);
   if (!hashes || !tmp) { snprintf(ctx->err, sizeof(ctx->err), "lz_forward: arena overflow"); return -KZ_ERR_DEVICE; }
   KZ_LAUNCH(ctx, KID_LZ_FWD, k_lz_fwd, dim3(B), dim3(64), bt.buf[bt.cur], bt.buf[bt.cur ^ 1], bt.stride, bt.d_len, bt.d_len2, bt.d_flag,
-            hashes, tmp, tmpStride, extra);
+            hashes, tmp, tmpStride, extra, bt.d_dtype);
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
   { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }

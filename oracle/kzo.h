@@ -32,6 +32,19 @@ enum { KZO_T_NONE = 0, KZO_T_BWT = 1, KZO_T_BWTS = 2, KZO_T_LZ = 3, KZO_T_RLT = 
 enum { KZO_E_NONE = 0, KZO_E_HUFFMAN = 1, KZO_E_FPAQ = 2, KZO_E_RANGE = 4, KZO_E_ANS0 = 5,
        KZO_E_CM = 6, KZO_E_TPAQ = 7, KZO_E_ANS1 = 8, KZO_E_TPAQX = 9 };
 
+/* Global.DataType (K/Global.java:40-80): the per-block "dataType" context entry that transforms read and write */
+enum { KZO_DT_UNDEFINED = 0, KZO_DT_DNA = 1, KZO_DT_SMALL_ALPHABET = 2, KZO_DT_TEXT = 3, KZO_DT_MULTIMEDIA = 4,
+       KZO_DT_EXE = 5, KZO_DT_NUMERIC = 6, KZO_DT_BASE64 = 7, KZO_DT_BIN = 8, KZO_DT_UTF8 = 9 };
+/* K/Magic.java constants referred to by name */
+#define KZO_MAGIC_JPG 0xFFD8FFE0u
+#define KZO_MAGIC_RIFF 0x52494646u
+#define KZO_MAGIC_BZIP2 0x425A68
+#define KZO_MAGIC_MP3_ID3 0x494433
+#define KZO_MAGIC_BMP 0x424D
+#define KZO_MAGIC_PBM 0x5034
+#define KZO_MAGIC_PGM 0x5035
+#define KZO_MAGIC_PPM 0x5036
+
 /* ---- MSB-first bit streams (K/bitstream/DefaultOutputBitStream.java:80-205,
  *      K/bitstream/DefaultInputBitStream.java:81-192) ---- */
 typedef struct { uint8_t* buf; size_t cap; uint64_t nbits; int owns; int overflow; } kzo_obs;
@@ -82,13 +95,29 @@ int kzo_lz_forward(int lzx, int dataType, const uint8_t* src, int n, uint8_t* ds
 int kzo_lz_inverse(int lzx, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
 void kzo_suffix_array(const uint8_t* t, int32_t* sa, int n);      /* SA-IS */
 
+/* Global / Magic helpers (kzo_global.c) */
+int kzo_log2_4096(int x);
+int kzo_log2_1024(int x);
+int kzo_entropy1024(int length, const int* histo);
+int kzo_detect_simple_type(int count, const int* freqs0);
+int32_t kzo_magic_type(const uint8_t* src);
+int kzo_magic_is_compressed(int32_t magic);
+int kzo_magic_is_multimedia(int32_t magic);
+int kzo_magic_is_executable(int32_t magic);
+int kzo_block_data_type(const uint8_t* data, int n);
+/* FSDCodec = transform MM (kzo_fsd.c); dataType in/out, NULL = transform built without a context */
+int kzo_fsd_max_encoded_len(int n);
+int kzo_fsd_forward(int* dataType, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
+int kzo_fsd_inverse(const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
+
 int kzo_transform_max_encoded_len(int type, int n);
-int kzo_transform_forward(int type, int dataType, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
+/* dataType: the block's context entry, read and updated by the stages that use it; NULL = no context */
+int kzo_transform_forward(int type, int* dataType, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
 int kzo_transform_inverse(int type, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
 
 /* ---- Sequence (K/transform/Sequence.java:56-207) ---- */
 /* types[nb] in chain order. Returns post-transform length; *skipFlags per reference. */
-int kzo_sequence_forward(const int* types, int nb, int dataType, const uint8_t* src, int n,
+int kzo_sequence_forward(const int* types, int nb, int* dataType, const uint8_t* src, int n,
                          uint8_t* dst, int dstCap, uint8_t* skipFlags);
 int kzo_sequence_inverse(const int* types, int nb, uint8_t skipFlags, const uint8_t* src, int n,
                          uint8_t* dst, int dstCap);

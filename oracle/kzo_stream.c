@@ -32,11 +32,12 @@ int kzo_transform_max_encoded_len(int type, int n) {
     case KZO_T_SRT: return n + 1024;                             /* SRT.java:30,365 */
     case KZO_T_LZ: case KZO_T_LZX:
       return ((n <= 1024) ? n + 16 : n + (n / 64)) + 2;          /* LZCodec.java:961-964 */
+    case KZO_T_MM: return kzo_fsd_max_encoded_len(n);            /* FSDCodec.java:320-323 */
     default: return n;                                           /* ZRLT.java:243, SBRT.java:224, NullTransform */
   }
 }
 
-int kzo_transform_forward(int type, int dataType, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced) {
+int kzo_transform_forward(int type, int* dataType, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced) {
   *produced = 0;
   switch (type) {
     case KZO_T_NONE: if (dstCap < n) return 0; memcpy(dst, src, (size_t)n); *produced = n; return 1;
@@ -45,8 +46,9 @@ int kzo_transform_forward(int type, int dataType, const uint8_t* src, int n, uin
     case KZO_T_MTFT: if (dstCap < n) return 0; *produced = n; return kzo_sbrt_forward(1, src, n, dst);
     case KZO_T_ZRLT: return kzo_zrlt_forward(src, n, dst, dstCap, produced);
     case KZO_T_SRT:  return kzo_srt_forward(src, n, dst, dstCap, produced);
-    case KZO_T_LZ:   return kzo_lz_forward(0, dataType, src, n, dst, dstCap, produced);
-    case KZO_T_LZX:  return kzo_lz_forward(1, dataType, src, n, dst, dstCap, produced);
+    case KZO_T_LZ:   return kzo_lz_forward(0, dataType ? *dataType : KZO_DT_UNDEFINED, src, n, dst, dstCap, produced);
+    case KZO_T_LZX:  return kzo_lz_forward(1, dataType ? *dataType : KZO_DT_UNDEFINED, src, n, dst, dstCap, produced);
+    case KZO_T_MM:   return kzo_fsd_forward(dataType, src, n, dst, dstCap, produced);
     default: return 0;
   }
 }
@@ -62,6 +64,7 @@ int kzo_transform_inverse(int type, const uint8_t* src, int n, uint8_t* dst, int
     case KZO_T_SRT:  return kzo_srt_inverse(src, n, dst, dstCap, produced);
     case KZO_T_LZ:   return kzo_lz_inverse(0, src, n, dst, dstCap, produced);
     case KZO_T_LZX:  return kzo_lz_inverse(1, src, n, dst, dstCap, produced);
+    case KZO_T_MM:   return kzo_fsd_inverse(src, n, dst, dstCap, produced);
     default: return 0;
   }
 }
@@ -112,7 +115,7 @@ static int seq_max_encoded_len(const int* types, int nb, int n) {   /* Sequence.
   return req;
 }
 
-int kzo_sequence_forward(const int* types, int nb, int dataType, const uint8_t* src, int n,
+int kzo_sequence_forward(const int* types, int nb, int* dataType, const uint8_t* src, int n,
                          uint8_t* dst, int dstCap, uint8_t* skipFlagsOut) {
   uint8_t skipFlags = 0xFF;
   *skipFlagsOut = skipFlags;
@@ -184,10 +187,8 @@ static uint8_t block_hdr_cksum(uint8_t mode, uint8_t headerSkipFlags, uint32_t p
 }
 
 /* Data-type side channel.  The writer tags a block BIN / MULTIMEDIA / EXE from its first four bytes (K/Magic.java,
- * CompressedOutputStream.java:795-804).  Of the stages restated here only LZ/LZX reads the tag, and it reacts to
- * DNA and SMALL_ALPHABET alone (LZCodec.java:343-352) -- values that only TextCodec / AliasCodec / UTFCodec can
- * set (Global.detectSimpleType), none of which is in scope.  So for every chain built here the tag cannot change a
- * byte and UNDEFINED (0) is passed; kzo_lz_forward keeps the parameter for when those stages arrive. */
+ * CompressedOutputStream.java:795-804, kzo_block_data_type); the tag travels through the Sequence as the context
+ * entry "dataType": MM (FSDCodec) reads and rewrites it, LZ/LZX reacts to DNA and SMALL_ALPHABET (LZCodec.java:343-352). */
 int64_t kzo_encode_block(uint64_t transformType, int entropyType, const uint8_t* data, int n,
                          uint8_t* out, size_t outCap, uint8_t* skipFlagsOut, int* postLenOut) {
   return kzo_encode_block_x(transformType, entropyType, 0, data, n, out, outCap, skipFlagsOut, postLenOut);
@@ -207,7 +208,8 @@ int64_t kzo_encode_block_x(uint64_t transformType, int entropyType, int chkKind,
   int required = seq_max_encoded_len(types, nb, n);
   uint8_t* buffer = (uint8_t*)malloc((size_t)required + 64);
   uint8_t skipFlags = 0xFF;
-  int postLen = kzo_sequence_forward(types, nb, 0, data, n, buffer, required, &skipFlags);
+  int dataType = kzo_block_data_type(data, n);                                     /* :795-804 */
+  int postLen = kzo_sequence_forward(types, nb, &dataType, data, n, buffer, required, &skipFlags);
   if (postLen < 0) { free(buffer); return -1; }
   int dataSize = (postLen < 256) ? 1 : (ilog2((uint32_t)postLen) >> 3) + 1;       /* :825-826 */
   mode |= (uint8_t)(((dataSize - 1) & 3) << 5);

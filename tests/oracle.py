@@ -10,7 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ODIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ODIR, "libkzo.so")
 
-T = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "LZX": 16}
+T = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "MM": 15, "LZX": 16}
+# Global.DataType as numbered in oracle/kzo.h
+DT = {"UNDEFINED": 0, "DNA": 1, "SMALL_ALPHABET": 2, "TEXT": 3, "MULTIMEDIA": 4, "EXE": 5, "NUMERIC": 6, "BASE64": 7, "BIN": 8, "UTF8": 9}
 E = {"NONE": 0, "HUFFMAN": 1, "FPAQ": 2, "ANS0": 5}
 
 
@@ -47,7 +49,7 @@ def lib():
         L.kzo_encode_block.argtypes = [c.c_uint64, c.c_int, c.c_void_p, c.c_int, c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p]
         L.kzo_decode_block.restype = c.c_int
         L.kzo_decode_block.argtypes = [c.c_uint64, c.c_int, c.c_int, c.c_void_p, c.c_int64, c.c_void_p, c.c_int]
-        L.kzo_transform_forward.argtypes = [c.c_int, c.c_int, c.c_void_p, c.c_int, c.c_void_p, c.c_int, c.c_void_p]
+        L.kzo_transform_forward.argtypes = [c.c_int, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_int, c.c_void_p]
         L.kzo_transform_inverse.argtypes = [c.c_int, c.c_void_p, c.c_int, c.c_void_p, c.c_int, c.c_void_p]
         L.kzo_transform_max_encoded_len.argtypes = [c.c_int, c.c_int]
         L.kzo_transform_type.restype = c.c_uint64
@@ -89,15 +91,19 @@ def ttype(names):
     return int(lib().kzo_transform_type(ids, len(names)))
 
 
-def transform_forward(name, data, cap=None):
-    """-> (applied, bytes)"""
+def transform_forward(name, data, cap=None, data_type=None):
+    """-> (applied, bytes); with data_type (a DT value: the block's "dataType" context entry) -> (applied, bytes,
+    data type after the call)"""
     a = _u8(data)
     t = T[name.upper()]
     if cap is None:
         cap = lib().kzo_transform_max_encoded_len(t, len(a))
     out = np.zeros(max(cap, 1) + 64, dtype=np.uint8)
     p = ctypes.c_int(0)
-    ok = lib().kzo_transform_forward(t, 0, a.ctypes.data if len(a) else out.ctypes.data, len(a), out.ctypes.data, cap, ctypes.byref(p))
+    dt = ctypes.c_int(0 if data_type is None else int(data_type))
+    ok = lib().kzo_transform_forward(t, None if data_type is None else ctypes.addressof(dt), a.ctypes.data if len(a) else out.ctypes.data, len(a), out.ctypes.data, cap, ctypes.byref(p))
+    if data_type is not None:
+        return bool(ok), out[:p.value].tobytes(), int(dt.value)
     return bool(ok), out[:p.value].tobytes()
 
 

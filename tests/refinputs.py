@@ -163,3 +163,33 @@ def corrupt(rng, good, kind):
         k = int(rng.integers(28, 70))
         bad[a:a + k] = bytes(rng.integers(0, 2, k, dtype=np.uint8))
     return bytes(bad)
+
+
+def multimedia_like(kind, n, seed=1):
+    """Inputs FSDCodec (MM) applies to: 0 = 16-bit little-endian PCM-like samples (XOR coding, step 2), 1 = smooth RGB
+    pixels (delta coding, step 3), 2 = smooth 8-bit samples (delta, step 1), 3 = RGBA with sharp edges every 97 pixels
+    (delta coding with escape tokens, step 4), 4 = two interleaved 16-bit channels (step 4)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    if kind == 0:
+        t = np.arange(n // 2 + 1)
+        x = (8000 * np.sin(t / 37.0) + 3000 * np.sin(t / 5.1) + rng.normal(0, 40, t.size)).astype(np.int16)
+        return x.astype("<i2").tobytes()[:n]
+    if kind == 1:
+        w = n // 3 + 1
+        t = np.arange(w)
+        px = np.stack([128 + 100 * np.sin(t / 91.0), 128 + 90 * np.sin(t / 57.0 + 1), 100 + 80 * np.sin(t / 33.0 + 2)], 1)
+        return np.clip(px + rng.normal(0, 1.5, (w, 3)), 0, 255).astype(np.uint8).tobytes()[:n]
+    if kind == 2:
+        t = np.arange(n)
+        return np.clip(128 + 100 * np.sin(t / 45.0) + rng.normal(0, 2, n), 0, 255).astype(np.uint8).tobytes()
+    if kind == 3:
+        w = n // 4 + 1
+        t = np.arange(w)
+        base = np.where((t // 97) % 2 == 0, 30.0, 220.0)
+        px = np.stack([base + 10 * np.sin(t / 9.0), 255 - base, base * 0.5 + 60, np.full(w, 255.0)], 1)
+        return np.clip(px + rng.normal(0, 1.0, (w, 4)), 0, 255).astype(np.uint8).tobytes()[:n]
+    t = np.arange(n // 4 + 1)
+    a = (6000 * np.sin(t / 23.0) + rng.normal(0, 30, t.size)).astype(np.int16)
+    b = (5000 * np.cos(t / 41.0) + rng.normal(0, 30, t.size)).astype(np.int16)
+    return np.stack([a, b], 1).astype("<i2").tobytes()[:n]

@@ -353,10 +353,96 @@ def _codec(ctx, name):
         return kz.LZCodec(ctx, kz.LZ_TYPE)
     if name == "LZX":
         return kz.LZCodec(ctx, kz.LZX_TYPE)
-    return {"BWT": kz.BWTBlockCodec, "ZRLT": kz.ZRLT, "SRT": kz.SRT}[name](ctx)
+    return {"BWT": kz.BWTBlockCodec, "ZRLT": kz.ZRLT, "SRT": kz.SRT, "MM": kz.FSDCodec}[name](ctx)
 
 
-@pytest.mark.parametrize("name", ["BWT", "SRT", "ZRLT", "RANK", "MTFT", "LZ", "LZX"])
+def _mm_inputs():
+    """(label, bytes, context dataType before the call)"""
+    rng = np.random.default_rng(11)
+    cases = []
+    for kind in range(5):
+        for n in (1024, 1500, 5000, 65536, 300001):
+            cases.append(("mm%d/%d" % (kind, n), refinputs.multimedia_like(kind, n, seed=kind + n), 0))
+    cases.append(("random", bytes(rng.integers(0, 256, 50000, dtype=np.uint8)), 0))
+    cases.append(("text", (b"the quick brown fox jumps over the lazy dog " * 2000)[:60000], 0))
+    cases.append(("dna", bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 80000)]), 0))
+    cases.append(("digits", bytes(np.frombuffer(b"0123456789,.", dtype=np.uint8)[rng.integers(0, 12, 30000)]), 0))
+    cases.append(("base64", bytes(np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/", dtype=np.uint8)[rng.integers(0, 64, 30000)]), 0))
+    cases.append(("two symbols", bytes(np.frombuffer(b"ab", dtype=np.uint8)[rng.integers(0, 2, 30000)]), 0))
+    cases.append(("short", refinputs.multimedia_like(0, 1023), 0))
+    cases.append(("png magic", b"\x89PNG" + refinputs.multimedia_like(0, 60000)[4:], 0))
+    cases.append(("riff magic", b"RIFF" + refinputs.multimedia_like(0, 60000)[4:], kz.DATA_TYPES["MULTIMEDIA"]))
+    cases.append(("bmp magic", b"BM" + refinputs.multimedia_like(1, 60000)[2:], kz.DATA_TYPES["MULTIMEDIA"]))
+    cases.append(("pgm magic", b"P5\n" + refinputs.multimedia_like(2, 60000)[3:], 0))
+    cases.append(("tagged exe", refinputs.multimedia_like(0, 60000), kz.DATA_TYPES["EXE"]))
+    cases.append(("tagged bin", refinputs.multimedia_like(0, 60000), kz.DATA_TYPES["BIN"]))
+    cases.append(("escapes everywhere", bytes(rng.integers(0, 2, 40000, dtype=np.uint8) * 255), 0))
+    return cases
+
+
+def test_mm_forward_inverse_and_data_type_match_oracle(ctx):
+    """FSDCodec (transform MM): verdict, bytes and the "dataType" context entry it leaves behind, forward and inverse,
+    against the oracle (FSDCodec.java:60-318; Global.detectSimpleType :556-605; Magic.getType)."""
+    for label, data, dt0 in _mm_inputs():
+        ok_o, out_o, dt_o = oracle.transform_forward("MM", data, data_type=dt0)
+        ctx.set_data_type(dt0)
+        codec = kz.FSDCodec(ctx)
+        cap = codec.getMaxEncodedLength(len(data))
+        assert cap == len(data) + max(64, len(data) >> 4)
+        src = kz.SliceByteArray(np.frombuffer(data, dtype=np.uint8).copy(), len(data), 0)
+        dst = kz.SliceByteArray(np.zeros(cap, dtype=np.uint8), cap, 0)
+        ok_p = codec.forward(src, dst)
+        assert bool(ok_p) == bool(ok_o), label
+        assert ctx.get_data_type() == dt_o, label
+        if ok_o:
+            assert bytes(dst.array[:dst.index]) == out_o, label
+            back = kz.SliceByteArray(np.zeros(len(data) + 64, dtype=np.uint8), len(data) + 64, 0)
+            assert kz.FSDCodec(ctx).inverse(kz.SliceByteArray(np.frombuffer(out_o, dtype=np.uint8).copy(), len(out_o), 0), back)
+            assert bytes(back.array[:back.index]) == data, label
+    ctx.set_data_type(0)
+
+
+def test_lz_honours_the_data_type_entry(ctx):
+    """LZCodec.forward reads the context's dataType: DNA raises minMatch to 6, SMALL_ALPHABET declines
+    (LZCodec.java:343-352)."""
+    rng = np.random.default_rng(4)
+    words = [bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(rng.integers(5, 40)))]) for _ in range(300)]
+    data = b"".join(words[int(i)] for i in rng.integers(0, 300, 6000))[:120000]
+    for name in ("LZ", "LZX"):
+        for dt in ("UNDEFINED", "DNA", "SMALL_ALPHABET", "MULTIMEDIA"):
+            ok_o, out_o, _ = oracle.transform_forward(name, data, data_type=oracle.DT[dt])
+            ctx.set_data_type(dt)
+            codec = _codec(ctx, name)
+            cap = codec.getMaxEncodedLength(len(data))
+            dst = kz.SliceByteArray(np.zeros(cap, dtype=np.uint8), cap, 0)
+            ok_p = codec.forward(kz.SliceByteArray(np.frombuffer(data, dtype=np.uint8).copy(), len(data), 0), dst)
+            assert bool(ok_p) == bool(ok_o), (name, dt)
+            if ok_o:
+                assert bytes(dst.array[:dst.index]) == out_o, (name, dt)
+                assert (out_o[12] >> 1) & 7 == (4 if dt == "DNA" else 2)
+    ctx.set_data_type(0)
+
+
+@pytest.mark.parametrize("chain,ent", [("MM+LZX", "HUFFMAN"), ("MM", "ANS0"), ("MM+BWT+RANK+ZRLT", "ANS0")])
+def test_mm_streams_match_oracle(ctx, chain, ent):
+    """Whole streams with MM in the chain (MM+LZX & HUFFMAN is the tail of the reference's level 3): blocks where MM
+    applies, declines, and is ruled out by the writer's Magic tag; bit-identical to the oracle's stream."""
+    rng = np.random.default_rng(8)
+    bs = 65536
+    parts = [refinputs.multimedia_like(0, bs), refinputs.multimedia_like(3, bs), bytes(rng.integers(0, 256, bs, dtype=np.uint8)),
+             (b"plain text block " * 5000)[:bs], b"\x7FELF" + refinputs.multimedia_like(1, bs)[4:], b"RIFF" + refinputs.multimedia_like(4, bs)[4:],
+             b"PK\x03\x04" + refinputs.multimedia_like(2, bs)[4:], refinputs.multimedia_like(1, 30001)]
+    data = b"".join(parts)
+    for chk in (0, 32):
+        ref = oracle.compress(chain, ent, bs, data, jobs=2, checksum=chk)
+        cos = kz.CompressedOutputStream(ctx, chain, ent, bs, checksum=chk)
+        cos.write(data)
+        cos.close()
+        assert cos.output == ref, (chain, ent, chk)
+        assert kz.CompressedInputStream(ctx, ref).read(len(data)) == data
+
+
+@pytest.mark.parametrize("name", ["BWT", "SRT", "ZRLT", "RANK", "MTFT", "LZ", "LZX", "MM"])
 def test_inverse_transforms_follow_the_reference_on_corrupted_input(ctx, name):
     """Malformed input to an inverse transform: the verdict (applied / failed) AND, when it applies, every output byte
     must be what the reference's code path yields (the oracle restates it, Java int wrap-around included): BWT's 8
@@ -367,7 +453,7 @@ def test_inverse_transforms_follow_the_reference_on_corrupted_input(ctx, name):
     cap = n + max(512, n >> 4)
     compared = 0
     for src_kind in range(8):
-        pre = datagen.block(src_kind, n).tobytes()
+        pre = datagen.block(src_kind, n).tobytes() if name != "MM" else refinputs.multimedia_like(src_kind % 5, n, seed=src_kind)
         if name in ("SRT", "RANK", "MTFT", "ZRLT"):
             pre = oracle.transform_forward("BWT", pre)[1]
             if name == "ZRLT":

@@ -173,9 +173,9 @@ def test_oracle_survives_corrupted_input():
     rng = np.random.default_rng(9)
     n = 12000
     cap = n + max(512, n >> 4)
-    for name in ["BWT", "SRT", "ZRLT", "RANK", "MTFT", "LZ", "LZX"]:
+    for name in ["BWT", "SRT", "ZRLT", "RANK", "MTFT", "LZ", "LZX", "MM"]:
         for src_kind in (0, 2, 3):
-            pre = datagen.block(src_kind, n).tobytes()
+            pre = datagen.block(src_kind, n).tobytes() if name != "MM" else refinputs.multimedia_like(src_kind, n)
             if name in ("SRT", "RANK", "MTFT", "ZRLT"):
                 pre = oracle.transform_forward("BWT", pre)[1]
             ok, good = oracle.transform_forward(name, pre)
@@ -202,3 +202,70 @@ def test_oracle_survives_corrupted_input():
         except oracle.OracleError as e:
             assert e.code in (2, 11, 13, 19)
     assert oracle.decompress(good, len(data)) == data
+
+
+def test_log_table_and_entropy_known_answers():
+    """Global.LOG2_4096 is generated (round(4096*log2 x)), not transcribed: pin it on entries read off
+    Global.java:104-127, and log2_1024 / computeFirstOrderEntropy1024 on values worked by hand from :222-235, :440-456."""
+    L = oracle.lib()
+    known = {0: 0, 1: 0, 2: 4096, 3: 6492, 5: 9511, 7: 11499, 10: 13607, 17: 16742, 100: 27213, 129: 28718, 200: 31309,
+             255: 32745, 256: 32768}
+    for x, v in known.items():
+        assert L.kzo_log2_4096(x) == v
+    assert L.kzo_log2_1024(1) == 0 and L.kzo_log2_1024(2) == 1024 and L.kzo_log2_1024(3) == (6492 + 2) >> 2
+    assert L.kzo_log2_1024(4096) == 12 * 1024                      # exact power of two
+    assert L.kzo_log2_1024(1000) == 2 * 1024 + ((L.kzo_log2_4096(1000 >> 2) + 2) >> 2)
+    h = (ctypes.c_int * 256)()
+    h[0] = h[1] = 512                                               # two equiprobable symbols: 1 bit; the scale is 1024 per 8 bits
+    assert L.kzo_entropy1024(1024, h) == 128                        # 2 * ((512 * (10240 - 9216)) >> 3) / 1024
+    for i in range(256):
+        h[i] = 4                                                    # uniform: 8 bits
+    assert L.kzo_entropy1024(1024, h) == 1024
+
+
+def test_magic_and_block_data_type():
+    """Magic.getType quirks: JPEG returns the key itself (only ...E0 counts as compressed), 3-byte and 2-byte magics,
+    PNM needs a whitespace third byte; the writer's tag (CompressedOutputStream.java:795-804)."""
+    L = oracle.lib()
+    L.kzo_magic_type.restype = ctypes.c_int32
+    t = lambda b: L.kzo_magic_type(ctypes.c_char_p(bytes(b) + b"\0" * 4))
+    assert t(b"\xFF\xD8\xFF\xE0") == ctypes.c_int32(0xFFD8FFE0).value and t(b"\xFF\xD8\xFF\xE1") == ctypes.c_int32(0xFFD8FFE1).value
+    assert t(b"BZh9") == 0x425A68 and t(b"ID3\x03") == 0x494433 and t(b"\x1F\x8B\x08\x00") == 0x1F8B
+    assert t(b"BM\x00\x00") == 0x424D and t(b"P5\n1") == 0x5035 and t(b"P5x1") == 0 and t(b"abcd") == 0
+    dt = lambda b: L.kzo_block_data_type(ctypes.c_char_p(bytes(b) + b"\0" * 4), len(b))
+    assert dt(b"\xFF\xD8\xFF\xE0....") == oracle.DT["BIN"] and dt(b"\xFF\xD8\xFF\xE1....") == oracle.DT["UNDEFINED"]
+    assert dt(b"RIFF....") == oracle.DT["MULTIMEDIA"] and dt(b"\x7FELF....") == oracle.DT["EXE"] and dt(b"MZ..") == oracle.DT["EXE"]
+    assert dt(b"PK\x03\x04") == oracle.DT["BIN"] and dt(b"BM") == oracle.DT["UNDEFINED"]
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])
+def test_mm_roundtrip_and_choices(kind):
+    """FSDCodec on multimedia-like inputs: applied, header (mode, step) as the sampling rules dictate, exact round
+    trip, context entry set to MULTIMEDIA; declined (with the detected simple type) where coding does not pay."""
+    want = {0: (1, 2), 1: (0, 3), 2: (0, 1), 3: (0, 4), 4: (1, 4)}[kind]
+    for n in (1024, 5000, 65536, 300001):
+        data = refinputs.multimedia_like(kind, n)
+        ok, out, dt = oracle.transform_forward("MM", data, data_type=oracle.DT["UNDEFINED"])
+        assert ok and dt == oracle.DT["MULTIMEDIA"], (kind, n)
+        if n >= 5000:
+            assert (out[0], out[1]) == want, (kind, n, out[0], out[1])
+        ok2, back = oracle.transform_inverse("MM", out, len(data) + 64)
+        assert ok2 and back == data
+    rnd = bytes(np.random.default_rng(0).integers(0, 256, 50000, dtype=np.uint8))
+    assert oracle.transform_forward("MM", rnd, data_type=0)[0::2] == (False, oracle.DT["BIN"])
+    txt = (b"the quick brown fox jumps over the lazy dog " * 2000)[:60000]
+    assert oracle.transform_forward("MM", txt, data_type=0)[0::2] == (False, oracle.DT["UNDEFINED"])
+    dna = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(3).integers(0, 4, 80000)])
+    assert oracle.transform_forward("MM", dna, data_type=0)[0::2] == (False, oracle.DT["DNA"])
+    png = b"\x89PNG" + refinputs.multimedia_like(0, 60000)[4:]
+    assert oracle.transform_forward("MM", png, data_type=0)[0::2] == (False, 0)            # magic not a candidate
+    assert oracle.transform_forward("MM", refinputs.multimedia_like(0, 60000), data_type=oracle.DT["EXE"])[0] is False
+    assert oracle.transform_forward("MM", refinputs.multimedia_like(0, 1023), data_type=0)[0] is False
+
+
+def test_mm_in_a_stream():
+    """MM+LZX & HUFFMAN (the tail of the reference's level 3 chain) as a whole stream, mixed applicable / declined blocks."""
+    data = refinputs.multimedia_like(0, 200000) + refinputs.multimedia_like(3, 150000) + bytes(np.random.default_rng(5).integers(0, 256, 70000, dtype=np.uint8)) + (b"plain text block " * 5000)
+    z = oracle.compress("MM+LZX", "HUFFMAN", 65536, data, checksum=32)
+    assert oracle.decompress(z, len(data)) == data
+    assert len(z) < len(oracle.compress("LZX", "HUFFMAN", 65536, data, checksum=32))
