@@ -25,6 +25,15 @@ JNIEXPORT jint JNICALL CLS(ctxSetChecksum)(JNIEnv* env, jclass c, jlong ctx, jin
   (void)env; (void)c;
   return kz_ctx_set_checksum((kz_ctx*)(intptr_t)ctx, bits);
 }
+/* context map key "dataType" (Global.DataType <-> KZ_DT_*): read by MM and LZ/LZX forward, rewritten by MM */
+JNIEXPORT jint JNICALL CLS(ctxSetDataType)(JNIEnv* env, jclass c, jlong ctx, jint dataType) {
+  (void)env; (void)c;
+  return kz_ctx_set_data_type((kz_ctx*)(intptr_t)ctx, dataType);
+}
+JNIEXPORT jint JNICALL CLS(ctxGetDataType)(JNIEnv* env, jclass c, jlong ctx) {
+  (void)env; (void)c;
+  return kz_ctx_get_data_type((kz_ctx*)(intptr_t)ctx);
+}
 
 JNIEXPORT jint JNICALL CLS(maxEncodedLength)(JNIEnv* env, jclass c, jint type, jint n) {
   (void)env; (void)c;
