@@ -10,8 +10,9 @@
 //   -> k_mm_emit (one wave: XOR coding is 1:1; delta coding writes 1 or 2 bytes per input byte, the offsets of a row
 //   of 64 come from one ballot) -> k_mm_check (sampled histogram of the coded form against the plain entropy).
 // inverse, per block (one wave): XOR coding is a prefix XOR along each of the `dist` interleaved chains = a strided
-//   wave scan per row of 64; delta coding mixes additions with the XOR of an escape, which does not compose into a
-//   scan, so this first version replays the tokens in order with the last two output rows held in registers.
+//   wave scan per row of 64; delta coding mixes additions with the XOR of an escape, which does not compose into one
+//   scan operator: token starts by ballot, tokens compacted through LDS, a segmented strided scan of the deltas that
+//   restarts at escapes, the (rare) escapes resolved in order, bases added.
 // All arithmetic is the reference's integer arithmetic (64-bit sums, truncating divide); nothing here is tunable.
 #include "kz_device.h"
 #include "kz_internal.h"
@@ -310,39 +311,81 @@ __global__ __launch_bounds__(64) void k_mm_inv(const u8* __restrict__ srcAll, u8
         produced = n;
       }
     } else if (mode == MM_DELTA) {
-      // tokens in order; the last two output rows live in registers (look-back <= 16 bytes)
-      u32 cur = 0, prev = 0;
-      int fill = 0, out = 0;
-      if (lane < dist) cur = src[2 + lane];
-      fill = dist;                                                                // dist <= 16 < 64
-      int s = 2 + dist;
-      int wbase = s & ~63;
-      u32 win = (wbase + lane < count) ? (u32)src[wbase + lane] : 0u;
+      // Tokens are 1 byte (zigzag delta: out = out[-dist] + d) or 2 bytes (escape: out = out[-dist] ^ v).  Per row of
+      // 64 source bytes: find the token starts (a 0xFF is a payload when an odd number of 0xFF precede it), compact
+      // the tokens through LDS, sum the deltas along each of the `dist` chains with a segmented strided scan that
+      // restarts at escapes, resolve the (rare) escapes in order, then add the bases.  Same values as the reference's
+      // token-by-token loop (:273-296) on any input.
+      __shared__ u32 tok[64];
+      const int jm = lane % dist;
       const int dstEnd = dstCap;
-      while (s < count && out + fill < dstEnd) {
-        if (s >= wbase + 64) { wbase = s & ~63; win = (wbase + lane < count) ? (u32)src[wbase + lane] : 0u; }
-        u32 t = (u32)__builtin_amdgcn_readlane((int)win, s - wbase);
-        const int li = fill - dist;
-        const u32 look = (li >= 0) ? (u32)__builtin_amdgcn_readlane((int)cur, li & 63) : (u32)__builtin_amdgcn_readlane((int)prev, (64 + li) & 63);
-        u32 val;
-        if (t == MM_ESCAPE) {
-          s++;
-          if (s == count) break;                                                 // :278-279
-          if (s >= wbase + 64) { wbase = s & ~63; win = (wbase + lane < count) ? (u32)src[wbase + lane] : 0u; }
-          t = (u32)__builtin_amdgcn_readlane((int)win, s - wbase);
-          val = (t ^ look) & 0xFFu;
-        } else {
-          const int delta = (int)(t >> 1) ^ -(int)(t & 1u);
-          val = (u32)((int)look + delta) & 0xFFu;
+      u32 prevVals = (lane < dist) ? (u32)src[2 + lane] : 0u;                    // the first `dist` bytes, as they are
+      int prevM = dist;
+      int outBase = dist;
+      if (lane < dist) dst[lane] = (u8)prevVals;
+      bool carryPayload = false;
+      bool loneTail = false;
+      for (int rs = 2 + dist; rs < count && ok; rs += 64) {
+        const int i = rs + lane;
+        const bool valid = i < count;
+        const u32 x = valid ? (u32)src[i] : 0u;
+        const u32 xn = (i + 1 < count) ? (u32)src[i + 1] : 0u;                   // payload of an escape starting here
+        const uint64_t F = kz_ballot(valid && x == MM_ESCAPE);
+        // run of 0xFF bytes right below this lane
+        const uint64_t below = F & kz_lanemask_lt();
+        const int run = (lane == 0) ? 0 : (int)__builtin_clzll(~(below << (64 - lane)) | 0ULL) ;
+        const int runc = (lane == 0) ? 0 : min(run, lane);
+        bool payload = (runc & 1) != 0;
+        if (runc == lane) payload = ((lane & 1) != 0) != carryPayload;           // the run reaches the row start
+        const bool isTok = valid && !payload;
+        const bool esc = isTok && x == MM_ESCAPE;
+        const bool lone = esc && (i + 1 >= count);                                // escape with nothing behind it (:278-279)
+        if (kz_ballot(lone)) loneTail = true;
+        const uint64_t T = kz_ballot(isTok && !lone);
+        const int m = (int)__popcll(T);
+        // next row's lane 0 is a payload iff this row's last byte is an escape token start
+        carryPayload = ((T | kz_ballot(lone)) >> 63) & ((F >> 63) & 1ULL);
+        if (outBase + m > dstEnd) { ok = false; break; }                          // output full before the input ends
+        const int rank = (int)__popcll(T & kz_lanemask_lt());
+        if (isTok && !lone) tok[rank] = esc ? (0x100u | xn) : x;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                       // lgkmcnt(0): LDS write visible to the wave
+        const u32 t = (lane < m) ? tok[lane] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        const bool isEsc = (t & 0x100u) != 0 && lane < m;
+        int sum = (lane < m && !isEsc) ? ((int)((t & 0xFFu) >> 1) ^ -(int)(t & 1u)) : 0;      // zigzag decode
+        int flag = isEsc ? 1 : 0;
+        int seg = isEsc ? lane : -1;
+        for (int st = dist; st < 64; st <<= 1) {
+          const int us = __shfl_up(sum, st, 64), uf = __shfl_up(flag, st, 64), ug = __shfl_up(seg, st, 64);
+          if (lane >= st && !flag) { sum += us; flag = uf; seg = ug; }
         }
-        s++;
-        cur = (lane == fill) ? val : cur;
-        fill++;
-        if (fill == 64) { dst[out + lane] = (u8)cur; out += 64; prev = cur; fill = 0; }
+        // base of a lane whose segment started before this row: its chain's last value in the previous row
+        const u32 carryBase = (u32)__shfl((int)prevVals, (prevM - dist + jm) & 63, 64);
+        u32 escVal = 0;
+        uint64_t E = kz_ballot(isEsc);
+        while (E) {                                                               // escapes, in order
+          const int e = (int)__builtin_ctzll(E);
+          E &= E - 1;
+          const int p = e - dist;
+          u32 pv;
+          if (p < 0) pv = (u32)__builtin_amdgcn_readlane((int)prevVals, (prevM + p) & 63);
+          else {
+            const int sp = __builtin_amdgcn_readlane(seg, p);
+            const u32 bp = (sp >= 0) ? (u32)__builtin_amdgcn_readlane((int)escVal, sp & 63) : (u32)__builtin_amdgcn_readlane((int)carryBase, p);
+            pv = (bp + (u32)__builtin_amdgcn_readlane(sum, p)) & 0xFFu;
+          }
+          const u32 v = ((u32)__builtin_amdgcn_readlane((int)t, e) ^ pv) & 0xFFu;
+          escVal = (lane == e) ? v : escVal;
+        }
+        const u32 base = (seg >= 0) ? (u32)__shfl((int)escVal, seg & 63, 64) : carryBase;
+        const u32 val = (base + (u32)sum) & 0xFFu;
+        if (lane < m) dst[outBase + lane] = (u8)val;
+        if (m > 0) { prevVals = val; prevM = m; }
+        outBase += m;
       }
-      if (lane < fill) dst[out + lane] = (u8)cur;
-      produced = out + fill;
-      ok = (s == count);                                                          // :316
+      if (ok && loneTail && outBase >= dstEnd) ok = false;                        // the loop would have stopped before the lone escape
+      produced = outBase;
     } else ok = false;                                                            // :302-305
   }
   if (lane == 0) { d_len2[b] = ok ? produced : 0; d_flag[b] = ok ? 1 : 0; }
