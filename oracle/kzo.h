@@ -110,6 +110,11 @@ int kzo_fsd_max_encoded_len(int n);
 int kzo_fsd_forward(int* dataType, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
 int kzo_fsd_inverse(const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
 
+/* AliasCodec = transforms PACK and DNA (kzo_alias.c) */
+int kzo_alias_max_encoded_len(int n);
+int kzo_alias_forward(int onlyDNA, int* dataType, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
+int kzo_alias_inverse(const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
+
 int kzo_transform_max_encoded_len(int type, int n);
 /* dataType: the block's context entry, read and updated by the stages that use it; NULL = no context */
 int kzo_transform_forward(int type, int* dataType, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);

@@ -33,6 +33,7 @@ int kzo_transform_max_encoded_len(int type, int n) {
     case KZO_T_LZ: case KZO_T_LZX:
       return ((n <= 1024) ? n + 16 : n + (n / 64)) + 2;          /* LZCodec.java:961-964 */
     case KZO_T_MM: return kzo_fsd_max_encoded_len(n);            /* FSDCodec.java:320-323 */
+    case KZO_T_PACK: case KZO_T_DNA: return kzo_alias_max_encoded_len(n);   /* AliasCodec.java:472-475 */
     default: return n;                                           /* ZRLT.java:243, SBRT.java:224, NullTransform */
   }
 }
@@ -49,6 +50,8 @@ int kzo_transform_forward(int type, int* dataType, const uint8_t* src, int n, ui
     case KZO_T_LZ:   return kzo_lz_forward(0, dataType ? *dataType : KZO_DT_UNDEFINED, src, n, dst, dstCap, produced);
     case KZO_T_LZX:  return kzo_lz_forward(1, dataType ? *dataType : KZO_DT_UNDEFINED, src, n, dst, dstCap, produced);
     case KZO_T_MM:   return kzo_fsd_forward(dataType, src, n, dst, dstCap, produced);
+    case KZO_T_PACK: return kzo_alias_forward(0, dataType, src, n, dst, dstCap, produced);
+    case KZO_T_DNA:  return kzo_alias_forward(1, dataType, src, n, dst, dstCap, produced);   /* TransformFactory.java:341-343 */
     default: return 0;
   }
 }
@@ -65,6 +68,7 @@ int kzo_transform_inverse(int type, const uint8_t* src, int n, uint8_t* dst, int
     case KZO_T_LZ:   return kzo_lz_inverse(0, src, n, dst, dstCap, produced);
     case KZO_T_LZX:  return kzo_lz_inverse(1, src, n, dst, dstCap, produced);
     case KZO_T_MM:   return kzo_fsd_inverse(src, n, dst, dstCap, produced);
+    case KZO_T_PACK: case KZO_T_DNA: return kzo_alias_inverse(src, n, dst, dstCap, produced);
     default: return 0;
   }
 }

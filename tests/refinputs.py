@@ -193,3 +193,34 @@ def multimedia_like(kind, n, seed=1):
     a = (6000 * np.sin(t / 23.0) + rng.normal(0, 30, t.size)).astype(np.int16)
     b = (5000 * np.cos(t / 41.0) + rng.normal(0, 30, t.size)).astype(np.int16)
     return np.stack([a, b], 1).astype("<i2").tobytes()[:n]
+
+
+def alias_inputs():
+    """(label, bytes) inputs for AliasCodec (PACK / DNA): every branch -- one symbol, <= 4 symbols (2-bit packing, all
+    four values of count & 3), <= 16 symbols (4-bit packing, odd and even lengths), digram aliasing on text-like data
+    (with and without a trailing odd byte), and inputs it declines (no absent symbols, too few savings, too short)."""
+    import numpy as np
+    import datagen
+    rng = np.random.default_rng(2024)
+    pick = lambda alphabet, n: bytes(np.frombuffer(alphabet, dtype=np.uint8)[rng.integers(0, len(alphabet), n)])
+    words = [pick(b"abcdefghijklmnopqrstuvwxyz", int(rng.integers(2, 9))) for _ in range(400)]
+    text = b" ".join(words[int(i)] for i in rng.integers(0, 400, 40000))
+    cases = [("one symbol", b"z" * 5000)]
+    for k in range(4):
+        cases.append(("acgt+%d" % k, pick(b"ACGT", 80000 + k)))
+        cases.append(("two symbols+%d" % k, pick(b"ab", 30000 + k)))
+    for k in range(2):
+        cases.append(("digits+%d" % k, pick(b"0123456789,.", 30000 + k)))
+        cases.append(("16 symbols+%d" % k, bytes(rng.integers(0, 16, 40000 + k, dtype=np.uint8))))
+        cases.append(("17 symbols+%d" % k, bytes(rng.integers(0, 17, 40000 + k, dtype=np.uint8))))
+        cases.append(("text+%d" % k, text[:150000 + k]))
+        cases.append(("markov+%d" % k, datagen.block(0, 100000 + k).tobytes()))
+    cases.append(("5 symbols", pick(b"ACGTN", 50001)))
+    cases.append(("239 absent", bytes(rng.integers(0, 17, 2000, dtype=np.uint8)) + text[:3000]))
+    cases.append(("random", bytes(rng.integers(0, 256, 40000, dtype=np.uint8))))
+    cases.append(("records", datagen.block(2, 100000).tobytes()))
+    cases.append(("mostly zeros", datagen.block(4, 100000).tobytes()))
+    cases.append(("short", text[:1023]))
+    cases.append(("min length", text[:1024]))
+    cases.append(("few savings", bytes(rng.integers(0, 200, 60000, dtype=np.uint8))))
+    return cases

@@ -173,9 +173,12 @@ def test_oracle_survives_corrupted_input():
     rng = np.random.default_rng(9)
     n = 12000
     cap = n + max(512, n >> 4)
-    for name in ["BWT", "SRT", "ZRLT", "RANK", "MTFT", "LZ", "LZX", "MM"]:
+    alias = [d for _, d in refinputs.alias_inputs()]
+    for name in ["BWT", "SRT", "ZRLT", "RANK", "MTFT", "LZ", "LZX", "MM", "PACK"]:
         for src_kind in (0, 2, 3):
             pre = datagen.block(src_kind, n).tobytes() if name != "MM" else refinputs.multimedia_like(src_kind, n)
+            if name == "PACK":
+                pre = alias[(1, 9, 17)[src_kind if src_kind < 3 else 2]][:n]
             if name in ("SRT", "RANK", "MTFT", "ZRLT"):
                 pre = oracle.transform_forward("BWT", pre)[1]
             ok, good = oracle.transform_forward(name, pre)
@@ -269,3 +272,37 @@ def test_mm_in_a_stream():
     z = oracle.compress("MM+LZX", "HUFFMAN", 65536, data, checksum=32)
     assert oracle.decompress(z, len(data)) == data
     assert len(z) < len(oracle.compress("LZX", "HUFFMAN", 65536, data, checksum=32))
+
+
+@pytest.mark.parametrize("name", ["PACK", "DNA"])
+def test_alias_codec_roundtrip_and_branches(name):
+    """AliasCodec (PACK; DNA = the same codec restricted to DNA-looking blocks, TransformFactory.java:341-343): every
+    branch round-trips, the header says which branch ran, the context entry gets Global.detectSimpleType's verdict."""
+    seen = set()
+    for label, data in refinputs.alias_inputs():
+        ok, out, dt = oracle.transform_forward(name, data, data_type=oracle.DT["UNDEFINED"])
+        if not ok:
+            seen.add("declined")
+            continue
+        assert len(out) < len(data), label                          # applied only when it shrinks (:276)
+        n0 = out[0]
+        seen.add("one" if n0 == 255 else "2bit" if n0 >= 252 else "4bit" if n0 >= 240 else "digram")
+        ok2, back = oracle.transform_inverse(name, out, len(data) + 64)
+        assert ok2 and back == data, label
+        if name == "DNA":
+            assert dt == oracle.DT["DNA"], label
+    assert seen >= ({"declined", "2bit"} if name == "DNA" else {"declined", "one", "2bit", "4bit", "digram"})
+    txt = dict(refinputs.alias_inputs())["text+0"]
+    for tag in ("MULTIMEDIA", "UTF8", "EXE", "BIN"):                # :103-109
+        assert oracle.transform_forward("PACK", txt, data_type=oracle.DT[tag])[0] is False
+    assert oracle.transform_forward("DNA", txt, data_type=oracle.DT["TEXT"])[0] is False      # :111-113
+    assert oracle.transform_forward("PACK", txt, data_type=oracle.DT["TEXT"])[0] is True
+
+
+def test_alias_codec_known_answer():
+    """Hand-worked from AliasCodec.java:143-199: 1024 bytes of "ab" repeated -> header 254 (two symbols present),
+    'a','b', count & 3 = 0, then 0b00010001 for every four bytes."""
+    ok, out, _ = oracle.transform_forward("PACK", b"ab" * 512, data_type=0)
+    assert ok and out == bytes([254, ord("a"), ord("b"), 0]) + bytes([0x11]) * 256
+    ok, out, _ = oracle.transform_forward("PACK", b"q" * 1500, data_type=0)
+    assert ok and out == bytes([255, ord("q")]) + (1500).to_bytes(4, "little")
