@@ -41,7 +41,7 @@ extern "C" {
 
 /* transform ids: K/transform/TransformFactory.java:36-60 */
 enum { KZ_T_NONE = 0, KZ_T_BWT = 1, KZ_T_LZ = 3, KZ_T_ZRLT = 6, KZ_T_MTFT = 7, KZ_T_RANK = 8,
-       KZ_T_SRT = 13, KZ_T_MM = 15, KZ_T_LZX = 16 };
+       KZ_T_SRT = 13, KZ_T_MM = 15, KZ_T_LZX = 16, KZ_T_PACK = 18, KZ_T_DNA = 19 };
 /* Global.DataType (K/Global.java:40-80): the per-block context entry "dataType" that MM (FSDCodec.java:78-85,160-168)
    and LZ/LZX (LZCodec.java:343-352) read and write */
 enum { KZ_DT_UNDEFINED = 0, KZ_DT_DNA = 1, KZ_DT_SMALL_ALPHABET = 2, KZ_DT_TEXT = 3, KZ_DT_MULTIMEDIA = 4, KZ_DT_EXE = 5,

@@ -21,9 +21,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkanzi_hip.so")
 
 # transform ids (K/transform/TransformFactory.java:36-60) and entropy ids (K/entropy/EntropyCodecFactory.java)
-NONE_TYPE, BWT_TYPE, LZ_TYPE, ZRLT_TYPE, MTFT_TYPE, RANK_TYPE, SRT_TYPE, MM_TYPE, LZX_TYPE = 0, 1, 3, 6, 7, 8, 13, 15, 16
+NONE_TYPE, BWT_TYPE, LZ_TYPE, ZRLT_TYPE, MTFT_TYPE, RANK_TYPE, SRT_TYPE, MM_TYPE, LZX_TYPE, PACK_TYPE, DNA_TYPE = 0, 1, 3, 6, 7, 8, 13, 15, 16, 18, 19
 E_NONE, E_HUFFMAN, E_FPAQ, E_ANS0 = 0, 1, 2, 5
-TRANSFORM_IDS = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "MM": 15, "LZX": 16}
+TRANSFORM_IDS = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "MM": 15, "LZX": 16, "PACK": 18, "DNA": 19}
 # Global.DataType (K/Global.java:40-80), numbered as KZ_DT_* in include/kanzi_hip.h
 DATA_TYPES = {"UNDEFINED": 0, "DNA": 1, "SMALL_ALPHABET": 2, "TEXT": 3, "MULTIMEDIA": 4, "EXE": 5, "NUMERIC": 6, "BASE64": 7, "BIN": 8, "UTF8": 9}
 ENTROPY_IDS = {"NONE": 0, "HUFFMAN": 1, "FPAQ": 2, "ANS0": 5}
@@ -267,6 +267,14 @@ class SRT(_Transform):
 
 class FSDCodec(_Transform):
     TYPE = MM_TYPE             # K/transform/FSDCodec.java (transform name "MM")
+
+
+class AliasCodec(_Transform):
+    """K/transform/AliasCodec.java: transform "PACK"; onlyDNA=True is transform "DNA" (TransformFactory.java:341-343)."""
+
+    def __init__(self, ctx, onlyDNA=False):
+        super().__init__(ctx)
+        self.TYPE = DNA_TYPE if onlyDNA else PACK_TYPE
 
 
 class LZCodec(_Transform):

@@ -115,6 +115,7 @@ extern "C" int32_t kz_transform_max_encoded_len(uint32_t type, int32_t n) {
     case KZ_T_SRT: return n + 1024;                                  // SRT.java:30,365
     case KZ_T_LZ: case KZ_T_LZX: return ((n <= 1024) ? n + 16 : n + (n / 64)) + 2;   // LZCodec.java:961-964
     case KZ_T_MM: return n + std::max(64, n >> 4);                   // FSDCodec.java:320-323
+    case KZ_T_PACK: case KZ_T_DNA: return n + 1024;                  // AliasCodec.java:472-475
     default: return n;                                               // ZRLT.java:243, SBRT.java:224
   }
 }
@@ -131,7 +132,7 @@ static int split_types(uint64_t tt, int* types) {                    // Transfor
   for (int i = 0; i < nbtr; i++) { int t = (int)((tt >> (42 - 6 * i)) & 0x3F); if (t != KZ_T_NONE || i == 0) types[k++] = t; }
   return k;
 }
-static bool transform_supported(int t) { return t == KZ_T_NONE || t == KZ_T_BWT || t == KZ_T_RANK || t == KZ_T_MTFT || t == KZ_T_ZRLT || t == KZ_T_SRT || t == KZ_T_LZ || t == KZ_T_LZX || t == KZ_T_MM; }
+static bool transform_supported(int t) { return t == KZ_T_NONE || t == KZ_T_BWT || t == KZ_T_RANK || t == KZ_T_MTFT || t == KZ_T_ZRLT || t == KZ_T_SRT || t == KZ_T_LZ || t == KZ_T_LZX || t == KZ_T_MM || t == KZ_T_PACK || t == KZ_T_DNA; }
 static bool entropy_supported(int e) { return e == KZ_E_NONE || e == KZ_E_ANS0 || e == KZ_E_HUFFMAN || e == KZ_E_FPAQ; }
 static int seq_max_len(const int* types, int nb, int n) {             // Sequence.java:215-226
   int req = n;
@@ -337,6 +338,7 @@ static size_t pipeline_scratch(int B, int maxLen, bool decode, const ChainSpec& 
       case KZ_T_SRT: s += decode ? 4096 : kz_srt_scratch(B, maxLen); break;
       case KZ_T_LZ: case KZ_T_LZX: s += decode ? 4096 : kz_lz_scratch(B, maxLen); break;
       case KZ_T_MM: s += kz_mm_scratch(B, maxLen); break;
+      case KZ_T_PACK: case KZ_T_DNA: s += kz_alias_scratch(B, maxLen, decode); break;
       default: break;
     }
   }
@@ -401,6 +403,8 @@ static int run_transform_stage(kz_ctx* ctx, kz_batch& bt, int type, bool forward
     case KZ_T_LZ: return forward ? kz_stage_lz_forward(ctx, bt, 0) : kz_stage_lz_inverse(ctx, bt, 0, dstCap);
     case KZ_T_LZX: return forward ? kz_stage_lz_forward(ctx, bt, 1) : kz_stage_lz_inverse(ctx, bt, 1, dstCap);
     case KZ_T_MM: return forward ? kz_stage_mm_forward(ctx, bt) : kz_stage_mm_inverse(ctx, bt, dstCap);
+    case KZ_T_PACK: return forward ? kz_stage_alias_forward(ctx, bt, 0) : kz_stage_alias_inverse(ctx, bt, dstCap);
+    case KZ_T_DNA: return forward ? kz_stage_alias_forward(ctx, bt, 1) : kz_stage_alias_inverse(ctx, bt, dstCap);   // TransformFactory.java:341-343
     default: snprintf(ctx->err, sizeof(ctx->err), "transform %d has no HIP stage", type); return -KZ_ERR_INVALID_CODEC;
   }
 }

@@ -16,21 +16,12 @@
 // All arithmetic is the reference's integer arithmetic (64-bit sums, truncating divide); nothing here is tunable.
 #include "kz_device.h"
 #include "kz_internal.h"
+#include "kz_datatype.h"
 #include <cmath>
 #include <mutex>
 
 typedef uint32_t u32;
 typedef uint8_t u8;
-
-// Global.DataType, numbered as in include/kanzi_hip.h
-#define DT_UNDEFINED 0
-#define DT_DNA 1
-#define DT_SMALL_ALPHABET 2
-#define DT_MULTIMEDIA 4
-#define DT_EXE 5
-#define DT_NUMERIC 6
-#define DT_BASE64 7
-#define DT_BIN 8
 
 #define MM_MIN_LENGTH 1024
 #define MM_ESCAPE 0xFFu
@@ -93,14 +84,7 @@ __device__ __forceinline__ int mm_log2_1024(const int32_t* __restrict__ tab, int
   if ((x & (x - 1)) == 0) return lg << 10;
   return ((lg - 7) * 1024) + ((tab[x >> (lg - 7)] + 2) >> 2);
 }
-// sum over the 256 bins (one per thread) of a workgroup of 256; every thread gets the total
-__device__ __forceinline__ long long mm_wg_sum64(long long v, long long* lds4) {
-  for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return lds4[0] + lds4[1] + lds4[2] + lds4[3];
-}
+#define mm_wg_sum64 kz_wg256_sum64
 __device__ __forceinline__ int mm_entropy1024(const int32_t* __restrict__ tab, int length, int h, long long* lds4) {
   long long term = 0;
   if (h != 0) term = ((long long)h * (long long)(mm_log2_1024(tab, length) - mm_log2_1024(tab, h))) >> 3;
@@ -166,29 +150,8 @@ __global__ __launch_bounds__(256) void k_mm_analyze(const u8* __restrict__ srcAl
   }
   __syncthreads();
   if (sh_pick < 0) {                                                             // :160-165 -> Global.detectSimpleType :556-605
-    const int len = 3 * count10;
-    const int f = histo[0][tid];
-    const bool isDna = tid == 'a' || tid == 'c' || tid == 'g' || tid == 'n' || tid == 't' || tid == 'u' ||
-                       tid == 'A' || tid == 'C' || tid == 'G' || tid == 'N' || tid == 'T' || tid == 'U';
-    const bool isDigit = tid >= '0' && tid <= '9';
-    const bool isNum = isDigit || tid == '+' || tid == '-' || tid == '*' || tid == '/' || tid == '=' || tid == ',' || tid == '.' ||
-                       tid == ':' || tid == ';' || tid == ' ';
-    const bool isB64 = isDigit || (tid >= 'A' && tid <= 'Z') || (tid >= 'a' && tid <= 'z') || tid == '+' || tid == '/';
-    const long long sDna = mm_wg_sum64(isDna ? f : 0, lds4);
-    const long long sNum = mm_wg_sum64(isNum ? f : 0, lds4);
-    const long long sB64 = mm_wg_sum64(isB64 ? f : 0, lds4) + ((histo[0][0x3D] == 1) ? 1 : 0);
-    const long long nSym = mm_wg_sum64(f > 0 ? 1 : 0, lds4);
-    if (tid == 0) {
-      int t = DT_UNDEFINED;
-      if (len != 0) {
-        if (sDna > len - len / 12) t = DT_DNA;
-        else if (sNum == len) t = DT_NUMERIC;
-        else if (sB64 == len) t = DT_BASE64;
-        else if (nSym == 256) t = DT_BIN;
-        else if (nSym <= 4) t = DT_SMALL_ALPHABET;
-      }
-      d_dtype[b] = t;
-    }
+    const int t = kz_detect_simple_type_wg(3 * count10, histo[0][tid], histo[0][0x3D], lds4);
+    if (tid == 0) d_dtype[b] = t;
     return;
   }
   const int DIST[7] = {0, 1, 2, 3, 4, 8, 16};

@@ -353,6 +353,8 @@ def _codec(ctx, name):
         return kz.LZCodec(ctx, kz.LZ_TYPE)
     if name == "LZX":
         return kz.LZCodec(ctx, kz.LZX_TYPE)
+    if name in ("PACK", "DNA"):
+        return kz.AliasCodec(ctx, onlyDNA=(name == "DNA"))
     return {"BWT": kz.BWTBlockCodec, "ZRLT": kz.ZRLT, "SRT": kz.SRT, "MM": kz.FSDCodec}[name](ctx)
 
 
@@ -402,6 +404,55 @@ def test_mm_forward_inverse_and_data_type_match_oracle(ctx):
     ctx.set_data_type(0)
 
 
+@pytest.mark.parametrize("name", ["PACK", "DNA"])
+def test_alias_codec_matches_oracle(ctx, name):
+    """AliasCodec (PACK / DNA): verdict, bytes and the "dataType" entry, forward and inverse, on every branch (one
+    symbol, 2-bit and 4-bit packing with every count remainder, digram aliases with and without a trailing byte, declined
+    inputs) and under the context tags that rule it out (AliasCodec.java:76-470)."""
+    cases = [(label, data, 0) for label, data in refinputs.alias_inputs()]
+    text = dict(refinputs.alias_inputs())["text+0"]
+    for tag in ("MULTIMEDIA", "UTF8", "EXE", "BIN", "TEXT", "DNA"):
+        cases.append(("tagged " + tag, text[:60000], kz.DATA_TYPES[tag]))
+    applied = 0
+    for label, data, dt0 in cases:
+        ok_o, out_o, dt_o = oracle.transform_forward(name, data, data_type=dt0)
+        ctx.set_data_type(dt0)
+        codec = _codec(ctx, name)
+        cap = codec.getMaxEncodedLength(len(data))
+        assert cap == len(data) + 1024
+        dst = kz.SliceByteArray(np.zeros(cap, dtype=np.uint8), cap, 0)
+        ok_p = codec.forward(kz.SliceByteArray(np.frombuffer(data, dtype=np.uint8).copy(), len(data), 0), dst)
+        assert bool(ok_p) == bool(ok_o), (name, label)
+        assert ctx.get_data_type() == dt_o, (name, label)
+        if ok_o:
+            applied += 1
+            assert bytes(dst.array[:dst.index]) == out_o, (name, label)
+            back = kz.SliceByteArray(np.zeros(len(data) + 64, dtype=np.uint8), len(data) + 64, 0)
+            assert _codec(ctx, name).inverse(kz.SliceByteArray(np.frombuffer(out_o, dtype=np.uint8).copy(), len(out_o), 0), back)
+            assert bytes(back.array[:back.index]) == data, (name, label)
+    assert applied >= (4 if name == "DNA" else 12)
+    ctx.set_data_type(0)
+
+
+@pytest.mark.parametrize("chain,ent", [("PACK+LZX", "HUFFMAN"), ("DNA+LZ", "HUFFMAN"), ("PACK+MM+LZX", "HUFFMAN"), ("PACK+BWT+RANK+ZRLT", "ANS0")])
+def test_alias_streams_match_oracle(ctx, chain, ent):
+    """Streams with PACK / DNA in front (DNA+LZ & HUFFMAN is the reference's level 2, PACK+MM+LZX & HUFFMAN the tail
+    of level 3): the data type PACK detects changes what LZ does with the same block (DNA -> minMatch 6, SMALL_ALPHABET
+    -> LZ steps aside), and all of it must equal the oracle's stream."""
+    inputs = dict(refinputs.alias_inputs())
+    bs = 65536
+    parts = [inputs["acgt+0"][:bs], inputs["text+0"][:bs], inputs["two symbols+1"][:30001] + inputs["digits+0"][:bs - 30001],
+             refinputs.multimedia_like(1, bs), inputs["random"][:40000] + inputs["one symbol"][:5000] + inputs["5 symbols"][:bs - 45000],
+             inputs["markov+0"][:bs], inputs["16 symbols+1"][:20001]]
+    data = b"".join(parts)
+    ref = oracle.compress(chain, ent, bs, data, jobs=2, checksum=32)
+    cos = kz.CompressedOutputStream(ctx, chain, ent, bs, checksum=32)
+    cos.write(data)
+    cos.close()
+    assert cos.output == ref, (chain, ent)
+    assert kz.CompressedInputStream(ctx, ref).read(len(data)) == data
+
+
 def test_lz_honours_the_data_type_entry(ctx):
     """LZCodec.forward reads the context's dataType: DNA raises minMatch to 6, SMALL_ALPHABET declines
     (LZCodec.java:343-352)."""
@@ -442,7 +493,7 @@ def test_mm_streams_match_oracle(ctx, chain, ent):
         assert kz.CompressedInputStream(ctx, ref).read(len(data)) == data
 
 
-@pytest.mark.parametrize("name", ["BWT", "SRT", "ZRLT", "RANK", "MTFT", "LZ", "LZX", "MM"])
+@pytest.mark.parametrize("name", ["BWT", "SRT", "ZRLT", "RANK", "MTFT", "LZ", "LZX", "MM", "PACK"])
 def test_inverse_transforms_follow_the_reference_on_corrupted_input(ctx, name):
     """Malformed input to an inverse transform: the verdict (applied / failed) AND, when it applies, every output byte
     must be what the reference's code path yields (the oracle restates it, Java int wrap-around included): BWT's 8
@@ -454,6 +505,8 @@ def test_inverse_transforms_follow_the_reference_on_corrupted_input(ctx, name):
     compared = 0
     for src_kind in range(8):
         pre = datagen.block(src_kind, n).tobytes() if name != "MM" else refinputs.multimedia_like(src_kind % 5, n, seed=src_kind)
+        if name == "PACK":
+            pre = refinputs.alias_inputs()[(0, 1, 5, 9, 11, 13, 15, 17)[src_kind]][1][:n]
         if name in ("SRT", "RANK", "MTFT", "ZRLT"):
             pre = oracle.transform_forward("BWT", pre)[1]
             if name == "ZRLT":
