@@ -15,7 +15,7 @@ public final class HipByteTransform implements ByteTransform {
       io.github.flanglet.kanzi.Global.DataType.NUMERIC, io.github.flanglet.kanzi.Global.DataType.BASE64,
       io.github.flanglet.kanzi.Global.DataType.BIN, io.github.flanglet.kanzi.Global.DataType.UTF8};
   private final long ctx;
-  private final int type;   // TransformFactory ids: BWT 1, LZ 3, ZRLT 6, MTFT 7, RANK 8, SRT 13, MM 15, LZX 16
+  private final int type;   // TransformFactory ids: BWT 1, LZ 3, ZRLT 6, MTFT 7, RANK 8, SRT 13, MM 15, LZX 16, PACK 18, DNA 19
   private final java.util.Map<String, Object> map;   // the task's context map (may be null, like the reference codecs)
 
   public HipByteTransform(long ctx, int type) { this(ctx, type, null); }

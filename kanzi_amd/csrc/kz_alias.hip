@@ -5,8 +5,8 @@
 // DNA-looking blocks (TransformFactory.java:341-343).
 //
 // forward:  k_alias_analyze (one workgroup per block: order-0 histogram in LDS, absent symbols, the "dataType" rules,
-//   which of the four codings applies) -> for the digram coding k_alias_hist1 (pair histogram, 65536 bins per block
-//   in global memory) and k_alias_select (the n0 most frequent pairs in the reference's TreeSet order = descending
+//   which of the four codings applies) -> for the digram coding k_alias_hist1 (pair histogram, 65536 bins per block,
+//   counted in LDS one half at a time) and k_alias_select (the n0 most frequent pairs in the reference's TreeSet order = descending
 //   (frequency << 16 | pair), picked one by one with a workgroup max; header; alias table) -> k_alias_emit (one wave
 //   per block).  Bit packing is position independent.  The digram parse is greedy -- a pair consumes two bytes, so
 //   whether position i starts a token depends on i-1 -- but the dependence is a parity: i starts a token iff an even
@@ -81,21 +81,26 @@ __global__ __launch_bounds__(256) void k_alias_analyze(const u8* __restrict__ sr
   }
 }
 
-// pair histogram (Global.computeHistogramOrder1: pair = (previous byte, byte); the first byte's previous is 0)
-#define AL_TILE 16384
-__global__ __launch_bounds__(256) void k_alias_hist1(const u8* __restrict__ srcAll, int64_t stride, const int32_t* __restrict__ d_len, AliasFwd A) {
+// pair histogram (Global.computeHistogramOrder1: pair = (previous byte, byte); the first byte's previous is 0).
+// 65536 bins do not fit LDS as 32-bit counters, half of them do (128 KiB): two workgroups per block, each reads the
+// whole block and counts the pairs whose first byte falls in its half, then stores its 32768 counters.  (Global
+// atomics on 64K bins per block took 206 ms for 1024 text blocks of 4 MiB, this takes a few.)
+__global__ __launch_bounds__(1024) void k_alias_hist1(const u8* __restrict__ srcAll, int64_t stride, const int32_t* __restrict__ d_len, AliasFwd A) {
   const int b = blockIdx.y;
   if (A.branch[b] != AL_DIGRAM) return;
+  const int half = blockIdx.x;
   const int count = d_len[b];
-  const int start = blockIdx.x * AL_TILE;
-  if (start >= count) return;
-  const int end = min(count, start + AL_TILE);
+  __shared__ u32 hist[32768];
+  for (int i = threadIdx.x; i < 32768; i += 1024) hist[i] = 0;
+  __syncthreads();
   const u8* src = srcAll + (int64_t)b * stride;
-  u32* fr = A.freqs1 + (int64_t)b * 65536;
-  for (int i = start + threadIdx.x; i < end; i += 256) {
+  for (int i = threadIdx.x; i < count; i += 1024) {
     const u32 prv = (i == 0) ? 0u : (u32)src[i - 1];
-    atomicAdd(&fr[(prv << 8) | (u32)src[i]], 1u);
+    if ((int)(prv >> 7) == half) atomicAdd(&hist[((prv & 127u) << 8) | (u32)src[i]], 1u);
   }
+  __syncthreads();
+  u32* fr = A.freqs1 + (int64_t)b * 65536 + half * 32768;
+  for (int i = threadIdx.x; i < 32768; i += 1024) fr[i] = hist[i];
 }
 
 __device__ __forceinline__ unsigned long long al_wg_max64(unsigned long long v, unsigned long long* lds4) {
@@ -340,11 +345,9 @@ int kz_stage_alias_forward(kz_ctx* ctx, kz_batch& bt, int onlyDNA) {
   hipStream_t st = ctx->stream;
   const u8* src = bt.buf[bt.cur];
   u8* dst = bt.buf[bt.cur ^ 1];
-  KZ_HIP(hipMemsetAsync(A.freqs1, 0, (size_t)B * 65536 * 4, st));
   KZ_HIP(hipMemsetAsync(A.map8, 0, (size_t)B * 256, st));
   KZ_LAUNCH(ctx, KID_ALIAS_ANALYZE, k_alias_analyze, dim3(B), dim3(256), src, bt.stride, bt.d_len, bt.d_dtype, A, onlyDNA);
-  const int tiles = (maxN + AL_TILE - 1) / AL_TILE;
-  if (tiles > 0) KZ_LAUNCH(ctx, KID_ALIAS_HIST1, k_alias_hist1, dim3(tiles, B), dim3(256), src, bt.stride, bt.d_len, A);
+  if (maxN > 0) KZ_LAUNCH(ctx, KID_ALIAS_HIST1, k_alias_hist1, dim3(2, B), dim3(1024), src, bt.stride, bt.d_len, A);
   KZ_LAUNCH(ctx, KID_ALIAS_SELECT, k_alias_select, dim3(B), dim3(256), dst, bt.stride, bt.d_len, A);
   KZ_LAUNCH(ctx, KID_ALIAS_EMIT, k_alias_emit, dim3(B), dim3(64), src, dst, bt.stride, bt.d_len, bt.d_len2, bt.d_flag, A);
   KZ_HIP(hipGetLastError());
