@@ -621,6 +621,25 @@ def test_large_blocks_match_oracle(ctx):
         assert kz.CompressedInputStream(ctx, ref).read() == data
 
 
+def test_levels_1_to_3_tail_at_4mib_blocks(ctx):
+    """The reference's level 1 (LZX & NONE), level 2 (DNA+LZ & HUFFMAN) and the tail of level 3 (PACK+MM+LZX &
+    HUFFMAN) at the default 4 MiB block size, on a stream whose blocks take every route: text (digram aliases), DNA
+    (2-bit packing, LZ with minMatch 6), 16-bit samples and RGB pixels (MM), random bytes, a short tail."""
+    rng = np.random.default_rng(12)
+    bs = 4 * 1024 * 1024
+    words = [bytes(rng.integers(97, 123, int(rng.integers(2, 10)), dtype=np.uint8)) for _ in range(500)]
+    text = b" ".join(words[int(i)] for i in rng.integers(0, 500, 900_000))[:bs]
+    dna = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, bs)])
+    data = text + dna + refinputs.multimedia_like(0, bs) + refinputs.multimedia_like(1, bs) + bytes(rng.integers(0, 256, bs, dtype=np.uint8)) + text[:123457]
+    for chain, ent in (("LZX", "NONE"), ("DNA+LZ", "HUFFMAN"), ("PACK+MM+LZX", "HUFFMAN")):
+        ref = oracle.compress(chain, ent, bs, data, jobs=3, checksum=32)
+        cos = kz.CompressedOutputStream(ctx, chain, ent, bs, checksum=32)
+        cos.write(data)
+        cos.close()
+        assert cos.output == ref, chain
+        assert kz.CompressedInputStream(ctx, ref).read() == data
+
+
 @pytest.mark.parametrize("force", ["lanes", "waves"])
 def test_fpaq_both_arrangements(ctx, force, monkeypatch):
     """FPAQ has two kernel arrangements (one wave per block for batches up to 8 blocks per CU, one lane per block above):
