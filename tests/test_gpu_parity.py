@@ -564,6 +564,34 @@ def test_stream_header_faults_report_reference_codes(ctx):
     assert kz.CompressedInputStream(ctx, good).read(len(data)) == data
 
 
+def test_fuzz_streams_with_pack_dna_mm(ctx):
+    """The same randomised parity for the chains that carry the "dataType" entry from stage to stage: PACK / DNA / MM in
+    front of LZ, LZX, BWT chains; inputs also drawn from the multimedia-like and alphabet-limited generators."""
+    rng = np.random.default_rng(20260929)
+    chains = ["PACK", "DNA", "MM", "PACK+MM+LZX", "DNA+LZ", "MM+LZX", "PACK+LZ", "PACK+BWT+RANK+ZRLT", "PACK+ZRLT", "MM+PACK", "DNA+MM+LZX"]
+    ents = ["ANS0", "HUFFMAN", "FPAQ", "NONE"]
+    alias = [d for _, d in refinputs.alias_inputs()]
+    for case in range(120):
+        n = int(rng.choice([0, 1, 16, 1023, 1024, 1025, 4096, int(rng.integers(1, 70000)), int(rng.integers(1, 200000))]))
+        pick = int(rng.integers(0, 3))
+        if pick == 0:
+            data = _fuzz_input(rng, n).tobytes()
+        elif pick == 1:
+            data = refinputs.multimedia_like(int(rng.integers(0, 5)), n, seed=case) if n else b""
+        else:
+            src = alias[int(rng.integers(0, len(alias)))]
+            data = (src * (n // len(src) + 1))[:n]
+        chain, ent = chains[int(rng.integers(0, len(chains)))], ents[int(rng.integers(0, len(ents)))]
+        bs = int(rng.choice([1024, 4096, 16384, 65536, 1 << 20]))
+        chk = int(rng.choice([0, 0, 32, 64]))
+        ref = oracle.compress(chain, ent, bs, data, jobs=4, checksum=chk)
+        cos = kz.CompressedOutputStream(ctx, chain, ent, bs, checksum=chk)
+        cos.write(data)
+        cos.close()
+        assert cos.output == ref, (case, n, chain, ent, bs, chk)
+        assert kz.CompressedInputStream(ctx, ref).read(max(n, 1)) == data, (case, n, chain, ent, bs, chk)
+
+
 @pytest.mark.parametrize("chain,ent", [("BWT+RANK+ZRLT", "ANS0"), ("LZ", "HUFFMAN"), ("BWT+SRT+ZRLT", "FPAQ"), ("LZX", "NONE")])
 def test_corrupted_streams_never_hang_or_crash(ctx, chain, ent):
     """Bit flips, truncations and garbage payloads: the decoder must return (an error code or some bytes) -- no hang,
