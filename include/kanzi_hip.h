@@ -76,6 +76,10 @@ int32_t     kz_ctx_set_checksum(kz_ctx* ctx, int32_t bits);
  * the way FSDCodec.forward / LZCodec.forward do (FSDCodec.java:78-85, LZCodec.java:343-352) and stores back what the
  * reference would store (FSDCodec.java:160-168).  The batched calls tag every block themselves, like the writer does
  * from the block's first four bytes (K/Magic.java, K/io/CompressedOutputStream.java:795-804). */
+/* the "skipBlocks" key of the context map (CLI --skip): kz_encode_blocks / kz_compress store a block as a copy block
+ * when its first bytes carry the magic number of a compressed format or its order-0 entropy is >= 0.95 * 8 bits
+ * (K/io/CompressedOutputStream.java:769-788, Magic.isCompressed, Global.computeFirstOrderEntropy1024). Default off. */
+int32_t     kz_ctx_set_skip_blocks(kz_ctx* ctx, int32_t on);
 int32_t     kz_ctx_set_data_type(kz_ctx* ctx, int32_t dataType);
 int32_t     kz_ctx_get_data_type(kz_ctx* ctx);
 /* HIP stream the context launches on (as void* = hipStream_t) so callers can bracket it with events */

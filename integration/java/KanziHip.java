@@ -7,6 +7,7 @@ public final class KanziHip {
   public static native long ctxCreate(int device);
   public static native void ctxDestroy(long ctx);
   public static native int ctxSetChecksum(long ctx, int bits);   // 0, 32 or 64
+  public static native int ctxSetSkipBlocks(long ctx, boolean on);   // context map key "skipBlocks"
   public static native int ctxSetDataType(long ctx, int dataType);   // Global.DataType as numbered by KZ_DT_* (kanzi_hip.h)
   public static native int ctxGetDataType(long ctx);
   public static native int maxEncodedLength(int type, int n);

@@ -25,6 +25,10 @@ JNIEXPORT jint JNICALL CLS(ctxSetChecksum)(JNIEnv* env, jclass c, jlong ctx, jin
   (void)env; (void)c;
   return kz_ctx_set_checksum((kz_ctx*)(intptr_t)ctx, bits);
 }
+JNIEXPORT jint JNICALL CLS(ctxSetSkipBlocks)(JNIEnv* env, jclass c, jlong ctx, jboolean on) {
+  (void)env; (void)c;
+  return kz_ctx_set_skip_blocks((kz_ctx*)(intptr_t)ctx, on ? 1 : 0);
+}
 /* context map key "dataType" (Global.DataType <-> KZ_DT_*): read by MM and LZ/LZX forward, rewritten by MM */
 JNIEXPORT jint JNICALL CLS(ctxSetDataType)(JNIEnv* env, jclass c, jlong ctx, jint dataType) {
   (void)env; (void)c;

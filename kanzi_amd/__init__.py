@@ -67,6 +67,7 @@ def load_library():
         "kz_last_error": (c.c_char_p, [vp]),
         "kz_ctx_stream": (vp, [vp]),
         "kz_ctx_set_checksum": (c.c_int32, [vp, c.c_int32]),
+        "kz_ctx_set_skip_blocks": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_set_data_type": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_get_data_type": (c.c_int32, [vp]),
         "kz_transform_forward": (c.c_int32, [vp, c.c_uint32, u8p, c.c_int32, u8p, c.c_int32, i32p]),
@@ -103,7 +104,7 @@ def load_library():
 
 
 ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_error", "kz_ctx_stream", "kz_ctx_set_checksum",
-               "kz_ctx_set_data_type", "kz_ctx_get_data_type",
+               "kz_ctx_set_data_type", "kz_ctx_get_data_type", "kz_ctx_set_skip_blocks",
                "kz_transform_forward", "kz_transform_inverse", "kz_transform_max_encoded_len",
                "kz_entropy_encode", "kz_entropy_decode", "kz_encode_blocks", "kz_decode_blocks",
                "kz_max_block_stream_bytes", "kz_compress", "kz_decompress", "kz_transform_type",
@@ -163,6 +164,10 @@ class Context:
     def set_checksum(self, bits):
         """0, 32 or 64: block checksum kind (the reference's -x32 / -x64)."""
         self.check(self.lib.kz_ctx_set_checksum(self.h, int(bits)))
+
+    def set_skip_blocks(self, on):
+        """The context map's "skipBlocks" entry (CLI --skip): incompressible-looking blocks become copy blocks."""
+        self.check(self.lib.kz_ctx_set_skip_blocks(self.h, 1 if on else 0))
 
     def set_data_type(self, data_type):
         """The context map's "dataType" entry (a DATA_TYPES name or value) that the next transform instance will see."""
@@ -402,7 +407,7 @@ class CompressedOutputStream:
     """K/io/CompressedOutputStream.java: write() bytes, close() -> .knz bytes in self.output.
     ctx keys mirror the reference's Map (transform, entropy, blockSize)."""
 
-    def __init__(self, ctx, transform="BWT+RANK+ZRLT", entropy="ANS0", blockSize=4 * 1024 * 1024, checksum=0):
+    def __init__(self, ctx, transform="BWT+RANK+ZRLT", entropy="ANS0", blockSize=4 * 1024 * 1024, checksum=0, skipBlocks=False):
         if blockSize > 1024 * 1024 * 1024:
             raise ValueError("The block size must be at most 1 GB")              # CompressedOutputStream.java:165-174
         if blockSize < 1024:
@@ -414,6 +419,7 @@ class CompressedOutputStream:
         self.et = ENTROPY_IDS[entropy.upper()]
         self.blockSize = blockSize
         self.checksum = checksum
+        self.skipBlocks = skipBlocks
         self._chunks = []
         self.closed = False
         self.output = None
@@ -433,10 +439,12 @@ class CompressedOutputStream:
         dst = np.empty(cap, dtype=np.uint8)
         sp = src.ctypes.data if n else dst.ctypes.data
         self.ctx.set_checksum(self.checksum)
+        self.ctx.set_skip_blocks(self.skipBlocks)
         try:
             rc = self.ctx.lib.kz_compress(self.ctx.h, self.tt, self.et, self.blockSize, sp, n, dst.ctypes.data, cap)
         finally:
             self.ctx.set_checksum(0)
+            self.ctx.set_skip_blocks(False)
         self.ctx.check(rc)
         self.output = dst[:rc].tobytes()
 

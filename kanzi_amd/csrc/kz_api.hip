@@ -39,6 +39,12 @@ extern "C" int32_t kz_ctx_set_checksum(kz_ctx* ctx, int32_t bits) {
   ctx->checksum = bits == 32 ? 1 : (bits == 64 ? 2 : 0);
   return 0;
 }
+// ctx map key "skipBlocks" (the reference CLI's --skip): blocks that look incompressible are stored as copy blocks
+extern "C" int32_t kz_ctx_set_skip_blocks(kz_ctx* ctx, int32_t on) {
+  if (!ctx) return -KZ_ERR_INVALID_PARAM;
+  ctx->skipBlocks = on ? 1 : 0;
+  return 0;
+}
 // ctx map key "dataType" (Global.DataType): what a transform instance built with this context would find / leave there
 extern "C" int32_t kz_ctx_set_data_type(kz_ctx* ctx, int32_t dataType) {
   if (!ctx || dataType < KZ_DT_UNDEFINED || dataType > KZ_DT_UTF8) return -KZ_ERR_INVALID_PARAM;
@@ -498,6 +504,13 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   // ---- transform chain (Sequence.forward, K/transform/Sequence.java:56-127) ----
   std::vector<int32_t> h_copy(B), h_mask(B), h_applied, h_skip(B, 0xFF);
   for (int b = 0; b < B; b++) h_copy[b] = (lengths[b] <= 15) ? 1 : 0;          // CompressedOutputStream.java:764-767
+  if (ctx->skipBlocks) {                                                         // :769-788
+    rc = kz_skip_block_flags(ctx, bt, P.d_applied);
+    if (rc) return rc;
+    KZ_HIP(hipMemcpyAsync(ctx->hpin, P.d_applied, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    KZ_HIP(hipStreamSynchronize(st));
+    for (int b = 0; b < B; b++) if (ctx->hpin[b]) h_copy[b] = 1;
+  }
   for (int i = 0; i < nb; i++) {
     for (int b = 0; b < B; b++) h_mask[b] = (!h_copy[b] && bt.h_len[b] > 0) ? 1 : 0;
     if (types[i] == KZ_T_NONE) { for (int b = 0; b < B; b++) if (h_mask[b]) h_skip[b] &= ~(1 << (7 - i)); continue; }
@@ -547,7 +560,8 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
         KZ_HIP(hipMemcpyAsync(F.bits, hb.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
         KZ_HIP(hipStreamSynchronize(st));
       } else {
-        for (int b = 0; b < B; b++) if (h_copy[b]) { int64_t v = 8LL * bt.h_len[b]; KZ_HIP(hipMemcpyAsync(F.bits + b, &v, 8, hipMemcpyHostToDevice, st)); KZ_HIP(hipStreamSynchronize(st)); }
+        for (int b = 0; b < B; b++) if (h_copy[b]) { hb[b] = 8LL * bt.h_len[b]; KZ_HIP(hipMemcpyAsync(F.bits + b, &hb[b], 8, hipMemcpyHostToDevice, st)); }
+        KZ_HIP(hipStreamSynchronize(st));                                          // hb is a local
       }
     }
     kz_stage_end(ctx, e0, KZ_STAGE_ENTROPY_ENC, inBytes);

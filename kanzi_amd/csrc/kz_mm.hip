@@ -92,6 +92,34 @@ __device__ __forceinline__ int mm_entropy1024(const int32_t* __restrict__ tab, i
   return (length == 0) ? 0 : (int)(sum / length);
 }
 
+// The writer's "skipBlocks" option (CompressedOutputStream.java:769-788): a block whose first bytes carry the magic
+// number of a compressed format, or whose order-0 entropy is at least 0.95 * 8 bits (EntropyUtils.INCOMPRESSIBLE_THRESHOLD
+// = 973 on the x1024 scale), is stored as a copy block.  One workgroup per block.
+#define MM_INCOMPRESSIBLE_THRESHOLD 973
+__global__ __launch_bounds__(256) void k_skip_decide(const u8* __restrict__ srcAll, int64_t stride, const int32_t* __restrict__ d_len,
+                                                      const int32_t* __restrict__ log2tab, int32_t* __restrict__ d_skip) {
+  const int b = blockIdx.x;
+  const int count = d_len[b];
+  const int tid = threadIdx.x;
+  __shared__ int h[256];
+  __shared__ long long lds4[4];
+  if (count <= 15) { if (tid == 0) d_skip[b] = 0; return; }                       // small blocks are copy blocks anyway (:764-767)
+  const u8* src = srcAll + (int64_t)b * stride;
+  if (mm_is_compressed(mm_magic_type(src))) { if (tid == 0) d_skip[b] = 1; return; }
+  h[tid] = 0;
+  __syncthreads();
+  for (int row = 0; row < count; row += 256) {
+    const int i = row + tid;
+    const bool valid = i < count;
+    const u32 v = valid ? (u32)src[i] : 0u;
+    const uint64_t peers = kz_match8(v, valid);
+    if (valid && (peers & kz_lanemask_lt()) == 0) atomicAdd(&h[v], (int)__popcll(peers));
+  }
+  __syncthreads();
+  const int e = mm_entropy1024(log2tab, count, h[tid], lds4);
+  if (tid == 0) d_skip[b] = (e >= MM_INCOMPRESSIBLE_THRESHOLD) ? 1 : 0;
+}
+
 struct MmFwd {
   int32_t* go;       // [B] 1 = analysis chose a coding, emit it
   int32_t* mode;     // [B]
@@ -377,6 +405,15 @@ static int mm_upload_table(kz_ctx* ctx, int32_t** d_tab) {
   *d_tab = (int32_t*)kz_arena_alloc(ctx, 257 * 4);
   if (!*d_tab) { snprintf(ctx->err, sizeof(ctx->err), "mm: arena overflow"); return -KZ_ERR_DEVICE; }
   KZ_HIP(hipMemcpyAsync(*d_tab, mm_log2_table_host(), 257 * 4, hipMemcpyHostToDevice, ctx->stream));
+  return 0;
+}
+
+// d_skip[b] = 1 for the blocks the writer would store as copy blocks under its "skipBlocks" option
+int kz_skip_block_flags(kz_ctx* ctx, kz_batch& bt, int32_t* d_skip) {
+  int32_t* tab = nullptr;
+  { const int rc = mm_upload_table(ctx, &tab); if (rc) return rc; }
+  KZ_LAUNCH(ctx, KID_SKIP_DECIDE, k_skip_decide, dim3(bt.B), dim3(256), bt.buf[bt.cur], bt.stride, bt.d_len, tab, d_skip);
+  KZ_HIP(hipGetLastError());
   return 0;
 }
 

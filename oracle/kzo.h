@@ -133,7 +133,8 @@ int64_t kzo_encode_block(uint64_t transformType, int entropyType, const uint8_t*
                          uint8_t* out, size_t outCap, uint8_t* skipFlagsOut, int* postLenOut);
 int     kzo_decode_block(uint64_t transformType, int entropyType, int blockSize, const uint8_t* in,
                          int64_t nbits, uint8_t* out, int outCap);
-/* _x variants: chkKind 0 none / 1 XXHash32 / 2 XXHash64 block checksum (-x32 / -x64) */
+/* _x variants: chkKind 0 none / 1 XXHash32 / 2 XXHash64 block checksum (-x32 / -x64); encoders: | 0x100 = the writer's
+   "skipBlocks" option (CompressedOutputStream.java:769-788) */
 int64_t kzo_encode_block_x(uint64_t transformType, int entropyType, int chkKind, const uint8_t* data, int n,
                            uint8_t* out, size_t outCap, uint8_t* skipFlagsOut, int* postLenOut);
 int     kzo_decode_block_x(uint64_t transformType, int entropyType, int chkKind, int blockSize, const uint8_t* in,

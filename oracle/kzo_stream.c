@@ -202,12 +202,24 @@ int64_t kzo_encode_block(uint64_t transformType, int entropyType, const uint8_t*
 int64_t kzo_encode_block_x(uint64_t transformType, int entropyType, int chkKind, const uint8_t* data, int n,
                            uint8_t* out, size_t outCap, uint8_t* skipFlagsOut, int* postLenOut) {
   if (n == 0) return 0;
+  const int skipBlocks = (chkKind >> 8) & 1;                     /* bit 8 of chkKind: the writer's "skipBlocks" option */
+  chkKind &= 0xFF;
   uint64_t checksum = 0;
   if (chkKind == 1) checksum = kzo_xxhash32(data, n, 0x4B414E5Au);
   else if (chkKind == 2) checksum = kzo_xxhash64(data, n, 0x4B414E5AULL);
   uint8_t mode = 0;
   int types[8];
   if (n <= 15) { transformType = 0; entropyType = KZO_E_NONE; mode |= 0x80; }   /* :764-767 */
+  else if (skipBlocks) {                                                         /* :769-788 */
+    int skip = kzo_magic_is_compressed(kzo_magic_type(data));
+    if (!skip) {
+      int histo[256];
+      memset(histo, 0, sizeof(histo));
+      for (int i = 0; i < n; i++) histo[data[i]]++;
+      skip = kzo_entropy1024(n, histo) >= 973;                                   /* EntropyUtils.INCOMPRESSIBLE_THRESHOLD */
+    }
+    if (skip) { transformType = 0; entropyType = KZO_E_NONE; mode |= 0x80; }
+  }
   int nb = split_types(transformType, types);
   int required = seq_max_encoded_len(types, nb, n);
   uint8_t* buffer = (uint8_t*)malloc((size_t)required + 64);
@@ -407,7 +419,7 @@ int64_t kzo_compress_x(uint64_t transformType, int entropyType, int blockSize, i
   if (!job.fail) {
     kzo_obs s; kzo_obs_init(&s, (size_t)(n / 2) + 4096);
     uint8_t hdr[40];
-    int hl = kzo_stream_header(transformType, entropyType, blockSize, chkKind, n, hdr);
+    int hl = kzo_stream_header(transformType, entropyType, blockSize, chkKind & 0xFF, n, hdr);
     kzo_obs_write_bytes(&s, hdr, (uint64_t)hl * 8);
     for (int b = 0; b < nblocks; b++) {                            /* :1024-1035 */
       uint64_t written = (uint64_t)bits[b];

@@ -161,11 +161,11 @@ def decode_block(chain, entropy, block_size, stream, nbits, cap):
     return r, out[:max(r, 0)].tobytes()
 
 
-def compress(chain, entropy, block_size, data, jobs=1, checksum=0):
+def compress(chain, entropy, block_size, data, jobs=1, checksum=0, skip_blocks=False):
     a = _u8(data)
     cap = len(a) + len(a) // 4 + 65536
     out = np.zeros(cap, dtype=np.uint8)
-    r = lib().kzo_compress_x(ttype(chain), E[entropy.upper()], block_size, {0: 0, 32: 1, 64: 2}[checksum], a.ctypes.data if len(a) else out.ctypes.data, len(a), out.ctypes.data, cap, jobs)
+    r = lib().kzo_compress_x(ttype(chain), E[entropy.upper()], block_size, {0: 0, 32: 1, 64: 2}[checksum] | (0x100 if skip_blocks else 0), a.ctypes.data if len(a) else out.ctypes.data, len(a), out.ctypes.data, cap, jobs)
     if r < 0:
         raise RuntimeError("oracle compress failed %d" % r)
     return out[:r].tobytes()

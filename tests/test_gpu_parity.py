@@ -564,6 +564,35 @@ def test_stream_header_faults_report_reference_codes(ctx):
     assert kz.CompressedInputStream(ctx, good).read(len(data)) == data
 
 
+def test_skip_blocks_option_matches_oracle(ctx):
+    """The writer's "skipBlocks" option (CompressedOutputStream.java:769-788): blocks that start with the magic number
+    of a compressed format, or whose order-0 entropy reaches 0.95 * 8 bits, become copy blocks -- large ones included;
+    the others go through the chain as usual.  Stream identical to the oracle's, and smaller work for the decoder."""
+    rng = np.random.default_rng(31)
+    bs = 65536
+    text = (b"blocks that compress are left alone by the option. " * 2000)[:bs]
+    nearly = bytes(rng.integers(0, 200, bs, dtype=np.uint8))                    # 7.64 bits: just above the threshold
+    below = bytes(rng.integers(0, 150, bs, dtype=np.uint8))                     # 7.23 bits: below it
+    parts = [text, bytes(rng.integers(0, 256, bs, dtype=np.uint8)), b"\x1F\x8B\x08\x00" + text[4:], nearly, below,
+             b"PK\x03\x04" + bytes(rng.integers(0, 4, bs - 4, dtype=np.uint8)), refinputs.multimedia_like(0, bs), text[:7000]]
+    data = b"".join(parts)
+    for chain, ent in (("BWT+RANK+ZRLT", "ANS0"), ("PACK+MM+LZX", "HUFFMAN"), ("LZ", "FPAQ")):
+        for chk in (0, 64):
+            ref = oracle.compress(chain, ent, bs, data, jobs=2, checksum=chk, skip_blocks=True)
+            plain = oracle.compress(chain, ent, bs, data, jobs=2, checksum=chk)
+            assert ref != plain
+            cos = kz.CompressedOutputStream(ctx, chain, ent, bs, checksum=chk, skipBlocks=True)
+            cos.write(data)
+            cos.close()
+            assert cos.output == ref, (chain, ent, chk)
+            assert kz.CompressedInputStream(ctx, ref).read(len(data)) == data
+            assert oracle.decompress(ref, len(data)) == data
+    z = oracle.compress("BWT+RANK+ZRLT", "ANS0", bs, data, skip_blocks=True)
+    modes = [kz.extract_bits(z, off, 8)[0] for off, nb in kz.knz_index(z)["blocks"]]
+    copied = [i for i, m in enumerate(modes) if (m & 0x80) and not (m & 0x10)]   # copy block, not a "transformed copy"
+    assert copied == [1, 2, 3, 5, 6]                # random, gzip magic, 7.64 bits, zip magic, 16-bit samples (noisy low bytes)
+
+
 def test_fuzz_streams_with_pack_dna_mm(ctx):
     """The same randomised parity for the chains that carry the "dataType" entry from stage to stage: PACK / DNA / MM in
     front of LZ, LZX, BWT chains; inputs also drawn from the multimedia-like and alphabet-limited generators."""
