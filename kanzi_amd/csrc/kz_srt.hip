@@ -149,6 +149,52 @@ struct SrtInvLds {
 };
 #define SRT_SYNC() __builtin_amdgcn_wave_barrier()   /* one wave per block: program order suffices, keep the compiler in line */
 
+#define SRT_INV_LOOP(GENERAL) \
+  while (i < count) { \
+    const int32_t cur = bstart[c], end = bend[c]; \
+    const int32_t lim = GENERAL ? min(end, count) : end; \
+    int32_t wb = wbase[c]; \
+    int vc = min(lim, wb + 32) - cur; /* ranks of c available in the cached window */ \
+    if (vc <= 0 && cur < lim) { /* window used up: fetch the next 32 ranks */ \
+      wb = cur; \
+      if (lane < 32) win[c][lane] = (cur + lane < lim) ? s[cur + lane] : (u8)0; \
+      if (lane == 0) wbase[c] = wb; \
+      vc = min(32, lim - cur); \
+    } \
+    if (GENERAL) { if (vc < 0) vc = 0; if (vc == 0 && cur < end) { bad = 1; break; } }   /* the next rank of c lies past the payload */ \
+    const u32 v = (lane < vc) ? (u32)win[c][((u32)(cur - wb) + (u32)lane) & 31u] : 0u; \
+    const uint64_t nz = kz_ballot(v != 0 && lane < vc); \
+    const int z = nz ? (int)__builtin_ctzll(nz) : vc; /* leading zero ranks = c repeats */ \
+    int r = 0; \
+    int emit, consumed; \
+    bool moveC = false, removeC = false; \
+    if (nz) { emit = z + 1; consumed = z + 1; r = __builtin_amdgcn_readlane((int)v, z); moveC = true; } \
+    else if (cur + vc >= end) { emit = vc + 1; consumed = vc; removeC = true; } /* bucket exhausted (:239-248) */ \
+    else { emit = vc; consumed = vc; } /* only zeros in the window, more to come */ \
+    if (emit > count - i) { emit = count - i; moveC = false; removeC = false; } \
+    if (lane < emit) o[i + lane] = (u8)c; \
+    i += emit; \
+    if (lane == 0) bstart[c] = cur + consumed; \
+    if (moveC || (removeC && nbSymbols > 1)) { \
+ /* moveC:   positions 0..r-1 <- 1..r, position r <- c                        (SRT.java:233-237) */ \
+ /* removeC: positions 0..nbSymbols-1 <- 1..nbSymbols, the rest stays          (:242-248) */ \
+      if (removeC) { nbSymbols--; r = nbSymbols; } \
+      const u32 nxt = KZ_DPP_SHL1(list); \
+      const u32 shifted = (list >> 8) | (nxt << 24); \
+      const int jb = 4 * lane; \
+      const int e = r - jb; /* bytes with position < r in this lane */ \
+      const u32 mask = (e <= 0) ? 0u : ((e >= 4) ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (8 * (4 - e)))); \
+      u32 nl = (shifted & mask) | (list & ~mask); \
+      if (moveC && lane == (r >> 2)) { const int sh = 8 * (r & 3); nl = (nl & ~(0xFFu << sh)) | ((u32)c << sh); } \
+      list = nl; \
+      c = (int)(__builtin_amdgcn_readfirstlane((int)list) & 0xFF); \
+    } else if (removeC) { \
+ /* single symbol left with an empty bucket: it repeats to the end (:239-240) */ \
+      for (int k = i + lane; k < count; k += 64) o[k] = (u8)c; \
+      i = count; \
+    } \
+  }
+
 // One wave per block replays SRT.java:178-257 step by step.  It follows the reference on ANY input, not only on
 // well-formed ones: frequencies are Java ints (a 5-byte varint can wrap negative; only freq > 0 counts, :268-273), the
 // three tables start zeroed like the fields of a fresh SRT (absent symbols have an empty bucket at 0), a removal shifts
@@ -207,6 +253,7 @@ __global__ __launch_bounds__(512) void k_srt_inv(const u8* __restrict__ src, u8*
   }
   SRT_SYNC();
   int bad = 0;
+  bool general = false;
   {
     int32_t acc = 0;
     for (int i = 0; i < nbSymbols; i++) {                           // :204-215 (uniform across lanes)
@@ -217,7 +264,9 @@ __global__ __launch_bounds__(512) void k_srt_inv(const u8* __restrict__ src, u8*
       if (lane == 0) { r2s0[first] = (u8)c; bstart[c] = acc + 1; }
       acc = (int32_t)((u32)acc + (u32)freq[c]);
       if (lane == 0) bend[c] = acc;
+      if (acc < 0) general = true;                                 // Java int wrap
     }
+    if (acc != count) general = true;
   }
   SRT_SYNC();
   if (bad) { if (lane == 0) { d_len2[b] = 0; d_flag[b] = 0; } return; }
@@ -235,51 +284,9 @@ __global__ __launch_bounds__(512) void k_srt_inv(const u8* __restrict__ src, u8*
   u32 list = (u32)r2s0[4 * lane] | ((u32)r2s0[4 * lane + 1] << 8) | ((u32)r2s0[4 * lane + 2] << 16) | ((u32)r2s0[4 * lane + 3] << 24);
   int i = 0;
   int c = (int)(__builtin_amdgcn_readfirstlane((int)list) & 0xFF);
-  while (i < count) {
-    const int32_t cur = bstart[c], end = bend[c];
-    const int32_t lim = min(end, count);
-    int32_t wb = wbase[c];
-    int vc = min(lim, wb + 32) - cur;                                 // ranks of c available in the cached window
-    if (vc <= 0 && cur < lim) {                                       // window used up: fetch the next 32 ranks
-      wb = cur;
-      if (lane < 32) win[c][lane] = (cur + lane < lim) ? s[cur + lane] : (u8)0;
-      if (lane == 0) wbase[c] = wb;
-      vc = min(32, lim - cur);
-    }
-    if (vc < 0) vc = 0;
-    if (vc == 0 && cur < end) { bad = 1; break; }                     // the next rank of c lies past the payload
-    const u32 v = (lane < vc) ? (u32)win[c][((u32)(cur - wb) + (u32)lane) & 31u] : 0u;
-    const uint64_t nz = kz_ballot(v != 0 && lane < vc);
-    const int z = nz ? (int)__builtin_ctzll(nz) : vc;                 // leading zero ranks = c repeats
-    int r = 0;
-    int emit, consumed;
-    bool moveC = false, removeC = false;
-    if (nz) { emit = z + 1; consumed = z + 1; r = __builtin_amdgcn_readlane((int)v, z); moveC = true; }
-    else if (cur + vc >= end) { emit = vc + 1; consumed = vc; removeC = true; }           // bucket exhausted (:239-248)
-    else { emit = vc; consumed = vc; }                                 // only zeros in the window, more to come
-    if (emit > count - i) { emit = count - i; moveC = false; removeC = false; }
-    if (lane < emit) o[i + lane] = (u8)c;
-    i += emit;
-    if (lane == 0) bstart[c] = cur + consumed;
-    if (moveC || (removeC && nbSymbols > 1)) {
-      // moveC:   positions 0..r-1 <- 1..r, position r <- c                        (SRT.java:233-237)
-      // removeC: positions 0..nbSymbols-1 <- 1..nbSymbols, the rest stays          (:242-248)
-      if (removeC) { nbSymbols--; r = nbSymbols; }
-      const u32 nxt = KZ_DPP_SHL1(list);
-      const u32 shifted = (list >> 8) | (nxt << 24);
-      const int jb = 4 * lane;
-      const int e = r - jb;                                            // bytes with position < r in this lane
-      const u32 mask = (e <= 0) ? 0u : ((e >= 4) ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (8 * (4 - e))));
-      u32 nl = (shifted & mask) | (list & ~mask);
-      if (moveC && lane == (r >> 2)) { const int sh = 8 * (r & 3); nl = (nl & ~(0xFFu << sh)) | ((u32)c << sh); }
-      list = nl;
-      c = (int)(__builtin_amdgcn_readfirstlane((int)list) & 0xFF);
-    } else if (removeC) {
-      // single symbol left with an empty bucket: it repeats to the end (:239-240)
-      for (int k = i + lane; k < count; k += 64) o[k] = (u8)c;
-      i = count;
-    }
-  }
+  // Well-formed input (frequencies add up to the payload: every bucket ends inside it) takes the tight loop; anything
+  // else the general one, which also watches for buckets that run past the payload.
+  if (general) { SRT_INV_LOOP(1) } else { SRT_INV_LOOP(0) }
   if (lane == 0) { d_len2[b] = bad ? 0 : count; d_flag[b] = bad ? 0 : 1; }
 }
 
