@@ -35,7 +35,6 @@ struct AliasFwd {
   u8* absent;        // [B][256] absent symbols, ascending
   u8* map8;          // [B][256] symbol -> index among the present symbols
   u32* freqs1;       // [B][65536] pair histogram, later the alias table (0x200 | alias for aliased pairs, else 0)
-  int32_t* produced; // [B]
 };
 
 __global__ __launch_bounds__(256) void k_alias_analyze(const u8* __restrict__ srcAll, int64_t stride, const int32_t* __restrict__ d_len,
@@ -337,7 +336,6 @@ int kz_stage_alias_forward(kz_ctx* ctx, kz_batch& bt, int onlyDNA) {
   AliasFwd A;
   A.branch = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   A.n0 = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
-  A.produced = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   A.absent = (u8*)kz_arena_alloc(ctx, (size_t)B * 256);
   A.map8 = (u8*)kz_arena_alloc(ctx, (size_t)B * 256);
   A.freqs1 = (u32*)kz_arena_alloc(ctx, (size_t)B * 65536 * 4);
