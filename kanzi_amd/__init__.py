@@ -114,6 +114,27 @@ ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_err
                "kz_get_kernel_launches", "kz_reset_kernel_timing"]
 
 
+# The reference's compression levels (K/app/BlockCompressor.java:537-573, getTransformAndCodec) as "transforms&entropy".
+# Levels 0-2 consist of stages built here; 3, 5 and 6 are listed with the part that is (their leading TEXT+UTF stages
+# are CPU pre-transforms that are not built: SURVEY 8 f-2); 4 and 7-9 need ROLZ / EXE / LZP / CM / TPAQ.
+LEVELS = {0: "NONE&NONE", 1: "LZX&NONE", 2: "DNA+LZ&HUFFMAN", 3: "TEXT+UTF+PACK+MM+LZX&HUFFMAN", 4: "TEXT+UTF+EXE+PACK+MM+ROLZ&NONE",
+          5: "TEXT+UTF+BWT+RANK+ZRLT&ANS0", 6: "TEXT+UTF+BWT+SRT+ZRLT&FPAQ", 7: "LZP+TEXT+UTF+BWT+LZP&CM",
+          8: "EXE+RLT+TEXT+UTF+DNA&TPAQ", 9: "EXE+RLT+TEXT+UTF+DNA&TPAQX"}
+
+
+def level_chain(level, allow_partial=False):
+    """(transform string, entropy name) of a reference level.  Raises for a level with stages that are not built, unless
+    allow_partial drops the leading TEXT+UTF pair (the result is then NOT level-exact on blocks those stages accept)."""
+    t, e = LEVELS[int(level)].split("&")
+    names = t.split("+")
+    if allow_partial and names[:2] == ["TEXT", "UTF"]:
+        names = names[2:]
+    missing = [n for n in names if n not in TRANSFORM_IDS] + ([e] if e not in ENTROPY_IDS else [])
+    if missing:
+        raise KanziError(3, "level %d needs %s, not built here" % (level, "/".join(missing)))       # ERR_INVALID_CODEC
+    return "+".join(names), e
+
+
 def transform_type(names):
     """'BWT+RANK+ZRLT' or a list of names/ids -> 48-bit id word (TransformFactory.java:132-158)."""
     if isinstance(names, str):
