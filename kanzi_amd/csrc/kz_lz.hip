@@ -112,6 +112,57 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
       }
       pfPos = max(pfPos, srcIdx) + 64;
     }
+    // Literal runs, 64 positions per round trip.  After two literal steps in a row (srcInc >= 2, repIdx == 0) the next
+    // positions are known in advance as long as they are literal steps too: p(k+1) = p(k) + 1 + ((srcInc + k) >> 6).
+    // Lane k tests position p(k) the way the step below does -- repeat candidates, hash-table candidate -- and the
+    // wave consumes the longest prefix of positions that have no 4-byte candidate at all: those are literal steps
+    // whatever minMatch is, and all they do is store their position in the table (:368-371).  The first position with
+    // a candidate (or past srcEnd) is left to the full step.  A lane's table entry is stale if an earlier lane of the
+    // batch has the same hash: its candidate is then that lane's position (match-any on the hash).
+    if (srcInc >= 2) {
+      const u32 stp = 1u + ((u32)(srcInc + lane) >> 6);
+      const u32 incl = kz_wave_incl_sum(stp);
+      const int pk = srcIdx + (int)(incl - stp);
+      const bool in = pk < srcEnd;
+      u64 ownk = 0; int hk = 0, r0 = 0, mr = 0, rA = 0, rB = 0;
+      u32 wAk = 0, wBk = 0, cw = 0;
+      if (in) {
+        ownk = lz_le64(src + pk);
+        hk = (int)(((ownk << 24) * LZ_SEED) >> (extra ? 45 : 48));
+        r0 = hashes[hk];
+        mr = max(pk - maxDist, 0);
+        rA = pk + 1 - repd0; rB = pk + 1 - repd1;
+        wAk = lz_le32(src + max(rA, 0)); wBk = lz_le32(src + max(rB, 0));
+        cw = lz_le32(src + r0);
+      }
+      const u32 own0k = (u32)ownk, own1k = (u32)(ownk >> 8);
+      uint64_t peers = kz_ballot(in);
+      const int hbits = extra ? 19 : 16;
+      for (int bb = 0; bb < hbits; bb++) {
+        const uint64_t m = kz_ballot(((hk >> bb) & 1) != 0);
+        peers &= ((hk >> bb) & 1) ? m : ~m;
+      }
+      const uint64_t earlier = peers & kz_lanemask_lt();
+      {                                                              // the latest earlier position with this hash
+        // (the shuffles run with every lane active: a lane that is masked off supplies nothing to ds_bpermute)
+        const int j = earlier ? 63 - (int)__builtin_clzll(earlier) : lane;
+        const int pj = __shfl(pk, j, 64);
+        const u32 oj = (u32)__shfl((int)own0k, j, 64);
+        if (earlier) { r0 = pj; cw = oj; }
+      }
+      const bool stop = !in || ((rA > mr) && (wAk == own1k)) || ((rB > mr) && (wBk == own1k)) || ((r0 > mr) && (cw == own0k));
+      const uint64_t sm = kz_ballot(stop);
+      const int f = sm ? (int)__builtin_ctzll(sm) : 64;
+      if (f > 0) {
+        const uint64_t consumed = (f == 64) ? ~0ULL : ((1ULL << f) - 1ULL);
+        const uint64_t later = peers & consumed & ~(kz_lanemask_lt() | (1ULL << lane));
+        if (lane < f && later == 0) hashes[hk] = pk;                 // the highest position of equal hashes wins, as in order
+        LZ_ORDER();
+        srcIdx = (f < 64) ? __builtin_amdgcn_readlane(pk, f & 63) : (__builtin_amdgcn_readlane(pk, 63) + (int)__builtin_amdgcn_readlane((int)stp, 63));
+        srcInc += f;
+        continue;
+      }
+    }
     int bestLen = 0;
     // every load whose address is known up front is issued before the dependent hash-table access: the two repeat
     // candidates and the current bytes travel together, the chain is then bytes -> table entry -> candidate
