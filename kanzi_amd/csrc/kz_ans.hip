@@ -35,6 +35,8 @@ __device__ __forceinline__ void bw_put(BitW& w, u32 v, int count) {
   }
 }
 
+typedef u16 __attribute__((aligned(1))) ans_u16_unaligned;
+
 // =================================================================================================
 // encode: one wave per chunk
 __global__ __launch_bounds__(64) void k_ans_enc_chunk(const u8* __restrict__ src, int64_t stride,
@@ -60,11 +62,7 @@ __global__ __launch_bounds__(64) void k_ans_enc_chunk(const u8* __restrict__ src
   __shared__ u32 hist[256];
   __shared__ u16 nfreq[256];
   __shared__ u8 alpha[256];
-  __shared__ u32 symXmax[256];
-  __shared__ u32 symBias[256];
-  __shared__ u32 symInv[256];
-  __shared__ u16 symCmpl[256];
-  __shared__ u8 symShift[256];
+  __shared__ uint4 symTab[256];                                 // {xmax, reciprocal, bias, cmpl | shift << 16}: one 16-byte LDS read per symbol
   __shared__ u8 data[ANS_CHUNK];
   __shared__ u32 hbuf[ANS_HDR_BYTES / 4];                       // header bits are assembled in LDS
 
@@ -180,15 +178,13 @@ __global__ __launch_bounds__(64) void k_ans_enc_chunk(const u8* __restrict__ src
     if (present[q]) {
       u32 freq = fv;
       if (freq >= scale) freq = scale - 1;
-      symXmax[s] = ((ANS_TOP >> ANS_LR) << 16) * freq;
-      symCmpl[s] = (u16)(scale - freq);
-      if (freq < 2) { symInv[s] = 0xFFFFFFFFu; symShift[s] = 32; symBias[s] = cumFreq + scale - 1; }
+      const u32 xmaxv = ((ANS_TOP >> ANS_LR) << 16) * freq;
+      const u32 cmplv = scale - freq;
+      if (freq < 2) symTab[s] = make_uint4(xmaxv, 0xFFFFFFFFu, cumFreq + scale - 1, cmplv | (32u << 16));
       else {
         int shift = 0;
         while (freq > (1u << shift)) shift++;
-        symInv[s] = (u32)((((1ULL << (shift + 31)) + freq - 1) / freq) & 0xFFFFFFFFULL);
-        symShift[s] = (u8)(32 + shift - 1);
-        symBias[s] = cumFreq;
+        symTab[s] = make_uint4(xmaxv, (u32)((((1ULL << (shift + 31)) + freq - 1) / freq) & 0xFFFFFFFFULL), cumFreq, cmplv | ((u32)(32 + shift - 1) << 16));
       }
     }
   }
@@ -245,14 +241,18 @@ __global__ __launch_bounds__(64) void k_ans_enc_chunk(const u8* __restrict__ src
   if (lane < 4) {
     for (int i = end4 - 1; i > 0; i -= 4) {
       const u32 c = data[i - lane];
-      const u32 xmax = symXmax[c];
-      const bool x = st >= xmax;                                    // (int) compare: both < 2^31
+      const uint4 sy = symTab[c];
+      const bool x = st >= sy.x;                                    // (int) compare: both < 2^31
       const uint64_t bal = kz_ballot(x) & 0xFULL;
       const int pre = (int)__popcll(bal & kz_lanemask_lt());
-      if (x) { const int e = idx - 2 * pre; scr[e] = (u8)st; scr[e - 1] = (u8)(st >> 8); st >>= 16; }
+      if (x) {                                                      // scr[e] = low byte, scr[e - 1] = next byte: one 2-byte store
+        const int e = idx - 2 * pre;
+        *(ans_u16_unaligned*)(scr + e - 1) = (u16)(((st & 0xFFu) << 8) | ((st >> 8) & 0xFFu));
+        st >>= 16;
+      }
       idx -= 2 * (int)__popcll(bal);
-      const u32 q = (u32)(((u64)st * (u64)symInv[c]) >> symShift[c]);
-      st = st + symBias[c] + q * (u32)symCmpl[c];
+      const u32 q = (u32)(((u64)st * (u64)sy.y) >> (sy.w >> 16));
+      st = st + sy.z + q * (sy.w & 0xFFFFu);
     }
   }
   idx = __shfl(idx, 0, 64);
@@ -481,6 +481,7 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
   __shared__ u16 cumf[256];
   __shared__ u8 alpha[256];
   __shared__ u8 f2s[4096];
+  __shared__ u32 fcTab[256];
   __shared__ int sh_asz, sh_lr, sh_bad;
   __shared__ u64 sh_pos;
   for (int i = lane; i < 256; i += 64) freq[i] = 0;
@@ -538,6 +539,8 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
     const u32 fv = freq[q * 64 + lane];
     const u32 inc = kz_wave_incl_sum(fv);
     cumf[q * 64 + lane] = (u16)(cum + inc - fv);
+    { u32 fq = fv; if (fq >= (1u << lr)) fq = (1u << lr) - 1u;                 // Symbol.reset mirror :576-579
+      fcTab[q * 64 + lane] = fq | ((cum + inc - fv) << 16); }
     cum += __shfl(inc, 63, 64);
   }
   __syncthreads();
@@ -578,8 +581,8 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
         cur = (u32)lo;
       }
       o[start + i + lane] = (u8)cur;
-      u32 fq = freq[cur]; if (fq >= (1u << lr)) fq = (1u << lr) - 1u;         // Symbol.reset mirror :576-579
-      st = fq * (st >> lr) + (st & mask) - (u32)cumf[cur];
+      const u32 fc = fcTab[cur];                                              // freq | cum << 16: one LDS read
+      st = (fc & 0xFFFFu) * (st >> lr) + (st & mask) - (fc >> 16);
       const bool need = (int)st < (int)ANS_TOP;
       const uint64_t bal = kz_ballot(need) & 0xFULL;
       if (need) {
