@@ -481,7 +481,6 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
   __shared__ u16 cumf[256];
   __shared__ u8 alpha[256];
   __shared__ u8 f2s[4096];
-  __shared__ u32 fcTab[256];
   __shared__ int sh_asz, sh_lr, sh_bad;
   __shared__ u64 sh_pos;
   for (int i = lane; i < 256; i += 64) freq[i] = 0;
@@ -539,8 +538,6 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
     const u32 fv = freq[q * 64 + lane];
     const u32 inc = kz_wave_incl_sum(fv);
     cumf[q * 64 + lane] = (u16)(cum + inc - fv);
-    { u32 fq = fv; if (fq >= (1u << lr)) fq = (1u << lr) - 1u;                 // Symbol.reset mirror :576-579
-      fcTab[q * 64 + lane] = fq | ((cum + inc - fv) << 16); }
     cum += __shfl(inc, 63, 64);
   }
   __syncthreads();
@@ -581,8 +578,8 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
         cur = (u32)lo;
       }
       o[start + i + lane] = (u8)cur;
-      const u32 fc = fcTab[cur];                                              // freq | cum << 16: one LDS read
-      st = (fc & 0xFFFFu) * (st >> lr) + (st & mask) - (fc >> 16);
+      u32 fq = freq[cur]; if (fq >= (1u << lr)) fq = (1u << lr) - 1u;         // Symbol.reset mirror :576-579
+      st = fq * (st >> lr) + (st & mask) - (u32)cumf[cur];
       const bool need = (int)st < (int)ANS_TOP;
       const uint64_t bal = kz_ballot(need) & 0xFULL;
       if (need) {
