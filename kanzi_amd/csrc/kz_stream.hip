@@ -348,8 +348,15 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
     }
     if (pending) done = true;
     if (cnt == 0) break;
+    {
+      // Blocks that start past the end of the destination cannot be stored: that is this interface's fault to report
+      // (ERR_WRITE_FILE), but only if every block before them decodes -- the reader reports the first failing block.
+      const int64_t room = dstCap - produced;
+      const int64_t fit = (room <= 0) ? 0 : (room + blockSize - 1) / blockSize;
+      if (fit < cnt) { cnt = (int)fit; pending = -KZ_ERR_WRITE_FILE; done = true; }
+      if (cnt == 0) break;
+    }
     parallel_blocks(cnt, [&](int i) { HostBitsIn t = bs; t.pos = starts[i]; t.error = false; t.getBytes(inbuf.get() + (size_t)i * iS, (uint64_t)bits[i]); });
-    if (produced + (int64_t)cnt * blockSize > dstCap + blockSize) return -KZ_ERR_WRITE_FILE;
     // decode into a temporary when the tail would overflow dst
     const int64_t room = dstCap - produced;
     if (room >= (int64_t)cnt * blockSize) {

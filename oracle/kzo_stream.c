@@ -281,8 +281,16 @@ int kzo_decode_block(uint64_t transformType, int entropyType, int blockSize, con
   return kzo_decode_block_x(transformType, entropyType, 0, blockSize, in, nbits, out, outCap);
 }
 
+static int decode_block_impl(uint64_t transformType, int entropyType, int chkKind, int blockSize, const uint8_t* in,
+                             int64_t nbits, uint8_t* out, int outCap, int headerOnly);
 int kzo_decode_block_x(uint64_t transformType, int entropyType, int chkKind, int blockSize, const uint8_t* in,
                        int64_t nbits, uint8_t* out, int outCap) {
+  return decode_block_impl(transformType, entropyType, chkKind, blockSize, in, nbits, out, outCap, 0);
+}
+/* headerOnly: the version 7 block header is parsed and verified on the shared stream before the payload is read
+   (CompressedInputStream.java:1142-1170), so its faults come before a truncated payload's */
+static int decode_block_impl(uint64_t transformType, int entropyType, int chkKind, int blockSize, const uint8_t* in,
+                             int64_t nbits, uint8_t* out, int outCap, int headerOnly) {
   if (nbits < 8) return -2;                                      /* ERR_BLOCK_SIZE :1027-1028 */
   kzo_ibs is; kzo_ibs_init(&is, in, (uint64_t)nbits);
   int types[8];
@@ -312,6 +320,7 @@ int kzo_decode_block_x(uint64_t transformType, int entropyType, int chkKind, int
     const int64_t checksumSize = chkKind == 2 ? 8 : (chkKind == 1 ? 4 : 0);
     if ((nbits + 7) >> 3 > (int64_t)preLen + headerSize + checksumSize) return -2;
   }
+  if (headerOnly) return 0;
   if (preLen == 0) return 0;
   uint64_t checksum1 = 0;
   if (chkKind == 1) checksum1 = kzo_ibs_read(&is, 32); else if (chkKind == 2) checksum1 = kzo_ibs_read(&is, 64);   /* :1256-1262 */
@@ -329,7 +338,8 @@ int kzo_decode_block_x(uint64_t transformType, int entropyType, int chkKind, int
       /* checksum first (:1349-1363), then the reader's "decoded > blockSize" test (:756-759) */
       if (chkKind == 1 && (uint32_t)checksum1 != kzo_xxhash32(tmp, r, 0x4B414E5Au)) ret = -19;      /* ERR_CRC_CHECK */
       else if (chkKind == 2 && checksum1 != kzo_xxhash64(tmp, r, 0x4B414E5AULL)) ret = -19;
-      else if (r > blockSize || r > outCap) ret = -13;                                            /* ERR_PROCESS_BLOCK */
+      else if (r > blockSize) ret = -13;                                                         /* ERR_PROCESS_BLOCK */
+      else if (r > outCap) ret = -12;                                                            /* destination too small (ERR_WRITE_FILE) */
       else { memcpy(out, tmp, (size_t)r); ret = r; }
     }
     free(tmp);
@@ -453,7 +463,10 @@ static void* dec_worker(void* arg) {
     if (b >= j->nblocks) break;
     int64_t off = (int64_t)b * j->blockSize;
     int64_t cap = j->dstCap - off; if (cap > j->blockSize) cap = j->blockSize;
-    if (cap < 0) { j->fail = 1; continue; }
+    if (cap <= 0 && j->bits[b] > 0) {                              /* no room left: only matters if every block before decodes */
+      int hc = decode_block_impl(j->transformType, j->entropyType, j->chkKind, j->blockSize, j->ins[b], j->bits[b], NULL, 0, 1);
+      j->lens[b] = hc < 0 ? hc : -12; j->fail = 1; continue;
+    }
     int r = kzo_decode_block_x(j->transformType, j->entropyType, j->chkKind, j->blockSize, j->ins[b], j->bits[b], j->dst + off, (int)cap);
     j->lens[b] = r;
     if (r < 0) j->fail = 1;
@@ -492,24 +505,44 @@ int64_t kzo_decompress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstC
   int capBlocks = 1024, nblocks = 0;
   uint8_t** ins = (uint8_t**)malloc(sizeof(uint8_t*) * (size_t)capBlocks);
   int64_t* bits = (int64_t*)malloc(sizeof(int64_t) * (size_t)capBlocks);
-  int bad = 0;
+  int bad = 0, badCode = -11;
   for (;;) {
     int lr = (int)kzo_ibs_read(&s, 5) + 3;
     uint64_t read = kzo_ibs_read(&s, lr);
     if (s.error) { bad = 1; break; }
     if (read == 0) break;
+    const uint64_t startPos = s.pos;
     if (nblocks == capBlocks) {
       capBlocks *= 2;
       ins = (uint8_t**)realloc(ins, sizeof(uint8_t*) * (size_t)capBlocks);
       bits = (int64_t*)realloc(bits, sizeof(int64_t) * (size_t)capBlocks);
     }
+    if (read > s.nbits - startPos) {                               /* stream ends inside this block: header faults first, else ERR_READ_FILE */
+      badCode = -11;
+      const uint64_t have = s.nbits - startPos;                    /* bits of the block that exist */
+      if (have >= 8) {
+        uint8_t hb[16];
+        memset(hb, 0, sizeof(hb));
+        kzo_ibs_read_bytes(&s, hb, have < 64 ? have : 64);
+        int tt[8];
+        const uint8_t mode = hb[0];
+        int hasSkip = 0;
+        if (mode & 0x80) { if ((mode & 0x10) && split_types(transformType, tt) > 4) hasSkip = 1; }
+        else if (mode & 0x10) hasSkip = 1;
+        const uint64_t headerBits = 8ULL * (uint64_t)(1 + hasSkip + 1 + ((mode >> 5) & 3) + 1);
+        if (read < headerBits || have >= headerBits) {             /* the header is whole (or the declared length is too short for one) */
+          int hc = decode_block_impl(transformType, entropyType, chkKind, blockSize, hb, (int64_t)read, NULL, 0, 1);
+          if (hc < 0) badCode = hc;
+        }
+      }
+      bad = 1; break;
+    }
     ins[nblocks] = (uint8_t*)malloc((size_t)((read + 7) >> 3) + 8);
     kzo_ibs_read_bytes(&s, ins[nblocks], read);
-    if (s.error) { free(ins[nblocks]); bad = 1; break; }           /* stream ends inside this block: it is not decoded */
     bits[nblocks] = (int64_t)read;
     nblocks++;
   }
-  int64_t ret = -11;                                               /* ERR_READ_FILE: stream ends inside a block */
+  int64_t ret = badCode;                                           /* stream ends inside a block */
   {
     int* lens = (int*)calloc((size_t)nblocks + 1, sizeof(int));
     pthread_mutex_t mu; pthread_mutex_init(&mu, NULL);
@@ -528,7 +561,7 @@ int64_t kzo_decompress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstC
         if (ret != (int64_t)b * blockSize && lens[b] > 0) memmove(dst + ret, dst + (int64_t)b * blockSize, (size_t)lens[b]);
         ret += lens[b];
       }
-      if (bad && ret >= 0) ret = -11;                              /* every whole block decoded; the fault is the truncated one after them */
+      if (bad && ret >= 0) ret = badCode;                          /* every whole block decoded; the fault is the truncated one after them */
     } else {                                                       /* code of the first failing block, as the reader would surface it */
       ret = -13;
       for (int b = 0; b < nblocks; b++) if (lens[b] < 0) { ret = lens[b]; break; }
