@@ -513,14 +513,19 @@ __global__ __launch_bounds__(64) void k_huf_dec_chunk(const u8* __restrict__ in,
   huf_canonical(sz, cd);
   for (int i = lane; i < (1 << HUF_MAXLEN); i += 64) table[i] = 7;      // :165-166 default
   __syncthreads();
+  // Code lengths that over-subscribe the code space give canonical codes past the table: the reference dies on
+  // table[idx] there (buildDecodingTables :183-186) -> the block fails; nothing is written out of range here.
+  bool over = false;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     if (!sz[q]) continue;
     const u16 val = (u16)((sz[q] << 8) | (u32)(q * 64 + lane));
-    const int idx = (int)(cd[q] << (HUF_MAXLEN - sz[q]));
-    const int cnt = 1 << (HUF_MAXLEN - sz[q]);
-    for (int k = 0; k < cnt; k++) table[idx + k] = val;
+    const u32 idx = cd[q] << (HUF_MAXLEN - sz[q]);
+    const u32 cnt = 1u << (HUF_MAXLEN - sz[q]);
+    if (idx >= (1u << HUF_MAXLEN) || idx + cnt > (1u << HUF_MAXLEN)) { over = true; continue; }
+    for (u32 k = 0; k < cnt; k++) table[idx + k] = val;
   }
+  if (kz_ballot(over)) { if (lane == 0) atomicExch(&D.status[b], -KZ_ERR_PROCESS_BLOCK); return; }
   __syncthreads();
   pos = sh_pos;
   u32 nbq[4];

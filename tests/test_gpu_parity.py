@@ -548,6 +548,20 @@ def test_entropy_decoders_follow_the_reference_on_corrupted_input(ctx, ent):
                 assert bytes(buf) == o, (ent, src_kind, trial)
 
 
+def test_huffman_oversubscribed_code_lengths_fail_cleanly(ctx):
+    """A Huffman header whose code lengths over-subscribe the code space (found by tools/explore_stage_garbage.py; the
+    fixture is that corrupted payload): the reference dies on the decoding-table index (HuffmanDecoder.java:183-186) and
+    the block fails; the decoder here must report failure too -- it once wrote past its table instead."""
+    bad = open(os.path.join(os.path.dirname(__file__), "golden", "huffman_oversubscribed_lengths.bin"), "rb").read()
+    r, _, _ = oracle.entropy_decode("HUFFMAN", bad, 190574, 40000)
+    assert r != 40000
+    buf = np.zeros(40000, dtype=np.uint8)
+    assert kz.HuffmanDecoder(ctx, bad, 190574).decode(buf, 0, 40000) != 40000
+    data = datagen.block(0, 40000).tobytes()                                   # and the context still works
+    good, nbits = oracle.entropy_encode("HUFFMAN", data)
+    assert kz.HuffmanDecoder(ctx, good, nbits).decode(buf, 0, 40000) == 40000 and bytes(buf) == data
+
+
 def test_stream_header_faults_report_reference_codes(ctx):
     """Stream-header faults surface with the code and in the order of CompressedInputStream.readHeader
     (CompressedInputStream.java:363-478, Error.java:24-43), the same as the oracle reports."""

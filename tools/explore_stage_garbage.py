@@ -11,7 +11,8 @@ def mk(name):
     if name == "MTFT": return kz.SBRT(ctx, 1)
     if name == "LZ": return kz.LZCodec(ctx, kz.LZ_TYPE)
     if name == "LZX": return kz.LZCodec(ctx, kz.LZX_TYPE)
-    return {"BWT": kz.BWTBlockCodec, "ZRLT": kz.ZRLT, "SRT": kz.SRT}[name](ctx)
+    if name in ("PACK", "DNA"): return kz.AliasCodec(ctx, onlyDNA=(name == "DNA"))
+    return {"BWT": kz.BWTBlockCodec, "ZRLT": kz.ZRLT, "SRT": kz.SRT, "MM": kz.FSDCodec}[name](ctx)
 
 DEC = {"ANS0": kz.ANSRangeDecoder, "HUFFMAN": kz.HuffmanDecoder, "FPAQ": kz.FPAQDecoder}
 
@@ -40,10 +41,14 @@ def mutate(rng, good, kind):
 
 stats = collections.Counter()
 N = int(os.environ.get("N", "20000"))
-rng = np.random.default_rng(123)
-for name in ["SRT", "ZRLT", "RANK", "MTFT", "BWT", "LZ", "LZX"]:
+import refinputs
+rng = np.random.default_rng(int(os.environ.get("SEED", "123")))
+alias = [d for _, d in refinputs.alias_inputs()]
+for name in ["SRT", "ZRLT", "RANK", "MTFT", "BWT", "LZ", "LZX", "MM", "PACK"]:
     for src_kind in range(8):
         data = datagen.block(src_kind, N).tobytes()
+        if name == "MM": data = refinputs.multimedia_like(src_kind % 5, N, seed=src_kind)
+        if name == "PACK": data = alias[(0, 1, 5, 9, 11, 13, 15, 17)[src_kind]][:N]
         pre = data
         if name in ("SRT", "RANK", "MTFT", "ZRLT"):
             ok, pre = oracle.transform_forward("BWT", data)
@@ -54,6 +59,10 @@ for name in ["SRT", "ZRLT", "RANK", "MTFT", "BWT", "LZ", "LZX"]:
         for trial in range(40):
             bad = mutate(rng, good, trial % 8)
             ok_o, o = oracle.transform_inverse(name, bad, cap)
+            if os.environ.get("TRACE"):
+                os.makedirs("gpurun_out", exist_ok=True)
+                open("gpurun_out/trace_last.bin", "wb").write(bad)
+                open("gpurun_out/trace_last.txt", "w").write("%s src %d trial %d kind %d cap %d len %d ok_o %d\n" % (name, src_kind, trial, trial % 8, cap, len(bad), ok_o))
             src = kz.SliceByteArray(np.frombuffer(bad, dtype=np.uint8).copy(), len(bad), 0)
             dst = kz.SliceByteArray(np.zeros(cap, dtype=np.uint8), cap, 0)
             try: ok_p = mk(name).inverse(src, dst); p = bytes(dst.array[:dst.index])
@@ -72,6 +81,10 @@ for ent in ["ANS0", "HUFFMAN", "FPAQ"]:
             bad = mutate(rng, good, trial % 8)
             nb = min(nbits, len(bad) * 8)
             r, o, used = oracle.entropy_decode(ent, bad, nb, len(data))
+            if os.environ.get("TRACE"):
+                os.makedirs("gpurun_out", exist_ok=True)
+                open("gpurun_out/trace_last.bin", "wb").write(bad)
+                open("gpurun_out/trace_last.txt", "w").write("%s src %d trial %d kind %d nb %d count %d r %d\n" % (ent, src_kind, trial, trial % 8, nb, len(data), r))
             ok_o = (r == len(data))
             buf = np.zeros(len(data), dtype=np.uint8)
             try: ok_p = DEC[ent](ctx, bad, nb).decode(buf, 0, len(data)) == len(data)
