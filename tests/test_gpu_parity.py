@@ -548,6 +548,39 @@ def test_entropy_decoders_follow_the_reference_on_corrupted_input(ctx, ent):
                 assert bytes(buf) == o, (ent, src_kind, trial)
 
 
+@pytest.mark.parametrize("chain,ent", [("BWT+RANK+ZRLT", "ANS0"), ("BWT+SRT+ZRLT", "FPAQ"), ("PACK+MM+LZX", "HUFFMAN")])
+def test_batched_decode_isolates_corrupted_blocks(ctx, chain, ent):
+    """kz_decode_blocks on a batch where a few blocks are corrupted: every block gets the status (or the bytes) the
+    oracle gives that block alone, and the clean neighbours decode as if nothing happened."""
+    rng = np.random.default_rng(17)
+    bs, B = 65536, 64
+    inp = np.zeros((B, bs), dtype=np.uint8)
+    for b in range(B):
+        inp[b] = datagen.block(b, bs) if b % 3 else np.frombuffer(refinputs.multimedia_like(b % 5, bs, seed=b), dtype=np.uint8)
+    ostride = kz.max_block_stream_bytes(bs)
+    out = np.zeros((B, ostride), dtype=np.uint8)
+    res = kz.encode_blocks(ctx, chain, ent, inp, bs, np.full(B, bs, dtype=np.int32), out, ostride)
+    bits = np.array([r.bits for r in res], dtype=np.int64)
+    for rnd in range(3):
+        bad = out.copy()
+        hit = set(int(x) for x in rng.integers(0, B, 8))
+        for b in hit:
+            nby = int((bits[b] + 7) // 8)
+            row = (refinputs.corrupt(rng, bytes(bad[b, :nby]), int(rng.integers(0, 8))) + bytes(nby))[:nby]
+            bad[b, :nby] = np.frombuffer(row, dtype=np.uint8)
+        dec = np.zeros((B, bs), dtype=np.uint8)
+        r2 = kz.decode_blocks(ctx, chain, ent, bs, bad, ostride, bits, dec, bs)
+        for b in range(B):
+            nby = int((bits[b] + 7) // 8)
+            ro, oo = oracle.decode_block(chain, ent, bs, bytes(bad[b, :nby]), int(bits[b]), bs)
+            if ro >= 0:
+                assert r2[b].status == 0 and r2[b].length == ro and bytes(dec[b, :ro]) == oo, (chain, rnd, b, b in hit)
+            else:
+                assert r2[b].status == ro, (chain, rnd, b, b in hit, ro, r2[b].status)
+            if b not in hit:
+                assert ro == bs and bytes(dec[b]) == bytes(inp[b])
+
+
 def test_huffman_oversubscribed_code_lengths_fail_cleanly(ctx):
     """A Huffman header whose code lengths over-subscribe the code space (found by tools/explore_stage_garbage.py; the
     fixture is that corrupted payload): the reference dies on the decoding-table index (HuffmanDecoder.java:183-186) and
