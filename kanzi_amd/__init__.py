@@ -330,9 +330,7 @@ class _EntropyEncoder:
 
     def encode(self, block, blkptr, count):
         """EntropyEncoder.encode: returns count on success. Output bit string appended to self.bits."""
-        if count == 0:
-            return 0
-        s = np.ascontiguousarray(block[blkptr:blkptr + count], dtype=np.uint8)
+        s = np.ascontiguousarray(block[blkptr:blkptr + count], dtype=np.uint8) if count else np.zeros(1, dtype=np.uint8)
         cap = int(self.ctx.lib.kz_max_block_stream_bytes(count))
         out = np.zeros(cap, dtype=np.uint8)
         nbits = self.ctx.lib.kz_entropy_encode(self.ctx.h, self.TYPE, s.ctypes.data, count, out.ctypes.data, cap)

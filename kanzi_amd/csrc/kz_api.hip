@@ -851,7 +851,15 @@ extern "C" int32_t kz_transform_inverse(kz_ctx* ctx, uint32_t type, const uint8_
 extern "C" int64_t kz_entropy_encode(kz_ctx* ctx, uint32_t type, const uint8_t* src, int32_t n, uint8_t* out, int64_t outCapBytes) {
   if (!ctx || !src || !out || n < 0) return -KZ_ERR_INVALID_PARAM;
   if (!entropy_supported((int)type)) return -KZ_ERR_INVALID_CODEC;
-  if (n == 0) return 0;
+  if (n == 0) {
+    // encode() of nothing writes nothing; FPAQ's dispose() still flushes its 56-bit low register, all zero but the
+    // 24 padding ones (FPAQEncoder.java:232-238): the call stands for encode + dispose
+    if (type != KZ_E_FPAQ) return 0;
+    if (outCapBytes < 7) return -KZ_ERR_INVALID_PARAM;
+    const uint8_t flush[7] = {0, 0, 0, 0, 0xFF, 0xFF, 0xFF};
+    memcpy(out, flush, 7);
+    return 56;
+  }
   KZ_HIP(hipSetDevice(ctx->device));
   Pipe P;
   const int64_t oS = kz_max_block_stream_bytes(n);
