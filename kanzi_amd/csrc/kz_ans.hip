@@ -63,7 +63,10 @@ __global__ __launch_bounds__(64) void k_ans_enc_chunk(const u8* __restrict__ src
   __shared__ u16 nfreq[256];
   __shared__ u8 alpha[256];
   __shared__ uint4 symTab[256];                                 // {xmax, reciprocal, bias, cmpl | shift << 16}: one 16-byte LDS read per symbol
-  __shared__ u8 data[ANS_CHUNK];
+  // the chunk's symbols are read from global memory twice (histogram, then the coding loop: 4 consecutive bytes per
+  // step, L1 hits): a 16 KiB LDS copy limited the kernel to 6 waves per CU, and the 4-lane coding loop needs many
+  // waves per SIMD to fill the issue slots
+  const u8* data = blk + start;
   __shared__ u32 hbuf[ANS_HDR_BYTES / 4];                       // header bits are assembled in LDS
 
   for (int i = lane; i < 256; i += 64) hist[i] = 0;
@@ -77,7 +80,6 @@ __global__ __launch_bounds__(64) void k_ans_enc_chunk(const u8* __restrict__ src
     for (int k = 0; k < 4; k++) {
       const bool valid = k < nb;
       const u32 c = (w >> (8 * k)) & 0xFF;
-      if (valid) data[i + k] = (u8)c;
       const uint64_t peers = kz_match8(c, valid);
       if (valid && (peers & kz_lanemask_lt()) == 0) atomicAdd(&hist[c], (u32)__popcll(peers));
     }
