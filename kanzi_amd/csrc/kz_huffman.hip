@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void k_huf_enc_chunk(const u8* __restrict__ src
   __shared__ u32 firstCode[16];
   __shared__ u32 hbuf[ANS_HDR_BYTES / 4];
   __shared__ u32 fragbuf[(4096 * HUF_MAXLEN) / 32 + 8];
-  __shared__ u8 data[ANS_CHUNK];
+  const u8* data = blk;                 // symbols are re-read from global memory (L1): a 16 KiB LDS copy halves the waves per CU
   __shared__ int sh_n, sh_maxlen;
   __shared__ u32 sh_nb[4];
 
@@ -134,7 +134,6 @@ __global__ __launch_bounds__(64) void k_huf_enc_chunk(const u8* __restrict__ src
     for (int k = 0; k < 4; k++) {
       const bool valid = k < nb;
       const u32 c = (w >> (8 * k)) & 0xFF;
-      if (valid) data[i + k] = (u8)c;
       const uint64_t peers = kz_match8(c, valid);
       if (valid && (peers & kz_lanemask_lt()) == 0) atomicAdd(&hist[c], (u32)__popcll(peers));
     }
