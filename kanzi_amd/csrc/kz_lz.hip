@@ -173,7 +173,13 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
     const u32 own1 = lz_le32(src + srcIdx1);
     const u32 wA = lz_le32(src + max(refA, 0)), wB = lz_le32(src + max(refB, 0));
     const int h0 = (int)(((own << 24) * LZ_SEED) >> (extra ? 45 : 48));
+    // the lazy probes' table entries (positions srcIdx+1, +2: their 5 hashed bytes are inside `own`) are requested
+    // together with ref0 and patched below for the stores that come in between
+    const int h1e = (int)((((own >> 8) << 24) * LZ_SEED) >> (extra ? 45 : 48));
+    const int h2e = (int)((((own >> 16) << 24) * LZ_SEED) >> (extra ? 45 : 48));
     const int ref0 = hashes[h0];
+    const int r1e = hashes[h1e];
+    const int r2e = extra ? hashes[h2e] : 0;
     LZ_ORDER();
     if (w) hashes[h0] = srcIdx;
     int ref = refA;
@@ -188,8 +194,8 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
       if ((ref > minRef) && (lz_le32(src + ref) == (u32)own)) bestLen = lz_find_match(src, srcIdx, ref, min(srcEnd - srcIdx, LZ_MAX_MATCH));
       if (bestLen < minMatch) { srcIdx = srcIdx1 + (srcInc >> 6); srcInc++; repIdx = 0; LZ_ORDER(); continue; }
       if ((ref != srcIdx - repd0) && (ref != srcIdx - repd1)) {
-        const int h1 = lz_hash(src + srcIdx1, extra);
-        const int ref1 = hashes[h1];
+        const int h1 = h1e;
+        const int ref1 = (h1 == h0) ? srcIdx : r1e;                 // hashes[h0] = srcIdx was stored since the early read
         LZ_ORDER();
         if (w) hashes[h1] = srcIdx1;
         if ((ref1 > minRef + 1) && !lz_diff4(src, ref1 + bestLen - 3, srcIdx1 + bestLen - 3)) {
@@ -198,9 +204,9 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
         }
         if (extra) {
           const int srcIdx2 = srcIdx1 + 1;
-          const int h2 = lz_hash(src + srcIdx2, extra);
+          const int h2 = h2e;
           LZ_ORDER();
-          const int ref2 = hashes[h2];
+          const int ref2 = (h2 == h1) ? srcIdx1 : ((h2 == h0) ? (srcIdx1 - 1) : r2e);   // stores at h0 and h1 since the early read
           LZ_ORDER();
           if (w) hashes[h2] = srcIdx2;
           if ((ref2 > minRef + 2) && !lz_diff4(src, ref2 + bestLen - 3, srcIdx2 + bestLen - 3)) {
