@@ -369,7 +369,8 @@ __global__ __launch_bounds__(64) void k_mm_inv(const u8* __restrict__ srcAll, u8
           const u32 v = ((u32)__builtin_amdgcn_readlane((int)t, e) ^ pv) & 0xFFu;
           escVal = (lane == e) ? v : escVal;
         }
-        const u32 base = (seg >= 0) ? (u32)__shfl((int)escVal, seg & 63, 64) : carryBase;
+        const u32 segVal = (u32)__shfl((int)escVal, seg & 63, 64);               // every lane active: masked-off lanes supply nothing
+        const u32 base = (seg >= 0) ? segVal : carryBase;
         const u32 val = (base + (u32)sum) & 0xFFu;
         if (lane < m) dst[outBase + lane] = (u8)val;
         if (m > 0) { prevVals = val; prevM = m; }
