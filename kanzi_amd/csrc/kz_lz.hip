@@ -191,7 +191,12 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
     }
     if (bestLen < minMatch) {
       ref = ref0;
-      if ((ref > minRef) && (lz_le32(src + ref) == (u32)own)) bestLen = lz_find_match(src, srcIdx, ref, min(srcEnd - srcIdx, LZ_MAX_MATCH));
+      // the reference first compares 4 bytes at the candidate, then measures the match (:377-381); here the measuring
+      // loads go out at once (one round trip instead of two): fewer than 4 common bytes = its 4-byte test failing, and
+      // either way a length below minMatch ends in the literal step
+      // (LZ only: with LZX's 8 times larger table most candidates are unrelated and the wide loads cost more than they save)
+      if (extra) { if ((ref > minRef) && (lz_le32(src + ref) == (u32)own)) bestLen = lz_find_match(src, srcIdx, ref, min(srcEnd - srcIdx, LZ_MAX_MATCH)); }
+      else if (ref > minRef) { const int l0 = lz_find_match(src, srcIdx, ref, min(srcEnd - srcIdx, LZ_MAX_MATCH)); if (l0 >= 4) bestLen = l0; }
       if (bestLen < minMatch) { srcIdx = srcIdx1 + (srcInc >> 6); srcInc++; repIdx = 0; LZ_ORDER(); continue; }
       if ((ref != srcIdx - repd0) && (ref != srcIdx - repd1)) {
         const int h1 = h1e;
