@@ -76,12 +76,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # dry run of the N>1 path on a one-GPU box (diagnostic only): KZ_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and
+    # rendezvous goes over gloo, since RCCL refuses two ranks on one device
+    share = os.environ.get("KZ_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     B, bs = args.blocks, args.block_size
@@ -137,7 +145,7 @@ def main():
     T1 = time.perf_counter()
     ctx.set_kernel_timing(False)
     elapsed = T1 - T0
-    tt = torch.tensor([elapsed, t_enc, t_dec], dtype=torch.float64, device=dev)
+    tt = torch.tensor([elapsed, t_enc, t_dec], dtype=torch.float64, device="cpu" if share else dev)
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed, t_enc, t_dec = [float(x) for x in tt.tolist()]
