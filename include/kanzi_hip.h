@@ -135,6 +135,10 @@ int64_t kz_max_block_stream_bytes(int32_t blockLength);
 int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
                     const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstCap);
 int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstCap);
+/* a dstCap that kz_compress never exceeds for n input bytes cut into blockSize blocks (a transform may grow a block:
+ * SRT puts up to 1024 bytes of frequencies in front, K/transform/SRT.java MAX_HEADER_SIZE, which is 28 % on 1 KiB
+ * blocks of random bytes; the reference's writer simply keeps writing to its OutputStream) */
+int64_t kz_compress_bound(int64_t n, int32_t blockSize);
 uint64_t kz_transform_type(const int32_t* types, int32_t nb);
 /* host-only container helpers (no GPU touched): assemble a .knz from per-block streams gathered in
  * block-id order (stream header :236-313, 5+lw bit length prefix + payload per block :1024-1035, end

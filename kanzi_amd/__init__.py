@@ -80,6 +80,7 @@ def load_library():
         "kz_max_block_stream_bytes": (c.c_int64, [c.c_int32]),
         "kz_compress": (c.c_int64, [vp, c.c_uint64, c.c_uint32, c.c_int32, u8p, c.c_int64, u8p, c.c_int64]),
         "kz_decompress": (c.c_int64, [vp, u8p, c.c_int64, u8p, c.c_int64]),
+        "kz_compress_bound": (c.c_int64, [c.c_int64, c.c_int32]),
         "kz_transform_type": (c.c_uint64, [i32p, c.c_int32]),
         "kz_knz_assemble": (c.c_int64, [c.c_uint64, c.c_uint32, c.c_int32, c.c_int64, u8p, c.c_int64, i64p, c.c_int32, u8p, c.c_int64]),
         "kz_knz_index": (c.c_int32, [u8p, c.c_int64, vp, vp, vp, vp, i64p, i64p, c.c_int32]),
@@ -107,7 +108,7 @@ ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_err
                "kz_ctx_set_data_type", "kz_ctx_get_data_type", "kz_ctx_set_skip_blocks",
                "kz_transform_forward", "kz_transform_inverse", "kz_transform_max_encoded_len",
                "kz_entropy_encode", "kz_entropy_decode", "kz_encode_blocks", "kz_decode_blocks",
-               "kz_max_block_stream_bytes", "kz_compress", "kz_decompress", "kz_transform_type",
+               "kz_max_block_stream_bytes", "kz_compress", "kz_decompress", "kz_compress_bound", "kz_transform_type",
                "kz_knz_assemble", "kz_knz_index",
                "kz_set_timing", "kz_get_stage_count", "kz_get_stage_ms", "kz_get_stage_alg_bytes", "kz_reset_timing",
                "kz_set_kernel_timing", "kz_get_kernel_count", "kz_get_kernel_name", "kz_get_kernel_ms",
@@ -454,7 +455,7 @@ class CompressedOutputStream:
         self.closed = True
         src = np.frombuffer(b"".join(self._chunks), dtype=np.uint8)
         n = len(src)
-        cap = n + n // 4 + 65536
+        cap = int(self.ctx.lib.kz_compress_bound(n, self.blockSize))
         dst = np.empty(cap, dtype=np.uint8)
         sp = src.ctypes.data if n else dst.ctypes.data
         self.ctx.set_checksum(self.checksum)

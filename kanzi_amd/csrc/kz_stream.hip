@@ -237,6 +237,13 @@ static void emit_blocks(HostBits& bs, const uint8_t* streams, int64_t stride, co
   });
 }
 
+extern "C" int64_t kz_compress_bound(int64_t n, int32_t blockSize) {
+  if (n < 0 || blockSize <= 0) return -KZ_ERR_INVALID_PARAM;
+  const int64_t nBlocks = (n + blockSize - 1) / blockSize;
+  // per block: its stream (kz_max_block_stream_bytes) + length prefix and checksum; stream header, end marker, padding
+  return 64 + nBlocks * (kz_max_block_stream_bytes((int32_t)std::min<int64_t>(n, blockSize)) + 24);
+}
+
 extern "C" int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
                                const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstCap) {
   if (!ctx || !src || !dst || n < 0) return -KZ_ERR_INVALID_PARAM;

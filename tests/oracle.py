@@ -163,7 +163,7 @@ def decode_block(chain, entropy, block_size, stream, nbits, cap):
 
 def compress(chain, entropy, block_size, data, jobs=1, checksum=0, skip_blocks=False):
     a = _u8(data)
-    cap = len(a) + len(a) // 4 + 65536
+    cap = 2 * len(a) + 65536                   # 1 KiB blocks of random bytes through SRT grow by 28 %: header of 256 frequencies per block
     out = np.zeros(cap, dtype=np.uint8)
     r = lib().kzo_compress_x(ttype(chain), E[entropy.upper()], block_size, {0: 0, 32: 1, 64: 2}[checksum] | (0x100 if skip_blocks else 0), a.ctypes.data if len(a) else out.ctypes.data, len(a), out.ctypes.data, cap, jobs)
     if r < 0:

@@ -791,3 +791,28 @@ def test_device_resident_buffers_match_host_buffers(ctx):
     for i in range(B):
         assert res2[i].status == 0 and res2[i].length == lens[i]
         assert dec[i, :lens[i]].tobytes() == inp[i, :lens[i]].tobytes()
+
+
+def test_small_blocks_that_grow_by_more_than_a_quarter(ctx):
+    """1 KiB blocks of random bytes through SRT: 256 frequencies in front of every block (SRT.java MAX_HEADER_SIZE) make
+    the stream 28 % larger than the input.  The writer keeps going like the reference's; `kz_compress_bound` is the
+    destination size that always suffices, and a smaller destination is reported as ERR_WRITE_FILE, not overrun."""
+    rng = np.random.default_rng(9103)
+    data = bytes(rng.integers(0, 256, 96 * 1024 + 77, dtype=np.uint8))
+    for chain, ent in (("MM+BWT+SRT+ZRLT", "HUFFMAN"), ("SRT", "ANS0")):
+        ref = oracle.compress(chain, ent, 1024, data, jobs=2, checksum=64)
+        assert len(ref) > len(data) + len(data) // 4
+        assert len(ref) <= ctx.lib.kz_compress_bound(len(data), 1024)
+        cos = kz.CompressedOutputStream(ctx, chain, ent, 1024, checksum=64)
+        cos.write(data)
+        cos.close()
+        assert cos.output == ref
+        assert kz.CompressedInputStream(ctx, ref).read(len(data)) == data
+    src = np.frombuffer(data, dtype=np.uint8)
+    small = np.empty(len(data) + len(data) // 8, dtype=np.uint8)
+    ctx.set_checksum(64)
+    try:
+        rc = ctx.lib.kz_compress(ctx.h, kz.transform_type("SRT"), kz.ENTROPY_IDS["ANS0"], 1024, src.ctypes.data, len(src), small.ctypes.data, len(small))
+    finally:
+        ctx.set_checksum(0)
+    assert rc == -12
