@@ -42,6 +42,7 @@ struct BwtArrays {
   u32* digitBase;    // [B][256]
   u32* tileA;        // [B][T] scan temporaries
   u32* tileB;        // [B][T]
+  u32* tileLive;     // [B][T] live suffixes of the text tile in the previous round (0 stays 0: suffixes only become final)
   int32_t* d_n;      // [B] block length
   int32_t* d_m;      // [B] compact size (current)
   int32_t* d_m2;     // [B] compact size (next)
@@ -346,12 +347,16 @@ __global__ __launch_bounds__(KZ_WG) void k_seg_apply(const u64* __restrict__ key
 
 // ---------------------------------------------------------------------------------------------
 // step 1 (text order): compact the LIVE suffixes and build their keys from sequential rank reads
-__global__ __launch_bounds__(KZ_WG) void k_live_count(BwtArrays A) {
+__global__ __launch_bounds__(KZ_WG) void k_live_count(BwtArrays A, int first) {
   const int b = blockIdx.y;
   const int n = A.d_n[b];
   const int tile = blockIdx.x;
   if ((int64_t)tile * RS_TILE >= n) return;
   __shared__ u32 lds[32];
+  if (!first && A.tileLive[(int64_t)b * A.T + tile] == 0) {        // nothing left to count here
+    if (threadIdx.x == 0) A.tileA[(int64_t)b * A.T + tile] = 0;
+    return;
+  }
   const u32* rank = A.rank + (int64_t)b * A.NS;
   u32 cnt = 0;
 #pragma unroll
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(KZ_WG) void k_live_count(BwtArrays A) {
   }
   u32 tot;
   kz_wg_excl_sum(cnt, lds, &tot);
-  if (threadIdx.x == 0) A.tileA[(int64_t)b * A.T + tile] = tot;
+  if (threadIdx.x == 0) { A.tileA[(int64_t)b * A.T + tile] = tot; A.tileLive[(int64_t)b * A.T + tile] = tot; }
 }
 __global__ void k_live_scan(BwtArrays A) {
   const int b = blockIdx.x;
@@ -384,6 +389,12 @@ __global__ __launch_bounds__(KZ_WG) void k_live_emit(u64* __restrict__ keyN, u32
   const int tile = blockIdx.x;
   if ((int64_t)tile * RS_TILE >= n) return;
   __shared__ u32 rowCnt[RS_ITEMS * 4 + 1];   // live suffixes per (wave, row), then exclusive prefix
+  {                                          // late rounds: a tile without a live suffix has nothing to read or write
+    const int tiles = (n + RS_TILE - 1) / RS_TILE;
+    const u32* ta = A.tileA + (int64_t)b * A.T;
+    const u32 here = ta[tile], next = (tile + 1 < tiles) ? ta[tile + 1] : (u32)A.d_m2[b];
+    if (next == here) return;
+  }
   const int64_t off = (int64_t)b * A.NS;
   const u32* rank = A.rank + off;
   const int wave = threadIdx.x >> 6, lane = kz_lane();
@@ -470,7 +481,7 @@ __global__ void k_bwt_emit(const u8* __restrict__ src, int64_t srcStride, u8* __
 size_t kz_bwt_forward_scratch(int B, int maxN) {
   const int64_t NS = (int64_t)kz_align((size_t)maxN, RS_TILE);
   const int T = (int)(NS / RS_TILE);
-  size_t per = (size_t)NS * (8 * 2 + 4 * 2 + 4 + 4) + (size_t)T * (256 * 4 + 8) + 256 * 4 + 64 + 8 * 256;
+  size_t per = (size_t)NS * (8 * 2 + 4 * 2 + 4 + 4) + (size_t)T * (256 * 4 + 12) + 256 * 4 + 64 + 9 * 256;
   return kz_align(per * (size_t)B + 4096 * 16, 4096) + (1 << 20);
 }
 
@@ -494,9 +505,10 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
   A.digitBase = (u32*)kz_arena_alloc(ctx, (size_t)B * 256 * 4);
   A.tileA = (u32*)kz_arena_alloc(ctx, (size_t)T * B * 4);
   A.tileB = (u32*)kz_arena_alloc(ctx, (size_t)T * B * 4);
+  A.tileLive = (u32*)kz_arena_alloc(ctx, (size_t)T * B * 4);
   A.d_m = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   A.d_m2 = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
-  if (!A.d_m2 || !A.tileB || !A.sa) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: arena overflow"); return -KZ_ERR_DEVICE; }
+  if (!A.d_m2 || !A.tileB || !A.tileLive || !A.sa) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: arena overflow"); return -KZ_ERR_DEVICE; }
   A.d_n = bt.d_len;
   hipStream_t st = ctx->stream;
   const u8* src = bt.buf[bt.cur];
@@ -533,7 +545,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
     KZ_LAUNCH(ctx, KID_SEG_APPLY, k_seg_apply, dim3(tiles, B), dim3(KZ_WG), kC, vC, A, gshift);
     // ---- text order: compact the live suffixes, keys for the next round ----
     h = (round == 0) ? 7 : h * 2;
-    KZ_LAUNCH(ctx, KID_LIVE_COUNT, k_live_count, dim3(tilesN, B), dim3(KZ_WG), A);
+    KZ_LAUNCH(ctx, KID_LIVE_COUNT, k_live_count, dim3(tilesN, B), dim3(KZ_WG), A, round == 0 ? 1 : 0);
     KZ_LAUNCH(ctx, KID_LIVE_SCAN, k_live_scan, dim3(B), dim3(64), A);
     KZ_LAUNCH(ctx, KID_LIVE_EMIT, k_live_emit, dim3(tilesN, B), dim3(KZ_WG), kF, vF, A, h, bitsR);
     { u64* tk = kC; kC = kF; kF = tk; u32* tv = vC; vC = vF; vF = tv; }
