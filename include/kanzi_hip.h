@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define KZ_ABI_VERSION 1
+#define KZ_ABI_VERSION 2
 
 /* transform ids: K/transform/TransformFactory.java:36-60 */
 enum { KZ_T_NONE = 0, KZ_T_BWT = 1, KZ_T_LZ = 3, KZ_T_ZRLT = 6, KZ_T_MTFT = 7, KZ_T_RANK = 8,
@@ -143,11 +143,14 @@ uint64_t kz_transform_type(const int32_t* types, int32_t nb);
 /* host-only container helpers (no GPU touched): assemble a .knz from per-block streams gathered in
  * block-id order (stream header :236-313, 5+lw bit length prefix + payload per block :1024-1035, end
  * marker :491-492); index = the serial walk of block prefixes a decoder must do first (:1127-1129). */
+/* checksumBits = 0 / 32 / 64: the kz_ctx_set_checksum value the block streams were coded with (it goes into the stream
+ * header, :244-250; the block streams already carry their hash bytes) */
 int64_t kz_knz_assemble(uint64_t transformType, uint32_t entropyType, int32_t blockSize, int64_t inputSize,
-                        const uint8_t* streams, int64_t stride, const int64_t* bits, int32_t nBlocks,
+                        int32_t checksumBits, const uint8_t* streams, int64_t stride, const int64_t* bits, int32_t nBlocks,
                         uint8_t* dst, int64_t dstCap);
 int32_t kz_knz_index(const uint8_t* src, int64_t n, uint64_t* transformType, uint32_t* entropyType,
-                     int32_t* blockSize, int64_t* inputSize, int64_t* blockBitOff, int64_t* blockBits, int32_t cap);
+                     int32_t* blockSize, int64_t* inputSize, int32_t* checksumBits,
+                     int64_t* blockBitOff, int64_t* blockBits, int32_t cap);
 
 /* ---- instrumentation (bench.py / roofline) ----------------------------------------------------- */
 void    kz_set_timing(kz_ctx* ctx, int32_t enable);     /* hipEvent-bracket every stage of the next calls */

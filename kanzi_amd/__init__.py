@@ -82,8 +82,8 @@ def load_library():
         "kz_decompress": (c.c_int64, [vp, u8p, c.c_int64, u8p, c.c_int64]),
         "kz_compress_bound": (c.c_int64, [c.c_int64, c.c_int32]),
         "kz_transform_type": (c.c_uint64, [i32p, c.c_int32]),
-        "kz_knz_assemble": (c.c_int64, [c.c_uint64, c.c_uint32, c.c_int32, c.c_int64, u8p, c.c_int64, i64p, c.c_int32, u8p, c.c_int64]),
-        "kz_knz_index": (c.c_int32, [u8p, c.c_int64, vp, vp, vp, vp, i64p, i64p, c.c_int32]),
+        "kz_knz_assemble": (c.c_int64, [c.c_uint64, c.c_uint32, c.c_int32, c.c_int64, c.c_int32, u8p, c.c_int64, i64p, c.c_int32, u8p, c.c_int64]),
+        "kz_knz_index": (c.c_int32, [u8p, c.c_int64, vp, vp, vp, vp, vp, i64p, i64p, c.c_int32]),
         "kz_set_timing": (None, [vp, c.c_int32]),
         "kz_get_stage_count": (c.c_int32, [vp]),
         "kz_get_stage_ms": (c.c_float, [vp, c.c_int32]),
@@ -484,18 +484,39 @@ class CompressedInputStream:
         return dst[:rc].tobytes()
 
     def _declared_size(self):
-        # stream header: 32+4+2+5+48+28 bits then szMask (2) and the size (CompressedOutputStream.java:236-290)
-        v = int.from_bytes(self.data[:24], "big")
-        total = 24 * 8
-        szmask = (v >> (total - 121)) & 3
-        if szmask == 0:
-            return max(len(self.data) * 64, 1 << 20)
-        size = (v >> (total - 121 - 16 * szmask)) & ((1 << (16 * szmask)) - 1)
-        return int(size)
+        # The size field of the stream header is informative and untrusted (CompressedOutputStream.java:236-290): what the
+        # stream can hold is bounded by its own block walk -- every block decodes to at most blockSize bytes.
+        try:
+            idx = knz_index(self.data)
+            return max(len(idx["blocks"]) * idx["blockSize"], 1)
+        except KanziError:
+            pass
+        # damaged stream: count the length prefixes that can still be walked (kz_decompress reports the fault itself)
+        d, nbits = self.data, len(self.data) * 8
+        if len(d) < 20:
+            return 1 << 20
+        v = int.from_bytes(d[:20], "big")
+        block_size = ((v >> (160 - 119)) & ((1 << 28) - 1)) << 4
+        szmask = (v >> (160 - 121)) & 3
+        pos, nb = 121 + 16 * szmask + 15 + 24, 0
+
+        def get(p, k):
+            w = int.from_bytes(d[p // 8:(p + k + 7) // 8 + 1].ljust((k + 15) // 8 + 1, b"\0"), "big")
+            tot = ((k + 15) // 8 + 1) * 8
+            return (w >> (tot - (p % 8) - k)) & ((1 << k) - 1)
+        while pos + 8 <= nbits and nb < (1 << 20):
+            lr = get(pos, 5) + 3
+            rd = get(pos + 5, lr)
+            if rd == 0:
+                break
+            nb += 1
+            pos += 5 + lr + rd
+        return max((nb + 1) * max(min(block_size, 1 << 30), 1024), 1 << 20)
 
 
-def knz_assemble(transform, entropy, block_size, input_size, streams, bits):
-    """Host-only: build a .knz from per-block private streams (list of bytes) in block-id order."""
+def knz_assemble(transform, entropy, block_size, input_size, streams, bits, checksum=0):
+    """Host-only: build a .knz from per-block private streams (list of bytes) in block-id order.
+    checksum = 0 / 32 / 64: what the block streams were coded with (Context.set_checksum)."""
     L = load_library()
     tt = transform if isinstance(transform, int) else transform_type(transform)
     et = entropy if isinstance(entropy, int) else ENTROPY_IDS[entropy.upper()]
@@ -507,7 +528,7 @@ def knz_assemble(transform, entropy, block_size, input_size, streams, bits):
     b = np.ascontiguousarray(bits, dtype=np.int64)
     cap = int(sum((int(x) + 7) // 8 + 8 for x in bits)) + 64
     dst = np.zeros(cap, dtype=np.uint8)
-    rc = L.kz_knz_assemble(tt, et, int(block_size), int(input_size), buf.ctypes.data, stride, b.ctypes.data, nb, dst.ctypes.data, cap)
+    rc = L.kz_knz_assemble(tt, et, int(block_size), int(input_size), int(checksum), buf.ctypes.data, stride, b.ctypes.data, nb, dst.ctypes.data, cap)
     if rc < 0:
         raise KanziError(-rc, "knz_assemble")
     return dst[:rc].tobytes()
@@ -517,15 +538,15 @@ def knz_index(data):
     """Host-only: -> dict(transform, entropy, blockSize, inputSize, blocks=[(bitOffset, bits), ...])."""
     L = load_library()
     src = np.frombuffer(bytes(data) + b"\0" * 16, dtype=np.uint8)
-    tt, et, bs, isz = ctypes.c_uint64(0), ctypes.c_uint32(0), ctypes.c_int32(0), ctypes.c_int64(0)
+    tt, et, bs, isz, chk = ctypes.c_uint64(0), ctypes.c_uint32(0), ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int32(0)
     cap = max(16, len(data) // 8 + 16)
     off = np.zeros(cap, dtype=np.int64)
     bits = np.zeros(cap, dtype=np.int64)
     nb = L.kz_knz_index(src.ctypes.data, len(data), ctypes.addressof(tt), ctypes.addressof(et), ctypes.addressof(bs),
-                        ctypes.addressof(isz), off.ctypes.data, bits.ctypes.data, cap)
+                        ctypes.addressof(isz), ctypes.addressof(chk), off.ctypes.data, bits.ctypes.data, cap)
     if nb < 0:
         raise KanziError(-nb, "knz_index")
-    return {"transform": tt.value, "entropy": et.value, "blockSize": bs.value, "inputSize": isz.value,
+    return {"transform": tt.value, "entropy": et.value, "blockSize": bs.value, "inputSize": isz.value, "checksum": chk.value,
             "blocks": [(int(off[i]), int(bits[i])) for i in range(nb)]}
 
 

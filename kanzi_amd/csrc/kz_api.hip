@@ -24,6 +24,7 @@ extern "C" kz_ctx* kz_ctx_create(int32_t deviceId) {
   { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, deviceId) == hipSuccess && cus > 0) ctx->numCUs = cus; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
   if (hipHostMalloc((void**)&ctx->hpin, 1 << 20, hipHostMallocDefault) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return nullptr; }
+  ctx->hpinInts = (1 << 20) / 4;
   return ctx;
 }
 extern "C" void kz_ctx_destroy(kz_ctx* ctx) {
@@ -54,6 +55,18 @@ extern "C" int32_t kz_ctx_set_data_type(kz_ctx* ctx, int32_t dataType) {
 extern "C" int32_t kz_ctx_get_data_type(kz_ctx* ctx) { return ctx ? ctx->dataType : -KZ_ERR_INVALID_PARAM; }
 extern "C" const char* kz_last_error(kz_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 extern "C" void* kz_ctx_stream(kz_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// pinned read-back buffer: the batched calls read up to 9 int arrays of B entries back per stage (run_stage: 2B,
+// kz_decode_blocks: 4B + 5B); grown here, never indexed beyond hpinInts
+int kz_hpin_reserve(kz_ctx* ctx, size_t ints) {
+  if (ints <= ctx->hpinInts) return 0;
+  KZ_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->hpin) { hipHostFree(ctx->hpin); ctx->hpin = nullptr; ctx->hpinInts = 0; }
+  ints = kz_align(ints + (ints >> 2), 1 << 16);
+  KZ_HIP(hipHostMalloc((void**)&ctx->hpin, ints * 4, hipHostMallocDefault));
+  ctx->hpinInts = ints;
+  return 0;
+}
 
 int kz_arena_reserve(kz_ctx* ctx, size_t total) {
   ctx->arenaTop = 0;
@@ -362,6 +375,8 @@ static int pipe_setup(kz_ctx* ctx, Pipe& P, int B, int maxLen, int64_t extraByte
   const size_t fixed = (size_t)bt.stride * B * 2 + (size_t)B * 4 * 16 + 65536 + (size_t)extraBytes;
   int rc = kz_arena_reserve(ctx, fixed + pipeline_scratch(B, maxLen, decode, C) + (1 << 20));
   if (rc) return rc;
+  rc = kz_hpin_reserve(ctx, (size_t)B * 9 + 64);
+  if (rc) return rc;
   bt.buf[0] = (u8*)kz_arena_alloc(ctx, (size_t)bt.stride * B);
   bt.buf[1] = (u8*)kz_arena_alloc(ctx, (size_t)bt.stride * B);
   bt.d_len = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
@@ -440,6 +455,13 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   int maxN = 0;
   for (int b = 0; b < B; b++) { if (lengths[b] < 0) return -KZ_ERR_INVALID_PARAM; maxN = std::max(maxN, lengths[b]); }
   const int maxLen = seq_max_len(types, nb, maxN);
+  // the inverse stages of BWT and RANK/MTFT keep 24-bit positions packed next to a byte (kz_bwt_inv.hip, kz_sbrt.hip): refuse
+  // up front what this library's own decoder could not take back (the reference goes to 1 GiB blocks)
+  for (int i = 0; i < nb; i++)
+    if ((types[i] == KZ_T_BWT || types[i] == KZ_T_RANK || types[i] == KZ_T_MTFT) && maxLen > KZ_MAX_PACKED_BLOCK) {
+      snprintf(ctx->err, sizeof(ctx->err), "block of %d bytes: BWT / RANK / MTFT chains take blocks up to %d bytes (16 MiB block size)", maxN, KZ_MAX_PACKED_BLOCK - 33);
+      return -KZ_ERR_BLOCK_SIZE;
+    }
   ChainSpec CS; CS.nb = nb; CS.entropy = (int)entropyType; for (int i = 0; i < nb; i++) CS.types[i] = types[i];
   {
     // bound the scratch arena: the suffix sort needs ~43 B per input byte, so very large batches are
@@ -450,7 +472,7 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     for (int i = 0; i < noBwt.nb; i++) if (noBwt.types[i] == KZ_T_BWT) noBwt.types[i] = KZ_T_NONE;
     const size_t perBlock = pipeline_scratch(1, maxLen, false, noBwt) + (size_t)maxLen * 2 + 8192 + (size_t)(memKind == KZ_MEM_HOST ? outStride : 0) + (1 << 16);
     const size_t avail = hasBwt ? kz_arena_budget() / 2 : kz_arena_budget();      // the other half: suffix-sort groups
-    const int maxB = (int)std::max<size_t>(1, avail / perBlock);
+    const int maxB = (int)std::min<size_t>(KZ_MAX_BATCH, std::max<size_t>(1, avail / perBlock));   // grid.y carries the block index
     if (B > maxB) {
       for (int b0 = 0; b0 < B; b0 += maxB) {
         const int cnt = std::min(maxB, B - b0);
@@ -598,7 +620,7 @@ struct FrameDec {
 };
 // CompressedInputStream.java:1025-1095 readBlockHeader
 __global__ void k_frame_parse(const u8* __restrict__ in, int64_t inStride, const int64_t* __restrict__ bitLen, FrameDec F,
-                              int nbFunctions, int maxTransformLength, int B) {
+                              int nbFunctions, int maxTransformLength, int entropyNone, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const u8* p = in + (int64_t)b * inStride;
@@ -630,6 +652,9 @@ __global__ void k_frame_parse(const u8* __restrict__ in, int64_t inStride, const
       else if (W < (int64_t)hdrBytes * 8) status = -KZ_ERR_BLOCK_SIZE;
       else if (preLen < 0 || preLen > maxTransformLength) status = -KZ_ERR_READ_FILE;
       else if (((W + 7) >> 3) > (int64_t)preLen + hdrBytes) status = -KZ_ERR_BLOCK_SIZE;     // :1158-1164
+      // raw bytes (copy block, "transformed copy", NONE entropy) are read with NullEntropyDecoder: a stream shorter than
+      // the stated length makes the bit stream throw -> ERR_PROCESS_BLOCK (CompressedInputStream.java:1305-1316,1366-1371)
+      else if (preLen > 0 && (raw || tcopy || entropyNone) && W < 8LL * ((int64_t)hdrBytes + preLen)) status = -KZ_ERR_PROCESS_BLOCK;
     }
   }
   if (status) { preLen = 0; }
@@ -671,7 +696,7 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   ChainSpec CS; CS.nb = nb; CS.entropy = (int)entropyType; for (int i = 0; i < nb; i++) CS.types[i] = types[i];
   {
     const size_t perBlock = pipeline_scratch(1, maxLen, true, CS) + (size_t)maxLen * 2 + (size_t)(host ? maxInBytes : 0) + (1 << 16);
-    int maxB = (int)std::max<size_t>(1, kz_arena_budget() / perBlock);
+    int maxB = (int)std::min<size_t>(KZ_MAX_BATCH, std::max<size_t>(1, kz_arena_budget() / perBlock));   // grid.y carries the block index
     // the serial-per-block inverse stages like whole multiples of 8 blocks per CU (one wave per block, two per SIMD)
     const int unit = 8 * (ctx->numCUs > 0 ? ctx->numCUs : 256);
     if (B > maxB && maxB > unit) maxB = (maxB / unit) * unit;       // only when the batch has to be split anyway
@@ -718,7 +743,7 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   if (!d_bitLen) { snprintf(ctx->err, sizeof(ctx->err), "decode: arena overflow"); return -KZ_ERR_DEVICE; }
   KZ_HIP(hipMemcpyAsync(d_bitLen, bitLengths, (size_t)B * 8, hipMemcpyHostToDevice, st));
   hipEvent_t e0; kz_stage_begin(ctx, &e0);
-  KZ_LAUNCH(ctx, KID_FRAME_PARSE, k_frame_parse, dim3((B + 255) / 256), dim3(256), d_in, inS, d_bitLen, F, nb, maxLen, B);
+  KZ_LAUNCH(ctx, KID_FRAME_PARSE, k_frame_parse, dim3((B + 255) / 256), dim3(256), d_in, inS, d_bitLen, F, nb, maxLen, (entropyType == KZ_E_NONE) ? 1 : 0, B);
   // read back descriptors
   int32_t* hp = ctx->hpin + 4 * B;
   KZ_HIP(hipMemcpyAsync(hp + 0 * B, F.preLen, (size_t)B * 4, hipMemcpyDeviceToHost, st));

@@ -17,7 +17,8 @@ struct kz_ctx {
   uint8_t* arena = nullptr;
   size_t arenaCap = 0, arenaTop = 0;
   // pinned host staging for small read-backs
-  int32_t* hpin = nullptr;       // 64K ints
+  int32_t* hpin = nullptr;       // hpinInts ints, grown by kz_hpin_reserve
+  size_t hpinInts = 0;
   char err[512] = {0};
   // last-call stage timings (ms) for bench/roofline (hipEvent based)
   float stageMs[KZ_MAX_STAGES] = {0};
@@ -41,6 +42,9 @@ struct kz_ctx {
   snprintf(ctx->err, sizeof(ctx->err), "%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
   return -KZ_ERR_DEVICE; } } while (0)
 
+#define KZ_MAX_PACKED_BLOCK ((1 << 24) - 257)   // largest block the packed inverse BWT / RANK kernels take
+#define KZ_MAX_BATCH 65535        // blocks per launch: the batched kernels carry the block index in gridDim.y (<= 65535)
+int kz_hpin_reserve(kz_ctx* ctx, size_t ints);
 static inline size_t kz_align(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Reserve `total` bytes of arena (may reallocate: only call before any sub-allocation).

@@ -19,6 +19,7 @@
 #include "kz_internal.h"
 #include <algorithm>
 #include <vector>
+#include <stdlib.h>
 
 typedef unsigned long long u64;
 typedef uint32_t u32;
@@ -242,8 +243,8 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
 // One wave per block, up to 8 blocks per workgroup: the waves of a workgroup are spread over the 4 SIMDs of one
 // CU (wave w and wave w+4 share a SIMD), so the host can pair an expensive block with a cheap one (order[]).
 template <int MODE>
-__global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
-                                                       const int32_t* __restrict__ d_len, const int32_t* __restrict__ order, int wavesPerGroup) {
+__global__ __launch_bounds__(512) void k_sbrt_inverse5(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                                                        const int32_t* __restrict__ d_len, const int32_t* __restrict__ order, int wavesPerGroup) {
   const int b = order[blockIdx.x * wavesPerGroup + (int)(threadIdx.x >> 6)];
   if (b < 0) return;
   const int n = d_len[b];
@@ -296,6 +297,184 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
       const int srcLane = below ? 63 - (int)__builtin_clzll(below) : 0;
       const u32 fv = (u32)__shfl((int)outv, srcLane, 64);
       if (!((nzRow >> lane) & 1ULL)) outv = below ? fv : f0;
+    }
+    if (lane < cnt) d[row + lane] = (u8)outv;
+    cur = nxt;
+  }
+}
+
+// ---- inverse v6: the list lives by POSITION ----------------------------------------------------------------
+// Row k (k = 0..3) holds list positions 64k..64k+63, one per lane, in two VGPRs:
+//   Q = (q << 8) | symbol    (q < 2^24: blocks below 2^24 bytes, as before)      P = p (index of the last occurrence)
+// The list is sorted by q descending at all times (a moved symbol's new q is never below its old one), so the bubble
+// loop of SBRT.java:194-209 moves the entry at position r up to rp = #{q > qc} and the entries of [rp, r) down by one:
+// in-range lanes M = {j <= r : Q_j <= TH}, TH = (qc << 8) | 0xFF, take their left neighbour (one DPP wave_shr per
+// register), and the one lane of M whose incoming neighbour is still above TH (or lane 0 of row 0: a sentinel) is rp and
+// takes the new entry.  Nothing on that chain leaves the VALU: the lane mask "<= r" is an EXEC mask built from the
+// rank by the scalar unit ahead of time, M is EXEC after v_cmpx, v_cmp -> v_cndmask go through an SGPR pair.  v5 kept
+// keys by symbol and counted rp with 4 ballots + s_bcnt1: three VALU->SALU hand-offs (~30 cycles each) and ~70
+// instructions per non-zero rank whatever its value; here a rank below 64 costs 14 VALU + ~8 SALU instructions and
+// each further row of 64 positions the move spans about 12 more.  x = 2q or 2q+1: RANK i + p, MTF 2i, TIMESTAMP 2p.
+// Hazards (inline asm is not padded by the compiler): VALU-written SGPR -> VALU read 2 wait states, VALU-written
+// VGPR -> DPP 2 / v_readlane 1, VALU-written EXEC -> DPP 5 / v_readlane, v_writelane 4.
+// One asm statement walks the non-zero ranks of a 64-rank row (the compiler cannot be trusted to keep eleven loop-carried
+// registers in place around per-step asm statements, nor to keep the rank uniform).  Physical temporaries, listed as
+// clobbers: v90 tp, v91 tq, v92 xi, v93 th, v94 nq, v95 vi; s40 j, s41 jn, s42 r, s43 r_next, s44 r&63, s45 t,
+// s[46:47] lanes <= r&63, s[48:49] non-zero positions left, s50 i, s51 j-prev, s52 pl, s53 x, s54 accessed Q, s55/s56 carries,
+// s57 r>>6, s[58:59] insert mask, s60 2i.
+#define KZ6_DPP " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define KZ6_XI_RANK(P) "v_add_u32 v92, s50, %[" P "]\n\t"
+#define KZ6_XI_MTF(P)  "v_mov_b32 v92, s60\n\t"
+#define KZ6_XI_TS(P)   "v_lshlrev_b32 v92, 1, %[" P "]\n\t"
+// zero run in front of position j: the front entry (row 0, lane 0) repeats, only its (q,p) change (SBRT.java:194-201):
+// p = pl, q = RANK (pl + (run >= 2 ? pl - 1 : p)) >> 1, MTF pl, TIMESTAMP run >= 2 ? pl - 1 : p
+#define KZ6_ZQ_RANK "v_mov_b32 v93, s45\n\tv_cndmask_b32 v92, %[p0], v93, vcc\n\tv_add_u32 v92, s52, v92\n\tv_lshrrev_b32 v92, 1, v92\n\t"
+#define KZ6_ZQ_MTF  "v_mov_b32 v92, s52\n\t"
+#define KZ6_ZQ_TS   "v_mov_b32 v93, s45\n\tv_cndmask_b32 v92, %[p0], v93, vcc\n\t"
+#define KZ6_ZERO(ZQ)                                           \
+    "s_sub_u32 s52, s50, 1\n\t"                                  \
+    "s_cmp_gt_u32 s51, 2\n\t"                                    \
+    "s_cselect_b64 vcc, -1, 0\n\t"                               \
+    "s_sub_u32 s45, s52, 1\n\t"                                  \
+    "s_mov_b64 exec, 1\n\t"                                      \
+    ZQ                                                           \
+    "v_lshlrev_b32 v92, 8, v92\n\t"                              \
+    "v_bfi_b32 %[q0], %[ff], %[q0], v92\n\t"                     \
+    "v_mov_b32 %[p0], s52\n\t"                                   \
+    "s_mov_b64 exec, -1\n\t"
+// head: read the accessed entry (row KR, lane r&63): x and Q
+#define KZ6_HEAD(XI, QK, PK)                                   \
+    XI(PK)                                                       \
+    "v_mov_b32 v95, s50\n\t"                                     \
+    "v_readlane_b32 s53, v92, s44\n\t"                           \
+    "v_readlane_b32 s54, %[" QK "], s44\n\t"
+#define KZ6_THNQ                                               \
+    "v_lshl_or_b32 v93, s53, 7, %[ff]\n\t"                       \
+    "v_bfi_b32 v94, %[ff], s54, v93\n\t"
+// rows 1..3: shifted copies with the carry from the row above in lane 0
+#define KZ6_ROW_SHIFT(QK, PK, QM, PM)                          \
+    "v_readlane_b32 s55, %[" QM "], 63\n\t"                      \
+    "v_readlane_b32 s56, %[" PM "], 63\n\t"                      \
+    "v_mov_b32_dpp v91, %[" QK "]" KZ6_DPP                       \
+    "v_mov_b32_dpp v90, %[" PK "]" KZ6_DPP                       \
+    "v_writelane_b32 v91, s55, 0\n\t"                            \
+    "v_writelane_b32 v90, s56, 0\n\t"
+#define KZ6_ROW_APPLY(QK, PK, TQ)                              \
+    "v_cmpx_le_u32 vcc, %[" QK "], v93\n\t"                      \
+    "v_cmp_lt_u32_e64 s[58:59], v93, " TQ "\n\t"                 \
+    "s_nop 1\n\t"                                                \
+    "v_cndmask_b32_e64 %[" QK "], " TQ ", v94, s[58:59]\n\t"     \
+    "v_cndmask_b32_e64 %[" PK "], v90, v95, s[58:59]\n\t"        \
+    "s_mov_b64 exec, -1\n\t"
+#define KZ6_ROW0                                               \
+    "v_mov_b32_dpp %[tq0], %[q0]" KZ6_DPP                        \
+    "v_mov_b32_dpp v90, %[p0]" KZ6_DPP
+// tail: lane j of outv <- accessed entry (low byte = symbol), lane j of fmv <- M of row 0 (bit 0: the symbol became the front)
+#define KZ6_TAIL                                               \
+    "s_mov_b32 m0, s40\n\t"                                      \
+    "s_nop 0\n\t"                                                \
+    "v_writelane_b32 %[outv], s54, m0\n\t"                       \
+    "v_writelane_b32 %[fmv], vcc_lo, m0\n\t"
+#define KZ6_SETLE "s_mov_b64 exec, s[46:47]\n\t"
+#define KZ6_ROWLOOP(XI, ZQ) asm volatile(                                                      \
+    "s_mov_b64 s[48:49], %[nz]\n\t"                                                              \
+    "s_mov_b32 %[prev], -1\n\t"                                                                  \
+    "s_ff1_i32_b64 s40, s[48:49]\n\t"                                                            \
+    "s_bitset0_b64 s[48:49], s40\n\t"                                                            \
+    "v_readlane_b32 s42, %[cur], s40\n\t"                                                        \
+  "L_step%=:\n\t"                                                                                \
+    "s_ff1_i32_b64 s41, s[48:49]\n\t"                                                            \
+    "s_max_i32 s41, s41, 0\n\t"                                                                  \
+    "v_readlane_b32 s43, %[cur], s41\n\t"              /* rank of the next non-zero position: ready long before it is needed */ \
+    "s_add_u32 s50, %[row], s40\n\t"                                                             \
+    "s_lshl_b32 s60, s50, 1\n\t"                                                                 \
+    "s_sub_u32 s51, s40, %[prev]\n\t"                                                            \
+    "s_cmp_lt_u32 s51, 2\n\t"                                                                    \
+    "s_cbranch_scc1 L_nz%=\n\t"                                                                  \
+    KZ6_ZERO(ZQ)                                                                                 \
+  "L_nz%=:\n\t"                                                                                  \
+    "s_and_b32 s44, s42, 63\n\t"                                                                 \
+    "s_xor_b32 s45, s44, 63\n\t"                                                                 \
+    "s_lshr_b64 s[46:47], -1, s45\n\t"                                                           \
+    "s_lshr_b32 s57, s42, 6\n\t"                                                                 \
+    "s_cmp_lg_u32 s57, 0\n\t"                                                                    \
+    "s_cbranch_scc1 L_cold%=\n\t"                                                                \
+    KZ6_HEAD(XI, "q0", "p0") KZ6_ROW0 KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL \
+  "L_next%=:\n\t"                                                                                \
+    "s_mov_b32 %[prev], s40\n\t"                                                                 \
+    "s_cmp_eq_u64 s[48:49], 0\n\t"                                                               \
+    "s_cbranch_scc1 L_done%=\n\t"                                                                \
+    "s_bitset0_b64 s[48:49], s41\n\t"                                                            \
+    "s_mov_b32 s40, s41\n\t"                                                                     \
+    "s_mov_b32 s42, s43\n\t"                                                                     \
+    "s_branch L_step%=\n\t"                                                                      \
+  "L_cold%=:\n\t"                                                                                \
+    "s_cmp_eq_u32 s57, 1\n\t"                                                                    \
+    "s_cbranch_scc1 L_k1%=\n\t"                                                                  \
+    "s_cmp_eq_u32 s57, 2\n\t"                                                                    \
+    "s_cbranch_scc1 L_k2%=\n\t"                                                                  \
+    KZ6_HEAD(XI, "q3", "p3") KZ6_ROW_SHIFT("q3", "p3", "q2", "p2") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q3", "p3", "v91") \
+    KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_ROW_APPLY("q2", "p2", "v91") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v91") \
+    KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL                                        \
+    "s_branch L_next%=\n\t"                                                                      \
+  "L_k2%=:\n\t"                                                                                  \
+    KZ6_HEAD(XI, "q2", "p2") KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q2", "p2", "v91") \
+    KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v91") KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL \
+    "s_branch L_next%=\n\t"                                                                      \
+  "L_k1%=:\n\t"                                                                                  \
+    KZ6_HEAD(XI, "q1", "p1") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q1", "p1", "v91") \
+    KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL                                        \
+    "s_branch L_next%=\n\t"                                                                      \
+  "L_done%=:\n\t"                                                                                \
+    : [q0]"+v"(Q0), [p0]"+v"(P0), [q1]"+v"(Q1), [p1]"+v"(P1), [q2]"+v"(Q2), [p2]"+v"(P2), [q3]"+v"(Q3), [p3]"+v"(P3),           \
+      [tq0]"+v"(tq0), [outv]"+v"(outv), [fmv]"+v"(fmv), [prev]"=&s"(prev)                                                      \
+    : [cur]"v"(cur), [ff]"v"(ff), [nz]"s"(nz), [row]"s"(row)                                                                   \
+    : "vcc", "scc", "v90", "v91", "v92", "v93", "v94", "v95", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", \
+      "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60");
+
+// zero run of zr ranks ending at index pl, compiler form (row tails and all-zero rows)
+#define KZ6_ZERO_RUN(zr, plv)                                                                  \
+  { const u32 pl = (u32)(plv);                                                                 \
+    const u32 t = (MODE == 1) ? pl : (((zr) >= 2) ? pl - 1u : ((MODE == 2) ? ((pl + P0) >> 1) : P0)); \
+    const u32 nqf = (t << 8) | (Q0 & 0xFFu);                                                   \
+    Q0 = isLane0 ? nqf : Q0; P0 = isLane0 ? pl : P0; }
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                                                       const int32_t* __restrict__ d_len, const int32_t* __restrict__ order, int wavesPerGroup) {
+  const int b = __builtin_amdgcn_readfirstlane(order[blockIdx.x * wavesPerGroup + (int)(threadIdx.x >> 6)]);
+  if (b < 0) return;
+  const int n = __builtin_amdgcn_readfirstlane(d_len[b]);
+  const u8* s = src + (int64_t)b * stride;
+  u8* d = dst + (int64_t)b * stride;
+  const int lane = kz_lane();
+  const bool isLane0 = lane == 0;
+  u32 Q0 = (u32)lane, Q1 = 64u + (u32)lane, Q2 = 128u + (u32)lane, Q3 = 192u + (u32)lane;   // q = 0, symbols in order (SBRT.java:176-180)
+  u32 P0 = 0, P1 = 0, P2 = 0, P3 = 0;
+  u32 tq0 = 0xFFFFFFFFu;                      // lane 0 stays the sentinel "above every key": the DPP shift never writes it
+  const u32 ff = 0xFFu;
+  u32 fmv = 0;
+  u32 cur = (lane < n) ? (u32)s[lane] : 0u;
+  for (int row = 0; row < n; row += 64) {
+    const int cnt = min(64, n - row);
+    const int nrow = row + 64;
+    const u32 nxt = (nrow + lane < n) ? (u32)s[nrow + lane] : 0u;  // prefetch the next row
+    const uint64_t nz = kz_ballot(cur != 0 && lane < cnt);
+    // non-zero lanes receive their symbol with v_writelane; zero ranks output the front symbol of their time
+    u32 outv = 0;
+    const u32 f0 = (u32)__builtin_amdgcn_readfirstlane((int)Q0) & 0xFFu;
+    int prev = -1;
+    if (nz) {
+      if (MODE == 2) { KZ6_ROWLOOP(KZ6_XI_RANK, KZ6_ZQ_RANK) } else if (MODE == 1) { KZ6_ROWLOOP(KZ6_XI_MTF, KZ6_ZQ_MTF) } else { KZ6_ROWLOOP(KZ6_XI_TS, KZ6_ZQ_TS) }
+    }
+    { const int zr = cnt - prev - 1; if (zr > 0) KZ6_ZERO_RUN(zr, row + cnt - 1) }
+    {
+      // zero-rank lane l: symbol of the last front change before l (held by that lane), else the front at row start
+      const uint64_t fm = kz_ballot((fmv & 1u) != 0) & nz;
+      const uint64_t below = fm & kz_lanemask_lt();
+      const int srcLane = below ? 63 - (int)__builtin_clzll(below) : 0;
+      const u32 fv = (u32)__shfl((int)outv, srcLane, 64);
+      if (!((nz >> lane) & 1ULL)) outv = below ? fv : f0;
     }
     if (lane < cnt) d[row + lane] = (u8)outv;
     cur = nxt;
@@ -419,10 +598,15 @@ int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
   const std::vector<int>& launchG = PL.G;
   const std::vector<int>& launchOff = PL.off;
   const int32_t* d_order = PL.d_order;
+  static const bool useV5 = getenv("KZ_SBRT_V5") != nullptr;          // A/B switch while v6 is being measured
   for (int rr = 0; rr < R; rr++) {
     const int G = launchG[rr];
     const int32_t* ord = d_order + launchOff[rr];
-    if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<2>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
+    if (useV5) {
+      if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse5<2>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
+      else if (mode == 1) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse5<1>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
+      else { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse5<3>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
+    } else if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<2>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
     else if (mode == 1) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<1>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
     else { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<3>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
   }

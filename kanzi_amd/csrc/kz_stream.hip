@@ -120,11 +120,14 @@ static void write_block(HostBits& bs, const uint8_t* stream, uint64_t written) {
 // Assemble a complete .knz stream from per-block private streams (e.g. gathered from several GPUs
 // in block-id order).  Pure host code.
 extern "C" int64_t kz_knz_assemble(uint64_t transformType, uint32_t entropyType, int32_t blockSize, int64_t inputSize,
-                                   const uint8_t* streams, int64_t stride, const int64_t* bits, int32_t nBlocks,
+                                   int32_t checksumBits, const uint8_t* streams, int64_t stride, const int64_t* bits, int32_t nBlocks,
                                    uint8_t* dst, int64_t dstCap) {
   if (!dst || nBlocks < 0 || (nBlocks > 0 && (!streams || !bits))) return -KZ_ERR_INVALID_PARAM;
+  if (checksumBits != 0 && checksumBits != 32 && checksumBits != 64) return -KZ_ERR_INVALID_PARAM;
   HostBits bs{dst, dstCap, 0, false};
-  write_stream_header(bs, transformType, entropyType, blockSize, inputSize);
+  // the block streams carry 4 / 8 hash bytes in their headers when they were coded with kz_ctx_set_checksum(32 / 64): the
+  // stream header must say so (CompressedOutputStream.java:244-250) or no reader can parse them
+  write_stream_header(bs, transformType, entropyType, blockSize, inputSize, checksumBits == 32 ? 1 : (checksumBits == 64 ? 2 : 0));
   for (int i = 0; i < nBlocks; i++) if (bits[i] > 0) write_block(bs, streams + (int64_t)i * stride, (uint64_t)bits[i]);
   bs.put(0, 5); bs.put(0, 3);
   if (bs.overflow) return -KZ_ERR_WRITE_FILE;
@@ -163,7 +166,7 @@ static int read_stream_header(HostBitsIn& bs, KnzHeader& h, char* err, size_t er
 }
 
 extern "C" int32_t kz_knz_index(const uint8_t* src, int64_t n, uint64_t* transformType, uint32_t* entropyType,
-                                int32_t* blockSize, int64_t* inputSize, int64_t* blockBitOff, int64_t* blockBits, int32_t cap) {
+                                int32_t* blockSize, int64_t* inputSize, int32_t* checksumBits, int64_t* blockBitOff, int64_t* blockBits, int32_t cap) {
   if (!src || n < 20) return -KZ_ERR_INVALID_FILE;
   HostBitsIn bs{src, (uint64_t)n * 8, 0, false};
   KnzHeader h;
@@ -173,6 +176,7 @@ extern "C" int32_t kz_knz_index(const uint8_t* src, int64_t n, uint64_t* transfo
   if (entropyType) *entropyType = (uint32_t)et;
   if (blockSize) *blockSize = bsz;
   if (inputSize) *inputSize = isz;
+  if (checksumBits) *checksumBits = h.chkKind == 1 ? 32 : (h.chkKind == 2 ? 64 : 0);
   int nb = 0;
   for (;;) {
     const int lr = (int)bs.get(5) + 3;
