@@ -376,6 +376,16 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse5(const u8* __restrict__ sr
     "v_writelane_b32 %[outv], s54, m0\n\t"                       \
     "v_writelane_b32 %[fmv], vcc_lo, m0\n\t"
 #define KZ6_SETLE "s_mov_b64 exec, s[46:47]\n\t"
+// end of a step of the row walk: next non-zero position, or out (every variant carries its own copy: one taken branch less)
+#define KZ6_NEXT                                               \
+    "s_mov_b32 %[prev], s40\n\t"                                \
+    "s_cmp_eq_u64 s[48:49], 0\n\t"                              \
+    "s_cbranch_scc1 L_done%=\n\t"                               \
+    "s_bitset0_b64 s[48:49], s41\n\t"                           \
+    "s_mov_b32 s40, s41\n\t"                                    \
+    "s_mov_b32 s42, s43\n\t"                                    \
+    "s_branch L_step%=\n\t"
+
 #define KZ6_ROWLOOP(XI, ZQ) asm volatile(                                                      \
     "s_mov_b64 s[48:49], %[nz]\n\t"                                                              \
     "s_mov_b32 %[prev], -1\n\t"                                                                  \
@@ -400,14 +410,7 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse5(const u8* __restrict__ sr
     "s_cmp_lg_u32 s57, 0\n\t"                                                                    \
     "s_cbranch_scc1 L_cold%=\n\t"                                                                \
     KZ6_HEAD(XI, "q0", "p0") KZ6_ROW0 KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL \
-  "L_next%=:\n\t"                                                                                \
-    "s_mov_b32 %[prev], s40\n\t"                                                                 \
-    "s_cmp_eq_u64 s[48:49], 0\n\t"                                                               \
-    "s_cbranch_scc1 L_done%=\n\t"                                                                \
-    "s_bitset0_b64 s[48:49], s41\n\t"                                                            \
-    "s_mov_b32 s40, s41\n\t"                                                                     \
-    "s_mov_b32 s42, s43\n\t"                                                                     \
-    "s_branch L_step%=\n\t"                                                                      \
+    KZ6_NEXT                                                                                     \
   "L_cold%=:\n\t"                                                                                \
     "s_cmp_eq_u32 s57, 1\n\t"                                                                    \
     "s_cbranch_scc1 L_k1%=\n\t"                                                                  \
@@ -416,21 +419,99 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse5(const u8* __restrict__ sr
     KZ6_HEAD(XI, "q3", "p3") KZ6_ROW_SHIFT("q3", "p3", "q2", "p2") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q3", "p3", "v91") \
     KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_ROW_APPLY("q2", "p2", "v91") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v91") \
     KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL                                        \
-    "s_branch L_next%=\n\t"                                                                      \
+    KZ6_NEXT                                                                                     \
   "L_k2%=:\n\t"                                                                                  \
     KZ6_HEAD(XI, "q2", "p2") KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q2", "p2", "v91") \
     KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v91") KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL \
-    "s_branch L_next%=\n\t"                                                                      \
+    KZ6_NEXT                                                                                     \
   "L_k1%=:\n\t"                                                                                  \
     KZ6_HEAD(XI, "q1", "p1") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q1", "p1", "v91") \
     KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL                                        \
-    "s_branch L_next%=\n\t"                                                                      \
+    KZ6_NEXT                                                                                     \
   "L_done%=:\n\t"                                                                                \
     : [q0]"+v"(Q0), [p0]"+v"(P0), [q1]"+v"(Q1), [p1]"+v"(P1), [q2]"+v"(Q2), [p2]"+v"(P2), [q3]"+v"(Q3), [p3]"+v"(P3),           \
       [tq0]"+v"(tq0), [outv]"+v"(outv), [fmv]"+v"(fmv), [prev]"=&s"(prev)                                                      \
     : [cur]"v"(cur), [ff]"v"(ff), [nz]"s"(nz), [row]"s"(row)                                                                   \
     : "vcc", "scc", "v90", "v91", "v92", "v93", "v94", "v95", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", \
       "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60");
+
+// Rows of 64 ranks with few zeros and few ranks >= 64 (poorly compressible data: the blocks that set the run time): straight-line
+// code, one step per rank with constant lane numbers, zero ranks included (a rank 0 is an ordinary step: M = lane 0).  No
+// loop control, no taken branch on the way; a rank >= 64 leaves through a stub to the row-spanning variants and comes back
+// with s_setpc.  RC / RN: the SGPRs holding this step's and the next step's rank (s64 / s65 alternate).
+#define KZ6A_STEP(J, JN, RC, RN, XI)                           \
+    "v_readlane_b32 " RN ", %[cur], " JN "\n\t"                  \
+    "s_and_b32 s44, " RC ", 63\n\t"                               \
+    "s_xor_b32 s45, s44, 63\n\t"                                  \
+    "s_lshr_b64 s[46:47], -1, s45\n\t"                            \
+    "s_lshl_b32 s60, s50, 1\n\t"                                  \
+    "s_cmp_ge_u32 " RC ", 64\n\t"                                 \
+    "s_cbranch_scc1 L_stub" J "_%=\n\t"                           \
+    KZ6_HEAD(XI, "q0", "p0") KZ6_ROW0 KZ6_THNQ KZ6_SETLE         \
+    "v_cmpx_le_u32 vcc, %[q0], v93\n\t"                          \
+    "v_cmp_lt_u32_e64 s[58:59], v93, %[tq0]\n\t"                 \
+    "s_add_u32 s50, s50, 1\n\t"                                  \
+    "s_nop 0\n\t"                                                \
+    "v_cndmask_b32_e64 %[q0], %[tq0], v94, s[58:59]\n\t"         \
+    "v_cndmask_b32_e64 %[p0], v90, v95, s[58:59]\n\t"            \
+    "s_mov_b64 exec, -1\n\t"                                     \
+    "v_writelane_b32 %[outv], s54, " J "\n\t"                    \
+  "L_after" J "_%=:\n\t"
+#define KZ6A_STUB(J, RC)                                       \
+  "L_stub" J "_%=:\n\t"                                          \
+    "s_mov_b32 s40, " J "\n\t"                                   \
+    "s_mov_b32 s42, " RC "\n\t"                                  \
+    "s_getpc_b64 s[62:63]\n\t"                                   \
+  "L_pc" J "_%=:\n\t"                                            \
+    "s_sub_u32 s62, s62, L_pc" J "_%=-L_after" J "_%=\n\t"       \
+    "s_subb_u32 s63, s63, 0\n\t"                                 \
+    "s_branch L_coldA_%=\n\t"
+#define KZ6A_STEP2(J0, J1, J2, XI) KZ6A_STEP(J0, J1, "s64", "s65", XI) KZ6A_STEP(J1, J2, "s65", "s64", XI)
+#define KZ6A_STUB2(J0, J1) KZ6A_STUB(J0, "s64") KZ6A_STUB(J1, "s65")
+#define KZ6A_STEPS(XI) \
+    KZ6A_STEP2("0", "1", "2", XI) KZ6A_STEP2("2", "3", "4", XI) KZ6A_STEP2("4", "5", "6", XI) KZ6A_STEP2("6", "7", "8", XI) \
+    KZ6A_STEP2("8", "9", "10", XI) KZ6A_STEP2("10", "11", "12", XI) KZ6A_STEP2("12", "13", "14", XI) KZ6A_STEP2("14", "15", "16", XI) \
+    KZ6A_STEP2("16", "17", "18", XI) KZ6A_STEP2("18", "19", "20", XI) KZ6A_STEP2("20", "21", "22", XI) KZ6A_STEP2("22", "23", "24", XI) \
+    KZ6A_STEP2("24", "25", "26", XI) KZ6A_STEP2("26", "27", "28", XI) KZ6A_STEP2("28", "29", "30", XI) KZ6A_STEP2("30", "31", "32", XI) \
+    KZ6A_STEP2("32", "33", "34", XI) KZ6A_STEP2("34", "35", "36", XI) KZ6A_STEP2("36", "37", "38", XI) KZ6A_STEP2("38", "39", "40", XI) \
+    KZ6A_STEP2("40", "41", "42", XI) KZ6A_STEP2("42", "43", "44", XI) KZ6A_STEP2("44", "45", "46", XI) KZ6A_STEP2("46", "47", "48", XI) \
+    KZ6A_STEP2("48", "49", "50", XI) KZ6A_STEP2("50", "51", "52", XI) KZ6A_STEP2("52", "53", "54", XI) KZ6A_STEP2("54", "55", "56", XI) \
+    KZ6A_STEP2("56", "57", "58", XI) KZ6A_STEP2("58", "59", "60", XI) KZ6A_STEP2("60", "61", "62", XI) KZ6A_STEP2("62", "63", "0", XI)
+#define KZ6A_STUBS \
+    KZ6A_STUB2("0", "1") KZ6A_STUB2("2", "3") KZ6A_STUB2("4", "5") KZ6A_STUB2("6", "7") KZ6A_STUB2("8", "9") KZ6A_STUB2("10", "11") \
+    KZ6A_STUB2("12", "13") KZ6A_STUB2("14", "15") KZ6A_STUB2("16", "17") KZ6A_STUB2("18", "19") KZ6A_STUB2("20", "21") KZ6A_STUB2("22", "23") \
+    KZ6A_STUB2("24", "25") KZ6A_STUB2("26", "27") KZ6A_STUB2("28", "29") KZ6A_STUB2("30", "31") KZ6A_STUB2("32", "33") KZ6A_STUB2("34", "35") \
+    KZ6A_STUB2("36", "37") KZ6A_STUB2("38", "39") KZ6A_STUB2("40", "41") KZ6A_STUB2("42", "43") KZ6A_STUB2("44", "45") KZ6A_STUB2("46", "47") \
+    KZ6A_STUB2("48", "49") KZ6A_STUB2("50", "51") KZ6A_STUB2("52", "53") KZ6A_STUB2("54", "55") KZ6A_STUB2("56", "57") KZ6A_STUB2("58", "59") \
+    KZ6A_STUB2("60", "61") KZ6A_STUB2("62", "63")
+#define KZ6A_RET "s_add_u32 s50, s50, 1\n\t" "s_setpc_b64 s[62:63]\n\t"
+#define KZ6_ROWDENSE(XI) asm volatile(                                                         \
+    "s_mov_b32 s50, %[row]\n\t"                                                                  \
+    "v_readlane_b32 s64, %[cur], 0\n\t"                                                          \
+    KZ6A_STEPS(XI)                                                                               \
+    "s_branch L_done%=\n\t"                                                                      \
+    KZ6A_STUBS                                                                                   \
+  "L_coldA_%=:\n\t"                                                                              \
+    "s_lshr_b32 s57, s42, 6\n\t"                                                                 \
+    "s_cmp_eq_u32 s57, 1\n\t"                                                                    \
+    "s_cbranch_scc1 L_k1%=\n\t"                                                                  \
+    "s_cmp_eq_u32 s57, 2\n\t"                                                                    \
+    "s_cbranch_scc1 L_k2%=\n\t"                                                                  \
+    KZ6_HEAD(XI, "q3", "p3") KZ6_ROW_SHIFT("q3", "p3", "q2", "p2") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q3", "p3", "v91") \
+    KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_ROW_APPLY("q2", "p2", "v91") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v91") \
+    KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL KZ6A_RET                               \
+  "L_k2%=:\n\t"                                                                                  \
+    KZ6_HEAD(XI, "q2", "p2") KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q2", "p2", "v91") \
+    KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v91") KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL KZ6A_RET \
+  "L_k1%=:\n\t"                                                                                  \
+    KZ6_HEAD(XI, "q1", "p1") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q1", "p1", "v91") \
+    KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL KZ6A_RET                               \
+  "L_done%=:\n\t"                                                                                \
+    : [q0]"+v"(Q0), [p0]"+v"(P0), [q1]"+v"(Q1), [p1]"+v"(P1), [q2]"+v"(Q2), [p2]"+v"(P2), [q3]"+v"(Q3), [p3]"+v"(P3),           \
+      [tq0]"+v"(tq0), [outv]"+v"(outv), [fmv]"+v"(fmv)                                                                         \
+    : [cur]"v"(cur), [ff]"v"(ff), [row]"s"(row)                                                                                \
+    : "vcc", "scc", "v90", "v91", "v92", "v93", "v94", "v95", "s40", "s42", "s44", "s45", "s46", "s47",                        \
+      "s50", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s62", "s63", "s64", "s65");
 
 // zero run of zr ranks ending at index pl, compiler form (row tails and all-zero rows)
 #define KZ6_ZERO_RUN(zr, plv)                                                                  \
@@ -464,9 +545,13 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
     u32 outv = 0;
     const u32 f0 = (u32)__builtin_amdgcn_readfirstlane((int)Q0) & 0xFFu;
     int prev = -1;
-    if (nz) {
+    const bool dense = cnt == 64 && __builtin_popcountll(nz) >= 48 && __builtin_popcountll(kz_ballot(cur >= 64u)) <= 6;
+    if (dense) {
+      if (MODE == 2) { KZ6_ROWDENSE(KZ6_XI_RANK) } else if (MODE == 1) { KZ6_ROWDENSE(KZ6_XI_MTF) } else { KZ6_ROWDENSE(KZ6_XI_TS) }
+    } else if (nz) {
       if (MODE == 2) { KZ6_ROWLOOP(KZ6_XI_RANK, KZ6_ZQ_RANK) } else if (MODE == 1) { KZ6_ROWLOOP(KZ6_XI_MTF, KZ6_ZQ_MTF) } else { KZ6_ROWLOOP(KZ6_XI_TS, KZ6_ZQ_TS) }
     }
+    if (!dense) {
     { const int zr = cnt - prev - 1; if (zr > 0) KZ6_ZERO_RUN(zr, row + cnt - 1) }
     {
       // zero-rank lane l: symbol of the last front change before l (held by that lane), else the front at row start
@@ -475,6 +560,7 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
       const int srcLane = below ? 63 - (int)__builtin_clzll(below) : 0;
       const u32 fv = (u32)__shfl((int)outv, srcLane, 64);
       if (!((nz >> lane) & 1ULL)) outv = below ? fv : f0;
+    }
     }
     if (lane < cnt) d[row + lane] = (u8)outv;
     cur = nxt;
