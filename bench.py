@@ -4,14 +4,23 @@
 One "step" = one pass of the hot path over one batch: kz_encode_blocks (BWT+RANK+ZRLT & ANS0, the
 level-5 core chain) followed by kz_decode_blocks of the produced block streams, inputs and outputs
 resident in HBM.  Blocks are independent (K/io/CompressedOutputStream.java:792,907): with N GPUs
-block g goes to rank g mod N, no collective on the data path (weak scaling: per-GPU work fixed).
+block g goes to rank g mod N, no collective on the data path.
 
-  python bench.py --gpus N --steps K --warmup W      (N>1: launched via torch.distributed.run)
-Prints ONE JSON line on rank 0.
+  python bench.py --gpus N --steps K --warmup W
+With N > 1 and no WORLD_SIZE in the environment the script re-executes itself under
+torch.distributed.run (one rank per GPU); launched by torch.distributed.run it uses the ranks it is given.
+Rank 0 prints ONE JSON line:
+  value              the bulk batch (--blocks 4 MiB blocks per GPU per step, weak scaling), timed without instrumentation
+  config.shapes      the same chain on batches of the size the metric names, split round-robin over the ranks
+                     (strong scaling): silesia (50 x 4 MiB + 2 242 560 B), enwik9 (238 x 4 MiB + 1 755 648 B), device
+                     resident; and the host-buffer, PCIe-inclusive kz_compress / kz_decompress rate on the silesia shape
+  roofline, kernels  from one extra instrumented step (HIP events around every launch on the context's stream)
+  cpu_baseline       the C oracle on this box's host cores (N = 1 only) + the reference's published row
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -22,32 +31,71 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+SILESIA_BYTES = 211957760      # 50 x 4 MiB + 2 242 560
+ENWIK9_BYTES = 1000000000      # 238 x 4 MiB + 1 755 648 (config 4)
+# /root/reference/README.md:86 (Kanzi 2.5.0, silesia.tar -l 5, Ryzen 9950X, 16 jobs): 1717 ms / 752 ms
+REFERENCE_PUBLISHED = {"source": "flanglet/kanzi README.md:86, silesia.tar -l 5, AMD Ryzen 9950X, Java 25, default jobs",
+                       "encode_MBps": 123.4, "decode_MBps": 281.9, "enc_dec_MBps": 85.8,
+                       "note": "other hardware; includes the TEXT+UTF stages of -l 5; no JVM on this box to run it here"}
 
 # kernel -> pipeline stage (for the algorithmic-byte attribution of SURVEY.md 8d)
 KERNEL_STAGE = {}
-for k in ("k_bwt_init", "k_radix_hist", "k_radix_scan", "k_radix_scatter", "k_seg_reduce", "k_seg_scan",
-          "k_seg_apply", "k_live_count", "k_live_scan", "k_live_emit", "k_bwt_emit"):
-    KERNEL_STAGE[k] = "bwt_fwd"
-for k in ("k_sbrt_last2", "k_sbrt_scan", "k_sbrt_replay"):
-    KERNEL_STAGE[k] = "sbrt_fwd"
-for k in ("k_zrlt_f1", "k_zrlt_f2", "k_zrlt_f3", "k_zrlt_ffin"):
-    KERNEL_STAGE[k] = "zrlt_fwd"
-for k in ("k_ans_enc_chunk", "k_ans_enc_scan", "k_ans_enc_concat"):
-    KERNEL_STAGE[k] = "ans_enc"
-for k in ("k_ans_dec_index", "k_ans_dec_chunk", "k_ans_dec_fin"):
-    KERNEL_STAGE[k] = "ans_dec"
-for k in ("k_zrlt_i1", "k_zrlt_i2", "k_zrlt_i3", "k_zrlt_ifin"):
-    KERNEL_STAGE[k] = "zrlt_inv"
-KERNEL_STAGE["k_sbrt_inverse"] = "sbrt_inv"
-for k in ("k_bwti_parse", "k_bwti_hist", "k_bwti_scan", "k_bwti_scatter", "k_bwti_walk1", "k_bwti_resolve", "k_bwti_copy", "k_bwti_literal", "k_bwti_fin"):
-    KERNEL_STAGE[k] = "bwt_inv"
+for _st, _ks in {
+    "bwt_fwd": ("k_bwt_init", "k_radix_hist", "k_radix_scan", "k_radix_scatter", "k_seg_reduce", "k_seg_scan", "k_seg_apply",
+                "k_live_count", "k_live_scan", "k_live_emit", "k_bwt_emit", "k_radix_hist3", "k_local_sort"),
+    "sbrt_fwd": ("k_sbrt_last2", "k_sbrt_scan", "k_sbrt_replay"),
+    "zrlt_fwd": ("k_zrlt_f1", "k_zrlt_f2", "k_zrlt_f3", "k_zrlt_ffin"),
+    "ans_enc": ("k_ans_enc_chunk", "k_ans_enc_scan", "k_ans_enc_concat"),
+    "ans_dec": ("k_ans_dec_index", "k_ans_dec_chunk", "k_ans_dec_fin"),
+    "huf_enc": ("k_huf_enc_chunk",), "huf_dec": ("k_huf_dec_index", "k_huf_dec_chunk", "k_huf_dec_fin"),
+    "fpaq_enc": ("k_fpaq_enc", "k_fpaq_pack"), "fpaq_dec": ("k_fpaq_dec",),
+    "zrlt_inv": ("k_zrlt_i1", "k_zrlt_i2", "k_zrlt_i3", "k_zrlt_ifin"),
+    "sbrt_inv": ("k_sbrt_inverse",),
+    "srt_fwd": ("k_srt_hist", "k_srt_prep", "k_srt_scatter"), "srt_inv": ("k_srt_inv",),
+    "lz_fwd": ("k_lz_fwd",), "lz_inv": ("k_lz_inv",),
+    "bwt_inv": ("k_bwti_parse", "k_bwti_hist", "k_bwti_scan", "k_bwti_scatter", "k_bwti_walk1", "k_bwti_resolve", "k_bwti_copy",
+                "k_bwti_literal", "k_bwti_fin"),
+}.items():
+    for _k in _ks:
+        KERNEL_STAGE[_k] = _st
 
 
-def stage_alg_bytes_per_input_byte(z, c):
-    """algorithmic HBM bytes per input byte, per stage. z = ZRLT-out/n, c = compressed/n.
-    ENC total 13+3z+c, DEC total 14+2z+c."""
-    return {"bwt_fwd": 10.0, "sbrt_fwd": 2.0, "zrlt_fwd": 1.0 + z, "ans_enc": 2.0 * z + c,
-            "ans_dec": c + z, "zrlt_inv": z + 1.0, "sbrt_inv": 2.0, "bwt_inv": 11.0}
+def stage_alg_bytes_per_input_byte(chain, entropy, z, c):
+    """algorithmic HBM bytes per input byte, per stage.  z = post-transform length / n (ZRLT-out or
+    LZ-out), c = compressed / n.  BWT+RANK+ZRLT&ANS0: ENC 13+3z+c, DEC 14+2z+c; BWT+SRT+ZRLT&FPAQ: ENC 14+2z+c,
+    DEC 14+2z+c; LZ*&HUFFMAN|ANS0: ENC 1+3l+c, DEC 1+2l+c (l = z)."""
+    names = chain.upper().split("+")
+    st = {}
+    if "BWT" in names:
+        st["bwt_fwd"], st["bwt_inv"] = 10.0, 11.0
+    if "RANK" in names or "MTFT" in names:
+        st["sbrt_fwd"], st["sbrt_inv"] = 2.0, 2.0
+    if "SRT" in names:
+        st["srt_fwd"], st["srt_inv"] = 3.0, 2.0           # count + code + write ; read + write
+        st["sbrt_fwd"] = 0.0                               # the MTF replay SRT shares with RANK is part of srt_fwd's 3 B/B
+    if "ZRLT" in names:
+        st["zrlt_fwd"], st["zrlt_inv"] = 1.0 + z, z + 1.0
+    if "LZ" in names or "LZX" in names:
+        st["lz_fwd"], st["lz_inv"] = 1.0 + z, z + 1.0
+    e = entropy.upper()
+    if e == "ANS0":
+        st["ans_enc"], st["ans_dec"] = 2.0 * z + c, c + z
+    elif e == "HUFFMAN":
+        st["huf_enc"], st["huf_dec"] = 2.0 * z + c, c + z
+        st["ans_enc"] = 0.0                                # the bit-concat kernels Huffman shares with ANS0
+    elif e == "FPAQ":
+        st["fpaq_enc"], st["fpaq_dec"] = z + c, c + z
+    enc = sum(v for k, v in st.items() if k.endswith("_fwd") or k.endswith("_enc"))
+    dec = sum(v for k, v in st.items() if k.endswith("_inv") or k.endswith("_dec"))
+    return st, enc, dec
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -55,17 +103,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=2048, help="4 MiB blocks per GPU per step (one wave per block in the serial kernels: throughput comes from blocks in flight)")
-    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic blocks generated per GPU; the step's blocks tile them (blocks are coded independently)")
+    ap.add_argument("--blocks", type=int, default=2048, help="4 MiB blocks per GPU per step of the bulk batch")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic blocks generated per GPU; batches tile them (blocks are coded independently)")
     ap.add_argument("--block-size", type=int, default=4 * 1024 * 1024)
     ap.add_argument("--chain", default="BWT+RANK+ZRLT")
     ap.add_argument("--entropy", default="ANS0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shapes", action="store_true", help="skip the silesia / enwik9 shaped batches and the host-buffer rate")
     ap.add_argument("--data-class", type=int, default=-1, help="diagnostic: force one class of the synthetic generator (0..4) instead of the mix")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"),
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"),
                     help="per-kernel HBM bytes from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)")
     ap.add_argument("--cpu-sample-blocks", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     args = ap.parse_args()
+
+    # ---- N > 1 without a launcher: start one rank per GPU ourselves (the driver's `python bench.py --gpus N`) ----
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
 
     import torch
     import kanzi_amd as kz
@@ -92,92 +147,110 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
-    B, bs = args.blocks, args.block_size
-    ctx = kz.Context(local_rank)
-    # ---- synthetic stream: global block g = i*world + rank (round-robin over ranks) ----
-    D = min(args.distinct, B)
-    host = np.empty((D, bs), dtype=np.uint8)
-    for i in range(D):
-        host[i] = datagen.block(i * world + rank, bs, None if args.data_class < 0 else args.data_class)
-    d_host = torch.from_numpy(host).to(dev)
-    d_in = d_host.repeat((B + D - 1) // D, 1)[:B].contiguous()
-    del d_host
-    o_stride = kz.max_block_stream_bytes(bs)
-    d_enc = torch.zeros((B, o_stride), dtype=torch.uint8, device=dev)
-    d_dec = torch.zeros((B, bs), dtype=torch.uint8, device=dev)
-    lengths = np.full(B, bs, dtype=np.int32)
-    torch.cuda.synchronize()
-
-    def step():
-        t0 = time.perf_counter()
-        res = kz.encode_blocks(ctx, args.chain, args.entropy, d_in.data_ptr(), bs, lengths, d_enc.data_ptr(), o_stride, kz.MEM_DEVICE)
-        t1 = time.perf_counter()
-        bits = np.array([r.bits for r in res], dtype=np.int64)
-        for r in res:
-            if r.status:
-                raise RuntimeError("encode status %d" % r.status)
-        res2 = kz.decode_blocks(ctx, args.chain, args.entropy, bs, d_enc.data_ptr(), o_stride, bits, d_dec.data_ptr(), bs, kz.MEM_DEVICE)
-        t2 = time.perf_counter()
-        for r in res2:
-            if r.status or r.length != bs:
-                raise RuntimeError("decode status %d len %d" % (r.status, r.length))
-        return t1 - t0, t2 - t1, res
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device="cpu" if share else dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t.tolist()]
+
+    B, bs = args.blocks, args.block_size
+    ctx = kz.Context(local_rank)
+    # ---- synthetic stream: the D distinct blocks of global ids i*world + rank (round-robin over ranks), tiled ----
+    D = min(args.distinct, B)
+    host = np.empty((D, bs), dtype=np.uint8)
+    for i in range(D):
+        host[i] = datagen.block(i * world + rank, bs, None if args.data_class < 0 else args.data_class)
+    d_host = torch.from_numpy(host).to(dev)
+    o_stride = kz.max_block_stream_bytes(bs)
+
+    class Batch:
+        """nb blocks of this rank resident in HBM (block k = distinct block k mod D), the last one tail_len bytes long"""
+
+        def __init__(self, nb, tail_len=bs):
+            self.nb = nb
+            self.lengths = np.full(nb, bs, dtype=np.int32)
+            if nb:
+                self.lengths[-1] = tail_len
+            self.nbytes = int(self.lengths.sum())
+            self.d_in = d_host.repeat((nb + D - 1) // D, 1)[:nb].contiguous() if nb else None
+            self.d_enc = torch.zeros((max(nb, 1), o_stride), dtype=torch.uint8, device=dev)
+            self.d_dec = torch.zeros((max(nb, 1), bs), dtype=torch.uint8, device=dev)
+
+        def step(self):
+            if self.nb == 0:
+                return 0.0, 0.0, []
+            t0 = time.perf_counter()
+            res = kz.encode_blocks(ctx, args.chain, args.entropy, self.d_in.data_ptr(), bs, self.lengths, self.d_enc.data_ptr(), o_stride, kz.MEM_DEVICE)
+            t1 = time.perf_counter()
+            bits = np.array([r.bits for r in res], dtype=np.int64)
+            for r in res:
+                if r.status:
+                    raise RuntimeError("encode status %d" % r.status)
+            res2 = kz.decode_blocks(ctx, args.chain, args.entropy, bs, self.d_enc.data_ptr(), o_stride, bits, self.d_dec.data_ptr(), bs, kz.MEM_DEVICE)
+            t2 = time.perf_counter()
+            for k, r in enumerate(res2):
+                if r.status or r.length != self.lengths[k]:
+                    raise RuntimeError("decode status %d len %d" % (r.status, r.length))
+            return t1 - t0, t2 - t1, res
+
+        def round_trip_ok(self):
+            if self.nb == 0:
+                return True
+            ok = bool(torch.equal(self.d_in[:-1], self.d_dec[:-1]))
+            tl = int(self.lengths[-1])
+            return ok and bool(torch.equal(self.d_in[-1, :tl], self.d_dec[-1, :tl]))
+
+    # ================= headline: the bulk batch, weak scaling, no instrumentation inside the timed region =================
+    bulk = Batch(B)
     for _ in range(args.warmup):
-        step()
-    ctx.set_kernel_timing(True)
-    ctx.reset_kernel_timing()
+        bulk.step()
     barrier()
     T0 = time.perf_counter()
     t_enc = t_dec = 0.0
     res = None
     for _ in range(args.steps):
-        a, b, res = step()
+        a, b, res = bulk.step()
         t_enc += a
         t_dec += b
     barrier()
     T1 = time.perf_counter()
-    ctx.set_kernel_timing(False)
-    elapsed = T1 - T0
-    tt = torch.tensor([elapsed, t_enc, t_dec], dtype=torch.float64, device="cpu" if share else dev)
-    if dist is not None:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed, t_enc, t_dec = [float(x) for x in tt.tolist()]
-
-    # ---- correctness outside the timed region: round trip identical ----
-    ok = bool(torch.equal(d_in, d_dec))
-    if not ok:
+    elapsed, t_enc, t_dec = max_over_ranks([T1 - T0, t_enc, t_dec])
+    if not bulk.round_trip_ok():
         raise SystemExit("round trip mismatch: decoded blocks differ from the input")
+    step_bytes = float(bulk.nbytes)
+    comp_bytes = float(sum((r.bits + 7) // 8 for r in res))
+    post_bytes = float(sum(r.length for r in res))
+    z, c = post_bytes / step_bytes, comp_bytes / step_bytes
+
+    # ---- one more step with HIP events around every kernel launch (context stream): kernel table + roofline ----
+    ctx.set_kernel_timing(True)
+    ctx.reset_kernel_timing()
+    bulk.step()
+    torch.cuda.synchronize()
+    ctx.set_kernel_timing(False)
+    ktimes = ctx.kernel_times()
 
     # ---- measured stream-copy rate of this GPU, printed next to the 8 TB/s spec peak (SURVEY 8d) ----
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    d_dec.copy_(d_in)
+    bulk.d_dec.copy_(bulk.d_in)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(3):
-        d_dec.copy_(d_in)
+        bulk.d_dec.copy_(bulk.d_in)
     e1.record()
     torch.cuda.synchronize()
     copy_gbs = 3 * 2.0 * B * bs / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
-    # ---- ratios + roofline ----
-    step_bytes = float(B) * bs
-    comp_bytes = float(sum((r.bits + 7) // 8 for r in res))
-    post_bytes = float(sum(r.length for r in res))
-    z, c = post_bytes / step_bytes, comp_bytes / step_bytes
-    ktimes = ctx.kernel_times()
-    per_stage_alg = stage_alg_bytes_per_input_byte(z, c)
-    roofline = None
+    per_stage_alg, alg_enc, alg_dec = stage_alg_bytes_per_input_byte(args.chain, args.entropy, z, c)
     kernels = []
     for name, v in ktimes.items():
-        kernels.append({"kernel": name, "ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps,
-                        "stage": KERNEL_STAGE.get(name, "frame")})
+        kernels.append({"kernel": name, "ms_per_step": v["ms"], "launches_per_step": v["launches"], "stage": KERNEL_STAGE.get(name, "frame")})
     kernels.sort(key=lambda k: -k["ms_per_step"])
     stage_ms = {}
     for k in kernels:
@@ -187,7 +260,7 @@ def main():
     try:
         with open(args.traffic_json) as f:
             tj = json.load(f)
-        if tj.get("blocks_per_gpu_per_step") != B or args.chain != "BWT+RANK+ZRLT" or args.entropy != "ANS0" or args.data_class >= 0:
+        if tj.get("blocks_per_gpu_per_step") != B or tj.get("chain", "BWT+RANK+ZRLT") != args.chain or tj.get("entropy", "ANS0") != args.entropy or args.data_class >= 0:
             tj = None
     except (OSError, ValueError):
         tj = None
@@ -196,6 +269,7 @@ def main():
             t = tj["kernels"].get(k["kernel"])
             if t and k["ms_per_step"] > 0:
                 k["hbm_traffic_GBs"] = t["hbm_bytes_per_launch"] * k["launches_per_step"] / (k["ms_per_step"] * 1e-3) / 1e9
+    roofline = None
     if kernels:
         dom = kernels[0]
         st = dom["stage"]
@@ -211,11 +285,69 @@ def main():
                     "kernel": dom["kernel"], "stage": st, "launches_per_step": launches, "avg_launch_ms": avg_ms,
                     "alg_bytes_per_launch": alg / launches,
                     "stage_achieved_GBs": (alg / (stage_ms[st] * 1e-3) / 1e9) if stage_ms.get(st) else None,
-                    "pipeline_enc_GBs": (13 + 3 * z + c) * step_bytes * args.steps / t_enc / 1e9,
-                    "pipeline_dec_GBs": (14 + 2 * z + c) * step_bytes * args.steps / t_dec / 1e9}
+                    "alg_bytes_per_input_byte": {"encode": alg_enc, "decode": alg_dec},
+                    "pipeline_enc_GBs": alg_enc * step_bytes * args.steps / t_enc / 1e9,
+                    "pipeline_dec_GBs": alg_dec * step_bytes * args.steps / t_dec / 1e9,
+                    "pipeline_frac": (alg_enc + alg_dec) * step_bytes * args.steps / (t_enc + t_dec) / 1e9 / HBM_PEAK_GBS}
 
     total_bytes = step_bytes * world * args.steps
     value = total_bytes / elapsed / 1e6
+
+    # ================= shaped batches: the sizes the metric names, split over the ranks (strong scaling) =================
+    shapes = {"bulk": {"blocks": B * world, "bytes": int(step_bytes) * world, "scaling": "weak",
+                       "encode_MBps": step_bytes * world * args.steps / t_enc / 1e6, "decode_MBps": step_bytes * world * args.steps / t_dec / 1e6,
+                       "enc_dec_MBps": value}}
+    del bulk
+    torch.cuda.empty_cache()
+    if not args.no_shapes:
+        for name, total in (("silesia", SILESIA_BYTES), ("enwik9", ENWIK9_BYTES)):
+            nblk = (total + bs - 1) // bs
+            mine = list(range(rank, nblk, world))                     # block g -> rank g mod N
+            tail = total - (nblk - 1) * bs if (mine and mine[-1] == nblk - 1) else bs
+            sb = Batch(len(mine), tail)
+            sb.step()
+            barrier()
+            S0 = time.perf_counter()
+            se = sd = 0.0
+            reps = 2
+            for _ in range(reps):
+                a, b, _r = sb.step()
+                se += a
+                sd += b
+            barrier()
+            S1 = time.perf_counter()
+            sel, se, sd = max_over_ranks([S1 - S0, se, sd])
+            if not sb.round_trip_ok():
+                raise SystemExit("round trip mismatch in the %s-shaped batch" % name)
+            shapes[name] = {"blocks": nblk, "bytes": total, "scaling": "strong", "blocks_on_rank0": len(mine),
+                            "encode_MBps": total * reps / se / 1e6, "decode_MBps": total * reps / sd / 1e6,
+                            "enc_dec_MBps": total * reps / sel / 1e6}
+            del sb
+            torch.cuda.empty_cache()
+        # host-buffer (PCIe-inclusive) rate through the stream entry points, silesia shape, rank 0's share; SURVEY 8d "two timings"
+        if rank == 0:
+            nblk = (SILESIA_BYTES + bs - 1) // bs
+            hdata = np.ascontiguousarray(np.tile(host, ((nblk + D - 1) // D, 1))[:nblk]).reshape(-1)[:SILESIA_BYTES]
+            tt, et = kz.transform_type(args.chain), kz.ENTROPY_IDS[args.entropy.upper()]
+            cap = int(ctx.lib.kz_compress_bound(hdata.size, bs))
+            knz = np.empty(cap, dtype=np.uint8)
+            back = np.empty(hdata.size, dtype=np.uint8)
+            best = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                m = ctx.check(ctx.lib.kz_compress(ctx.h, tt, et, bs, hdata.ctypes.data, hdata.size, knz.ctypes.data, cap))
+                t1 = time.perf_counter()
+                r = ctx.check(ctx.lib.kz_decompress(ctx.h, knz.ctypes.data, m, back.ctypes.data, hdata.size))
+                t2 = time.perf_counter()
+                if r != hdata.size or not np.array_equal(back, hdata):
+                    raise SystemExit("kz_compress / kz_decompress round trip mismatch")
+                row = {"bytes": int(hdata.size), "knz_bytes": int(m), "compress_MBps": hdata.size / (t1 - t0) / 1e6,
+                       "decompress_MBps": hdata.size / (t2 - t1) / 1e6, "enc_dec_MBps": hdata.size / (t2 - t0) / 1e6}
+                if best is None or row["enc_dec_MBps"] > best["enc_dec_MBps"]:
+                    best = row
+            best["what"] = "kz_compress / kz_decompress on pageable host buffers: H2D, codec, D2H and host bit assembly inside the timed region; one GPU"
+            shapes["silesia_host_pcie"] = best
+        barrier()
 
     out = {
         "metric": "encode+decode MB/s, 4 MiB-block synthetic stream, %s & %s (level-5 core chain), bit-exact .knz" % (args.chain, args.entropy),
@@ -226,7 +358,8 @@ def main():
                    "block_size": bs, "blocks_per_gpu_per_step": B, "parallelism": "blocks%%%d" % world,
                    "encode_MBps": step_bytes * world * args.steps / t_enc / 1e6,
                    "decode_MBps": step_bytes * world * args.steps / t_dec / 1e6,
-                   "z_post_transform_ratio": z, "c_compressed_ratio": c, "round_trip_ok": ok},
+                   "z_post_transform_ratio": z, "c_compressed_ratio": c, "round_trip_ok": True,
+                   "shapes": shapes},
         "roofline": roofline,
         "kernels": kernels[:12],
     }
@@ -254,9 +387,10 @@ def main():
         cos.close()
         pref = oracle.compress(args.chain, args.entropy, bs, psample, jobs=jobs)
         out["cpu_baseline"] = {"value": len(sample) / (t2 - t0) / 1e6, "unit": "MB/s", "cores": jobs, "kind": "port",
-                               "sample": "%d blocks (%d B; the %d distinct blocks tiled) of the same stream; oracle/libkzo.so (C restatement, SA-IS BWT), %d threads over blocks; enc %.2f s dec %.2f s" % (ns, len(sample), D, jobs, t1 - t0, t2 - t1),
+                               "sample": "%d blocks (%d B; the %d distinct blocks tiled) of the same stream; oracle/libkzo.so (C restatement, -O3 -march=x86-64-v3, SA-IS BWT), %d threads over blocks; enc %.2f s dec %.2f s" % (ns, len(sample), D, jobs, t1 - t0, t2 - t1),
                                "encode_MBps": len(sample) / (t1 - t0) / 1e6, "decode_MBps": len(sample) / (t2 - t1) / 1e6,
-                               "knz_identical_to_hip": bool(cos.output == pref)}
+                               "knz_identical_to_hip": bool(cos.output == pref),
+                               "reference_published": REFERENCE_PUBLISHED}
         if cos.output != pref:
             raise SystemExit("PARITY FAILURE: HIP .knz differs from the oracle on the cpu_baseline sample")
         # second row: the reference's default job count min(logical CPUs / 2, 64), on a smaller sample
@@ -272,7 +406,7 @@ def main():
             assert back2 == sample2.tobytes()
             row2 = {"value": len(sample2) / (t2 - t0) / 1e6, "unit": "MB/s", "cores": jobs2,
                     "encode_MBps": len(sample2) / (t1 - t0) / 1e6, "decode_MBps": len(sample2) / (t2 - t1) / 1e6,
-                    "sample": "%d blocks (%d B) of the same stream; oracle/libkzo.so (C restatement, SA-IS BWT), %d threads over blocks; enc %.2f s dec %.2f s" % (ns2, len(sample2), jobs2, t1 - t0, t2 - t1)}
+                    "sample": "%d blocks (%d B) of the same stream; oracle/libkzo.so (C restatement, -O3 -march=x86-64-v3, SA-IS BWT), %d threads over blocks; enc %.2f s dec %.2f s" % (ns2, len(sample2), jobs2, t1 - t0, t2 - t1)}
             cb = out["cpu_baseline"]
             row1 = {k: cb[k] for k in ("value", "unit", "cores", "encode_MBps", "decode_MBps", "sample")}
             # the headline CPU figure is the better of the two thread counts (oversubscribing SMT threads can lose)

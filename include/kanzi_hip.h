@@ -7,7 +7,10 @@
  *   kz_transform_forward / _inverse / _max_encoded_len
  *       K/ByteTransform.java:36,48,56  (boolean forward(SliceByteArray,SliceByteArray), inverse, getMaxEncodedLength)
  *       for the codecs K/transform/BWTBlockCodec.java:71-213, K/transform/SBRT.java:87-214 (RANK, MTFT),
- *       K/transform/ZRLT.java:54-233, K/transform/SRT.java:66-257, K/transform/LZCodec.java:299-756 (LZ, LZX).   "false" is a normal outcome (Sequence.java:95-105) -> return 0.
+ *       K/transform/ZRLT.java:54-233, K/transform/SRT.java:66-257, K/transform/LZCodec.java:299-756 (LZ, LZX),
+ *       K/transform/FSDCodec.java:60-323 (MM), K/transform/AliasCodec.java:76-475 (PACK, DNA), and, as host (CPU) stages in front of
+ *       the GPU chain, K/transform/TextCodec.java:482-531 (TEXT) and K/transform/UTFCodec.java:68-305 (UTF).
+ *       "false" is a normal outcome (Sequence.java:95-105) -> return 0.
  *   kz_entropy_encode / kz_entropy_decode
  *       K/EntropyEncoder.java:34 (int encode(byte[],int,int)) + dispose(), K/EntropyDecoder.java:33
  *       for K/entropy/ANSRangeEncoder.java:263-305, K/entropy/ANSRangeDecoder.java:189-236,
@@ -40,8 +43,8 @@ extern "C" {
 #define KZ_ABI_VERSION 2
 
 /* transform ids: K/transform/TransformFactory.java:36-60 */
-enum { KZ_T_NONE = 0, KZ_T_BWT = 1, KZ_T_LZ = 3, KZ_T_ZRLT = 6, KZ_T_MTFT = 7, KZ_T_RANK = 8,
-       KZ_T_SRT = 13, KZ_T_MM = 15, KZ_T_LZX = 16, KZ_T_PACK = 18, KZ_T_DNA = 19 };
+enum { KZ_T_NONE = 0, KZ_T_BWT = 1, KZ_T_LZ = 3, KZ_T_ZRLT = 6, KZ_T_MTFT = 7, KZ_T_RANK = 8, KZ_T_TEXT = 10 /* DICT_TYPE */,
+       KZ_T_SRT = 13, KZ_T_MM = 15, KZ_T_LZX = 16, KZ_T_UTF = 17, KZ_T_PACK = 18, KZ_T_DNA = 19 };
 /* Global.DataType (K/Global.java:40-80): the per-block context entry "dataType" that MM (FSDCodec.java:78-85,160-168)
    and LZ/LZX (LZCodec.java:343-352) read and write */
 enum { KZ_DT_UNDEFINED = 0, KZ_DT_DNA = 1, KZ_DT_SMALL_ALPHABET = 2, KZ_DT_TEXT = 3, KZ_DT_MULTIMEDIA = 4, KZ_DT_EXE = 5,
@@ -60,7 +63,7 @@ enum { KZ_MEM_HOST = 0, KZ_MEM_DEVICE = 1 };
 enum { KZ_STAGE_BWT_FWD = 0, KZ_STAGE_SBRT_FWD = 1, KZ_STAGE_ZRLT_FWD = 2, KZ_STAGE_ENTROPY_ENC = 3,
        KZ_STAGE_FRAME_ENC = 4, KZ_STAGE_ENTROPY_DEC = 5, KZ_STAGE_ZRLT_INV = 6, KZ_STAGE_SBRT_INV = 7,
        KZ_STAGE_BWT_INV = 8, KZ_STAGE_FRAME_DEC = 9, KZ_STAGE_LZ_FWD = 10, KZ_STAGE_LZ_INV = 11,
-       KZ_STAGE_SRT_FWD = 12, KZ_STAGE_SRT_INV = 13 };
+       KZ_STAGE_SRT_FWD = 12, KZ_STAGE_SRT_INV = 13, KZ_STAGE_HOST_FWD = 14, KZ_STAGE_HOST_INV = 15 };
 
 typedef struct kz_ctx kz_ctx;
 
@@ -80,6 +83,13 @@ int32_t     kz_ctx_set_checksum(kz_ctx* ctx, int32_t bits);
  * when its first bytes carry the magic number of a compressed format or its order-0 entropy is >= 0.95 * 8 bits
  * (K/io/CompressedOutputStream.java:769-788, Magic.isCompressed, Global.computeFirstOrderEntropy1024). Default off. */
 int32_t     kz_ctx_set_skip_blocks(kz_ctx* ctx, int32_t on);
+/* the "blockSize" and "entropy" keys of the context map as the TEXT transform reads them: TextCodec sizes its hash map by the
+ * stream's block size (K/transform/TextCodec.java:561-575,1068-1081) and TransformFactory picks TextCodec1 or TextCodec2 by the
+ * stream's entropy codec (TransformFactory.java:275-286).  kz_encode_blocks / kz_decode_blocks take the entropy codec from
+ * their own argument and the block size from here (default 4 MiB; kz_decode_blocks from its blockSize argument);
+ * kz_transform_forward / _inverse take both from here; kz_compress / kz_decompress set them from the stream. */
+int32_t     kz_ctx_set_block_size(kz_ctx* ctx, int32_t blockSize);
+int32_t     kz_ctx_set_entropy(kz_ctx* ctx, uint32_t entropyType);
 int32_t     kz_ctx_set_data_type(kz_ctx* ctx, int32_t dataType);
 int32_t     kz_ctx_get_data_type(kz_ctx* ctx);
 /* HIP stream the context launches on (as void* = hipStream_t) so callers can bracket it with events */
@@ -92,6 +102,14 @@ int32_t kz_transform_forward(kz_ctx* ctx, uint32_t type, const uint8_t* src, int
 int32_t kz_transform_inverse(kz_ctx* ctx, uint32_t type, const uint8_t* src, int32_t n,
                              uint8_t* dst, int32_t dstCap, int32_t* produced);
 int32_t kz_transform_max_encoded_len(uint32_t type, int32_t n);
+
+/* TEXT and UTF (KZ_T_TEXT, KZ_T_UTF) are host stages: the same ByteTransform contract without a context, no GPU touched.
+ * entropyType / blockSize = the "entropy" / "blockSize" entries of the reference's context map (TEXT only), *dataType = its
+ * "dataType" entry, read and updated (NULL = a transform built without a context). */
+int32_t kz_host_stage_forward(uint32_t type, uint32_t entropyType, int32_t blockSize, int32_t* dataType,
+                              const uint8_t* src, int32_t n, uint8_t* dst, int32_t dstCap, int32_t* produced);
+int32_t kz_host_stage_inverse(uint32_t type, int32_t blockSize, const uint8_t* src, int32_t n,
+                              uint8_t* dst, int32_t dstCap, int32_t* produced);
 
 /* ---- EntropyEncoder / EntropyDecoder mirror (host buffers; one block) ------------------------- */
 /* returns number of BITS written to out (MSB first, last byte zero padded), <0 = error */

@@ -23,14 +23,15 @@ LIB_PATH = os.path.join(_HERE, "libkanzi_hip.so")
 # transform ids (K/transform/TransformFactory.java:36-60) and entropy ids (K/entropy/EntropyCodecFactory.java)
 NONE_TYPE, BWT_TYPE, LZ_TYPE, ZRLT_TYPE, MTFT_TYPE, RANK_TYPE, SRT_TYPE, MM_TYPE, LZX_TYPE, PACK_TYPE, DNA_TYPE = 0, 1, 3, 6, 7, 8, 13, 15, 16, 18, 19
 E_NONE, E_HUFFMAN, E_FPAQ, E_ANS0 = 0, 1, 2, 5
-TRANSFORM_IDS = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "MM": 15, "LZX": 16, "PACK": 18, "DNA": 19}
+TRANSFORM_IDS = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "TEXT": 10, "SRT": 13, "MM": 15, "LZX": 16, "UTF": 17, "PACK": 18, "DNA": 19}
+TEXT_TYPE, UTF_TYPE = 10, 17
 # Global.DataType (K/Global.java:40-80), numbered as KZ_DT_* in include/kanzi_hip.h
 DATA_TYPES = {"UNDEFINED": 0, "DNA": 1, "SMALL_ALPHABET": 2, "TEXT": 3, "MULTIMEDIA": 4, "EXE": 5, "NUMERIC": 6, "BASE64": 7, "BIN": 8, "UTF8": 9}
 ENTROPY_IDS = {"NONE": 0, "HUFFMAN": 1, "FPAQ": 2, "ANS0": 5}
 MEM_HOST, MEM_DEVICE = 0, 1
 
 STAGE_NAMES = ["bwt_fwd", "sbrt_fwd", "zrlt_fwd", "entropy_enc", "frame_enc",
-               "entropy_dec", "zrlt_inv", "sbrt_inv", "bwt_inv", "frame_dec", "lz_fwd", "lz_inv", "srt_fwd", "srt_inv"]
+               "entropy_dec", "zrlt_inv", "sbrt_inv", "bwt_inv", "frame_dec", "lz_fwd", "lz_inv", "srt_fwd", "srt_inv", "host_fwd", "host_inv"]
 
 
 class KanziError(RuntimeError):
@@ -68,11 +69,15 @@ def load_library():
         "kz_ctx_stream": (vp, [vp]),
         "kz_ctx_set_checksum": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_set_skip_blocks": (c.c_int32, [vp, c.c_int32]),
+        "kz_ctx_set_block_size": (c.c_int32, [vp, c.c_int32]),
+        "kz_ctx_set_entropy": (c.c_int32, [vp, c.c_uint32]),
         "kz_ctx_set_data_type": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_get_data_type": (c.c_int32, [vp]),
         "kz_transform_forward": (c.c_int32, [vp, c.c_uint32, u8p, c.c_int32, u8p, c.c_int32, i32p]),
         "kz_transform_inverse": (c.c_int32, [vp, c.c_uint32, u8p, c.c_int32, u8p, c.c_int32, i32p]),
         "kz_transform_max_encoded_len": (c.c_int32, [c.c_uint32, c.c_int32]),
+        "kz_host_stage_forward": (c.c_int32, [c.c_uint32, c.c_uint32, c.c_int32, i32p, u8p, c.c_int32, u8p, c.c_int32, i32p]),
+        "kz_host_stage_inverse": (c.c_int32, [c.c_uint32, c.c_int32, u8p, c.c_int32, u8p, c.c_int32, i32p]),
         "kz_entropy_encode": (c.c_int64, [vp, c.c_uint32, u8p, c.c_int32, u8p, c.c_int64]),
         "kz_entropy_decode": (c.c_int32, [vp, c.c_uint32, u8p, c.c_int64, u8p, c.c_int32, i64p]),
         "kz_encode_blocks": (c.c_int32, [vp, c.c_uint64, c.c_uint32, u8p, c.c_int64, i32p, c.c_int32, u8p, c.c_int64, vp, c.c_int32]),
@@ -105,8 +110,8 @@ def load_library():
 
 
 ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_error", "kz_ctx_stream", "kz_ctx_set_checksum",
-               "kz_ctx_set_data_type", "kz_ctx_get_data_type", "kz_ctx_set_skip_blocks",
-               "kz_transform_forward", "kz_transform_inverse", "kz_transform_max_encoded_len",
+               "kz_ctx_set_data_type", "kz_ctx_get_data_type", "kz_ctx_set_skip_blocks", "kz_ctx_set_block_size", "kz_ctx_set_entropy",
+               "kz_transform_forward", "kz_transform_inverse", "kz_transform_max_encoded_len", "kz_host_stage_forward", "kz_host_stage_inverse",
                "kz_entropy_encode", "kz_entropy_decode", "kz_encode_blocks", "kz_decode_blocks",
                "kz_max_block_stream_bytes", "kz_compress", "kz_decompress", "kz_compress_bound", "kz_transform_type",
                "kz_knz_assemble", "kz_knz_index",
@@ -116,8 +121,8 @@ ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_err
 
 
 # The reference's compression levels (K/app/BlockCompressor.java:537-573, getTransformAndCodec) as "transforms&entropy".
-# Levels 0-2 consist of stages built here; 3, 5 and 6 are listed with the part that is (their leading TEXT+UTF stages
-# are CPU pre-transforms that are not built: SURVEY 8 f-2); 4 and 7-9 need ROLZ / EXE / LZP / CM / TPAQ.
+# Levels 0-3, 5 and 6 consist of stages built here (TEXT and UTF run as host stages in front of the GPU chain);
+# 4 and 7-9 need ROLZ / EXE / LZP / CM / TPAQ.
 LEVELS = {0: "NONE&NONE", 1: "LZX&NONE", 2: "DNA+LZ&HUFFMAN", 3: "TEXT+UTF+PACK+MM+LZX&HUFFMAN", 4: "TEXT+UTF+EXE+PACK+MM+ROLZ&NONE",
           5: "TEXT+UTF+BWT+RANK+ZRLT&ANS0", 6: "TEXT+UTF+BWT+SRT+ZRLT&FPAQ", 7: "LZP+TEXT+UTF+BWT+LZP&CM",
           8: "EXE+RLT+TEXT+UTF+DNA&TPAQ", 9: "EXE+RLT+TEXT+UTF+DNA&TPAQX"}
@@ -134,6 +139,34 @@ def level_chain(level, allow_partial=False):
     if missing:
         raise KanziError(3, "level %d needs %s, not built here" % (level, "/".join(missing)))       # ERR_INVALID_CODEC
     return "+".join(names), e
+
+
+def host_stage_forward(name, data, entropy="NONE", block_size=4 * 1024 * 1024, data_type=0, cap=None):
+    """TEXT / UTF forward on the host (no context, no GPU) -> (applied, bytes, data type after the call)"""
+    L = load_library()
+    a = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
+    t = TRANSFORM_IDS[name.upper()]
+    if cap is None:
+        cap = int(L.kz_transform_max_encoded_len(t, len(a)))
+    out = np.zeros(max(cap, 1) + 64, dtype=np.uint8)
+    p, dt = ctypes.c_int32(0), ctypes.c_int32(int(data_type))
+    r = L.kz_host_stage_forward(t, ENTROPY_IDS[entropy.upper()], int(block_size), ctypes.addressof(dt), a.ctypes.data if len(a) else out.ctypes.data, len(a),
+                                out.ctypes.data, cap, ctypes.addressof(p))
+    if r < 0:
+        raise KanziError(-r, "host_stage_forward")
+    return bool(r), out[:p.value].tobytes(), int(dt.value)
+
+
+def host_stage_inverse(name, data, cap, block_size=4 * 1024 * 1024):
+    """TEXT / UTF inverse on the host -> (ok, bytes)"""
+    L = load_library()
+    a = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
+    out = np.zeros(max(cap, 1) + 64, dtype=np.uint8)
+    p = ctypes.c_int32(0)
+    r = L.kz_host_stage_inverse(TRANSFORM_IDS[name.upper()], int(block_size), a.ctypes.data if len(a) else out.ctypes.data, len(a), out.ctypes.data, cap, ctypes.addressof(p))
+    if r < 0:
+        raise KanziError(-r, "host_stage_inverse")
+    return bool(r), out[:p.value].tobytes()
 
 
 def transform_type(names):
@@ -190,6 +223,14 @@ class Context:
     def set_skip_blocks(self, on):
         """The context map's "skipBlocks" entry (CLI --skip): incompressible-looking blocks become copy blocks."""
         self.check(self.lib.kz_ctx_set_skip_blocks(self.h, 1 if on else 0))
+
+    def set_block_size(self, block_size):
+        """The context map's "blockSize" entry (the stream's block size): TEXT sizes its hash map by it."""
+        self.check(self.lib.kz_ctx_set_block_size(self.h, int(block_size)))
+
+    def set_entropy(self, entropy):
+        """The context map's "entropy" entry for single-transform calls: TEXT is TextCodec2 for NONE/ANS0/HUFFMAN/RANGE, else TextCodec1."""
+        self.check(self.lib.kz_ctx_set_entropy(self.h, ENTROPY_IDS[entropy.upper()] if isinstance(entropy, str) else int(entropy)))
 
     def set_data_type(self, data_type):
         """The context map's "dataType" entry (a DATA_TYPES name or value) that the next transform instance will see."""
@@ -282,6 +323,21 @@ class _Transform:
 
 class BWTBlockCodec(_Transform):
     TYPE = BWT_TYPE            # K/transform/BWTBlockCodec.java
+
+
+class TextCodec(_Transform):
+    """K/transform/TextCodec.java (host stage).  Like the reference's constructor it takes the variant from the context map:
+    entropy (TextCodec2 for NONE / ANS0 / HUFFMAN / RANGE, else TextCodec1) and blockSize (hash map size)."""
+    TYPE = TEXT_TYPE
+
+    def __init__(self, ctx, entropy="NONE", blockSize=4 * 1024 * 1024):
+        super().__init__(ctx)
+        ctx.set_entropy(entropy)
+        ctx.set_block_size(blockSize)
+
+
+class UTFCodec(_Transform):
+    TYPE = UTF_TYPE            # K/transform/UTFCodec.java (host stage)
 
 
 class ZRLT(_Transform):

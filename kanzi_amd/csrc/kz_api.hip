@@ -5,6 +5,9 @@
 #include "kz_internal.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
+#include <memory>
+#include <thread>
 
 typedef uint32_t u32;
 typedef uint8_t u8;
@@ -52,6 +55,17 @@ extern "C" int32_t kz_ctx_set_data_type(kz_ctx* ctx, int32_t dataType) {
   ctx->dataType = dataType;
   return 0;
 }
+// ctx map keys "blockSize" and "entropy" as TEXT reads them (TextCodec.java:561-575,1068-1081; TransformFactory.java:275-286)
+extern "C" int32_t kz_ctx_set_block_size(kz_ctx* ctx, int32_t blockSize) {
+  if (!ctx || blockSize < 1024 || blockSize > (1 << 30) || (blockSize & 15)) return -KZ_ERR_BLOCK_SIZE;   // CompressedOutputStream.java:165-174
+  ctx->blockSize = blockSize;
+  return 0;
+}
+extern "C" int32_t kz_ctx_set_entropy(kz_ctx* ctx, uint32_t entropyType) {
+  if (!ctx || entropyType > 9 || entropyType == 3) return -KZ_ERR_INVALID_CODEC;
+  ctx->entropy = (int)entropyType;
+  return 0;
+}
 extern "C" int32_t kz_ctx_get_data_type(kz_ctx* ctx) { return ctx ? ctx->dataType : -KZ_ERR_INVALID_PARAM; }
 extern "C" const char* kz_last_error(kz_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 extern "C" void* kz_ctx_stream(kz_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
@@ -66,6 +80,16 @@ int kz_hpin_reserve(kz_ctx* ctx, size_t ints) {
   KZ_HIP(hipHostMalloc((void**)&ctx->hpin, ints * 4, hipHostMallocDefault));
   ctx->hpinInts = ints;
   return 0;
+}
+
+void kz_parallel_for(int n, int maxThreads, void (*fn)(int, void*), void* arg) {
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int T = std::max(1, std::min(std::min(n, maxThreads), hw > 0 ? hw : 1));
+  if (T == 1) { for (int i = 0; i < n; i++) fn(i, arg); return; }
+  std::atomic<int> next(0);
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; t++) th.emplace_back([&]() { for (;;) { const int i = next.fetch_add(1); if (i >= n) break; fn(i, arg); } });
+  for (auto& x : th) x.join();
 }
 
 int kz_arena_reserve(kz_ctx* ctx, size_t total) {
@@ -135,6 +159,7 @@ extern "C" int32_t kz_transform_max_encoded_len(uint32_t type, int32_t n) {
     case KZ_T_LZ: case KZ_T_LZX: return ((n <= 1024) ? n + 16 : n + (n / 64)) + 2;   // LZCodec.java:961-964
     case KZ_T_MM: return n + std::max(64, n >> 4);                   // FSDCodec.java:320-323
     case KZ_T_PACK: case KZ_T_DNA: return n + 1024;                  // AliasCodec.java:472-475
+    case KZ_T_UTF: return n + 8192;                                  // UTFCodec.java:308-310
     default: return n;                                               // ZRLT.java:243, SBRT.java:224
   }
 }
@@ -151,7 +176,7 @@ static int split_types(uint64_t tt, int* types) {                    // Transfor
   for (int i = 0; i < nbtr; i++) { int t = (int)((tt >> (42 - 6 * i)) & 0x3F); if (t != KZ_T_NONE || i == 0) types[k++] = t; }
   return k;
 }
-static bool transform_supported(int t) { return t == KZ_T_NONE || t == KZ_T_BWT || t == KZ_T_RANK || t == KZ_T_MTFT || t == KZ_T_ZRLT || t == KZ_T_SRT || t == KZ_T_LZ || t == KZ_T_LZX || t == KZ_T_MM || t == KZ_T_PACK || t == KZ_T_DNA; }
+static bool transform_supported(int t) { return t == KZ_T_NONE || t == KZ_T_TEXT || t == KZ_T_UTF || t == KZ_T_BWT || t == KZ_T_RANK || t == KZ_T_MTFT || t == KZ_T_ZRLT || t == KZ_T_SRT || t == KZ_T_LZ || t == KZ_T_LZX || t == KZ_T_MM || t == KZ_T_PACK || t == KZ_T_DNA; }
 static bool entropy_supported(int e) { return e == KZ_E_NONE || e == KZ_E_ANS0 || e == KZ_E_HUFFMAN || e == KZ_E_FPAQ; }
 static int seq_max_len(const int* types, int nb, int n) {             // Sequence.java:215-226
   int req = n;
@@ -440,6 +465,81 @@ static int stage_id(int type, bool forward) {
 }
 
 // =================================================================================================
+// host (CPU) stages: TEXT and UTF lead the chains of the reference's levels 3, 5 and 6.  They are sequential dictionary coders
+// (kz_text.hip); the batched calls run them per block on host threads, in front of the GPU stages when encoding and behind
+// them when decoding, and carry their skip flags and the block's "dataType" entry through like Sequence does.
+static int host_prefix(kz_ctx* ctx, const int* types, int nb) {          // number of leading host stages, or <0
+  int hp = 0;
+  while (hp < nb && kz_is_host_transform(types[hp])) hp++;
+  for (int i = hp; i < nb; i++)
+    if (kz_is_host_transform(types[i])) {
+      snprintf(ctx->err, sizeof(ctx->err), "TEXT / UTF are built as host stages in front of the GPU stages only (as in the reference's levels)");
+      return -KZ_ERR_INVALID_CODEC;
+    }
+  return hp;
+}
+struct HostFwd {
+  kz_ctx* ctx; const int* types; int hp; int entropy; int cap;
+  const uint8_t* hsrc; int64_t hstride;             // the blocks in host memory
+  uint8_t* dbuf; int64_t dstride;                   // their slots in HBM
+  const int32_t* lengths; const int32_t* copy;
+  int32_t* outLen; int32_t* skip; int32_t* dtype; std::atomic<int> fail{0};
+};
+static void host_forward_block(int b, void* arg) {
+  HostFwd& H = *(HostFwd*)arg;
+  const int n = H.lengths[b];
+  H.outLen[b] = n;
+  H.dtype[b] = KZ_DT_UNDEFINED;
+  if (n == 0 || H.copy[b]) return;
+  static thread_local std::vector<uint8_t> bufA, bufB;
+  if ((int)bufA.size() < H.cap + 64) { bufA.resize((size_t)H.cap + 64); bufB.resize((size_t)H.cap + 64); }
+  const uint8_t* cur = H.hsrc + (int64_t)b * H.hstride;
+  int dt = kz_host_block_data_type(cur, n, KZ_DT_UNDEFINED);            // CompressedOutputStream.java:795-804
+  int len = n;
+  uint8_t* out = bufA.data();
+  for (int i = 0; i < H.hp; i++) {
+    int produced = 0;
+    if (!kz_host_transform_forward(H.types[i], H.entropy, H.ctx->blockSize, &dt, cur, len, out, H.cap, &produced)) continue;   // declined: data untouched
+    H.skip[b] &= ~(1 << (7 - i));
+    cur = out; len = produced;
+    out = (out == bufA.data()) ? bufB.data() : bufA.data();
+  }
+  H.dtype[b] = dt;
+  if (cur != H.hsrc + (int64_t)b * H.hstride) {                         // a stage applied: the block in HBM is replaced
+    if (hipSetDevice(H.ctx->device) != hipSuccess || hipMemcpy(H.dbuf + (int64_t)b * H.dstride, cur, (size_t)len, hipMemcpyHostToDevice) != hipSuccess) H.fail = 1;
+    H.outLen[b] = len;
+  }
+}
+struct HostInv {
+  kz_ctx* ctx; const int* types; int hp; int blockSize; int cap;
+  uint8_t* dbuf; int64_t dstride;
+  int32_t* len; const int32_t* skip; int32_t* status; std::atomic<int> fail{0};
+};
+static void host_inverse_block(int b, void* arg) {
+  HostInv& H = *(HostInv*)arg;
+  int len = H.len[b];
+  if (H.status[b] || len <= 0) return;
+  bool any = false;
+  for (int i = 0; i < H.hp; i++) any |= !(H.skip[b] & (1 << (7 - i)));
+  if (!any) return;
+  static thread_local std::vector<uint8_t> bufA, bufB;
+  const size_t need = (size_t)std::max(H.cap, len) + 64;
+  if (bufA.size() < need) { bufA.resize(need); bufB.resize(need); }
+  if (hipSetDevice(H.ctx->device) != hipSuccess || hipMemcpy(bufA.data(), H.dbuf + (int64_t)b * H.dstride, (size_t)len, hipMemcpyDeviceToHost) != hipSuccess) { H.fail = 1; return; }
+  uint8_t* cur = bufA.data();
+  uint8_t* out = bufB.data();
+  for (int i = H.hp - 1; i >= 0; i--) {                                 // Sequence.inverse: last applied first
+    if (H.skip[b] & (1 << (7 - i))) continue;
+    int produced = 0;
+    if (!kz_host_transform_inverse(H.types[i], H.blockSize, cur, len, out, H.cap, &produced)) { H.status[b] = -KZ_ERR_PROCESS_BLOCK; H.len[b] = 0; return; }
+    len = produced;
+    std::swap(cur, out);
+  }
+  if (hipMemcpy(H.dbuf + (int64_t)b * H.dstride, cur, (size_t)len, hipMemcpyHostToDevice) != hipSuccess) { H.fail = 1; return; }
+  H.len[b] = len;
+}
+
+// =================================================================================================
 // encode
 extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType,
                                     const uint8_t* in, int64_t inStride, const int32_t* lengths, int32_t nBlocks,
@@ -452,6 +552,8 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   for (int i = 0; i < nb; i++) if (!transform_supported(types[i])) { snprintf(ctx->err, sizeof(ctx->err), "unsupported transform id %d", types[i]); return -KZ_ERR_INVALID_CODEC; }
   if (!entropy_supported((int)entropyType)) { snprintf(ctx->err, sizeof(ctx->err), "unsupported entropy id %u", entropyType); return -KZ_ERR_INVALID_CODEC; }
   const int B = nBlocks;
+  const int hp = host_prefix(ctx, types, nb);
+  if (hp < 0) return hp;
   int maxN = 0;
   for (int b = 0; b < B; b++) { if (lengths[b] < 0) return -KZ_ERR_INVALID_PARAM; maxN = std::max(maxN, lengths[b]); }
   const int maxLen = seq_max_len(types, nb, maxN);
@@ -533,7 +635,34 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     KZ_HIP(hipStreamSynchronize(st));
     for (int b = 0; b < B; b++) if (ctx->hpin[b]) h_copy[b] = 1;
   }
-  for (int i = 0; i < nb; i++) {
+  if (hp > 0) {
+    // host stages (TEXT, UTF): per block on host threads; a block a stage applied to is replaced in HBM, its skip flag bits and
+    // its "dataType" entry (the writer's Magic tag, then whatever TEXT / UTF leave there) go on to the GPU stages
+    hipEvent_t e0; kz_stage_begin(ctx, &e0);
+    std::unique_ptr<uint8_t[]> hostCopy;
+    const uint8_t* hsrc = in;
+    int64_t hstride = inStride;
+    if (!host) {
+      hostCopy.reset(new uint8_t[(size_t)B * (size_t)maxN + 64]);
+      for (int b = 0; b < B; b++)
+        if (lengths[b]) KZ_HIP(hipMemcpyAsync(hostCopy.get() + (size_t)b * maxN, in + (int64_t)b * inStride, (size_t)lengths[b], hipMemcpyDeviceToHost, st));
+      hsrc = hostCopy.get(); hstride = maxN;
+    }
+    KZ_HIP(hipStreamSynchronize(st));                                            // the blocks are in HBM, hashed and tagged: slots may be rewritten
+    std::vector<int32_t> h_dt(B), h_out(B);
+    HostFwd H;
+    H.ctx = ctx; H.types = types; H.hp = hp; H.entropy = (int)entropyType; H.cap = maxLen;
+    H.hsrc = hsrc; H.hstride = hstride; H.dbuf = bt.buf[0]; H.dstride = bt.stride;
+    H.lengths = lengths; H.copy = h_copy.data(); H.outLen = h_out.data(); H.skip = h_skip.data(); H.dtype = h_dt.data();
+    kz_parallel_for(B, 256, host_forward_block, &H);
+    if (H.fail) { snprintf(ctx->err, sizeof(ctx->err), "host stage: copy to the device failed"); return -KZ_ERR_DEVICE; }
+    for (int b = 0; b < B; b++) bt.h_len[b] = h_out[b];
+    KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    KZ_HIP(hipMemcpyAsync(bt.d_dtype, h_dt.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    KZ_HIP(hipStreamSynchronize(st));                                            // h_dt is a local
+    kz_stage_end(ctx, e0, KZ_STAGE_HOST_FWD, 0);
+  }
+  for (int i = hp; i < nb; i++) {
     for (int b = 0; b < B; b++) h_mask[b] = (!h_copy[b] && bt.h_len[b] > 0) ? 1 : 0;
     if (types[i] == KZ_T_NONE) { for (int b = 0; b < B; b++) if (h_mask[b]) h_skip[b] &= ~(1 << (7 - i)); continue; }
     hipEvent_t e0; kz_stage_begin(ctx, &e0);
@@ -683,6 +812,8 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   for (int i = 0; i < nb; i++) if (!transform_supported(types[i])) { snprintf(ctx->err, sizeof(ctx->err), "unsupported transform id %d", types[i]); return -KZ_ERR_INVALID_CODEC; }
   if (!entropy_supported((int)entropyType)) { snprintf(ctx->err, sizeof(ctx->err), "unsupported entropy id %u", entropyType); return -KZ_ERR_INVALID_CODEC; }
   const int B = nBlocks;
+  const int hp = host_prefix(ctx, types, nb);
+  if (hp < 0) return hp;
   const bool host = memKind == KZ_MEM_HOST;
   // decoder's working size: blockSize + max(512, blockSize/16) (CompressedInputStream.java:694-695)
   const int dataCap = blockSize + std::max(512, blockSize >> 4);
@@ -745,15 +876,15 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   hipEvent_t e0; kz_stage_begin(ctx, &e0);
   KZ_LAUNCH(ctx, KID_FRAME_PARSE, k_frame_parse, dim3((B + 255) / 256), dim3(256), d_in, inS, d_bitLen, F, nb, maxLen, (entropyType == KZ_E_NONE) ? 1 : 0, B);
   // read back descriptors
-  int32_t* hp = ctx->hpin + 4 * B;
-  KZ_HIP(hipMemcpyAsync(hp + 0 * B, F.preLen, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-  KZ_HIP(hipMemcpyAsync(hp + 1 * B, F.skipFlags, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-  KZ_HIP(hipMemcpyAsync(hp + 2 * B, F.raw, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-  KZ_HIP(hipMemcpyAsync(hp + 3 * B, F.tcopy, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-  KZ_HIP(hipMemcpyAsync(hp + 4 * B, F.status, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  int32_t* hpb = ctx->hpin + 4 * B;
+  KZ_HIP(hipMemcpyAsync(hpb + 0 * B, F.preLen, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  KZ_HIP(hipMemcpyAsync(hpb + 1 * B, F.skipFlags, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  KZ_HIP(hipMemcpyAsync(hpb + 2 * B, F.raw, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  KZ_HIP(hipMemcpyAsync(hpb + 3 * B, F.tcopy, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  KZ_HIP(hipMemcpyAsync(hpb + 4 * B, F.status, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   KZ_HIP(hipStreamSynchronize(st));
   kz_stage_end(ctx, e0, KZ_STAGE_FRAME_DEC, 0);
-  std::vector<int32_t> h_pre(hp, hp + B), h_skip(hp + B, hp + 2 * B), h_raw(hp + 2 * B, hp + 3 * B), h_tc(hp + 3 * B, hp + 4 * B), h_status(hp + 4 * B, hp + 5 * B);
+  std::vector<int32_t> h_pre(hpb, hpb + B), h_skip(hpb + B, hpb + 2 * B), h_raw(hpb + 2 * B, hpb + 3 * B), h_tc(hpb + 3 * B, hpb + 4 * B), h_status(hpb + 4 * B, hpb + 5 * B);
   for (int b = 0; b < B; b++) bt.h_len[b] = h_status[b] ? 0 : h_pre[b];
   KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
 
@@ -784,7 +915,7 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   // (for RANK behind ZRLT that is the ZRLT-coded length ~ the number of non-zero ranks)
   std::vector<int32_t> prevIn(B);
   for (int b = 0; b < B; b++) prevIn[b] = (int32_t)std::min<int64_t>((bitLengths[b] + 7) >> 3, 0x7FFFFFFF);
-  for (int i = nb - 1; i >= 0; i--) {
+  for (int i = nb - 1; i >= hp; i--) {
     if (types[i] == KZ_T_NONE) continue;
     bt.h_cost = prevIn;
     prevIn = bt.h_len;
@@ -798,6 +929,20 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     int64_t outBytes = 0; for (int b = 0; b < B; b++) if (h_mask[b]) outBytes += bt.h_len[b];
     kz_stage_end(ctx, e1, stage_id(type, false), outBytes);
     for (int b = 0; b < B; b++) if (h_mask[b] && !h_applied[b]) { h_status[b] = -KZ_ERR_PROCESS_BLOCK; bt.h_len[b] = 0; }
+  }
+  if (hp > 0) {
+    // host stages (UTF, TEXT inverse) behind the GPU stages: blocks that went through one come back to the host, are decoded
+    // on host threads and return to their slot
+    hipEvent_t e1; kz_stage_begin(ctx, &e1);
+    KZ_HIP(hipStreamSynchronize(st));
+    HostInv H;
+    H.ctx = ctx; H.types = types; H.hp = hp; H.blockSize = blockSize; H.cap = dataCap;
+    H.dbuf = bt.buf[bt.cur]; H.dstride = bt.stride; H.len = bt.h_len.data(); H.skip = h_skip.data(); H.status = h_status.data();
+    kz_parallel_for(B, 256, host_inverse_block, &H);
+    if (H.fail) { snprintf(ctx->err, sizeof(ctx->err), "host stage: copy from / to the device failed"); return -KZ_ERR_DEVICE; }
+    KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    KZ_HIP(hipStreamSynchronize(st));
+    kz_stage_end(ctx, e1, KZ_STAGE_HOST_INV, 0);
   }
   // ---- checksum verification (CompressedInputStream.java:1349-1363) ----
   if (F.chk) {
@@ -835,8 +980,16 @@ static int32_t transform_one(kz_ctx* ctx, uint32_t type, bool forward, const uin
   *produced = 0;
   if (n == 0) return 1;                                             // every reference codec: length 0 -> true
   if (!transform_supported((int)type) || type == KZ_T_NONE) { snprintf(ctx->err, sizeof(ctx->err), "transform %u has no HIP stage", type); return -KZ_ERR_INVALID_CODEC; }
-  KZ_HIP(hipSetDevice(ctx->device));
   if (forward && dstCap < kz_transform_max_encoded_len(type, n)) return 0;   // e.g. ZRLT.java:68, BWTBlockCodec.java:84-86
+  if (kz_is_host_transform((int)type)) {                                     // TEXT, UTF: host stages, no GPU involved
+    int dt = ctx->dataType;
+    const int r = forward ? kz_host_transform_forward((int)type, ctx->entropy, ctx->blockSize, &dt, src, n, dst, dstCap, produced)
+                          : kz_host_transform_inverse((int)type, ctx->blockSize, src, n, dst, dstCap, produced);
+    if (forward) ctx->dataType = dt;
+    if (!r) *produced = 0;
+    return r ? 1 : 0;
+  }
+  KZ_HIP(hipSetDevice(ctx->device));
   Pipe P;
   const int maxLen = std::max(kz_transform_max_encoded_len(type, n), std::max(dstCap, n));
   ChainSpec CS; CS.nb = 1; CS.types[0] = (int)type; CS.entropy = KZ_E_NONE;

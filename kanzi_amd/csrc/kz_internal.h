@@ -27,6 +27,8 @@ struct kz_ctx {
   int checksum = 0;              // 0 none, 1 XXHash32, 2 XXHash64 (ctx map key "checksum")
   int skipBlocks = 0;            // ctx map key "skipBlocks": store incompressible-looking blocks as copy blocks
   int dataType = 0;              // ctx map key "dataType" for the single-block calls (Global.DataType, KZ_DT_*)
+  int blockSize = 4 * 1024 * 1024;   // ctx map key "blockSize" (TEXT sizes its hash map by it)
+  int entropy = KZ_E_NONE;       // ctx map key "entropy" for the single-block calls (TEXT: TextCodec1 / TextCodec2)
   int numCUs = 256;              // compute units of the device (placement of the serial-per-block kernels)
   long long* d_endBits = nullptr; // optional [B] device array: bit position behind each block's entropy payload (kz_entropy_decode)
   bool timing = false;
@@ -118,6 +120,14 @@ void kz_ktimer_flush(kz_ctx* ctx);     // call after the stream has been synchro
   if ((ctx)->ktiming) { a_ = kz_ev(ctx); b_ = kz_ev(ctx); (void)hipEventRecord(a_, (ctx)->stream); } \
   hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__); \
   if ((ctx)->ktiming) { (void)hipEventRecord(b_, (ctx)->stream); (ctx)->pending.push_back({a_, b_, kid}); } } while (0)
+
+// ---- host (CPU) stages in front of the GPU chain: TEXT and UTF (kz_text.hip) ----
+bool kz_is_host_transform(int type);
+int kz_host_block_data_type(const uint8_t* p, int n, int init);
+int kz_host_transform_forward(int type, int entropyType, int blockSize, int* dataType, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
+int kz_host_transform_inverse(int type, int blockSize, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
+// run fn(i) for i in [0, n) on host threads (blocks are independent)
+void kz_parallel_for(int n, int maxThreads, void (*fn)(int, void*), void* arg);
 
 // timing helpers
 void kz_stage_begin(kz_ctx*, hipEvent_t* e0);

@@ -17,6 +17,7 @@
 #include "kz_device.h"
 #include "kz_internal.h"
 #include "kz_datatype.h"
+#include "kz_magic.h"
 #include <cmath>
 #include <mutex>
 
@@ -27,39 +28,6 @@ typedef uint8_t u8;
 #define MM_ESCAPE 0xFFu
 #define MM_DELTA 0
 #define MM_XOR 1
-
-// ---- Magic.getType (K/Magic.java:147-185); Java int semantics: arithmetic shifts, exact match for JPG ----
-__device__ __forceinline__ int32_t mm_magic_type(const u8* p) {
-  const int32_t key = (int32_t)(((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3]);
-  if ((key & ~0x0F) == (int32_t)0xFFD8FFE0u) return key;                       // JPG
-  if ((key >> 8) == 0x425A68 || (key >> 8) == 0x494433) return key >> 8;       // BZIP2, MP3 ID3
-  const u32 k = (u32)key;
-  if (k == 0x47494638u || k == 0x25504446u || k == 0x504B0304u || k == 0x377ABCAFu || k == 0x89504E47u || k == 0x7F454C46u ||
-      k == 0xFEEDFACEu || k == 0xCEFAEDFEu || k == 0xFEEDFACFu || k == 0xCFFAEDFEu || k == 0x28B52FFDu || k == 0x81CFB2CEu ||
-      k == 0x4D534346u || k == 0x52494646u || k == 0x664C6143u || k == 0xFD377A58u || k == 0x4B414E5Au || k == 0x52617221u) return key;
-  const int32_t key16 = key >> 16;
-  if (key16 == 0x1F8B || key16 == 0x424D || key16 == 0x4D5A) return key16;       // GZIP, BMP, WIN
-  if (key16 == 0x5034 || key16 == 0x5035 || key16 == 0x5036) {                   // PBM, PGM, PPM (binary flavours)
-    const int sub = (key >> 8) & 0xFF;
-    if (sub == 0x07 || sub == 0x0A || sub == 0x0D || sub == 0x20) return key16;
-  }
-  return 0;                                                                      // NO_MAGIC
-}
-__device__ __forceinline__ bool mm_is_compressed(int32_t m) {
-  const u32 k = (u32)m;
-  return k == 0xFFD8FFE0u || k == 0x47494638u || k == 0x89504E47u || k == 0x377ABCAFu || k == 0x28B52FFDu || k == 0x81CFB2CEu ||
-         k == 0x4D534346u || k == 0x504B0304u || k == 0x1F8Bu || k == 0x425A68u || k == 0x664C6143u || k == 0x494433u ||
-         k == 0xFD377A58u || k == 0x4B414E5Au || k == 0x52617221u;
-}
-__device__ __forceinline__ bool mm_is_multimedia(int32_t m) {
-  const u32 k = (u32)m;
-  return k == 0xFFD8FFE0u || k == 0x47494638u || k == 0x89504E47u || k == 0x52494646u || k == 0x664C6143u || k == 0x494433u ||
-         k == 0x424Du || k == 0x5034u || k == 0x5035u || k == 0x5036u;
-}
-__device__ __forceinline__ bool mm_is_executable(int32_t m) {
-  const u32 k = (u32)m;
-  return k == 0x7F454C46u || k == 0x4D5Au || k == 0xFEEDFACEu || k == 0xCEFAEDFEu || k == 0xFEEDFACFu || k == 0xCFFAEDFEu;
-}
 
 // the writer's tag (CompressedOutputStream.java:795-804); `init` is what the context held before (UNDEFINED for the
 // batched calls, kz_ctx_set_data_type for the single-block ones)

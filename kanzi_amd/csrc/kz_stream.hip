@@ -262,6 +262,11 @@ extern "C" int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t ent
   std::unique_ptr<uint8_t[]> outbuf(new uint8_t[(size_t)oS * (size_t)std::min<int64_t>(NB, std::max<int64_t>(nblocks, 1))]);
   std::vector<int32_t> lens(NB);
   std::vector<kz_block_result> res(NB);
+  struct BlockSizeScope {                                          // the context's "blockSize" entry = this stream's (TEXT reads it)
+    kz_ctx* c; int saved;
+    BlockSizeScope(kz_ctx* c_, int v) : c(c_), saved(c_->blockSize) { c->blockSize = v; }
+    ~BlockSizeScope() { c->blockSize = saved; }
+  } scope(ctx, blockSize);
   for (int64_t b0 = 0; b0 < nblocks; b0 += NB) {
     const int cnt = (int)std::min<int64_t>(NB, nblocks - b0);
     for (int i = 0; i < cnt; i++) lens[i] = (int32_t)std::min<int64_t>(blockSize, n - (b0 + i) * blockSize);

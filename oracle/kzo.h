@@ -115,6 +115,16 @@ int kzo_alias_max_encoded_len(int n);
 int kzo_alias_forward(int onlyDNA, int* dataType, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
 int kzo_alias_inverse(const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
 
+/* TextCodec = transform TEXT (kzo_text.c): codecType 1 / 2 = TextCodec1 / TextCodec2, blockSize = the context's "blockSize";
+   UTFCodec = transform UTF (kzo_utf.c).  Both read and write the block's dataType. */
+int kzo_text_forward(int codecType, int blockSize, int* dataType, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
+int kzo_text_inverse(int blockSize, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
+int kzo_text_static_dict_words(void);
+int kzo_utf_forward(int* dataType, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
+int kzo_utf_inverse(const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
+/* the context entries "entropy" and "blockSize" for the calling thread's next transform calls (TEXT reads them) */
+void kzo_set_transform_ctx(int entropyType, int blockSize);
+
 int kzo_transform_max_encoded_len(int type, int n);
 /* dataType: the block's context entry, read and updated by the stages that use it; NULL = no context */
 int kzo_transform_forward(int type, int* dataType, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
@@ -139,6 +149,8 @@ int64_t kzo_encode_block_x(uint64_t transformType, int entropyType, int chkKind,
                            uint8_t* out, size_t outCap, uint8_t* skipFlagsOut, int* postLenOut);
 int     kzo_decode_block_x(uint64_t transformType, int entropyType, int chkKind, int blockSize, const uint8_t* in,
                            int64_t nbits, uint8_t* out, int outCap);
+int64_t kzo_encode_block_y(uint64_t transformType, int entropyType, int chkKind, int blockSize, const uint8_t* data, int n,
+                           uint8_t* out, size_t outCap, uint8_t* skipFlagsOut, int* postLenOut);
 int64_t kzo_compress_x(uint64_t transformType, int entropyType, int blockSize, int chkKind, const uint8_t* src,
                        int64_t n, uint8_t* dst, int64_t dstCap, int jobs);
 uint32_t kzo_xxhash32(const uint8_t* data, int length, uint32_t seed);

@@ -26,8 +26,19 @@ static void tune_malloc(void) {
 }
 
 /* ---------------- dispatch ---------------- */
+/* The two entries of the context map that TEXT reads besides "dataType": "entropy" selects TextCodec1 / TextCodec2
+ * (TransformFactory.java:275-286) and "blockSize" sizes its hash map (TextCodec.java:561-575,1068-1081).  Per thread: set by the
+ * block coder before it runs a Sequence, or by kzo_set_transform_ctx for single-transform calls. */
+static __thread int tls_entropy = KZO_E_NONE;
+static __thread int tls_block_size = 4 * 1024 * 1024;
+void kzo_set_transform_ctx(int entropyType, int blockSize) { tls_entropy = entropyType; tls_block_size = blockSize; }
+static int text_codec_type(void) {
+  return (tls_entropy == KZO_E_NONE || tls_entropy == KZO_E_ANS0 || tls_entropy == KZO_E_HUFFMAN || tls_entropy == KZO_E_RANGE) ? 2 : 1;
+}
+
 int kzo_transform_max_encoded_len(int type, int n) {
   switch (type) {
+    case KZO_T_UTF: return n + 8192;                             /* UTFCodec.java:308-310 */
     case KZO_T_BWT: return n + 33;                               /* BWTBlockCodec.java:40,222 */
     case KZO_T_SRT: return n + 1024;                             /* SRT.java:30,365 */
     case KZO_T_LZ: case KZO_T_LZX:
@@ -52,6 +63,8 @@ int kzo_transform_forward(int type, int* dataType, const uint8_t* src, int n, ui
     case KZO_T_MM:   return kzo_fsd_forward(dataType, src, n, dst, dstCap, produced);
     case KZO_T_PACK: return kzo_alias_forward(0, dataType, src, n, dst, dstCap, produced);
     case KZO_T_DNA:  return kzo_alias_forward(1, dataType, src, n, dst, dstCap, produced);   /* TransformFactory.java:341-343 */
+    case KZO_T_TEXT: return kzo_text_forward(text_codec_type(), tls_block_size, dataType, src, n, dst, dstCap, produced);
+    case KZO_T_UTF:  return kzo_utf_forward(dataType, src, n, dst, dstCap, produced);
     default: return 0;
   }
 }
@@ -69,6 +82,8 @@ int kzo_transform_inverse(int type, const uint8_t* src, int n, uint8_t* dst, int
     case KZO_T_LZX:  return kzo_lz_inverse(1, src, n, dst, dstCap, produced);
     case KZO_T_MM:   return kzo_fsd_inverse(src, n, dst, dstCap, produced);
     case KZO_T_PACK: case KZO_T_DNA: return kzo_alias_inverse(src, n, dst, dstCap, produced);
+    case KZO_T_TEXT: return kzo_text_inverse(tls_block_size, src, n, dst, dstCap, produced);
+    case KZO_T_UTF:  return kzo_utf_inverse(src, n, dst, dstCap, produced);
     default: return 0;
   }
 }
@@ -201,7 +216,14 @@ int64_t kzo_encode_block(uint64_t transformType, int entropyType, const uint8_t*
 /* chkKind: 0 none, 1 XXHash32, 2 XXHash64 of the ORIGINAL block (CompressedOutputStream.java:749-755,887-891) */
 int64_t kzo_encode_block_x(uint64_t transformType, int entropyType, int chkKind, const uint8_t* data, int n,
                            uint8_t* out, size_t outCap, uint8_t* skipFlagsOut, int* postLenOut) {
+  return kzo_encode_block_y(transformType, entropyType, chkKind, 4 * 1024 * 1024, data, n, out, outCap, skipFlagsOut, postLenOut);
+}
+
+/* blockSize: the stream's block size = the context entry "blockSize" (only TEXT looks at it) */
+int64_t kzo_encode_block_y(uint64_t transformType, int entropyType, int chkKind, int blockSize, const uint8_t* data, int n,
+                           uint8_t* out, size_t outCap, uint8_t* skipFlagsOut, int* postLenOut) {
   if (n == 0) return 0;
+  kzo_set_transform_ctx(entropyType, blockSize);
   const int skipBlocks = (chkKind >> 8) & 1;                     /* bit 8 of chkKind: the writer's "skipBlocks" option */
   chkKind &= 0xFF;
   uint64_t checksum = 0;
@@ -322,6 +344,7 @@ static int decode_block_impl(uint64_t transformType, int entropyType, int chkKin
   }
   if (headerOnly) return 0;
   if (preLen == 0) return 0;
+  kzo_set_transform_ctx(entropyType, blockSize);
   uint64_t checksum1 = 0;
   if (chkKind == 1) checksum1 = kzo_ibs_read(&is, 32); else if (chkKind == 2) checksum1 = kzo_ibs_read(&is, 64);   /* :1256-1262 */
   if (rawCopy) { transformType = 0; entropyType = KZO_E_NONE; skipFlags = 0xFF; }
@@ -400,7 +423,7 @@ static void* enc_worker(void* arg) {
     int len = (int)((j->n - off) < j->blockSize ? (j->n - off) : j->blockSize);
     size_t cap = (size_t)len + (len >> 3) + 1024;
     j->outs[b] = (uint8_t*)malloc(cap);
-    j->bits[b] = kzo_encode_block_x(j->transformType, j->entropyType, j->chkKind, j->src + off, len, j->outs[b], cap, NULL, NULL);
+    j->bits[b] = kzo_encode_block_y(j->transformType, j->entropyType, j->chkKind, j->blockSize, j->src + off, len, j->outs[b], cap, NULL, NULL);
     if (j->bits[b] < 0) j->fail = 1;
   }
   return NULL;

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ODIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ODIR, "libkzo.so")
 
-T = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "SRT": 13, "MM": 15, "LZX": 16, "PACK": 18, "DNA": 19}
+T = {"NONE": 0, "BWT": 1, "LZ": 3, "ZRLT": 6, "MTFT": 7, "RANK": 8, "TEXT": 10, "SRT": 13, "MM": 15, "LZX": 16, "UTF": 17, "PACK": 18, "DNA": 19}
 # Global.DataType as numbered in oracle/kzo.h
 DT = {"UNDEFINED": 0, "DNA": 1, "SMALL_ALPHABET": 2, "TEXT": 3, "MULTIMEDIA": 4, "EXE": 5, "NUMERIC": 6, "BASE64": 7, "BIN": 8, "UTF8": 9}
 E = {"NONE": 0, "HUFFMAN": 1, "FPAQ": 2, "ANS0": 5}
@@ -39,6 +39,10 @@ def lib():
         L.kzo_compress_x.argtypes = [c.c_uint64, c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_int64, c.c_void_p, c.c_int64, c.c_int]
         L.kzo_encode_block_x.restype = c.c_int64
         L.kzo_encode_block_x.argtypes = [c.c_uint64, c.c_int, c.c_int, c.c_void_p, c.c_int, c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p]
+        L.kzo_encode_block_y.restype = c.c_int64
+        L.kzo_encode_block_y.argtypes = [c.c_uint64, c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_int, c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p]
+        L.kzo_set_transform_ctx.argtypes = [c.c_int, c.c_int]
+        L.kzo_set_transform_ctx.restype = None
         L.kzo_xxhash32.restype = c.c_uint32
         L.kzo_xxhash32.argtypes = [c.c_void_p, c.c_int, c.c_uint32]
         L.kzo_xxhash64.restype = c.c_uint64
@@ -91,6 +95,11 @@ def ttype(names):
     return int(lib().kzo_transform_type(ids, len(names)))
 
 
+def set_transform_ctx(entropy="NONE", block_size=4 * 1024 * 1024):
+    """the context entries "entropy" and "blockSize" the next single-transform calls of this thread see (TEXT reads them)"""
+    lib().kzo_set_transform_ctx(E[entropy.upper()], int(block_size))
+
+
 def transform_forward(name, data, cap=None, data_type=None):
     """-> (applied, bytes); with data_type (a DT value: the block's "dataType" context entry) -> (applied, bytes,
     data type after the call)"""
@@ -141,14 +150,14 @@ def entropy_decode(name, data, nbits, count):
     return r, out[:count].tobytes(), int(s.pos)
 
 
-def encode_block(chain, entropy, data, checksum=0):
-    """-> (stream bytes, W bits, skipFlags, postLen); checksum 0 / 32 / 64"""
+def encode_block(chain, entropy, data, checksum=0, block_size=4 * 1024 * 1024):
+    """-> (stream bytes, W bits, skipFlags, postLen); checksum 0 / 32 / 64; block_size = the stream's (TEXT sizes its hash map by it)"""
     a = _u8(data)
     cap = len(a) + len(a) // 8 + 2048
     out = np.zeros(cap, dtype=np.uint8)
     sf = ctypes.c_uint8(0)
     pl = ctypes.c_int(0)
-    w = lib().kzo_encode_block_x(ttype(chain), E[entropy.upper()], {0: 0, 32: 1, 64: 2}[checksum], a.ctypes.data, len(a), out.ctypes.data, cap, ctypes.byref(sf), ctypes.byref(pl))
+    w = lib().kzo_encode_block_y(ttype(chain), E[entropy.upper()], {0: 0, 32: 1, 64: 2}[checksum], int(block_size), a.ctypes.data, len(a), out.ctypes.data, cap, ctypes.byref(sf), ctypes.byref(pl))
     if w < 0:
         raise RuntimeError("oracle encode_block failed")
     return out[:(w + 7) // 8].tobytes(), int(w), sf.value, pl.value

@@ -104,15 +104,16 @@ def test_no_oracle_in_product_path():
 
 
 def test_reference_levels_map_to_chains():
-    """BlockCompressor.getTransformAndCodec (K/app/BlockCompressor.java:537-573): levels 0-2 are made of built stages,
-    3/5/6 only without their TEXT+UTF head, the rest are refused with ERR_INVALID_CODEC."""
+    """BlockCompressor.getTransformAndCodec (K/app/BlockCompressor.java:537-573): levels 0-3, 5 and 6 are made of built stages
+    (TEXT and UTF as host stages), the rest are refused with ERR_INVALID_CODEC."""
     assert kz.level_chain(1) == ("LZX", "NONE") and kz.level_chain(2) == ("DNA+LZ", "HUFFMAN") and kz.level_chain(0) == ("NONE", "NONE")
-    assert kz.level_chain(3, allow_partial=True) == ("PACK+MM+LZX", "HUFFMAN")
+    assert kz.level_chain(3) == ("TEXT+UTF+PACK+MM+LZX", "HUFFMAN")
+    assert kz.level_chain(5) == ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0")
+    assert kz.level_chain(6) == ("TEXT+UTF+BWT+SRT+ZRLT", "FPAQ")
     assert kz.level_chain(5, allow_partial=True) == ("BWT+RANK+ZRLT", "ANS0")
-    assert kz.level_chain(6, allow_partial=True) == ("BWT+SRT+ZRLT", "FPAQ")
-    for lvl in (3, 4, 5, 6, 7, 8, 9):
+    for lvl in (4, 7, 8, 9):
         with pytest.raises(kz.KanziError) as e:
             kz.level_chain(lvl)
         assert e.value.code == 3
-    for t, _ in (kz.level_chain(l, True) for l in (0, 1, 2, 3, 5, 6)):
+    for t, _ in (kz.level_chain(l) for l in (0, 1, 2, 3, 5, 6)):
         kz.transform_type(t)

@@ -12,6 +12,7 @@ import kanzi_amd as kz
 import datagen
 import oracle
 import refinputs
+import textgen
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -816,3 +817,97 @@ def test_small_blocks_that_grow_by_more_than_a_quarter(ctx):
     finally:
         ctx.set_checksum(0)
     assert rc == -12
+
+
+LEVEL_CHAINS = [kz.level_chain(3), kz.level_chain(5), kz.level_chain(6)]
+
+
+@pytest.mark.parametrize("chain,ent", LEVEL_CHAINS)
+def test_level_exact_streams_match_oracle(ctx, chain, ent):
+    """The reference's levels 3, 5 and 6 with their TEXT+UTF head (host stages in front of the GPU chain): whole .knz streams equal
+    the oracle's on English / CRLF / XML text, UTF-8, binary and synthetic blocks, and decode back."""
+    c = textgen.cases()
+    data = (c["english"][:150000] + c["utf8"] + c["random"][:40000] + c["english_crlf"][:70000] + c["xml"][:60000] + c["english_escapes"][:50000]
+            + datagen.stream(3, 30000).tobytes() + c["gif_magic_text"] + c["spaces_then_text"] + c["utf8_bom"])
+    for bs in (32768, 262144):
+        cos = kz.CompressedOutputStream(ctx, chain, ent, bs)
+        cos.write(data)
+        cos.close()
+        ref = oracle.compress(chain, ent, bs, data, jobs=4)
+        assert cos.output == ref, (chain, ent, bs, len(cos.output), len(ref))
+        assert kz.CompressedInputStream(ctx, ref).read() == data
+        # the skip flags differ from block to block: TEXT takes the prose, UTF the UTF-8, neither the binary blocks
+        if bs == 32768:
+            modes = [kz.extract_bits(ref, off, 16) for off, nb in kz.knz_index(ref)["blocks"]]
+            assert len(set(modes)) > 2
+    # checksummed, device-resident blocks through the batched calls
+    torch = pytest.importorskip("torch")
+    bs = 65536
+    nb = len(data) // bs
+    blocks = np.frombuffer(data[:nb * bs], dtype=np.uint8).reshape(nb, bs).copy()
+    lens = np.full(nb, bs, dtype=np.int32)
+    ostride = kz.max_block_stream_bytes(bs)
+    ctx.set_block_size(bs)
+    try:
+        out_h = np.zeros((nb, ostride), dtype=np.uint8)
+        res_h = kz.encode_blocks(ctx, chain, ent, blocks, bs, lens, out_h, ostride)
+        d_in = torch.from_numpy(blocks).cuda()
+        d_out = torch.zeros((nb, ostride), dtype=torch.uint8, device="cuda")
+        res_d = kz.encode_blocks(ctx, chain, ent, d_in.data_ptr(), bs, lens, d_out.data_ptr(), ostride, kz.MEM_DEVICE)
+        out_d = d_out.cpu().numpy()
+        for i in range(nb):
+            s, w, sf, pl = oracle.encode_block(chain, ent, blocks[i], block_size=bs)
+            assert res_h[i].status == 0 and res_d[i].status == 0
+            assert (res_h[i].bits, res_h[i].skipFlags, res_h[i].length) == (w, sf, pl) == (res_d[i].bits, res_d[i].skipFlags, res_d[i].length), i
+            assert out_h[i, :(w + 7) // 8].tobytes() == s and out_d[i, :(w + 7) // 8].tobytes() == s, i
+        bits = np.array([r.bits for r in res_d], dtype=np.int64)
+        d_dec = torch.zeros((nb, bs), dtype=torch.uint8, device="cuda")
+        res2 = kz.decode_blocks(ctx, chain, ent, bs, d_out.data_ptr(), ostride, bits, d_dec.data_ptr(), bs, kz.MEM_DEVICE)
+        assert all(r.status == 0 and r.length == bs for r in res2)
+        assert np.array_equal(d_dec.cpu().numpy(), blocks)
+    finally:
+        ctx.set_block_size(4 * 1024 * 1024)
+
+
+def test_text_and_utf_through_the_transform_mirror(ctx):
+    """kz_transform_forward / _inverse for TEXT and UTF (the ByteTransform mirror with a context): same answers as the
+    context-free host entry points and the oracle, dataType entry included."""
+    c = textgen.cases()
+    for ent in ("ANS0", "FPAQ"):
+        t = kz.TextCodec(ctx, ent, 65536)
+        oracle.set_transform_ctx(ent, 65536)
+        for name in ("english", "utf8", "random", "xml"):
+            ctx.set_data_type(0)
+            ok, enc = _fwd(ctx, kz.TEXT_TYPE, c[name])
+            ok_o, enc_o, dt_o = oracle.transform_forward("TEXT", c[name], data_type=0)
+            assert ok == ok_o and ctx.get_data_type() == dt_o, (ent, name)
+            if ok:
+                assert enc == enc_o
+                assert _inv(ctx, kz.TEXT_TYPE, enc, len(c[name]) + 4096) == (True, c[name])
+            ok, enc = _fwd(ctx, kz.UTF_TYPE, c[name])
+            ok_o, enc_o, dt_o2 = oracle.transform_forward("UTF", c[name], data_type=dt_o)
+            assert ok == ok_o and ctx.get_data_type() == dt_o2, (ent, name)
+            if ok:
+                assert enc == enc_o and _inv(ctx, kz.UTF_TYPE, enc, len(c[name]) + 4096) == (True, c[name])
+        del t
+    ctx.set_data_type(0)
+    ctx.set_entropy("NONE")
+    ctx.set_block_size(4 * 1024 * 1024)
+    # a host stage behind a GPU stage is not a chain the reference's levels use: refused, not mis-coded
+    with pytest.raises(kz.KanziError) as e:
+        cos = kz.CompressedOutputStream(ctx, "BWT+TEXT", "ANS0", 65536)
+        cos.write(c["english"][:100000])
+        cos.close()
+    assert e.value.code == 3
+
+
+def test_level5_at_4mib_blocks(ctx):
+    """-l 5 at its own block size: 3 text-like 4 MiB blocks + one synthetic, HIP .knz == oracle's, round trip."""
+    bs = 4 * 1024 * 1024
+    data = textgen.english(bs, 31) + textgen.many_words(bs, 32) + textgen.utf8(bs, 33) + datagen.block(2, bs).tobytes()[:bs // 2]
+    chain, ent = kz.level_chain(5)
+    cos = kz.CompressedOutputStream(ctx, chain, ent, bs)
+    cos.write(data)
+    cos.close()
+    assert cos.output == oracle.compress(chain, ent, bs, data, jobs=4)
+    assert kz.CompressedInputStream(ctx, cos.output).read() == data

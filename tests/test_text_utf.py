@@ -1,0 +1,109 @@
+"""TEXT and UTF (host stages): hand-derived known answers, the product's host code against the oracle,
+round trips.  CPU only: these two stages never touch the GPU (kz_host_stage_forward / _inverse)."""
+import numpy as np
+import pytest
+
+import kanzi_amd as kz
+import oracle
+import textgen
+
+
+def both_forward(name, data, entropy, block_size=4 * 1024 * 1024, data_type=0):
+    oracle.set_transform_ctx(entropy, block_size)
+    ok_o, enc_o, dt_o = oracle.transform_forward(name, data, data_type=data_type)
+    ok_p, enc_p, dt_p = kz.host_stage_forward(name, data, entropy, block_size, data_type)
+    assert (ok_o, dt_o) == (ok_p, dt_p), (name, entropy, ok_o, ok_p, dt_o, dt_p)
+    if ok_o:
+        assert enc_o == enc_p, (name, entropy, len(enc_o), len(enc_p))
+    return ok_p, enc_p, dt_p
+
+
+def test_text_known_answers_worked_from_the_reference(built):
+    """Worked by hand from K/transform/TextCodec.java on 256 x "the " (1024 bytes, the minimum block):
+    "the" is word 0 of the static dictionary (:89); TextCodec2 (ANS0) writes the mode byte 0x10 (:496-501, no CRLF / XML),
+    then per word the index byte 0x80 | (0 + 1) (:1370-1394), the single space between two references is implied
+    (:1239-1241) and the last space is plain text.  TextCodec1 (FPAQ) writes mode 0x00 and per word the token 0x0F and
+    the index 0 (:767-768, :850-863).  "The" is found through the case-flipped hash: 0x80 then the index (:1249-1252),
+    resp. the token 0x0E."""
+    lower, upper = b"the " * 256, b"The " * 256
+    assert both_forward("TEXT", lower, "ANS0")[:2] == (True, b"\x10" + b"\x81" * 256 + b" ")
+    assert both_forward("TEXT", lower, "FPAQ")[:2] == (True, b"\x00" + b"\x0f\x00" * 256 + b" ")
+    assert both_forward("TEXT", upper, "ANS0")[:2] == (True, b"\x10" + b"\x80\x81" * 256 + b" ")
+    assert both_forward("TEXT", upper, "FPAQ")[:2] == (True, b"\x00" + b"\x0e\x00" * 256 + b" ")
+    # word 129 ("first" ... whichever it is) takes the two-byte forms: 110xxxxx x (TextCodec2, index + 1 >= 64) and 1xxxxxxx 0xxxxxxx
+    words = textgen.dict_words()
+    assert len(words) == 1024 and words[0] == "The" and oracle.lib().kzo_text_static_dict_words() == 1024
+    w = words[200].lower().encode()
+    data = (w + b" ") * (1024 // (len(w) + 1) + 1)
+    ok, enc, dt = both_forward("TEXT", data, "ANS0")
+    assert ok and dt == kz.DATA_TYPES["TEXT"] and enc[:3] == bytes([0x10, 0xC0 | (201 >> 8), 201 & 0xFF])
+    ok, enc, _ = both_forward("TEXT", data, "FPAQ")
+    assert ok and enc[:4] == bytes([0x00, 0x0F, 0x80 | (200 >> 7), 200 & 0x7F])
+
+
+def test_utf_known_answer_worked_from_the_reference(built):
+    """600 x U+00E9 (C3 A9), worked by hand from K/transform/UTFCodec.java:68-218: no byte order mark and a valid lead byte,
+    so start = 0; one symbol, key (1 << 19) | 0xC3A9 (:455); header = start, adjust, n (2 bytes), the key in 3 bytes; the 598 code
+    points in front of the last four bytes become alias 0; the last four bytes are copied."""
+    data = b"\xc3\xa9" * 600
+    ok, enc, dt = both_forward("UTF", data, "ANS0")
+    assert ok and dt == kz.DATA_TYPES["UTF8"]
+    assert enc == bytes([0, 0, 0, 1, 0x08, 0xC3, 0xA9]) + b"\x00" * 598 + b"\xc3\xa9\xc3\xa9"
+    assert kz.host_stage_inverse("UTF", enc, len(data) + 4096) == (True, data)
+    assert oracle.transform_inverse("UTF", enc, len(data) + 4096) == (True, data)
+
+
+@pytest.mark.parametrize("entropy,block_size", [("ANS0", 65536), ("FPAQ", 65536), ("HUFFMAN", 4 * 1024 * 1024), ("FPAQ", 4 * 1024 * 1024)])
+def test_host_stages_match_oracle(built, entropy, block_size):
+    for name, data in textgen.cases().items():
+        for dt0 in (0, kz.DATA_TYPES["BIN"], kz.DATA_TYPES["UTF8"], kz.DATA_TYPES["MULTIMEDIA"]):
+            ok, enc, dt = both_forward("TEXT", data, entropy, block_size, dt0)
+            if ok:
+                assert (enc[0] & 0x10) == (0x10 if entropy in ("ANS0", "HUFFMAN", "NONE") else 0)
+                cap = len(data) + max(512, len(data) // 16)
+                assert kz.host_stage_inverse("TEXT", enc, cap, block_size) == (True, data), name
+                assert oracle.transform_inverse("TEXT", enc, cap) == (True, data), name
+            ok, enc, dt = both_forward("UTF", data, entropy, block_size, dt0)
+            if ok:
+                cap = len(data) + max(512, len(data) // 16)
+                assert kz.host_stage_inverse("UTF", enc, cap) == (True, data), name
+                assert oracle.transform_inverse("UTF", enc, cap) == (True, data), name
+
+
+def test_text_declines_and_tags_like_the_reference(built):
+    c = textgen.cases()
+    # TextCodec2 refuses blocks that start with a known magic (TextCodec.java:272-273) and leaves UNDEFINED behind; TextCodec1 does not look
+    assert both_forward("TEXT", c["gif_magic_text"], "ANS0") == (False, b"", 0)
+    assert both_forward("TEXT", c["gif_magic_text"], "FPAQ")[0] is True
+    assert both_forward("TEXT", c["utf8"], "ANS0")[2] == kz.DATA_TYPES["UTF8"]
+    assert both_forward("TEXT", c["random"], "ANS0")[2] == kz.DATA_TYPES["BIN"]
+    assert both_forward("TEXT", c["digits"], "ANS0")[2] == kz.DATA_TYPES["NUMERIC"]
+    assert both_forward("TEXT", c["short"], "ANS0")[0] is False            # below MIN_BLOCK_SIZE (:491)
+    # a block already tagged MULTIMEDIA / UTF8 / ... is not even analysed (:636-645): the tag stays
+    assert both_forward("TEXT", c["english"], "ANS0", data_type=kz.DATA_TYPES["MULTIMEDIA"]) == (False, b"", kz.DATA_TYPES["MULTIMEDIA"])
+    # UTF only takes UNDEFINED or UTF8 blocks (UTFCodec.java:93-101)
+    assert both_forward("UTF", c["utf8"], "ANS0", data_type=kz.DATA_TYPES["TEXT"]) == (False, b"", kz.DATA_TYPES["TEXT"])
+
+
+def test_corrupted_text_and_utf_blocks_fail_cleanly(built):
+    rng = np.random.default_rng(5)
+    c = textgen.cases()
+    for name, src, ent in (("TEXT", c["english"], "ANS0"), ("TEXT", c["english_escapes"], "FPAQ"), ("UTF", c["utf8"], "ANS0")):
+        ok, enc, _ = both_forward(name, src, ent)
+        assert ok
+        cap = len(src) + max(512, len(src) // 16)
+        for trial in range(60):
+            bad = bytearray(enc)
+            kind = trial % 3
+            if kind == 0:
+                for _ in range(1 + trial % 4):
+                    bad[int(rng.integers(0, len(bad)))] = int(rng.integers(0, 256))
+            elif kind == 1:
+                del bad[int(rng.integers(1, len(bad))):]
+            else:
+                bad[int(rng.integers(0, min(len(bad), 64)))] ^= 1 << int(rng.integers(0, 8))
+            r_p = kz.host_stage_inverse(name, bytes(bad), cap)
+            r_o = oracle.transform_inverse(name, bytes(bad), cap)
+            assert r_p[0] == r_o[0], (name, trial)
+            if r_p[0]:
+                assert r_p[1] == r_o[1], (name, trial)
