@@ -513,6 +513,56 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse5(const u8* __restrict__ sr
     : "vcc", "scc", "v90", "v91", "v92", "v93", "v94", "v95", "s40", "s42", "s44", "s45", "s46", "s47",                        \
       "s50", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s62", "s63", "s64", "s65");
 
+// Dense rows with many ranks >= 64 (incompressible data): a plain loop over the 64 positions, zero ranks as ordinary steps (no run
+// bookkeeping, no s_ff1 walk), the row-spanning variant picked by two bit tests of the rank: K0 falls through, K1 / K2 take one
+// branch, K3 two, plus the loop's back edge.
+#define KZ6C_TAIL                                              \
+    "s_mov_b32 m0, s40\n\t"                                      \
+    "s_nop 0\n\t"                                                \
+    "v_writelane_b32 %[outv], s54, m0\n\t"
+#define KZ6C_NEXT                                              \
+    "s_add_u32 s50, s50, 1\n\t"                                  \
+    "s_add_u32 s40, s40, 1\n\t"                                  \
+    "s_mov_b32 s42, s43\n\t"                                     \
+    "s_cmp_lt_u32 s40, 64\n\t"                                   \
+    "s_cbranch_scc1 L_step%=\n\t"                                \
+    "s_branch L_done%=\n\t"
+#define KZ6_ROWCOLD(XI) asm volatile(                                                          \
+    "s_mov_b32 s40, 0\n\t"                                                                       \
+    "s_mov_b32 s50, %[row]\n\t"                                                                  \
+    "v_readlane_b32 s42, %[cur], 0\n\t"                                                          \
+  "L_step%=:\n\t"                                                                                \
+    "s_add_u32 s41, s40, 1\n\t"                                                                  \
+    "s_and_b32 s41, s41, 63\n\t"                                                                 \
+    "v_readlane_b32 s43, %[cur], s41\n\t"                                                        \
+    "s_and_b32 s44, s42, 63\n\t"                                                                 \
+    "s_xor_b32 s45, s44, 63\n\t"                                                                 \
+    "s_lshr_b64 s[46:47], -1, s45\n\t"                                                           \
+    "s_lshl_b32 s60, s50, 1\n\t"                                                                 \
+    "s_bitcmp1_b32 s42, 7\n\t"                                                                   \
+    "s_cbranch_scc1 L_hi%=\n\t"                                                                  \
+    "s_bitcmp1_b32 s42, 6\n\t"                                                                   \
+    "s_cbranch_scc1 L_k1%=\n\t"                                                                  \
+    KZ6_HEAD(XI, "q0", "p0") KZ6_ROW0 KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6C_TAIL KZ6C_NEXT \
+  "L_k1%=:\n\t"                                                                                  \
+    KZ6_HEAD(XI, "q1", "p1") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q1", "p1", "v91") \
+    KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6C_TAIL KZ6C_NEXT                             \
+  "L_hi%=:\n\t"                                                                                  \
+    "s_bitcmp1_b32 s42, 6\n\t"                                                                   \
+    "s_cbranch_scc1 L_k3%=\n\t"                                                                  \
+    KZ6_HEAD(XI, "q2", "p2") KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q2", "p2", "v91") \
+    KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v91") KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6C_TAIL KZ6C_NEXT \
+  "L_k3%=:\n\t"                                                                                  \
+    KZ6_HEAD(XI, "q3", "p3") KZ6_ROW_SHIFT("q3", "p3", "q2", "p2") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q3", "p3", "v91") \
+    KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_ROW_APPLY("q2", "p2", "v91") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v91") \
+    KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6C_TAIL KZ6C_NEXT                             \
+  "L_done%=:\n\t"                                                                                \
+    : [q0]"+v"(Q0), [p0]"+v"(P0), [q1]"+v"(Q1), [p1]"+v"(P1), [q2]"+v"(Q2), [p2]"+v"(P2), [q3]"+v"(Q3), [p3]"+v"(P3),           \
+      [tq0]"+v"(tq0), [outv]"+v"(outv)                                                                                         \
+    : [cur]"v"(cur), [ff]"v"(ff), [row]"s"(row)                                                                                \
+    : "vcc", "scc", "v90", "v91", "v92", "v93", "v94", "v95", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",          \
+      "s50", "s53", "s54", "s55", "s56", "s58", "s59", "s60");
+
 // zero run of zr ranks ending at index pl, compiler form (row tails and all-zero rows)
 #define KZ6_ZERO_RUN(zr, plv)                                                                  \
   { const u32 pl = (u32)(plv);                                                                 \
@@ -545,9 +595,13 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
     u32 outv = 0;
     const u32 f0 = (u32)__builtin_amdgcn_readfirstlane((int)Q0) & 0xFFu;
     int prev = -1;
-    const bool dense = cnt == 64 && __builtin_popcountll(nz) >= 48 && __builtin_popcountll(kz_ballot(cur >= 64u)) <= 6;
+    const bool dense = cnt == 64 && __builtin_popcountll(nz) >= 48;
     if (dense) {
-      if (MODE == 2) { KZ6_ROWDENSE(KZ6_XI_RANK) } else if (MODE == 1) { KZ6_ROWDENSE(KZ6_XI_MTF) } else { KZ6_ROWDENSE(KZ6_XI_TS) }
+      if (__builtin_popcountll(kz_ballot(cur >= 64u)) <= 6) {
+        if (MODE == 2) { KZ6_ROWDENSE(KZ6_XI_RANK) } else if (MODE == 1) { KZ6_ROWDENSE(KZ6_XI_MTF) } else { KZ6_ROWDENSE(KZ6_XI_TS) }
+      } else {
+        if (MODE == 2) { KZ6_ROWCOLD(KZ6_XI_RANK) } else if (MODE == 1) { KZ6_ROWCOLD(KZ6_XI_MTF) } else { KZ6_ROWCOLD(KZ6_XI_TS) }
+      }
     } else if (nz) {
       if (MODE == 2) { KZ6_ROWLOOP(KZ6_XI_RANK, KZ6_ZQ_RANK) } else if (MODE == 1) { KZ6_ROWLOOP(KZ6_XI_MTF, KZ6_ZQ_MTF) } else { KZ6_ROWLOOP(KZ6_XI_TS, KZ6_ZQ_TS) }
     }

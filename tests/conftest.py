@@ -23,6 +23,12 @@ def built():
 
 @pytest.fixture(scope="session")
 def ctx(built):
+    # PyTorch ships its own copy of the HIP runtime: in a process that uses both, torch has to come first (a torch imported
+    # after libkanzi_hip.so has initialised /opt/rocm's runtime finds "No HIP GPUs").  Some tests use torch for device buffers.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     import kanzi_amd as kz
     c = kz.Context(0)
     yield c
