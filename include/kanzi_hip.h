@@ -147,6 +147,22 @@ int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyTy
                          const uint8_t* in, int64_t inStride, const int64_t* bitLengths, int32_t nBlocks,
                          uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind);
 int64_t kz_max_block_stream_bytes(int32_t blockLength);
+/*
+ * The same two calls queued on the context's worker thread (what SURVEY 8b calls kz_submit / kz_wait): they return a job id
+ * (> 0) at once, kz_wait(job) blocks until the call has run and gives its return code, kz_poll(job) says whether it has.  Every
+ * array passed (lengths / bitLengths / results, and host in / out buffers) stays the caller's and must stay valid until kz_wait.
+ * Jobs of one context run one at a time in submission order; use two contexts to overlap batches (the copies and the encode of
+ * batch k+1 under the decode of batch k).  Between a submit and its wait only kz_submit_*, kz_wait and kz_poll may be called on
+ * that context.
+ */
+int64_t kz_submit_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType,
+                                const uint8_t* in, int64_t inStride, const int32_t* lengths, int32_t nBlocks,
+                                uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind);
+int64_t kz_submit_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
+                                const uint8_t* in, int64_t inStride, const int64_t* bitLengths, int32_t nBlocks,
+                                uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind);
+int32_t kz_wait(kz_ctx* ctx, int64_t job);
+int32_t kz_poll(kz_ctx* ctx, int64_t job);
 
 /* ---- whole .knz stream on host memory (K/io/CompressedOutputStream / CompressedInputStream) --- */
 /* returns compressed size in bytes or <0 */

@@ -15,9 +15,17 @@ public final class HipByteTransform implements ByteTransform {
       io.github.flanglet.kanzi.Global.DataType.NUMERIC, io.github.flanglet.kanzi.Global.DataType.BASE64,
       io.github.flanglet.kanzi.Global.DataType.BIN, io.github.flanglet.kanzi.Global.DataType.UTF8};
   private final long ctx;
-  private final int type;   // TransformFactory ids: BWT 1, LZ 3, ZRLT 6, MTFT 7, RANK 8, SRT 13, MM 15, LZX 16, PACK 18, DNA 19
+  private final int type;   // TransformFactory ids: BWT 1, LZ 3, ZRLT 6, MTFT 7, RANK 8, TEXT (DICT) 10, SRT 13, MM 15, LZX 16, UTF 17, PACK 18, DNA 19
   private final java.util.Map<String, Object> map;   // the task's context map (may be null, like the reference codecs)
 
+  /** what TransformFactory.newFunctionToken asks before it builds the Java codec (integration/kanzi-hip.patch) */
+  public static boolean supports(int type) {
+    switch (type) {
+      case 1: case 3: case 6: case 7: case 8: case 10: case 13: case 15: case 16: case 17: case 18: case 19: return true;
+      default: return false;
+    }
+  }
+  public HipByteTransform(java.util.Map<String, Object> map, int type) { this(HipRuntime.context(map), type, map); }
   public HipByteTransform(long ctx, int type) { this(ctx, type, null); }
   public HipByteTransform(long ctx, int type, java.util.Map<String, Object> map) { this.ctx = ctx; this.type = type; this.map = map; }
 

@@ -20,8 +20,15 @@ public final class HipEntropyDecoder implements EntropyDecoder {
   private final long bitLen;
   private final long[] used = new long[1];
 
+  public static boolean supports(int type) { return (type == 0) || (type == 1) || (type == 2) || (type == 5); }
   public HipEntropyDecoder(long ctx, int type, InputBitStream bs, byte[] payload, long bitLen) {
     this.ctx = ctx; this.type = type; this.bitstream = bs; this.payload = payload; this.bitLen = bitLen;
+    this.bitPos = bs.read();      // the block header (and checksum) in front of the payload have been read from the same stream
+  }
+  /** built by the patched EntropyCodecFactory.newDecoder from what the patched DecodingTask left in the map:
+   *  "hipPayload" = the block's bytes (data.array), "hipPayloadBits" = its bit length W */
+  public HipEntropyDecoder(java.util.Map<String, Object> map, int type, InputBitStream bs) {
+    this(HipRuntime.context(map), type, bs, (byte[]) map.get("hipPayload"), (Long) map.get("hipPayloadBits"));
   }
 
   @Override public int decode(byte[] block, int blkptr, int count) {

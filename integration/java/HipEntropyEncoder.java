@@ -12,6 +12,7 @@ public final class HipEntropyEncoder implements EntropyEncoder {
   private final OutputBitStream bitstream;
   private byte[] buf = new byte[0];
 
+  public static boolean supports(int type) { return (type == 0) || (type == 1) || (type == 2) || (type == 5); }   // NONE, HUFFMAN, FPAQ, ANS0
   public HipEntropyEncoder(long ctx, int type, OutputBitStream bs) { this.ctx = ctx; this.type = type; this.bitstream = bs; }
 
   @Override public int encode(byte[] block, int blkptr, int count) {

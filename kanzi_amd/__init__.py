@@ -83,6 +83,10 @@ def load_library():
         "kz_encode_blocks": (c.c_int32, [vp, c.c_uint64, c.c_uint32, u8p, c.c_int64, i32p, c.c_int32, u8p, c.c_int64, vp, c.c_int32]),
         "kz_decode_blocks": (c.c_int32, [vp, c.c_uint64, c.c_uint32, c.c_int32, u8p, c.c_int64, i64p, c.c_int32, u8p, c.c_int64, vp, c.c_int32]),
         "kz_max_block_stream_bytes": (c.c_int64, [c.c_int32]),
+        "kz_submit_encode_blocks": (c.c_int64, [vp, c.c_uint64, c.c_uint32, u8p, c.c_int64, i32p, c.c_int32, u8p, c.c_int64, vp, c.c_int32]),
+        "kz_submit_decode_blocks": (c.c_int64, [vp, c.c_uint64, c.c_uint32, c.c_int32, u8p, c.c_int64, i64p, c.c_int32, u8p, c.c_int64, vp, c.c_int32]),
+        "kz_wait": (c.c_int32, [vp, c.c_int64]),
+        "kz_poll": (c.c_int32, [vp, c.c_int64]),
         "kz_compress": (c.c_int64, [vp, c.c_uint64, c.c_uint32, c.c_int32, u8p, c.c_int64, u8p, c.c_int64]),
         "kz_decompress": (c.c_int64, [vp, u8p, c.c_int64, u8p, c.c_int64]),
         "kz_compress_bound": (c.c_int64, [c.c_int64, c.c_int32]),
@@ -113,7 +117,7 @@ ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_err
                "kz_ctx_set_data_type", "kz_ctx_get_data_type", "kz_ctx_set_skip_blocks", "kz_ctx_set_block_size", "kz_ctx_set_entropy",
                "kz_transform_forward", "kz_transform_inverse", "kz_transform_max_encoded_len", "kz_host_stage_forward", "kz_host_stage_inverse",
                "kz_entropy_encode", "kz_entropy_decode", "kz_encode_blocks", "kz_decode_blocks",
-               "kz_max_block_stream_bytes", "kz_compress", "kz_decompress", "kz_compress_bound", "kz_transform_type",
+               "kz_max_block_stream_bytes", "kz_submit_encode_blocks", "kz_submit_decode_blocks", "kz_wait", "kz_poll", "kz_compress", "kz_decompress", "kz_compress_bound", "kz_transform_type",
                "kz_knz_assemble", "kz_knz_index",
                "kz_set_timing", "kz_get_stage_count", "kz_get_stage_ms", "kz_get_stage_alg_bytes", "kz_reset_timing",
                "kz_set_kernel_timing", "kz_get_kernel_count", "kz_get_kernel_name", "kz_get_kernel_ms",
@@ -477,6 +481,44 @@ def decode_blocks(ctx, transform, entropy, block_size, inp, in_stride, bit_lengt
                                   _ptr(out), int(out_stride), ctypes.addressof(res), mem)
     ctx.check(rc)
     return res
+
+
+class Job:
+    """A batch queued with submit_encode_blocks / submit_decode_blocks; wait() -> the BlockResult array.  Keeps the arrays the
+    C side still points at alive."""
+
+    def __init__(self, ctx, job, res, keep):
+        self.ctx, self.job, self.res, self._keep = ctx, job, res, keep
+
+    def done(self):
+        return bool(self.ctx.lib.kz_poll(self.ctx.h, self.job))
+
+    def wait(self):
+        self.ctx.check(self.ctx.lib.kz_wait(self.ctx.h, self.job))
+        return self.res
+
+
+def submit_encode_blocks(ctx, transform, entropy, inp, in_stride, lengths, out, out_stride, mem=MEM_HOST):
+    """kz_submit_encode_blocks: returns a Job at once; the call runs on the context's worker thread."""
+    tt = transform if isinstance(transform, int) else transform_type(transform)
+    et = entropy if isinstance(entropy, int) else ENTROPY_IDS[entropy.upper()]
+    lens = np.ascontiguousarray(lengths, dtype=np.int32)
+    res = (BlockResult * len(lens))()
+    job = ctx.lib.kz_submit_encode_blocks(ctx.h, tt, et, _ptr(inp), int(in_stride), lens.ctypes.data, len(lens),
+                                          _ptr(out), int(out_stride), ctypes.addressof(res), mem)
+    ctx.check(min(job, 0))
+    return Job(ctx, job, res, (lens, inp, out))
+
+
+def submit_decode_blocks(ctx, transform, entropy, block_size, inp, in_stride, bit_lengths, out, out_stride, mem=MEM_HOST):
+    tt = transform if isinstance(transform, int) else transform_type(transform)
+    et = entropy if isinstance(entropy, int) else ENTROPY_IDS[entropy.upper()]
+    bl = np.ascontiguousarray(bit_lengths, dtype=np.int64)
+    res = (BlockResult * len(bl))()
+    job = ctx.lib.kz_submit_decode_blocks(ctx.h, tt, et, int(block_size), _ptr(inp), int(in_stride), bl.ctypes.data, len(bl),
+                                          _ptr(out), int(out_stride), ctypes.addressof(res), mem)
+    ctx.check(min(job, 0))
+    return Job(ctx, job, res, (bl, inp, out))
 
 
 class CompressedOutputStream:

@@ -32,6 +32,11 @@ extern "C" kz_ctx* kz_ctx_create(int32_t deviceId) {
 }
 extern "C" void kz_ctx_destroy(kz_ctx* ctx) {
   if (!ctx) return;
+  if (ctx->worker.joinable()) {                                     // queued batches finish first
+    { std::lock_guard<std::mutex> g(ctx->qmu); ctx->stopWorker = true; }
+    ctx->qcv.notify_all();
+    ctx->worker.join();
+  }
   hipSetDevice(ctx->device);
   if (ctx->arena) hipFree(ctx->arena);
   if (ctx->hpin) hipHostFree(ctx->hpin);
@@ -196,8 +201,8 @@ __global__ void k_passthrough(const u8* __restrict__ src, u8* __restrict__ dst, 
                               int32_t* __restrict__ lenNew, const int32_t* __restrict__ mask, const int32_t* __restrict__ flag,
                               int32_t* __restrict__ applied) {
   const int b = blockIdx.y;
-  const bool ran = mask[b] != 0 && flag[b] != 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { applied[b] = ran ? 1 : 0; if (!ran) lenNew[b] = lenOld[b]; }
+  const bool ran = mask[b] != 0 && flag[b] > 0;                     // flag < 0: the reference's transform would have thrown
+  if (blockIdx.x == 0 && threadIdx.x == 0) { applied[b] = ran ? 1 : ((mask[b] != 0 && flag[b] < 0) ? -1 : 0); if (!ran) lenNew[b] = lenOld[b]; }
   if (ran) return;
   const int n = lenOld[b];
   const u8* s = src + (int64_t)b * stride;
@@ -626,7 +631,7 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   if (F.chk) { rc = kz_block_hashes(ctx, bt.buf[0], bt.stride, bt.d_len, B, F.chk, F.hash); if (rc) return rc; }
 
   // ---- transform chain (Sequence.forward, K/transform/Sequence.java:56-127) ----
-  std::vector<int32_t> h_copy(B), h_mask(B), h_applied, h_skip(B, 0xFF);
+  std::vector<int32_t> h_copy(B), h_mask(B), h_applied, h_skip(B, 0xFF), h_threw(B, 0);
   for (int b = 0; b < B; b++) h_copy[b] = (lengths[b] <= 15) ? 1 : 0;          // CompressedOutputStream.java:764-767
   if (ctx->skipBlocks) {                                                         // :769-788
     rc = kz_skip_block_flags(ctx, bt, P.d_applied);
@@ -671,7 +676,10 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     rc = run_stage(ctx, P, h_mask, h_applied, [&](kz_batch& x) { return run_transform_stage(ctx, x, type, true, 0); });
     if (rc) return rc;
     kz_stage_end(ctx, e0, stage_id(type, true), inBytes);
-    for (int b = 0; b < B; b++) if (h_applied[b]) h_skip[b] &= ~(1 << (7 - i));
+    for (int b = 0; b < B; b++) {
+      if (h_applied[b] > 0) h_skip[b] &= ~(1 << (7 - i));
+      else if (h_applied[b] < 0) h_threw[b] = 1;                    // an exception in the reference: ERR_PROCESS_BLOCK for the block
+    }
   }
   for (int b = 0; b < B; b++) if (h_copy[b]) h_skip[b] = 0x7F;                   // NullTransform applies (NONE_TYPE chain)
   KZ_HIP(hipMemcpyAsync(F.skipFlags, h_skip.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
@@ -727,6 +735,7 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   }
   KZ_HIP(hipMemcpyAsync(results, d_res, (size_t)B * sizeof(kz_block_result), hipMemcpyDeviceToHost, st));
   KZ_HIP(hipStreamSynchronize(st));
+  for (int b = 0; b < B; b++) if (h_threw[b]) { results[b].status = -KZ_ERR_PROCESS_BLOCK; results[b].bits = 0; results[b].length = 0; }
   if (host) {
     for (int b = 0; b < B; b++) {
       const size_t nbytes = (size_t)((results[b].bits + 7) >> 3);
@@ -974,6 +983,63 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
 }
 
 // =================================================================================================
+// asynchronous batches: kz_submit_encode_blocks / kz_submit_decode_blocks queue the same call on the context's worker thread
+// and return at once; kz_wait collects the call's return code.  A context runs its jobs one at a time in submission order
+// (it owns one stream and one arena); overlap comes from a second context: one host thread can keep the H2D copies and the
+// encode of batch k+1 on context A running under the decode of batch k on context B ("two streams"), which is how
+// the reference's task pool overlaps blocks (K/io/CompressedOutputStream.java:541-566).
+static void ctx_worker(kz_ctx* ctx) {
+  for (;;) {
+    std::pair<int64_t, std::function<int32_t()>> job;
+    {
+      std::unique_lock<std::mutex> lk(ctx->qmu);
+      ctx->qcv.wait(lk, [&] { return ctx->stopWorker || !ctx->queue.empty(); });
+      if (ctx->queue.empty()) return;                               // stop requested and nothing left
+      job = std::move(ctx->queue.front());
+      ctx->queue.pop_front();
+    }
+    const int32_t rc = job.second();
+    { std::lock_guard<std::mutex> g(ctx->qmu); ctx->finished[job.first] = rc; }
+    ctx->qcv.notify_all();
+  }
+}
+static int64_t ctx_submit(kz_ctx* ctx, std::function<int32_t()> fn) {
+  std::lock_guard<std::mutex> g(ctx->qmu);
+  if (!ctx->worker.joinable()) ctx->worker = std::thread(ctx_worker, ctx);
+  const int64_t id = ctx->nextJob++;
+  ctx->queue.emplace_back(id, std::move(fn));
+  ctx->qcv.notify_all();
+  return id;
+}
+extern "C" int64_t kz_submit_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType,
+                                           const uint8_t* in, int64_t inStride, const int32_t* lengths, int32_t nBlocks,
+                                           uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind) {
+  if (!ctx) return -KZ_ERR_INVALID_PARAM;
+  return ctx_submit(ctx, [=]() { return kz_encode_blocks(ctx, transformType, entropyType, in, inStride, lengths, nBlocks, out, outStride, results, memKind); });
+}
+extern "C" int64_t kz_submit_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
+                                           const uint8_t* in, int64_t inStride, const int64_t* bitLengths, int32_t nBlocks,
+                                           uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind) {
+  if (!ctx) return -KZ_ERR_INVALID_PARAM;
+  return ctx_submit(ctx, [=]() { return kz_decode_blocks(ctx, transformType, entropyType, blockSize, in, inStride, bitLengths, nBlocks, out, outStride, results, memKind); });
+}
+extern "C" int32_t kz_wait(kz_ctx* ctx, int64_t job) {
+  if (!ctx || job <= 0) return -KZ_ERR_INVALID_PARAM;
+  std::unique_lock<std::mutex> lk(ctx->qmu);
+  if (job >= ctx->nextJob) return -KZ_ERR_INVALID_PARAM;
+  ctx->qcv.wait(lk, [&] { return ctx->finished.count(job) != 0; });
+  const int32_t rc = ctx->finished[job];
+  ctx->finished.erase(job);
+  return rc;
+}
+extern "C" int32_t kz_poll(kz_ctx* ctx, int64_t job) {            // 1 = finished (kz_wait will not block), 0 = queued or running
+  if (!ctx || job <= 0) return -KZ_ERR_INVALID_PARAM;
+  std::lock_guard<std::mutex> g(ctx->qmu);
+  if (job >= ctx->nextJob) return -KZ_ERR_INVALID_PARAM;
+  return ctx->finished.count(job) ? 1 : 0;
+}
+
+// =================================================================================================
 // single-block mirrors of ByteTransform / EntropyEncoder / EntropyDecoder (host buffers)
 static int32_t transform_one(kz_ctx* ctx, uint32_t type, bool forward, const uint8_t* src, int32_t n, uint8_t* dst, int32_t dstCap, int32_t* produced) {
   if (!ctx || !src || !dst || !produced || n < 0) return -KZ_ERR_INVALID_PARAM;
@@ -1012,6 +1078,7 @@ static int32_t transform_one(kz_ctx* ctx, uint32_t type, bool forward, const uin
     KZ_HIP(hipStreamSynchronize(st));
     ctx->dataType = dt;
   }
+  if (applied[0] < 0) { snprintf(ctx->err, sizeof(ctx->err), "transform %u: the reference codec throws on this block (LZ token buffer)", type); return -KZ_ERR_PROCESS_BLOCK; }
   if (!applied[0]) return 0;
   if (bt.h_len[0] > dstCap) return 0;
   *produced = bt.h_len[0];

@@ -5,6 +5,12 @@
 #include <stdio.h>
 #include <string.h>
 #include <vector>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <thread>
 #include "../../include/kanzi_hip.h"
 
 enum KzKernelId { KID_ANS_ENC_CHUNK, KID_ANS_ENC_SCAN, KID_ANS_ENC_CONCAT, KID_ANS_DEC_INDEX, KID_ANS_DEC_CHUNK, KID_ANS_DEC_FIN, KID_MASK_LEN, KID_PASSTHROUGH, KID_FRAME_PREPARE, KID_COPY_BYTES, KID_FRAME_DECIDE, KID_FRAME_HEADER, KID_FRAME_PARSE, KID_COPY_PAYLOAD, KID_BWT_INIT, KID_RADIX_HIST, KID_RADIX_SCAN, KID_RADIX_SCATTER, KID_SEG_REDUCE, KID_SEG_SCAN, KID_SEG_APPLY, KID_LIVE_COUNT, KID_LIVE_SCAN, KID_LIVE_EMIT, KID_BWT_EMIT, KID_BWTI_PARSE, KID_BWTI_HIST, KID_BWTI_SCAN, KID_BWTI_SCATTER, KID_BWTI_WALK1, KID_BWTI_RESOLVE, KID_BWTI_COPY, KID_BWTI_LITERAL, KID_BWTI_FIN, KID_SBRT_LAST2, KID_SBRT_SCAN, KID_SBRT_REPLAY, KID_COPY_LEN, KID_SBRT_INVERSE, KID_ZRLT_F1, KID_ZRLT_F2, KID_ZRLT_F3, KID_ZRLT_FFIN, KID_ZRLT_I1, KID_ZRLT_I2, KID_ZRLT_I3, KID_ZRLT_IFIN, KID_HUF_ENC_CHUNK, KID_HUF_DEC_INDEX, KID_HUF_DEC_CHUNK, KID_HUF_DEC_FIN, KID_FPAQ_ENC, KID_FPAQ_PACK, KID_FPAQ_DEC, KID_SRT_HIST, KID_SRT_PREP, KID_SRT_SCATTER, KID_SRT_INV, KID_LZ_FWD, KID_LZ_INV, KID_XXHASH, KID_BLOCK_MAGIC, KID_MM_ANALYZE, KID_MM_EMIT, KID_MM_CHECK, KID_MM_INV, KID_ALIAS_ANALYZE, KID_ALIAS_HIST1, KID_ALIAS_SELECT, KID_ALIAS_EMIT, KID_ALIAS_INV, KID_SKIP_DECIDE, KID_COUNT };
@@ -38,6 +44,14 @@ struct kz_ctx {
   std::vector<hipEvent_t> evPool;
   double kMs[KID_COUNT] = {0};
   long long kLaunches[KID_COUNT] = {0};
+  // asynchronous batches (kz_submit_* / kz_wait): one worker thread per context runs the queued calls in order
+  std::thread worker;
+  std::mutex qmu;
+  std::condition_variable qcv;
+  std::deque<std::pair<int64_t, std::function<int32_t()>>> queue;
+  std::map<int64_t, int32_t> finished;
+  int64_t nextJob = 1;
+  bool stopWorker = false;
 };
 
 #define KZ_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \

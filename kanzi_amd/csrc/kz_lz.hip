@@ -92,6 +92,10 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
   const int maxDist = (srcEnd < 4 * LZ_MAXD1) ? LZ_MAXD1 : LZ_MAXD2;
   if (w) dst[12] = (u8)(((maxDist == LZ_MAXD1) ? 0 : 1) | (((minMatch - 2) & 7) << 1));
   int srcIdx = 0, anchor = 0, dstIdx = 13, mIdx = 0, mLenIdx = 0, tkIdx = 0;
+  // the reference's token buffer holds max(count / 5, 256) tokens and never grows (LZCodec.java:324-333): one more is an exception
+  // that ends the block with ERR_PROCESS_BLOCK (CompressedOutputStream.java:1041-1044) -> d_flag = -1
+  const int tkCap = max(count / 5, 256);
+  bool tkOver = false;
   int repd0 = count, repd1 = count;
   int repIdx = 0, srcInc = 0;
   bool ok = true;
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
     else token += mLen;
     repd1 = repd0; repd0 = dist; repIdx = 1;
     const int litLen = srcIdx - anchor;
+    if (tkIdx >= tkCap) { tkOver = true; break; }
     if (litLen == 0) { if (w) tkBuf[tkIdx] = (u8)token; tkIdx++; }
     else {
       if (litLen >= 7) {
@@ -297,6 +302,7 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
   if (ok) {
     const int litLen = count - anchor;
     if (dstIdx + litLen + tkIdx + mIdx + mLenIdx >= count) ok = false;                    // :571-572
+    else if (tkIdx >= tkCap) tkOver = true;
     else {
       if (litLen >= 7) { if (w) tkBuf[tkIdx] = (u8)(7 << 5); tkIdx++; dstIdx = lz_emit_length(dst, dstIdx, litLen - 7, w); }
       else { if (w) tkBuf[tkIdx] = (u8)(litLen << 5); tkIdx++; }
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
     }
   }
   asm volatile("" :: "v"(pfSink));                               // keep the prefetch loads alive
-  if (w) { d_flag[b] = (ok && res) ? 1 : 0; d_len2[b] = (ok && res) ? produced : count; }
+  if (w) { d_flag[b] = tkOver ? -1 : ((ok && res) ? 1 : 0); d_len2[b] = (!tkOver && ok && res) ? produced : count; }
 }
 
 // readLength; reads are bounded by the block length (past it the Java code throws or sees stale bytes: failure)

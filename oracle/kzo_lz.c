@@ -46,7 +46,9 @@ int kzo_lz_forward(int extra, int dataType, const uint8_t* src, int count, uint8
   if (dataType == 1) mm = 6; else if (dataType == 2) return 0;
   const int hsize = extra ? (1 << 19) : (1 << 16);
   int32_t* hashes = (int32_t*)calloc((size_t)hsize, sizeof(int32_t));
-  /* the reference grows mBuf/mLenBuf on demand and never grows tkBuf (count/5): sized here for the worst case */
+  /* the reference grows mBuf / mLenBuf on demand but never tkBuf, which holds max(count / 5, 256) tokens (LZCodec.java:324-333): one
+     token more is an ArrayIndexOutOfBoundsException that nothing catches before EncodingTask.call, i.e. the block and with it
+     the whole write fails with ERR_PROCESS_BLOCK (CompressedOutputStream.java:1041-1044).  Returned as -1. */
   const size_t bufSize = (size_t)count + 1024;
   uint8_t* mBuf = (uint8_t*)malloc(bufSize);
   uint8_t* mLenBuf = (uint8_t*)malloc(bufSize);
@@ -57,6 +59,8 @@ int kzo_lz_forward(int extra, int dataType, const uint8_t* src, int count, uint8
   dst[12] |= (uint8_t)(((mm - 2) & 0x07) << 1);
   const int minMatch = mm;
   int srcIdx = 0, anchor = 0, dstIdx = 13, mIdx = 0, mLenIdx = 0, tkIdx = 0;
+  const int tkCap = (count / 5 > 256) ? count / 5 : 256;
+  int tkOver = 0;
   int repd[2] = { count, count };
   int repIdx = 0, srcInc = 0, ok = 1;
 
@@ -133,6 +137,7 @@ int kzo_lz_forward(int extra, int dataType, const uint8_t* src, int count, uint8
     else token += mLen;
     repd[1] = repd[0]; repd[0] = dist; repIdx = 1;
     const int litLen = srcIdx - anchor;
+    if (tkIdx >= tkCap) { tkOver = 1; break; }
     if (litLen == 0) tkBuf[tkIdx++] = (uint8_t)token;
     else {
       if (litLen >= 7) {
@@ -157,6 +162,7 @@ int kzo_lz_forward(int extra, int dataType, const uint8_t* src, int count, uint8
   if (ok) {
     const int litLen = count - anchor;
     if (dstIdx + litLen + tkIdx + mIdx + mLenIdx >= count) ok = 0;           /* :571-572 */
+    else if (tkIdx >= tkCap) tkOver = 1;
     else {
       if (litLen >= 7) { tkBuf[tkIdx++] = (uint8_t)(7 << 5); dstIdx = emit_length(dst, dstIdx, litLen - 7); }
       else tkBuf[tkIdx++] = (uint8_t)(litLen << 5);
@@ -172,6 +178,7 @@ int kzo_lz_forward(int extra, int dataType, const uint8_t* src, int count, uint8
     }
   }
   free(hashes); free(mBuf); free(mLenBuf); free(tkBuf);
+  if (tkOver) { *produced = 0; return -1; }
   return ok ? res : 0;
 }
 

@@ -147,8 +147,11 @@ int kzo_sequence_forward(const int* types, int nb, int* dataType, const uint8_t*
   int count = n;
   for (int i = 0; i < nb; i++) {
     int produced = 0;
-    /* a transform that returns false leaves the data untouched (Sequence.java:95-105) */
-    if (!kzo_transform_forward(types[i], dataType, in, count, out, required, &produced)) continue;
+    /* a transform that returns false leaves the data untouched (Sequence.java:95-105); one that throws (LZ's token buffer) ends
+       the block: nothing catches it before EncodingTask.call (-13 = ERR_PROCESS_BLOCK) */
+    const int tr = kzo_transform_forward(types[i], dataType, in, count, out, required, &produced);
+    if (tr < 0) { free(bufA); free(bufB); return -13; }
+    if (!tr) continue;
     skipFlags &= (uint8_t)~(1 << (7 - i));
     count = produced;
     uint8_t* t = in; in = out; out = t;
@@ -248,7 +251,7 @@ int64_t kzo_encode_block_y(uint64_t transformType, int entropyType, int chkKind,
   uint8_t skipFlags = 0xFF;
   int dataType = kzo_block_data_type(data, n);                                     /* :795-804 */
   int postLen = kzo_sequence_forward(types, nb, &dataType, data, n, buffer, required, &skipFlags);
-  if (postLen < 0) { free(buffer); return -1; }
+  if (postLen < 0) { free(buffer); return postLen == -13 ? -13 : -1; }
   int dataSize = (postLen < 256) ? 1 : (ilog2((uint32_t)postLen) >> 3) + 1;       /* :825-826 */
   mode |= (uint8_t)(((dataSize - 1) & 3) << 5);
   kzo_obs os; kzo_obs_init(&os, (size_t)n + (n >> 3) + 1024);
@@ -424,7 +427,7 @@ static void* enc_worker(void* arg) {
     size_t cap = (size_t)len + (len >> 3) + 1024;
     j->outs[b] = (uint8_t*)malloc(cap);
     j->bits[b] = kzo_encode_block_y(j->transformType, j->entropyType, j->chkKind, j->blockSize, j->src + off, len, j->outs[b], cap, NULL, NULL);
-    if (j->bits[b] < 0) j->fail = 1;
+    if (j->bits[b] < 0) j->fail = (j->bits[b] == -13) ? 13 : 1;
   }
   return NULL;
 }
@@ -466,6 +469,7 @@ int64_t kzo_compress_x(uint64_t transformType, int entropyType, int blockSize, i
     if (nbytes <= dstCap) { memcpy(dst, s.buf, (size_t)nbytes); ret = nbytes; }
     kzo_obs_free(&s);
   }
+  if (job.fail == 13) ret = -13;                                   /* a block's transform threw: ERR_PROCESS_BLOCK */
   for (int b = 0; b < nblocks; b++) free(outs[b]);
   free(outs); free(bits); pthread_mutex_destroy(&mu);
   return ret;

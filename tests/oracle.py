@@ -95,6 +95,10 @@ def ttype(names):
     return int(lib().kzo_transform_type(ids, len(names)))
 
 
+class TransformThrows(RuntimeError):
+    """the reference's transform would throw (LZ: more tokens than its fixed token buffer holds): the block fails with ERR_PROCESS_BLOCK"""
+
+
 def set_transform_ctx(entropy="NONE", block_size=4 * 1024 * 1024):
     """the context entries "entropy" and "blockSize" the next single-transform calls of this thread see (TEXT reads them)"""
     lib().kzo_set_transform_ctx(E[entropy.upper()], int(block_size))
@@ -111,6 +115,8 @@ def transform_forward(name, data, cap=None, data_type=None):
     p = ctypes.c_int(0)
     dt = ctypes.c_int(0 if data_type is None else int(data_type))
     ok = lib().kzo_transform_forward(t, None if data_type is None else ctypes.addressof(dt), a.ctypes.data if len(a) else out.ctypes.data, len(a), out.ctypes.data, cap, ctypes.byref(p))
+    if ok < 0:
+        raise TransformThrows(name)
     if data_type is not None:
         return bool(ok), out[:p.value].tobytes(), int(dt.value)
     return bool(ok), out[:p.value].tobytes()
@@ -158,6 +164,8 @@ def encode_block(chain, entropy, data, checksum=0, block_size=4 * 1024 * 1024):
     sf = ctypes.c_uint8(0)
     pl = ctypes.c_int(0)
     w = lib().kzo_encode_block_y(ttype(chain), E[entropy.upper()], {0: 0, 32: 1, 64: 2}[checksum], int(block_size), a.ctypes.data, len(a), out.ctypes.data, cap, ctypes.byref(sf), ctypes.byref(pl))
+    if w == -13:
+        raise OracleError(13)
     if w < 0:
         raise RuntimeError("oracle encode_block failed")
     return out[:(w + 7) // 8].tobytes(), int(w), sf.value, pl.value
@@ -175,6 +183,8 @@ def compress(chain, entropy, block_size, data, jobs=1, checksum=0, skip_blocks=F
     cap = 2 * len(a) + 65536                   # 1 KiB blocks of random bytes through SRT grow by 28 %: header of 256 frequencies per block
     out = np.zeros(cap, dtype=np.uint8)
     r = lib().kzo_compress_x(ttype(chain), E[entropy.upper()], block_size, {0: 0, 32: 1, 64: 2}[checksum] | (0x100 if skip_blocks else 0), a.ctypes.data if len(a) else out.ctypes.data, len(a), out.ctypes.data, cap, jobs)
+    if r == -13:
+        raise OracleError(13)
     if r < 0:
         raise RuntimeError("oracle compress failed %d" % r)
     return out[:r].tobytes()

@@ -117,3 +117,35 @@ def test_reference_levels_map_to_chains():
         assert e.value.code == 3
     for t, _ in (kz.level_chain(l) for l in (0, 1, 2, 3, 5, 6)):
         kz.transform_type(t)
+
+
+def test_jni_shim_compiles_against_the_stub_header():
+    """integration/jni/kanzi_hip_jni.c cannot be built here (no JDK); it is kept compilable with gcc -fsyntax-only against
+    integration/jni/stub/jni.h, which declares the JNI functions it uses with the specification's signatures."""
+    import subprocess
+    src = os.path.join(ROOT, "integration", "jni", "kanzi_hip_jni.c")
+    r = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-std=c11", "-I" + os.path.join(ROOT, "integration", "jni", "stub"),
+                        "-I" + os.path.join(ROOT, "include"), src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # every native method KanziHip.java declares has its JNI function, and vice versa
+    java = open(os.path.join(ROOT, "integration", "java", "KanziHip.java")).read()
+    natives = set(re.findall(r"static native \w+ (\w+)\(", java))
+    funcs = set(re.findall(r"CLS\((\w+)\)\(", open(src).read()))
+    assert natives == funcs and "decodeBlocks" in natives, (natives ^ funcs)
+
+
+def test_reference_patch_applies():
+    """integration/kanzi-hip.patch is a diff against the reference's Java tree (factories, DecodingTask, processBlock)."""
+    import shutil
+    import subprocess
+    import tempfile
+    ref = "/root/reference/java"
+    if not os.path.isdir(ref):
+        pytest.skip("the reference tree only exists in the build container")
+    with tempfile.TemporaryDirectory() as tmp:
+        for rel in ("transform/TransformFactory.java", "entropy/EntropyCodecFactory.java", "io/CompressedOutputStream.java", "io/CompressedInputStream.java"):
+            dst = os.path.join(tmp, "java/src/main/java/io/github/flanglet/kanzi", rel)
+            os.makedirs(os.path.dirname(dst), exist_ok=True)
+            shutil.copy(os.path.join(ref, "src/main/java/io/github/flanglet/kanzi", rel), dst)
+        r = subprocess.run(["patch", "-p1", "--dry-run", "-i", os.path.join(ROOT, "integration", "kanzi-hip.patch")], cwd=tmp, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr

@@ -165,26 +165,29 @@ def test_corrupt_block_header_is_rejected(ctx):
         kz.CompressedInputStream(ctx, bytes(knz)).read(len(data))
 
 
-def test_full_size_blocks_properties(ctx):
-    """BASELINE sizes (4 MiB blocks): encode -> decode identity for a batch, and the HIP .knz equals the
-    oracle's on a two-block sample (the oracle needs seconds per 4 MiB block)."""
+@pytest.mark.parametrize("chain,ent", [("BWT+RANK+ZRLT", "ANS0"), ("LZ", "ANS0"), ("BWT+SRT+ZRLT", "FPAQ"), ("LZ", "HUFFMAN")])
+def test_full_size_blocks_properties(ctx, chain, ent):
+    """Every BASELINE config at its own size (4 MiB blocks): encode -> decode identity for a batch of six blocks (one of each
+    synthetic class, the uniform random one ends as a raw "transformed copy"), and the HIP block streams equal the oracle's on
+    two of them (the oracle needs seconds per 4 MiB block)."""
     bs = 4 * 1024 * 1024
     B = 6
     inp = np.stack([datagen.block(i, bs) for i in range(B)])
     lens = np.full(B, bs, dtype=np.int32)
     ostride = kz.max_block_stream_bytes(bs)
     out = np.zeros((B, ostride), dtype=np.uint8)
-    res = kz.encode_blocks(ctx, "BWT+RANK+ZRLT", "ANS0", inp, bs, lens, out, ostride)
+    res = kz.encode_blocks(ctx, chain, ent, inp, bs, lens, out, ostride)
     assert all(r.status == 0 for r in res)
-    assert res[3].mode & 0x80 and res[3].skipFlags == 0x1F or res[3].skipFlags != 0x1F   # uniform random block: raw fallback expected
+    assert res[3].mode & 0x80                                             # uniform random block: nothing compresses it
     bits = np.array([r.bits for r in res], dtype=np.int64)
     dec = np.zeros((B, bs), dtype=np.uint8)
-    res2 = kz.decode_blocks(ctx, "BWT+RANK+ZRLT", "ANS0", bs, out, ostride, bits, dec, bs)
+    res2 = kz.decode_blocks(ctx, chain, ent, bs, out, ostride, bits, dec, bs)
     assert all(r.status == 0 and r.length == bs for r in res2)
     assert np.array_equal(dec, inp)
     for i in (0, 4):
-        s, w, sf, pl = oracle.encode_block("BWT+RANK+ZRLT", "ANS0", inp[i])
-        assert res[i].bits == w and out[i, :(w + 7) // 8].tobytes() == s
+        s, w, sf, pl = oracle.encode_block(chain, ent, inp[i])
+        assert (res[i].bits, res[i].skipFlags, res[i].length) == (w, sf, pl)
+        assert out[i, :(w + 7) // 8].tobytes() == s
 
 
 @pytest.mark.parametrize("bits", [32, 64])
@@ -911,3 +914,40 @@ def test_level5_at_4mib_blocks(ctx):
     cos.close()
     assert cos.output == oracle.compress(chain, ent, bs, data, jobs=4)
     assert kz.CompressedInputStream(ctx, cos.output).read() == data
+
+
+def test_async_batches_on_two_contexts(ctx):
+    """kz_submit_* / kz_wait: one host thread keeps two contexts busy (encode of batch k+1 under the decode of batch k); results equal
+    the synchronous calls'."""
+    bs, B = 65536, 16
+    ctx2 = kz.Context(0)
+    try:
+        batches = [np.stack([datagen.block(k * B + i, bs) for i in range(B)]) for k in range(3)]
+        lens = np.full(B, bs, dtype=np.int32)
+        ostride = kz.max_block_stream_bytes(bs)
+        sync = []
+        for inp in batches:
+            out = np.zeros((B, ostride), dtype=np.uint8)
+            res = kz.encode_blocks(ctx, "BWT+RANK+ZRLT", "ANS0", inp, bs, lens, out, ostride)
+            sync.append((out, [(r.bits, r.length, r.skipFlags) for r in res]))
+        outs = [np.zeros((B, ostride), dtype=np.uint8) for _ in batches]
+        decs = [np.zeros((B, bs), dtype=np.uint8) for _ in batches]
+        enc_job = kz.submit_encode_blocks(ctx, "BWT+RANK+ZRLT", "ANS0", batches[0], bs, lens, outs[0], ostride)
+        dec_jobs = []
+        for k in range(len(batches)):
+            res = enc_job.wait()
+            assert [(r.bits, r.length, r.skipFlags) for r in res] == sync[k][1]
+            for i in range(B):
+                nby = (res[i].bits + 7) // 8
+                assert outs[k][i, :nby].tobytes() == sync[k][0][i, :nby].tobytes()
+            if k + 1 < len(batches):
+                enc_job = kz.submit_encode_blocks(ctx, "BWT+RANK+ZRLT", "ANS0", batches[k + 1], bs, lens, outs[k + 1], ostride)
+            bits = np.array([r.bits for r in res], dtype=np.int64)
+            dec_jobs.append(kz.submit_decode_blocks(ctx2, "BWT+RANK+ZRLT", "ANS0", bs, outs[k], ostride, bits, decs[k], bs))
+        for k, j in enumerate(dec_jobs):
+            res2 = j.wait()
+            assert all(r.status == 0 and r.length == bs for r in res2)
+            assert np.array_equal(decs[k], batches[k])
+        assert ctx.lib.kz_wait(ctx.h, 10 ** 6) == -18                     # unknown job: ERR_INVALID_PARAM
+    finally:
+        ctx2.close()
