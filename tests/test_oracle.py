@@ -306,3 +306,18 @@ def test_alias_codec_known_answer():
     assert ok and out == bytes([254, ord("a"), ord("b"), 0]) + bytes([0x11]) * 256
     ok, out, _ = oracle.transform_forward("PACK", b"q" * 1500, data_type=0)
     assert ok and out == bytes([255, ord("q")]) + (1500).to_bytes(4, "little")
+
+
+def test_fpaq_known_answers_from_a_python_model_of_the_reference():
+    """FPAQ on blocks of a few bytes against tests/katmodels.fpaq_encode, a pure-Python model written from
+    K/entropy/FPAQEncoder.java:84-97,128-238 (not from oracle/kzo_fpaq_srt.c).  First step by hand, block 00 00: low = 0,
+    high = 2^56 - 1, p[1] = 32768: split = ((2^56 - 1) >>> 8) * 32768 >>> 8 = 0x7FFFFFFFFFFF80, the bit is 0 so
+    low = split + 1 = 0x7FFFFFFFFFFF81 and p[1] = 32768 - 512 = 32256; the top 32 bits of low and high still differ, so nothing is
+    flushed.  After the 16 bits nothing has been flushed: the chunk is empty (varint 00) and dispose() writes low | 0xFFFFFF in
+    56 bits."""
+    import katmodels
+    assert katmodels.fpaq_encode(b"\x00\x00").hex() == "00fffede31ffffff"
+    for data in (b"\x00\x00", b"AB", b"\xff\x00\x80\x7f", bytes(range(40)), b"a" * 100, bytes([0x0F, 0xF0] * 9)):
+        model = katmodels.fpaq_encode(data)
+        enc, nbits = oracle.entropy_encode("FPAQ", data)
+        assert nbits == 8 * len(model) and enc[:len(model)] == model, data[:8]
