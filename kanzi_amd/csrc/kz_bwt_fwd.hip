@@ -23,6 +23,7 @@
 //      final: sa[slot] = val.  Two max-scans (old-group start index, new-group start index) give the slots.
 #include "kz_device.h"
 #include "kz_internal.h"
+#include <stdlib.h>
 
 #define RS_ITEMS 16
 #define RS_TILE (KZ_WG * RS_ITEMS)   // 4096 elements per workgroup
@@ -554,6 +555,10 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
     KZ_HIP(hipStreamSynchronize(st));
     mMax = 0;
     for (int b = 0; b < B; b++) if (ctx->hpin[b] > mMax) mMax = ctx->hpin[b];
+    if (getenv("KZ_BWT_TRACE")) {                                   // diagnostic: live suffixes left after every doubling round
+      long long tot = 0, totN = 0; for (int b = 0; b < B; b++) { tot += ctx->hpin[b]; totN += bt.h_len[b]; }
+      fprintf(stderr, "[bwt] round %d h=%d: live %lld of %lld (%.1f%%), max per block %d\n", round, h, tot, totN, 100.0 * tot / (totN ? totN : 1), mMax);
+    }
     int32_t* tm = A.d_m; A.d_m = A.d_m2; A.d_m2 = tm;
   }
   if (mMax > 0) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: suffix sort did not converge"); return -KZ_ERR_PROCESS_BLOCK; }
