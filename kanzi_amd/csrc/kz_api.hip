@@ -39,6 +39,9 @@ extern "C" void kz_ctx_destroy(kz_ctx* ctx) {
   }
   hipSetDevice(ctx->device);
   if (ctx->arena) hipFree(ctx->arena);
+  if (ctx->side) hipStreamDestroy(ctx->side);
+  if (ctx->evFork) hipEventDestroy(ctx->evFork);
+  if (ctx->evJoin) hipEventDestroy(ctx->evJoin);
   if (ctx->hpin) hipHostFree(ctx->hpin);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -544,6 +547,86 @@ static void host_inverse_block(int b, void* arg) {
   H.len[b] = len;
 }
 
+// ---- decoder: RANK / MTFT inverse and BWT inverse of a large batch, overlapped -------------------------------------------
+// The RANK inverse is serial per block (one wave per block, no HBM traffic to speak of) and its launch lasts as long as its
+// slowest block; the BWT inverse behind it is bandwidth bound.  Run back to back the second waits for blocks the first has long
+// finished.  Here the expensive blocks (cost hint = length at the previous stage's input ~ non-zero ranks) take the RANK
+// inverse on a side stream while the cheap ones go through RANK inverse AND BWT inverse on the main stream; the expensive
+// blocks' BWT inverse follows.  Blocks live in fixed slots of the two ping-pong buffers, so the groups are lengths-masked
+// views of the same batch.  Only for batches where both stages apply to the same blocks.
+__global__ void k_merge_groups(const int32_t* __restrict__ inS, const int32_t* __restrict__ lenS, const int32_t* __restrict__ flagS,
+                               const int32_t* __restrict__ inF, const int32_t* __restrict__ lenF, const int32_t* __restrict__ flagF,
+                               const int32_t* __restrict__ lenOld, int32_t* __restrict__ lenOut, int32_t* __restrict__ applied, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (inS[b]) { lenOut[b] = flagS[b] > 0 ? lenS[b] : lenOld[b]; applied[b] = flagS[b] > 0 ? 1 : 0; }
+  else if (inF[b]) { lenOut[b] = flagF[b] > 0 ? lenF[b] : lenOld[b]; applied[b] = flagF[b] > 0 ? 1 : 0; }
+  else { lenOut[b] = lenOld[b]; applied[b] = 0; }
+}
+static int fuse_min_blocks() {                                      // batches below this take the stages one after the other
+  const char* e = getenv("KZ_FUSE_MIN_BLOCKS");                     // (read per call: the tests force both schedules)
+  return e ? atoi(e) : 512;
+}
+// returns 1 when it ran both stages (h_applied = blocks both were applied to), 0 when the schedule does not apply, <0 on error
+static int overlapped_rank_bwt_inverse(kz_ctx* ctx, Pipe& P, int mode, const std::vector<int32_t>& h_mask, const std::vector<int32_t>& cost,
+                                       std::vector<int32_t>& h_applied) {
+  kz_batch& bt = P.bt;
+  const int B = bt.B;
+  if (B < fuse_min_blocks()) return 0;
+  int64_t maxCost = 0;
+  for (int b = 0; b < B; b++) if (h_mask[b]) maxCost = std::max<int64_t>(maxCost, cost[b]);
+  std::vector<int32_t> inS(B, 0), inF(B, 0);
+  int nS = 0, nF = 0;
+  for (int b = 0; b < B; b++) {
+    if (!h_mask[b]) continue;
+    if ((int64_t)cost[b] * 4 >= maxCost * 3) { inS[b] = 1; nS++; } else { inF[b] = 1; nF++; }
+  }
+  if (nS < 8 || nF < 8) return 0;                                   // nothing to overlap
+  hipStream_t st = ctx->stream;
+  if (!ctx->side) {
+    KZ_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    KZ_HIP(hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming));
+    KZ_HIP(hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming));
+  }
+  int32_t* d = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4 * 9);
+  if (!d) { snprintf(ctx->err, sizeof(ctx->err), "overlapped inverse: arena overflow"); return -KZ_ERR_DEVICE; }
+  int32_t *d_inS = d, *d_inF = d + B, *lenS = d + 2 * B, *lenS2 = d + 3 * B, *flagS = d + 4 * B, *lenF = d + 5 * B, *lenF2 = d + 6 * B, *flagF = d + 7 * B, *lenOld = d + 8 * B;
+  KZ_HIP(hipMemcpyAsync(d_inS, inS.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemcpyAsync(d_inF, inF.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemcpyAsync(lenOld, bt.d_len, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+  KZ_LAUNCH(ctx, KID_MASK_LEN, k_mask_len, dim3((B + 255) / 256), dim3(256), lenOld, d_inS, lenS, B);
+  KZ_LAUNCH(ctx, KID_MASK_LEN, k_mask_len, dim3((B + 255) / 256), dim3(256), lenOld, d_inF, lenF, B);
+  KZ_HIP(hipStreamSynchronize(st));                                 // inS / inF are locals; the side stream starts from here
+  kz_batch vS = bt, vF = bt;                                        // views: same slots, masked lengths, own length / flag arrays
+  vS.d_len = lenS; vS.d_len2 = lenS2; vS.d_flag = flagS;
+  vF.d_len = lenF; vF.d_len2 = lenF2; vF.d_flag = flagF;
+  for (int b = 0; b < B; b++) { if (!inS[b]) vS.h_len[b] = 0; if (!inF[b]) vF.h_len[b] = 0; }
+  int rc;
+  std::swap(ctx->stream, ctx->side);                                // the expensive blocks' RANK inverse goes first, on the side stream
+  rc = kz_stage_sbrt_inverse(ctx, vS, mode);
+  if (!rc) { hipError_t e = hipEventRecord(ctx->evJoin, ctx->stream); if (e != hipSuccess) rc = -KZ_ERR_DEVICE; }
+  std::swap(ctx->stream, ctx->side);
+  if (rc) return rc;
+  rc = kz_stage_sbrt_inverse(ctx, vF, mode);
+  if (rc) return rc;
+  const size_t mark = ctx->arenaTop;
+  rc = kz_stage_bwt_inverse(ctx, vF);
+  if (rc) return rc;
+  KZ_HIP(hipStreamWaitEvent(st, ctx->evJoin, 0));
+  ctx->arenaTop = mark;                                             // same stream, in order: the scratch is free again
+  rc = kz_stage_bwt_inverse(ctx, vS);
+  if (rc) return rc;
+  // both views are back in the buffer they started from (two stages each); the batch's own state is untouched except lengths
+  KZ_LAUNCH(ctx, KID_MASK_LEN, k_merge_groups, dim3((B + 255) / 256), dim3(256), d_inS, vS.d_len, vS.d_flag, d_inF, vF.d_len, vF.d_flag,
+            lenOld, bt.d_len, P.d_applied, B);
+  KZ_HIP(hipMemcpyAsync(ctx->hpin + B, P.d_applied, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  rc = sync_lengths(ctx, bt);
+  if (rc) return rc;
+  h_applied.resize(B);
+  for (int b = 0; b < B; b++) h_applied[b] = ctx->hpin[B + b];
+  return 1;
+}
+
 // =================================================================================================
 // encode
 extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType,
@@ -931,8 +1014,23 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     bool any = false;
     for (int b = 0; b < B; b++) { h_mask[b] = (!h_status[b] && !(h_skip[b] & (1 << (7 - i))) && bt.h_len[b] > 0) ? 1 : 0; any |= h_mask[b] != 0; }
     if (!any) continue;
-    hipEvent_t e1; kz_stage_begin(ctx, &e1);
     const int type = types[i];
+    if ((type == KZ_T_RANK || type == KZ_T_MTFT) && i - 1 >= hp && types[i - 1] == KZ_T_BWT) {
+      // RANK / MTFT inverse followed by the BWT inverse on the same blocks: overlapped schedule for large batches
+      bool same = true;
+      for (int b = 0; b < B && same; b++) same = ((h_skip[b] >> (7 - i)) & 1) == ((h_skip[b] >> (8 - i)) & 1);
+      if (same) {
+        const int fr = overlapped_rank_bwt_inverse(ctx, P, type == KZ_T_RANK ? 2 : 1, h_mask, bt.h_cost, h_applied);
+        if (fr < 0) return fr;
+        if (fr > 0) {
+          for (int b = 0; b < B; b++) if (h_mask[b] && !h_applied[b]) { h_status[b] = -KZ_ERR_PROCESS_BLOCK; bt.h_len[b] = 0; }
+          prevIn = bt.h_len;
+          i--;                                                        // the BWT stage is done as well
+          continue;
+        }
+      }
+    }
+    hipEvent_t e1; kz_stage_begin(ctx, &e1);
     rc = run_stage(ctx, P, h_mask, h_applied, [&](kz_batch& x) { return run_transform_stage(ctx, x, type, false, dataCap); });
     if (rc) return rc;
     int64_t outBytes = 0; for (int b = 0; b < B; b++) if (h_mask[b]) outBytes += bt.h_len[b];

@@ -19,6 +19,8 @@ struct KzPending { hipEvent_t e0, e1; int id; };
 struct kz_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;     // second stream for the overlapped RANK-inverse / BWT-inverse schedule (created on first use)
+  hipEvent_t evFork = nullptr, evJoin = nullptr;
   // grow-only device arena, bump-allocated per API call
   uint8_t* arena = nullptr;
   size_t arenaCap = 0, arenaTop = 0;

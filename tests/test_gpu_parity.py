@@ -951,3 +951,33 @@ def test_async_batches_on_two_contexts(ctx):
         assert ctx.lib.kz_wait(ctx.h, 10 ** 6) == -18                     # unknown job: ERR_INVALID_PARAM
     finally:
         ctx2.close()
+
+
+def test_overlapped_rank_bwt_inverse_schedule(ctx, monkeypatch):
+    """Large batches decode the expensive blocks' RANK inverse on a side stream while the other blocks go on to the BWT
+    inverse (kz_api.hip: overlapped_rank_bwt_inverse).  Forced here on a small batch: same bytes, lengths and statuses as the
+    stage-by-stage schedule, corrupted blocks and raw / copy blocks included."""
+    bs, B = 65536, 40
+    inp = np.stack([datagen.block(i, bs) for i in range(B)])
+    lens = np.full(B, bs, dtype=np.int32)
+    lens[3], lens[11], lens[17] = 9, 0, 30000
+    ostride = kz.max_block_stream_bytes(bs)
+    for chain in ("BWT+RANK+ZRLT", "BWT+MTFT+ZRLT"):
+        out = np.zeros((B, ostride), dtype=np.uint8)
+        res = kz.encode_blocks(ctx, chain, "ANS0", inp, bs, lens, out, ostride)
+        bits = np.array([r.bits for r in res], dtype=np.int64)
+        bad = out.copy()
+        bad[5, 40:60] ^= 0x5A                       # damage inside one block's payload
+        bad[22, 3] ^= 0x01                          # and inside another block's header
+        results = {}
+        for mode, env in (("staged", "1000000"), ("overlapped", "8")):
+            monkeypatch.setenv("KZ_FUSE_MIN_BLOCKS", env)
+            for name, streams in (("good", out), ("bad", bad)):
+                dec = np.zeros((B, bs), dtype=np.uint8)
+                r2 = kz.decode_blocks(ctx, chain, "ANS0", bs, streams, ostride, bits, dec, bs)
+                results[(mode, name)] = ([(r.status, r.length) for r in r2], [dec[i, :max(r2[i].length, 0)].tobytes() for i in range(B)])
+        assert results[("staged", "good")] == results[("overlapped", "good")]
+        assert results[("staged", "bad")] == results[("overlapped", "bad")]
+        st = results[("overlapped", "good")][0]
+        assert all(s == 0 and l == lens[i] for i, (s, l) in enumerate(st))
+        assert all(results[("overlapped", "good")][1][i] == inp[i, :lens[i]].tobytes() for i in range(B))
