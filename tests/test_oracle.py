@@ -321,3 +321,24 @@ def test_fpaq_known_answers_from_a_python_model_of_the_reference():
         model = katmodels.fpaq_encode(data)
         enc, nbits = oracle.entropy_encode("FPAQ", data)
         assert nbits == 8 * len(model) and enc[:len(model)] == model, data[:8]
+
+
+def test_ans0_known_answers_from_a_python_model_of_the_reference():
+    """ANS0 against tests/katmodels.ans0_encode, a pure-Python model written from K/entropy/ANSRangeEncoder.java:263-407,473-496 and
+    K/entropy/EntropyUtils.java:38-75,141-250 (not from oracle/kzo_ans.c): a 33-byte chunk (the smallest that is not stored, :267-270),
+    chunks with a partial and with the full alphabet, a one-symbol chunk (header only, :292-295), a two-chunk block, skewed
+    frequencies that take normalizeFrequencies' fast and slow paths."""
+    import katmodels
+    rng = np.random.default_rng(2)
+    cases = [bytes(range(33)), b"abracadabra" * 3, bytes(rng.integers(0, 256, 100, dtype=np.uint8)), b"a" * 40, b"ab" * 20 + b"c",
+             bytes(np.minimum(rng.geometric(0.2, 700) - 1, 255).astype(np.uint8)), bytes(rng.integers(0, 4, 20000, dtype=np.uint8)),
+             bytes(rng.integers(0, 256, 5000, dtype=np.uint8)), b"x" * 10,
+             bytes(np.minimum(rng.geometric(0.01, 3000) - 1, 255).astype(np.uint8)), bytes([0] * 3000 + [1, 2, 3] * 11)]
+    for data in cases:
+        model, nbits = katmodels.ans0_encode(data)
+        enc, obits = oracle.entropy_encode("ANS0", data)
+        assert obits == nbits and enc[:len(model)] == model, (len(data), nbits, obits)
+    # the 33-byte ramp, first bits by hand: logRange - 8 = 4 in 3 bits (100), partial alphabet (1), last mask byte 33 >> 3 = 4 in 5 bits
+    # (00100), then the masks FF FF FF FF 01
+    model, _ = katmodels.ans0_encode(bytes(range(33)))
+    assert model[:6].hex() == "927fffffff80" and (model[6] & 0x80) == 0x80      # those 49 bits; the frequency header follows
