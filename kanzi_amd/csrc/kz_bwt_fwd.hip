@@ -338,7 +338,9 @@ __global__ __launch_bounds__(KZ_WG) void k_seg_apply(const u64* __restrict__ key
       const bool headN = (c + 1 >= m) || (nextk != k[r]);
       const u32 sv = val[c];
       const bool live = !(headC && headN);
-      rank[sv] = (g + (hh - ss)) | (live ? BW_LIVE : 0u);
+      // the first new group of an old group keeps the old head slot: while it stays LIVE its members' ranks (g | LIVE since the
+      // round before) do not change, and the random 4-byte store is saved (not in the first round: ranks are unwritten then)
+      if (!(live && hh == ss && gshift < 64)) rank[sv] = (g + (hh - ss)) | (live ? BW_LIVE : 0u);
       if (!live) sa[g + ((u32)c - ss)] = sv;
     }
     if (hb[r]) carH = (u32)(rowBase + 63 - (int)__builtin_clzll(hb[r])) + 1;
