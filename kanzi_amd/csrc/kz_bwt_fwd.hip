@@ -39,8 +39,11 @@ typedef u64 __attribute__((aligned(1))) bw_u64_unaligned;
 struct BwtArrays {
   u64* key[2]; u32* val[2];
   u32* rank; u32* sa;
-  u32* tileHist;     // [B][T][256]
-  u32* digitBase;    // [B][256]
+  u32* tileHist;     // [B][radix tiles][256 | MSD_BINS]
+  u32* digitBase;    // [B][MSD_BINS]
+  u32* bucketCnt;    // [B][MSD_BINS] elements per bucket of the current round (bit 31: too large for the LDS sort)
+  int32_t* d_w;      // [B] window start: the LSD passes and the k_seg_* kernels work on [d_w, d_m) of the compact arrays
+  int32_t* d_big;    // [B] d_m - d_w after k_msd_scan
   u32* tileA;        // [B][T] scan temporaries
   u32* tileB;        // [B][T]
   u32* tileLive;     // [B][T] live suffixes of the text tile in the previous round (0 stays 0: suffixes only become final)
@@ -49,13 +52,14 @@ struct BwtArrays {
   int32_t* d_m2;     // [B] compact size (next)
   int64_t NS;        // element stride per block
   int T;             // tile stride per block
+  int64_t HS;        // tileHist stride per block: radix tiles x MSD_BINS
 };
 
 // ---------------------------------------------------------------------------------------------
 // round 0 keys: the first 7 bytes, zero padded at the end of the text.  A truncated suffix can therefore share a
 // group with suffixes that continue with real zero bytes; it is a prefix of all of them, must sort first, and
 // does: k_live_emit gives positions past the end of the text the smallest, distinct secondary keys.
-__global__ void k_bwt_init(const u8* __restrict__ src, int64_t srcStride, u64* keyC, u32* valC, BwtArrays A) {
+__global__ void k_bwt_init(const u8* __restrict__ src, int64_t srcStride, u64* keyC, u32* valC, BwtArrays A, int K) {
   const int b = blockIdx.y;
   const int n = A.d_n[b];
   const u8* s = src + (int64_t)b * srcStride;
@@ -64,31 +68,35 @@ __global__ void k_bwt_init(const u8* __restrict__ src, int64_t srcStride, u64* k
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int rem = n - i;
     // first 7 bytes as a big-endian number: one unaligned 8-byte load (blocks have >= 4 KiB of slack behind them)
-    u64 k = __builtin_bswap64(*(const bw_u64_unaligned*)(s + i)) >> 8;
-    if (rem < 7) k &= ~0ULL << (8 * (7 - rem));                     // zero padding at the end of the text
-    key[i] = k; val[i] = (u32)i;                                    // 56 bits: 7 radix passes
+    u64 k = __builtin_bswap64(*(const bw_u64_unaligned*)(s + i)) >> (8 * (8 - K));
+    if (rem < K) k &= ~0ULL << (8 * (K - rem));                     // zero padding at the end of the text
+    key[i] = k; val[i] = (u32)i;                                    // 8K bits: K radix passes
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { A.d_m[b] = n; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { A.d_m[b] = n; A.d_w[b] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------
-// radix pass 1/3: per-tile digit histogram (LDS, wave-aggregated via ballot match-any)
-__global__ __launch_bounds__(KZ_WG) void k_radix_hist(const u64* __restrict__ keyIn, BwtArrays A, int shift) {
+// radix pass 1/3: per-tile digit histogram (LDS, wave-aggregated via ballot match-any).  BINS = 256 for the LSD passes,
+// MSD_BINS for the bucket partition of the later rounds (k_msd_*).
+#define MSD_BINS 1024
+template <int BINS, bool MSD>
+__device__ __forceinline__ void radix_hist_body(const u64* __restrict__ keyIn, const BwtArrays& A, int shift) {
   const int b = blockIdx.y;
-  const int m = A.d_m[b];
+  const int w0 = MSD ? 0 : A.d_w[b];
+  const int m = A.d_m[b] - w0;
   const int tile = blockIdx.x;
   if ((int64_t)tile * RSORT_TILE >= m) return;
-  __shared__ u32 hist[256];
-  hist[threadIdx.x] = 0;
+  __shared__ u32 hist[BINS];
+  for (int i = threadIdx.x; i < BINS; i += KZ_WG) hist[i] = 0;
   __syncthreads();
-  const u64* key = keyIn + (int64_t)b * A.NS;
+  const u64* key = keyIn + (int64_t)b * A.NS + w0;
   const int base = tile * RSORT_TILE;
   const int lane = kz_lane();
 #pragma unroll 4
   for (int r = 0; r < RSORT_ITEMS; r++) {
     const int idx = base + r * KZ_WG + threadIdx.x;
     const bool valid = idx < m;
-    const u32 d = valid ? (u32)((key[idx] >> shift) & 0xFF) : 0;
+    const u32 d = valid ? (u32)((key[idx] >> shift) & (BINS - 1)) : 0;
     // skewed digits (one value for the whole row: high key bytes, runs) would serialise 64 LDS atomics on one
     // address: those rows add once; rows with mixed digits use plain LDS atomics (conflicts only on equal digits)
     const uint64_t vm = kz_ballot(valid);
@@ -96,19 +104,21 @@ __global__ __launch_bounds__(KZ_WG) void k_radix_hist(const u64* __restrict__ ke
     if (vm != 0 && kz_ballot(valid && d == d0) == vm) { if (lane == (int)__builtin_ctzll(vm)) atomicAdd(&hist[d0], (u32)__popcll(vm)); }
     else if (valid) atomicAdd(&hist[d], 1u);
   }
-  (void)lane;
   __syncthreads();
-  A.tileHist[((int64_t)b * A.T + tile) * 256 + threadIdx.x] = hist[threadIdx.x];
+  u32* th = A.tileHist + (int64_t)b * A.HS + (int64_t)tile * BINS;
+  for (int i = threadIdx.x; i < BINS; i += KZ_WG) th[i] = hist[i];
 }
+__global__ __launch_bounds__(KZ_WG) void k_radix_hist(const u64* __restrict__ keyIn, BwtArrays A, int shift) { radix_hist_body<256, false>(keyIn, A, shift); }
+__global__ __launch_bounds__(KZ_WG) void k_msd_hist(const u64* __restrict__ keyIn, BwtArrays A, int shift) { radix_hist_body<MSD_BINS, true>(keyIn, A, shift); }
 
 // radix pass 2/3: per block, thread d walks the tiles (coalesced across d) -> exclusive tile
 // offsets per digit, then an exclusive scan over digit totals.
 __global__ __launch_bounds__(256) void k_radix_scan(BwtArrays A) {
   const int b = blockIdx.x;
-  const int m = A.d_m[b];
+  const int m = A.d_m[b] - A.d_w[b];
   const int tiles = (m + RSORT_TILE - 1) / RSORT_TILE;
   __shared__ u32 lds[32];
-  u32* h = A.tileHist + (int64_t)b * A.T * 256;
+  u32* h = A.tileHist + (int64_t)b * A.HS;
   u32 run = 0;
   for (int t = 0; t < tiles; t++) {
     u32 v = h[(int64_t)t * 256 + threadIdx.x];
@@ -117,7 +127,38 @@ __global__ __launch_bounds__(256) void k_radix_scan(BwtArrays A) {
   }
   u32 total;
   u32 ex = kz_wg_excl_sum(run, lds, &total);
-  A.digitBase[b * 256 + threadIdx.x] = ex;
+  A.digitBase[b * MSD_BINS + threadIdx.x] = ex;
+}
+
+// Bucket partition of a later round (k_msd_hist / k_msd_scan / k_msd_scatter): the top bits of the OLD GROUP (a slot of
+// the suffix array) split the compact list into buckets of BK_SLOTS slots; a bucket holds at most as many live suffixes
+// as it has slots (plus the overhang of its last group), and old groups never span buckets, so a bucket that fits the
+// LDS is sorted and applied by one workgroup (k_bucket_sort): one read of the pair instead of six LSD passes.
+// Buckets above BK_CAP elements (long runs: one old group of many thousand suffixes) are placed BEHIND the small ones,
+// in bucket order, and that window [d_w, d_m) goes through the LSD passes and k_seg_* as before.
+#define BK_BITS 12
+#define BK_CAP 6144            // 4096 slots + an overhang of 2048: 48 KiB of LDS, two workgroups per CU
+#define BK_BIG 0x80000000u
+__global__ __launch_bounds__(MSD_BINS) void k_msd_scan(BwtArrays A) {
+  const int b = blockIdx.x;
+  const int m = A.d_m[b];
+  const int tiles = (m + RSORT_TILE - 1) / RSORT_TILE;
+  __shared__ u32 lds[32];
+  u32* h = A.tileHist + (int64_t)b * A.HS;
+  u32 run = 0;
+  for (int t = 0; t < tiles; t++) {
+    u32 v = h[(int64_t)t * MSD_BINS + threadIdx.x];
+    h[(int64_t)t * MSD_BINS + threadIdx.x] = run;
+    run += v;
+  }
+  const bool big = run > BK_CAP;
+  u32 mSmall, mBig;
+  const u32 exS = kz_wg_excl_sum(big ? 0u : run, lds, &mSmall);
+  __syncthreads();
+  const u32 exB = kz_wg_excl_sum(big ? run : 0u, lds, &mBig);
+  A.digitBase[b * MSD_BINS + threadIdx.x] = big ? mSmall + exB : exS;
+  A.bucketCnt[b * MSD_BINS + threadIdx.x] = big ? (run | BK_BIG) : run;
+  if (threadIdx.x == 0) { A.d_w[b] = (int32_t)mSmall; A.d_big[b] = (int32_t)mBig; }
 }
 
 // radix pass 3/3: stable scatter.  Wave w owns the contiguous sub-tile [w*1024, (w+1)*1024);
@@ -128,20 +169,32 @@ __global__ __launch_bounds__(256) void k_radix_scan(BwtArrays A) {
 #define RSC_WAVES 16                      // scatter workgroup: 16 waves x 16 rows of 64 keys = one radix tile
 #define RSC_ITEMS (RSORT_TILE / (64 * RSC_WAVES))
 #define RSC_WG (64 * RSC_WAVES)
-__global__ __launch_bounds__(RSC_WG) void k_radix_scatter(const u64* __restrict__ keyIn, const u32* __restrict__ valIn,
-                                                           u64* __restrict__ keyOut, u32* __restrict__ valOut,
-                                                           BwtArrays A, int shift) {
+template <int NBITS>
+__device__ __forceinline__ uint64_t bw_match(u32 d, bool valid) {
+  uint64_t m = kz_ballot(valid);
+#pragma unroll
+  for (int b = 0; b < NBITS; b++) {
+    const uint64_t bal = kz_ballot((d >> b) & 1u);
+    m &= ((d >> b) & 1u) ? bal : ~bal;
+  }
+  return valid ? m : 0ULL;
+}
+template <int BINS, int NBITS, bool MSD, typename CNT>
+__device__ __forceinline__ void radix_scatter_body(const u64* __restrict__ keyIn, const u32* __restrict__ valIn,
+                                                   u64* __restrict__ keyOut, u32* __restrict__ valOut,
+                                                   const BwtArrays& A, int shift) {
   const int b = blockIdx.y;
-  const int m = A.d_m[b];
+  const int w0 = MSD ? 0 : A.d_w[b];
+  const int m = A.d_m[b] - w0;
   const int tile = blockIdx.x;
   if ((int64_t)tile * RSORT_TILE >= m) return;
-  __shared__ u32 cnt[RSC_WAVES][256];
-  __shared__ u32 gdelta[256];        // global slot of the digit's first element of this tile - its tile-local slot
+  __shared__ CNT cnt[RSC_WAVES][BINS];
+  __shared__ u32 gdelta[BINS];       // global slot of the digit's first element of this tile - its tile-local slot
   __shared__ u32 scan[32];
   __shared__ u64 stage[RSORT_TILE];  // 64 KiB: keys, then values
-  for (int i = threadIdx.x; i < RSC_WAVES * 256; i += RSC_WG) (&cnt[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < RSC_WAVES * BINS; i += RSC_WG) (&cnt[0][0])[i] = 0;
   __syncthreads();
-  const int64_t off = (int64_t)b * A.NS;
+  const int64_t off = (int64_t)b * A.NS + w0;
   const int wave = threadIdx.x >> 6;
   const int lane = kz_lane();
   const int tbase = tile * RSORT_TILE;
@@ -160,41 +213,41 @@ __global__ __launch_bounds__(RSC_WG) void k_radix_scatter(const u64* __restrict_
   for (int r = 0; r < RSC_ITEMS; r++) {
     const int idx = base + r * 64 + lane;
     const bool valid = idx < m;
-    const u32 d = (u32)((k[r] >> shift) & 0xFF);
+    const u32 d = (u32)((k[r] >> shift) & (BINS - 1));
     // rows holding a single digit value (high key bytes, runs) skip the 8-ballot match-any
     const uint64_t vm = kz_ballot(valid);
     const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
     const bool uni = (vm != 0) && (kz_ballot(valid && d == d0) == vm);
-    const uint64_t peers = uni ? (valid ? vm : 0ULL) : kz_match8(d, valid);
+    const uint64_t peers = uni ? (valid ? vm : 0ULL) : bw_match<NBITS>(d, valid);
     u32 pre = 0;
     if (valid) pre = cnt[wave][d];
     const u32 rnk = pre + (u32)__popcll(peers & lt);
     // the highest peer lane publishes the new count (all peers read `pre` before: same wave, in order)
-    if (valid && (peers >> lane) == 1ULL) cnt[wave][d] = pre + (u32)__popcll(peers);
-    dr[r] = d | (rnk << 8);
+    if (valid && (peers >> lane) == 1ULL) cnt[wave][d] = (CNT)(pre + (u32)__popcll(peers));
+    dr[r] = d | (rnk << 16);
   }
   __syncthreads();
   {
     u32 tot = 0;
     u32 c[RSC_WAVES];
-    const int d = threadIdx.x & 255;
+    const int d = threadIdx.x & (BINS - 1);
 #pragma unroll
     for (int w = 0; w < RSC_WAVES; w++) { c[w] = cnt[w][d]; tot += c[w]; }
     u32 total;
-    // exclusive scan over the 256 digits (threads 256..511 carry zero and are ignored)
-    const u32 ts = kz_wg_excl_sum(threadIdx.x < 256 ? tot : 0u, scan, &total);
-    if (threadIdx.x < 256) {
-      gdelta[d] = A.digitBase[b * 256 + d] + A.tileHist[((int64_t)b * A.T + tile) * 256 + d] - ts;
+    // exclusive scan over the digits (the threads behind them carry zero and are ignored)
+    const u32 ts = kz_wg_excl_sum(threadIdx.x < BINS ? tot : 0u, scan, &total);
+    if (threadIdx.x < BINS) {
+      gdelta[d] = A.digitBase[b * MSD_BINS + d] + A.tileHist[(int64_t)b * A.HS + (int64_t)tile * BINS + d] - ts;
       u32 run = ts;
 #pragma unroll
-      for (int w = 0; w < RSC_WAVES; w++) { cnt[w][d] = run; run += c[w]; }
+      for (int w = 0; w < RSC_WAVES; w++) { cnt[w][d] = (CNT)run; run += c[w]; }
     }
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < RSC_ITEMS; r++) {
     const int idx = base + r * 64 + lane;
-    if (idx < m) { const u32 slot = cnt[wave][dr[r] & 0xFF] + (dr[r] >> 8); dr[r] = slot; stage[slot] = k[r]; }
+    if (idx < m) { const u32 slot = cnt[wave][dr[r] & 0xFFFF] + (dr[r] >> 16); dr[r] = slot; stage[slot] = k[r]; }
   }
   __syncthreads();
   u32 gp[RSC_ITEMS];
@@ -203,7 +256,7 @@ __global__ __launch_bounds__(RSC_WG) void k_radix_scatter(const u64* __restrict_
     const int slot = r * RSC_WG + threadIdx.x;
     if (slot < tcount) {
       const u64 kk = stage[slot];
-      gp[r] = gdelta[(u32)((kk >> shift) & 0xFF)] + (u32)slot;
+      gp[r] = gdelta[(u32)((kk >> shift) & (BINS - 1))] + (u32)slot;
       keyOut[off + gp[r]] = kk;
     }
   }
@@ -212,6 +265,92 @@ __global__ __launch_bounds__(RSC_WG) void k_radix_scatter(const u64* __restrict_
 #pragma unroll
   for (int r = 0; r < RSC_ITEMS; r++) {
     const int idx = base + r * 64 + lane;
+    if (idx < m) stageV[dr[r]] = v[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RSC_ITEMS; r++) {
+    const int slot = r * RSC_WG + threadIdx.x;
+    if (slot < tcount) valOut[off + gp[r]] = stageV[slot];
+  }
+}
+__global__ __launch_bounds__(RSC_WG) void k_radix_scatter(const u64* __restrict__ keyIn, const u32* __restrict__ valIn,
+                                                           u64* __restrict__ keyOut, u32* __restrict__ valOut,
+                                                           BwtArrays A, int shift) { radix_scatter_body<256, 8, false, u32>(keyIn, valIn, keyOut, valOut, A, shift); }
+// The bucket partition need not be stable (k_bucket_sort orders by the whole key, and suffixes with equal keys stay
+// one group whatever their order), so the tile-local rank of an element is simply an LDS atomic on its bucket's counter.
+__global__ __launch_bounds__(RSC_WG) void k_msd_scatter(const u64* __restrict__ keyIn, const u32* __restrict__ valIn,
+                                                         u64* __restrict__ keyOut, u32* __restrict__ valOut,
+                                                         BwtArrays A, int shift) {
+  const int b = blockIdx.y;
+  const int m = A.d_m[b];
+  const int tile = blockIdx.x;
+  if ((int64_t)tile * RSORT_TILE >= m) return;
+  __shared__ u32 cnt[MSD_BINS];
+  __shared__ u32 gdelta[MSD_BINS];
+  __shared__ u32 scan[32];
+  __shared__ u64 stage[RSORT_TILE];  // 128 KiB: keys, then values
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t off = (int64_t)b * A.NS;
+  const int lane = kz_lane();
+  const int tbase = tile * RSORT_TILE;
+  const int tcount = min(RSORT_TILE, m - tbase);
+  const uint64_t lt = kz_lanemask_lt();
+  u64 k[RSC_ITEMS]; u32 v[RSC_ITEMS]; u32 dr[RSC_ITEMS];
+#pragma unroll
+  for (int r = 0; r < RSC_ITEMS; r++) {
+    const int idx = tbase + r * RSC_WG + threadIdx.x;
+    const bool valid = idx < m;
+    k[r] = valid ? keyIn[off + idx] : 0;
+    v[r] = valid ? valIn[off + idx] : 0;
+  }
+#pragma unroll
+  for (int r = 0; r < RSC_ITEMS; r++) {
+    const int idx = tbase + r * RSC_WG + threadIdx.x;
+    const bool valid = idx < m;
+    const u32 d = (u32)(k[r] >> shift) & (MSD_BINS - 1);
+    const uint64_t vm = kz_ballot(valid);
+    const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
+    u32 pos = 0;
+    if (vm != 0 && kz_ballot(valid && d == d0) == vm) {             // one bucket for the whole row: one atomic
+      u32 basePos = 0;
+      if (lane == (int)__builtin_ctzll(vm)) basePos = atomicAdd(&cnt[d0], (u32)__popcll(vm));
+      basePos = (u32)__shfl((int)basePos, (int)__builtin_ctzll(vm), 64);
+      pos = basePos + (u32)__popcll(vm & lt);
+    } else if (valid) pos = atomicAdd(&cnt[d], 1u);
+    dr[r] = pos;
+  }
+  __syncthreads();
+  {
+    const u32 tot = cnt[threadIdx.x];
+    u32 total;
+    const u32 ts = kz_wg_excl_sum(tot, scan, &total);
+    gdelta[threadIdx.x] = A.digitBase[b * MSD_BINS + threadIdx.x] + A.tileHist[(int64_t)b * A.HS + (int64_t)tile * MSD_BINS + threadIdx.x] - ts;
+    cnt[threadIdx.x] = ts;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RSC_ITEMS; r++) {
+    const int idx = tbase + r * RSC_WG + threadIdx.x;
+    if (idx < m) { const u32 slot = cnt[(u32)(k[r] >> shift) & (MSD_BINS - 1)] + dr[r]; dr[r] = slot; stage[slot] = k[r]; }
+  }
+  __syncthreads();
+  u32 gp[RSC_ITEMS];
+#pragma unroll
+  for (int r = 0; r < RSC_ITEMS; r++) {
+    const int slot = r * RSC_WG + threadIdx.x;
+    if (slot < tcount) {
+      const u64 kk = stage[slot];
+      gp[r] = gdelta[(u32)(kk >> shift) & (MSD_BINS - 1)] + (u32)slot;
+      keyOut[off + gp[r]] = kk;
+    }
+  }
+  __syncthreads();
+  u32* stageV = (u32*)stage;
+#pragma unroll
+  for (int r = 0; r < RSC_ITEMS; r++) {
+    const int idx = tbase + r * RSC_WG + threadIdx.x;
     if (idx < m) stageV[dr[r]] = v[r];
   }
   __syncthreads();
@@ -249,11 +388,12 @@ __device__ __forceinline__ void bw_row_flags(const u64* __restrict__ key, int ba
 // per tile: (last index+1 where the old group changes, last index+1 where the key changes)
 __global__ __launch_bounds__(KZ_WG) void k_seg_reduce(const u64* __restrict__ keyS, BwtArrays A, int gshift) {
   const int b = blockIdx.y;
-  const int m = A.d_m[b];
+  const int w0 = A.d_w[b];
+  const int m = A.d_m[b] - w0;
   const int tile = blockIdx.x;
   if ((int64_t)tile * RS_TILE >= m) return;
   __shared__ u32 wS[4], wH[4];
-  const u64* key = keyS + (int64_t)b * A.NS;
+  const u64* key = keyS + (int64_t)b * A.NS + w0;
   const int wave = threadIdx.x >> 6, lane = kz_lane();
   const int base = tile * RS_TILE + wave * (64 * RS_ITEMS);
   u64 k[RS_ITEMS]; uint64_t hb[RS_ITEMS], sb[RS_ITEMS];
@@ -274,7 +414,7 @@ __global__ __launch_bounds__(KZ_WG) void k_seg_reduce(const u64* __restrict__ ke
 // per block: exclusive max-scans over the tiles -- one wave per block
 __global__ void k_seg_scan(BwtArrays A) {
   const int b = blockIdx.x;
-  const int m = A.d_m[b];
+  const int m = A.d_m[b] - A.d_w[b];
   const int tiles = (m + RS_TILE - 1) / RS_TILE;
   u32* ta = A.tileA + (int64_t)b * A.T;
   u32* tb = A.tileB + (int64_t)b * A.T;
@@ -295,12 +435,13 @@ __global__ void k_seg_scan(BwtArrays A) {
 // group is a singleton, in which case the suffix is final
 __global__ __launch_bounds__(KZ_WG) void k_seg_apply(const u64* __restrict__ keyS, const u32* __restrict__ valS, BwtArrays A, int gshift) {
   const int b = blockIdx.y;
-  const int m = A.d_m[b];
+  const int w0 = A.d_w[b];
+  const int m = A.d_m[b] - w0;
   const int tile = blockIdx.x;
   if ((int64_t)tile * RS_TILE >= m) return;
   __shared__ u32 wS[4], wH[4];
   const int64_t off = (int64_t)b * A.NS;
-  const u64* key = keyS + off;
+  const u64* key = keyS + off + w0;
   const int wave = threadIdx.x >> 6, lane = kz_lane();
   const int base = tile * RS_TILE + wave * (64 * RS_ITEMS);
   u64 k[RS_ITEMS]; uint64_t hb[RS_ITEMS], sb[RS_ITEMS];
@@ -318,7 +459,7 @@ __global__ __launch_bounds__(KZ_WG) void k_seg_apply(const u64* __restrict__ key
   for (int w = 0; w < wave; w++) { carS = max(carS, wS[w]); carH = max(carH, wH[w]); }
   u32* rank = A.rank + off;
   u32* sa = A.sa + off;
-  const u32* val = valS + off;
+  const u32* val = valS + off + w0;
   const uint64_t le = kz_lanemask_lt() | (1ULL << lane);
   const u64 afterLast = (base + 64 * RS_ITEMS < m) ? key[base + 64 * RS_ITEMS] : 0;   // uniform
 #pragma unroll
@@ -346,6 +487,327 @@ __global__ __launch_bounds__(KZ_WG) void k_seg_apply(const u64* __restrict__ key
     if (hb[r]) carH = (u32)(rowBase + 63 - (int)__builtin_clzll(hb[r])) + 1;
     if (sb[r]) carS = (u32)(rowBase + 63 - (int)__builtin_clzll(sb[r])) + 1;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One bucket of a later round, start to finish in one workgroup: load the bucket's pairs, LSD radix sort them in LDS
+// by (old group, secondary key), then do what k_seg_reduce / k_seg_apply do for the sorted run.  An element is one
+// u64: (group - bucket base : BK_BITS | r2 : bitsR | suffix : bitsG), 58 bits for 4 MiB blocks.  Wave w owns the
+// contiguous rows [w*R, (w+1)*R) of 64 elements; between passes the elements live in registers, the LDS buffer is
+// only the exchange.  Two shapes are launched over all buckets and each takes the buckets of its size class:
+// k_bucket_sort_s (4 waves, up to 1024 elements, 12 KiB of LDS: many per CU; a bucket of <= 64 is ranked by one wave
+// with all-pairs compares and no barrier at all) and k_bucket_sort (16 waves, up to BK_CAP).
+#define BK_DBITS 9             // LDS sort digit: 36 key bits of a 4 MiB block in four passes
+#define BK_DBINS (1 << BK_DBITS)
+#define BK_SMALL 1024
+#define BK_SORT 0x40000000u
+static_assert(RSC_WG == MSD_BINS, "k_msd_scatter geometry");
+
+template <int WAVES, int ROWS, int LO, int HI>
+__device__ __forceinline__ void bucket_body(const u64* __restrict__ keyS, const u32* __restrict__ valS, const BwtArrays& A, int bitsR, int bitsG) {
+  const int b = blockIdx.y;
+  const u32 d = blockIdx.x;
+  const u32 bc0 = A.bucketCnt[b * MSD_BINS + d];
+  if ((bc0 & (BK_SORT | BK_BIG)) != BK_SORT) return;          // only the buckets k_bucket_count left behind
+  const u32 bc = bc0 & ~BK_SORT;
+  const int cnt = (int)bc;
+  const int wave = threadIdx.x >> 6, lane = kz_lane();
+  const bool tiny = false;
+  if (tiny && wave != 0) return;
+  __shared__ u64 buf[WAVES * ROWS * 64];
+  __shared__ uint16_t cw[WAVES][BK_DBINS];                     // per-wave digit counts, then bucket-local slots
+  __shared__ u32 wsum[BK_DBINS / 64];
+  __shared__ u32 wS[WAVES], wH[WAVES];
+  __shared__ int skip[8];
+  const int64_t off = (int64_t)b * A.NS;
+  const u32 bo = A.digitBase[b * MSD_BINS + d];
+  const int rows = (cnt + 63) >> 6;
+  const int R = (rows + WAVES - 1) / WAVES;                    // rows per wave, 1..ROWS (uniform)
+  const int base = wave * R * 64;
+  const uint64_t lt = kz_lanemask_lt();
+  const u64 kbase = (u64)d << (bitsR + BK_BITS);
+  u64 k[ROWS]; u32 dr[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+    const int idx = base + r * 64 + lane;
+    k[r] = ~0ULL;
+    if (r < R && idx < cnt) k[r] = ((keyS[off + bo + idx] - kbase) << bitsG) | (u64)valS[off + bo + idx];
+  }
+  if (tiny) {
+    // all elements differ (the suffix is part of the element): rank = number of smaller elements
+    const u32 klo = (u32)k[0], khi = (u32)(k[0] >> 32);
+    u32 rk = 0;
+    for (int j = 0; j < cnt; j++) {
+      const u64 kj = ((u64)(u32)__builtin_amdgcn_readlane((int)khi, j) << 32) | (u32)__builtin_amdgcn_readlane((int)klo, j);
+      rk += (kj < k[0]) ? 1u : 0u;
+    }
+    if (lane < cnt) buf[rk] = k[0];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < cnt) k[0] = buf[lane];
+  } else {
+    if (threadIdx.x < 8) skip[threadIdx.x] = 0;
+    const int keyBits = bitsR + BK_BITS;
+    const int passes = (keyBits + BK_DBITS - 1) / BK_DBITS;
+    for (int p = 0; p < passes; p++) {
+      const int shift = bitsG + BK_DBITS * p;
+      for (int i = threadIdx.x; i < WAVES * BK_DBINS / 2; i += WAVES * 64) ((u32*)&cw[0][0])[i] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < ROWS; r++) {
+        if (r < R) {
+          const int idx = base + r * 64 + lane;
+          const bool valid = idx < cnt;
+          const u32 dg = (u32)(k[r] >> shift) & (BK_DBINS - 1);
+          const uint64_t vm = kz_ballot(valid);
+          if (vm == 0) continue;                               // rows behind the bucket's last element (uniform)
+          const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)dg);
+          const bool uni = kz_ballot(valid && dg == d0) == vm;
+          const uint64_t peers = uni ? (valid ? vm : 0ULL) : bw_match<BK_DBITS>(dg, valid);
+          u32 pre = 0;
+          if (valid) pre = cw[wave][dg];
+          const u32 rnk = pre + (u32)__popcll(peers & lt);
+          if (valid && (peers >> lane) == 1ULL) cw[wave][dg] = (uint16_t)(pre + (u32)__popcll(peers));
+          dr[r] = dg | (rnk << 16);
+        }
+      }
+      __syncthreads();
+      // digit totals and their exclusive scan: thread t owns the digits t, t + WAVES*64, ...
+      constexpr int DPT = (BK_DBINS + WAVES * 64 - 1) / (WAVES * 64);
+      u32 c[DPT][WAVES]; u32 tot[DPT]; u32 mine = 0;
+#pragma unroll
+      for (int q = 0; q < DPT; q++) {
+        const int dg = threadIdx.x * DPT + q;                  // consecutive digits per thread: a plain scan order
+        tot[q] = 0;
+        if (dg < BK_DBINS) {
+#pragma unroll
+          for (int w = 0; w < WAVES; w++) { c[q][w] = cw[w][dg]; tot[q] += c[q][w]; }
+          if (tot[q] == (u32)cnt) skip[p] = 1;                 // one digit value for the whole bucket: nothing moves
+        }
+        mine += tot[q];
+      }
+      const u32 inc = kz_wave_incl_sum(mine);
+      if (lane == 63 && wave < BK_DBINS / 64) wsum[wave] = inc;
+      __syncthreads();
+      if (skip[p]) continue;                                   // uniform
+      {
+        u32 run = inc - mine;
+        for (int w = 0; w < wave && w < BK_DBINS / 64; w++) run += wsum[w];
+#pragma unroll
+        for (int q = 0; q < DPT; q++) {
+          const int dg = threadIdx.x * DPT + q;
+          if (dg < BK_DBINS) {
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) { cw[w][dg] = (uint16_t)run; run += c[q][w]; }
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < ROWS; r++) {
+        if (r < R) {
+          const int idx = base + r * 64 + lane;
+          if (idx < cnt) buf[cw[wave][dr[r] & 0xFFFF] + (dr[r] >> 16)] = k[r];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < ROWS; r++) {
+        if (r < R) {
+          const int idx = base + r * 64 + lane;
+          if (idx < cnt) k[r] = buf[idx];
+        }
+      }
+      __syncthreads();
+    }
+    // sorted: neighbours through the LDS buffer
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+      if (r < R) {
+        const int idx = base + r * 64 + lane;
+        if (idx < cnt) buf[idx] = k[r];
+      }
+    }
+    __syncthreads();
+  }
+  uint64_t hb[ROWS], sb[ROWS];
+  u32 ms = 0, mh = 0;
+  const int gsh = bitsG + bitsR;
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+    hb[r] = 0; sb[r] = 0;
+    if (r < R) {
+      const int idx = base + r * 64 + lane;
+      const bool valid = idx < cnt;
+      const u64 prev = (valid && idx > 0) ? buf[idx - 1] : 0;
+      const bool head = valid && (idx == 0 || (k[r] >> bitsG) != (prev >> bitsG));
+      const bool seg = head && (idx == 0 || (k[r] >> gsh) != (prev >> gsh));
+      hb[r] = kz_ballot(head);
+      sb[r] = kz_ballot(seg);
+      if (hb[r]) mh = (u32)(base + r * 64 + 63 - (int)__builtin_clzll(hb[r])) + 1;
+      if (sb[r]) ms = (u32)(base + r * 64 + 63 - (int)__builtin_clzll(sb[r])) + 1;
+    }
+  }
+  u32 carS = 0, carH = 0;
+  if (!tiny) {
+    if (lane == 0) { wS[wave] = ms; wH[wave] = mh; }
+    __syncthreads();
+    for (int w = 0; w < wave; w++) { carS = max(carS, wS[w]); carH = max(carH, wH[w]); }
+  }
+  u32* rank = A.rank + off;
+  u32* sa = A.sa + off;
+  const uint64_t le = lt | (1ULL << lane);
+  const u64 vmask = (1ULL << bitsG) - 1ULL;
+  const u32 gbase = d << BK_BITS;
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+    if (r < R) {
+      const int rowBase = base + r * 64;
+      const int idx = rowBase + lane;
+      const uint64_t hbl = hb[r] & le, sbl = sb[r] & le;
+      const u32 hh = hbl ? (u32)(rowBase + 63 - (int)__builtin_clzll(hbl)) : carH - 1;
+      const u32 ss = sbl ? (u32)(rowBase + 63 - (int)__builtin_clzll(sbl)) : carS - 1;
+      if (idx < cnt) {
+        const u64 nextk = (idx + 1 < cnt) ? buf[idx + 1] : 0;
+        const bool headC = hh == (u32)idx;
+        const bool headN = (idx + 1 >= cnt) || ((nextk >> bitsG) != (k[r] >> bitsG));
+        const bool live = !(headC && headN);
+        const u32 g = gbase + (u32)(k[r] >> gsh);
+        const u32 sv = (u32)(k[r] & vmask);
+        if (!(live && hh == ss)) rank[sv] = (g + (hh - ss)) | (live ? BW_LIVE : 0u);     // see k_seg_apply
+        if (!live) sa[g + ((u32)idx - ss)] = sv;
+      }
+      if (hb[r]) carH = (u32)(rowBase + 63 - (int)__builtin_clzll(hb[r])) + 1;
+      if (sb[r]) carS = (u32)(rowBase + 63 - (int)__builtin_clzll(sb[r])) + 1;
+    }
+  }
+}
+__global__ __launch_bounds__(1024, 8) void k_bucket_sort(const u64* __restrict__ keyS, const u32* __restrict__ valS, BwtArrays A, int bitsR, int bitsG) {
+  bucket_body<16, BK_CAP / 1024, BK_SMALL, BK_CAP>(keyS, valS, A, bitsR, bitsG);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same job without sorting.  What the apply step needs of a suffix is only, among the members of its old group,
+// how many have a smaller secondary key (rk) and how many the same one (eq): the new group starts rk slots behind the
+// old head, it is a singleton iff eq == 1, and then the suffix's final slot is head + rk.  So the bucket is only
+// PARTITIONED by old group (LDS atomics on one counter per slot of the bucket: order inside a group is irrelevant), and
+// every element then walks the members of its group.  Groups are small where this is used (a handful of suffixes
+// sharing 7, 14, ... bytes); a bucket holding a group above BK_GMAX is left to k_bucket_sort (flag BK_SORT).
+#define BK_GMAX 256
+#define BK_SLOTS (1 << BK_BITS)
+template <int WAVES, int ROWS, int LO, int HI, typename CNT>
+__device__ __forceinline__ void bucket_count_body(const u64* __restrict__ keyS, const u32* __restrict__ valS, const BwtArrays& A, int bitsR, int bitsG, u32 gmax) {
+  const int b = blockIdx.y;
+  const u32 d = blockIdx.x;
+  const u32 bc = A.bucketCnt[b * MSD_BINS + d];
+  if (bc <= (u32)LO || bc > (u32)HI) return;
+  const int cnt = (int)bc;
+  const int wave = threadIdx.x >> 6, lane = kz_lane();
+  const bool tiny = LO == 0 && cnt <= 64;
+  if (tiny && wave != 0) return;
+  const int64_t off = (int64_t)b * A.NS;
+  const u32 bo = A.digitBase[b * MSD_BINS + d];
+  u32* rank = A.rank + off;
+  u32* sa = A.sa + off;
+  const u32 gbase = d << BK_BITS;
+  const u32 rmask = (1u << bitsR) - 1u;
+  constexpr int WG = WAVES * 64;
+  if (tiny) {
+    const bool valid = lane < cnt;
+    const u64 key = valid ? keyS[off + bo + lane] : ~0ULL;
+    const u32 sv = valid ? valS[off + bo + lane] : 0u;
+    const u32 gv = (u32)(key >> bitsR), rv = (u32)key & rmask;
+    u32 rk = 0, eq = 0;
+    for (int j = 0; j < cnt; j++) {
+      const u32 gj = (u32)__builtin_amdgcn_readlane((int)gv, j), rj = (u32)__builtin_amdgcn_readlane((int)rv, j);
+      if (gj == gv) { rk += (rj < rv) ? 1u : 0u; eq += (rj == rv) ? 1u : 0u; }
+    }
+    if (valid) {
+      const bool live = eq > 1;
+      if (!(live && rk == 0)) rank[sv] = (gv + rk) | (live ? BW_LIVE : 0u);               // see k_seg_apply
+      if (!live) sa[gv + rk] = sv;
+    }
+    return;
+  }
+  __shared__ u64 buf[WAVES * ROWS * 64];
+  __shared__ CNT start[BK_SLOTS];
+  __shared__ u32 wsum[WAVES];
+  __shared__ u32 gmaxS;
+  for (int i = threadIdx.x; i < BK_SLOTS; i += WG) start[i] = 0;
+  if (threadIdx.x == 0) gmaxS = 0;
+  __syncthreads();
+  const u64 kbase = (u64)d << (bitsR + BK_BITS);
+  u64 k[ROWS]; u32 pos[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+    const int idx = r * WG + threadIdx.x;
+    k[r] = 0; pos[r] = 0;
+    if (idx < cnt) {
+      k[r] = ((keyS[off + bo + idx] - kbase) << bitsG) | (u64)valS[off + bo + idx];
+      pos[r] = (u32)atomicAdd(&start[(u32)(k[r] >> (bitsG + bitsR))], (CNT)1);
+    }
+  }
+  __syncthreads();
+  {                                                            // exclusive scan over the slots: BK_SLOTS / WG consecutive per thread
+    constexpr int SPT = BK_SLOTS / WG;
+    u32 c[SPT]; u32 mine = 0, gm = 0;
+#pragma unroll
+    for (int q = 0; q < SPT; q++) { c[q] = start[threadIdx.x * SPT + q]; mine += c[q]; gm = max(gm, c[q]); }
+    const u32 inc = kz_wave_incl_sum(mine);
+    if (lane == 63) wsum[wave] = inc;
+    if (gm > gmax) atomicMax(&gmaxS, gm);
+    __syncthreads();
+    u32 run = inc - mine;
+    for (int w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+    for (int q = 0; q < SPT; q++) { start[threadIdx.x * SPT + q] = (CNT)run; run += c[q]; }
+  }
+  __syncthreads();
+  if (gmaxS > gmax) {                                        // a long group: the sorting kernel takes this bucket
+    if (threadIdx.x == 0) A.bucketCnt[b * MSD_BINS + d] = bc | BK_SORT;
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+    const int idx = r * WG + threadIdx.x;
+    if (idx < cnt) buf[(u32)start[(u32)(k[r] >> (bitsG + bitsR))] + pos[r]] = k[r];
+  }
+  __syncthreads();
+  const u64 vmask = (1ULL << bitsG) - 1ULL;
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+    const int idx = r * WG + threadIdx.x;                      // position in group order: a wave reads a few neighbouring groups
+    if (idx < cnt) {
+      const u64 e = buf[idx];
+      const u32 grel = (u32)(e >> (bitsG + bitsR));
+      const u32 rv = (u32)(e >> bitsG) & rmask;
+      const int gs = (int)start[grel];
+      const int ge = (grel + 1 < (u32)BK_SLOTS) ? (int)start[grel + 1] : cnt;
+      u32 rk = 0, eq = 0;
+      int j = gs;
+      for (; j + 4 <= ge; j += 4) {                            // four independent LDS reads in flight
+        const u64 e0 = buf[j], e1 = buf[j + 1], e2 = buf[j + 2], e3 = buf[j + 3];
+        const u32 r0 = (u32)(e0 >> bitsG) & rmask, r1 = (u32)(e1 >> bitsG) & rmask, r2_ = (u32)(e2 >> bitsG) & rmask, r3 = (u32)(e3 >> bitsG) & rmask;
+        rk += (r0 < rv) + (r1 < rv) + (r2_ < rv) + (r3 < rv);
+        eq += (r0 == rv) + (r1 == rv) + (r2_ == rv) + (r3 == rv);
+      }
+      for (; j < ge; j++) {
+        const u32 rj = (u32)(buf[j] >> bitsG) & rmask;
+        rk += (rj < rv) ? 1u : 0u; eq += (rj == rv) ? 1u : 0u;
+      }
+      const u32 sv = (u32)(e & vmask);
+      const u32 g = gbase + grel;
+      const bool live = eq > 1;
+      if (!(live && rk == 0)) rank[sv] = (g + rk) | (live ? BW_LIVE : 0u);
+      if (!live) sa[g + rk] = sv;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_bucket_count_s(const u64* __restrict__ keyS, const u32* __restrict__ valS, BwtArrays A, int bitsR, int bitsG, u32 gmax) {
+  bucket_count_body<4, BK_SMALL / 256, 0, BK_SMALL, u32>(keyS, valS, A, bitsR, bitsG, gmax);
+}
+__global__ __launch_bounds__(1024) void k_bucket_count(const u64* __restrict__ keyS, const u32* __restrict__ valS, BwtArrays A, int bitsR, int bitsG, u32 gmax) {
+  bucket_count_body<16, BK_CAP / 1024, BK_SMALL, BK_CAP, u32>(keyS, valS, A, bitsR, bitsG, gmax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -484,7 +946,7 @@ __global__ void k_bwt_emit(const u8* __restrict__ src, int64_t srcStride, u8* __
 size_t kz_bwt_forward_scratch(int B, int maxN) {
   const int64_t NS = (int64_t)kz_align((size_t)maxN, RS_TILE);
   const int T = (int)(NS / RS_TILE);
-  size_t per = (size_t)NS * (8 * 2 + 4 * 2 + 4 + 4) + (size_t)T * (256 * 4 + 12) + 256 * 4 + 64 + 9 * 256;
+  size_t per = (size_t)NS * (8 * 2 + 4 * 2 + 4 + 4) + (size_t)(T + 4) * (256 * 4 + 12) + 2 * MSD_BINS * 4 + 64 + 11 * 256;
   return kz_align(per * (size_t)B + 4096 * 16, 4096) + (1 << 20);
 }
 
@@ -497,21 +959,24 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
   const int64_t NS = (int64_t)kz_align((size_t)(maxN > 0 ? maxN : 1), RS_TILE);
   const int T = (int)(NS / RS_TILE);
   BwtArrays A;
-  A.NS = NS; A.T = T;
+  A.NS = NS; A.T = T; A.HS = (int64_t)((NS + RSORT_TILE - 1) / RSORT_TILE) * MSD_BINS;
   for (int i = 0; i < 2; i++) {
     A.key[i] = (u64*)kz_arena_alloc(ctx, (size_t)NS * B * 8);
     A.val[i] = (u32*)kz_arena_alloc(ctx, (size_t)NS * B * 4);
   }
   A.rank = (u32*)kz_arena_alloc(ctx, (size_t)NS * B * 4);
   A.sa = (u32*)kz_arena_alloc(ctx, (size_t)NS * B * 4);
-  A.tileHist = (u32*)kz_arena_alloc(ctx, (size_t)T * B * 256 * 4);
-  A.digitBase = (u32*)kz_arena_alloc(ctx, (size_t)B * 256 * 4);
+  A.tileHist = (u32*)kz_arena_alloc(ctx, (size_t)A.HS * B * 4);
+  A.digitBase = (u32*)kz_arena_alloc(ctx, (size_t)B * MSD_BINS * 4);
+  A.bucketCnt = (u32*)kz_arena_alloc(ctx, (size_t)B * MSD_BINS * 4);
+  A.d_w = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  A.d_big = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   A.tileA = (u32*)kz_arena_alloc(ctx, (size_t)T * B * 4);
   A.tileB = (u32*)kz_arena_alloc(ctx, (size_t)T * B * 4);
   A.tileLive = (u32*)kz_arena_alloc(ctx, (size_t)T * B * 4);
   A.d_m = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   A.d_m2 = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
-  if (!A.d_m2 || !A.tileB || !A.tileLive || !A.sa) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: arena overflow"); return -KZ_ERR_DEVICE; }
+  if (!A.d_m2 || !A.tileB || !A.tileLive || !A.sa || !A.d_big || !A.bucketCnt) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: arena overflow"); return -KZ_ERR_DEVICE; }
   A.d_n = bt.d_len;
   hipStream_t st = ctx->stream;
   const u8* src = bt.buf[bt.cur];
@@ -522,32 +987,70 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
   int bitsG = 1;
   while ((1LL << bitsG) < (int64_t)maxN) bitsG++;
 
+  const char* ek = getenv("KZ_BWT_K");
+  const int K0 = (ek && ek[0] >= '2' && ek[0] <= '7') ? ek[0] - '0' : 7;   // bytes of the first-round key
   u64 *kC = A.key[0], *kF = A.key[1];
   u32 *vC = A.val[0], *vF = A.val[1];
-  KZ_LAUNCH(ctx, KID_BWT_INIT, k_bwt_init, dim3(gridFor(maxN, 256 * 8), B), dim3(256), src, bt.stride, kC, vC, A);
+  KZ_LAUNCH(ctx, KID_BWT_INIT, k_bwt_init, dim3(gridFor(maxN, 256 * 8), B), dim3(256), src, bt.stride, kC, vC, A, K0);
   int mMax = maxN;
   int h = 0;
+  // bucket path of the later rounds: the packed LDS element needs BK_BITS + bitsR + bitsG <= 64
+  const char* eb = getenv("KZ_BWT_BUCKETS");
+  const bool useBuckets = (BK_BITS + bitsR + bitsG <= 64) && (1 << (bitsG > BK_BITS ? bitsG - BK_BITS : 0)) <= MSD_BINS && !(eb && eb[0] == '0');
+  const int nBuckets = 1 << (bitsG > BK_BITS ? bitsG - BK_BITS : 0);
+  const int bucketMin = 4096;                                      // below: the whole list is a handful of LSD tiles
+  bool windowed = false;
+  const char* eg = getenv("KZ_BWT_GMAX");
+  const u32 gmax = eg ? (u32)atoi(eg) : (u32)BK_GMAX;
   const int tilesN = gridFor(maxN, RS_TILE);
   for (int round = 0; round < 64 && mMax > 0; round++) {
-    // ---- sort (kC,vC): LSD radix, 8-bit digits, ping-pong with the free pair ----
-    const int nbits = (round == 0) ? 56 : bitsR + bitsG;
+    // ---- sort (kC,vC) and apply.  Later rounds of blocks up to 4 MiB: bucket partition + one LDS sort per bucket, the
+    //      LSD passes only for the window of oversized buckets; otherwise LSD radix over the whole compact list ----
+    const int nbits = (round == 0) ? 8 * K0 : bitsR + bitsG;
     const int passes = (nbits + 7) / 8;
-    const int tiles = gridFor(mMax, RS_TILE);
-    const int rtiles = gridFor(mMax, RSORT_TILE);
-    for (int p = 0; p < passes; p++) {
-      KZ_LAUNCH(ctx, KID_RADIX_HIST, k_radix_hist, dim3(rtiles, B), dim3(KZ_WG), kC, A, p * 8);
-      KZ_LAUNCH(ctx, KID_RADIX_SCAN, k_radix_scan, dim3(B), dim3(256), A);
-      KZ_LAUNCH(ctx, KID_RADIX_SCATTER, k_radix_scatter, dim3(rtiles, B), dim3(RSC_WG), kC, vC, kF, vF, A, p * 8);
-      u64* tk = kC; kC = kF; kF = tk;
-      u32* tv = vC; vC = vF; vF = tv;
-    }
-    // ---- SA order: new groups, ranks, final suffixes ----
     const int gshift = (round == 0) ? 64 : bitsR;
-    KZ_LAUNCH(ctx, KID_SEG_REDUCE, k_seg_reduce, dim3(tiles, B), dim3(KZ_WG), kC, A, gshift);
-    KZ_LAUNCH(ctx, KID_SEG_SCAN, k_seg_scan, dim3(B), dim3(64), A);
-    KZ_LAUNCH(ctx, KID_SEG_APPLY, k_seg_apply, dim3(tiles, B), dim3(KZ_WG), kC, vC, A, gshift);
+    const bool buckets = useBuckets && round > 0 && mMax >= bucketMin;
+    int wMax = mMax;                                               // largest LSD window of the batch
+    if (buckets) {
+      const int rt = gridFor(mMax, RSORT_TILE);
+      const int sh = bitsR + BK_BITS;
+      KZ_LAUNCH(ctx, KID_MSD_HIST, k_msd_hist, dim3(rt, B), dim3(KZ_WG), kC, A, sh);
+      KZ_LAUNCH(ctx, KID_MSD_SCAN, k_msd_scan, dim3(B), dim3(MSD_BINS), A);
+      KZ_HIP(hipMemcpyAsync(ctx->hpin, A.d_big, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+      KZ_LAUNCH(ctx, KID_MSD_SCATTER, k_msd_scatter, dim3(rt, B), dim3(RSC_WG), kC, vC, kF, vF, A, sh);
+      { u64* tk = kC; kC = kF; kF = tk; u32* tv = vC; vC = vF; vF = tv; }
+      KZ_LAUNCH(ctx, KID_BUCKET_COUNT_S, k_bucket_count_s, dim3(nBuckets, B), dim3(256), kC, vC, A, bitsR, bitsG, gmax);
+      KZ_LAUNCH(ctx, KID_BUCKET_COUNT, k_bucket_count, dim3(nBuckets, B), dim3(1024), kC, vC, A, bitsR, bitsG, gmax);
+      KZ_LAUNCH(ctx, KID_BUCKET_SORT, k_bucket_sort, dim3(nBuckets, B), dim3(1024), kC, vC, A, bitsR, bitsG);
+      KZ_HIP(hipStreamSynchronize(st));
+      wMax = 0;
+      for (int b = 0; b < B; b++) if (ctx->hpin[b] > wMax) wMax = ctx->hpin[b];
+      windowed = true;
+      if (getenv("KZ_BWT_TRACE")) {
+        long long tot = 0; for (int b = 0; b < B; b++) tot += ctx->hpin[b];
+        fprintf(stderr, "[bwt] round %d: %lld suffixes in oversized buckets, max per block %d\n", round, tot, wMax);
+      }
+    } else if (windowed) {
+      KZ_HIP(hipMemsetAsync(A.d_w, 0, (size_t)B * 4, st));
+      windowed = false;
+    }
+    if (wMax > 0) {
+      const int tiles = gridFor(wMax, RS_TILE);
+      const int rtiles = gridFor(wMax, RSORT_TILE);
+      for (int p = 0; p < passes; p++) {
+        KZ_LAUNCH(ctx, KID_RADIX_HIST, k_radix_hist, dim3(rtiles, B), dim3(KZ_WG), kC, A, p * 8);
+        KZ_LAUNCH(ctx, KID_RADIX_SCAN, k_radix_scan, dim3(B), dim3(256), A);
+        KZ_LAUNCH(ctx, KID_RADIX_SCATTER, k_radix_scatter, dim3(rtiles, B), dim3(RSC_WG), kC, vC, kF, vF, A, p * 8);
+        u64* tk = kC; kC = kF; kF = tk;
+        u32* tv = vC; vC = vF; vF = tv;
+      }
+      // ---- SA order: new groups, ranks, final suffixes ----
+      KZ_LAUNCH(ctx, KID_SEG_REDUCE, k_seg_reduce, dim3(tiles, B), dim3(KZ_WG), kC, A, gshift);
+      KZ_LAUNCH(ctx, KID_SEG_SCAN, k_seg_scan, dim3(B), dim3(64), A);
+      KZ_LAUNCH(ctx, KID_SEG_APPLY, k_seg_apply, dim3(tiles, B), dim3(KZ_WG), kC, vC, A, gshift);
+    }
     // ---- text order: compact the live suffixes, keys for the next round ----
-    h = (round == 0) ? 7 : h * 2;
+    h = (round == 0) ? K0 : h * 2;
     KZ_LAUNCH(ctx, KID_LIVE_COUNT, k_live_count, dim3(tilesN, B), dim3(KZ_WG), A, round == 0 ? 1 : 0);
     KZ_LAUNCH(ctx, KID_LIVE_SCAN, k_live_scan, dim3(B), dim3(64), A);
     KZ_LAUNCH(ctx, KID_LIVE_EMIT, k_live_emit, dim3(tilesN, B), dim3(KZ_WG), kF, vF, A, h, bitsR);

@@ -62,6 +62,59 @@ def test_transform_forward_and_inverse_match_oracle(ctx, name):
         assert ok_i and back == data, (name, len(data))
 
 
+def _group_shape_inputs():
+    """Inputs that steer the later suffix-sort rounds of the forward BWT through each of their paths (kz_bwt_fwd.hip):
+    groups of a few suffixes (counted in LDS), groups of several hundred to several thousand (sorted in LDS), groups
+    larger than a bucket (LSD window), and mixes of them in one block."""
+    rng = np.random.default_rng(77)
+    out = []
+    def repeats(n, nwords, wlen):
+        words = rng.integers(0, 256, (nwords, wlen), dtype=np.uint8)
+        idx = rng.integers(0, nwords, n // wlen + 1)
+        return words[idx].reshape(-1)[:n].tobytes()
+    out.append(repeats(300000, 900, 16))          # ~20 copies per word: groups of tens
+    out.append(repeats(700001, 64, 24))           # ~450 copies: groups of hundreds
+    out.append(repeats(1 << 20, 12, 40))          # ~2000 copies: groups of thousands, buckets beyond the count path
+    out.append(repeats(900000, 3, 33))            # ~9000 copies: groups larger than a bucket
+    out.append((b"abcdefghijklmnopqrstuvwxy" * 40000)[:999983])            # one period: n/25 per group until the end decides
+    z = bytearray(1 << 20)
+    for p_ in rng.integers(0, 1 << 20, 3000):
+        z[p_] = int(rng.integers(1, 256))
+    out.append(bytes(z))                           # long zero runs: one group over most of the block for many rounds
+    out.append(repeats(200000, 900, 16) + bytes(z[:300000]) + repeats(400000, 12, 40) + bytes(rng.integers(0, 256, 100000, dtype=np.uint8)))
+    out.append(repeats(4099, 5, 7))                # just above the list length where the bucket path starts
+    return out
+
+
+@pytest.mark.gpu
+def test_bwt_forward_group_shapes_match_oracle(ctx, monkeypatch):
+    """BWT is unique: every path of the suffix sort must give the oracle's bytes and primary indexes.
+    The same inputs are run with the bucket path switched off (KZ_BWT_BUCKETS=0: LSD passes only), batched."""
+    inputs = _group_shape_inputs()
+    want = [oracle.transform_forward("BWT", d) for d in inputs]
+    for d, (ok_o, enc_o) in zip(inputs, want):
+        ok_g, enc_g = _fwd(ctx, kz.BWT_TYPE, d)
+        assert ok_g == ok_o and enc_g == enc_o, len(d)
+    # one batch with blocks of different lengths: the bucket geometry follows the longest block
+    bs = max(len(d) for d in inputs)
+    B = len(inputs)
+    inp = np.zeros((B, bs), dtype=np.uint8)
+    lens = np.array([len(d) for d in inputs], dtype=np.int32)
+    for i, d in enumerate(inputs):
+        inp[i, :len(d)] = np.frombuffer(d, dtype=np.uint8)
+    ostride = kz.max_block_stream_bytes(bs)
+    out = np.zeros((B, ostride), dtype=np.uint8)
+    res = kz.encode_blocks(ctx, "BWT", "NONE", inp, bs, lens, out, ostride)
+    for i, d in enumerate(inputs):
+        so, w, sf, pl = oracle.encode_block("BWT", "NONE", d)
+        assert res[i].status == 0 and (res[i].bits, res[i].skipFlags, res[i].length) == (w, sf, pl), len(d)
+        assert out[i, :(w + 7) // 8].tobytes() == so, len(d)
+    monkeypatch.setenv("KZ_BWT_BUCKETS", "0")
+    for d, (ok_o, enc_o) in zip(inputs[:4], want[:4]):
+        ok_g, enc_g = _fwd(ctx, kz.BWT_TYPE, d)
+        assert ok_g == ok_o and enc_g == enc_o, len(d)
+
+
 def test_python_mirror_slice_semantics(ctx):
     # ByteTransform contract (K/ByteTransform.java:36-56): indexes advance on success, False = declined
     src = kz.SliceByteArray(np.frombuffer(b"mississippi", dtype=np.uint8).copy(), 11, 0)
