@@ -575,6 +575,9 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
                                                        const int32_t* __restrict__ d_len, const int32_t* __restrict__ order, int wavesPerGroup) {
   const int b = __builtin_amdgcn_readfirstlane(order[blockIdx.x * wavesPerGroup + (int)(threadIdx.x >> 6)]);
   if (b < 0) return;
+  // one serial chain per wave: when the overlapped decoder schedule (kz_api.hip) runs other kernels on the same SIMDs,
+  // this wave's next instruction should not wait behind theirs
+  __builtin_amdgcn_s_setprio(3);
   const int n = __builtin_amdgcn_readfirstlane(d_len[b]);
   const u8* s = src + (int64_t)b * stride;
   u8* d = dst + (int64_t)b * stride;
