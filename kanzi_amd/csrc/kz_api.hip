@@ -202,8 +202,12 @@ __global__ void k_mask_len(const int32_t* __restrict__ len, const int32_t* __res
 // pass-through for blocks whose stage did not run (mask==0) or declined (flag==0)
 __global__ void k_passthrough(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride, const int32_t* __restrict__ lenOld,
                               int32_t* __restrict__ lenNew, const int32_t* __restrict__ mask, const int32_t* __restrict__ flag,
-                              int32_t* __restrict__ applied) {
+                              int32_t* __restrict__ applied, const int32_t* __restrict__ part) {
   const int b = blockIdx.y;
+  if (part && !part[b]) {                                           // not this pass's business: the slot is left alone
+    if (blockIdx.x == 0 && threadIdx.x == 0) { applied[b] = 0; lenNew[b] = lenOld[b]; }
+    return;
+  }
   const bool ran = mask[b] != 0 && flag[b] > 0;                     // flag < 0: the reference's transform would have thrown
   if (blockIdx.x == 0 && threadIdx.x == 0) { applied[b] = ran ? 1 : ((mask[b] != 0 && flag[b] < 0) ? -1 : 0); if (!ran) lenNew[b] = lenOld[b]; }
   if (ran) return;
@@ -333,7 +337,7 @@ static int sync_lengths(kz_ctx* ctx, kz_batch& bt) {
 // run one stage on the blocks selected by h_mask; others (and blocks where the transform declines)
 // pass through unchanged.  On return h_applied[b] tells which blocks the transform was applied to.
 template <typename F>
-static int run_stage(kz_ctx* ctx, Pipe& P, const std::vector<int32_t>& h_mask, std::vector<int32_t>& h_applied, F stage) {
+static int run_stage(kz_ctx* ctx, Pipe& P, const std::vector<int32_t>& h_mask, std::vector<int32_t>& h_applied, F stage, const int32_t* d_part = nullptr) {
   kz_batch& bt = P.bt;
   const int B = bt.B;
   hipStream_t st = ctx->stream;
@@ -347,7 +351,7 @@ static int run_stage(kz_ctx* ctx, Pipe& P, const std::vector<int32_t>& h_mask, s
   int rc = stage(bt);
   if (rc) return rc;
   u8* dstAfter = bt.buf[bt.cur];
-  KZ_LAUNCH(ctx, KID_PASSTHROUGH, k_passthrough, dim3(64, B), dim3(256), srcBefore, dstAfter, bt.stride, P.d_lenSave, bt.d_len, P.d_mask, bt.d_flag, P.d_applied);
+  KZ_LAUNCH(ctx, KID_PASSTHROUGH, k_passthrough, dim3(64, B), dim3(256), srcBefore, dstAfter, bt.stride, P.d_lenSave, bt.d_len, P.d_mask, bt.d_flag, P.d_applied, d_part);
   KZ_HIP(hipMemcpyAsync(ctx->hpin + B, P.d_applied, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   rc = sync_lengths(ctx, bt);
   if (rc) return rc;
@@ -554,77 +558,112 @@ static void host_inverse_block(int b, void* arg) {
 // inverse on a side stream while the cheap ones go through RANK inverse AND BWT inverse on the main stream; the expensive
 // blocks' BWT inverse follows.  Blocks live in fixed slots of the two ping-pong buffers, so the groups are lengths-masked
 // views of the same batch.  Only for batches where both stages apply to the same blocks.
-__global__ void k_merge_groups(const int32_t* __restrict__ inS, const int32_t* __restrict__ lenS, const int32_t* __restrict__ flagS,
-                               const int32_t* __restrict__ inF, const int32_t* __restrict__ lenF, const int32_t* __restrict__ flagF,
-                               const int32_t* __restrict__ lenOld, int32_t* __restrict__ lenOut, int32_t* __restrict__ applied, int B) {
+__global__ void k_merge_groups(const int32_t* __restrict__ inS, const int32_t* __restrict__ lenS, const int32_t* __restrict__ flagS, const int32_t* __restrict__ oldS,
+                               const int32_t* __restrict__ inF, const int32_t* __restrict__ lenF, const int32_t* __restrict__ flagF, const int32_t* __restrict__ oldF,
+                               int32_t* __restrict__ lenOut, int32_t* __restrict__ applied, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  if (inS[b]) { lenOut[b] = flagS[b] > 0 ? lenS[b] : lenOld[b]; applied[b] = flagS[b] > 0 ? 1 : 0; }
-  else if (inF[b]) { lenOut[b] = flagF[b] > 0 ? lenF[b] : lenOld[b]; applied[b] = flagF[b] > 0 ? 1 : 0; }
-  else { lenOut[b] = lenOld[b]; applied[b] = 0; }
+  if (inS[b]) { lenOut[b] = flagS[b] > 0 ? lenS[b] : oldS[b]; applied[b] = flagS[b] > 0 ? 1 : 0; }
+  else if (inF[b]) { lenOut[b] = flagF[b] > 0 ? lenF[b] : oldF[b]; applied[b] = flagF[b] > 0 ? 1 : 0; }
+  else applied[b] = 0;                                              // lenOut (the batch's own lengths) stays
 }
 static int fuse_min_blocks() {                                      // batches below this take the stages one after the other
   const char* e = getenv("KZ_FUSE_MIN_BLOCKS");                     // (read per call: the tests force both schedules)
   return e ? atoi(e) : 512;
 }
-// returns 1 when it ran both stages (h_applied = blocks both were applied to), 0 when the schedule does not apply, <0 on error
-static int overlapped_rank_bwt_inverse(kz_ctx* ctx, Pipe& P, int mode, const std::vector<int32_t>& h_mask, const std::vector<int32_t>& cost,
-                                       std::vector<int32_t>& h_applied) {
-  kz_batch& bt = P.bt;
-  const int B = bt.B;
-  if (B < fuse_min_blocks()) return 0;
+struct Overlap {
+  std::vector<int32_t> inS, inF;
+  int32_t *d_inS = nullptr, *d_inF = nullptr, *lenS = nullptr, *lenS2 = nullptr, *flagS = nullptr, *oldS = nullptr,
+          *lenF = nullptr, *lenF2 = nullptr, *flagF = nullptr, *oldF = nullptr;
+  kz_batch vS, vF;
+};
+// host side: S = the blocks whose cost is within a quarter of the largest; false when there is nothing to overlap
+static bool overlap_classify(int B, const std::vector<int32_t>& h_mask, const std::vector<int32_t>& cost, Overlap& O) {
+  if (B < fuse_min_blocks()) return false;
   int64_t maxCost = 0;
   for (int b = 0; b < B; b++) if (h_mask[b]) maxCost = std::max<int64_t>(maxCost, cost[b]);
-  std::vector<int32_t> inS(B, 0), inF(B, 0);
+  O.inS.assign(B, 0); O.inF.assign(B, 0);
   int nS = 0, nF = 0;
   for (int b = 0; b < B; b++) {
     if (!h_mask[b]) continue;
-    if ((int64_t)cost[b] * 4 >= maxCost * 3) { inS[b] = 1; nS++; } else { inF[b] = 1; nF++; }
+    if ((int64_t)cost[b] * 4 >= maxCost * 3) { O.inS[b] = 1; nS++; } else { O.inF[b] = 1; nF++; }
   }
-  if (nS < 8 || nF < 8) return 0;                                   // nothing to overlap
-  hipStream_t st = ctx->stream;
+  return nS >= 8 && nF >= 8;
+}
+static int overlap_alloc(kz_ctx* ctx, int B, Overlap& O) {
   if (!ctx->side) {
     KZ_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     KZ_HIP(hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming));
     KZ_HIP(hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming));
   }
-  int32_t* d = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4 * 9);
+  int32_t* d = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4 * 10);
   if (!d) { snprintf(ctx->err, sizeof(ctx->err), "overlapped inverse: arena overflow"); return -KZ_ERR_DEVICE; }
-  int32_t *d_inS = d, *d_inF = d + B, *lenS = d + 2 * B, *lenS2 = d + 3 * B, *flagS = d + 4 * B, *lenF = d + 5 * B, *lenF2 = d + 6 * B, *flagF = d + 7 * B, *lenOld = d + 8 * B;
-  KZ_HIP(hipMemcpyAsync(d_inS, inS.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-  KZ_HIP(hipMemcpyAsync(d_inF, inF.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-  KZ_HIP(hipMemcpyAsync(lenOld, bt.d_len, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
-  KZ_LAUNCH(ctx, KID_MASK_LEN, k_mask_len, dim3((B + 255) / 256), dim3(256), lenOld, d_inS, lenS, B);
-  KZ_LAUNCH(ctx, KID_MASK_LEN, k_mask_len, dim3((B + 255) / 256), dim3(256), lenOld, d_inF, lenF, B);
-  KZ_HIP(hipStreamSynchronize(st));                                 // inS / inF are locals; the side stream starts from here
-  kz_batch vS = bt, vF = bt;                                        // views: same slots, masked lengths, own length / flag arrays
-  vS.d_len = lenS; vS.d_len2 = lenS2; vS.d_flag = flagS;
-  vF.d_len = lenF; vF.d_len2 = lenF2; vF.d_flag = flagF;
-  for (int b = 0; b < B; b++) { if (!inS[b]) vS.h_len[b] = 0; if (!inF[b]) vF.h_len[b] = 0; }
-  int rc;
-  std::swap(ctx->stream, ctx->side);                                // the expensive blocks' RANK inverse goes first, on the side stream
-  rc = kz_stage_sbrt_inverse(ctx, vS, mode);
+  O.d_inS = d; O.d_inF = d + B; O.lenS = d + 2 * B; O.lenS2 = d + 3 * B; O.flagS = d + 4 * B; O.oldS = d + 5 * B;
+  O.lenF = d + 6 * B; O.lenF2 = d + 7 * B; O.flagF = d + 8 * B; O.oldF = d + 9 * B;
+  KZ_HIP(hipMemcpyAsync(O.d_inS, O.inS.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+  KZ_HIP(hipMemcpyAsync(O.d_inF, O.inF.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+  KZ_HIP(hipStreamSynchronize(ctx->stream));                        // pageable sources
+  return 0;
+}
+// a view of one group: same slots, lengths masked to the group, own length / flag arrays
+static int overlap_view(kz_ctx* ctx, const kz_batch& bt, const std::vector<int32_t>& in, const int32_t* d_in, int32_t* len, int32_t* len2,
+                        int32_t* flag, int32_t* old, kz_batch& v) {
+  const int B = bt.B;
+  KZ_LAUNCH(ctx, KID_MASK_LEN, k_mask_len, dim3((B + 255) / 256), dim3(256), bt.d_len, d_in, len, B);
+  KZ_HIP(hipMemcpyAsync(old, len, (size_t)B * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  v = bt;
+  v.d_len = len; v.d_len2 = len2; v.d_flag = flag;
+  for (int b = 0; b < B; b++) if (!in[b]) v.h_len[b] = 0;
+  return 0;
+}
+// the expensive blocks' RANK inverse goes first, on the side stream (everything queued on the main stream so far is waited for)
+static int overlap_start_S(kz_ctx* ctx, const kz_batch& bt, int mode, Overlap& O) {
+  int rc = overlap_view(ctx, bt, O.inS, O.d_inS, O.lenS, O.lenS2, O.flagS, O.oldS, O.vS);
+  if (rc) return rc;
+  KZ_HIP(hipStreamSynchronize(ctx->stream));
+  std::swap(ctx->stream, ctx->side);
+  rc = kz_stage_sbrt_inverse(ctx, O.vS, mode);
   if (!rc) { hipError_t e = hipEventRecord(ctx->evJoin, ctx->stream); if (e != hipSuccess) rc = -KZ_ERR_DEVICE; }
   std::swap(ctx->stream, ctx->side);
+  return rc;
+}
+// the other blocks' RANK and BWT inverse on the main stream, then the expensive blocks' BWT inverse; merges lengths and flags
+static int overlap_finish(kz_ctx* ctx, Pipe& P, int mode, Overlap& O, std::vector<int32_t>& h_applied) {
+  kz_batch& bt = P.bt;
+  const int B = bt.B;
+  hipStream_t st = ctx->stream;
+  int rc = overlap_view(ctx, bt, O.inF, O.d_inF, O.lenF, O.lenF2, O.flagF, O.oldF, O.vF);
   if (rc) return rc;
-  rc = kz_stage_sbrt_inverse(ctx, vF, mode);
+  rc = kz_stage_sbrt_inverse(ctx, O.vF, mode);
   if (rc) return rc;
   const size_t mark = ctx->arenaTop;
-  rc = kz_stage_bwt_inverse(ctx, vF);
+  rc = kz_stage_bwt_inverse(ctx, O.vF);
   if (rc) return rc;
   KZ_HIP(hipStreamWaitEvent(st, ctx->evJoin, 0));
   ctx->arenaTop = mark;                                             // same stream, in order: the scratch is free again
-  rc = kz_stage_bwt_inverse(ctx, vS);
+  rc = kz_stage_bwt_inverse(ctx, O.vS);
   if (rc) return rc;
   // both views are back in the buffer they started from (two stages each); the batch's own state is untouched except lengths
-  KZ_LAUNCH(ctx, KID_MASK_LEN, k_merge_groups, dim3((B + 255) / 256), dim3(256), d_inS, vS.d_len, vS.d_flag, d_inF, vF.d_len, vF.d_flag,
-            lenOld, bt.d_len, P.d_applied, B);
+  KZ_LAUNCH(ctx, KID_MASK_LEN, k_merge_groups, dim3((B + 255) / 256), dim3(256), O.d_inS, O.vS.d_len, O.vS.d_flag, O.oldS,
+            O.d_inF, O.vF.d_len, O.vF.d_flag, O.oldF, bt.d_len, P.d_applied, B);
   KZ_HIP(hipMemcpyAsync(ctx->hpin + B, P.d_applied, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   rc = sync_lengths(ctx, bt);
   if (rc) return rc;
   h_applied.resize(B);
   for (int b = 0; b < B; b++) h_applied[b] = ctx->hpin[B + b];
-  return 1;
+  return 0;
+}
+// returns 1 when it ran both stages (h_applied = blocks both were applied to), 0 when the schedule does not apply, <0 on error
+static int overlapped_rank_bwt_inverse(kz_ctx* ctx, Pipe& P, int mode, const std::vector<int32_t>& h_mask, const std::vector<int32_t>& cost,
+                                       std::vector<int32_t>& h_applied) {
+  Overlap O;
+  if (!overlap_classify(P.bt.B, h_mask, cost, O)) return 0;
+  int rc = overlap_alloc(ctx, P.bt.B, O);
+  if (rc) return rc;
+  rc = overlap_start_S(ctx, P.bt, mode, O);
+  if (rc) return rc;
+  rc = overlap_finish(ctx, P, mode, O, h_applied);
+  return rc ? rc : 1;
 }
 
 // =================================================================================================
@@ -935,7 +974,9 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   }
   Pipe P;
   const int64_t inS = host ? (int64_t)kz_align((size_t)maxInBytes + 64, 256) : inStride;
-  const int64_t extra = (host ? inS * B : 0) + (int64_t)B * (sizeof(kz_block_result) + 128) + (int64_t)B * 32 + 8192;
+  // (the expensive-blocks-first schedule runs the entropy and ZRLT stages once per group: a second set of their small scratch)
+  const int64_t extra = (host ? inS * B : 0) + (int64_t)B * (sizeof(kz_block_result) + 128) + (int64_t)B * 32 + 8192 +
+                        (int64_t)kz_zrlt_scratch(B, maxLen) + (int64_t)B * ((int64_t)(maxLen / 16384 + 4) * 8 + 64) + 65536 + (int64_t)B * 64;
   int rc = pipe_setup(ctx, P, B, maxLen, extra, true, CS);
   if (rc) return rc;
   kz_batch& bt = P.bt;
@@ -982,26 +1023,90 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
 
   // ---- entropy decode into buf ----
   std::vector<int32_t> h_mask(B), h_applied;
-  {
+  // one pass of the entropy stage over the blocks of `part` (all blocks when null)
+  auto entropy_pass = [&](const std::vector<int32_t>* part, const int32_t* d_part) -> int {
     hipEvent_t e1; kz_stage_begin(ctx, &e1);
-    int64_t outBytes = 0; for (int b = 0; b < B; b++) outBytes += bt.h_len[b];
+    int64_t outBytes = 0;
     std::vector<int32_t> h_rawp(B);
-    for (int b = 0; b < B; b++) h_rawp[b] = (entropyType == KZ_E_NONE || h_raw[b] || h_tc[b]) ? 1 : 0;
+    for (int b = 0; b < B; b++) {
+      const bool in = !part || (*part)[b];
+      if (in) outBytes += bt.h_len[b];
+      h_rawp[b] = (in && (entropyType == KZ_E_NONE || h_raw[b] || h_tc[b])) ? 1 : 0;
+    }
     if (entropyType == KZ_E_ANS0 || entropyType == KZ_E_HUFFMAN || entropyType == KZ_E_FPAQ) {
-      for (int b = 0; b < B; b++) h_mask[b] = h_rawp[b] ? 0 : 1;
-      rc = run_stage(ctx, P, h_mask, h_applied, [&](kz_batch& x) {
+      for (int b = 0; b < B; b++) h_mask[b] = ((!part || (*part)[b]) && !(h_raw[b] || h_tc[b])) ? 1 : 0;
+      int r = run_stage(ctx, P, h_mask, h_applied, [&](kz_batch& x) {
         return (entropyType == KZ_E_ANS0) ? kz_stage_ans0_decode(ctx, x, d_in, inS, F.bitOff, F.bitEnd)
              : (entropyType == KZ_E_HUFFMAN) ? kz_stage_huffman_decode(ctx, x, d_in, inS, F.bitOff, F.bitEnd)
-                                             : kz_stage_fpaq_decode(ctx, x, d_in, inS, F.bitOff, F.bitEnd); });
-      if (rc) return rc;
+                                             : kz_stage_fpaq_decode(ctx, x, d_in, inS, F.bitOff, F.bitEnd); }, d_part);
+      if (r) return r;
       for (int b = 0; b < B; b++) if (h_mask[b] && !h_applied[b] && !h_status[b]) h_status[b] = -KZ_ERR_PROCESS_BLOCK;
     } else {
       bt.cur ^= 1;    // raw path writes into the "next" buffer below
     }
     KZ_HIP(hipMemcpyAsync(P.d_mask, h_rawp.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     KZ_LAUNCH(ctx, KID_COPY_PAYLOAD, k_copy_payload, dim3(64, B), dim3(256), d_in, inS, bt.buf[bt.cur], bt.stride, bt.d_len, F.hdrBytes, P.d_mask);
+    KZ_HIP(hipStreamSynchronize(st));                               // h_rawp is a local
     kz_stage_end(ctx, e1, KZ_STAGE_ENTROPY_DEC, outBytes);
+    return 0;
+  };
+  // one inverse transform stage over the blocks of `part`
+  auto transform_pass = [&](int i, const std::vector<int32_t>* part, const int32_t* d_part) -> int {
+    const int type = types[i];
+    bool any = false;
+    for (int b = 0; b < B; b++) {
+      h_mask[b] = ((!part || (*part)[b]) && !h_status[b] && !(h_skip[b] & (1 << (7 - i))) && bt.h_len[b] > 0) ? 1 : 0;
+      any |= h_mask[b] != 0;
+    }
+    if (!any && !part) return 0;
+    hipEvent_t e1; kz_stage_begin(ctx, &e1);
+    int r = run_stage(ctx, P, h_mask, h_applied, [&](kz_batch& x) { return run_transform_stage(ctx, x, type, false, dataCap); }, d_part);
+    if (r) return r;
+    int64_t outBytes = 0; for (int b = 0; b < B; b++) if (h_mask[b]) outBytes += bt.h_len[b];
+    kz_stage_end(ctx, e1, stage_id(type, false), outBytes);
+    for (int b = 0; b < B; b++) if (h_mask[b] && !h_applied[b]) { h_status[b] = -KZ_ERR_PROCESS_BLOCK; bt.h_len[b] = 0; }
+    return 0;
+  };
+  // ---- "expensive blocks first" for BWT+RANK+ZRLT (or MTFT) chains on large batches: the RANK inverse of a block is serial and
+  //      its cost (the ZRLT-coded length = the decoded length, known from the block header) differs by an order of magnitude
+  //      between blocks.  The expensive blocks go through entropy decoding and ZRLT inverse FIRST and start their RANK inverse on
+  //      the side stream; the others follow on the main stream underneath it (overlap_* above). ----
+  bool chainDone = false;
+  if (nb - hp == 3 && types[hp] == KZ_T_BWT && (types[hp + 1] == KZ_T_RANK || types[hp + 1] == KZ_T_MTFT) && types[hp + 2] == KZ_T_ZRLT &&
+      (entropyType == KZ_E_ANS0 || entropyType == KZ_E_HUFFMAN) && !getenv("KZ_NO_SFIRST")) {
+    bool all = true;
+    const int need = (1 << (7 - hp)) | (1 << (7 - (hp + 1)));       // BWT and RANK applied to every block
+    for (int b = 0; b < B && all; b++) all = !h_status[b] && bt.h_len[b] > 0 && !(h_skip[b] & need);   // (copy blocks carry all skip bits)
+    Overlap O;
+    std::vector<int32_t> ones(B, 1);
+    if (getenv("KZ_TRACE_SCHED")) {
+      int nst = 0, ntc = 0, nz = 0, nsk = 0, nraw = 0;
+      for (int b = 0; b < B; b++) { nst += h_status[b] != 0; ntc += h_tc[b] != 0; nz += bt.h_len[b] <= 0; nsk += (h_skip[b] & need) != 0; nraw += h_raw[b] != 0; }
+      fprintf(stderr, "[sched] B=%d all=%d status=%d tcopy=%d empty=%d skipBwtRank=%d raw=%d\n", B, (int)all, nst, ntc, nz, nsk, nraw);
+    }
+    if (all && overlap_classify(B, ones, bt.h_len, O)) {
+      const int mode = types[hp + 1] == KZ_T_RANK ? 2 : 1;
+      const std::vector<int32_t> cost = bt.h_len;                   // the decoded (ZRLT-coded) lengths
+      rc = overlap_alloc(ctx, B, O);
+      if (rc) return rc;
+      rc = entropy_pass(&O.inS, O.d_inS);
+      if (!rc) rc = transform_pass(hp + 2, &O.inS, O.d_inS);
+      if (rc) return rc;
+      bt.h_cost = cost;
+      rc = overlap_start_S(ctx, bt, mode, O);
+      if (rc) return rc;
+      rc = entropy_pass(&O.inF, O.d_inF);
+      if (!rc) rc = transform_pass(hp + 2, &O.inF, O.d_inF);
+      if (rc) return rc;
+      rc = overlap_finish(ctx, P, mode, O, h_applied);
+      if (rc) return rc;
+      for (int b = 0; b < B; b++) if (!h_status[b] && !h_applied[b]) { h_status[b] = -KZ_ERR_PROCESS_BLOCK; bt.h_len[b] = 0; }
+      chainDone = true;
+    }
   }
+  if (!chainDone) {
+  rc = entropy_pass(nullptr, nullptr);
+  if (rc) return rc;
   // ---- inverse chain (Sequence.inverse, K/transform/Sequence.java:137-207) ----
   // cost hint for the serial-per-block inverse stages: the length a block had at the input of the previous stage
   // (for RANK behind ZRLT that is the ZRLT-coded length ~ the number of non-zero ranks)
@@ -1030,12 +1135,9 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
         }
       }
     }
-    hipEvent_t e1; kz_stage_begin(ctx, &e1);
-    rc = run_stage(ctx, P, h_mask, h_applied, [&](kz_batch& x) { return run_transform_stage(ctx, x, type, false, dataCap); });
+    rc = transform_pass(i, nullptr, nullptr);
     if (rc) return rc;
-    int64_t outBytes = 0; for (int b = 0; b < B; b++) if (h_mask[b]) outBytes += bt.h_len[b];
-    kz_stage_end(ctx, e1, stage_id(type, false), outBytes);
-    for (int b = 0; b < B; b++) if (h_mask[b] && !h_applied[b]) { h_status[b] = -KZ_ERR_PROCESS_BLOCK; bt.h_len[b] = 0; }
+  }
   }
   if (hp > 0) {
     // host stages (UTF, TEXT inverse) behind the GPU stages: blocks that went through one come back to the host, are decoded

@@ -308,6 +308,16 @@ __global__ __launch_bounds__(64) void k_zrlt_i2(const int32_t* __restrict__ d_le
   }
 }
 
+// zero the output of the blocks this call decodes, and only theirs (zero runs are "written" here).  Other slots of the
+// batch may be in use by another stream at this moment (the decoder's expensive-blocks-first schedule, kz_api.hip).
+__global__ __launch_bounds__(256) void k_zrlt_izero(u8* __restrict__ dst, int64_t stride, const int32_t* __restrict__ d_len, ZiScratch S) {
+  const int b = blockIdx.y;
+  if (d_len[b] <= 0 || S.fail[b]) return;
+  const int64_t n = ((int64_t)S.total[b] + 15) & ~15LL;             // slots are 256-byte aligned with >= 4 KiB of slack
+  uint4* d = (uint4*)(dst + (int64_t)b * stride);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i * 16 < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = make_uint4(0, 0, 0, 0);
+}
+
 __global__ __launch_bounds__(KZ_WG) void k_zrlt_i3(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
                                                     const int32_t* __restrict__ d_len, ZiScratch S) {
   const int b = blockIdx.y, t = blockIdx.x;
@@ -393,11 +403,11 @@ int kz_stage_zrlt_inverse(kz_ctx* ctx, kz_batch& bt, int dstCap) {
   if ((int64_t)dstCap > bt.stride) dstCap = (int)bt.stride;
   KZ_HIP(hipMemsetAsync(S.fail, 0, (size_t)B * 4, st));
   KZ_HIP(hipMemsetAsync(S.total, 0, (size_t)B * 4, st));
-  KZ_HIP(hipMemsetAsync(dst, 0, (size_t)bt.stride * B, st));       // zero runs are "written" here
   if (maxN > 0) {
     const int tiles = (maxN + ZR_TILE - 1) / ZR_TILE;
     KZ_LAUNCH(ctx, KID_ZRLT_I1, k_zrlt_i1, dim3(tiles, B), dim3(KZ_WG), src, bt.stride, bt.d_len, S);
     KZ_LAUNCH(ctx, KID_ZRLT_I2, k_zrlt_i2, dim3(B), dim3(64), bt.d_len, S, dstCap);
+    KZ_LAUNCH(ctx, KID_ZRLT_I2, k_zrlt_izero, dim3(64, B), dim3(256), dst, bt.stride, bt.d_len, S);
     KZ_LAUNCH(ctx, KID_ZRLT_I3, k_zrlt_i3, dim3(tiles, B), dim3(KZ_WG), src, dst, bt.stride, bt.d_len, S);
   }
   KZ_LAUNCH(ctx, KID_ZRLT_IFIN, k_zrlt_ifin, dim3((B + 255) / 256), dim3(256), bt.d_len, bt.d_len2, bt.d_flag, S, B);

@@ -1034,3 +1034,39 @@ def test_overlapped_rank_bwt_inverse_schedule(ctx, monkeypatch):
         st = results[("overlapped", "good")][0]
         assert all(s == 0 and l == lens[i] for i, (s, l) in enumerate(st))
         assert all(results[("overlapped", "good")][1][i] == inp[i, :lens[i]].tobytes() for i in range(B))
+
+
+def test_expensive_blocks_first_decode_schedule(ctx, monkeypatch):
+    """BWT+RANK+ZRLT / BWT+MTFT+ZRLT batches without empty or damaged-header blocks take the "expensive blocks first" decoder
+    schedule (kz_api.hip): the expensive group runs entropy decoding and ZRLT inverse first and starts its RANK inverse on the
+    side stream while the other group is still being entropy decoded.  Same results as the staged schedule, transformed-copy
+    blocks (uniform data), blocks with ZRLT skipped and a damaged payload included."""
+    bs, B = 131072, 40
+    inp = np.stack([datagen.block(i, bs) for i in range(B)])
+    lens = np.full(B, bs, dtype=np.int32)
+    lens[7], lens[18] = 50000, 4097
+    ostride = kz.max_block_stream_bytes(bs)
+    for chain, ent in (("BWT+RANK+ZRLT", "ANS0"), ("BWT+MTFT+ZRLT", "HUFFMAN")):
+        out = np.zeros((B, ostride), dtype=np.uint8)
+        res = kz.encode_blocks(ctx, chain, ent, inp, bs, lens, out, ostride)
+        assert any(out[i, 0] & 0x90 == 0x90 for i in range(B))            # transformed-copy blocks are in the batch
+        bits = np.array([r.bits for r in res], dtype=np.int64)
+        bad = out.copy()
+        bad[5, 400:420] ^= 0x5A                     # inside one block's payload: the header still parses
+        results = {}
+        for mode, fuse, nosf in (("staged", "1000000", None), ("overlapped", "8", "1"), ("first", "8", None)):
+            monkeypatch.setenv("KZ_FUSE_MIN_BLOCKS", fuse)
+            if nosf:
+                monkeypatch.setenv("KZ_NO_SFIRST", nosf)
+            else:
+                monkeypatch.delenv("KZ_NO_SFIRST", raising=False)
+            for name, streams in (("good", out), ("bad", bad)):
+                dec = np.zeros((B, bs), dtype=np.uint8)
+                r2 = kz.decode_blocks(ctx, chain, ent, bs, streams, ostride, bits, dec, bs)
+                results[(mode, name)] = ([(r.status, r.length) for r in r2], [dec[i, :max(r2[i].length, 0)].tobytes() for i in range(B)])
+        for name in ("good", "bad"):
+            assert results[("staged", name)] == results[("overlapped", name)] == results[("first", name)], (chain, name)
+        st = results[("first", "good")][0]
+        assert all(s == 0 and l == lens[i] for i, (s, l) in enumerate(st))
+        assert all(results[("first", "good")][1][i] == inp[i, :lens[i]].tobytes() for i in range(B))
+
