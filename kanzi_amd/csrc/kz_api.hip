@@ -40,6 +40,8 @@ extern "C" void kz_ctx_destroy(kz_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->arena) hipFree(ctx->arena);
   if (ctx->side) hipStreamDestroy(ctx->side);
+  if (ctx->side2) hipStreamDestroy(ctx->side2);
+  if (ctx->evJoin2) hipEventDestroy(ctx->evJoin2);
   if (ctx->evFork) hipEventDestroy(ctx->evFork);
   if (ctx->evJoin) hipEventDestroy(ctx->evJoin);
   if (ctx->hpin) hipHostFree(ctx->hpin);
@@ -558,37 +560,60 @@ static void host_inverse_block(int b, void* arg) {
 // inverse on a side stream while the cheap ones go through RANK inverse AND BWT inverse on the main stream; the expensive
 // blocks' BWT inverse follows.  Blocks live in fixed slots of the two ping-pong buffers, so the groups are lengths-masked
 // views of the same batch.  Only for batches where both stages apply to the same blocks.
-__global__ void k_merge_groups(const int32_t* __restrict__ inS, const int32_t* __restrict__ lenS, const int32_t* __restrict__ flagS, const int32_t* __restrict__ oldS,
-                               const int32_t* __restrict__ inF, const int32_t* __restrict__ lenF, const int32_t* __restrict__ flagF, const int32_t* __restrict__ oldF,
-                               int32_t* __restrict__ lenOut, int32_t* __restrict__ applied, int B) {
+__global__ void k_merge_group(const int32_t* __restrict__ in, const int32_t* __restrict__ len, const int32_t* __restrict__ flag, const int32_t* __restrict__ old,
+                              int32_t* __restrict__ lenOut, int32_t* __restrict__ applied, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  if (inS[b]) { lenOut[b] = flagS[b] > 0 ? lenS[b] : oldS[b]; applied[b] = flagS[b] > 0 ? 1 : 0; }
-  else if (inF[b]) { lenOut[b] = flagF[b] > 0 ? lenF[b] : oldF[b]; applied[b] = flagF[b] > 0 ? 1 : 0; }
-  else applied[b] = 0;                                              // lenOut (the batch's own lengths) stays
+  if (b >= B || !in[b]) return;                                     // other blocks: lenOut (the batch's own lengths) and applied stay
+  lenOut[b] = flag[b] > 0 ? len[b] : old[b];
+  applied[b] = flag[b] > 0 ? 1 : 0;
 }
 static int fuse_min_blocks() {                                      // batches below this take the stages one after the other
   const char* e = getenv("KZ_FUSE_MIN_BLOCKS");                     // (read per call: the tests force both schedules)
   return e ? atoi(e) : 512;
 }
-struct Overlap {
-  std::vector<int32_t> inS, inF;
-  int32_t *d_inS = nullptr, *d_inF = nullptr, *lenS = nullptr, *lenS2 = nullptr, *flagS = nullptr, *oldS = nullptr,
-          *lenF = nullptr, *lenF2 = nullptr, *flagF = nullptr, *oldF = nullptr;
-  kz_batch vS, vF;
+// One cost class of the batch: a lengths-masked view of the same slots with its own length / flag arrays.
+struct OverlapGroup {
+  std::vector<int32_t> in;
+  int32_t *d_in = nullptr, *len = nullptr, *len2 = nullptr, *flag = nullptr, *old = nullptr;
+  int prio = 0;
+  kz_batch v;
 };
-// host side: S = the blocks whose cost is within a quarter of the largest; false when there is nothing to overlap
+// groups[0] goes on the main stream (the cheapest class), groups[1], groups[2] on the side streams, most expensive last
+struct Overlap { std::vector<OverlapGroup> groups; };
+// host side: classes by cost relative to the largest: >= 3/4 | >= 3/8 | the rest; classes of fewer than 8 blocks join the
+// class below (or above for the cheapest).  false when there is nothing to overlap.
 static bool overlap_classify(int B, const std::vector<int32_t>& h_mask, const std::vector<int32_t>& cost, Overlap& O) {
   if (B < fuse_min_blocks()) return false;
   int64_t maxCost = 0;
   for (int b = 0; b < B; b++) if (h_mask[b]) maxCost = std::max<int64_t>(maxCost, cost[b]);
-  O.inS.assign(B, 0); O.inF.assign(B, 0);
-  int nS = 0, nF = 0;
+  const char* e3 = getenv("KZ_OVERLAP_CLASSES");
+  const int nClasses = (e3 && e3[0] == '2') ? 2 : 3;
+  std::vector<int> cls(B, -1);
+  int cnt[3] = {0, 0, 0};
   for (int b = 0; b < B; b++) {
     if (!h_mask[b]) continue;
-    if ((int64_t)cost[b] * 4 >= maxCost * 3) { O.inS[b] = 1; nS++; } else { O.inF[b] = 1; nF++; }
+    const int64_t c8 = (int64_t)cost[b] * 8;
+    cls[b] = (c8 >= maxCost * 6) ? 2 : ((nClasses == 3 && c8 >= maxCost * 3) ? 1 : 0);
+    cnt[cls[b]]++;
   }
-  return nS >= 8 && nF >= 8;
+  int to[3] = {0, 1, 2};
+  if (cnt[2] < 8) { to[2] = 1; cnt[1] += cnt[2]; cnt[2] = 0; }
+  if (cnt[1] < 8) { to[1] = 0; if (to[2] == 1) to[2] = 0; cnt[0] += cnt[1]; cnt[1] = 0; }
+  if (cnt[0] < 8) {                                                  // the cheapest class is too small: the next one takes the main stream
+    if (cnt[1] > 0) { to[0] = 1; cnt[1] += cnt[0]; } else if (cnt[2] > 0) { to[0] = 2; cnt[2] += cnt[0]; }
+    cnt[0] = 0;
+  }
+  int order[3], n = 0;
+  for (int c = 0; c < 3; c++) if (cnt[c] > 0) order[n++] = c;
+  if (n < 2) return false;
+  O.groups.resize(n);
+  for (int g = 0; g < n; g++) { O.groups[g].in.assign(B, 0); O.groups[g].prio = (g == n - 1) ? 2 : (g > 0 ? 1 : 0); }
+  for (int b = 0; b < B; b++) {
+    if (cls[b] < 0) continue;
+    const int c = to[cls[b]];
+    for (int g = 0; g < n; g++) if (order[g] == c) O.groups[g].in[b] = 1;
+  }
+  return true;
 }
 static int overlap_alloc(kz_ctx* ctx, int B, Overlap& O) {
   if (!ctx->side) {
@@ -596,56 +621,64 @@ static int overlap_alloc(kz_ctx* ctx, int B, Overlap& O) {
     KZ_HIP(hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming));
     KZ_HIP(hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming));
   }
-  int32_t* d = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4 * 10);
-  if (!d) { snprintf(ctx->err, sizeof(ctx->err), "overlapped inverse: arena overflow"); return -KZ_ERR_DEVICE; }
-  O.d_inS = d; O.d_inF = d + B; O.lenS = d + 2 * B; O.lenS2 = d + 3 * B; O.flagS = d + 4 * B; O.oldS = d + 5 * B;
-  O.lenF = d + 6 * B; O.lenF2 = d + 7 * B; O.flagF = d + 8 * B; O.oldF = d + 9 * B;
-  KZ_HIP(hipMemcpyAsync(O.d_inS, O.inS.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
-  KZ_HIP(hipMemcpyAsync(O.d_inF, O.inF.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (!ctx->side2) {
+    KZ_HIP(hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
+    KZ_HIP(hipEventCreateWithFlags(&ctx->evJoin2, hipEventDisableTiming));
+  }
+  for (auto& G : O.groups) {
+    int32_t* d = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4 * 5);
+    if (!d) { snprintf(ctx->err, sizeof(ctx->err), "overlapped inverse: arena overflow"); return -KZ_ERR_DEVICE; }
+    G.d_in = d; G.len = d + B; G.len2 = d + 2 * B; G.flag = d + 3 * B; G.old = d + 4 * B;
+    KZ_HIP(hipMemcpyAsync(G.d_in, G.in.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
   KZ_HIP(hipStreamSynchronize(ctx->stream));                        // pageable sources
   return 0;
 }
-// a view of one group: same slots, lengths masked to the group, own length / flag arrays
-static int overlap_view(kz_ctx* ctx, const kz_batch& bt, const std::vector<int32_t>& in, const int32_t* d_in, int32_t* len, int32_t* len2,
-                        int32_t* flag, int32_t* old, kz_batch& v) {
+static int overlap_view(kz_ctx* ctx, const kz_batch& bt, OverlapGroup& G) {
   const int B = bt.B;
-  KZ_LAUNCH(ctx, KID_MASK_LEN, k_mask_len, dim3((B + 255) / 256), dim3(256), bt.d_len, d_in, len, B);
-  KZ_HIP(hipMemcpyAsync(old, len, (size_t)B * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  v = bt;
-  v.d_len = len; v.d_len2 = len2; v.d_flag = flag;
-  for (int b = 0; b < B; b++) if (!in[b]) v.h_len[b] = 0;
+  KZ_LAUNCH(ctx, KID_MASK_LEN, k_mask_len, dim3((B + 255) / 256), dim3(256), bt.d_len, G.d_in, G.len, B);
+  KZ_HIP(hipMemcpyAsync(G.old, G.len, (size_t)B * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  G.v = bt;
+  G.v.d_len = G.len; G.v.d_len2 = G.len2; G.v.d_flag = G.flag;
+  G.v.prio = G.prio;
+  for (int b = 0; b < B; b++) if (!G.in[b]) G.v.h_len[b] = 0;
   return 0;
 }
-// the expensive blocks' RANK inverse goes first, on the side stream (everything queued on the main stream so far is waited for)
-static int overlap_start_S(kz_ctx* ctx, const kz_batch& bt, int mode, Overlap& O) {
-  int rc = overlap_view(ctx, bt, O.inS, O.d_inS, O.lenS, O.lenS2, O.flagS, O.oldS, O.vS);
+// RANK inverse of side group g (1 or 2) on its own stream (everything queued on the main stream so far is waited for)
+static int overlap_start_side(kz_ctx* ctx, const kz_batch& bt, int mode, Overlap& O, int g) {
+  OverlapGroup& G = O.groups[g];
+  int rc = overlap_view(ctx, bt, G);
   if (rc) return rc;
   KZ_HIP(hipStreamSynchronize(ctx->stream));
-  std::swap(ctx->stream, ctx->side);
-  rc = kz_stage_sbrt_inverse(ctx, O.vS, mode);
-  if (!rc) { hipError_t e = hipEventRecord(ctx->evJoin, ctx->stream); if (e != hipSuccess) rc = -KZ_ERR_DEVICE; }
-  std::swap(ctx->stream, ctx->side);
+  hipStream_t& sd = (g == 1) ? ctx->side : ctx->side2;
+  std::swap(ctx->stream, sd);
+  rc = kz_stage_sbrt_inverse(ctx, G.v, mode);
+  if (!rc) { hipError_t e = hipEventRecord(g == 1 ? ctx->evJoin : ctx->evJoin2, ctx->stream); if (e != hipSuccess) rc = -KZ_ERR_DEVICE; }
+  std::swap(ctx->stream, sd);
   return rc;
 }
-// the other blocks' RANK and BWT inverse on the main stream, then the expensive blocks' BWT inverse; merges lengths and flags
+// the main group's RANK and BWT inverse on the main stream, then the side groups' BWT inverse, cheapest first; merges lengths and flags
 static int overlap_finish(kz_ctx* ctx, Pipe& P, int mode, Overlap& O, std::vector<int32_t>& h_applied) {
   kz_batch& bt = P.bt;
   const int B = bt.B;
   hipStream_t st = ctx->stream;
-  int rc = overlap_view(ctx, bt, O.inF, O.d_inF, O.lenF, O.lenF2, O.flagF, O.oldF, O.vF);
+  int rc = overlap_view(ctx, bt, O.groups[0]);
   if (rc) return rc;
-  rc = kz_stage_sbrt_inverse(ctx, O.vF, mode);
+  rc = kz_stage_sbrt_inverse(ctx, O.groups[0].v, mode);
   if (rc) return rc;
   const size_t mark = ctx->arenaTop;
-  rc = kz_stage_bwt_inverse(ctx, O.vF);
+  rc = kz_stage_bwt_inverse(ctx, O.groups[0].v);
   if (rc) return rc;
-  KZ_HIP(hipStreamWaitEvent(st, ctx->evJoin, 0));
-  ctx->arenaTop = mark;                                             // same stream, in order: the scratch is free again
-  rc = kz_stage_bwt_inverse(ctx, O.vS);
-  if (rc) return rc;
-  // both views are back in the buffer they started from (two stages each); the batch's own state is untouched except lengths
-  KZ_LAUNCH(ctx, KID_MASK_LEN, k_merge_groups, dim3((B + 255) / 256), dim3(256), O.d_inS, O.vS.d_len, O.vS.d_flag, O.oldS,
-            O.d_inF, O.vF.d_len, O.vF.d_flag, O.oldF, bt.d_len, P.d_applied, B);
+  for (size_t g = 1; g < O.groups.size(); g++) {
+    KZ_HIP(hipStreamWaitEvent(st, g == 1 ? ctx->evJoin : ctx->evJoin2, 0));
+    ctx->arenaTop = mark;                                           // same stream, in order: the scratch is free again
+    rc = kz_stage_bwt_inverse(ctx, O.groups[g].v);
+    if (rc) return rc;
+  }
+  // every view is back in the buffer it started from (two stages each); the batch's own state is untouched except lengths
+  KZ_HIP(hipMemsetAsync(P.d_applied, 0, (size_t)B * 4, st));
+  for (auto& G : O.groups)
+    KZ_LAUNCH(ctx, KID_MASK_LEN, k_merge_group, dim3((B + 255) / 256), dim3(256), G.d_in, G.v.d_len, G.v.d_flag, G.old, bt.d_len, P.d_applied, B);
   KZ_HIP(hipMemcpyAsync(ctx->hpin + B, P.d_applied, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   rc = sync_lengths(ctx, bt);
   if (rc) return rc;
@@ -660,7 +693,7 @@ static int overlapped_rank_bwt_inverse(kz_ctx* ctx, Pipe& P, int mode, const std
   if (!overlap_classify(P.bt.B, h_mask, cost, O)) return 0;
   int rc = overlap_alloc(ctx, P.bt.B, O);
   if (rc) return rc;
-  rc = overlap_start_S(ctx, P.bt, mode, O);
+  for (int g = (int)O.groups.size() - 1; g >= 1 && !rc; g--) rc = overlap_start_side(ctx, P.bt, mode, O, g);
   if (rc) return rc;
   rc = overlap_finish(ctx, P, mode, O, h_applied);
   return rc ? rc : 1;
@@ -1084,20 +1117,21 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
       for (int b = 0; b < B; b++) { nst += h_status[b] != 0; ntc += h_tc[b] != 0; nz += bt.h_len[b] <= 0; nsk += (h_skip[b] & need) != 0; nraw += h_raw[b] != 0; }
       fprintf(stderr, "[sched] B=%d all=%d status=%d tcopy=%d empty=%d skipBwtRank=%d raw=%d\n", B, (int)all, nst, ntc, nz, nsk, nraw);
     }
-    if (all && overlap_classify(B, ones, bt.h_len, O)) {
+    // cost of a block's RANK inverse: its COMPRESSED size.  The time per rank grows with the rank (positions shifted), and so
+    // does the entropy coder's output; the ZRLT-coded length alone puts skewed and uniform data in one class (68 vs 134 ns / rank)
+    std::vector<int32_t> cost(B);
+    for (int b = 0; b < B; b++) cost[b] = (int32_t)std::min<int64_t>((bitLengths[b] + 7) >> 3, 0x7FFFFFFF);
+    if (all && overlap_classify(B, ones, cost, O)) {
       const int mode = types[hp + 1] == KZ_T_RANK ? 2 : 1;
-      const std::vector<int32_t> cost = bt.h_len;                   // the decoded (ZRLT-coded) lengths
       rc = overlap_alloc(ctx, B, O);
       if (rc) return rc;
-      rc = entropy_pass(&O.inS, O.d_inS);
-      if (!rc) rc = transform_pass(hp + 2, &O.inS, O.d_inS);
-      if (rc) return rc;
       bt.h_cost = cost;
-      rc = overlap_start_S(ctx, bt, mode, O);
-      if (rc) return rc;
-      rc = entropy_pass(&O.inF, O.d_inF);
-      if (!rc) rc = transform_pass(hp + 2, &O.inF, O.d_inF);
-      if (rc) return rc;
+      for (int g = (int)O.groups.size() - 1; g >= 0; g--) {           // most expensive class first
+        rc = entropy_pass(&O.groups[g].in, O.groups[g].d_in);
+        if (!rc) rc = transform_pass(hp + 2, &O.groups[g].in, O.groups[g].d_in);
+        if (!rc && g >= 1) rc = overlap_start_side(ctx, bt, mode, O, g);
+        if (rc) return rc;
+      }
       rc = overlap_finish(ctx, P, mode, O, h_applied);
       if (rc) return rc;
       for (int b = 0; b < B; b++) if (!h_status[b] && !h_applied[b]) { h_status[b] = -KZ_ERR_PROCESS_BLOCK; bt.h_len[b] = 0; }

@@ -19,8 +19,8 @@ struct KzPending { hipEvent_t e0, e1; int id; };
 struct kz_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t side = nullptr;     // second stream for the overlapped RANK-inverse / BWT-inverse schedule (created on first use)
-  hipEvent_t evFork = nullptr, evJoin = nullptr;
+  hipStream_t side = nullptr, side2 = nullptr;     // side streams of the overlapped RANK-inverse / BWT-inverse schedule (created on first use)
+  hipEvent_t evFork = nullptr, evJoin = nullptr, evJoin2 = nullptr;
   // grow-only device arena, bump-allocated per API call
   uint8_t* arena = nullptr;
   size_t arenaCap = 0, arenaTop = 0;
@@ -81,6 +81,7 @@ struct kz_batch {
   int32_t* d_flag = nullptr;    // [B] per-stage applied flag (device)
   int32_t* d_dtype = nullptr;   // [B] Global.DataType of each block: the reference's per-block context entry "dataType"
   std::vector<int32_t> h_len;   // host mirror of d_len
+  int prio = 0;                 // issue priority of the serial-per-block kernels launched for this view (overlapped decoder schedule)
   std::vector<int32_t> h_cost;  // optional per-block cost hint for serial-per-block stages (length at the previous stage's input)
 };
 

@@ -572,12 +572,13 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse5(const u8* __restrict__ sr
 
 template <int MODE>
 __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
-                                                       const int32_t* __restrict__ d_len, const int32_t* __restrict__ order, int wavesPerGroup) {
+                                                       const int32_t* __restrict__ d_len, const int32_t* __restrict__ order, int wavesPerGroup, int prio) {
   const int b = __builtin_amdgcn_readfirstlane(order[blockIdx.x * wavesPerGroup + (int)(threadIdx.x >> 6)]);
   if (b < 0) return;
-  // one serial chain per wave: when the overlapped decoder schedule (kz_api.hip) runs other kernels on the same SIMDs,
-  // this wave's next instruction should not wait behind theirs
-  __builtin_amdgcn_s_setprio(3);
+  // one serial chain per wave.  The overlapped decoder schedule (kz_api.hip) runs several launches of this kernel and HBM-bound
+  // kernels on the same SIMDs: the launch on the critical path (the most expensive blocks) issues ahead of its neighbours
+  if (prio >= 2) __builtin_amdgcn_s_setprio(3);
+  else if (prio == 1) __builtin_amdgcn_s_setprio(1);
   const int n = __builtin_amdgcn_readfirstlane(d_len[b]);
   const u8* s = src + (int64_t)b * stride;
   u8* d = dst + (int64_t)b * stride;
@@ -749,9 +750,9 @@ int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
       if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse5<2>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
       else if (mode == 1) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse5<1>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
       else { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse5<3>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
-    } else if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<2>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
-    else if (mode == 1) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<1>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
-    else { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<3>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
+    } else if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<2>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio); }
+    else if (mode == 1) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<1>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio); }
+    else { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<3>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio); }
   }
   KZ_LAUNCH(ctx, KID_COPY_LEN, k_copy_len, dim3((B + 255) / 256), dim3(256), bt.d_len, bt.d_len2, bt.d_flag, B);
   KZ_HIP(hipGetLastError());
