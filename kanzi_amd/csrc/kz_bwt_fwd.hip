@@ -59,28 +59,27 @@ struct BwtArrays {
 // round 0 keys: the first 7 bytes, zero padded at the end of the text.  A truncated suffix can therefore share a
 // group with suffixes that continue with real zero bytes; it is a prefix of all of them, must sort first, and
 // does: k_live_emit gives positions past the end of the text the smallest, distinct secondary keys.
-__global__ void k_bwt_init(const u8* __restrict__ src, int64_t srcStride, u64* keyC, u32* valC, BwtArrays A, int K) {
-  const int b = blockIdx.y;
-  const int n = A.d_n[b];
-  const u8* s = src + (int64_t)b * srcStride;
-  u64* key = keyC + (int64_t)b * A.NS;
-  u32* val = valC + (int64_t)b * A.NS;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int rem = n - i;
-    // first 7 bytes as a big-endian number: one unaligned 8-byte load (blocks have >= 4 KiB of slack behind them)
-    u64 k = __builtin_bswap64(*(const bw_u64_unaligned*)(s + i)) >> (8 * (8 - K));
-    if (rem < K) k &= ~0ULL << (8 * (K - rem));                     // zero padding at the end of the text
-    key[i] = k; val[i] = (u32)i;                                    // 8K bits: K radix passes
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { A.d_m[b] = n; A.d_w[b] = 0; }
+__device__ __forceinline__ u64 bw_text_key(const u8* __restrict__ s, int i, int n, int K) {
+  // first K bytes as a big-endian number: one unaligned 8-byte load (blocks have >= 4 KiB of slack behind them)
+  u64 k = __builtin_bswap64(*(const bw_u64_unaligned*)(s + i)) >> (8 * (8 - K));
+  const int rem = n - i;
+  if (rem < K) k &= ~0ULL << (8 * (K - rem));                       // zero padding at the end of the text
+  return k;
+}
+// The first LSD pass of round 0 reads the text itself (TextSrc below): the pairs (key, suffix) are never written in
+// their initial order, which saves a 12-byte write and a 20-byte read per input byte.
+struct TextSrc { const u8* src; int64_t stride; int K; };
+__global__ void k_bwt_init(BwtArrays A, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) { A.d_m[b] = A.d_n[b]; A.d_w[b] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------
 // radix pass 1/3: per-tile digit histogram (LDS, wave-aggregated via ballot match-any).  BINS = 256 for the LSD passes,
 // MSD_BINS for the bucket partition of the later rounds (k_msd_*).
 #define MSD_BINS 1024
-template <int BINS, bool MSD>
-__device__ __forceinline__ void radix_hist_body(const u64* __restrict__ keyIn, const BwtArrays& A, int shift) {
+template <int BINS, bool MSD, bool TEXT>
+__device__ __forceinline__ void radix_hist_body(const u64* __restrict__ keyIn, const BwtArrays& A, int shift, TextSrc X) {
   const int b = blockIdx.y;
   const int w0 = MSD ? 0 : A.d_w[b];
   const int m = A.d_m[b] - w0;
@@ -96,7 +95,7 @@ __device__ __forceinline__ void radix_hist_body(const u64* __restrict__ keyIn, c
   for (int r = 0; r < RSORT_ITEMS; r++) {
     const int idx = base + r * KZ_WG + threadIdx.x;
     const bool valid = idx < m;
-    const u32 d = valid ? (u32)((key[idx] >> shift) & (BINS - 1)) : 0;
+    const u32 d = valid ? (u32)(((TEXT ? bw_text_key(X.src + (int64_t)b * X.stride, idx, m, X.K) : key[idx]) >> shift) & (BINS - 1)) : 0;
     // skewed digits (one value for the whole row: high key bytes, runs) would serialise 64 LDS atomics on one
     // address: those rows add once; rows with mixed digits use plain LDS atomics (conflicts only on equal digits)
     const uint64_t vm = kz_ballot(valid);
@@ -108,8 +107,9 @@ __device__ __forceinline__ void radix_hist_body(const u64* __restrict__ keyIn, c
   u32* th = A.tileHist + (int64_t)b * A.HS + (int64_t)tile * BINS;
   for (int i = threadIdx.x; i < BINS; i += KZ_WG) th[i] = hist[i];
 }
-__global__ __launch_bounds__(KZ_WG) void k_radix_hist(const u64* __restrict__ keyIn, BwtArrays A, int shift) { radix_hist_body<256, false>(keyIn, A, shift); }
-__global__ __launch_bounds__(KZ_WG) void k_msd_hist(const u64* __restrict__ keyIn, BwtArrays A, int shift) { radix_hist_body<MSD_BINS, true>(keyIn, A, shift); }
+__global__ __launch_bounds__(KZ_WG) void k_radix_hist(const u64* __restrict__ keyIn, BwtArrays A, int shift) { radix_hist_body<256, false, false>(keyIn, A, shift, TextSrc{nullptr, 0, 0}); }
+__global__ __launch_bounds__(KZ_WG) void k_radix_hist0(BwtArrays A, TextSrc X) { radix_hist_body<256, false, true>(nullptr, A, 0, X); }
+__global__ __launch_bounds__(KZ_WG) void k_msd_hist(const u64* __restrict__ keyIn, BwtArrays A, int shift) { radix_hist_body<MSD_BINS, true, false>(keyIn, A, shift, TextSrc{nullptr, 0, 0}); }
 
 // radix pass 2/3: per block, thread d walks the tiles (coalesced across d) -> exclusive tile
 // offsets per digit, then an exclusive scan over digit totals.
@@ -179,10 +179,10 @@ __device__ __forceinline__ uint64_t bw_match(u32 d, bool valid) {
   }
   return valid ? m : 0ULL;
 }
-template <int BINS, int NBITS, bool MSD, typename CNT>
+template <int BINS, int NBITS, bool MSD, typename CNT, bool TEXT>
 __device__ __forceinline__ void radix_scatter_body(const u64* __restrict__ keyIn, const u32* __restrict__ valIn,
                                                    u64* __restrict__ keyOut, u32* __restrict__ valOut,
-                                                   const BwtArrays& A, int shift) {
+                                                   const BwtArrays& A, int shift, TextSrc X) {
   const int b = blockIdx.y;
   const int w0 = MSD ? 0 : A.d_w[b];
   const int m = A.d_m[b] - w0;
@@ -206,8 +206,13 @@ __device__ __forceinline__ void radix_scatter_body(const u64* __restrict__ keyIn
   for (int r = 0; r < RSC_ITEMS; r++) {
     const int idx = base + r * 64 + lane;
     const bool valid = idx < m;
-    k[r] = valid ? keyIn[off + idx] : 0;
-    v[r] = valid ? valIn[off + idx] : 0;
+    if (TEXT) {
+      k[r] = valid ? bw_text_key(X.src + (int64_t)b * X.stride, idx, m, X.K) : 0;
+      v[r] = (u32)idx;
+    } else {
+      k[r] = valid ? keyIn[off + idx] : 0;
+      v[r] = valid ? valIn[off + idx] : 0;
+    }
   }
 #pragma unroll
   for (int r = 0; r < RSC_ITEMS; r++) {
@@ -276,7 +281,10 @@ __device__ __forceinline__ void radix_scatter_body(const u64* __restrict__ keyIn
 }
 __global__ __launch_bounds__(RSC_WG) void k_radix_scatter(const u64* __restrict__ keyIn, const u32* __restrict__ valIn,
                                                            u64* __restrict__ keyOut, u32* __restrict__ valOut,
-                                                           BwtArrays A, int shift) { radix_scatter_body<256, 8, false, u32>(keyIn, valIn, keyOut, valOut, A, shift); }
+                                                           BwtArrays A, int shift) { radix_scatter_body<256, 8, false, u32, false>(keyIn, valIn, keyOut, valOut, A, shift, TextSrc{nullptr, 0, 0}); }
+__global__ __launch_bounds__(RSC_WG) void k_radix_scatter0(u64* __restrict__ keyOut, u32* __restrict__ valOut, BwtArrays A, TextSrc X) {
+  radix_scatter_body<256, 8, false, u32, true>(nullptr, nullptr, keyOut, valOut, A, 0, X);
+}
 // The bucket partition need not be stable (k_bucket_sort orders by the whole key, and suffixes with equal keys stay
 // one group whatever their order), so the tile-local rank of an element is simply an LDS atomic on its bucket's counter.
 __global__ __launch_bounds__(RSC_WG) void k_msd_scatter(const u64* __restrict__ keyIn, const u32* __restrict__ valIn,
@@ -991,7 +999,8 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
   const int K0 = (ek && ek[0] >= '2' && ek[0] <= '7') ? ek[0] - '0' : 7;   // bytes of the first-round key
   u64 *kC = A.key[0], *kF = A.key[1];
   u32 *vC = A.val[0], *vF = A.val[1];
-  KZ_LAUNCH(ctx, KID_BWT_INIT, k_bwt_init, dim3(gridFor(maxN, 256 * 8), B), dim3(256), src, bt.stride, kC, vC, A, K0);
+  KZ_LAUNCH(ctx, KID_BWT_INIT, k_bwt_init, dim3((B + 255) / 256), dim3(256), A, B);
+  const TextSrc X0 = {src, bt.stride, K0};
   int mMax = maxN;
   int h = 0;
   // bucket path of the later rounds: the packed LDS element needs BK_BITS + bitsR + bitsG <= 64
@@ -1038,9 +1047,15 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
       const int tiles = gridFor(wMax, RS_TILE);
       const int rtiles = gridFor(wMax, RSORT_TILE);
       for (int p = 0; p < passes; p++) {
+        if (round == 0 && p == 0) {                                  // keys straight from the text
+          KZ_LAUNCH(ctx, KID_RADIX_HIST, k_radix_hist0, dim3(rtiles, B), dim3(KZ_WG), A, X0);
+          KZ_LAUNCH(ctx, KID_RADIX_SCAN, k_radix_scan, dim3(B), dim3(256), A);
+          KZ_LAUNCH(ctx, KID_RADIX_SCATTER, k_radix_scatter0, dim3(rtiles, B), dim3(RSC_WG), kF, vF, A, X0);
+        } else {
         KZ_LAUNCH(ctx, KID_RADIX_HIST, k_radix_hist, dim3(rtiles, B), dim3(KZ_WG), kC, A, p * 8);
         KZ_LAUNCH(ctx, KID_RADIX_SCAN, k_radix_scan, dim3(B), dim3(256), A);
         KZ_LAUNCH(ctx, KID_RADIX_SCATTER, k_radix_scatter, dim3(rtiles, B), dim3(RSC_WG), kC, vC, kF, vF, A, p * 8);
+        }
         u64* tk = kC; kC = kF; kF = tk;
         u32* tv = vC; vC = vF; vF = tv;
       }
