@@ -197,6 +197,7 @@ void        kz_set_kernel_timing(kz_ctx* ctx, int32_t enable);
 int32_t     kz_get_kernel_count(void);
 const char* kz_get_kernel_name(int32_t id);
 double      kz_get_kernel_ms(kz_ctx* ctx, int32_t id);        /* summed launch durations since reset */
+double      kz_get_kernel_max_ms(kz_ctx* ctx, int32_t id);    /* longest single launch since reset (launches on the decoder's side streams overlap) */
 int64_t     kz_get_kernel_launches(kz_ctx* ctx, int32_t id);
 void        kz_reset_kernel_timing(kz_ctx* ctx);
 

@@ -12,6 +12,11 @@ Reference interfaces mirrored (K/ = java/src/main/java/io/github/flanglet/kanzi/
   * ``Sequence`` / block span of EncodingTask.encodeBlock -> :func:`encode_blocks` / :func:`decode_blocks`
   * ``CompressedOutputStream`` / ``CompressedInputStream`` -> same-named classes (whole .knz stream)
 """
+# The decoder keeps four HIP streams busy side by side; HIP shares 4 hardware queues among all streams of a process unless
+# GPU_MAX_HW_QUEUES says otherwise WHEN THE RUNTIME STARTS (first HIP call, also PyTorch's).  Without it the library measures
+# that its streams share queues and falls back to a three-stream schedule.
+import os as _os
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import ctypes
 import os
 
@@ -102,6 +107,7 @@ def load_library():
         "kz_get_kernel_count": (c.c_int32, []),
         "kz_get_kernel_name": (c.c_char_p, [c.c_int32]),
         "kz_get_kernel_ms": (c.c_double, [vp, c.c_int32]),
+        "kz_get_kernel_max_ms": (c.c_double, [vp, c.c_int32]),
         "kz_get_kernel_launches": (c.c_int64, [vp, c.c_int32]),
         "kz_reset_kernel_timing": (None, [vp]),
     }
@@ -120,7 +126,7 @@ ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_err
                "kz_max_block_stream_bytes", "kz_submit_encode_blocks", "kz_submit_decode_blocks", "kz_wait", "kz_poll", "kz_compress", "kz_decompress", "kz_compress_bound", "kz_transform_type",
                "kz_knz_assemble", "kz_knz_index",
                "kz_set_timing", "kz_get_stage_count", "kz_get_stage_ms", "kz_get_stage_alg_bytes", "kz_reset_timing",
-               "kz_set_kernel_timing", "kz_get_kernel_count", "kz_get_kernel_name", "kz_get_kernel_ms",
+               "kz_set_kernel_timing", "kz_get_kernel_count", "kz_get_kernel_name", "kz_get_kernel_ms", "kz_get_kernel_max_ms",
                "kz_get_kernel_launches", "kz_reset_kernel_timing"]
 
 
@@ -263,12 +269,13 @@ class Context:
         self.lib.kz_reset_kernel_timing(self.h)
 
     def kernel_times(self):
-        """{kernel name: {"ms": summed launch durations, "launches": n}} since the last reset."""
+        """{kernel name: {"ms": summed launch durations, "launches": n, "max_ms": longest launch}} since the last reset."""
         out = {}
         for i in range(self.lib.kz_get_kernel_count()):
             n = int(self.lib.kz_get_kernel_launches(self.h, i))
             if n:
-                out[self.lib.kz_get_kernel_name(i).decode()] = {"ms": float(self.lib.kz_get_kernel_ms(self.h, i)), "launches": n}
+                out[self.lib.kz_get_kernel_name(i).decode()] = {"ms": float(self.lib.kz_get_kernel_ms(self.h, i)), "launches": n,
+                                                                "max_ms": float(self.lib.kz_get_kernel_max_ms(self.h, i))}
         return out
 
     def stage_times(self):

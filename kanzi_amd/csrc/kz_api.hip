@@ -8,6 +8,7 @@
 #include <atomic>
 #include <memory>
 #include <thread>
+#include <chrono>
 
 typedef uint32_t u32;
 typedef uint8_t u8;
@@ -17,6 +18,10 @@ typedef unsigned long long u64;
 // context / arena
 extern "C" int32_t kz_abi_version(void) { return KZ_ABI_VERSION; }
 
+// The decoder's wide schedule keeps four streams busy side by side; HIP's default is four hardware queues for ALL streams of
+// the process.  Asked for before the runtime starts (library load: nothing has called HIP through this library yet; a host
+// that has initialised HIP before loading it sets GPU_MAX_HW_QUEUES itself, or gets the three-stream schedule).
+namespace { struct KzEnvInit { KzEnvInit() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } kzEnvInit; }
 extern "C" kz_ctx* kz_ctx_create(int32_t deviceId) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return nullptr;   // fail loudly: no CPU fallback
@@ -39,11 +44,7 @@ extern "C" void kz_ctx_destroy(kz_ctx* ctx) {
   }
   hipSetDevice(ctx->device);
   if (ctx->arena) hipFree(ctx->arena);
-  if (ctx->side) hipStreamDestroy(ctx->side);
-  if (ctx->side2) hipStreamDestroy(ctx->side2);
-  if (ctx->evJoin2) hipEventDestroy(ctx->evJoin2);
-  if (ctx->evFork) hipEventDestroy(ctx->evFork);
-  if (ctx->evJoin) hipEventDestroy(ctx->evJoin);
+  for (int i = 0; i < 5; i++) { if (ctx->side[i]) hipStreamDestroy(ctx->side[i]); if (ctx->evJoin[i]) hipEventDestroy(ctx->evJoin[i]); }
   if (ctx->hpin) hipHostFree(ctx->hpin);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -132,7 +133,7 @@ hipEvent_t kz_ev(kz_ctx* ctx) {
 void kz_ktimer_flush(kz_ctx* ctx) {
   for (auto& p : ctx->pending) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) { ctx->kMs[p.id] += ms; ctx->kLaunches[p.id]++; }
+    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) { ctx->kMs[p.id] += ms; ctx->kLaunches[p.id]++; if (ms > ctx->kMaxMs[p.id]) ctx->kMaxMs[p.id] = ms; }
     ctx->evPool.push_back(p.e0); ctx->evPool.push_back(p.e1);
   }
   ctx->pending.clear();
@@ -141,8 +142,9 @@ extern "C" void kz_set_kernel_timing(kz_ctx* ctx, int32_t enable) { ctx->ktiming
 extern "C" int32_t kz_get_kernel_count(void) { return KID_COUNT; }
 extern "C" const char* kz_get_kernel_name(int32_t id) { static const char* n[] = KZ_KERNEL_NAMES; return (id >= 0 && id < KID_COUNT) ? n[id] : ""; }
 extern "C" double kz_get_kernel_ms(kz_ctx* ctx, int32_t id) { return (id >= 0 && id < KID_COUNT) ? ctx->kMs[id] : 0.0; }
+extern "C" double kz_get_kernel_max_ms(kz_ctx* ctx, int32_t id) { return (id >= 0 && id < KID_COUNT) ? ctx->kMaxMs[id] : 0.0; }
 extern "C" int64_t kz_get_kernel_launches(kz_ctx* ctx, int32_t id) { return (id >= 0 && id < KID_COUNT) ? ctx->kLaunches[id] : 0; }
-extern "C" void kz_reset_kernel_timing(kz_ctx* ctx) { for (int i = 0; i < KID_COUNT; i++) { ctx->kMs[i] = 0; ctx->kLaunches[i] = 0; } }
+extern "C" void kz_reset_kernel_timing(kz_ctx* ctx) { for (int i = 0; i < KID_COUNT; i++) { ctx->kMs[i] = 0; ctx->kMaxMs[i] = 0; ctx->kLaunches[i] = 0; } }
 
 void kz_stage_begin(kz_ctx* ctx, hipEvent_t* e0) {
   *e0 = nullptr;
@@ -569,42 +571,56 @@ __global__ void k_merge_group(const int32_t* __restrict__ in, const int32_t* __r
 }
 static int fuse_min_blocks() {                                      // batches below this take the stages one after the other
   const char* e = getenv("KZ_FUSE_MIN_BLOCKS");                     // (read per call: the tests force both schedules)
-  return e ? atoi(e) : 512;
+  return e ? atoi(e) : 32;
 }
 // One cost class of the batch: a lengths-masked view of the same slots with its own length / flag arrays.
 struct OverlapGroup {
   std::vector<int32_t> in;
   int32_t *d_in = nullptr, *len = nullptr, *len2 = nullptr, *flag = nullptr, *old = nullptr;
   int prio = 0;
+  int ev = -1;                            // index of the side stream / join event of its RANK inverse (-1: on the main stream)
+  double tPre = 0, tRank = 0, tBwt = 0;   // modelled seconds of the group's entropy + ZRLT pass, RANK inverse and BWT inverse
   kz_batch v;
 };
-// groups[0] goes on the main stream (the cheapest class), groups[1], groups[2] on the side streams, most expensive last
-struct Overlap { std::vector<OverlapGroup> groups; };
-// host side: classes by cost relative to the largest: >= 3/4 | >= 3/8 | the rest; classes of fewer than 8 blocks join the
-// class below (or above for the cheapest).  false when there is nothing to overlap.
+// groups[0] goes on the main stream (the cheapest class), groups[1..] on the side streams, most expensive last
+struct Overlap { std::vector<OverlapGroup> groups; std::vector<int> launchOrder, bwtOrder; int mainGroup = -1; int64_t started = 0; };
+#define KZ_OVERLAP_MAXG 5
+// host side: classes by cost relative to the largest: >= 3/4 | >= 3/8 | >= 3/16 | >= 3/32 | the rest; classes of fewer than 8
+// blocks join the class below (the cheapest one: the class above).  false when there is nothing to overlap.
 static bool overlap_classify(int B, const std::vector<int32_t>& h_mask, const std::vector<int32_t>& cost, Overlap& O) {
   if (B < fuse_min_blocks()) return false;
   int64_t maxCost = 0;
   for (int b = 0; b < B; b++) if (h_mask[b]) maxCost = std::max<int64_t>(maxCost, cost[b]);
   const char* e3 = getenv("KZ_OVERLAP_CLASSES");
-  const int nClasses = (e3 && e3[0] == '2') ? 2 : 3;
+  int nClasses = e3 ? atoi(e3) : 3;                                // main + two side streams fit HIP's default of 4 hardware queues
+  nClasses = std::min(std::max(nClasses, 2), KZ_OVERLAP_MAXG);
   std::vector<int> cls(B, -1);
-  int cnt[3] = {0, 0, 0};
+  int cnt[KZ_OVERLAP_MAXG] = {0};
   for (int b = 0; b < B; b++) {
     if (!h_mask[b]) continue;
-    const int64_t c8 = (int64_t)cost[b] * 8;
-    cls[b] = (c8 >= maxCost * 6) ? 2 : ((nClasses == 3 && c8 >= maxCost * 3) ? 1 : 0);
-    cnt[cls[b]]++;
+    int c = nClasses - 1;                                          // most expensive
+    int64_t lim = maxCost * 3;                                     // cost * 4 >= maxCost * 3, then halving
+    while (c > 0 && (int64_t)cost[b] * 4 < lim) { c--; lim >>= 1; }
+    cls[b] = c;
+    cnt[c]++;
   }
-  int to[3] = {0, 1, 2};
-  if (cnt[2] < 8) { to[2] = 1; cnt[1] += cnt[2]; cnt[2] = 0; }
-  if (cnt[1] < 8) { to[1] = 0; if (to[2] == 1) to[2] = 0; cnt[0] += cnt[1]; cnt[1] = 0; }
-  if (cnt[0] < 8) {                                                  // the cheapest class is too small: the next one takes the main stream
-    if (cnt[1] > 0) { to[0] = 1; cnt[1] += cnt[0]; } else if (cnt[2] > 0) { to[0] = 2; cnt[2] += cnt[0]; }
-    cnt[0] = 0;
+  int to[KZ_OVERLAP_MAXG];
+  for (int c = 0; c < KZ_OVERLAP_MAXG; c++) to[c] = c;
+  for (int c = nClasses - 1; c >= 1; c--)
+    if (cnt[c] > 0 && cnt[c] < 8) { cnt[c - 1] += cnt[c]; cnt[c] = 0; for (int k = 0; k < KZ_OVERLAP_MAXG; k++) if (to[k] == c) to[k] = c - 1; }
+  if (cnt[0] > 0 && cnt[0] < 8) {                                  // the cheapest class is too small: the next one takes the main stream
+    int up = -1;
+    for (int c = 1; c < nClasses; c++) if (cnt[c] > 0) { up = c; break; }
+    if (up > 0) { cnt[up] += cnt[0]; cnt[0] = 0; for (int k = 0; k < KZ_OVERLAP_MAXG; k++) if (to[k] == 0) to[k] = up; }
   }
-  int order[3], n = 0;
-  for (int c = 0; c < 3; c++) if (cnt[c] > 0) order[n++] = c;
+  if (getenv("KZ_TRACE_SCHED")) {
+    int raw[KZ_OVERLAP_MAXG] = {0};
+    for (int b = 0; b < B; b++) if (cls[b] >= 0) raw[cls[b]]++;
+    fprintf(stderr, "[sched] classes (cheap..expensive) raw %d %d %d %d %d merged %d %d %d %d %d maxCost %lld\n", raw[0], raw[1], raw[2], raw[3], raw[4],
+            cnt[0], cnt[1], cnt[2], cnt[3], cnt[4], (long long)maxCost);
+  }
+  int order[KZ_OVERLAP_MAXG], n = 0;
+  for (int c = 0; c < nClasses; c++) if (cnt[c] > 0) order[n++] = c;
   if (n < 2) return false;
   O.groups.resize(n);
   for (int g = 0; g < n; g++) { O.groups[g].in.assign(B, 0); O.groups[g].prio = (g == n - 1) ? 2 : (g > 0 ? 1 : 0); }
@@ -615,16 +631,9 @@ static bool overlap_classify(int B, const std::vector<int32_t>& h_mask, const st
   }
   return true;
 }
+static int overlap_streams(kz_ctx* ctx);
 static int overlap_alloc(kz_ctx* ctx, int B, Overlap& O) {
-  if (!ctx->side) {
-    KZ_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-    KZ_HIP(hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming));
-    KZ_HIP(hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming));
-  }
-  if (!ctx->side2) {
-    KZ_HIP(hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
-    KZ_HIP(hipEventCreateWithFlags(&ctx->evJoin2, hipEventDisableTiming));
-  }
+  { const int qrc = overlap_streams(ctx); if (qrc) return qrc; }
   for (auto& G : O.groups) {
     int32_t* d = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4 * 5);
     if (!d) { snprintf(ctx->err, sizeof(ctx->err), "overlapped inverse: arena overflow"); return -KZ_ERR_DEVICE; }
@@ -636,41 +645,122 @@ static int overlap_alloc(kz_ctx* ctx, int B, Overlap& O) {
 }
 static int overlap_view(kz_ctx* ctx, const kz_batch& bt, OverlapGroup& G) {
   const int B = bt.B;
-  KZ_LAUNCH(ctx, KID_MASK_LEN, k_mask_len, dim3((B + 255) / 256), dim3(256), bt.d_len, G.d_in, G.len, B);
-  KZ_HIP(hipMemcpyAsync(G.old, G.len, (size_t)B * 4, hipMemcpyDeviceToDevice, ctx->stream));
   G.v = bt;
   G.v.d_len = G.len; G.v.d_len2 = G.len2; G.v.d_flag = G.flag;
   G.v.prio = G.prio;
   for (int b = 0; b < B; b++) if (!G.in[b]) G.v.h_len[b] = 0;
+  // the view's device lengths come from the HOST mirror: a block that failed in an earlier stage has length 0 there while the
+  // batch's device array still holds its old length, and the stages size their scratch by the host's count of non-empty blocks
+  KZ_HIP(hipMemcpyAsync(G.len, G.v.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+  KZ_HIP(hipMemcpyAsync(G.old, G.len, (size_t)B * 4, hipMemcpyDeviceToDevice, ctx->stream));
   return 0;
 }
-// RANK inverse of side group g (1 or 2) on its own stream (everything queued on the main stream so far is waited for)
-static int overlap_start_side(kz_ctx* ctx, const kz_batch& bt, int mode, Overlap& O, int g) {
+// Does this process get as many concurrent hardware queues as the wide schedule needs (main + three side streams)?  HIP
+// multiplexes its streams over GPU_MAX_HW_QUEUES hardware queues (4 unless the variable says otherwise when the runtime
+// starts; kz_ctx_create sets it to 8 when it is unset, which only helps if no HIP call was made before), and two streams on
+// one queue run one after the other.  Measured once per context: four 2 ms spin kernels on the four streams take 2 ms or 4+.
+__global__ void k_spin(long long ticks) {
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+static int overlap_streams(kz_ctx* ctx) {
+  for (int i = 0; i < 5; i++) if (!ctx->side[i]) {
+    KZ_HIP(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
+    KZ_HIP(hipEventCreateWithFlags(&ctx->evJoin[i], hipEventDisableTiming));
+  }
+  const char* e = getenv("KZ_WIDE_QUEUES");                         // (read per call: the tests force both schedules)
+  if (e) { ctx->wideNow = atoi(e) ? 1 : 0; return 0; }
+  if (ctx->wideQueues < 0) {
+    KZ_HIP(hipStreamSynchronize(ctx->stream));
+    hipStream_t q[4] = {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]};
+    for (int r = 0; r < 2; r++) {                                   // first round: warm-up (queue creation, code load)
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < 4; i++) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, q[i], (long long)200000);   // 100 MHz: 2 ms
+      for (int i = 0; i < 4; i++) KZ_HIP(hipStreamSynchronize(q[i]));
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      ctx->wideQueues = ms < 3.5 ? 1 : 0;
+    }
+    if (getenv("KZ_TRACE_SCHED")) fprintf(stderr, "[sched] four streams run %s\n", ctx->wideQueues ? "side by side" : "on shared hardware queues: three-stream schedule");
+  }
+  ctx->wideNow = ctx->wideQueues;
+  return 0;
+}
+// Order of the groups.  Wide schedule (four concurrent hardware queues): every group's RANK inverse runs on its own side stream;
+// the main stream prepares the groups one after the other (entropy decoding + ZRLT inverse, when the caller has not done them
+// yet) and then runs the BWT inverses as the RANK inverses finish (HBM-bound kernels with huge grids do not share the GPU with
+// another queue's kernels anyway: chains "RANK, BWT" per stream were measured, the BWT stages ran one after the other and
+// started late).  The order of the preparation decides which serial chain is on the critical path; it is picked by trying all
+// permutations against a three-constant model: RANK inverse = 115 ns per byte of the group's longest ZRLT-coded block (a
+// serial chain per block; batches this large keep two waves per SIMD), BWT inverse = 40 ps per byte, preparation = 12 ps per
+// entropy-coded byte (MI355X, profiles/).  Narrow schedule: two side streams, the cheapest group's RANK inverse on the main
+// stream behind all the preparations.
+static void overlap_plan(kz_ctx* ctx, Overlap& O, const std::vector<int32_t>& zlen, const std::vector<int32_t>& rawp, int blockSize, bool withPre) {
+  const int n = (int)O.groups.size();
+  O.mainGroup = -1;
+  if (!ctx->wideNow || n > 3) {
+    O.launchOrder.clear(); O.bwtOrder.clear();
+    for (int g = n - 1; g >= 0; g--) O.launchOrder.push_back(g);
+    for (int g = 0; g < n; g++) O.bwtOrder.push_back(g);
+    O.mainGroup = 0;
+    return;
+  }
+  for (auto& G : O.groups) {
+    int64_t maxZ = 0, pre = 0, cnt = 0;
+    for (size_t b = 0; b < G.in.size(); b++) if (G.in[b]) { maxZ = std::max<int64_t>(maxZ, zlen[b]); cnt++; pre += rawp[b] ? zlen[b] / 16 : zlen[b]; }
+    G.tRank = 115e-9 * (double)maxZ;
+    G.tBwt = 40e-12 * (double)cnt * (double)blockSize;
+    G.tPre = withPre ? 12e-12 * (double)pre : 0.0;
+  }
+  std::vector<int> perm(n), best;
+  for (int i = 0; i < n; i++) perm[i] = i;
+  double bestT = 1e30;
+  do {
+    double t = 0, endR[KZ_OVERLAP_MAXG];
+    for (int i = 0; i < n; i++) { t += O.groups[perm[i]].tPre; endR[perm[i]] = t + O.groups[perm[i]].tRank; }
+    std::vector<int> byEnd(perm);
+    std::sort(byEnd.begin(), byEnd.end(), [&](int a, int b) { return endR[a] < endR[b]; });
+    double tb = t;                                                  // the main stream is busy with the preparations until t
+    for (int g : byEnd) tb = std::max(tb, endR[g]) + O.groups[g].tBwt;
+    if (tb < bestT - 1e-9) { bestT = tb; best = perm; O.bwtOrder = byEnd; }
+  } while (std::next_permutation(perm.begin(), perm.end()));
+  O.launchOrder = best;
+  if (getenv("KZ_TRACE_SCHED")) {
+    fprintf(stderr, "[sched] plan %.0f ms: launch", bestT * 1e3);
+    for (int g : O.launchOrder) fprintf(stderr, " %d(pre %.0f rank %.0f bwt %.0f)", g, O.groups[g].tPre * 1e3, O.groups[g].tRank * 1e3, O.groups[g].tBwt * 1e3);
+    fprintf(stderr, " | bwt order"); for (int g : O.bwtOrder) fprintf(stderr, " %d", g); fprintf(stderr, "\n");
+  }
+}
+// RANK inverse of group g: on the main stream for the narrow schedule's main group, else on side stream k (everything queued
+// on the main stream so far is waited for)
+static int overlap_start_rank(kz_ctx* ctx, const kz_batch& bt, int mode, Overlap& O, int g, int k) {
   OverlapGroup& G = O.groups[g];
   int rc = overlap_view(ctx, bt, G);
   if (rc) return rc;
+  {                                                                 // the launches so far occupy the first SIMDs of every CU
+    int64_t act = 0;
+    for (int b = 0; b < bt.B; b++) act += G.in[b] ? 1 : 0;
+    G.v.slotRot = (int)((O.started / std::max(1, (bt.B + 7) / 8)) & 3);
+    O.started += act;
+  }
+  if (g == O.mainGroup) { G.ev = -1; return kz_stage_sbrt_inverse(ctx, G.v, mode); }
+  G.ev = k;
   KZ_HIP(hipStreamSynchronize(ctx->stream));
-  hipStream_t& sd = (g == 1) ? ctx->side : ctx->side2;
+  hipStream_t& sd = ctx->side[k];
   std::swap(ctx->stream, sd);
   rc = kz_stage_sbrt_inverse(ctx, G.v, mode);
-  if (!rc) { hipError_t e = hipEventRecord(g == 1 ? ctx->evJoin : ctx->evJoin2, ctx->stream); if (e != hipSuccess) rc = -KZ_ERR_DEVICE; }
+  if (!rc) { hipError_t e = hipEventRecord(ctx->evJoin[k], ctx->stream); if (e != hipSuccess) rc = -KZ_ERR_DEVICE; }
   std::swap(ctx->stream, sd);
   return rc;
 }
-// the main group's RANK and BWT inverse on the main stream, then the side groups' BWT inverse, cheapest first; merges lengths and flags
-static int overlap_finish(kz_ctx* ctx, Pipe& P, int mode, Overlap& O, std::vector<int32_t>& h_applied) {
+// the groups' BWT inverses on the main stream, in the planned order; merges lengths and flags
+static int overlap_finish(kz_ctx* ctx, Pipe& P, Overlap& O, std::vector<int32_t>& h_applied) {
   kz_batch& bt = P.bt;
   const int B = bt.B;
   hipStream_t st = ctx->stream;
-  int rc = overlap_view(ctx, bt, O.groups[0]);
-  if (rc) return rc;
-  rc = kz_stage_sbrt_inverse(ctx, O.groups[0].v, mode);
-  if (rc) return rc;
   const size_t mark = ctx->arenaTop;
-  rc = kz_stage_bwt_inverse(ctx, O.groups[0].v);
-  if (rc) return rc;
-  for (size_t g = 1; g < O.groups.size(); g++) {
-    KZ_HIP(hipStreamWaitEvent(st, g == 1 ? ctx->evJoin : ctx->evJoin2, 0));
+  int rc = 0;
+  for (int g : O.bwtOrder) {
+    if (O.groups[g].ev >= 0) KZ_HIP(hipStreamWaitEvent(st, ctx->evJoin[O.groups[g].ev], 0));
     ctx->arenaTop = mark;                                           // same stream, in order: the scratch is free again
     rc = kz_stage_bwt_inverse(ctx, O.groups[g].v);
     if (rc) return rc;
@@ -693,9 +783,12 @@ static int overlapped_rank_bwt_inverse(kz_ctx* ctx, Pipe& P, int mode, const std
   if (!overlap_classify(P.bt.B, h_mask, cost, O)) return 0;
   int rc = overlap_alloc(ctx, P.bt.B, O);
   if (rc) return rc;
-  for (int g = (int)O.groups.size() - 1; g >= 1 && !rc; g--) rc = overlap_start_side(ctx, P.bt, mode, O, g);
-  if (rc) return rc;
-  rc = overlap_finish(ctx, P, mode, O, h_applied);
+  {
+    std::vector<int32_t> none(P.bt.B, 0);
+    overlap_plan(ctx, O, P.bt.h_len, none, P.bt.maxN, false);
+  }
+  for (size_t k = 0; k < O.launchOrder.size(); k++) { rc = overlap_start_rank(ctx, P.bt, mode, O, O.launchOrder[k], (int)k); if (rc) return rc; }
+  rc = overlap_finish(ctx, P, O, h_applied);
   return rc ? rc : 1;
 }
 
@@ -1126,13 +1219,19 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
       rc = overlap_alloc(ctx, B, O);
       if (rc) return rc;
       bt.h_cost = cost;
-      for (int g = (int)O.groups.size() - 1; g >= 0; g--) {           // most expensive class first
+      {
+        std::vector<int32_t> rawp(B);
+        for (int b = 0; b < B; b++) rawp[b] = (h_raw[b] || h_tc[b]) ? 1 : 0;
+        overlap_plan(ctx, O, bt.h_len, rawp, blockSize, true);
+      }
+      for (size_t k = 0; k < O.launchOrder.size(); k++) {
+        const int g = O.launchOrder[k];
         rc = entropy_pass(&O.groups[g].in, O.groups[g].d_in);
         if (!rc) rc = transform_pass(hp + 2, &O.groups[g].in, O.groups[g].d_in);
-        if (!rc && g >= 1) rc = overlap_start_side(ctx, bt, mode, O, g);
+        if (!rc) rc = overlap_start_rank(ctx, bt, mode, O, g, (int)k);
         if (rc) return rc;
       }
-      rc = overlap_finish(ctx, P, mode, O, h_applied);
+      rc = overlap_finish(ctx, P, O, h_applied);
       if (rc) return rc;
       for (int b = 0; b < B; b++) if (!h_status[b] && !h_applied[b]) { h_status[b] = -KZ_ERR_PROCESS_BLOCK; bt.h_len[b] = 0; }
       chainDone = true;

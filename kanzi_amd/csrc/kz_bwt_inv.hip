@@ -28,18 +28,19 @@ typedef uint8_t u8;
 #define BI_TILE (KZ_WG * BI_ITEMS)
 
 struct BwtInv {
-  u32* data;        // [B][NS]
-  u32* tileHist;    // [B][T][256]
+  const int32_t* ord; // [B] dense index of the block among the blocks of this call that have data (the [A] arrays below)
+  u32* data;        // [A][NS]
+  u32* tileHist;    // [A][T][256]
   u32* bucket;      // [B][256]
   int32_t* n;       // [B] payload length
   int32_t* hdr;     // [B] header size
   int32_t* prim;    // [B][8] primary indexes (as stored + 1)
   int32_t* status;  // [B]
-  u32* segLen;      // [B][GS]  walker segment lengths
-  int32_t* segNext; // [B][GS]  next segment id on the text path, -1 = end of text
-  u32* segOff;      // [B][GS]  text offset of each segment
-  u8* pool;         // [B][maxChunks * BI_CH] bytes recorded by the walkers, in chunks of BI_CH bytes
-  uint2* chunkMeta; // [B][maxChunks] (walker, sequence number inside its segment)
+  u32* segLen;      // [A][GS]  walker segment lengths
+  int32_t* segNext; // [A][GS]  next segment id on the text path, -1 = end of text
+  u32* segOff;      // [A][GS]  text offset of each segment
+  u8* pool;         // [A][maxChunks * BI_CH] bytes recorded by the walkers, in chunks of BI_CH bytes
+  uint2* chunkMeta; // [A][maxChunks] (walker, sequence number inside its segment)
   u32* chunkCount;  // [B] chunks handed out
   int maxChunks;
   int64_t NS; int T;
@@ -51,6 +52,20 @@ struct BwtInv {
 #define BI_SUSPECT 1       // status: not stitched, k_bwti_literal decides
 #define BI_HEADS 8         // walkers G..G+7 start at the primary indexes (only head 0 records bytes)
 
+// dense scratch index of every block that has data (one workgroup; B <= KZ_MAX_BATCH)
+__global__ __launch_bounds__(1024) void k_bwti_ord(const int32_t* __restrict__ d_len, int32_t* __restrict__ ord, int B) {
+  __shared__ uint32_t lds[32];
+  uint32_t carry = 0;
+  for (int base = 0; base < B; base += 1024) {
+    const int b = base + (int)threadIdx.x;
+    const uint32_t a = (b < B && d_len[b] > 0) ? 1u : 0u;
+    uint32_t total;
+    const uint32_t ex = kz_wg_excl_sum(a, lds, &total);
+    if (b < B) ord[b] = a ? (int32_t)(carry + ex) : 0;
+    carry += total;
+    __syncthreads();
+  }
+}
 __global__ void k_bwti_parse(const u8* __restrict__ src, int64_t stride, const int32_t* __restrict__ d_len, BwtInv V, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
@@ -108,7 +123,7 @@ __global__ __launch_bounds__(KZ_WG) void k_bwti_hist(const u8* __restrict__ src,
     if (valid && (peers & kz_lanemask_lt()) == 0) atomicAdd(&hist[d], (u32)__popcll(peers));
   }
   __syncthreads();
-  V.tileHist[((int64_t)b * V.T + tile) * 256 + threadIdx.x] = hist[threadIdx.x];
+  V.tileHist[((int64_t)V.ord[b] * V.T + tile) * 256 + threadIdx.x] = hist[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void k_bwti_scan(BwtInv V) {
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(256) void k_bwti_scan(BwtInv V) {
   const int n = V.n[b];
   const int tiles = (n + BI_TILE - 1) / BI_TILE;
   __shared__ u32 lds[32];
-  u32* h = V.tileHist + (int64_t)b * V.T * 256;
+  u32* h = V.tileHist + (int64_t)V.ord[b] * V.T * 256;
   u32 run = 0;
   for (int t = 0; t < tiles; t++) {
     const u32 v = h[(int64_t)t * 256 + threadIdx.x];
@@ -136,7 +151,7 @@ __global__ __launch_bounds__(KZ_WG) void k_bwti_scatter(const u8* __restrict__ s
   for (int i = threadIdx.x; i < 1024; i += KZ_WG) (&cnt[0][0])[i] = 0;
   __syncthreads();
   const u8* s = src + (int64_t)b * stride + V.hdr[b];
-  u32* data = V.data + (int64_t)b * V.NS;
+  u32* data = V.data + (int64_t)V.ord[b] * V.NS;
   const int pIdx = V.prim[b * 8];
   const int wave = threadIdx.x >> 6, lane = kz_lane();
   const int base = tile * BI_TILE + wave * (64 * BI_ITEMS);
@@ -157,7 +172,7 @@ __global__ __launch_bounds__(KZ_WG) void k_bwti_scatter(const u8* __restrict__ s
   __syncthreads();
   {
     const int d = threadIdx.x;
-    u32 runv = V.bucket[b * 256 + d] + V.tileHist[((int64_t)b * V.T + tile) * 256 + d];
+    u32 runv = V.bucket[b * 256 + d] + V.tileHist[((int64_t)V.ord[b] * V.T + tile) * 256 + d];
 #pragma unroll
     for (int w = 0; w < 4; w++) { const u32 t = cnt[w][d]; cnt[w][d] = runv; runv += t; }
   }
@@ -190,11 +205,11 @@ __global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V, int b0) {
   const int w = blockIdx.x * 64 + threadIdx.x;
   if (w >= G + BI_HEADS) return;
   const int head = w - G;                                       // >= 0: starts at primary index `head`
-  if (head > 0 && n < 256) { V.segLen[(int64_t)b * V.GS + w] = 0; V.segNext[(int64_t)b * V.GS + w] = -1; return; }   // one primary index only
+  if (head > 0 && n < 256) { V.segLen[(int64_t)V.ord[b] * V.GS + w] = 0; V.segNext[(int64_t)V.ord[b] * V.GS + w] = -1; return; }   // one primary index only
   const bool rec = head <= 0;
-  const u32* data = V.data + (int64_t)b * V.NS;
-  u8* pool = V.pool + (int64_t)b * V.maxChunks * BI_CH;
-  uint2* meta = V.chunkMeta + (int64_t)b * V.maxChunks;
+  const u32* data = V.data + (int64_t)V.ord[b] * V.NS;
+  u8* pool = V.pool + (int64_t)V.ord[b] * V.maxChunks * BI_CH;
+  uint2* meta = V.chunkMeta + (int64_t)V.ord[b] * V.maxChunks;
   u32 t = (head < 0) ? (u32)w << V.logS : (u32)(V.prim[b * 8 + head] - 1);
   u32 steps = 0;
   int nxt = -2;
@@ -233,8 +248,8 @@ __global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V, int b0) {
     if (!full) *(unsigned long long*)(cp + fill) = acc;
   }
   if (nxt == -2 || full) { atomicCAS(&V.status[b], 0, BI_SUSPECT); nxt = -1; }
-  V.segLen[(int64_t)b * V.GS + w] = steps;
-  V.segNext[(int64_t)b * V.GS + w] = nxt;
+  V.segLen[(int64_t)V.ord[b] * V.GS + w] = steps;
+  V.segNext[(int64_t)V.ord[b] * V.GS + w] = nxt;
 }
 
 // per block: suffix sums along the segment chain by pointer jumping in LDS -> text offsets
@@ -248,7 +263,7 @@ __global__ __launch_bounds__(256) void k_bwti_resolve(BwtInv V, int b0) {
   const int M = G + BI_HEADS;
   __shared__ u32 R[BI_MAXSEG];
   __shared__ int NX[BI_MAXSEG];
-  const int64_t o = (int64_t)b * V.GS;
+  const int64_t o = (int64_t)V.ord[b] * V.GS;
   for (int i = threadIdx.x; i < M; i += 256) { R[i] = V.segLen[o + i]; NX[i] = V.segNext[o + i]; }
   __syncthreads();
   for (int round = 0; round < 13; round++) {
@@ -289,14 +304,14 @@ __global__ __launch_bounds__(256) void k_bwti_copy(u8* __restrict__ dst, int64_t
   const u32 id = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (id >= V.chunkCount[b] || id >= (u32)V.maxChunks) return;
   const int lane = threadIdx.x & 63;
-  const uint2 m = V.chunkMeta[(int64_t)b * V.maxChunks + id];
-  const u32 len = V.segLen[(int64_t)b * V.GS + m.x];
-  const u32 off = V.segOff[(int64_t)b * V.GS + m.x];
+  const uint2 m = V.chunkMeta[(int64_t)V.ord[b] * V.maxChunks + id];
+  const u32 len = V.segLen[(int64_t)V.ord[b] * V.GS + m.x];
+  const u32 off = V.segOff[(int64_t)V.ord[b] * V.GS + m.x];
   if (off == 0xFFFFFFFFu || (unsigned long long)off + len > (unsigned long long)n) return;   // not on the text path
   const u32 start = m.y * BI_CH;
   if (start >= len) return;
   const u32 cnt = min((u32)BI_CH, len - start);
-  const u8* src = V.pool + ((int64_t)b * V.maxChunks + id) * BI_CH;
+  const u8* src = V.pool + ((int64_t)V.ord[b] * V.maxChunks + id) * BI_CH;
   u8* d = dst + (int64_t)b * stride + off + start;
   const u32 k = 4u * (u32)lane;
   if (k + 4 <= cnt) *(bi_u32_unaligned*)(d + k) = *(const u32*)(src + k);
@@ -311,7 +326,7 @@ __global__ __launch_bounds__(64) void k_bwti_literal(u8* __restrict__ dst, int64
   if (V.status[b] != BI_SUSPECT) return;
   const int n = V.n[b];
   const int lane = threadIdx.x;
-  const u32* data = V.data + (int64_t)b * V.NS;
+  const u32* data = V.data + (int64_t)V.ord[b] * V.NS;
   u8* o = dst + (int64_t)b * stride;
   bool fail = false;
   const int walkers = (n < 256) ? 1 : 8;
@@ -357,8 +372,15 @@ int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
   BwtInv V;
   V.NS = (int64_t)kz_align((size_t)(maxN > 0 ? maxN : 1), BI_TILE);
   V.T = (int)(V.NS / BI_TILE);
-  V.data = (u32*)kz_arena_alloc(ctx, (size_t)V.NS * B * 4);
-  V.tileHist = (u32*)kz_arena_alloc(ctx, (size_t)V.T * B * 1024);
+  // the large arrays only exist for the blocks that have data: a lengths-masked view of a batch (kz_api.hip: one cost class
+  // of the decoder's overlapped schedule) takes its share of the scratch, and the classes' stages can be in flight together
+  int A = 0;
+  for (int b = 0; b < B; b++) if (bt.h_len[b] > 0) A++;
+  if (A < 1) A = 1;
+  int32_t* d_ord = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  V.ord = d_ord;
+  V.data = (u32*)kz_arena_alloc(ctx, (size_t)V.NS * A * 4);
+  V.tileHist = (u32*)kz_arena_alloc(ctx, (size_t)V.T * A * 1024);
   V.bucket = (u32*)kz_arena_alloc(ctx, (size_t)B * 1024);
   V.n = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   V.hdr = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
@@ -367,18 +389,19 @@ int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
   V.logS = 6;
   while (((maxN + (1 << V.logS) - 1) >> V.logS) > 4096) V.logS++;
   V.GS = ((maxN + (1 << V.logS) - 1) >> V.logS) + BI_HEADS;
-  V.segLen = (u32*)kz_arena_alloc(ctx, (size_t)B * V.GS * 4);
-  V.segNext = (int32_t*)kz_arena_alloc(ctx, (size_t)B * V.GS * 4);
-  V.segOff = (u32*)kz_arena_alloc(ctx, (size_t)B * V.GS * 4);
+  V.segLen = (u32*)kz_arena_alloc(ctx, (size_t)A * V.GS * 4);
+  V.segNext = (int32_t*)kz_arena_alloc(ctx, (size_t)A * V.GS * 4);
+  V.segOff = (u32*)kz_arena_alloc(ctx, (size_t)A * V.GS * 4);
   V.maxChunks = (int)(V.NS / BI_CH) + V.GS + 4;
-  V.pool = (u8*)kz_arena_alloc(ctx, (size_t)B * V.maxChunks * BI_CH);
-  V.chunkMeta = (uint2*)kz_arena_alloc(ctx, (size_t)B * V.maxChunks * sizeof(uint2));
+  V.pool = (u8*)kz_arena_alloc(ctx, (size_t)A * V.maxChunks * BI_CH);
+  V.chunkMeta = (uint2*)kz_arena_alloc(ctx, (size_t)A * V.maxChunks * sizeof(uint2));
   V.chunkCount = (u32*)kz_arena_alloc(ctx, (size_t)B * 4);
-  if (!V.status || !V.data || !V.segOff || !V.chunkCount || !V.pool || !V.chunkMeta) { snprintf(ctx->err, sizeof(ctx->err), "bwt_inverse: arena overflow"); return -KZ_ERR_DEVICE; }
+  if (!V.status || !V.data || !V.segOff || !V.chunkCount || !V.pool || !V.chunkMeta || !d_ord) { snprintf(ctx->err, sizeof(ctx->err), "bwt_inverse: arena overflow"); return -KZ_ERR_DEVICE; }
   hipStream_t st = ctx->stream;
   const u8* src = bt.buf[bt.cur];
   u8* dst = bt.buf[bt.cur ^ 1];
   KZ_HIP(hipMemsetAsync(V.chunkCount, 0, (size_t)B * 4, st));
+  KZ_LAUNCH(ctx, KID_BWTI_PARSE, k_bwti_ord, dim3(1), dim3(1024), bt.d_len, d_ord, B);
   KZ_LAUNCH(ctx, KID_BWTI_PARSE, k_bwti_parse, dim3((B + 63) / 64), dim3(64), src, bt.stride, bt.d_len, V, B);
   const int tiles = (maxN + BI_TILE - 1) / BI_TILE;
   if (tiles > 0) {

@@ -19,8 +19,10 @@ struct KzPending { hipEvent_t e0, e1; int id; };
 struct kz_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t side = nullptr, side2 = nullptr;     // side streams of the overlapped RANK-inverse / BWT-inverse schedule (created on first use)
-  hipEvent_t evFork = nullptr, evJoin = nullptr, evJoin2 = nullptr;
+  hipStream_t side[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // side streams of the overlapped RANK-inverse / BWT-inverse schedule (created on first use)
+  hipEvent_t evJoin[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int wideQueues = -1;           // main + three side streams run side by side (-1: not measured yet)
+  int wideNow = 0;               // what the current call uses (KZ_WIDE_QUEUES overrides the measurement)
   // grow-only device arena, bump-allocated per API call
   uint8_t* arena = nullptr;
   size_t arenaCap = 0, arenaTop = 0;
@@ -45,6 +47,7 @@ struct kz_ctx {
   std::vector<KzPending> pending;
   std::vector<hipEvent_t> evPool;
   double kMs[KID_COUNT] = {0};
+  double kMaxMs[KID_COUNT] = {0};     // longest single launch (launches of one kernel on several streams overlap)
   long long kLaunches[KID_COUNT] = {0};
   // asynchronous batches (kz_submit_* / kz_wait): one worker thread per context runs the queued calls in order
   std::thread worker;
@@ -81,6 +84,7 @@ struct kz_batch {
   int32_t* d_flag = nullptr;    // [B] per-stage applied flag (device)
   int32_t* d_dtype = nullptr;   // [B] Global.DataType of each block: the reference's per-block context entry "dataType"
   std::vector<int32_t> h_len;   // host mirror of d_len
+  int slotRot = 0;              // rotation of the SIMD assignment in kz_place_blocks (views launched side by side start on different SIMDs)
   int prio = 0;                 // issue priority of the serial-per-block kernels launched for this view (overlapped decoder schedule)
   std::vector<int32_t> h_cost;  // optional per-block cost hint for serial-per-block stages (length at the previous stage's input)
 };

@@ -563,6 +563,96 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse5(const u8* __restrict__ sr
     : "vcc", "scc", "v90", "v91", "v92", "v93", "v94", "v95", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",          \
       "s50", "s53", "s54", "s55", "s56", "s58", "s59", "s60");
 
+// ---- cold rows, interleaved layout -------------------------------------------------------------------------------------
+// Rows of high ranks (uniform or badly predicted data: most ranks above 63) paid two or three taken branches per rank in
+// KZ6_ROWCOLD (dispatch on the row of the accessed position, ~40 cycles each for a lone wave) plus the lane-63 -> lane-0
+// carries between rows.  For such rows the list is re-laid out: position j sits in register (j & 3), lane (j >> 2).
+// A shift by one position is then "register k takes register k-1 of the same lane" for k = 1..3 and one DPP wave_shr for
+// register 0: every rank runs the SAME straight-line code (four identical register blocks, processed 3, 2, 1, 0 so that
+// each reads its neighbour before it changes), no dispatch, no carries.  The accessed entry is fetched with a register-indexed v_mov
+// (s_set_gpr_idx_on, index r & 3) + v_readlane (lane r >> 2); x, TH and the new Q are scalar arithmetic.
+// The two layouts are converted with ds_bpermute when a cold row follows a warm one or the other way round.
+#define KZ6I_XS_RANK "s_add_u32 s53, s50, s53\n\t"
+#define KZ6I_XS_MTF  "s_lshl_b32 s53, s50, 1\n\t"
+#define KZ6I_XS_TS   "s_lshl_b32 s53, s53, 1\n\t"
+#define KZ6I_REG(POS, Q, P, NQ, NP, RC)                        \
+    "v_cmpx_ge_u32 vcc, " RC ", " POS "\n\t"                    \
+    "v_cmpx_ge_u32 vcc, s55, " Q "\n\t"                         \
+    "v_cmp_lt_u32_e64 s[58:59], s55, " NQ "\n\t"                \
+    "s_nop 1\n\t"                                               \
+    "v_cndmask_b32_e64 " Q ", " NQ ", v94, s[58:59]\n\t"        \
+    "v_cndmask_b32_e64 " P ", " NP ", v95, s[58:59]\n\t"        \
+    "s_mov_b64 exec, -1\n\t"
+// one rank at row position J (a constant); RC holds its rank, RN receives the next one (the two alternate)
+#define KZ6I_STEP(J, JN, RC, RN, XS)                           \
+    "s_and_b32 s45, " RC ", 3\n\t"                              \
+    "v_readlane_b32 " RN ", %[cur], " #JN "\n\t"                \
+    "s_lshr_b32 s44, " RC ", 2\n\t"                             \
+    "s_set_gpr_idx_on s45, gpr_idx(SRC0)\n\t"                   \
+    "v_mov_b32 v92, v80\n\t"                                    \
+    "v_mov_b32 v93, v84\n\t"                                    \
+    "s_set_gpr_idx_off\n\t"                                     \
+    "v_mov_b32 v95, s50\n\t"                                    \
+    "v_readlane_b32 s54, v92, s44\n\t"                          \
+    "v_readlane_b32 s53, v93, s44\n\t"                          \
+    "v_mov_b32_dpp %[tq0], v83" KZ6_DPP                         \
+    "v_mov_b32_dpp v90, v87" KZ6_DPP                            \
+    XS                                                          \
+    "s_lshl_b32 s55, s53, 7\n\t"                                \
+    "s_or_b32 s55, s55, 0xff\n\t"                               \
+    "v_mov_b32 v93, s55\n\t"                                    \
+    "v_bfi_b32 v94, %[ff], s54, v93\n\t"                        \
+    KZ6I_REG("v75", "v83", "v87", "v82", "v86", RC)             \
+    KZ6I_REG("v74", "v82", "v86", "v81", "v85", RC)             \
+    KZ6I_REG("v73", "v81", "v85", "v80", "v84", RC)             \
+    KZ6I_REG("v72", "v80", "v84", "%[tq0]", "v90", RC)          \
+    "v_writelane_b32 %[outv], s54, " #J "\n\t"                  \
+    "s_add_u32 s50, s50, 1\n\t"
+#define KZ6I_STEP2(A, B, C, XS) KZ6I_STEP(A, B, "s42", "s43", XS) KZ6I_STEP(B, C, "s43", "s42", XS)
+#define KZ6I_STEP8(A, B, C, D, E, F, G, H, I, XS) KZ6I_STEP2(A, B, C, XS) KZ6I_STEP2(C, D, E, XS) KZ6I_STEP2(E, F, G, XS) KZ6I_STEP2(G, H, I, XS)
+#define KZ6I_ROWCOLD(XS) asm volatile(                                                         \
+    "v_mov_b32 v80, %[q0]\n\tv_mov_b32 v81, %[q1]\n\tv_mov_b32 v82, %[q2]\n\tv_mov_b32 v83, %[q3]\n\t"  \
+    "v_mov_b32 v84, %[p0]\n\tv_mov_b32 v85, %[p1]\n\tv_mov_b32 v86, %[p2]\n\tv_mov_b32 v87, %[p3]\n\t"  \
+    "v_mov_b32 v72, %[lane4]\n\tv_add_u32 v73, 1, %[lane4]\n\tv_add_u32 v74, 2, %[lane4]\n\tv_add_u32 v75, 3, %[lane4]\n\t" \
+    "s_mov_b32 s50, %[row]\n\t"                                                                  \
+    "v_readlane_b32 s42, %[cur], 0\n\t"                                                          \
+    KZ6I_STEP8(0, 1, 2, 3, 4, 5, 6, 7, 8, XS) KZ6I_STEP8(8, 9, 10, 11, 12, 13, 14, 15, 16, XS)    \
+    KZ6I_STEP8(16, 17, 18, 19, 20, 21, 22, 23, 24, XS) KZ6I_STEP8(24, 25, 26, 27, 28, 29, 30, 31, 32, XS) \
+    KZ6I_STEP8(32, 33, 34, 35, 36, 37, 38, 39, 40, XS) KZ6I_STEP8(40, 41, 42, 43, 44, 45, 46, 47, 48, XS) \
+    KZ6I_STEP8(48, 49, 50, 51, 52, 53, 54, 55, 56, XS) KZ6I_STEP8(56, 57, 58, 59, 60, 61, 62, 63, 0, XS)  \
+    "v_mov_b32 %[q0], v80\n\tv_mov_b32 %[q1], v81\n\tv_mov_b32 %[q2], v82\n\tv_mov_b32 %[q3], v83\n\t"  \
+    "v_mov_b32 %[p0], v84\n\tv_mov_b32 %[p1], v85\n\tv_mov_b32 %[p2], v86\n\tv_mov_b32 %[p3], v87\n\t"  \
+    : [q0]"+v"(Q0), [p0]"+v"(P0), [q1]"+v"(Q1), [p1]"+v"(P1), [q2]"+v"(Q2), [p2]"+v"(P2), [q3]"+v"(Q3), [p3]"+v"(P3),           \
+      [tq0]"+v"(tq0), [outv]"+v"(outv)                                                                                         \
+    : [cur]"v"(cur), [lane4]"v"(lane4), [ff]"v"(ff), [row]"s"(row)                                                             \
+    : "vcc", "scc", "m0", "v72", "v73", "v74", "v75", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87",                  \
+      "v90", "v92", "v93", "v94", "v95", "s42", "s43", "s44", "s45", "s50", "s53", "s54", "s55", "s58", "s59");
+// layout changes: by position (register k = positions 64k..64k+63) <-> interleaved (register k = positions 4l + k)
+__device__ __forceinline__ void kz6_to_interleaved(u32& A0, u32& A1, u32& A2, u32& A3, int lane) {
+  const int grp = lane >> 4;
+  u32 N[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int a = (4 * (lane & 15) + r) << 2;
+    const u32 t0 = (u32)__builtin_amdgcn_ds_bpermute(a, (int)A0), t1 = (u32)__builtin_amdgcn_ds_bpermute(a, (int)A1);
+    const u32 t2 = (u32)__builtin_amdgcn_ds_bpermute(a, (int)A2), t3 = (u32)__builtin_amdgcn_ds_bpermute(a, (int)A3);
+    N[r] = grp == 0 ? t0 : (grp == 1 ? t1 : (grp == 2 ? t2 : t3));
+  }
+  A0 = N[0]; A1 = N[1]; A2 = N[2]; A3 = N[3];
+}
+__device__ __forceinline__ void kz6_from_interleaved(u32& A0, u32& A1, u32& A2, u32& A3, int lane) {
+  const int sel = lane & 3;
+  u32 N[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int a = (16 * k + (lane >> 2)) << 2;
+    const u32 t0 = (u32)__builtin_amdgcn_ds_bpermute(a, (int)A0), t1 = (u32)__builtin_amdgcn_ds_bpermute(a, (int)A1);
+    const u32 t2 = (u32)__builtin_amdgcn_ds_bpermute(a, (int)A2), t3 = (u32)__builtin_amdgcn_ds_bpermute(a, (int)A3);
+    N[k] = sel == 0 ? t0 : (sel == 1 ? t1 : (sel == 2 ? t2 : t3));
+  }
+  A0 = N[0]; A1 = N[1]; A2 = N[2]; A3 = N[3];
+}
+
 // zero run of zr ranks ending at index pl, compiler form (row tails and all-zero rows)
 #define KZ6_ZERO_RUN(zr, plv)                                                                  \
   { const u32 pl = (u32)(plv);                                                                 \
@@ -577,8 +667,9 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
   if (b < 0) return;
   // one serial chain per wave.  The overlapped decoder schedule (kz_api.hip) runs several launches of this kernel and HBM-bound
   // kernels on the same SIMDs: the launch on the critical path (the most expensive blocks) issues ahead of its neighbours
-  if (prio >= 2) __builtin_amdgcn_s_setprio(3);
-  else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+  const bool useOldCold = (prio & 8) != 0;                          // A/B switch (KZ_SBRT_OLDCOLD): cold rows in the by-position layout
+  if ((prio & 7) >= 2) __builtin_amdgcn_s_setprio(3);
+  else if ((prio & 7) == 1) __builtin_amdgcn_s_setprio(1);
   const int n = __builtin_amdgcn_readfirstlane(d_len[b]);
   const u8* s = src + (int64_t)b * stride;
   u8* d = dst + (int64_t)b * stride;
@@ -589,6 +680,8 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
   u32 tq0 = 0xFFFFFFFFu;                      // lane 0 stays the sentinel "above every key": the DPP shift never writes it
   const u32 ff = 0xFFu;
   u32 fmv = 0;
+  const u32 lane4 = 4u * (u32)lane;
+  bool inter = false;                         // the list is in the interleaved layout (between consecutive cold rows)
   u32 cur = (lane < n) ? (u32)s[lane] : 0u;
   for (int row = 0; row < n; row += 64) {
     const int cnt = min(64, n - row);
@@ -600,11 +693,20 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
     const u32 f0 = (u32)__builtin_amdgcn_readfirstlane((int)Q0) & 0xFFu;
     int prev = -1;
     const bool dense = cnt == 64 && __builtin_popcountll(nz) >= 48;
+    const bool cold = dense && __builtin_popcountll(kz_ballot(cur >= 64u)) > 6;
+    const bool wantInter = cold && !useOldCold;
+    if (wantInter != inter) {                                             // (uniform) change of layout
+      if (wantInter) { kz6_to_interleaved(Q0, Q1, Q2, Q3, lane); kz6_to_interleaved(P0, P1, P2, P3, lane); }
+      else { kz6_from_interleaved(Q0, Q1, Q2, Q3, lane); kz6_from_interleaved(P0, P1, P2, P3, lane); }
+      inter = wantInter;
+    }
     if (dense) {
-      if (__builtin_popcountll(kz_ballot(cur >= 64u)) <= 6) {
+      if (!cold) {
         if (MODE == 2) { KZ6_ROWDENSE(KZ6_XI_RANK) } else if (MODE == 1) { KZ6_ROWDENSE(KZ6_XI_MTF) } else { KZ6_ROWDENSE(KZ6_XI_TS) }
-      } else {
+      } else if (useOldCold) {
         if (MODE == 2) { KZ6_ROWCOLD(KZ6_XI_RANK) } else if (MODE == 1) { KZ6_ROWCOLD(KZ6_XI_MTF) } else { KZ6_ROWCOLD(KZ6_XI_TS) }
+      } else {
+        if (MODE == 2) { KZ6I_ROWCOLD(KZ6I_XS_RANK) } else if (MODE == 1) { KZ6I_ROWCOLD(KZ6I_XS_MTF) } else { KZ6I_ROWCOLD(KZ6I_XS_TS) }
       }
     } else if (nz) {
       if (MODE == 2) { KZ6_ROWLOOP(KZ6_XI_RANK, KZ6_ZQ_RANK) } else if (MODE == 1) { KZ6_ROWLOOP(KZ6_XI_MTF, KZ6_ZQ_MTF) } else { KZ6_ROWLOOP(KZ6_XI_TS, KZ6_ZQ_TS) }
@@ -714,7 +816,8 @@ int kz_place_blocks(kz_ctx* ctx, const kz_batch& bt, KzPlacement& PL) {
       if (haveCost) {
         const int p = k / G, q = k % G;
         const int wg = (p & 1) ? G - 1 - q : q;                    // snake over the workgroups
-        const int slot = p < 4 ? p : 11 - p;                        // 4 most expensive on waves 0..3, the cheapest facing them
+        const int slot0 = p < 4 ? p : 11 - p;                       // 4 most expensive on waves 0..3, the cheapest facing them
+        const int slot = (slot0 & 4) | ((slot0 + bt.slotRot) & 3);  // wave w runs on SIMD w & 3: views in flight together start on different SIMDs
         o[(size_t)wg * 8 + slot] = blk;
       } else o[k] = blk;
     }
@@ -743,6 +846,7 @@ int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
   const std::vector<int>& launchOff = PL.off;
   const int32_t* d_order = PL.d_order;
   static const bool useV5 = getenv("KZ_SBRT_V5") != nullptr;          // A/B switch while v6 is being measured
+  const int oldCold = getenv("KZ_SBRT_OLDCOLD") ? 8 : 0;
   for (int rr = 0; rr < R; rr++) {
     const int G = launchG[rr];
     const int32_t* ord = d_order + launchOff[rr];
@@ -750,9 +854,9 @@ int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
       if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse5<2>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
       else if (mode == 1) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse5<1>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
       else { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse5<3>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
-    } else if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<2>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio); }
-    else if (mode == 1) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<1>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio); }
-    else { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<3>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio); }
+    } else if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<2>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio | oldCold); }
+    else if (mode == 1) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<1>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio | oldCold); }
+    else { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<3>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio | oldCold); }
   }
   KZ_LAUNCH(ctx, KID_COPY_LEN, k_copy_len, dim3((B + 255) / 256), dim3(256), bt.d_len, bt.d_len2, bt.d_flag, B);
   KZ_HIP(hipGetLastError());

@@ -1,4 +1,5 @@
 import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the first HIP call of the process (kanzi_amd/__init__.py)
 import sys
 
 import pytest

@@ -1054,18 +1054,26 @@ def test_expensive_blocks_first_decode_schedule(ctx, monkeypatch):
         bad = out.copy()
         bad[5, 400:420] ^= 0x5A                     # inside one block's payload: the header still parses
         results = {}
-        for mode, fuse, nosf in (("staged", "1000000", None), ("overlapped", "8", "1"), ("first", "8", None)):
+        # "first": four streams (every class's RANK inverse on a side stream, planned order); "first3": the three-stream form
+        # taken when the process has too few hardware queues
+        for mode, fuse, nosf, wide in (("staged", "1000000", None, None), ("overlapped", "8", "1", "1"), ("overlapped3", "8", "1", "0"),
+                                       ("first", "8", None, "1"), ("first3", "8", None, "0")):
             monkeypatch.setenv("KZ_FUSE_MIN_BLOCKS", fuse)
             if nosf:
                 monkeypatch.setenv("KZ_NO_SFIRST", nosf)
             else:
                 monkeypatch.delenv("KZ_NO_SFIRST", raising=False)
+            if wide:
+                monkeypatch.setenv("KZ_WIDE_QUEUES", wide)
+            else:
+                monkeypatch.delenv("KZ_WIDE_QUEUES", raising=False)
             for name, streams in (("good", out), ("bad", bad)):
                 dec = np.zeros((B, bs), dtype=np.uint8)
                 r2 = kz.decode_blocks(ctx, chain, ent, bs, streams, ostride, bits, dec, bs)
                 results[(mode, name)] = ([(r.status, r.length) for r in r2], [dec[i, :max(r2[i].length, 0)].tobytes() for i in range(B)])
         for name in ("good", "bad"):
-            assert results[("staged", name)] == results[("overlapped", name)] == results[("first", name)], (chain, name)
+            for mode in ("overlapped", "overlapped3", "first", "first3"):
+                assert results[("staged", name)] == results[(mode, name)], (chain, name, mode)
         st = results[("first", "good")][0]
         assert all(s == 0 and l == lens[i] for i, (s, l) in enumerate(st))
         assert all(results[("first", "good")][1][i] == inp[i, :lens[i]].tobytes() for i in range(B))

@@ -11,6 +11,10 @@ import re
 import sys
 
 
+# kernels the library times under one id (kz_internal.h: KZ_KERNEL_NAMES): the text-sourced first radix pass
+ALIASES = {"k_radix_hist0": "k_radix_hist", "k_radix_scatter0": "k_radix_scatter"}
+
+
 def agg(path, counter):
     out = {}
     with open(path, newline="") as f:
@@ -19,6 +23,7 @@ def agg(path, counter):
                 continue
             name = re.sub(r"\(.*", "", row["Kernel_Name"]).strip()
             name = re.sub(r"<.*", "", name.replace("void ", "")).strip()      # templated kernels: "void k_x<2>"
+            name = ALIASES.get(name, name)
             d = out.setdefault(name, {"launches": 0, "sum": 0.0})
             d["launches"] += 1
             d["sum"] += float(row["Counter_Value"])
