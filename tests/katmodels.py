@@ -229,3 +229,178 @@ def ans0_encode(data):
         for b in reversed(buf):
             bs.write(b, 8)
     return bs.bytes(), bs.n
+
+
+def _encode_alphabet(bs, alphabet):
+    """EntropyUtils.encodeAlphabet :38-75 (alphabet: ascending symbols)"""
+    n = len(alphabet)
+    if n == 0:
+        bs.write(0, 1); bs.write(1, 1)
+    elif n == 256:
+        bs.write(0, 1); bs.write(0, 1)
+    else:
+        bs.write(1, 1)
+        masks = [0] * 32
+        for a in alphabet:
+            masks[a >> 3] |= 1 << (a & 7)
+        last = alphabet[-1] >> 3
+        bs.write(last, 5)
+        for i in range(last + 1):
+            bs.write(masks[i], 8)
+
+
+def _exp_golomb_signed(bs, v):
+    """ExpGolombEncoder.encodeByte, signed form (:123-132; the cache row is the plain code: |v| + 1 in Exp-Golomb, then the sign)"""
+    if v == 0:
+        bs.write(1, 1)
+        return
+    n = abs(v) + 1
+    length = n.bit_length()
+    bs.write(0, length - 1)
+    bs.write(n, length)
+    bs.write(1 if v < 0 else 0, 1)
+
+
+def huffman_encode(data):
+    """K/entropy/HuffmanEncoder.java for blocks of ONE chunk (< 65536 bytes) whose minimum-redundancy code lengths do not depend
+    on how ties between equal weights are broken (powers of two, all equal, ...): the lengths come from a textbook two-queue
+    Huffman construction here, NOT from the in-place Moffat-Katajainen passes the encoder (and oracle/kzo_huffman.c) use, and
+    must not exceed 12.  updateFrequencies :103-176 (alphabet, canonical codes HuffmanCommon.java:71-111, signed Exp-Golomb
+    deltas of the lengths starting from 2), encode :380-413, encodeChunk :417-489 (four fragments, bit counts as varints).
+    Returns (bytes, number of bits)."""
+    import heapq
+    bs = _Bits()
+    count = len(data)
+    assert count < 65536
+    if count < 32:                                                            # :399-401
+        for b in data:
+            bs.write(b, 8)
+        return bs.bytes(), bs.n
+    freqs = [0] * 256
+    for b in data:
+        freqs[b] += 1
+    alphabet = [i for i in range(256) if freqs[i]]
+    _encode_alphabet(bs, alphabet)
+    sizes = {}
+    if len(alphabet) == 1:
+        sizes[alphabet[0]] = 1
+    else:
+        heap = [(freqs[a], i, (a,)) for i, a in enumerate(alphabet)]
+        heapq.heapify(heap)
+        depth = {a: 0 for a in alphabet}
+        tick = len(heap)
+        while len(heap) > 1:
+            f1, _, s1 = heapq.heappop(heap)
+            f2, _, s2 = heapq.heappop(heap)
+            for a in s1 + s2:
+                depth[a] += 1
+            heapq.heappush(heap, (f1 + f2, tick, s1 + s2))
+            tick += 1
+        sizes = depth
+        assert max(sizes.values()) <= 12
+    prev = 2
+    for a in alphabet:                                                        # :163-173
+        _exp_golomb_signed(bs, sizes[a] - prev)
+        prev = sizes[a]
+    if len(alphabet) == 1:                                                    # :407-408: a one-symbol chunk is its header
+        return bs.bytes(), bs.n
+    codes, code, cur = {}, 0, None
+    for a in sorted(alphabet, key=lambda x: (sizes[x], x)):                   # canonical: by (length, symbol)
+        if cur is None:
+            cur = sizes[a]
+        code <<= sizes[a] - cur
+        cur = sizes[a]
+        codes[a] = code
+        code += 1
+    frag = count // 4
+    parts = []
+    for j in range(4):
+        fb = _Bits()
+        for b in data[j * frag:(j + 1) * frag]:
+            fb.write(codes[b], sizes[b])
+        parts.append(fb)
+    for fb in parts:
+        _write_varint(bs, fb.n)
+    for fb in parts:
+        if fb.n:
+            bs.write(fb.v, fb.n)
+    for b in data[4 * frag:]:
+        bs.write(b, 8)
+    return bs.bytes(), bs.n
+
+
+def lz_decode(src, out_cap):
+    """K/transform/LZCodec.java inverseV6 :617-756 + readLength :241-258, as a pure-Python reader of the LZ / LZX frame: three little-
+    endian lengths (offset of the token stream = 13 + literal bytes, token bytes, match-index bytes; the match lengths fill the rest), a flag byte (bit 0: the 2^24 window, bits 1..3:
+    minMatch - 2), the literals, then the token, match-index and match-length streams.  Returns the decoded bytes or None."""
+    count = len(src)
+    if count == 0:
+        return b""
+    if count < 13:
+        return None
+    tk_len = int.from_bytes(src[0:4], "little", signed=True)
+    m_idx_len = int.from_bytes(src[4:8], "little", signed=True)
+    m_len_len = int.from_bytes(src[8:12], "little", signed=True)
+    if tk_len < 13 or tk_len > count or m_idx_len < 0 or m_len_len < 0 or m_idx_len > count - tk_len or m_len_len > count - tk_len - m_idx_len:
+        return None
+    tk = tk_len
+    mi = tk + m_idx_len
+    ml = mi + m_len_len
+    src_end = tk - 13
+    max_dist = (1 << 16) - 2 if (src[12] & 1) == 0 else (1 << 24) - 2          # MAX_DISTANCE1 / MAX_DISTANCE2 :152-153
+    min_match = ((src[12] >> 1) & 7) + 2
+    pos = 13
+    dst = bytearray()
+    repd0 = repd1 = count
+
+    def read_length(p):
+        r = src[p]; p += 1
+        if r < 254:
+            return r, p
+        if r == 254:
+            return r + (src[p] << 8) + src[p + 1], p + 2
+        return r + (src[p] << 16) + (src[p + 1] << 8) + src[p + 2], p + 3
+
+    while True:
+        token = src[tk]; tk += 1
+        if token >= 32:
+            if token >= 0xE0:
+                n, pos = read_length(pos)
+                lit = 7 + n
+            else:
+                lit = token >> 5
+            if lit > out_cap - len(dst) or lit > tk_len - pos:
+                return None
+            dst += src[pos:pos + lit]
+            pos += lit
+            if pos >= src_end + 13:                                            # srcIdx >= srcEnd, srcEnd = token stream - 13 + the 13-byte header
+                break
+        f = token & 0x18
+        if f == 0:
+            mlen = token & 3
+            if mlen == 3:
+                n, ml = read_length(ml)
+                mlen += min_match + n
+            else:
+                mlen += min_match
+            dist = repd0 if (token & 4) == 0 else repd1
+        else:
+            mlen = token & 7
+            if mlen == 7:
+                n, ml = read_length(ml)
+                mlen += min_match + n
+            else:
+                mlen += min_match
+            dist = src[mi]; mi += 1
+            if f == 0x18:
+                dist = (dist << 16) | (src[mi] << 8) | src[mi + 1]; mi += 2
+            elif f == 0x10:
+                dist = (dist << 8) | src[mi]; mi += 1
+        repd1, repd0 = repd0, dist
+        ref = len(dst) - dist
+        if ref < 0 or dist > max_dist or len(dst) + mlen > out_cap:
+            return None
+        for i in range(mlen):
+            dst.append(dst[ref + i])
+    return bytes(dst) if pos == tk_len else None
+

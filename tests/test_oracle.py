@@ -8,6 +8,7 @@ import os
 import numpy as np
 import pytest
 
+import datagen
 import oracle
 import refinputs
 
@@ -342,3 +343,50 @@ def test_ans0_known_answers_from_a_python_model_of_the_reference():
     # (00100), then the masks FF FF FF FF 01
     model, _ = katmodels.ans0_encode(bytes(range(33)))
     assert model[:6].hex() == "927fffffff80" and (model[6] & 0x80) == 0x80      # those 49 bits; the frequency header follows
+
+
+def test_huffman_known_answers_from_a_python_model_of_the_reference():
+    """Huffman against tests/katmodels.huffman_encode (written from K/entropy/HuffmanEncoder.java, its code lengths from a
+    textbook construction instead of the in-place passes): inputs whose optimal lengths are unique -- dyadic weights, a flat
+    alphabet of 256, 16 and 2 symbols, a one-symbol chunk (header only), a block below 32 bytes (stored), a tail behind the
+    four fragments -- plus the first bits of one case by hand."""
+    import katmodels
+    dyadic = bytes([97] * 32 + [98] * 16 + [99] * 8 + [100] * 4 + [101] * 2 + [102, 103])
+    rng = np.random.default_rng(8)
+    perm = bytes(rng.permutation(np.frombuffer(dyadic, dtype=np.uint8)))
+    cases = [dyadic, perm, perm + b"ab", bytes(range(256)) * 3, bytes(range(16)) * 9 + bytes(range(3)), b"ab" * 40, b"q" * 77, b"short block",
+             bytes(rng.permutation(np.repeat(np.arange(8, dtype=np.uint8), [64, 64, 32, 32, 16, 16, 16, 16])))]
+    for data in cases:
+        model, nbits = katmodels.huffman_encode(data)
+        enc, obits = oracle.entropy_encode("HUFFMAN", data)
+        assert obits == nbits and enc[:len(model)] == model, (len(data), nbits, obits)
+    # by hand, the dyadic block: partial alphabet (1), last mask byte 103 >> 3 = 12 (01100), masks 0 x 12 then 0xFE (symbols 97..103 =
+    # bits 1..7 of byte 12): 1 01100 | 96 zero bits | 11111110; lengths 1,2,3,4,5,6,6 as signed Exp-Golomb deltas from 2:
+    # -1 = 0101, +1 = 0100 five times, 0 = 1; 16-byte fragments: "a" x 16 = 16 bits, "a" x 16 = 16 bits, "b" x 16 = 32 bits, c x 8, d x 4,
+    # e x 2, f, g = 24 + 16 + 10 + 12 = 62 bits -> varints 10 10 20 3E
+    model, nbits = katmodels.huffman_encode(dyadic)
+    want = "1" + "01100" + "0" * 96 + "11111110" + "0101" + "0100" * 5 + "1" + "".join(format(v, "08b") for v in (16, 16, 32, 62))
+    want += "0" * 32 + "10" * 16 + "110" * 8 + "1110" * 4 + "11110" * 2 + "111110" + "111111"
+    assert nbits == len(want)
+    assert model == int(want + "0" * (-len(want) % 8), 2).to_bytes((len(want) + 7) // 8, "big")
+
+
+def test_lz_frames_are_read_back_by_a_python_model_of_the_reference_decoder():
+    """LZ / LZX forward output of the oracle, decoded by tests/katmodels.lz_decode (written from K/transform/LZCodec.java
+    inverseV6 :617-756, not from oracle/kzo_lz.c), and one frame taken apart by hand."""
+    import katmodels
+    rng = np.random.default_rng(3)
+    cases = [b"abc" * 420, datagen.block(0, 50000).tobytes(), datagen.block(2, 70000).tobytes(), bytes(rng.integers(0, 4, 30000, dtype=np.uint8)),
+             bytes(1000) + b"xyz" * 500, b"0123456789" * 8 + b"ABCD", datagen.block(4, 300000).tobytes(), bytes(rng.integers(0, 256, 2000, dtype=np.uint8)) * 40]
+    for name in ("LZ", "LZX"):
+        for d in cases:
+            ok, enc = oracle.transform_forward(name, d)
+            if ok:
+                assert katmodels.lz_decode(enc, len(d)) == d, (name, len(d))
+    # "abc" x 420 through LZ, by the frame rules: token stream at 40 = 13 + 27 literal bytes, 2 token bytes, 1 match-index byte,
+    # flag 04 = 64 KiB window, minMatch 4.  Token 6f: 3 literals "abc", then a match with a 1-byte distance (03) and length
+    # 7 + 4 + readLength(fe 03 c9 = 254 + 0x03c9) = 1234; token e0: 7 + readLength(10) = 23 literals, the tail the encoder never
+    # matches; 3 + 1234 + 23 = 1260
+    ok, enc = oracle.transform_forward("LZ", b"abc" * 420)
+    assert ok and enc.hex() == "28000000" "02000000" "01000000" "04" + "616263" + "10" + (b"bca" * 8)[:23].hex() + "6fe0" + "03" + "fe03c9"
+
