@@ -498,20 +498,18 @@ __global__ __launch_bounds__(KZ_WG) void k_seg_apply(const u64* __restrict__ key
 }
 
 // ---------------------------------------------------------------------------------------------
-// One bucket of a later round, start to finish in one workgroup: load the bucket's pairs, LSD radix sort them in LDS
-// by (old group, secondary key), then do what k_seg_reduce / k_seg_apply do for the sorted run.  An element is one
-// u64: (group - bucket base : BK_BITS | r2 : bitsR | suffix : bitsG), 58 bits for 4 MiB blocks.  Wave w owns the
-// contiguous rows [w*R, (w+1)*R) of 64 elements; between passes the elements live in registers, the LDS buffer is
-// only the exchange.  Two shapes are launched over all buckets and each takes the buckets of its size class:
-// k_bucket_sort_s (4 waves, up to 1024 elements, 12 KiB of LDS: many per CU; a bucket of <= 64 is ranked by one wave
-// with all-pairs compares and no barrier at all) and k_bucket_sort (16 waves, up to BK_CAP).
+// One bucket of a later round whose longest old group is above BK_GMAX (flagged by k_bucket_count*), start to finish in one
+// workgroup: load the bucket's pairs, LSD radix sort them in LDS by (old group, secondary key), then do what k_seg_reduce /
+// k_seg_apply do for the sorted run.  An element is one u64: (group - bucket base : BK_BITS | r2 : bitsR | suffix : bitsG),
+// 58 bits for 4 MiB blocks.  Wave w owns the contiguous rows [w*R, (w+1)*R) of 64 elements; between passes the elements
+// live in registers, the LDS buffer is only the exchange (48 KiB + 16 KiB of u16 counters, 64 VGPRs: two workgroups per CU).
 #define BK_DBITS 9             // LDS sort digit: 36 key bits of a 4 MiB block in four passes
 #define BK_DBINS (1 << BK_DBITS)
 #define BK_SMALL 1024
 #define BK_SORT 0x40000000u
 static_assert(RSC_WG == MSD_BINS, "k_msd_scatter geometry");
 
-template <int WAVES, int ROWS, int LO, int HI>
+template <int WAVES, int ROWS>
 __device__ __forceinline__ void bucket_body(const u64* __restrict__ keyS, const u32* __restrict__ valS, const BwtArrays& A, int bitsR, int bitsG) {
   const int b = blockIdx.y;
   const u32 d = blockIdx.x;
@@ -520,8 +518,6 @@ __device__ __forceinline__ void bucket_body(const u64* __restrict__ keyS, const 
   const u32 bc = bc0 & ~BK_SORT;
   const int cnt = (int)bc;
   const int wave = threadIdx.x >> 6, lane = kz_lane();
-  const bool tiny = false;
-  if (tiny && wave != 0) return;
   __shared__ u64 buf[WAVES * ROWS * 64];
   __shared__ uint16_t cw[WAVES][BK_DBINS];                     // per-wave digit counts, then bucket-local slots
   __shared__ u32 wsum[BK_DBINS / 64];
@@ -541,19 +537,7 @@ __device__ __forceinline__ void bucket_body(const u64* __restrict__ keyS, const 
     k[r] = ~0ULL;
     if (r < R && idx < cnt) k[r] = ((keyS[off + bo + idx] - kbase) << bitsG) | (u64)valS[off + bo + idx];
   }
-  if (tiny) {
-    // all elements differ (the suffix is part of the element): rank = number of smaller elements
-    const u32 klo = (u32)k[0], khi = (u32)(k[0] >> 32);
-    u32 rk = 0;
-    for (int j = 0; j < cnt; j++) {
-      const u64 kj = ((u64)(u32)__builtin_amdgcn_readlane((int)khi, j) << 32) | (u32)__builtin_amdgcn_readlane((int)klo, j);
-      rk += (kj < k[0]) ? 1u : 0u;
-    }
-    if (lane < cnt) buf[rk] = k[0];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane < cnt) k[0] = buf[lane];
-  } else {
+  {
     if (threadIdx.x < 8) skip[threadIdx.x] = 0;
     const int keyBits = bitsR + BK_BITS;
     const int passes = (keyBits + BK_DBITS - 1) / BK_DBITS;
@@ -657,7 +641,7 @@ __device__ __forceinline__ void bucket_body(const u64* __restrict__ keyS, const 
     }
   }
   u32 carS = 0, carH = 0;
-  if (!tiny) {
+  {
     if (lane == 0) { wS[wave] = ms; wH[wave] = mh; }
     __syncthreads();
     for (int w = 0; w < wave; w++) { carS = max(carS, wS[w]); carH = max(carH, wH[w]); }
@@ -691,7 +675,7 @@ __device__ __forceinline__ void bucket_body(const u64* __restrict__ keyS, const 
   }
 }
 __global__ __launch_bounds__(1024, 8) void k_bucket_sort(const u64* __restrict__ keyS, const u32* __restrict__ valS, BwtArrays A, int bitsR, int bitsG) {
-  bucket_body<16, BK_CAP / 1024, BK_SMALL, BK_CAP>(keyS, valS, A, bitsR, bitsG);
+  bucket_body<16, BK_CAP / 1024>(keyS, valS, A, bitsR, bitsG);
 }
 
 // ---------------------------------------------------------------------------------------------

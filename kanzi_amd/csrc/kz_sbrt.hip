@@ -12,9 +12,9 @@
 //   one wave64 per tile holds the 256 keys in VGPRs (symbol s = element s>>6, lane s&63);
 //   a rank is 4 v_cmp_gt_u64 ballots + s_bcnt1; runs of equal bytes are skipped from the third byte on.
 // inverse (serial per block by nature: the list state depends on every decoded symbol): one wave
-//   per block; the rank->symbol list lives in ONE VGPR (position j = lane j>>2, byte j&3), a move-up
-//   is a DPP wave shift + v_perm; keys stay with their symbol; blocks of the batch decode concurrently,
-//   placed on the SIMDs by cost (kz_place_blocks).
+//   per block; the list lives by POSITION in VGPRs (row k = positions 64k..64k+63, or interleaved for rows of
+//   high ranks), a move is a masked DPP shift; blocks of the batch decode concurrently, placed on the SIMDs
+//   by cost (kz_place_blocks).  See "inverse v6" below.
 #include "kz_device.h"
 #include "kz_internal.h"
 #include <algorithm>
@@ -167,137 +167,6 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
       prev = j;
     }
     if (cnt - prev - 1 > 0) KZ_SBRT_FIX_RUN(cp, row + cnt - 1)
-    if (lane < cnt) d[row + lane] = (u8)outv;
-    cur = nxt;
-  }
-}
-
-// ---- inverse: one wave per block; symbol order in ONE VGPR, keys per symbol ---------------------
-// (v4 kept the list as 256 (key,symbol) pairs in 8 VGPRs and shifted all of them per symbol: ~110 VALU per rank)
-// ord : byte k of lane l = symbol at list position 4l+k.  A move of position r up to rp is a rotation of
-//       [rp, r]: one DPP wave_shr + one v_perm_b32 whose per-lane byte selector is built from two clamped
-//       shifts of 0x01010101 (bytes <= r minus bytes <= rp select "predecessor"), then a v_bfi for byte rp.
-// K   : keys stay with their SYMBOL (symbol s = lane s&63, element pair 2*(s>>6)), so nothing but the moved
-//       symbol's key ever changes: an indexed-VGPR write (s_set_gpr_idx) under a single-lane select.
-//       new position rp = #keys above the new key = 4 v_cmp_gt_u64 ballots + s_bcnt1 (order-free count).
-// Uniform values (rank, symbol, new key, rp) live in SGPRs; per non-zero rank the step has ~33 VALU and
-// ~38 SALU instructions and 4 VALU->SALU hand-offs.  Cost model (tools/ubench_lonewave.hip): a lone wave issues
-// one instruction per 4 cycles whatever its type, a VALU->SALU hand-off costs ~30 cycles, a taken branch ~40.
-#define KZ_DPP_SHR1_Z(x) ((u32)__builtin_amdgcn_update_dpp(0, (int)(x), 0x138 /*wave_shr:1*/, 0xF, 0xF, true))
-
-// zero run of zr ranks ending at index pl: the front symbol repeats, only its (q,p) change (SBRT.java:194-201)
-#define KZ_SBRT_ZERO_RUN(zr, plv)                                                              \
-  if (MODE != 1) { const u32 pold = max(fplo, 256u) - 256u;                                                   \
-    const u32 pl = (u32)(plv);                                                                 \
-    const u32 pp = ((zr) >= 2) ? pl - 1u : pold;                                               \
-    const u32 fq = (MODE == 2) ? ((pl + pp) >> 1) : ((MODE == 1) ? pl : pp);                   \
-    fplo = pl + 256u;                                                                          \
-    const int fs = (int)(f >> 6);                                                              \
-    const u64 ok = K[fs];                                                                      \
-    K[fs] = (lane == (int)(f & 63u)) ? (((u64)fq << 32) | (u64)fplo) : ok; }
-
-// One non-zero rank at row position JV (iv = row + JV).  WRITE_OUT stores the decoded symbol c in lane JV of outv.
-#define KZ_SBRT_NZ_STEP(JV, RVAL, WRITE_OUT)                                                   \
-  { const u32 r = (RVAL);                                                                      \
-    const u32 w = (u32)__builtin_amdgcn_readlane((int)ord, (int)(r >> 2));                     \
-    const u32 c = (w >> ((r & 3u) * 8u)) & 0xFFu;                                              \
-    const int cl = (int)(c & 63u), cs = (int)(c >> 6);                                         \
-    const u64 ok = (MODE == 1) ? 0ULL : K[cs];                  /* MTF: always to the front, no keys needed */ \
-    const u32 plo = (MODE == 1) ? 0u : (u32)__builtin_amdgcn_readlane((int)(u32)ok, cl);       \
-    const u32 pc = max(plo, 256u) - 256u;                                                      \
-    const u32 iv = (u32)(row + (JV));                                                          \
-    const u32 nhi = (MODE == 2) ? ((iv + pc) >> 1) : ((MODE == 1) ? iv : pc);                  \
-    const u32 nlo = iv + 256u;                                                                 \
-    const u64 nk = ((u64)nhi << 32) | (u64)nlo;                                                \
-    /* new position = number of keys above the new key.  The new key's low half (iv + 256) exceeds every existing \
-       one, so key > nk <=> q > nhi: 32-bit compares of the high halves (never-seen symbols have q = 0) */ \
-    const u32 rp = (MODE == 1) ? 0u :                                                          \
-                   (u32)(__builtin_popcountll(kz_ballot((u32)(K[0] >> 32) > nhi)) + __builtin_popcountll(kz_ballot((u32)(K[1] >> 32) > nhi)) + \
-                         __builtin_popcountll(kz_ballot((u32)(K[2] >> 32) > nhi)) + __builtin_popcountll(kz_ballot((u32)(K[3] >> 32) > nhi))); \
-    if (MODE != 1) K[cs] = (lane == cl) ? nk : ok;                                             \
-    /* rotate list positions [rp, r]: (rp, r] take their predecessor, rp takes c */            \
-    const u32 prevw = KZ_DPP_SHR1_Z(ord);                                                      \
-    const int sx = (24 - 8 * (int)r) + v32l, sy = (24 - 8 * (int)rp) + v32l;                   \
-    const u32 lmx = 0x01010101u >> (u32)min(max(sx, 0), 31);     /* 0x01 in bytes at positions <= r  */ \
-    const u32 lmy = 0x01010101u >> (u32)min(max(sy, 0), 31);     /*                          <= rp */ \
-    const u32 sel = 0x07060504u - lmx + lmy;                      /* keep: 4+k (ord byte k) ; shift: 3+k (byte k-1 / prevw byte 3) */ \
-    const u32 res = __builtin_amdgcn_perm(ord, prevw, sel);                                    \
-    const u32 am = (lane == (int)(rp >> 2)) ? (0xFFu << ((rp & 3u) * 8u)) : 0u;                \
-    ord = (am & (c * 0x01010101u)) | (~am & res);                                              \
-    WRITE_OUT                                                                                  \
-    if (rp == 0) { f = c; fplo = nlo; fm |= 1ULL << (JV); } }     /* front changed here: resolved at the end of the row */
-
-// unrolled row position J: skipped when its rank is zero; zeros right before it repair the front key first
-#define KZ_SBRT_STEP_CONST(J)                                                                  \
-  rq0 = rq1; rq1 = (u32)__builtin_amdgcn_readlane((int)cur, (J + 1) & 63);   /* rank of the next position: off the critical chain */ \
-  if ((nz >> J) & 1ULL) {                                                                      \
-    if (J > 0 && !((nz >> (J > 0 ? J - 1 : 0)) & 1ULL)) {                                      \
-      const uint64_t below = nz & ((1ULL << J) - 1ULL);                                        \
-      const int pz = below ? 63 - (int)__builtin_clzll(below) : -1;                            \
-      KZ_SBRT_ZERO_RUN(J - pz - 1, row + J - 1)                                                \
-    }                                                                                          \
-    KZ_SBRT_NZ_STEP(J, rq0, asm volatile("v_writelane_b32 %0, %1, " #J : "+v"(outv) : "s"(c));)  \
-  }
-#define KZ_SBRT_STEP4(A, B, C, D) KZ_SBRT_STEP_CONST(A) KZ_SBRT_STEP_CONST(B) KZ_SBRT_STEP_CONST(C) KZ_SBRT_STEP_CONST(D)
-
-// One wave per block, up to 8 blocks per workgroup: the waves of a workgroup are spread over the 4 SIMDs of one
-// CU (wave w and wave w+4 share a SIMD), so the host can pair an expensive block with a cheap one (order[]).
-template <int MODE>
-__global__ __launch_bounds__(512) void k_sbrt_inverse5(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
-                                                        const int32_t* __restrict__ d_len, const int32_t* __restrict__ order, int wavesPerGroup) {
-  const int b = order[blockIdx.x * wavesPerGroup + (int)(threadIdx.x >> 6)];
-  if (b < 0) return;
-  const int n = d_len[b];
-  const u8* s = src + (int64_t)b * stride;
-  u8* d = dst + (int64_t)b * stride;
-  const int lane = kz_lane();
-  const u32 p0 = 4u * (u32)lane;
-  u32 ord = p0 | ((p0 + 1u) << 8) | ((p0 + 2u) << 16) | ((p0 + 3u) << 24);
-  // 8 elements (4 used) so that the compiler keeps the uniform-index accesses as VGPR-indexed moves
-  kz_u64x8 K = (kz_u64x8)(0ULL);
-  K[0] = (u64)(255 - lane); K[1] = (u64)(191 - lane); K[2] = (u64)(127 - lane); K[3] = (u64)(63 - lane);   // never seen: 255 - s
-  u32 f = 0, fplo = 255u;                      // front symbol and the low half (p + 256) of its key
-  const int v32l = 32 * lane;
-  u32 cur = (lane < n) ? (u32)s[lane] : 0u;
-  for (int row = 0; row < n; row += 64) {
-    const int cnt = min(64, n - row);
-    const int nrow = row + 64;
-    const u32 nxt = (nrow + lane < n) ? (u32)s[nrow + lane] : 0u;  // prefetch the next row
-    uint64_t nz = kz_ballot(cur != 0 && lane < cnt);
-    // non-zero lanes receive their symbol with v_writelane; zero ranks output the front symbol of their time: the
-    // positions where the front changed are collected in the scalar mask fm and resolved once per row
-    u32 outv = 0;
-    uint64_t fm = 0;
-    const u32 f0 = f;
-    const uint64_t nzRow = nz;
-    if (cnt == 64 && __builtin_popcountll(nz) >= 40) {
-      // most ranks of the row are non-zero (poorly compressible data: the blocks that set the kernel's run time):
-      // straight-line code with constant lane numbers, no loop control; zero ranks are skipped with a bit test
-      u32 rq0 = 0, rq1 = (u32)__builtin_amdgcn_readlane((int)cur, 0);
-      KZ_SBRT_STEP4(0, 1, 2, 3) KZ_SBRT_STEP4(4, 5, 6, 7) KZ_SBRT_STEP4(8, 9, 10, 11) KZ_SBRT_STEP4(12, 13, 14, 15)
-      KZ_SBRT_STEP4(16, 17, 18, 19) KZ_SBRT_STEP4(20, 21, 22, 23) KZ_SBRT_STEP4(24, 25, 26, 27) KZ_SBRT_STEP4(28, 29, 30, 31)
-      KZ_SBRT_STEP4(32, 33, 34, 35) KZ_SBRT_STEP4(36, 37, 38, 39) KZ_SBRT_STEP4(40, 41, 42, 43) KZ_SBRT_STEP4(44, 45, 46, 47)
-      KZ_SBRT_STEP4(48, 49, 50, 51) KZ_SBRT_STEP4(52, 53, 54, 55) KZ_SBRT_STEP4(56, 57, 58, 59) KZ_SBRT_STEP4(60, 61, 62, 63)
-      { const int pz = 63 - (int)__builtin_clzll(nz); if (pz < 63) KZ_SBRT_ZERO_RUN(63 - pz, row + 63) }      // trailing zeros
-    } else {
-      int prev = -1;
-      while (nz) {
-        const int j = (int)__builtin_ctzll(nz);
-        nz &= nz - 1;
-        const int zr = j - prev - 1;
-        if (zr > 0) KZ_SBRT_ZERO_RUN(zr, row + j - 1)
-        KZ_SBRT_NZ_STEP(j, (u32)__builtin_amdgcn_readlane((int)cur, j), asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(c), "s"(j) : "m0");)
-        prev = j;
-      }
-      { const int zr = cnt - prev - 1; if (zr > 0) KZ_SBRT_ZERO_RUN(zr, row + cnt - 1) }
-    }
-    {
-      // zero-rank lane l: symbol of the last front change before l (held by that lane), else the front at row start
-      const uint64_t below = fm & kz_lanemask_lt();
-      const int srcLane = below ? 63 - (int)__builtin_clzll(below) : 0;
-      const u32 fv = (u32)__shfl((int)outv, srcLane, 64);
-      if (!((nzRow >> lane) & 1ULL)) outv = below ? fv : f0;
-    }
     if (lane < cnt) d[row + lane] = (u8)outv;
     cur = nxt;
   }
@@ -845,16 +714,11 @@ int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
   const std::vector<int>& launchG = PL.G;
   const std::vector<int>& launchOff = PL.off;
   const int32_t* d_order = PL.d_order;
-  static const bool useV5 = getenv("KZ_SBRT_V5") != nullptr;          // A/B switch while v6 is being measured
-  const int oldCold = getenv("KZ_SBRT_OLDCOLD") ? 8 : 0;
+  const int oldCold = getenv("KZ_SBRT_OLDCOLD") ? 8 : 0;            // A/B: cold rows in the by-position layout
   for (int rr = 0; rr < R; rr++) {
     const int G = launchG[rr];
     const int32_t* ord = d_order + launchOff[rr];
-    if (useV5) {
-      if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse5<2>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
-      else if (mode == 1) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse5<1>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
-      else { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse5<3>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg); }
-    } else if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<2>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio | oldCold); }
+    if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<2>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio | oldCold); }
     else if (mode == 1) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<1>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio | oldCold); }
     else { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<3>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio | oldCold); }
   }
