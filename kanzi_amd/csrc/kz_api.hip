@@ -230,7 +230,14 @@ __global__ void k_copy_bytes(const u8* __restrict__ src, int64_t sstride, u8* __
   const int n = len[b];
   const u8* s = src + (int64_t)b * sstride;
   u8* d = dst + (int64_t)b * dstride + (dstOff ? dstOff[b] : 0);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+  if (((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {            // both 16-byte aligned (uniform per block): 16 bytes per lane
+    const int n16 = n >> 4;
+    for (int i = t; i < n16; i += nt) ((uint4*)d)[i] = ((const uint4*)s)[i];
+    for (int i = (n16 << 4) + t; i < n; i += nt) d[i] = s[i];
+  } else {
+    for (int i = t; i < n; i += nt) d[i] = s[i];
+  }
 }
 
 __device__ __forceinline__ u32 kz_mix32(u32 c, u32 h, u32 v) {        // CompressedOutputStream.java:89-93
