@@ -40,13 +40,15 @@
 extern "C" {
 #endif
 
-#define KZ_ABI_VERSION 2
+#define KZ_ABI_VERSION 3
 
 /* transform ids: K/transform/TransformFactory.java:36-60 */
 enum { KZ_T_NONE = 0, KZ_T_BWT = 1, KZ_T_LZ = 3, KZ_T_ZRLT = 6, KZ_T_MTFT = 7, KZ_T_RANK = 8, KZ_T_TEXT = 10 /* DICT_TYPE */,
        KZ_T_SRT = 13, KZ_T_MM = 15, KZ_T_LZX = 16, KZ_T_UTF = 17, KZ_T_PACK = 18, KZ_T_DNA = 19 };
 /* Global.DataType (K/Global.java:40-80): the per-block context entry "dataType" that MM (FSDCodec.java:78-85,160-168)
-   and LZ/LZX (LZCodec.java:343-352) read and write */
+   and LZ/LZX (LZCodec.java:343-352) read and write.  The KZ_DT_* VALUES ARE THIS LIBRARY'S OWN and are NOT the Java enum's
+   ordinals (Java order: UNDEFINED, TEXT, MULTIMEDIA, EXE, NUMERIC, BASE64, DNA, BIN, UTF8, SMALL_ALPHABET); the value never
+   reaches the stream, and a binding maps by NAME (integration/java/HipByteTransform.java). */
 enum { KZ_DT_UNDEFINED = 0, KZ_DT_DNA = 1, KZ_DT_SMALL_ALPHABET = 2, KZ_DT_TEXT = 3, KZ_DT_MULTIMEDIA = 4, KZ_DT_EXE = 5,
        KZ_DT_NUMERIC = 6, KZ_DT_BASE64 = 7, KZ_DT_BIN = 8, KZ_DT_UTF8 = 9 };
 /* entropy ids: K/entropy/EntropyCodecFactory.java */
@@ -86,12 +88,20 @@ int32_t     kz_ctx_set_skip_blocks(kz_ctx* ctx, int32_t on);
 /* the "blockSize" and "entropy" keys of the context map as the TEXT transform reads them: TextCodec sizes its hash map by the
  * stream's block size (K/transform/TextCodec.java:561-575,1068-1081) and TransformFactory picks TextCodec1 or TextCodec2 by the
  * stream's entropy codec (TransformFactory.java:275-286).  kz_encode_blocks / kz_decode_blocks take the entropy codec from
- * their own argument and the block size from here (default 4 MiB; kz_decode_blocks from its blockSize argument);
- * kz_transform_forward / _inverse take both from here; kz_compress / kz_decompress set them from the stream. */
+ * their own argument; kz_encode_blocks takes the block size from here AS OF THE CALL (kz_submit_encode_blocks: as of the
+ * submit) and refuses a chain with TEXT (-KZ_ERR_MISSING_PARAM) when it was never set, because the decoder is told the block
+ * size explicitly and a silent default would write blocks another block size cannot read; kz_decode_blocks takes it from its
+ * blockSize argument; kz_transform_forward / _inverse take both from here; kz_compress / kz_decompress set them from the
+ * stream.  kz_ctx_set_entropy refuses TPAQX (9): TEXT's extra hash bit under it (TextCodec.java:561-575) is not modelled. */
 int32_t     kz_ctx_set_block_size(kz_ctx* ctx, int32_t blockSize);
 int32_t     kz_ctx_set_entropy(kz_ctx* ctx, uint32_t entropyType);
 int32_t     kz_ctx_set_data_type(kz_ctx* ctx, int32_t dataType);
 int32_t     kz_ctx_get_data_type(kz_ctx* ctx);
+/* One process per GPU, N on one host: pin this process (and the threads it creates later: TEXT / UTF stages, bit assembly,
+ * staging copies) to the CPUs of the GPU's NUMA node (/sys/bus/pci/devices/<bdf>/local_cpulist).  Returns the number of CPUs
+ * in the new mask, 0 if the topology is not visible (nothing changed), <0 on error.  The reference has no equivalent: its
+ * task pool is one JVM on one socket (K/app/BlockCompressor.java:199-206). */
+int32_t     kz_pin_to_device_numa(int32_t deviceId);
 /* HIP stream the context launches on (as void* = hipStream_t) so callers can bracket it with events */
 void*       kz_ctx_stream(kz_ctx* ctx);
 
@@ -161,6 +171,7 @@ int64_t kz_submit_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t en
 int64_t kz_submit_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
                                 const uint8_t* in, int64_t inStride, const int64_t* bitLengths, int32_t nBlocks,
                                 uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind);
+/* kz_wait hands a job's return code out ONCE: a second kz_wait / kz_poll on the same id returns -KZ_ERR_INVALID_PARAM. */
 int32_t kz_wait(kz_ctx* ctx, int64_t job);
 int32_t kz_poll(kz_ctx* ctx, int64_t job);
 

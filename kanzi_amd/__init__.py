@@ -13,10 +13,10 @@ Reference interfaces mirrored (K/ = java/src/main/java/io/github/flanglet/kanzi/
   * ``CompressedOutputStream`` / ``CompressedInputStream`` -> same-named classes (whole .knz stream)
 """
 # The decoder keeps four HIP streams busy side by side; HIP shares 4 hardware queues among all streams of a process unless
-# GPU_MAX_HW_QUEUES says otherwise WHEN THE RUNTIME STARTS (first HIP call, also PyTorch's).  Without it the library measures
-# that its streams share queues and falls back to a three-stream schedule.
-import os as _os
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# GPU_MAX_HW_QUEUES says otherwise WHEN THE RUNTIME STARTS (first HIP call, also PyTorch's).  That is the APPLICATION's setting
+# (bench.py and tests/conftest.py export GPU_MAX_HW_QUEUES=8 before importing torch); neither this binding nor the library
+# touches the process environment.  Without it the library measures that its streams share queues and falls back to a
+# three-stream schedule.
 import ctypes
 import os
 
@@ -72,6 +72,7 @@ def load_library():
         "kz_ctx_destroy": (None, [vp]),
         "kz_last_error": (c.c_char_p, [vp]),
         "kz_ctx_stream": (vp, [vp]),
+        "kz_pin_to_device_numa": (c.c_int32, [c.c_int32]),
         "kz_ctx_set_checksum": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_set_skip_blocks": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_set_block_size": (c.c_int32, [vp, c.c_int32]),
@@ -119,7 +120,7 @@ def load_library():
     return L
 
 
-ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_error", "kz_ctx_stream", "kz_ctx_set_checksum",
+ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_error", "kz_ctx_stream", "kz_pin_to_device_numa", "kz_ctx_set_checksum",
                "kz_ctx_set_data_type", "kz_ctx_get_data_type", "kz_ctx_set_skip_blocks", "kz_ctx_set_block_size", "kz_ctx_set_entropy",
                "kz_transform_forward", "kz_transform_inverse", "kz_transform_max_encoded_len", "kz_host_stage_forward", "kz_host_stage_inverse",
                "kz_entropy_encode", "kz_entropy_decode", "kz_encode_blocks", "kz_decode_blocks",
@@ -653,6 +654,15 @@ def knz_index(data):
         raise KanziError(-nb, "knz_index")
     return {"transform": tt.value, "entropy": et.value, "blockSize": bs.value, "inputSize": isz.value, "checksum": chk.value,
             "blocks": [(int(off[i]), int(bits[i])) for i in range(nb)]}
+
+
+def pin_host_threads_to_gpu(device, world=2):
+    """One process per GPU, `world` of them on one host: keep this process's host threads (TEXT / UTF stages, bit assembly,
+    staging copies) on the CPUs of the GPU's NUMA node.  A single process (world == 1) keeps the whole machine.  Returns the
+    number of CPUs pinned to (0: nothing changed)."""
+    if world <= 1:
+        return 0
+    return max(0, int(load_library().kz_pin_to_device_numa(int(device))))
 
 
 def shard_blocks(n_blocks, world, rank):

@@ -9,6 +9,7 @@
 #include <memory>
 #include <thread>
 #include <chrono>
+#include <sched.h>
 
 typedef uint32_t u32;
 typedef uint8_t u8;
@@ -19,9 +20,9 @@ typedef unsigned long long u64;
 extern "C" int32_t kz_abi_version(void) { return KZ_ABI_VERSION; }
 
 // The decoder's wide schedule keeps four streams busy side by side; HIP's default is four hardware queues for ALL streams of
-// the process.  Asked for before the runtime starts (library load: nothing has called HIP through this library yet; a host
-// that has initialised HIP before loading it sets GPU_MAX_HW_QUEUES itself, or gets the three-stream schedule).
-namespace { struct KzEnvInit { KzEnvInit() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } kzEnvInit; }
+// the process.  The library does NOT touch the process environment: the application exports GPU_MAX_HW_QUEUES=8 before its
+// first HIP call (bench.py, tests/conftest.py and the Python binding do; a JVM is started with it in its environment,
+// INTEGRATION.md 3) or gets the measured three-stream fallback (overlap_streams).
 extern "C" kz_ctx* kz_ctx_create(int32_t deviceId) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return nullptr;   // fail loudly: no CPU fallback
@@ -70,14 +71,49 @@ extern "C" int32_t kz_ctx_set_data_type(kz_ctx* ctx, int32_t dataType) {
 extern "C" int32_t kz_ctx_set_block_size(kz_ctx* ctx, int32_t blockSize) {
   if (!ctx || blockSize < 1024 || blockSize > (1 << 30) || (blockSize & 15)) return -KZ_ERR_BLOCK_SIZE;   // CompressedOutputStream.java:165-174
   ctx->blockSize = blockSize;
+  ctx->blockSizeSet = true;
   return 0;
 }
 extern "C" int32_t kz_ctx_set_entropy(kz_ctx* ctx, uint32_t entropyType) {
-  if (!ctx || entropyType > 9 || entropyType == 3) return -KZ_ERR_INVALID_CODEC;
+  // TPAQX (9) is refused: the reference gives TEXT one more hash bit under it (TextCodec.java:561-575 extraPerf), which the host
+  // stage does not model, and no entropy coder in scope is TPAQX
+  if (!ctx || entropyType >= 9 || entropyType == 3) return -KZ_ERR_INVALID_CODEC;
   ctx->entropy = (int)entropyType;
   return 0;
 }
 extern "C" int32_t kz_ctx_get_data_type(kz_ctx* ctx) { return ctx ? ctx->dataType : -KZ_ERR_INVALID_PARAM; }
+// N ranks on one host (one process per GPU): keep the process's host threads (TEXT / UTF stages, bit assembly, staging copies)
+// on the CPUs next to its GPU.  Reads /sys/bus/pci/devices/<bdf>/local_cpulist; returns the number of CPUs pinned to, 0 when
+// the topology is not visible (nothing changed), <0 on error.  Threads created afterwards inherit the mask.
+extern "C" int32_t kz_pin_to_device_numa(int32_t deviceId) {
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), deviceId) != hipSuccess) return -KZ_ERR_DEVICE;
+  for (char* p = bdf; *p; p++) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+  FILE* f = fopen(path, "r");
+  if (!f) return 0;
+  char line[4096] = {0};
+  const bool got = fgets(line, sizeof(line), f) != nullptr;
+  fclose(f);
+  if (!got) return 0;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  int count = 0;
+  for (char* p = line; *p;) {                                       // "0-31,64-95"
+    char* e = nullptr;
+    const long a = strtol(p, &e, 10);
+    if (e == p) break;
+    long b = a;
+    p = e;
+    if (*p == '-') { b = strtol(p + 1, &e, 10); p = e; }
+    for (long c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET((int)c, &set); count++; }
+    if (*p == ',') p++;
+  }
+  if (count == 0) return 0;
+  if (sched_setaffinity(0, sizeof(set), &set) != 0) return 0;
+  return count;
+}
 extern "C" const char* kz_last_error(kz_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 extern "C" void* kz_ctx_stream(kz_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
@@ -93,8 +129,19 @@ int kz_hpin_reserve(kz_ctx* ctx, size_t ints) {
   return 0;
 }
 
-void kz_parallel_for(int n, int maxThreads, void (*fn)(int, void*), void* arg) {
+// host threads of the TEXT / UTF stages: the reference's job limit (BlockCompressor.java:199-203: at most 64); every thread keeps
+// its own dictionary and UTF alias map (tens of MiB)
+#define KZ_HOST_STAGE_THREADS 64
+// the CPUs this process may run on (N ranks on one host are pinned to their GPU's NUMA node: kz_pin_to_device_numa)
+static int kz_usable_cpus() {
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) return c; }
   const int hw = (int)std::thread::hardware_concurrency();
+  return hw > 0 ? hw : 1;
+}
+void kz_parallel_for(int n, int maxThreads, void (*fn)(int, void*), void* arg) {
+  const int hw = kz_usable_cpus();
   const int T = std::max(1, std::min(std::min(n, maxThreads), hw > 0 ? hw : 1));
   if (T == 1) { for (int i = 0; i < n; i++) fn(i, arg); return; }
   std::atomic<int> next(0);
@@ -502,7 +549,7 @@ static int host_prefix(kz_ctx* ctx, const int* types, int nb) {          // numb
   return hp;
 }
 struct HostFwd {
-  kz_ctx* ctx; const int* types; int hp; int entropy; int cap;
+  kz_ctx* ctx; const int* types; int hp; int entropy; int cap; int blockSize;
   const uint8_t* hsrc; int64_t hstride;             // the blocks in host memory
   uint8_t* dbuf; int64_t dstride;                   // their slots in HBM
   const int32_t* lengths; const int32_t* copy;
@@ -522,7 +569,7 @@ static void host_forward_block(int b, void* arg) {
   uint8_t* out = bufA.data();
   for (int i = 0; i < H.hp; i++) {
     int produced = 0;
-    if (!kz_host_transform_forward(H.types[i], H.entropy, H.ctx->blockSize, &dt, cur, len, out, H.cap, &produced)) continue;   // declined: data untouched
+    if (!kz_host_transform_forward(H.types[i], H.entropy, H.blockSize, &dt, cur, len, out, H.cap, &produced)) continue;   // declined: data untouched
     H.skip[b] &= ~(1 << (7 - i));
     cur = out; len = produced;
     out = (out == bufA.data()) ? bufB.data() : bufA.data();
@@ -801,9 +848,11 @@ static int overlapped_rank_bwt_inverse(kz_ctx* ctx, Pipe& P, int mode, const std
 
 // =================================================================================================
 // encode
-extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType,
-                                    const uint8_t* in, int64_t inStride, const int32_t* lengths, int32_t nBlocks,
-                                    uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind) {
+// blockSize = the stream's "blockSize" entry as TEXT reads it, fixed when the call was made (a queued job keeps the value of its
+// submit time: later kz_ctx_set_block_size calls or kz_compress's scope do not reach it)
+static int32_t encode_blocks_bs(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
+                                const uint8_t* in, int64_t inStride, const int32_t* lengths, int32_t nBlocks,
+                                uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind) {
   if (!ctx) return -KZ_ERR_INVALID_PARAM;
   if (nBlocks <= 0) return 0;
   KZ_HIP(hipSetDevice(ctx->device));
@@ -838,7 +887,7 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     if (B > maxB) {
       for (int b0 = 0; b0 < B; b0 += maxB) {
         const int cnt = std::min(maxB, B - b0);
-        int rc = kz_encode_blocks(ctx, transformType, entropyType, in + (int64_t)b0 * inStride, inStride, lengths + b0, cnt,
+        int rc = encode_blocks_bs(ctx, transformType, entropyType, blockSize, in + (int64_t)b0 * inStride, inStride, lengths + b0, cnt,
                                   out + (int64_t)b0 * outStride, outStride, results + b0, memKind);
         if (rc) return rc;
       }
@@ -911,10 +960,10 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     KZ_HIP(hipStreamSynchronize(st));                                            // the blocks are in HBM, hashed and tagged: slots may be rewritten
     std::vector<int32_t> h_dt(B), h_out(B);
     HostFwd H;
-    H.ctx = ctx; H.types = types; H.hp = hp; H.entropy = (int)entropyType; H.cap = maxLen;
+    H.ctx = ctx; H.types = types; H.hp = hp; H.entropy = (int)entropyType; H.cap = maxLen; H.blockSize = blockSize;
     H.hsrc = hsrc; H.hstride = hstride; H.dbuf = bt.buf[0]; H.dstride = bt.stride;
     H.lengths = lengths; H.copy = h_copy.data(); H.outLen = h_out.data(); H.skip = h_skip.data(); H.dtype = h_dt.data();
-    kz_parallel_for(B, 256, host_forward_block, &H);
+    kz_parallel_for(B, KZ_HOST_STAGE_THREADS, host_forward_block, &H);
     if (H.fail) { snprintf(ctx->err, sizeof(ctx->err), "host stage: copy to the device failed"); return -KZ_ERR_DEVICE; }
     for (int b = 0; b < B; b++) bt.h_len[b] = h_out[b];
     KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
@@ -1003,6 +1052,28 @@ extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   return 0;
 }
 
+// TEXT sizes its hash map by the stream's block size and the decoder is told that size explicitly: an encoder that silently
+// used the context's default would write blocks a decoder of another block size cannot read.  Chains with TEXT therefore need
+// kz_ctx_set_block_size first (kz_compress and the Python / Java bindings do it).
+static int32_t encode_block_size(kz_ctx* ctx, uint64_t transformType) {
+  if (!ctx) return -KZ_ERR_INVALID_PARAM;
+  int types[8];
+  const int nb = split_types(transformType, types);
+  for (int i = 0; i < nb; i++)
+    if (types[i] == KZ_T_TEXT && !ctx->blockSizeSet) {
+      snprintf(ctx->err, sizeof(ctx->err), "chains with TEXT need the stream's block size: call kz_ctx_set_block_size first");
+      return -KZ_ERR_MISSING_PARAM;
+    }
+  return ctx->blockSize;
+}
+extern "C" int32_t kz_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType,
+                                    const uint8_t* in, int64_t inStride, const int32_t* lengths, int32_t nBlocks,
+                                    uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind) {
+  const int32_t bsz = encode_block_size(ctx, transformType);
+  if (bsz < 0) return bsz;
+  return encode_blocks_bs(ctx, transformType, entropyType, bsz, in, inStride, lengths, nBlocks, out, outStride, results, memKind);
+}
+
 // =================================================================================================
 // decode
 struct FrameDec {
@@ -1065,9 +1136,9 @@ __global__ void k_copy_payload(const u8* __restrict__ in, int64_t inStride, u8* 
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
 }
 
-extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
-                                    const uint8_t* in, int64_t inStride, const int64_t* bitLengths, int32_t nBlocks,
-                                    uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind) {
+static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
+                                  const uint8_t* in, int64_t inStride, const int64_t* bitLengths, int32_t nBlocks,
+                                  uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind) {
   if (!ctx) return -KZ_ERR_INVALID_PARAM;
   if (nBlocks <= 0) return 0;
   KZ_HIP(hipSetDevice(ctx->device));
@@ -1098,8 +1169,8 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     if (B > maxB) {
       for (int b0 = 0; b0 < B; b0 += maxB) {
         const int cnt = std::min(maxB, B - b0);
-        int rc = kz_decode_blocks(ctx, transformType, entropyType, blockSize, in + (int64_t)b0 * inStride, inStride, bitLengths + b0, cnt,
-                                  out + (int64_t)b0 * outStride, outStride, results + b0, memKind);
+        int rc = decode_blocks_impl(ctx, transformType, entropyType, blockSize, in + (int64_t)b0 * inStride, inStride, bitLengths + b0, cnt,
+                                    out + (int64_t)b0 * outStride, outStride, results + b0, memKind);
         if (rc) return rc;
       }
       return 0;
@@ -1287,7 +1358,7 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     HostInv H;
     H.ctx = ctx; H.types = types; H.hp = hp; H.blockSize = blockSize; H.cap = dataCap;
     H.dbuf = bt.buf[bt.cur]; H.dstride = bt.stride; H.len = bt.h_len.data(); H.skip = h_skip.data(); H.status = h_status.data();
-    kz_parallel_for(B, 256, host_inverse_block, &H);
+    kz_parallel_for(B, KZ_HOST_STAGE_THREADS, host_inverse_block, &H);
     if (H.fail) { snprintf(ctx->err, sizeof(ctx->err), "host stage: copy from / to the device failed"); return -KZ_ERR_DEVICE; }
     KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     KZ_HIP(hipStreamSynchronize(st));
@@ -1322,6 +1393,19 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   return 0;
 }
 
+extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
+                                    const uint8_t* in, int64_t inStride, const int64_t* bitLengths, int32_t nBlocks,
+                                    uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind) {
+  const int32_t rc = decode_blocks_impl(ctx, transformType, entropyType, blockSize, in, inStride, bitLengths, nBlocks, out, outStride, results, memKind);
+  if (rc && ctx) {
+    // an error exit may leave kernels of the overlapped schedule running on the side streams: the next call reuses (or
+    // frees) the arena they work in
+    for (int i = 0; i < 5; i++) if (ctx->side[i]) hipStreamSynchronize(ctx->side[i]);
+    hipStreamSynchronize(ctx->stream);
+  }
+  return rc;
+}
+
 // =================================================================================================
 // asynchronous batches: kz_submit_encode_blocks / kz_submit_decode_blocks queue the same call on the context's worker thread
 // and return at once; kz_wait collects the call's return code.  A context runs its jobs one at a time in submission order
@@ -1354,8 +1438,9 @@ static int64_t ctx_submit(kz_ctx* ctx, std::function<int32_t()> fn) {
 extern "C" int64_t kz_submit_encode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType,
                                            const uint8_t* in, int64_t inStride, const int32_t* lengths, int32_t nBlocks,
                                            uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind) {
-  if (!ctx) return -KZ_ERR_INVALID_PARAM;
-  return ctx_submit(ctx, [=]() { return kz_encode_blocks(ctx, transformType, entropyType, in, inStride, lengths, nBlocks, out, outStride, results, memKind); });
+  const int32_t bsz = encode_block_size(ctx, transformType);      // the context's "blockSize" entry NOW, not when the job runs
+  if (bsz < 0) return bsz;
+  return ctx_submit(ctx, [=]() { return encode_blocks_bs(ctx, transformType, entropyType, bsz, in, inStride, lengths, nBlocks, out, outStride, results, memKind); });
 }
 extern "C" int64_t kz_submit_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
                                            const uint8_t* in, int64_t inStride, const int64_t* bitLengths, int32_t nBlocks,
@@ -1367,15 +1452,19 @@ extern "C" int32_t kz_wait(kz_ctx* ctx, int64_t job) {
   if (!ctx || job <= 0) return -KZ_ERR_INVALID_PARAM;
   std::unique_lock<std::mutex> lk(ctx->qmu);
   if (job >= ctx->nextJob) return -KZ_ERR_INVALID_PARAM;
+  if (job < ctx->collectedBelow || ctx->collected.count(job)) return -KZ_ERR_INVALID_PARAM;   // a job's result is handed out once
   ctx->qcv.wait(lk, [&] { return ctx->finished.count(job) != 0; });
   const int32_t rc = ctx->finished[job];
   ctx->finished.erase(job);
+  ctx->collected.insert(job);
+  while (ctx->collected.count(ctx->collectedBelow)) { ctx->collected.erase(ctx->collectedBelow); ctx->collectedBelow++; }
   return rc;
 }
 extern "C" int32_t kz_poll(kz_ctx* ctx, int64_t job) {            // 1 = finished (kz_wait will not block), 0 = queued or running
   if (!ctx || job <= 0) return -KZ_ERR_INVALID_PARAM;
   std::lock_guard<std::mutex> g(ctx->qmu);
   if (job >= ctx->nextJob) return -KZ_ERR_INVALID_PARAM;
+  if (job < ctx->collectedBelow || ctx->collected.count(job)) return -KZ_ERR_INVALID_PARAM;
   return ctx->finished.count(job) ? 1 : 0;
 }
 

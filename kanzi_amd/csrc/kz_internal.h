@@ -9,6 +9,7 @@
 #include <deque>
 #include <functional>
 #include <map>
+#include <set>
 #include <mutex>
 #include <thread>
 #include "../../include/kanzi_hip.h"
@@ -38,6 +39,7 @@ struct kz_ctx {
   int skipBlocks = 0;            // ctx map key "skipBlocks": store incompressible-looking blocks as copy blocks
   int dataType = 0;              // ctx map key "dataType" for the single-block calls (Global.DataType, KZ_DT_*)
   int blockSize = 4 * 1024 * 1024;   // ctx map key "blockSize" (TEXT sizes its hash map by it)
+  bool blockSizeSet = false;     // kz_ctx_set_block_size was called: chains with TEXT refuse to guess
   int entropy = KZ_E_NONE;       // ctx map key "entropy" for the single-block calls (TEXT: TextCodec1 / TextCodec2)
   int numCUs = 256;              // compute units of the device (placement of the serial-per-block kernels)
   long long* d_endBits = nullptr; // optional [B] device array: bit position behind each block's entropy payload (kz_entropy_decode)
@@ -55,6 +57,8 @@ struct kz_ctx {
   std::condition_variable qcv;
   std::deque<std::pair<int64_t, std::function<int32_t()>>> queue;
   std::map<int64_t, int32_t> finished;
+  std::set<int64_t> collected;   // ids kz_wait has handed out (>= collectedBelow; everything below is collected too)
+  int64_t collectedBelow = 1;
   int64_t nextJob = 1;
   bool stopWorker = false;
 };

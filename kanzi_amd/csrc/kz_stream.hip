@@ -263,9 +263,9 @@ extern "C" int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t ent
   std::vector<int32_t> lens(NB);
   std::vector<kz_block_result> res(NB);
   struct BlockSizeScope {                                          // the context's "blockSize" entry = this stream's (TEXT reads it)
-    kz_ctx* c; int saved;
-    BlockSizeScope(kz_ctx* c_, int v) : c(c_), saved(c_->blockSize) { c->blockSize = v; }
-    ~BlockSizeScope() { c->blockSize = saved; }
+    kz_ctx* c; int saved; bool savedSet;
+    BlockSizeScope(kz_ctx* c_, int v) : c(c_), saved(c_->blockSize), savedSet(c_->blockSizeSet) { c->blockSize = v; c->blockSizeSet = true; }
+    ~BlockSizeScope() { c->blockSize = saved; c->blockSizeSet = savedSet; }
   } scope(ctx, blockSize);
   for (int64_t b0 = 0; b0 < nblocks; b0 += NB) {
     const int cnt = (int)std::min<int64_t>(NB, nblocks - b0);

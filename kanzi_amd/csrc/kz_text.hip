@@ -496,9 +496,12 @@ int utf_forward(int* dataType, const u8* src, int n, u8* dst, int dstCap, int* p
   else while (start < 4 && utf8_lead_ok(src[start]) == 0) start++;
   if (mustValidate && !utf_validate(src, start, body - start)) return 0;
   if (dataType) *dataType = KZ_DT_UTF8;
-  std::vector<int32_t> seen((size_t)1 << 22, 0);   // occurrences per key, later the alias per key
+  // occurrences per key, later the alias per key: 16 MiB, kept per host thread and cleaned by key (a block touches < 32768 keys)
+  static thread_local std::vector<int32_t> seen;
+  if (seen.empty()) seen.assign((size_t)1 << 22, 0);
   struct Sym { int32_t key, freq; };
   std::vector<Sym> syms;
+  struct Clean { std::vector<int32_t>& t; std::vector<Sym>& s; ~Clean() { for (const Sym& x : s) t[x.key] = 0; } } clean_{seen, syms};
   bool ok = true;
   for (int i = start; i < body;) {
     u32 key;
@@ -622,6 +625,8 @@ extern "C" int32_t kz_host_stage_forward(uint32_t type, uint32_t entropyType, in
                                          const uint8_t* src, int32_t n, uint8_t* dst, int32_t dstCap, int32_t* produced) {
   if (!src || !dst || !produced || n < 0) return -KZ_ERR_INVALID_PARAM;
   if (!kz_is_host_transform((int)type)) return -KZ_ERR_INVALID_CODEC;
+  // TPAQX (9): the reference gives TEXT one more hash bit under it (TextCodec.java extraPerf); not modelled, so refused
+  if (entropyType >= 9 || entropyType == 3) return -KZ_ERR_INVALID_CODEC;
   *produced = 0;
   if (dstCap < kz_transform_max_encoded_len(type, n)) return 0;
   int dt = dataType ? *dataType : KZ_DT_UNDEFINED;

@@ -404,3 +404,571 @@ def lz_decode(src, out_cap):
             dst.append(dst[ref + i])
     return bytes(dst) if pos == tk_len else None
 
+
+
+# =====================================================================================================================
+# Round 3: models of the stages whose OUTPUT IS A CHOICE (any valid parse / order round-trips), written from the Java lines
+# cited, not from oracle/*.c.  They run on inputs of up to a few hundred KiB.
+
+class JavaException(Exception):
+    """the reference would throw here (ArrayIndexOutOfBoundsException): the block fails with ERR_PROCESS_BLOCK"""
+
+
+def _emit_length(buf, idx, length):                                           # LZCodec.java:211-231
+    if length < 254:
+        buf[idx] = length
+        return idx + 1
+    if length < 65536 + 254:
+        length -= 254
+        buf[idx] = 254
+        buf[idx + 1] = (length >> 8) & 0xFF
+        buf[idx + 2] = length & 0xFF
+        return idx + 3
+    length -= 255
+    buf[idx] = 255
+    buf[idx + 1] = (length >> 16) & 0xFF
+    buf[idx + 2] = (length >> 8) & 0xFF
+    buf[idx + 3] = length & 0xFF
+    return idx + 4
+
+
+class _JavaBytes(list):
+    """byte[] of fixed length: an index past the end throws, like Java"""
+
+    def __setitem__(self, i, v):
+        if not 0 <= i < len(self):
+            raise JavaException("ArrayIndexOutOfBounds %d / %d" % (i, len(self)))
+        list.__setitem__(self, i, v & 0xFF)
+
+
+def lz_forward(data, extra=False, data_type="UNDEFINED"):
+    """K/transform/LZCodec.java LZXCodec.forward :299-597 (LZ: extra = false, 2^16 hash entries; LZX: extra = true, 2^19 entries and the
+    second lazy probe), hash :904-911, findMatch :271-287, emitLength :211-231, differentInts :134-137.  data_type = the context's
+    "dataType" entry (:343-352).  Returns (applied, bytes); raises JavaException where the reference's fixed tkBuf / mLenBuf overflow."""
+    src = bytes(data)
+    count = len(src)
+    if count == 0:
+        return True, b""
+    max_enc = (count + 16 if count <= 1024 else count + count // 64) + 2          # getMaxEncodedLength :961-964 (the caller provides it)
+    if count < 24:                                                                # MIN_BLOCK_LENGTH :312
+        return False, b""
+    SEED, MAXD1, MAXD2, MAX_MATCH = 0x1E35A7BD, (1 << 16) - 2, (1 << 24) - 2, 65535 + 254 + 4
+    log = 19 if extra else 16
+    hashes = [0] * (1 << log)
+    min_buf = max(count // 5, 256)                                                # :325
+    mbuf, mlenbuf, tkbuf = _JavaBytes([0] * min_buf), _JavaBytes([0] * min_buf), _JavaBytes([0] * min_buf)
+    dst = _JavaBytes([0] * (max_enc + 16))
+    pad = src + bytes(16)
+
+    def h(i):                                                                     # :904-911: (long << 24) * seed >>> (64 - log)
+        v = int.from_bytes(pad[i:i + 8], "little")
+        return ((((v << 24) & M64) * SEED) & M64) >> (64 - log)
+
+    def differ(a, b):
+        return src[a:a + 4] != src[b:b + 4]
+
+    def find_match(s, r, max_match):                                              # :271-287 (8 bytes at a time, stops below max_match - 7)
+        best = 0
+        while best + 8 <= max_match:
+            x = int.from_bytes(pad[s + best:s + best + 8], "little") ^ int.from_bytes(pad[r + best:r + best + 8], "little")
+            if x:
+                best += ((x & -x).bit_length() - 1) >> 3
+                break
+            best += 8
+        return best
+
+    src_end = count - 16 - 2
+    max_dist = MAXD1 if src_end < 4 * MAXD1 else MAXD2
+    dst[12] = 0 if max_dist == MAXD1 else 1
+    mm = 4
+    if data_type == "DNA":
+        mm = 6
+    elif data_type == "SMALL_ALPHABET":
+        return False, b""
+    dst[12] = dst[12] | (((mm - 2) & 7) << 1)
+    src_idx = anchor = 0
+    dst_idx = 13
+    m_idx = mlen_idx = tk_idx = 0
+    repd = [count, count]
+    rep_idx = 0
+    src_inc = 0
+    while src_idx < src_end:
+        best = 0
+        h0 = h(src_idx)
+        ref0 = hashes[h0]
+        hashes[h0] = src_idx
+        s1 = src_idx + 1
+        ref = s1 - repd[rep_idx]
+        min_ref = max(src_idx - max_dist, 0)
+        if ref > min_ref and not differ(ref, s1):                                # repd first :378-387
+            best = find_match(s1, ref, min(src_end - s1, MAX_MATCH))
+        else:
+            ref = s1 - repd[rep_idx ^ 1]
+            if ref > min_ref and not differ(ref, s1):
+                best = find_match(s1, ref, min(src_end - s1, MAX_MATCH))
+        if best < mm:
+            ref = ref0                                                            # :391-395
+            if ref > min_ref and not differ(ref, src_idx):
+                best = find_match(src_idx, ref, min(src_end - src_idx, MAX_MATCH))
+            if best < mm:                                                         # :398-403
+                src_idx = s1 + (src_inc >> 6)
+                src_inc += 1
+                rep_idx = 0
+                continue
+            if ref != src_idx - repd[0] and ref != src_idx - repd[1]:             # :405-443 lazy probes
+                h1 = h(s1)
+                ref1 = hashes[h1]
+                hashes[h1] = s1
+                if ref1 > min_ref + 1 and not differ(ref1 + best - 3, s1 + best - 3):
+                    b1 = find_match(s1, ref1, min(src_end - s1, MAX_MATCH))
+                    if b1 >= best:
+                        ref, best, src_idx = ref1, b1, s1
+                if extra:
+                    s2 = s1 + 1
+                    h2 = h(s2)
+                    ref2 = hashes[h2]
+                    hashes[h2] = s2
+                    if ref2 > min_ref + 2 and not differ(ref2 + best - 3, s2 + best - 3):
+                        b2 = find_match(s2, ref2, min(src_end - s2, MAX_MATCH))
+                        if b2 >= best:
+                            ref, best, src_idx = ref2, b2, s2
+            while src_idx > anchor and ref > min_ref and src[src_idx - 1] == src[ref - 1]:   # :446-450 extend backwards
+                best += 1
+                ref -= 1
+                src_idx -= 1
+            if best > MAX_MATCH:                                                  # :452-456
+                ref += best - MAX_MATCH
+                src_idx += best - MAX_MATCH
+                best = MAX_MATCH
+        else:                                                                     # :457-466 repeat match found at srcIdx + 1
+            if best >= MAX_MATCH or src[src_idx] != src[ref - 1]:
+                src_idx += 1
+                hashes[h(src_idx)] = src_idx
+            else:
+                best += 1
+                ref -= 1
+        src_inc = 0
+        dist = src_idx - ref
+        if dist == repd[0]:
+            token, th = 0x00, 3
+        elif dist == repd[1]:
+            token, th = 0x04, 3
+        else:                                                                     # :492-500
+            mbuf[m_idx] = dist >> 16
+            inc1 = 1 if dist >= 65536 else 0
+            m_idx += inc1
+            mbuf[m_idx] = dist >> 8
+            inc2 = 1 if dist >= 256 else 0
+            m_idx += inc2
+            mbuf[m_idx] = dist
+            m_idx += 1
+            token, th = (inc1 + inc2 + 1) << 3, 7
+        mlen = best - mm
+        if mlen >= th:
+            token += th
+            mlen_idx = _emit_length(mlenbuf, mlen_idx, mlen - th)
+        else:
+            token += mlen
+        repd[1] = repd[0]
+        repd[0] = dist
+        rep_idx = 1
+        lit = src_idx - anchor
+        if lit == 0:
+            tkbuf[tk_idx] = token
+            tk_idx += 1
+        else:
+            if lit >= 7:
+                if lit >= 1 << 24:
+                    return False, b""
+                tkbuf[tk_idx] = (7 << 5) | token
+                tk_idx += 1
+                dst_idx = _emit_length(dst, dst_idx, lit - 7)
+            else:
+                tkbuf[tk_idx] = (lit << 5) | token
+                tk_idx += 1
+            for k in range(lit):
+                dst[dst_idx + k] = src[anchor + k]
+            dst_idx += lit
+        if m_idx >= len(mbuf) - 8:                                                # :538-549 (tkBuf is never grown)
+            mbuf.extend([0] * ((len(mbuf) * 3) // 2 - len(mbuf)))
+            if mlen_idx >= len(mlenbuf) - 4:
+                mlenbuf.extend([0] * ((len(mlenbuf) * 3) // 2 - len(mlenbuf)))
+        anchor = src_idx + best                                                   # :552-564 hash fill
+        while src_idx + 4 < anchor:
+            src_idx += 4
+            for k in (3, 2, 1, 0):
+                hashes[h(src_idx - k)] = src_idx - k
+        src_idx += 1
+        while src_idx < anchor:
+            hashes[h(src_idx)] = src_idx
+            src_idx += 1
+    lit = count - anchor                                                          # :567-596
+    if dst_idx + lit + tk_idx + m_idx + mlen_idx >= count:
+        return False, b""
+    if lit >= 7:
+        tkbuf[tk_idx] = 7 << 5
+        tk_idx += 1
+        dst_idx = _emit_length(dst, dst_idx, lit - 7)
+    else:
+        tkbuf[tk_idx] = lit << 5
+        tk_idx += 1
+    for k in range(lit):
+        dst[dst_idx + k] = src[anchor + k]
+    dst_idx += lit
+    out = bytearray(dst[:dst_idx])
+    out[0:4] = dst_idx.to_bytes(4, "little")
+    out[4:8] = tk_idx.to_bytes(4, "little")
+    out[8:12] = m_idx.to_bytes(4, "little")
+    out += bytes(tkbuf[:tk_idx]) + bytes(mbuf[:m_idx]) + bytes(mlenbuf[:mlen_idx])
+    return len(out) <= count - count // 100, bytes(out)
+
+
+def srt_forward(data):
+    """K/transform/SRT.java forward :73-168, preprocess :266-302 (shell sort by (freq desc, symbol asc)), encodeHeader :312-325."""
+    src = bytes(data)
+    count = len(src)
+    freqs, r2s, s2r = [0] * 256, [0] * 256, [0] * 256
+    i = b = 0
+    while i < count:                                                              # :100-117 first appearances and run-wise counts
+        c = src[i]
+        if freqs[c] == 0:
+            r2s[b] = c
+            s2r[c] = b
+            b += 1
+        j = i + 1
+        while j < count and src[j] == c:
+            j += 1
+        freqs[c] += j - i
+        i = j
+    symbols = [s for s in range(256) if freqs[s] > 0]                             # preprocess
+    nb = len(symbols)
+    hgap = 4
+    while hgap < nb:
+        hgap = hgap * 3 + 1
+    while True:
+        hgap //= 3
+        for i in range(hgap, nb):
+            t = symbols[i]
+            bb = i - hgap
+            while bb >= 0 and (freqs[symbols[bb]] < freqs[t] or (freqs[t] == freqs[symbols[bb]] and t < symbols[bb])):
+                symbols[bb + hgap] = symbols[bb]
+                bb -= hgap
+            symbols[bb + hgap] = t
+        if hgap == 1:
+            break
+    buckets = [0] * 256
+    pos = 0
+    for s in symbols:
+        buckets[s] = pos
+        pos += freqs[s]
+    header = bytearray()
+    for f in freqs:                                                               # encodeHeader
+        while f >= 128:
+            header.append(0x80 | (f & 0x7F))
+            f >>= 7
+        header.append(f)
+    out = bytearray(count)
+    i = 0
+    while i < count:                                                              # :133-163
+        c = src[i]
+        r = s2r[c]
+        p = buckets[c]
+        out[p] = r
+        p += 1
+        if r != 0:
+            while r != 0:
+                r2s[r] = r2s[r - 1]
+                s2r[r2s[r]] = r
+                r -= 1
+            r2s[0] = c
+            s2r[c] = 0
+        i += 1
+        while i < count and src[i] == c:
+            out[p] = 0
+            p += 1
+            i += 1
+        buckets[c] = p
+    return bytes(header) + bytes(out)
+
+
+def sbrt_forward(data, mode):
+    """K/transform/SBRT.java forward :87-151; mode 1 = MTF, 2 = RANK, 3 = TIMESTAMP (:36-38): m1 masks the index, m2 the previous
+    occurrence, RANK halves their sum."""
+    src = bytes(data)
+    m1 = 0 if mode == 3 else -1
+    m2 = 0 if mode == 1 else -1
+    s = 1 if mode == 2 else 0
+    p, q = [0] * 256, [0] * 256
+    s2r, r2s = list(range(256)), list(range(256))
+    out = bytearray(len(src))
+    for i, c in enumerate(src):
+        r = s2r[c]
+        out[i] = r
+        qc = ((i & m1) + (p[c] & m2)) >> s
+        p[c] = i
+        q[c] = qc
+        while r > 0 and q[r2s[r - 1]] <= qc:
+            r2s[r] = r2s[r - 1]
+            s2r[r2s[r]] = r
+            r -= 1
+        r2s[r] = c
+        s2r[c] = r
+    return bytes(out)
+
+
+_DNA, _NUMERIC = b"acgntuACGNTU", b"0123456789+-*/=,.:; "
+_BASE64 = b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/"
+
+
+def detect_simple_type(count, freqs0):
+    """K/Global.java detectSimpleType :556-605"""
+    if count == 0:
+        return "UNDEFINED"
+    if sum(freqs0[c] for c in _DNA) > count - count // 12:
+        return "DNA"
+    if sum(freqs0[c] for c in _NUMERIC) == count:
+        return "NUMERIC"
+    if (1 if freqs0[0x3D] == 1 else 0) + sum(freqs0[c] for c in _BASE64) == count:
+        return "BASE64"
+    present = sum(1 for f in freqs0 if f > 0)
+    if present == 256:
+        return "BIN"
+    if present <= 4:
+        return "SMALL_ALPHABET"
+    return "UNDEFINED"
+
+
+def alias_forward(data, data_type="UNDEFINED", only_dna=False):
+    """K/transform/AliasCodec.java forward :78-278 with a context (so the detected type is stored back); Alias.compareTo :476-489
+    (TreeSet order: frequency descending, then value descending); Global.computeHistogramOrder1 :341-420 as called here (its first
+    lane starts from prv = 0: the pair (0, src[0]) is counted too).  Returns (applied, bytes, dataType left in the context)."""
+    src = bytes(data)
+    count = len(src)
+    if count == 0:
+        return True, b"", data_type
+    if count < 1024:
+        return False, b"", data_type
+    dt = data_type
+    if dt in ("MULTIMEDIA", "UTF8", "EXE", "BIN"):
+        return False, b"", dt
+    if only_dna and dt not in ("UNDEFINED", "DNA"):
+        return False, b"", dt
+    freqs0 = [0] * 256
+    for c in src:
+        freqs0[c] += 1
+    absent = [i for i in range(256) if freqs0[i] == 0]
+    n0 = len(absent)
+    if n0 < 16:
+        return False, b"", dt
+    left = data_type
+    if dt == "UNDEFINED":
+        dt = detect_simple_type(count, freqs0)
+        if dt != "UNDEFINED":
+            left = dt
+        if dt != "DNA" and only_dna:
+            return False, b"", left
+    out = bytearray()
+    si = 0
+    if n0 >= 240:
+        out.append(n0)
+        if n0 == 255:
+            out.append(src[0])
+            out += count.to_bytes(4, "little")
+            si = count
+        else:
+            map8 = {}
+            for i in range(256):
+                if freqs0[i]:
+                    out.append(i)
+                    map8[i] = len(map8)
+            if n0 >= 252:
+                out.append(count & 3)
+                for _ in range(count & 3):
+                    out.append(src[si])
+                    si += 1
+                while si < count:
+                    out.append((map8[src[si]] << 6) | (map8[src[si + 1]] << 4) | (map8[src[si + 2]] << 2) | map8[src[si + 3]])
+                    si += 4
+            else:
+                out.append(count & 1)
+                if count & 1:
+                    out.append(src[si])
+                    si += 1
+                while si < count:
+                    out.append((map8[src[si]] << 4) | map8[src[si + 1]])
+                    si += 2
+    else:
+        freqs1 = {}
+        prv = 0
+        for c in src:
+            freqs1[(prv << 8) | c] = freqs1.get((prv << 8) | c, 0) + 1
+            prv = c
+        order = sorted(freqs1.items(), key=lambda kv: (-kv[1], -kv[0]))           # TreeSet.pollFirst order
+        if len(order) < n0:
+            n0 = len(order)
+            if n0 < 16:
+                return False, b"", left
+        map16 = {}
+        savings = 0
+        out += bytes([n0, 0])
+        for i in range(n0):
+            val, f = order[i]
+            savings += f
+            map16[val] = absent[i] | 0x200
+            out += bytes([val >> 8, val & 0xFF, absent[i]])
+        if savings < count // 20:
+            return False, b"", left
+        src_end = count - 1
+        while si < src_end:
+            alias = map16.get((src[si] << 8) | src[si + 1], src[si] | 0x100)
+            out.append(alias & 0xFF)
+            si += alias >> 8
+        if si != src_end + 1:
+            out[1] = 1
+            out.append(src[si])
+            si += 1
+    return len(out) < count, bytes(out), left
+
+
+def _utf_len_seq(b):                                                              # UTFCodec.java LEN_SEQ :34-43, by rule
+    if b < 0x80:
+        return 1
+    if 0xC2 <= b <= 0xDF:
+        return 2
+    if 0xE0 <= b <= 0xEF:
+        return 3
+    if 0xF0 <= b <= 0xF4:
+        return 4
+    return 0
+
+
+def _utf_pack(src, i):                                                            # UTFCodec.pack :437-466, SIZES :32
+    b0 = src[i]
+    s = (1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 2, 2, 3, 4)[b0 >> 4]
+    if s == 1:
+        return 1, b0
+    if s == 2:
+        return 2, (1 << 19) | (b0 << 8) | src[i + 1]
+    if s == 3:
+        return 3, (2 << 19) | ((b0 & 0x0F) << 12) | ((src[i + 1] & 0x3F) << 6) | (src[i + 2] & 0x3F)
+    if s == 4:
+        return 4, (4 << 19) | ((b0 & 0x07) << 18) | ((src[i + 1] & 0x3F) << 12) | ((src[i + 2] & 0x3F) << 6) | (src[i + 3] & 0x3F)
+    return 0, 0
+
+
+def _utf_validate(block, start, count):                                           # UTFCodec.validate :313-434
+    freqs0 = [0] * 256
+    freqs1 = {}
+    prv = 0
+    end = start + count
+    end4 = start + (count & -4)
+
+    def bad1():
+        return freqs0[0xC0] + freqs0[0xC1] + sum(freqs0[0xF5:0x100]) != 0
+
+    i = start
+    while i < end4:
+        for k in range(4):
+            cur = block[i + k]
+            freqs0[cur] += 1
+            freqs1[(prv, cur)] = freqs1.get((prv, cur), 0) + 1
+            prv = cur
+        if (i & 0x0FFF) == start and bad1():
+            return False
+        i += 4
+    if end4 != end:
+        for i in range(end4, end):
+            cur = block[i]
+            freqs0[cur] += 1
+            freqs1[(prv, cur)] = freqs1.get((prv, cur), 0) + 1
+            prv = cur
+        if bad1():
+            return False
+    sum2 = 0
+    f1 = lambda a, b: freqs1.get((a, b), 0)
+    for i in range(256):
+        s1 = 0
+        if i < 0xA0 or i > 0xBF:
+            s1 += f1(0xE0, i)
+        if i < 0x80 or i > 0x9F:
+            s1 += f1(0xED, i)
+        if i < 0x90 or i > 0xBF:
+            s1 += f1(0xF0, i)
+        if i < 0x80 or i > 0x8F:
+            s1 += f1(0xF4, i)
+        if i < 0x80 or i > 0xBF:
+            s1 += sum(f1(j, i) for j in range(0xC2, 0xE0)) + sum(f1(j, i) for j in range(0xE1, 0xED))
+            s1 += f1(0xF1, i) + f1(0xF2, i) + f1(0xF3, i) + f1(0xEE, i) + f1(0xEF, i)
+        else:
+            sum2 += freqs0[i]
+        if s1:
+            return False
+    return sum2 >= count // 8
+
+
+def utf_forward(data, data_type="UNDEFINED"):
+    """K/transform/UTFCodec.java forward :68-218 with a context; the sort (QuickSort with SymbolComparator :553-565) is a total order:
+    frequency ascending, then symbol ascending, read backwards.  Returns (applied, bytes, dataType left in the context)."""
+    src = bytes(data)
+    count = len(src)
+    if count == 0:
+        return True, b"", data_type
+    if count < 1024:
+        return False, b"", data_type
+    if data_type not in ("UNDEFINED", "UTF8"):
+        return False, b"", data_type
+    must_validate = data_type != "UTF8"
+    src_end = count - 4
+    start = 0
+    if src[0] == 0xEF and src[1] == 0xBB and src[2] == 0xBF:
+        start = 3
+    else:
+        while start < 4 and _utf_len_seq(src[start]) == 0:
+            start += 1
+    if must_validate and not _utf_validate(src, start, src_end - start):
+        return False, b"", data_type
+    left = "UTF8"
+    alias_map = {}
+    syms = []
+    res = True
+    i = start
+    pad = src + bytes(8)
+    while i < src_end:
+        s, val = _utf_pack(pad, i)
+        res = s != 0
+        res = res and (s != 3 or 0x80 <= pad[i + 2] <= 0xBF)
+        res = res and (s != 4 or (((pad[i + 2] << 8) | pad[i + 3]) & 0xC0C0) == 0x8080)
+        if alias_map.get(val, 0) == 0:
+            syms.append(val)
+            res = res and len(syms) < 32768
+        if not res:
+            break
+        alias_map[val] = alias_map.get(val, 0) + 1
+        i += s
+    n = len(syms)
+    max_target = count - count // 10
+    if not res or n == 0 or 3 * n + 6 >= max_target:
+        return False, b"", left
+    ranked = sorted(syms, key=lambda v: (alias_map[v], v), reverse=True)
+    out = bytearray([0, 0, n >> 8, n & 0xFF])
+    estimate = 4 + 6
+    alias = {}
+    for r, v in enumerate(ranked):
+        out += bytes([(v >> 16) & 0xFF, (v >> 8) & 0xFF, v & 0xFF])
+        estimate += alias_map[v] if r < 128 else 2 * alias_map[v]
+        alias[v] = r if r < 128 else (0x10080 | ((r << 1) & 0xFF00) | (r & 0x7F))
+    if estimate >= max_target:
+        return False, b"", left
+    out += src[:start]
+    i = start
+    while i < src_end:
+        s, val = _utf_pack(pad, i)
+        i += s
+        a = alias[val]
+        out.append(a & 0xFF)
+        if a >> 16:
+            out.append((a >> 8) & 0xFF)
+    out[0] = start
+    out[1] = i - src_end
+    out += src[i:src_end + 4]
+    return len(out) < max_target, bytes(out), left

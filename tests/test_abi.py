@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in declared:
         assert hasattr(L, name), "libkanzi_hip.so does not export %s" % name
     assert sorted(kz.ABI_SYMBOLS) == declared, "python binding list out of sync with the header"
-    assert kz.load_library().kz_abi_version() == 2
+    assert kz.load_library().kz_abi_version() == 3
 
 
 def test_max_encoded_len_matches_reference_values(built):

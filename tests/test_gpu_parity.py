@@ -1078,3 +1078,52 @@ def test_expensive_blocks_first_decode_schedule(ctx, monkeypatch):
         assert all(s == 0 and l == lens[i] for i, (s, l) in enumerate(st))
         assert all(results[("first", "good")][1][i] == inp[i, :lens[i]].tobytes() for i in range(B))
 
+
+
+def test_text_block_size_is_fixed_at_call_time(ctx):
+    """TEXT sizes its hash map by the stream's block size.  A chain with TEXT is refused until the context has been told
+    that size; blocks coded at two block sizes decode with their own size; a queued job keeps the size of its submit time."""
+    c = textgen.cases()
+    data = (c["english"] + c["many_words"])[:4 * 131072]
+    fresh = kz.Context(0)
+    try:
+        blocks = np.frombuffer(data, dtype=np.uint8).reshape(4, 131072).copy()
+        lens = np.full(4, 131072, dtype=np.int32)
+        ostride = kz.max_block_stream_bytes(131072)
+        out = np.zeros((4, ostride), dtype=np.uint8)
+        with pytest.raises(kz.KanziError) as e:
+            kz.encode_blocks(fresh, "TEXT+BWT+RANK+ZRLT", "ANS0", blocks, 131072, lens, out, ostride)
+        assert e.value.code == 1                                          # ERR_MISSING_PARAM: "blockSize" was never set
+        assert fresh.lib.kz_submit_encode_blocks(fresh.h, kz.transform_type("TEXT+BWT"), 5, blocks.ctypes.data, 131072, lens.ctypes.data, 4,
+                                                 out.ctypes.data, ostride, 0, 0) == -1
+        coded = {}
+        for stream_bs in (131072, 1 << 20):                              # two streams with different block sizes, same block bytes
+            fresh.set_block_size(stream_bs)
+            res = kz.encode_blocks(fresh, "TEXT+BWT+RANK+ZRLT", "ANS0", blocks, 131072, lens, out, ostride)
+            for i in range(4):
+                s, w, sf, pl = oracle.encode_block("TEXT+BWT+RANK+ZRLT", "ANS0", blocks[i], block_size=stream_bs)
+                assert (res[i].bits, res[i].skipFlags, res[i].length) == (w, sf, pl)
+                assert out[i, :(w + 7) // 8].tobytes() == s
+            coded[stream_bs] = (out.copy(), np.array([r.bits for r in res], dtype=np.int64))
+        for stream_bs, (o, bits) in coded.items():
+            dec = np.zeros((4, stream_bs), dtype=np.uint8)
+            res2 = kz.decode_blocks(fresh, "TEXT+BWT+RANK+ZRLT", "ANS0", stream_bs, o, ostride, bits, dec, stream_bs)
+            assert all(r.status == 0 and r.length == 131072 for r in res2)
+            assert np.array_equal(dec[:, :131072], blocks)
+        # a queued job keeps the block size of its submit time
+        fresh.set_block_size(131072)
+        out2 = np.zeros((4, ostride), dtype=np.uint8)
+        job = kz.submit_encode_blocks(fresh, "TEXT+BWT+RANK+ZRLT", "ANS0", blocks, 131072, lens, out2, ostride)
+        res = job.wait()
+        fresh.set_block_size(1 << 20)
+        for i in range(4):
+            nby = (res[i].bits + 7) // 8
+            assert res[i].bits == coded[131072][1][i] and out2[i, :nby].tobytes() == coded[131072][0][i, :nby].tobytes()
+        # a job's result is handed out once
+        assert fresh.lib.kz_wait(fresh.h, job.job) == -18
+        assert fresh.lib.kz_poll(fresh.h, job.job) == -18
+    finally:
+        fresh.close()
+    with pytest.raises(kz.KanziError) as e:
+        ctx.set_entropy(9)                                                # TPAQX: TEXT's extra hash bit is not modelled
+    assert e.value.code == 3

@@ -390,3 +390,125 @@ def test_lz_frames_are_read_back_by_a_python_model_of_the_reference_decoder():
     ok, enc = oracle.transform_forward("LZ", b"abc" * 420)
     assert ok and enc.hex() == "28000000" "02000000" "01000000" "04" + "616263" + "10" + (b"bca" * 8)[:23].hex() + "6fe0" + "03" + "fe03c9"
 
+
+
+# ---- round 3: the stages whose output is a CHOICE, pinned by pure-Python models written from the Java (tests/katmodels.py) ----
+def _model_inputs():
+    """the reference's own transform generators (T/test/TestTransforms.java:183-254, capped at 40 000 bytes for the Python loops)
+    + 64 KiB of every synthetic class + text-like cases"""
+    import textgen
+    out = [("ref%d" % i, bytes(a[:40000])) for i, a in enumerate(refinputs.transform_inputs())]
+    out += [("class%d" % c, datagen.block(c, 65536, c).tobytes()) for c in range(5)]
+    tc = textgen.cases()
+    out += [(k, tc[k][:50000]) for k in ("english", "xml", "utf8", "dna", "digits")]
+    return out
+
+
+def _sbrt_oracle(mode, data):
+    a = np.frombuffer(bytes(data), dtype=np.uint8)
+    out = np.zeros(max(len(a), 1), dtype=np.uint8)
+    fn = oracle.lib().kzo_sbrt_forward
+    fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    assert fn(mode, a.ctypes.data if len(a) else out.ctypes.data, len(a), out.ctypes.data)
+    return out[:len(a)].tobytes()
+
+
+def test_lz_lzx_parse_known_answers_from_a_python_model(built):
+    """LZXCodec.forward (LZCodec.java:299-597) for LZ and LZX: hash, the two repeat distances, lazy +1 / +2 probes, the skip
+    acceleration srcInc >> 6, backward extension, MAX_MATCH clamp, the fixed token buffer.  Any valid parse round-trips, so only a
+    second implementation pins the decisions."""
+    import katmodels
+    differ = 0
+    for name, d in _model_inputs():
+        for tname, extra in (("LZ", False), ("LZX", True)):
+            for dt in ("UNDEFINED", "DNA"):
+                if dt == "DNA" and not name.startswith(("dna", "class0", "ref20")):
+                    continue
+                try:
+                    ok_m, enc_m = katmodels.lz_forward(d, extra, dt)
+                    threw_m = False
+                except katmodels.JavaException:
+                    threw_m = True
+                try:
+                    ok_o, enc_o, _ = oracle.transform_forward(tname, d, data_type=oracle.DT[dt])
+                    threw_o = False
+                except oracle.TransformThrows:
+                    threw_o = True
+                assert threw_m == threw_o, (name, tname, dt)
+                if threw_m or len(d) == 0:
+                    continue
+                assert ok_m == ok_o, (name, tname, dt, ok_m, ok_o)
+                # a declined block's bytes are not part of the contract (Sequence copies the input through): compare applied ones
+                if ok_m:
+                    assert enc_m == enc_o, (name, tname, dt, len(enc_m), len(enc_o))
+                    differ += 1
+    assert differ > 40
+    assert katmodels.lz_forward(b"ab" * 600, False, "SMALL_ALPHABET") == (False, b"")
+
+
+def test_srt_forward_known_answers_from_a_python_model(built):
+    """SRT.forward (SRT.java:73-168), preprocess (shell sort :266-302) and encodeHeader (:312-325)"""
+    import katmodels
+    for name, d in _model_inputs():
+        if not d:
+            continue
+        ok, enc = oracle.transform_forward("SRT", d)
+        assert ok and enc == katmodels.srt_forward(d), name
+    # worked by hand: "abracadabra": first appearances a b r c d = the initial list; frequencies a5 b2 r2 c1 d1 -> bucket order
+    # a b r c d (freq desc, symbol asc) at offsets 0 5 7 9 10.  Move-to-front ranks in text order: a0 b1 r2 a2 c3 a1 d4 a1 b4 r4 a2
+    # (lists: abrcd, bar.., rba.., arb.., carbd, acrbd, dacrb, adcrb, badcr, rbadc), gathered per symbol
+    enc = katmodels.srt_forward(b"abracadabra")
+    freqs = [0] * 256
+    for c in b"abracadabra":
+        freqs[c] += 1
+    assert enc[:256] == bytes(freqs)
+    assert enc[256:] == bytes([0, 2, 1, 1, 2]) + bytes([1, 4]) + bytes([2, 4]) + bytes([3]) + bytes([4])
+
+
+def test_sbrt_rank_and_timestamp_known_answers_from_a_python_model(built):
+    """SBRT.forward (SBRT.java:87-151) in all three modes (MTF 1, RANK 2, TIMESTAMP 3)"""
+    import katmodels
+    for name, d in _model_inputs():
+        for mode in (1, 2, 3):
+            assert _sbrt_oracle(mode, d) == katmodels.sbrt_forward(d, mode), (name, mode)
+    # RANK by hand on "abab" + "c": ranks of a, b = 97, 98; then a sits at rank 1 (b moved in front), b at 1, ...
+    assert katmodels.sbrt_forward(b"ababc", 2) == bytes([97, 98, 1, 1, 99])
+    assert katmodels.sbrt_forward(b"aab", 1) == bytes([97, 0, 98])
+
+
+def test_alias_forward_known_answers_from_a_python_model(built):
+    """AliasCodec.forward (AliasCodec.java:78-278): packing for <= 16 symbols, digram aliases picked in TreeSet order, the savings
+    test, the dataType rules and what is stored back"""
+    import katmodels
+    rng = np.random.default_rng(11)
+    extra = [("four", bytes(rng.choice(np.frombuffer(b"acgt", dtype=np.uint8), 4099))), ("one", b"z" * 3000),
+             ("sixteen", bytes(rng.integers(64, 80, 5001, dtype=np.uint8))), ("nodigram", bytes(rng.integers(0, 200, 30000, dtype=np.uint8)))]
+    applied = 0
+    for name, d in _model_inputs() + extra + [(k, bytes(v)[:60000]) for k, v in refinputs.alias_inputs()]:
+        for tname, only_dna in (("PACK", False), ("DNA", True)):
+            for dt in ("UNDEFINED", "TEXT", "BIN", "DNA"):
+                ok_m, enc_m, left_m = katmodels.alias_forward(d, dt, only_dna)
+                ok_o, enc_o, left_o = oracle.transform_forward(tname, d, data_type=oracle.DT[dt])
+                assert (ok_m, oracle.DT[left_m]) == (ok_o, left_o), (name, tname, dt, ok_m, ok_o, left_m, left_o)
+                if ok_m and len(d):
+                    assert enc_m == enc_o, (name, tname, dt)
+                    applied += 1
+    assert applied > 30
+
+
+def test_utf_forward_known_answers_from_a_python_model(built):
+    """UTFCodec.forward (UTFCodec.java:68-218) with validate (:313-434) and pack (:437-466)"""
+    import katmodels
+    import textgen
+    tc = textgen.cases()
+    cases = _model_inputs() + [(k, tc[k]) for k in ("utf8_bom", "utf8_cut", "english_escapes", "random")]
+    applied = 0
+    for name, d in cases:
+        for dt in ("UNDEFINED", "UTF8", "TEXT"):
+            ok_m, enc_m, left_m = katmodels.utf_forward(d, dt)
+            ok_o, enc_o, left_o = oracle.transform_forward("UTF", d, data_type=oracle.DT[dt])
+            assert (ok_m, oracle.DT[left_m]) == (ok_o, left_o), (name, dt, ok_m, ok_o, left_m, left_o)
+            if ok_m and len(d):
+                assert enc_m == enc_o, (name, dt)
+                applied += 1
+    assert applied >= 4

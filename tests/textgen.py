@@ -87,3 +87,40 @@ def cases(scale=1):
         "gif_magic_text": b"GIF8" + english(30000, 14),
     }
     return c
+
+
+def bulk_text(n, seed, kind="english"):
+    """Full-size (MiB) text blocks for bench.py's level-exact rows, assembled with array operations only (the generators above
+    loop per line in Python).  kind: "english" (dictionary + invented words, Zipf reuse, sentence punctuation, LF or CRLF by
+    seed), "xml" (tags around dictionary words), "utf8" (Cyrillic words between ASCII ones)."""
+    rng = np.random.default_rng(seed)
+    wl = [w.lower() for w in dict_words()]
+    letters = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz", dtype=np.uint8)
+    made = ["".join(chr(c) for c in rng.choice(letters, rng.integers(3, 12))) for _ in range(600)]
+    eol = "\r\n" if (seed & 3) == 3 else "\n"
+    vocab = []
+    if kind == "utf8":
+        cyr = ["".join(chr(int(c)) for c in rng.integers(0x430, 0x450, rng.integers(2, 10))) for _ in range(1500)]
+        for w in cyr + wl[:300]:
+            vocab += [w + " ", w + ", ", w + "." + eol]
+    elif kind == "xml":
+        for w in wl[:400]:
+            vocab += ["<" + w + ">", "</" + w + ">" + eol, w + " ", w + " &amp; ", "<" + w + " id=\"" + str(len(w) * 37) + "\">"]
+    else:
+        for w in wl + made:
+            vocab += [w + " ", w + " ", w + " ", w.capitalize() + " ", w + ", ", w + "." + eol, w.upper() + " "]
+    enc = [v.encode("utf-8") for v in vocab]
+    lens = np.array([len(e) for e in enc], dtype=np.int64)
+    starts = np.concatenate(([0], np.cumsum(lens)[:-1]))
+    blob = np.frombuffer(b"".join(enc), dtype=np.uint8)
+    need = int(n // max(lens.mean() * 0.8, 1)) + 64
+    ids = (len(enc) * rng.random(need) ** 2.5).astype(np.int64)           # power-law reuse, no single word dominating
+    ids = rng.permutation(len(enc))[ids]                              # frequent ids spread over the vocabulary
+    L = lens[ids]
+    total = int(L.sum())
+    off = np.cumsum(L) - L
+    src = np.repeat(starts[ids] - off, L) + np.arange(total)
+    out = blob[src]
+    if len(out) < n:
+        out = np.resize(out, n)
+    return np.ascontiguousarray(out[:n])
