@@ -129,27 +129,10 @@ int kz_hpin_reserve(kz_ctx* ctx, size_t ints) {
   return 0;
 }
 
-// host threads of the TEXT / UTF stages: the reference's job limit (BlockCompressor.java:199-203: at most 64); every thread keeps
-// its own dictionary and UTF alias map (tens of MiB)
-#define KZ_HOST_STAGE_THREADS 64
-// the CPUs this process may run on (N ranks on one host are pinned to their GPU's NUMA node: kz_pin_to_device_numa)
-static int kz_usable_cpus() {
-  cpu_set_t set;
-  CPU_ZERO(&set);
-  if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) return c; }
-  const int hw = (int)std::thread::hardware_concurrency();
-  return hw > 0 ? hw : 1;
-}
-void kz_parallel_for(int n, int maxThreads, void (*fn)(int, void*), void* arg) {
-  const int hw = kz_usable_cpus();
-  const int T = std::max(1, std::min(std::min(n, maxThreads), hw > 0 ? hw : 1));
-  if (T == 1) { for (int i = 0; i < n; i++) fn(i, arg); return; }
-  std::atomic<int> next(0);
-  std::vector<std::thread> th;
-  for (int t = 0; t < T; t++) th.emplace_back([&]() { for (;;) { const int i = next.fetch_add(1); if (i >= n) break; fn(i, arg); } });
-  for (auto& x : th) x.join();
-}
-
+// host threads of the TEXT / UTF stages.  The reference caps its jobs at 64 (BlockCompressor.java:199-203) on hosts of a few
+// dozen cores; a GPU box brings hundreds, and these stages are what the GPU waits for in the level-exact chains: up to 128
+// (every thread keeps a dictionary, stage buffers and a small alias map: a few MiB)
+#define KZ_HOST_STAGE_THREADS 128
 int kz_arena_reserve(kz_ctx* ctx, size_t total) {
   ctx->arenaTop = 0;
   if (total <= ctx->arenaCap) return 0;
@@ -548,41 +531,66 @@ static int host_prefix(kz_ctx* ctx, const int* types, int nb) {          // numb
     }
   return hp;
 }
+// Result of the host stages (TEXT, UTF) of a set of blocks, computed host -> host so that it can run on a helper thread while the
+// GPU codes the previous set: per block its length, skip flag bits and "dataType" entry, and -- when a stage applied -- the
+// transformed bytes (slot b of `store`).
+struct HostPre {
+  std::vector<int32_t> outLen, skip, dtype;
+  std::vector<uint8_t> changed;
+  std::unique_ptr<uint8_t[]> store;
+  int64_t slot = 0;
+  const uint8_t* data(int b) const { return store.get() + (int64_t)b * slot; }
+};
 struct HostFwd {
-  kz_ctx* ctx; const int* types; int hp; int entropy; int cap; int blockSize;
+  const int* types; int hp; int entropy; int cap; int blockSize;
   const uint8_t* hsrc; int64_t hstride;             // the blocks in host memory
-  uint8_t* dbuf; int64_t dstride;                   // their slots in HBM
-  const int32_t* lengths; const int32_t* copy;
-  int32_t* outLen; int32_t* skip; int32_t* dtype; std::atomic<int> fail{0};
+  const int32_t* lengths; const int32_t* copy;      // copy: blocks the chain does not apply to (null: those of <= 15 bytes)
+  HostPre* P;
 };
 static void host_forward_block(int b, void* arg) {
   HostFwd& H = *(HostFwd*)arg;
+  HostPre& P = *H.P;
   const int n = H.lengths[b];
-  H.outLen[b] = n;
-  H.dtype[b] = KZ_DT_UNDEFINED;
-  if (n == 0 || H.copy[b]) return;
-  static thread_local std::vector<uint8_t> bufA, bufB;
-  if ((int)bufA.size() < H.cap + 64) { bufA.resize((size_t)H.cap + 64); bufB.resize((size_t)H.cap + 64); }
+  P.outLen[b] = n;
+  P.dtype[b] = KZ_DT_UNDEFINED;
+  P.skip[b] = 0xFF;
+  P.changed[b] = 0;
+  if (n == 0 || (H.copy ? H.copy[b] != 0 : n <= 15)) return;
+  static thread_local std::vector<uint8_t> bufA;
+  if ((int)bufA.size() < H.cap + 64) bufA.resize((size_t)H.cap + 64);
   const uint8_t* cur = H.hsrc + (int64_t)b * H.hstride;
   int dt = kz_host_block_data_type(cur, n, KZ_DT_UNDEFINED);            // CompressedOutputStream.java:795-804
   int len = n;
-  uint8_t* out = bufA.data();
+  uint8_t* mine = P.store.get() + (int64_t)b * P.slot;
+  uint8_t* out = mine;                                                  // ping-pong between the block's slot and a scratch buffer
   for (int i = 0; i < H.hp; i++) {
     int produced = 0;
     if (!kz_host_transform_forward(H.types[i], H.entropy, H.blockSize, &dt, cur, len, out, H.cap, &produced)) continue;   // declined: data untouched
-    H.skip[b] &= ~(1 << (7 - i));
+    P.skip[b] &= ~(1 << (7 - i));
     cur = out; len = produced;
-    out = (out == bufA.data()) ? bufB.data() : bufA.data();
+    out = (out == mine) ? bufA.data() : mine;
   }
-  H.dtype[b] = dt;
-  if (cur != H.hsrc + (int64_t)b * H.hstride) {                         // a stage applied: the block in HBM is replaced
-    if (hipSetDevice(H.ctx->device) != hipSuccess || hipMemcpy(H.dbuf + (int64_t)b * H.dstride, cur, (size_t)len, hipMemcpyHostToDevice) != hipSuccess) H.fail = 1;
-    H.outLen[b] = len;
+  P.dtype[b] = dt;
+  if (cur != H.hsrc + (int64_t)b * H.hstride) {                         // a stage applied
+    if (cur != mine) memcpy(mine, cur, (size_t)len);
+    P.changed[b] = 1;
+    P.outLen[b] = len;
   }
 }
+// runs the chain's host stages over B blocks in host memory
+static void host_prestage(const int* types, int hp, int entropy, int blockSize, int cap, const uint8_t* hsrc, int64_t hstride,
+                          const int32_t* lengths, const int32_t* copy, int B, HostPre& P) {
+  P.outLen.assign(B, 0); P.skip.assign(B, 0xFF); P.dtype.assign(B, 0); P.changed.assign(B, 0);
+  P.slot = (int64_t)kz_align((size_t)cap + 64, 64);
+  P.store.reset(new uint8_t[(size_t)P.slot * (size_t)B + 64]);        // uninitialised: only the bytes a stage writes are touched
+  HostFwd H;
+  H.types = types; H.hp = hp; H.entropy = entropy; H.cap = cap; H.blockSize = blockSize;
+  H.hsrc = hsrc; H.hstride = hstride; H.lengths = lengths; H.copy = copy; H.P = &P;
+  kz_parallel_for(B, KZ_HOST_STAGE_THREADS, host_forward_block, &H);
+}
 struct HostInv {
-  kz_ctx* ctx; const int* types; int hp; int blockSize; int cap;
-  uint8_t* dbuf; int64_t dstride;
+  int device; const int* types; int hp; int blockSize; int cap;
+  uint8_t* dbuf; int64_t dstride; int64_t slotCap; bool hostMem;        // the blocks' slots: in HBM (copied over and back) or in host memory
   int32_t* len; const int32_t* skip; int32_t* status; std::atomic<int> fail{0};
 };
 static void host_inverse_block(int b, void* arg) {
@@ -595,7 +603,9 @@ static void host_inverse_block(int b, void* arg) {
   static thread_local std::vector<uint8_t> bufA, bufB;
   const size_t need = (size_t)std::max(H.cap, len) + 64;
   if (bufA.size() < need) { bufA.resize(need); bufB.resize(need); }
-  if (hipSetDevice(H.ctx->device) != hipSuccess || hipMemcpy(bufA.data(), H.dbuf + (int64_t)b * H.dstride, (size_t)len, hipMemcpyDeviceToHost) != hipSuccess) { H.fail = 1; return; }
+  uint8_t* slot = H.dbuf + (int64_t)b * H.dstride;
+  if (H.hostMem) memcpy(bufA.data(), slot, (size_t)len);
+  else if (hipSetDevice(H.device) != hipSuccess || hipMemcpy(bufA.data(), slot, (size_t)len, hipMemcpyDeviceToHost) != hipSuccess) { H.fail = 1; return; }
   uint8_t* cur = bufA.data();
   uint8_t* out = bufB.data();
   for (int i = H.hp - 1; i >= 0; i--) {                                 // Sequence.inverse: last applied first
@@ -605,7 +615,9 @@ static void host_inverse_block(int b, void* arg) {
     len = produced;
     std::swap(cur, out);
   }
-  if (hipMemcpy(H.dbuf + (int64_t)b * H.dstride, cur, (size_t)len, hipMemcpyHostToDevice) != hipSuccess) { H.fail = 1; return; }
+  if ((int64_t)len > H.slotCap) { H.status[b] = -KZ_ERR_PROCESS_BLOCK; H.len[b] = 0; return; }   // more than a block: "incorrectly decompressed"
+  if (H.hostMem) memcpy(slot, cur, (size_t)len);
+  else if (hipMemcpy(slot, cur, (size_t)len, hipMemcpyHostToDevice) != hipSuccess) { H.fail = 1; return; }
   H.len[b] = len;
 }
 
@@ -850,9 +862,19 @@ static int overlapped_rank_bwt_inverse(kz_ctx* ctx, Pipe& P, int mode, const std
 // encode
 // blockSize = the stream's "blockSize" entry as TEXT reads it, fixed when the call was made (a queued job keeps the value of its
 // submit time: later kz_ctx_set_block_size calls or kz_compress's scope do not reach it)
+// pre (optional): the host stages' results for exactly these blocks, computed ahead (host_prestage) by the caller.
+int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
+                             const uint8_t* in, int64_t inStride, const int32_t* lengths, int32_t nBlocks,
+                             uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind, const HostPre* pre);
+static int host_chunk_blocks() { const char* e = getenv("KZ_HOST_CHUNK"); const int v = e ? atoi(e) : 256; return v < 8 ? 8 : v; }
 static int32_t encode_blocks_bs(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
                                 const uint8_t* in, int64_t inStride, const int32_t* lengths, int32_t nBlocks,
                                 uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind) {
+  return kz_encode_blocks_pre(ctx, transformType, entropyType, blockSize, in, inStride, lengths, nBlocks, out, outStride, results, memKind, nullptr);
+}
+int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
+                             const uint8_t* in, int64_t inStride, const int32_t* lengths, int32_t nBlocks,
+                             uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind, const HostPre* pre) {
   if (!ctx) return -KZ_ERR_INVALID_PARAM;
   if (nBlocks <= 0) return 0;
   KZ_HIP(hipSetDevice(ctx->device));
@@ -884,7 +906,7 @@ static int32_t encode_blocks_bs(kz_ctx* ctx, uint64_t transformType, uint32_t en
     const size_t perBlock = pipeline_scratch(1, maxLen, false, noBwt) + (size_t)maxLen * 2 + 8192 + (size_t)(memKind == KZ_MEM_HOST ? outStride : 0) + (1 << 16);
     const size_t avail = hasBwt ? kz_arena_budget() / 2 : kz_arena_budget();      // the other half: suffix-sort groups
     const int maxB = (int)std::min<size_t>(KZ_MAX_BATCH, std::max<size_t>(1, avail / perBlock));   // grid.y carries the block index
-    if (B > maxB) {
+    if (B > maxB && !pre) {
       for (int b0 = 0; b0 < B; b0 += maxB) {
         const int cnt = std::min(maxB, B - b0);
         int rc = encode_blocks_bs(ctx, transformType, entropyType, blockSize, in + (int64_t)b0 * inStride, inStride, lengths + b0, cnt,
@@ -893,6 +915,46 @@ static int32_t encode_blocks_bs(kz_ctx* ctx, uint64_t transformType, uint32_t en
       }
       return 0;
     }
+    if (B > maxB) { snprintf(ctx->err, sizeof(ctx->err), "encode: a pre-staged batch of %d blocks exceeds the arena budget (%d)", B, maxB); return -KZ_ERR_INVALID_PARAM; }
+  }
+  // ---- chains led by TEXT / UTF on large batches: the host stages of chunk k+1 run on a helper thread (and the host pool) while
+  //      the GPU codes chunk k.  Blocks are independent, so chunking changes nothing in the output.  (With "skipBlocks" the copy
+  //      decision comes from the device and precedes the host stages: that case takes the one-pass path below.) ----
+  if (hp > 0 && !pre && !ctx->skipBlocks && B >= 2 * host_chunk_blocks()) {
+    const int CH = host_chunk_blocks();
+    const int nch = (B + CH - 1) / CH;
+    const bool hostIn = memKind == KZ_MEM_HOST;
+    struct Chunk { HostPre P; std::unique_ptr<uint8_t[]> copy; int rc = 0; };
+    std::vector<Chunk> ck(nch);
+    const int dev = ctx->device;
+    auto stage = [&](int k) {
+      const int b0 = k * CH, cnt = std::min(CH, B - b0);
+      const uint8_t* hsrc = in + (int64_t)b0 * inStride;
+      int64_t hstride = inStride;
+      if (!hostIn) {                                                // device input: one copy back for the host stages (legacy stream:
+        ck[k].copy.reset(new uint8_t[(size_t)cnt * (size_t)maxN + 64]);   // it does not wait for the context's non-blocking stream)
+        if (hipSetDevice(dev) != hipSuccess) { ck[k].rc = -KZ_ERR_DEVICE; return; }
+        if (inStride == (int64_t)maxN) {
+          if (hipMemcpy(ck[k].copy.get(), hsrc, (size_t)cnt * (size_t)maxN, hipMemcpyDeviceToHost) != hipSuccess) { ck[k].rc = -KZ_ERR_DEVICE; return; }
+        } else if (hipMemcpy2D(ck[k].copy.get(), (size_t)maxN, hsrc, (size_t)inStride, (size_t)maxN, (size_t)cnt, hipMemcpyDeviceToHost) != hipSuccess) { ck[k].rc = -KZ_ERR_DEVICE; return; }
+        hsrc = ck[k].copy.get(); hstride = maxN;
+      }
+      host_prestage(types, hp, (int)entropyType, blockSize, maxLen, hsrc, hstride, lengths + b0, nullptr, cnt, ck[k].P);
+      ck[k].copy.reset();
+    };
+    stage(0);
+    for (int k = 0; k < nch; k++) {
+      std::thread ahead;
+      if (k + 1 < nch) ahead = std::thread(stage, k + 1);
+      const int b0 = k * CH, cnt = std::min(CH, B - b0);
+      int rc = ck[k].rc;
+      if (!rc) rc = kz_encode_blocks_pre(ctx, transformType, entropyType, blockSize, in + (int64_t)b0 * inStride, inStride, lengths + b0, cnt,
+                                         out + (int64_t)b0 * outStride, outStride, results + b0, memKind, &ck[k].P);
+      ck[k].P = HostPre();
+      if (ahead.joinable()) ahead.join();
+      if (rc) { if (rc == -KZ_ERR_DEVICE && !ctx->err[0]) snprintf(ctx->err, sizeof(ctx->err), "host stage: copy from the device failed"); return rc; }
+    }
+    return 0;
   }
   const int64_t needOut = kz_max_block_stream_bytes(maxN);
   if (outStride < needOut || (outStride & 3)) { snprintf(ctx->err, sizeof(ctx->err), "outStride %lld < %lld or not a multiple of 4", (long long)outStride, (long long)needOut); return -KZ_ERR_INVALID_PARAM; }
@@ -945,30 +1007,36 @@ static int32_t encode_blocks_bs(kz_ctx* ctx, uint64_t transformType, uint32_t en
     for (int b = 0; b < B; b++) if (ctx->hpin[b]) h_copy[b] = 1;
   }
   if (hp > 0) {
-    // host stages (TEXT, UTF): per block on host threads; a block a stage applied to is replaced in HBM, its skip flag bits and
-    // its "dataType" entry (the writer's Magic tag, then whatever TEXT / UTF leave there) go on to the GPU stages
+    // host stages (TEXT, UTF): per block on host threads (ahead of this call when `pre` is given); a block a stage applied to is
+    // replaced in HBM, its skip flag bits and its "dataType" entry (the writer's Magic tag, then whatever TEXT / UTF leave
+    // there) go on to the GPU stages
     hipEvent_t e0; kz_stage_begin(ctx, &e0);
-    std::unique_ptr<uint8_t[]> hostCopy;
-    const uint8_t* hsrc = in;
-    int64_t hstride = inStride;
-    if (!host) {
-      hostCopy.reset(new uint8_t[(size_t)B * (size_t)maxN + 64]);
-      for (int b = 0; b < B; b++)
-        if (lengths[b]) KZ_HIP(hipMemcpyAsync(hostCopy.get() + (size_t)b * maxN, in + (int64_t)b * inStride, (size_t)lengths[b], hipMemcpyDeviceToHost, st));
-      hsrc = hostCopy.get(); hstride = maxN;
+    HostPre mine;
+    if (!pre) {
+      std::unique_ptr<uint8_t[]> hostCopy;
+      const uint8_t* hsrc = in;
+      int64_t hstride = inStride;
+      if (!host) {
+        hostCopy.reset(new uint8_t[(size_t)B * (size_t)maxN + 64]);
+        for (int b = 0; b < B; b++)
+          if (lengths[b]) KZ_HIP(hipMemcpyAsync(hostCopy.get() + (size_t)b * maxN, in + (int64_t)b * inStride, (size_t)lengths[b], hipMemcpyDeviceToHost, st));
+        hsrc = hostCopy.get(); hstride = maxN;
+        KZ_HIP(hipStreamSynchronize(st));
+      }
+      host_prestage(types, hp, (int)entropyType, blockSize, maxLen, hsrc, hstride, lengths, h_copy.data(), B, mine);
+      pre = &mine;
     }
     KZ_HIP(hipStreamSynchronize(st));                                            // the blocks are in HBM, hashed and tagged: slots may be rewritten
-    std::vector<int32_t> h_dt(B), h_out(B);
-    HostFwd H;
-    H.ctx = ctx; H.types = types; H.hp = hp; H.entropy = (int)entropyType; H.cap = maxLen; H.blockSize = blockSize;
-    H.hsrc = hsrc; H.hstride = hstride; H.dbuf = bt.buf[0]; H.dstride = bt.stride;
-    H.lengths = lengths; H.copy = h_copy.data(); H.outLen = h_out.data(); H.skip = h_skip.data(); H.dtype = h_dt.data();
-    kz_parallel_for(B, KZ_HOST_STAGE_THREADS, host_forward_block, &H);
-    if (H.fail) { snprintf(ctx->err, sizeof(ctx->err), "host stage: copy to the device failed"); return -KZ_ERR_DEVICE; }
-    for (int b = 0; b < B; b++) bt.h_len[b] = h_out[b];
+    for (int b = 0; b < B; b++) {
+      if (h_copy[b]) { bt.h_len[b] = lengths[b]; continue; }                     // (a pre-staged block of <= 15 bytes was left alone as well)
+      h_skip[b] = pre->skip[b];
+      bt.h_len[b] = pre->outLen[b];
+      if (pre->changed[b] && pre->outLen[b] > 0)
+        KZ_HIP(hipMemcpyAsync(bt.buf[0] + (int64_t)b * bt.stride, pre->data(b), (size_t)pre->outLen[b], hipMemcpyHostToDevice, st));
+    }
     KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-    KZ_HIP(hipMemcpyAsync(bt.d_dtype, h_dt.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-    KZ_HIP(hipStreamSynchronize(st));                                            // h_dt is a local
+    KZ_HIP(hipMemcpyAsync(bt.d_dtype, pre->dtype.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    KZ_HIP(hipStreamSynchronize(st));                                            // pageable sources; `mine` is a local
     kz_stage_end(ctx, e0, KZ_STAGE_HOST_FWD, 0);
   }
   for (int i = hp; i < nb; i++) {
@@ -1136,9 +1204,11 @@ __global__ void k_copy_payload(const u8* __restrict__ in, int64_t inStride, u8* 
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
 }
 
+// deferHost: leave the host stages (TEXT / UTF inverse) to the caller: the blocks come out as the GPU chain left them, results[b]
+// carry their skip flags and lengths (kz_decode_blocks runs those stages on a helper thread under the next chunk's GPU work).
 static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
                                   const uint8_t* in, int64_t inStride, const int64_t* bitLengths, int32_t nBlocks,
-                                  uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind) {
+                                  uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind, bool deferHost = false) {
   if (!ctx) return -KZ_ERR_INVALID_PARAM;
   if (nBlocks <= 0) return 0;
   KZ_HIP(hipSetDevice(ctx->device));
@@ -1170,7 +1240,7 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
       for (int b0 = 0; b0 < B; b0 += maxB) {
         const int cnt = std::min(maxB, B - b0);
         int rc = decode_blocks_impl(ctx, transformType, entropyType, blockSize, in + (int64_t)b0 * inStride, inStride, bitLengths + b0, cnt,
-                                    out + (int64_t)b0 * outStride, outStride, results + b0, memKind);
+                                    out + (int64_t)b0 * outStride, outStride, results + b0, memKind, deferHost);
         if (rc) return rc;
       }
       return 0;
@@ -1350,14 +1420,15 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
     if (rc) return rc;
   }
   }
-  if (hp > 0) {
+  if (hp > 0 && !deferHost) {
     // host stages (UTF, TEXT inverse) behind the GPU stages: blocks that went through one come back to the host, are decoded
     // on host threads and return to their slot
     hipEvent_t e1; kz_stage_begin(ctx, &e1);
     KZ_HIP(hipStreamSynchronize(st));
     HostInv H;
-    H.ctx = ctx; H.types = types; H.hp = hp; H.blockSize = blockSize; H.cap = dataCap;
-    H.dbuf = bt.buf[bt.cur]; H.dstride = bt.stride; H.len = bt.h_len.data(); H.skip = h_skip.data(); H.status = h_status.data();
+    H.device = ctx->device; H.types = types; H.hp = hp; H.blockSize = blockSize; H.cap = dataCap;
+    H.dbuf = bt.buf[bt.cur]; H.dstride = bt.stride; H.slotCap = bt.stride; H.hostMem = false;
+    H.len = bt.h_len.data(); H.skip = h_skip.data(); H.status = h_status.data();
     kz_parallel_for(B, KZ_HOST_STAGE_THREADS, host_inverse_block, &H);
     if (H.fail) { snprintf(ctx->err, sizeof(ctx->err), "host stage: copy from / to the device failed"); return -KZ_ERR_DEVICE; }
     KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
@@ -1376,7 +1447,7 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
   }
   // ---- results ----
   for (int b = 0; b < B; b++) {
-    if (!h_status[b] && (bt.h_len[b] > blockSize || bt.h_len[b] > outStride)) h_status[b] = -KZ_ERR_PROCESS_BLOCK;
+    if (!h_status[b] && (bt.h_len[b] > outStride || (!deferHost && bt.h_len[b] > blockSize))) h_status[b] = -KZ_ERR_PROCESS_BLOCK;
     results[b].bits = bitLengths[b]; results[b].length = h_status[b] ? 0 : bt.h_len[b]; results[b].status = h_status[b];
     results[b].skipFlags = (uint8_t)h_skip[b]; results[b].mode = 0;
     if (host && !h_status[b] && bt.h_len[b] > 0)
@@ -1393,16 +1464,62 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
   return 0;
 }
 
+static void decode_error_sync(kz_ctx* ctx) {
+  // an error exit may leave kernels of the overlapped schedule running on the side streams: the next call reuses (or frees) the
+  // arena they work in
+  for (int i = 0; i < 5; i++) if (ctx->side[i]) hipStreamSynchronize(ctx->side[i]);
+  hipStreamSynchronize(ctx->stream);
+}
+static int host_chunk_blocks_dec() { const char* e = getenv("KZ_HOST_CHUNK_DEC"); const int v = e ? atoi(e) : 512; return v < 8 ? 8 : v; }
 extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
                                     const uint8_t* in, int64_t inStride, const int64_t* bitLengths, int32_t nBlocks,
                                     uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind) {
-  const int32_t rc = decode_blocks_impl(ctx, transformType, entropyType, blockSize, in, inStride, bitLengths, nBlocks, out, outStride, results, memKind);
-  if (rc && ctx) {
-    // an error exit may leave kernels of the overlapped schedule running on the side streams: the next call reuses (or
-    // frees) the arena they work in
-    for (int i = 0; i < 5; i++) if (ctx->side[i]) hipStreamSynchronize(ctx->side[i]);
-    hipStreamSynchronize(ctx->stream);
+  if (!ctx) return -KZ_ERR_INVALID_PARAM;
+  int types[8];
+  const int nb = split_types(transformType, types);
+  int hp = 0;
+  while (hp < nb && kz_is_host_transform(types[hp])) hp++;
+  const int CH = host_chunk_blocks_dec();
+  // ---- chains led by TEXT / UTF on large batches: the host inverse stages of chunk k run on a helper thread (and the host pool)
+  //      while the GPU decodes chunk k+1.  (Block checksums are verified on the device AFTER the host stages: that case takes the
+  //      one-pass path.) ----
+  if (hp > 0 && ctx->checksum == 0 && nBlocks >= 2 * CH) {
+    const int B = nBlocks, nch = (B + CH - 1) / CH;
+    const int dataCap = blockSize + std::max(512, blockSize >> 4);
+    std::vector<std::thread> finishers;
+    std::vector<std::unique_ptr<HostInv>> jobs;
+    std::vector<std::vector<int32_t>> lens(nch), skips(nch), stats(nch);
+    int rc = 0;
+    for (int k = 0; k < nch && !rc; k++) {
+      const int b0 = k * CH, cnt = std::min(CH, B - b0);
+      rc = decode_blocks_impl(ctx, transformType, entropyType, blockSize, in + (int64_t)b0 * inStride, inStride, bitLengths + b0, cnt,
+                              out + (int64_t)b0 * outStride, outStride, results + b0, memKind, true);
+      if (rc) break;
+      lens[k].resize(cnt); skips[k].resize(cnt); stats[k].resize(cnt);
+      for (int i = 0; i < cnt; i++) { lens[k][i] = results[b0 + i].length; skips[k][i] = results[b0 + i].skipFlags; stats[k][i] = results[b0 + i].status; }
+      jobs.emplace_back(new HostInv());
+      HostInv* H = jobs.back().get();
+      H->device = ctx->device; H->types = types; H->hp = hp; H->blockSize = blockSize; H->cap = dataCap;
+      H->dbuf = out + (int64_t)b0 * outStride; H->dstride = outStride; H->slotCap = outStride; H->hostMem = memKind == KZ_MEM_HOST;
+      H->len = lens[k].data(); H->skip = skips[k].data(); H->status = stats[k].data();
+      finishers.emplace_back([H, cnt]() { kz_parallel_for(cnt, KZ_HOST_STAGE_THREADS, host_inverse_block, H); });
+    }
+    for (auto& t : finishers) t.join();
+    if (rc) { decode_error_sync(ctx); return rc; }
+    for (int k = 0; k < nch; k++) {
+      if (jobs[k]->fail) { snprintf(ctx->err, sizeof(ctx->err), "host stage: copy from / to the device failed"); return -KZ_ERR_DEVICE; }
+      const int b0 = k * CH;
+      for (size_t i = 0; i < lens[k].size(); i++) {
+        kz_block_result& r = results[b0 + (int)i];
+        if (!stats[k][i] && lens[k][i] > blockSize) stats[k][i] = -KZ_ERR_PROCESS_BLOCK;
+        r.status = stats[k][i];
+        r.length = stats[k][i] ? 0 : lens[k][i];
+      }
+    }
+    return 0;
   }
+  const int32_t rc = decode_blocks_impl(ctx, transformType, entropyType, blockSize, in, inStride, bitLengths, nBlocks, out, outStride, results, memKind);
+  if (rc) decode_error_sync(ctx);
   return rc;
 }
 

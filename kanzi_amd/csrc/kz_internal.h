@@ -152,7 +152,8 @@ int kz_host_block_data_type(const uint8_t* p, int n, int init);
 int kz_host_transform_forward(int type, int entropyType, int blockSize, int* dataType, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
 int kz_host_transform_inverse(int type, int blockSize, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
 // run fn(i) for i in [0, n) on host threads (blocks are independent)
-void kz_parallel_for(int n, int maxThreads, void (*fn)(int, void*), void* arg);
+void kz_parallel_for(int n, int maxThreads, void (*fn)(int, void*), void* arg);   // kz_host.hip: persistent pool
+int kz_usable_cpus();
 
 // timing helpers
 void kz_stage_begin(kz_ctx*, hipEvent_t* e0);

@@ -496,12 +496,23 @@ int utf_forward(int* dataType, const u8* src, int n, u8* dst, int dstCap, int* p
   else while (start < 4 && utf8_lead_ok(src[start]) == 0) start++;
   if (mustValidate && !utf_validate(src, start, body - start)) return 0;
   if (dataType) *dataType = KZ_DT_UTF8;
-  // occurrences per key, later the alias per key: 16 MiB, kept per host thread and cleaned by key (a block touches < 32768 keys)
-  static thread_local std::vector<int32_t> seen;
-  if (seen.empty()) seen.assign((size_t)1 << 22, 0);
+  // occurrences per key, later the alias per key.  The reference indexes an int[1 << 22] by key (UTFCodec.java:128); a block has
+  // fewer than 32768 distinct keys, so a 65536-slot open-addressing map (512 KiB per host thread, cache resident, cleaned by slot)
+  // gives the same answers
   struct Sym { int32_t key, freq; };
+  struct KeyMap {
+    std::vector<uint32_t> key, val; std::vector<uint32_t> used;
+    KeyMap() : key(65536, 0xFFFFFFFFu), val(65536, 0) {}
+    uint32_t& at(uint32_t k) {                                   // the slot of k, claimed (value 0) when new
+      uint32_t h = (k * 2654435761u) >> 16;
+      while (key[h] != k) { if (key[h] == 0xFFFFFFFFu) { key[h] = k; val[h] = 0; used.push_back(h); break; } h = (h + 1) & 0xFFFF; }
+      return val[h];
+    }
+    void clear() { for (uint32_t h : used) key[h] = 0xFFFFFFFFu; used.clear(); }
+  };
+  static thread_local KeyMap seenMap;
+  struct Clean { KeyMap& m; ~Clean() { m.clear(); } } clean_{seenMap};
   std::vector<Sym> syms;
-  struct Clean { std::vector<int32_t>& t; std::vector<Sym>& s; ~Clean() { for (const Sym& x : s) t[x.key] = 0; } } clean_{seen, syms};
   bool ok = true;
   for (int i = start; i < body;) {
     u32 key;
@@ -509,15 +520,16 @@ int utf_forward(int* dataType, const u8* src, int n, u8* dst, int dstCap, int* p
     ok = s != 0;
     if (s == 3) ok = ok && src[i + 2] >= 0x80 && src[i + 2] <= 0xBF;                                  // :140-145
     if (s == 4) ok = ok && ((((u32)src[i + 2] << 8) | src[i + 3]) & 0xC0C0) == 0x8080;
-    if (seen[key] == 0) { syms.push_back(Sym{(int32_t)key, 0}); ok = ok && syms.size() < 32768; }
+    uint32_t& cnt = seenMap.at(key);
+    if (cnt == 0) { syms.push_back(Sym{(int32_t)key, 0}); ok = ok && syms.size() < 32768; }
     if (!ok) break;
-    seen[key]++;
+    cnt++;
     i += s;
   }
   const int nsym = (int)syms.size();
   const int maxTarget = n - n / 10;
   if (!ok || nsym == 0 || 3 * nsym + 6 >= maxTarget) return 0;
-  for (Sym& s : syms) s.freq = seen[s.key];
+  for (Sym& s : syms) s.freq = (int32_t)seenMap.at((uint32_t)s.key);
   // most frequent first; equal counts: larger key first (the reference sorts ascending by (freq, key) and reads backwards)
   std::sort(syms.begin(), syms.end(), [](const Sym& a, const Sym& b) { return a.freq != b.freq ? a.freq > b.freq : a.key > b.key; });
   int at = 2;
@@ -528,7 +540,7 @@ int utf_forward(int* dataType, const u8* src, int n, u8* dst, int dstCap, int* p
     dst[at] = (u8)(key >> 16); dst[at + 1] = (u8)(key >> 8); dst[at + 2] = (u8)key;
     at += 3;
     estimate += (r < 128) ? syms[r].freq : 2 * (int64_t)syms[r].freq;
-    seen[key] = (r < 128) ? r : (0x10080 | ((r << 1) & 0xFF00) | (r & 0x7F));                        // two-byte alias + its size in bits 16..
+    seenMap.at((uint32_t)key) = (uint32_t)((r < 128) ? r : (0x10080 | ((r << 1) & 0xFF00) | (r & 0x7F)));                        // two-byte alias + its size in bits 16..
   }
   if (estimate >= maxTarget) return 0;
   for (int i = 0; i < start; i++) dst[at++] = src[i];
@@ -536,7 +548,7 @@ int utf_forward(int* dataType, const u8* src, int n, u8* dst, int dstCap, int* p
   while (i < body) {
     u32 key;
     i += utf8_key(src + i, &key);
-    const u32 alias = (u32)seen[key];
+    const u32 alias = seenMap.at(key);
     dst[at++] = (u8)alias;
     dst[at] = (u8)(alias >> 8);
     at += alias >> 16;

@@ -168,7 +168,21 @@ typedef struct { uint64_t seed; } kzo_jrandom;
 void    kzo_jrandom_init(kzo_jrandom* r, int64_t seed);
 int32_t kzo_jrandom_next_int(kzo_jrandom* r, int32_t bound);
 
+/* scratch allocation of the oracle's sources: big buffers are parked per thread instead of going back to the kernel (kzo_alloc.c) */
+void*   kzo_malloc(size_t n);
+void*   kzo_calloc(size_t a, size_t b);
+void*   kzo_realloc(void* p, size_t n);
+void    kzo_free(void* p);
+void    kzo_alloc_thread_cleanup(void);
+
 #ifdef __cplusplus
 }
+#endif
+#ifndef KZO_NO_ALLOC_MACROS
+#include <stdlib.h>
+#define malloc kzo_malloc
+#define calloc kzo_calloc
+#define realloc kzo_realloc
+#define free kzo_free
 #endif
 #endif

@@ -9,21 +9,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <pthread.h>
-#include <malloc.h>
 
 static int ilog2(uint32_t x) { return 31 - __builtin_clz(x); }
-
-/* The baseline runs one block per thread on up to hundreds of threads: keep multi-megabyte scratch on the
- * per-thread malloc arenas instead of mmap/munmap per block (kernel mm lock contention would otherwise
- * dominate and make the CPU baseline look slower than it is). */
-static void tune_malloc(void) {
-  static int done = 0;
-  if (done) return;
-  done = 1;
-  mallopt(M_MMAP_THRESHOLD, 1 << 30);
-  mallopt(M_TRIM_THRESHOLD, 1 << 30);
-  mallopt(M_TOP_PAD, 64 << 20);
-}
 
 /* ---------------- dispatch ---------------- */
 /* The two entries of the context map that TEXT reads besides "dataType": "entropy" selects TextCodec1 / TextCodec2
@@ -424,8 +411,7 @@ static void* enc_worker(void* arg) {
     if (b >= j->nblocks) break;
     int64_t off = (int64_t)b * j->blockSize;
     int len = (int)((j->n - off) < j->blockSize ? (j->n - off) : j->blockSize);
-    size_t cap = (size_t)len + (len >> 3) + 1024;
-    j->outs[b] = (uint8_t*)malloc(cap);
+    size_t cap = (size_t)j->blockSize + ((size_t)j->blockSize >> 3) + 1024;   /* its slot of the slab */
     j->bits[b] = kzo_encode_block_y(j->transformType, j->entropyType, j->chkKind, j->blockSize, j->src + off, len, j->outs[b], cap, NULL, NULL);
     if (j->bits[b] < 0) j->fail = (j->bits[b] == -13) ? 13 : 1;
   }
@@ -439,10 +425,13 @@ int64_t kzo_compress(uint64_t transformType, int entropyType, int blockSize, con
 
 int64_t kzo_compress_x(uint64_t transformType, int entropyType, int blockSize, int chkKind, const uint8_t* src,
                        int64_t n, uint8_t* dst, int64_t dstCap, int jobs) {
-  tune_malloc();
   int nblocks = (int)((n + blockSize - 1) / blockSize);
   uint8_t** outs = (uint8_t**)calloc((size_t)nblocks + 1, sizeof(uint8_t*));
   int64_t* bits = (int64_t*)calloc((size_t)nblocks + 1, sizeof(int64_t));
+  /* one slab for the block streams (only the bytes written are ever touched) instead of one allocation per block */
+  const size_t slot = (size_t)blockSize + ((size_t)blockSize >> 3) + 1024;
+  uint8_t* slab = (uint8_t*)malloc(slot * (size_t)(nblocks > 0 ? nblocks : 1));
+  for (int b = 0; b < nblocks; b++) outs[b] = slab + slot * (size_t)b;
   pthread_mutex_t mu; pthread_mutex_init(&mu, NULL);
   int next = 0;
   enc_job job = { transformType, entropyType, blockSize, chkKind, src, n, nblocks, outs, bits, &next, &mu, 0 };
@@ -470,7 +459,7 @@ int64_t kzo_compress_x(uint64_t transformType, int entropyType, int blockSize, i
     kzo_obs_free(&s);
   }
   if (job.fail == 13) ret = -13;                                   /* a block's transform threw: ERR_PROCESS_BLOCK */
-  for (int b = 0; b < nblocks; b++) free(outs[b]);
+  free(slab);
   free(outs); free(bits); pthread_mutex_destroy(&mu);
   return ret;
 }
@@ -502,7 +491,6 @@ static void* dec_worker(void* arg) {
 }
 
 int64_t kzo_decompress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstCap, int jobs) {
-  tune_malloc();
   kzo_ibs s; kzo_ibs_init(&s, src, (uint64_t)n * 8);
   /* header checks in the reference's order, returning -(Error.java code) (CompressedInputStream.java:359-478) */
   if (kzo_ibs_read(&s, 32) != 0x4B414E5A) return -15;              /* ERR_INVALID_FILE :367-368 */

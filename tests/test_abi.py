@@ -149,3 +149,41 @@ def test_reference_patch_applies():
             shutil.copy(os.path.join(ref, "src/main/java/io/github/flanglet/kanzi", rel), dst)
         r = subprocess.run(["patch", "-p1", "--dry-run", "-i", os.path.join(ROOT, "integration", "kanzi-hip.patch")], cwd=tmp, capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_patch_hooks_exist_in_the_java_adapters():
+    """Every io.github.flanglet.kanzi.hip.<Class>.<method>( the patch calls is a static method of integration/java/<Class>.java with
+    that many parameters (no JDK here: the cheapest check that the patch and the adapters agree), both batched hooks are there (the
+    writer's processBlock and, since round 3, the reader's), and the Java sources have balanced brackets."""
+    patch = open(os.path.join(ROOT, "integration", "kanzi-hip.patch")).read()
+    added = "\n".join(l[1:] for l in patch.splitlines() if l.startswith("+") and not l.startswith("+++"))
+    jdir = os.path.join(ROOT, "integration", "java")
+
+    def args_at(txt, i):                                                  # number of top-level arguments of the call opening at txt[i] == "("
+        depth, n, any_ = 0, 0, False
+        for ch in txt[i:]:
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+                if depth == 0:
+                    return n + 1 if any_ else 0
+            elif ch == "," and depth == 1:
+                n += 1
+            elif not ch.isspace():
+                any_ = True
+        raise AssertionError("unbalanced")
+
+    calls = list(re.finditer(r"io\.github\.flanglet\.kanzi\.hip\.(\w+)\.(\w+)\(", added))
+    assert {(m.group(1), m.group(2)) for m in calls} >= {("HipBlockBatch", "encode"), ("HipBlockBatch", "decode"), ("HipRuntime", "enabled")}
+    for m in calls:
+        cls, meth = m.group(1), m.group(2)
+        src = re.sub(r"<[\w, ]*>", "", open(os.path.join(jdir, cls + ".java")).read())     # generic parameters carry commas
+        d = re.search(r"public static [\w\[\]]+ " + meth + r"\(", src)
+        assert d, (cls, meth)
+        assert args_at(src, d.end() - 1) == args_at(added, m.end() - 1), (cls, meth)
+    assert "CompressedInputStream.java" in patch and "HipBlockBatch.decode" in patch and "this.maxBufferId" in added
+    for f in os.listdir(jdir):
+        src = re.sub(r'"(\\.|[^"\\])*"|//[^\n]*|/\*.*?\*/', "", open(os.path.join(jdir, f)).read(), flags=re.S)
+        for a, b in ("()", "{}", "[]"):
+            assert src.count(a) == src.count(b), (f, a)

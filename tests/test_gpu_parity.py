@@ -1127,3 +1127,87 @@ def test_text_block_size_is_fixed_at_call_time(ctx):
     with pytest.raises(kz.KanziError) as e:
         ctx.set_entropy(9)                                                # TPAQX: TEXT's extra hash bit is not modelled
     assert e.value.code == 3
+
+
+def test_full_size_batch_of_45_blocks_matches_oracle(ctx):
+    """the decoder's cost-class schedule (batches >= 32 blocks: four streams, "expensive first") and the suffix sort's
+    bucket path at the full 4 MiB block size, compared with the ORACLE and not just round-tripped: 45 device-resident blocks (9 of
+    every synthetic class, the last one ragged) through kz_encode_blocks -> every block stream equals the oracle's .knz payload;
+    kz_decode_blocks of the batch restores the input."""
+    torch = pytest.importorskip("torch")
+    bs, nb = 4 * 1024 * 1024, 45
+    host = np.stack([datagen.block(100 + i, bs) for i in range(nb)])
+    lens = np.full(nb, bs, dtype=np.int32)
+    lens[-1] = 2242560                                                    # silesia.tar's tail
+    ostride = kz.max_block_stream_bytes(bs)
+    d_in = torch.from_numpy(host).cuda()
+    d_out = torch.zeros((nb, ostride), dtype=torch.uint8, device="cuda")
+    res = kz.encode_blocks(ctx, "BWT+RANK+ZRLT", "ANS0", d_in.data_ptr(), bs, lens, d_out.data_ptr(), ostride, kz.MEM_DEVICE)
+    assert all(r.status == 0 for r in res)
+    out = d_out.cpu().numpy()
+    bits = [int(r.bits) for r in res]
+    data = host.reshape(-1)[:(nb - 1) * bs + int(lens[-1])]
+    knz = kz.knz_assemble("BWT+RANK+ZRLT", "ANS0", bs, len(data), [out[i, :(bits[i] + 7) // 8].tobytes() for i in range(nb)], bits)
+    ref = oracle.compress("BWT+RANK+ZRLT", "ANS0", bs, data, jobs=min(16, os.cpu_count() or 1))
+    assert knz == ref, (len(knz), len(ref))
+    d_dec = torch.zeros((nb, bs), dtype=torch.uint8, device="cuda")
+    res2 = kz.decode_blocks(ctx, "BWT+RANK+ZRLT", "ANS0", bs, d_out.data_ptr(), ostride, np.array(bits, dtype=np.int64), d_dec.data_ptr(), bs, kz.MEM_DEVICE)
+    assert [r.length for r in res2] == list(lens) and all(r.status == 0 for r in res2)
+    dec = d_dec.cpu().numpy()
+    assert np.array_equal(dec[:-1], host[:-1]) and np.array_equal(dec[-1, :lens[-1]], host[-1, :lens[-1]])
+
+
+@pytest.mark.parametrize("level", [5, 6, 3])
+def test_host_stage_pipeline_gives_the_same_blocks(ctx, monkeypatch, level):
+    """Chains led by TEXT / UTF on large batches run the host stages of chunk k+1 under the GPU work of chunk k (encode) and the host
+    inverse of chunk k under the GPU work of chunk k+1 (decode).  Forced here with 8-block chunks on 44 blocks (ragged last chunk),
+    host and device memory: every block stream equals the oracle's, decoding restores the input."""
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("KZ_HOST_CHUNK", "8")
+    monkeypatch.setenv("KZ_HOST_CHUNK_DEC", "8")
+    chain, ent = kz.level_chain(level)
+    c = textgen.cases()
+    bs, nb = 65536, 44
+    pool = c["english"] + c["utf8"] + c["xml"] + datagen.stream(6, bs).tobytes() + c["english_crlf"] + c["many_words"] + c["utf8_bom"] + c["random"]
+    data = (pool * (nb * bs // len(pool) + 1))[:nb * bs]
+    blocks = np.frombuffer(data, dtype=np.uint8).reshape(nb, bs).copy()
+    blocks[7, :10] = 0                                                    # a block TEXT declines next to ones it takes
+    lens = np.full(nb, bs, dtype=np.int32)
+    lens[-1] = 12345
+    lens[3] = 9                                                           # a copy block (<= 15 bytes) in the middle of a chunk
+    ostride = kz.max_block_stream_bytes(bs)
+    ctx.set_block_size(bs)
+    try:
+        ref = [oracle.encode_block(chain, ent, blocks[i, :lens[i]], block_size=bs) for i in range(nb)]
+        out_h = np.zeros((nb, ostride), dtype=np.uint8)
+        res_h = kz.encode_blocks(ctx, chain, ent, blocks, bs, lens, out_h, ostride)
+        d_in = torch.from_numpy(blocks).cuda()
+        d_out = torch.zeros((nb, ostride), dtype=torch.uint8, device="cuda")
+        res_d = kz.encode_blocks(ctx, chain, ent, d_in.data_ptr(), bs, lens, d_out.data_ptr(), ostride, kz.MEM_DEVICE)
+        out_d = d_out.cpu().numpy()
+        flags = set()
+        for i in range(nb):
+            s, w, sf, pl = ref[i]
+            assert res_h[i].status == 0 and res_d[i].status == 0
+            assert (res_h[i].bits, res_h[i].skipFlags, res_h[i].length) == (w, sf, pl) == (res_d[i].bits, res_d[i].skipFlags, res_d[i].length), i
+            assert out_h[i, :(w + 7) // 8].tobytes() == s and out_d[i, :(w + 7) // 8].tobytes() == s, i
+            flags.add(sf)
+        assert len(flags) >= 3                                            # TEXT taken / UTF taken / neither
+        bits = np.array([r.bits for r in res_d], dtype=np.int64)
+        dec_h = np.zeros((nb, bs), dtype=np.uint8)
+        res2 = kz.decode_blocks(ctx, chain, ent, bs, out_h, ostride, bits, dec_h, bs)
+        d_dec = torch.zeros((nb, bs), dtype=torch.uint8, device="cuda")
+        res3 = kz.decode_blocks(ctx, chain, ent, bs, d_out.data_ptr(), ostride, bits, d_dec.data_ptr(), bs, kz.MEM_DEVICE)
+        dec_d = d_dec.cpu().numpy()
+        for i in range(nb):
+            assert res2[i].status == 0 and res3[i].status == 0 and res2[i].length == lens[i] == res3[i].length, i
+            assert np.array_equal(dec_h[i, :lens[i]], blocks[i, :lens[i]]) and np.array_equal(dec_d[i, :lens[i]], blocks[i, :lens[i]]), i
+        # a damaged TEXT block in the middle of a chunk fails alone (ERR_PROCESS_BLOCK), its neighbours decode
+        if level == 5:
+            bad = out_h.copy()
+            victim = next(i for i in range(8, nb) if not (res_h[i].skipFlags & 0x80))
+            bad[victim, 40:60] ^= 0x5A
+            res4 = kz.decode_blocks(ctx, chain, ent, bs, bad, ostride, bits, dec_h, bs)
+            assert all(res4[i].status == 0 for i in range(nb) if i != victim)
+    finally:
+        ctx.set_block_size(4 * 1024 * 1024)
