@@ -102,6 +102,9 @@ int32_t     kz_ctx_get_data_type(kz_ctx* ctx);
  * in the new mask, 0 if the topology is not visible (nothing changed), <0 on error.  The reference has no equivalent: its
  * task pool is one JVM on one socket (K/app/BlockCompressor.java:199-206). */
 int32_t     kz_pin_to_device_numa(int32_t deviceId);
+/* host CPUs the library's thread pool (TEXT / UTF stages, staging copies, bit assembly) will use: the process's affinity mask cut
+ * down to its cgroup CPU quota, if any */
+int32_t     kz_host_cpus(void);
 /* HIP stream the context launches on (as void* = hipStream_t) so callers can bracket it with events */
 void*       kz_ctx_stream(kz_ctx* ctx);
 

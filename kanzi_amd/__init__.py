@@ -73,6 +73,7 @@ def load_library():
         "kz_last_error": (c.c_char_p, [vp]),
         "kz_ctx_stream": (vp, [vp]),
         "kz_pin_to_device_numa": (c.c_int32, [c.c_int32]),
+        "kz_host_cpus": (c.c_int32, []),
         "kz_ctx_set_checksum": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_set_skip_blocks": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_set_block_size": (c.c_int32, [vp, c.c_int32]),
@@ -120,7 +121,7 @@ def load_library():
     return L
 
 
-ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_error", "kz_ctx_stream", "kz_pin_to_device_numa", "kz_ctx_set_checksum",
+ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_error", "kz_ctx_stream", "kz_pin_to_device_numa", "kz_host_cpus", "kz_ctx_set_checksum",
                "kz_ctx_set_data_type", "kz_ctx_get_data_type", "kz_ctx_set_skip_blocks", "kz_ctx_set_block_size", "kz_ctx_set_entropy",
                "kz_transform_forward", "kz_transform_inverse", "kz_transform_max_encoded_len", "kz_host_stage_forward", "kz_host_stage_inverse",
                "kz_entropy_encode", "kz_entropy_decode", "kz_encode_blocks", "kz_decode_blocks",
@@ -654,6 +655,11 @@ def knz_index(data):
         raise KanziError(-nb, "knz_index")
     return {"transform": tt.value, "entropy": et.value, "blockSize": bs.value, "inputSize": isz.value, "checksum": chk.value,
             "blocks": [(int(off[i]), int(bits[i])) for i in range(nb)]}
+
+
+def usable_cpus():
+    """CPUs this process can actually use: its affinity mask cut down to the cgroup CPU quota, if any (kz_host.hip)."""
+    return int(load_library().kz_host_cpus())
 
 
 def pin_host_threads_to_gpu(device, world=2):

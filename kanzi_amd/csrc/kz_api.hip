@@ -47,6 +47,16 @@ extern "C" void kz_ctx_destroy(kz_ctx* ctx) {
   if (ctx->arena) hipFree(ctx->arena);
   for (int i = 0; i < 5; i++) { if (ctx->side[i]) hipStreamDestroy(ctx->side[i]); if (ctx->evJoin[i]) hipEventDestroy(ctx->evJoin[i]); }
   if (ctx->hpin) hipHostFree(ctx->hpin);
+  for (int i = 0; i < 2; i++) {
+    if (ctx->pinIn[i].p) hipHostFree(ctx->pinIn[i].p);
+    if (ctx->pinOut[i].p) hipHostFree(ctx->pinOut[i].p);
+    if (ctx->hsIn[i].p) hipHostFree(ctx->hsIn[i].p);
+    if (ctx->hsOut[i].p) hipHostFree(ctx->hsOut[i].p);
+    if (ctx->devIn[i].p) hipFree(ctx->devIn[i].p);
+    if (ctx->devOut[i].p) hipFree(ctx->devOut[i].p);
+  }
+  if (ctx->copyUp) hipStreamDestroy(ctx->copyUp);
+  if (ctx->copyDown) hipStreamDestroy(ctx->copyDown);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -537,9 +547,10 @@ static int host_prefix(kz_ctx* ctx, const int* types, int nb) {          // numb
 struct HostPre {
   std::vector<int32_t> outLen, skip, dtype;
   std::vector<uint8_t> changed;
-  std::unique_ptr<uint8_t[]> store;
+  std::unique_ptr<uint8_t[]> own;                   // the slots' memory when the caller gave none
+  uint8_t* store = nullptr;
   int64_t slot = 0;
-  const uint8_t* data(int b) const { return store.get() + (int64_t)b * slot; }
+  const uint8_t* data(int b) const { return store + (int64_t)b * slot; }
 };
 struct HostFwd {
   const int* types; int hp; int entropy; int cap; int blockSize;
@@ -561,7 +572,7 @@ static void host_forward_block(int b, void* arg) {
   const uint8_t* cur = H.hsrc + (int64_t)b * H.hstride;
   int dt = kz_host_block_data_type(cur, n, KZ_DT_UNDEFINED);            // CompressedOutputStream.java:795-804
   int len = n;
-  uint8_t* mine = P.store.get() + (int64_t)b * P.slot;
+  uint8_t* mine = P.store + (int64_t)b * P.slot;
   uint8_t* out = mine;                                                  // ping-pong between the block's slot and a scratch buffer
   for (int i = 0; i < H.hp; i++) {
     int produced = 0;
@@ -578,16 +589,37 @@ static void host_forward_block(int b, void* arg) {
   }
 }
 // runs the chain's host stages over B blocks in host memory
+static int64_t host_pre_slot(int cap) { return (int64_t)kz_align((size_t)cap + 64, 64); }
+// store: B slots of host_pre_slot(cap) bytes for the stages' outputs (pinned staging of the pipelines), or null
 static void host_prestage(const int* types, int hp, int entropy, int blockSize, int cap, const uint8_t* hsrc, int64_t hstride,
-                          const int32_t* lengths, const int32_t* copy, int B, HostPre& P) {
+                          const int32_t* lengths, const int32_t* copy, int B, HostPre& P, uint8_t* store = nullptr) {
   P.outLen.assign(B, 0); P.skip.assign(B, 0xFF); P.dtype.assign(B, 0); P.changed.assign(B, 0);
-  P.slot = (int64_t)kz_align((size_t)cap + 64, 64);
-  P.store.reset(new uint8_t[(size_t)P.slot * (size_t)B + 64]);        // uninitialised: only the bytes a stage writes are touched
+  P.slot = host_pre_slot(cap);
+  if (store) P.store = store;
+  else { P.own.reset(new uint8_t[(size_t)P.slot * (size_t)B + 64]); P.store = P.own.get(); }   // uninitialised: only the bytes a stage writes are touched
   HostFwd H;
   H.types = types; H.hp = hp; H.entropy = entropy; H.cap = cap; H.blockSize = blockSize;
   H.hsrc = hsrc; H.hstride = hstride; H.lengths = lengths; H.copy = copy; H.P = &P;
   kz_parallel_for(B, KZ_HOST_STAGE_THREADS, host_forward_block, &H);
 }
+HostPre* kz_host_prestage(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize, const uint8_t* hsrc, int64_t hstride,
+                          const int32_t* lengths, int32_t nBlocks, int slotId) {
+  int types[8];
+  const int nb = split_types(transformType, types);
+  int hp = 0;
+  while (hp < nb && kz_is_host_transform(types[hp])) hp++;
+  if (hp == 0 || ctx->skipBlocks || nBlocks <= 0) return nullptr;   // ("skipBlocks": the copy decision comes from the device first)
+  int maxN = 0;
+  for (int b = 0; b < nBlocks; b++) maxN = std::max(maxN, lengths[b]);
+  HostPre* P = new HostPre();
+  const int cap = seq_max_len(types, nb, maxN);
+  uint8_t* store = nullptr;
+  if (slotId >= 0 && slotId < 2 && hipSetDevice(ctx->device) == hipSuccess &&
+      kz_stage_reserve(ctx, ctx->hsOut[slotId], (size_t)host_pre_slot(cap) * (size_t)nBlocks + 64, true) == 0) store = ctx->hsOut[slotId].p;
+  host_prestage(types, hp, (int)entropyType, blockSize, cap, hsrc, hstride, lengths, nullptr, nBlocks, *P, store);
+  return P;
+}
+void kz_host_pre_free(HostPre* p) { delete p; }
 struct HostInv {
   int device; const int* types; int hp; int blockSize; int cap;
   uint8_t* dbuf; int64_t dstride; int64_t slotCap; bool hostMem;        // the blocks' slots: in HBM (copied over and back) or in host memory
@@ -924,23 +956,33 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
     const int CH = host_chunk_blocks();
     const int nch = (B + CH - 1) / CH;
     const bool hostIn = memKind == KZ_MEM_HOST;
-    struct Chunk { HostPre P; std::unique_ptr<uint8_t[]> copy; int rc = 0; };
+    struct Chunk { HostPre P; int rc = 0; };
     std::vector<Chunk> ck(nch);
     const int dev = ctx->device;
+    for (int q = 0; q < 2; q++) {                                   // pinned, kept by the context: no fresh pages per chunk, DMA both ways
+      int rc = kz_stage_reserve(ctx, ctx->hsOut[q], (size_t)host_pre_slot(maxLen) * (size_t)CH + 64, true);
+      if (!rc && !hostIn) rc = kz_stage_reserve(ctx, ctx->hsIn[q], (size_t)CH * (size_t)maxN + 64, true);
+      if (rc) return rc;
+    }
+    const bool trace = getenv("KZ_TRACE_PIPE") != nullptr;
+    const auto tStart = std::chrono::steady_clock::now();
+    auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tStart).count(); };
     auto stage = [&](int k) {
+      const double t0 = ms();
       const int b0 = k * CH, cnt = std::min(CH, B - b0);
       const uint8_t* hsrc = in + (int64_t)b0 * inStride;
       int64_t hstride = inStride;
       if (!hostIn) {                                                // device input: one copy back for the host stages (legacy stream:
-        ck[k].copy.reset(new uint8_t[(size_t)cnt * (size_t)maxN + 64]);   // it does not wait for the context's non-blocking stream)
+        uint8_t* back = ctx->hsIn[k & 1].p;                         // it does not wait for the context's non-blocking stream)
         if (hipSetDevice(dev) != hipSuccess) { ck[k].rc = -KZ_ERR_DEVICE; return; }
         if (inStride == (int64_t)maxN) {
-          if (hipMemcpy(ck[k].copy.get(), hsrc, (size_t)cnt * (size_t)maxN, hipMemcpyDeviceToHost) != hipSuccess) { ck[k].rc = -KZ_ERR_DEVICE; return; }
-        } else if (hipMemcpy2D(ck[k].copy.get(), (size_t)maxN, hsrc, (size_t)inStride, (size_t)maxN, (size_t)cnt, hipMemcpyDeviceToHost) != hipSuccess) { ck[k].rc = -KZ_ERR_DEVICE; return; }
-        hsrc = ck[k].copy.get(); hstride = maxN;
+          if (hipMemcpy(back, hsrc, (size_t)cnt * (size_t)maxN, hipMemcpyDeviceToHost) != hipSuccess) { ck[k].rc = -KZ_ERR_DEVICE; return; }
+        } else if (hipMemcpy2D(back, (size_t)maxN, hsrc, (size_t)inStride, (size_t)maxN, (size_t)cnt, hipMemcpyDeviceToHost) != hipSuccess) { ck[k].rc = -KZ_ERR_DEVICE; return; }
+        hsrc = back; hstride = maxN;
       }
-      host_prestage(types, hp, (int)entropyType, blockSize, maxLen, hsrc, hstride, lengths + b0, nullptr, cnt, ck[k].P);
-      ck[k].copy.reset();
+      const double t1 = ms();
+      host_prestage(types, hp, (int)entropyType, blockSize, maxLen, hsrc, hstride, lengths + b0, nullptr, cnt, ck[k].P, ctx->hsOut[k & 1].p);
+      if (trace) fprintf(stderr, "[pipe] stage %d: copy back %.0f ms, host stages %.0f ms (at %.0f)\n", k, t1 - t0, ms() - t1, ms());
     };
     stage(0);
     for (int k = 0; k < nch; k++) {
@@ -948,10 +990,13 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
       if (k + 1 < nch) ahead = std::thread(stage, k + 1);
       const int b0 = k * CH, cnt = std::min(CH, B - b0);
       int rc = ck[k].rc;
+      const double tg = ms();
       if (!rc) rc = kz_encode_blocks_pre(ctx, transformType, entropyType, blockSize, in + (int64_t)b0 * inStride, inStride, lengths + b0, cnt,
                                          out + (int64_t)b0 * outStride, outStride, results + b0, memKind, &ck[k].P);
       ck[k].P = HostPre();
+      const double tj = ms();
       if (ahead.joinable()) ahead.join();
+      if (trace) fprintf(stderr, "[pipe] chunk %d: gpu %.0f ms, waited %.0f ms for the next stage (at %.0f)\n", k, tj - tg, ms() - tj, ms());
       if (rc) { if (rc == -KZ_ERR_DEVICE && !ctx->err[0]) snprintf(ctx->err, sizeof(ctx->err), "host stage: copy from the device failed"); return rc; }
     }
     return 0;

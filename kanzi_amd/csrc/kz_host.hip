@@ -5,6 +5,7 @@
 // and several callers (a batch's host stages, the stream writer's assembly of the previous batch) share one set of threads.
 #include "kz_internal.h"
 #include <sched.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -27,12 +28,33 @@ struct Pool {
   std::vector<PfJob*> active;
   int threads = 0, cap = 1;
 };
+// CPUs this process can actually use: its affinity mask, cut down to the cgroup's CPU bandwidth quota when there is one.  A
+// container may see every CPU of the host and still be allowed only N CPU-seconds per second (cgroup v2 cpu.max "quota period",
+// v1 cpu.cfs_quota_us / cpu.cfs_period_us); running more busy threads than that makes the kernel freeze ALL threads of the group
+// for the rest of each period -- including the one that drives the GPU (measured on the MI355X box: 256 CPUs visible, quota 16:
+// 128 host-stage threads stretched every GPU call of the pipeline from 0.21 s to 0.55 s).
+int quota_cpus() {
+  long long quota = -1, period = 100000;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64] = {0};
+    if (fscanf(f, "%63s %lld", q, &period) >= 1 && strcmp(q, "max") != 0) quota = atoll(q);
+    fclose(f);
+  } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+    if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+    fclose(g);
+    if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
+  }
+  if (quota <= 0 || period <= 0) return 1 << 30;
+  return (int)std::max<long long>(1, (quota + period - 1) / period);
+}
 int usable_cpus() {
+  static const int quota = quota_cpus();
   cpu_set_t set;
   CPU_ZERO(&set);
-  if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) return c; }
-  const int hw = (int)std::thread::hardware_concurrency();
-  return hw > 0 ? hw : 1;
+  int c = 0;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) c = CPU_COUNT(&set);
+  if (c <= 0) { const int hw = (int)std::thread::hardware_concurrency(); c = hw > 0 ? hw : 1; }
+  return std::min(c, quota);
 }
 Pool& pool() {
   static Pool* p = new Pool();     // never destroyed: its detached threads may outlive static destructors
@@ -59,6 +81,7 @@ void worker(Pool* P) {
 
 // the CPUs this process may run on (N ranks on one host are pinned to their GPU's NUMA node: kz_pin_to_device_numa)
 int kz_usable_cpus() { return usable_cpus(); }
+extern "C" int32_t kz_host_cpus(void) { return usable_cpus(); }
 
 // fn(i, arg) for i in [0, n) on up to maxThreads threads (the caller is one of them); returns when all are done.  May be called
 // from several host threads at once.
@@ -83,4 +106,14 @@ void kz_parallel_for(int n, int maxThreads, void (*fn)(int, void*), void* arg) {
   job.done += did;
   P.finished.wait(lk, [&] { return job.workers == 0 && job.done >= n; });
   P.active.erase(std::find(P.active.begin(), P.active.end(), &job));
+}
+
+// grow-only staging buffer kept by the context: pinned host memory or HBM outside the arena
+int kz_stage_reserve(kz_ctx* ctx, kz_ctx::Stage& s, size_t need, bool pinned) {
+  if (need <= s.cap) return 0;
+  if (s.p) { if (pinned) hipHostFree(s.p); else hipFree(s.p); s.p = nullptr; s.cap = 0; }
+  need = kz_align(need + (need >> 4), 1 << 20);
+  if (pinned) KZ_HIP(hipHostMalloc((void**)&s.p, need, hipHostMallocDefault)); else KZ_HIP(hipMalloc((void**)&s.p, need));
+  s.cap = need;
+  return 0;
 }

@@ -61,6 +61,12 @@ struct kz_ctx {
   int64_t collectedBelow = 1;
   int64_t nextJob = 1;
   bool stopWorker = false;
+  // staging of the host-buffer stream calls (kz_compress / kz_decompress, kz_stream.hip): grow-only, two slots each
+  struct Stage { uint8_t* p = nullptr; size_t cap = 0; };
+  Stage pinIn[2], pinOut[2];       // pinned host memory (hipHostMalloc)
+  Stage devIn[2], devOut[2];       // HBM outside the arena (the arena is reset by every batched call)
+  Stage hsIn[2], hsOut[2];         // pinned: the host-stage pipeline's copy of a chunk's blocks / the stages' outputs (kz_api.hip)
+  hipStream_t copyUp = nullptr, copyDown = nullptr;
 };
 
 #define KZ_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
@@ -154,6 +160,15 @@ int kz_host_transform_inverse(int type, int blockSize, const uint8_t* src, int n
 // run fn(i) for i in [0, n) on host threads (blocks are independent)
 void kz_parallel_for(int n, int maxThreads, void (*fn)(int, void*), void* arg);   // kz_host.hip: persistent pool
 int kz_usable_cpus();
+struct HostPre;
+int kz_stage_reserve(kz_ctx* ctx, kz_ctx::Stage& s, size_t need, bool pinned);   // grow-only staging buffer (kz_host.hip)
+int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize, const uint8_t* in, int64_t inStride,
+                             const int32_t* lengths, int32_t nBlocks, uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind, const HostPre* pre);
+// the host stages (TEXT / UTF) of nBlocks blocks in host memory, ahead of kz_encode_blocks_pre (null when the chain has none or they
+// cannot be run ahead); kz_host_pre_free releases it
+HostPre* kz_host_prestage(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize, const uint8_t* hsrc, int64_t hstride,
+                          const int32_t* lengths, int32_t nBlocks, int slotId);   // slotId 0/1: the outputs go to the context's pinned hsOut[slotId]
+void kz_host_pre_free(HostPre* p);
 
 // timing helpers
 void kz_stage_begin(kz_ctx*, hipEvent_t* e0);

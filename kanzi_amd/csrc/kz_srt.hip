@@ -142,9 +142,13 @@ __global__ void k_srt_ffin(const int32_t* __restrict__ d_len, int32_t* __restric
 
 // per-wave working set of k_srt_inv (up to 8 waves = 8 blocks per workgroup, see kz_place_blocks)
 struct SrtInvLds {
-  int32_t freq[256]; int32_t bstart[256]; int32_t bend[256]; int32_t wbase[256];
+  union { int32_t freq[256]; int32_t wbase[256]; };   // freq: header and bucket ranges only; wbase: the general loop's window bases
+  int32_t bstart[256]; int32_t bend[256];
   u8 order[256]; u8 r2s0[256];
-  u8 win[256][32];                   // next 32 ranks of every symbol
+  union {
+    u8 win[256][32];                 // general loop: next 32 ranks of every symbol
+    u8 ring[256][64];                // fast loop: slot t & 63 holds rank t of the symbol's bucket, valid from the cursor to the next multiple of 64
+  };
   int h, bad;
 };
 #define SRT_SYNC() __builtin_amdgcn_wave_barrier()   /* one wave per block: program order suffices, keep the compiler in line */
@@ -273,6 +277,72 @@ __global__ __launch_bounds__(512) void k_srt_inv(const u8* __restrict__ src, u8*
   // Every step needs the next rank of the symbol that just became current: a dependent load.  Each symbol's
   // next 32 ranks are therefore cached in LDS (8 KiB per block): a step is an LDS read, global memory is touched once
   // per 32 ranks of a symbol.  Ranks are readable below `count` only (s[-H..-1] is the header, still inside the block).
+  // list: position j -> lane j>>2, byte j&3
+  u32 list = (u32)r2s0[4 * lane] | ((u32)r2s0[4 * lane + 1] << 8) | ((u32)r2s0[4 * lane + 2] << 16) | ((u32)r2s0[4 * lane + 3] << 24);
+  int i = 0;
+  int c = (int)(__builtin_amdgcn_readfirstlane((int)list) & 0xFF);
+  if (!general) {
+    // ---- well-formed input (every bucket ends inside the payload): the fast loop (round 3).  A step is ONE LDS round trip: the
+    //      symbol's cursor / end and its 64-slot ring are read side by side (both addresses depend on c only), the zero run and the
+    //      next non-zero rank come out of a ballot rotated by the cursor on the scalar unit.  A ring is refilled when the cursor
+    //      reaches a multiple of 64: the load is issued at once and written to LDS one step later (or when its symbol comes
+    //      up again first), so the memory latency is off the dependent chain. ----
+    u8 (*ring)[64] = L.ring;
+    for (int sym = 0; sym < 256; sym++) {
+      const int32_t bs = bstart[sym];
+      const int32_t t = (bs & ~63) + lane;                         // slot `lane` holds rank t
+      if (t >= bs && t < bend[sym]) ring[sym][lane] = s[t];
+    }
+    SRT_SYNC();
+    int pendSym = -1, pendCnt = 0, pendAge = 0;
+    u32 vpend = 0;
+#define SRT_FLUSH() do { if (lane < pendCnt) ring[pendSym][lane] = (u8)vpend; pendSym = -1; SRT_SYNC(); } while (0)
+    while (i < count) {
+      if (pendSym == c) SRT_FLUSH();
+      const int32_t cur = bstart[c], end = bend[c];
+      const u32 v = ring[c][lane];
+      const int32_t fend = min(end, (cur & ~63) + 64);
+      const int avail = fend - cur;                                  // valid ranks in the ring: 0..64
+      const uint64_t nzm = kz_ballot(v != 0);
+      const int sh = cur & 63;
+      uint64_t rot = sh ? ((nzm >> sh) | (nzm << (64 - sh))) : nzm;  // bit j: rank cur + j is not zero
+      if (avail < 64) rot &= ((1ull << avail) - 1ull);
+      const int z = rot ? (int)__builtin_ctzll(rot) : avail;         // leading zero ranks = c repeats
+      int r = 0, emit, consumed;
+      bool moveC = false, removeC = false;
+      if (rot) { emit = z + 1; consumed = z + 1; r = __builtin_amdgcn_readlane((int)v, (cur + z) & 63); moveC = true; }
+      else if (fend >= end) { emit = avail + 1; consumed = avail; removeC = true; }   // bucket exhausted (:239-248)
+      else { emit = avail; consumed = avail; }                        // only zeros up to the ring's end, more to come
+      if (emit > count - i) { emit = count - i; moveC = false; removeC = false; }
+      if (lane < emit) o[i + lane] = (u8)c;
+      if (emit > 64 && lane == 0) o[i + 64] = (u8)c;
+      i += emit;
+      const int32_t ncur = cur + consumed;
+      if (lane == 0) bstart[c] = ncur;
+      if (consumed > 0 && ncur == fend && ncur < end) {               // ring used up, bucket goes on: fetch the next 64 ranks
+        if (pendSym >= 0) SRT_FLUSH();
+        pendCnt = min(64, end - ncur);
+        vpend = (lane < pendCnt) ? (u32)s[ncur + lane] : 0u;
+        pendSym = c; pendAge = 0;
+      }
+      if (moveC || (removeC && nbSymbols > 1)) {
+        if (removeC) { nbSymbols--; r = nbSymbols; }
+        const u32 nxt = KZ_DPP_SHL1(list);
+        const u32 shifted = (list >> 8) | (nxt << 24);
+        const int e = r - 4 * lane;                                   // bytes with position < r in this lane
+        const u32 mask = (e <= 0) ? 0u : ((e >= 4) ? 0xFFFFFFFFu : (0xFFFFFFFFu >> (8 * (4 - e))));
+        u32 nl = (shifted & mask) | (list & ~mask);
+        if (moveC && lane == (r >> 2)) { const int shb = 8 * (r & 3); nl = (nl & ~(0xFFu << shb)) | ((u32)c << shb); }
+        list = nl;
+        c = (int)(__builtin_amdgcn_readfirstlane((int)list) & 0xFF);
+      } else if (removeC) {
+        for (int k = i + lane; k < count; k += 64) o[k] = (u8)c;      // single symbol left with an empty bucket (:239-240)
+        i = count;
+      }
+      if (pendSym >= 0) { if (pendAge >= 1) SRT_FLUSH(); else pendAge++; }
+    }
+#undef SRT_FLUSH
+  } else {
   for (int sym = 0; sym < 256; sym++) {
     const int32_t bs = bstart[sym];
     const int32_t lim = min(bend[sym], count);
@@ -280,13 +350,10 @@ __global__ __launch_bounds__(512) void k_srt_inv(const u8* __restrict__ src, u8*
     if (lane == 0) wbase[sym] = bs;
   }
   SRT_SYNC();
-  // list: position j -> lane j>>2, byte j&3
-  u32 list = (u32)r2s0[4 * lane] | ((u32)r2s0[4 * lane + 1] << 8) | ((u32)r2s0[4 * lane + 2] << 16) | ((u32)r2s0[4 * lane + 3] << 24);
-  int i = 0;
-  int c = (int)(__builtin_amdgcn_readfirstlane((int)list) & 0xFF);
+  }
   // Well-formed input (frequencies add up to the payload: every bucket ends inside it) takes the tight loop; anything
   // else the general one, which also watches for buckets that run past the payload.
-  if (general) { SRT_INV_LOOP(1) } else { SRT_INV_LOOP(0) }
+  if (general) { SRT_INV_LOOP(1) }
   if (lane == 0) { d_len2[b] = bad ? 0 : count; d_flag[b] = bad ? 0 : 1; }
 }
 

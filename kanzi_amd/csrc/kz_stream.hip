@@ -9,6 +9,8 @@
 #include <memory>
 #include <thread>
 #include <atomic>
+#include <mutex>
+#include <condition_variable>
 
 namespace {
 struct HostBits {            // MSB-first writer (DefaultOutputBitStream.java:103-205)
@@ -192,16 +194,11 @@ extern "C" int32_t kz_knz_index(const uint8_t* src, int64_t n, uint64_t* transfo
 }
 
 
-// run fn(i) for i in [0, n) on a few host threads (blocks are independent)
+// run fn(i) for i in [0, n) on the host pool (blocks are independent)
 template <typename F>
-static void parallel_blocks(int n, F fn) {
-  const int hw = (int)std::thread::hardware_concurrency();
-  const int T = std::max(1, std::min(std::min(n, 16), hw > 0 ? hw : 1));
-  if (T == 1) { for (int i = 0; i < n; i++) fn(i); return; }
-  std::atomic<int> next(0);
-  std::vector<std::thread> th;
-  for (int t = 0; t < T; t++) th.emplace_back([&]() { for (;;) { const int i = next.fetch_add(1); if (i >= n) break; fn(i); } });
-  for (auto& x : th) x.join();
+static void parallel_blocks(int n, F fn, int maxThreads = 32) {
+  struct Thunk { static void run(int i, void* a) { (*(F*)a)(i); } };
+  kz_parallel_for(n, maxThreads, &Thunk::run, (void*)&fn);
 }
 
 // Ordered emission of a batch (CompressedOutputStream.java:1024-1035) at bit granularity.  The serial pass writes,
@@ -248,34 +245,136 @@ extern "C" int64_t kz_compress_bound(int64_t n, int32_t blockSize) {
   return 64 + nBlocks * (kz_max_block_stream_bytes((int32_t)std::min<int64_t>(n, blockSize)) + 24);
 }
 
+// ---- staging for the host-buffer stream calls: pinned host memory and HBM outside the arena, grow-only, kept by the context ----
+static int stage_reserve(kz_ctx* ctx, kz_ctx::Stage& s, size_t need, bool pinned) { return kz_stage_reserve(ctx, s, need, pinned); }
+static int stage_streams(kz_ctx* ctx) {
+  if (!ctx->copyUp) KZ_HIP(hipStreamCreateWithFlags(&ctx->copyUp, hipStreamNonBlocking));
+  if (!ctx->copyDown) KZ_HIP(hipStreamCreateWithFlags(&ctx->copyDown, hipStreamNonBlocking));
+  return 0;
+}
+static int stream_chunk_blocks(int blockSize) {                   // blocks per pipeline step of kz_compress: about 1 GiB of input
+  const char* e = getenv("KZ_STREAM_CHUNK");
+  if (e && atoi(e) > 0) return atoi(e);
+  return (int)std::max<int64_t>(8, std::min<int64_t>(2048, (1LL << 30) / blockSize));
+}
+struct BlockSizeScope {                                            // the context's "blockSize" entry = this stream's (TEXT reads it)
+  kz_ctx* c; int saved; bool savedSet;
+  BlockSizeScope(kz_ctx* c_, int v) : c(c_), saved(c_->blockSize), savedSet(c_->blockSizeSet) { c->blockSize = v; c->blockSizeSet = true; }
+  ~BlockSizeScope() { c->blockSize = saved; c->blockSizeSet = savedSet; }
+};
+
+// Inputs of several chunks: a three-stage pipeline like the reference's task pool (K/io/CompressedOutputStream.java:541-566 fills
+// `jobs` buffers, codes them side by side and emits in order).  Thread U stages chunk k+1 (host TEXT / UTF stages, copy into pinned
+// memory, H2D on its own stream), the calling thread codes chunk k on the GPU (HBM in, HBM out), thread D brings chunk k-1 back
+// (D2H of the bytes produced, ordered bit-granular emission into dst).  Blocks are independent: the stream is the same as the
+// one-batch-at-a-time form's.
+static int64_t compress_pipelined(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
+                                  const uint8_t* src, int64_t n, HostBits& bs, int64_t nblocks, int CH) {
+  const int nch = (int)((nblocks + CH - 1) / CH);
+  const int64_t oS = kz_max_block_stream_bytes(blockSize);
+  { int rc = stage_streams(ctx); if (rc) return rc; }
+  for (int i = 0; i < 2; i++) {
+    int rc = stage_reserve(ctx, ctx->pinIn[i], (size_t)CH * blockSize, true);
+    if (!rc) rc = stage_reserve(ctx, ctx->devIn[i], (size_t)CH * blockSize, false);
+    if (!rc) rc = stage_reserve(ctx, ctx->devOut[i], (size_t)CH * oS, false);
+    if (!rc) rc = stage_reserve(ctx, ctx->pinOut[i], (size_t)CH * oS, true);
+    if (rc) return rc;
+  }
+  struct Chunk { std::vector<int32_t> lens; std::vector<kz_block_result> res; HostPre* pre = nullptr; };
+  std::vector<Chunk> ck(nch);
+  std::mutex mu;
+  std::condition_variable cv;
+  int uploaded = 0, encoded = 0, emitted = 0, failed = 0;          // chunks through each stage (under mu)
+  auto fail = [&](int code) { std::lock_guard<std::mutex> g(mu); if (!failed) failed = code; cv.notify_all(); };
+  const int dev = ctx->device;
+  std::thread U([&]() {
+    if (hipSetDevice(dev) != hipSuccess) { fail(-KZ_ERR_DEVICE); return; }
+    for (int k = 0; k < nch; k++) {
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return failed || encoded >= k - 1; }); if (failed) return; }   // slot k & 1 is free
+      const int64_t b0 = (int64_t)k * CH;
+      const int cnt = (int)std::min<int64_t>(CH, nblocks - b0);
+      ck[k].lens.resize(cnt);
+      for (int i = 0; i < cnt; i++) ck[k].lens[i] = (int32_t)std::min<int64_t>(blockSize, n - (b0 + i) * blockSize);
+      const uint8_t* cs = src + b0 * blockSize;
+      ck[k].pre = kz_host_prestage(ctx, transformType, entropyType, blockSize, cs, blockSize, ck[k].lens.data(), cnt, k & 1);
+      uint8_t* pin = ctx->pinIn[k & 1].p;
+      const int64_t bytes = std::min<int64_t>((int64_t)cnt * blockSize, n - b0 * blockSize);
+      const int pieces = (int)((bytes + (8 << 20) - 1) / (8 << 20));
+      parallel_blocks(pieces, [&](int q) { const int64_t o = (int64_t)q << 23; memcpy(pin + o, cs + o, (size_t)std::min<int64_t>(8 << 20, bytes - o)); });
+      if (hipMemcpyAsync(ctx->devIn[k & 1].p, pin, (size_t)bytes, hipMemcpyHostToDevice, ctx->copyUp) != hipSuccess ||
+          hipStreamSynchronize(ctx->copyUp) != hipSuccess) { fail(-KZ_ERR_DEVICE); return; }
+      { std::lock_guard<std::mutex> g(mu); uploaded = k + 1; }
+      cv.notify_all();
+    }
+  });
+  std::thread D([&]() {
+    if (hipSetDevice(dev) != hipSuccess) { fail(-KZ_ERR_DEVICE); return; }
+    for (int k = 0; k < nch; k++) {
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return failed || encoded >= k + 1; }); if (failed) return; }
+      const int cnt = (int)ck[k].lens.size();
+      uint8_t* pin = ctx->pinOut[k & 1].p;
+      const uint8_t* d = ctx->devOut[k & 1].p;
+      bool ok = true;
+      for (int i = 0; i < cnt && ok; i++) {
+        if (ck[k].res[i].status) { fail(ck[k].res[i].status); return; }
+        const size_t nby = (size_t)((ck[k].res[i].bits + 7) >> 3);
+        if (nby) ok = hipMemcpyAsync(pin + (size_t)i * oS, d + (size_t)i * oS, nby + 1 <= (size_t)oS ? nby + 1 : nby, hipMemcpyDeviceToHost, ctx->copyDown) == hipSuccess;
+      }
+      if (!ok || hipStreamSynchronize(ctx->copyDown) != hipSuccess) { fail(-KZ_ERR_DEVICE); return; }
+      emit_blocks(bs, pin, oS, ck[k].res.data(), cnt);              // ordered emission (:1024-1035)
+      if (bs.overflow) { fail(-KZ_ERR_WRITE_FILE); return; }
+      { std::lock_guard<std::mutex> g(mu); emitted = k + 1; }
+      cv.notify_all();
+    }
+  });
+  for (int k = 0; k < nch; k++) {
+    { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return failed || (uploaded >= k + 1 && emitted >= k - 1); }); if (failed) break; }
+    const int cnt = (int)ck[k].lens.size();
+    ck[k].res.resize(cnt);
+    const int rc = kz_encode_blocks_pre(ctx, transformType, entropyType, blockSize, ctx->devIn[k & 1].p, blockSize, ck[k].lens.data(), cnt,
+                                        ctx->devOut[k & 1].p, oS, ck[k].res.data(), KZ_MEM_DEVICE, ck[k].pre);
+    kz_host_pre_free(ck[k].pre); ck[k].pre = nullptr;
+    if (rc) { fail(rc); break; }
+    { std::lock_guard<std::mutex> g(mu); encoded = k + 1; }
+    cv.notify_all();
+  }
+  U.join(); D.join();
+  for (auto& c : ck) kz_host_pre_free(c.pre);
+  return failed;
+}
+
 extern "C" int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
                                const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstCap) {
   if (!ctx || !src || !dst || n < 0) return -KZ_ERR_INVALID_PARAM;
   if (blockSize < 1024 || blockSize > (1 << 30) || (blockSize & 15)) return -KZ_ERR_BLOCK_SIZE;   // :165-174
+  KZ_HIP(hipSetDevice(ctx->device));
   HostBits bs{dst, dstCap, 0, false};
   // ---- stream header (CompressedOutputStream.java:236-313) ----
   write_stream_header(bs, transformType, entropyType, blockSize, n, ctx->checksum);
-  // ---- blocks, in batches ----
   const int64_t nblocks = (n + blockSize - 1) / blockSize;
-  const int NB = batch_blocks(blockSize);
-  const int64_t oS = kz_max_block_stream_bytes(blockSize);
-  std::unique_ptr<uint8_t[]> outbuf(new uint8_t[(size_t)oS * (size_t)std::min<int64_t>(NB, std::max<int64_t>(nblocks, 1))]);
-  std::vector<int32_t> lens(NB);
-  std::vector<kz_block_result> res(NB);
-  struct BlockSizeScope {                                          // the context's "blockSize" entry = this stream's (TEXT reads it)
-    kz_ctx* c; int saved; bool savedSet;
-    BlockSizeScope(kz_ctx* c_, int v) : c(c_), saved(c_->blockSize), savedSet(c_->blockSizeSet) { c->blockSize = v; c->blockSizeSet = true; }
-    ~BlockSizeScope() { c->blockSize = saved; c->blockSizeSet = savedSet; }
-  } scope(ctx, blockSize);
-  for (int64_t b0 = 0; b0 < nblocks; b0 += NB) {
-    const int cnt = (int)std::min<int64_t>(NB, nblocks - b0);
-    for (int i = 0; i < cnt; i++) lens[i] = (int32_t)std::min<int64_t>(blockSize, n - (b0 + i) * blockSize);
-    int rc = kz_encode_blocks(ctx, transformType, entropyType, src + b0 * blockSize, blockSize, lens.data(), cnt,
-                              outbuf.get(), oS, res.data(), KZ_MEM_HOST);
+  BlockSizeScope scope(ctx, blockSize);
+  const int CH = stream_chunk_blocks(blockSize);
+  if (nblocks >= 2LL * CH && !getenv("KZ_STREAM_SERIAL")) {
+    const int64_t rc = compress_pipelined(ctx, transformType, entropyType, blockSize, src, n, bs, nblocks, CH);
+    if (rc == -KZ_ERR_WRITE_FILE) snprintf(ctx->err, sizeof(ctx->err), "kz_compress: destination too small");
     if (rc) return rc;
-    for (int i = 0; i < cnt; i++) if (res[i].status) return res[i].status;
-    emit_blocks(bs, outbuf.get(), oS, res.data(), cnt);           // ordered emission (:1024-1035)
-    if (bs.overflow) break;
+  } else {
+    // ---- blocks, one batch after the other ----
+    const int NB = batch_blocks(blockSize);
+    const int64_t oS = kz_max_block_stream_bytes(blockSize);
+    std::unique_ptr<uint8_t[]> outbuf(new uint8_t[(size_t)oS * (size_t)std::min<int64_t>(NB, std::max<int64_t>(nblocks, 1))]);
+    std::vector<int32_t> lens(NB);
+    std::vector<kz_block_result> res(NB);
+    for (int64_t b0 = 0; b0 < nblocks; b0 += NB) {
+      const int cnt = (int)std::min<int64_t>(NB, nblocks - b0);
+      for (int i = 0; i < cnt; i++) lens[i] = (int32_t)std::min<int64_t>(blockSize, n - (b0 + i) * blockSize);
+      int rc = kz_encode_blocks(ctx, transformType, entropyType, src + b0 * blockSize, blockSize, lens.data(), cnt,
+                                outbuf.get(), oS, res.data(), KZ_MEM_HOST);
+      if (rc) return rc;
+      for (int i = 0; i < cnt; i++) if (res[i].status) return res[i].status;
+      emit_blocks(bs, outbuf.get(), oS, res.data(), cnt);           // ordered emission (:1024-1035)
+      if (bs.overflow) break;
+    }
   }
   bs.put(0, 5); bs.put(0, 3);                                   // end marker (:491-492)
   if (bs.overflow) { snprintf(ctx->err, sizeof(ctx->err), "kz_compress: destination too small"); return -KZ_ERR_WRITE_FILE; }
@@ -322,6 +421,7 @@ static int precheck_block_header(HostBitsIn bs /* by value: peek */, uint64_t W,
 
 extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstCap) {
   if (!ctx || !src || !dst || n < 0) return -KZ_ERR_INVALID_PARAM;
+  KZ_HIP(hipSetDevice(ctx->device));
   HostBitsIn bs{src, (uint64_t)n * 8, 0, false};
   KnzHeader h;
   { const int hrc = read_stream_header(bs, h, ctx->err, sizeof(ctx->err)); if (hrc) return hrc; }
@@ -338,7 +438,7 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
   if (szMask && inputSize > 0) NB = (int)std::min<int64_t>(NB, (inputSize + blockSize - 1) / blockSize);
   else NB = (int)std::min<int64_t>(NB, n / 8 + 1);
   const int64_t iS = (int64_t)kz_align((size_t)blockSize + (size_t)(blockSize >> 3) + 1024 + 64, 256);
-  std::unique_ptr<uint8_t[]> inbuf(new uint8_t[(size_t)iS * NB]);
+  std::unique_ptr<uint8_t[]> inbuf;                                // (the unstaged path's strided copy of the payloads)
   std::vector<int64_t> bits(NB);
   std::vector<uint64_t> starts(NB);
   std::vector<kz_block_result> res(NB);
@@ -372,6 +472,58 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
       if (fit < cnt) { cnt = (int)fit; pending = -KZ_ERR_WRITE_FILE; done = true; }
       if (cnt == 0) break;
     }
+    if (cnt >= 16 && !getenv("KZ_STREAM_SERIAL")) {
+      // ---- staged batch: payloads are extracted (bit-shifted) straight into pinned memory, go to HBM with asynchronous copies,
+      //      the batch is decoded HBM -> HBM, and the blocks come back through a pinned ring while host threads move the previous
+      //      piece to its place in dst ----
+      { int rc = stage_streams(ctx); if (rc) return rc; }
+      std::vector<int64_t> off(cnt + 1, 0);
+      for (int i = 0; i < cnt; i++) off[i + 1] = off[i] + (int64_t)kz_align((size_t)((bits[i] + 7) >> 3) + 64, 256);
+      const int P = (int)std::max<int64_t>(1, std::min<int64_t>(cnt, (256LL << 20) / blockSize));   // blocks per piece of the way back
+      int rc = stage_reserve(ctx, ctx->pinIn[0], (size_t)off[cnt], true);
+      if (!rc) rc = stage_reserve(ctx, ctx->devIn[0], (size_t)cnt * iS, false);
+      if (!rc) rc = stage_reserve(ctx, ctx->devOut[0], (size_t)cnt * blockSize, false);
+      for (int q = 0; q < 2 && !rc; q++) rc = stage_reserve(ctx, ctx->pinOut[q], (size_t)P * blockSize, true);
+      if (rc) return rc;
+      uint8_t* pin = ctx->pinIn[0].p;
+      parallel_blocks(cnt, [&](int i) { HostBitsIn t = bs; t.pos = starts[i]; t.error = false; t.getBytes(pin + off[i], (uint64_t)bits[i]); });
+      for (int i = 0; i < cnt; i++)
+        KZ_HIP(hipMemcpyAsync(ctx->devIn[0].p + (size_t)i * iS, pin + off[i], (size_t)((bits[i] + 7) >> 3), hipMemcpyHostToDevice, ctx->copyUp));
+      KZ_HIP(hipStreamSynchronize(ctx->copyUp));
+      rc = kz_decode_blocks(ctx, tt, (uint32_t)entropyType, blockSize, ctx->devIn[0].p, iS, bits.data(), cnt,
+                            ctx->devOut[0].p, blockSize, res.data(), KZ_MEM_DEVICE);
+      if (rc) return rc;
+      // where every block goes: the reader appends whatever a block produced (:783-785); the first failing block ends the stream
+      std::vector<int64_t> at(cnt + 1, produced);
+      int good = 0, code = 0;
+      for (; good < cnt; good++) {
+        if (res[good].status) { code = res[good].status; break; }
+        if (res[good].length > blockSize) { code = -KZ_ERR_PROCESS_BLOCK; break; }              // "incorrectly decompressed" (:756-759)
+        if (at[good] + res[good].length > dstCap) { code = -KZ_ERR_WRITE_FILE; break; }
+        at[good + 1] = at[good] + res[good].length;
+      }
+      if (code) return code;
+      const int pieces = (cnt + P - 1) / P;
+      auto fetch = [&](int p) -> hipError_t {
+        const int i0 = p * P, c = std::min(P, cnt - i0);
+        return hipMemcpyAsync(ctx->pinOut[p & 1].p, ctx->devOut[0].p + (size_t)i0 * blockSize, (size_t)c * blockSize, hipMemcpyDeviceToHost, ctx->copyDown);
+      };
+      KZ_HIP(fetch(0));
+      for (int p = 0; p < pieces; p++) {
+        KZ_HIP(hipStreamSynchronize(ctx->copyDown));
+        if (p + 1 < pieces) KZ_HIP(fetch(p + 1));                       // the next piece travels while this one is put in place
+        const int i0 = p * P, c = std::min(P, cnt - i0);
+        const uint8_t* ring = ctx->pinOut[p & 1].p;
+        parallel_blocks(c * 4, [&](int q) {                             // four copies per block
+          const int i = i0 + (q >> 2);
+          const int64_t len = res[i].length, a = (len * (q & 3)) >> 2, b = (len * ((q & 3) + 1)) >> 2;
+          if (b > a) memcpy(dst + at[i] + a, ring + (size_t)(i - i0) * blockSize + a, (size_t)(b - a));
+        });
+      }
+      produced = at[cnt];
+      continue;
+    }
+    if (!inbuf) inbuf.reset(new uint8_t[(size_t)iS * NB]);
     parallel_blocks(cnt, [&](int i) { HostBitsIn t = bs; t.pos = starts[i]; t.error = false; t.getBytes(inbuf.get() + (size_t)i * iS, (uint64_t)bits[i]); });
     // decode into a temporary when the tail would overflow dst
     const int64_t room = dstCap - produced;

@@ -1211,3 +1211,44 @@ def test_host_stage_pipeline_gives_the_same_blocks(ctx, monkeypatch, level):
             assert all(res4[i].status == 0 for i in range(nb) if i != victim)
     finally:
         ctx.set_block_size(4 * 1024 * 1024)
+
+
+@pytest.mark.parametrize("chain,ent,chk", [("BWT+RANK+ZRLT", "ANS0", 0), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0", 32), ("LZX", "NONE", 64), ("BWT+SRT+ZRLT", "FPAQ", 0)])
+def test_pipelined_stream_writer_and_staged_reader(ctx, monkeypatch, chain, ent, chk):
+    """kz_compress on inputs of several chunks runs a three-stage pipeline (stage chunk k+1 | code chunk k | bring chunk k-1 back and emit
+    it in order), kz_decompress moves whole batches through pinned staging: forced here with 4-block chunks over 37 blocks + a
+    ragged tail.  The stream equals the oracle's and the one-batch-at-a-time form's; both readers restore the input."""
+    c = textgen.cases()
+    bs = 65536
+    data = (c["english"] + datagen.stream(20, bs).tobytes() + c["utf8"] + c["xml"] + c["random"])[:37 * bs + 4321]
+    ctx.set_checksum(chk)
+    try:
+        ref = oracle.compress(chain, ent, bs, data, jobs=4, checksum=chk)
+        monkeypatch.setenv("KZ_STREAM_CHUNK", "4")
+        cos = kz.CompressedOutputStream(ctx, chain, ent, bs, checksum=chk)
+        cos.write(data)
+        cos.close()
+        assert cos.output == ref, (len(cos.output), len(ref))
+        assert kz.CompressedInputStream(ctx, ref).read() == data
+        monkeypatch.setenv("KZ_STREAM_SERIAL", "1")
+        cos2 = kz.CompressedOutputStream(ctx, chain, ent, bs, checksum=chk)
+        cos2.write(data)
+        cos2.close()
+        assert cos2.output == ref
+        assert kz.CompressedInputStream(ctx, ref).read() == data
+        monkeypatch.delenv("KZ_STREAM_SERIAL")
+        # a destination that is too small: ERR_WRITE_FILE from the pipeline's emitter, and the context still works afterwards
+        lib = ctx.lib
+        src = np.frombuffer(data, dtype=np.uint8)
+        small = np.zeros(len(ref) // 2, dtype=np.uint8)
+        ctx.set_block_size(bs)
+        assert lib.kz_compress(ctx.h, kz.transform_type(chain), kz.ENTROPY_IDS[ent], bs, src.ctypes.data, len(src), small.ctypes.data, len(small)) == -12
+        back = np.zeros(len(data), dtype=np.uint8)
+        knz = np.frombuffer(ref, dtype=np.uint8)
+        assert lib.kz_decompress(ctx.h, knz.ctypes.data, len(knz), back.ctypes.data, len(back)) == len(data) and back.tobytes() == data
+        # and a destination one block short for the reader: ERR_WRITE_FILE as before
+        short = np.zeros(len(data) - bs, dtype=np.uint8)
+        assert lib.kz_decompress(ctx.h, knz.ctypes.data, len(knz), short.ctypes.data, len(short)) == -12
+    finally:
+        ctx.set_checksum(0)
+        ctx.set_block_size(4 * 1024 * 1024)
