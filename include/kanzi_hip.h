@@ -196,6 +196,15 @@ uint64_t kz_transform_type(const int32_t* types, int32_t nb);
 int64_t kz_knz_assemble(uint64_t transformType, uint32_t entropyType, int32_t blockSize, int64_t inputSize,
                         int32_t checksumBits, const uint8_t* streams, int64_t stride, const int64_t* bits, int32_t nBlocks,
                         uint8_t* dst, int64_t dstCap);
+/* the same, block by block: a gatherer appends block streams in block-id order as they arrive (rank 0 of a multi-GPU job: round
+ * r brings blocks r*N .. r*N+N-1 from ranks 0..N-1), holding one round instead of the whole stream.  _open writes the stream header
+ * into dst, _add the 5 + lw bit length prefix and the bits of the next block, _close the end marker and returns the size in bytes
+ * (or -KZ_ERR_WRITE_FILE when dst was too small); the writer is freed by _close. */
+typedef struct kz_knz_writer kz_knz_writer;
+kz_knz_writer* kz_knz_writer_open(uint64_t transformType, uint32_t entropyType, int32_t blockSize, int64_t inputSize,
+                                  int32_t checksumBits, uint8_t* dst, int64_t dstCap);
+int32_t kz_knz_writer_add(kz_knz_writer* w, const uint8_t* stream, int64_t bits);
+int64_t kz_knz_writer_close(kz_knz_writer* w);
 int32_t kz_knz_index(const uint8_t* src, int64_t n, uint64_t* transformType, uint32_t* entropyType,
                      int32_t* blockSize, int64_t* inputSize, int32_t* checksumBits,
                      int64_t* blockBitOff, int64_t* blockBits, int32_t cap);

@@ -99,6 +99,9 @@ def load_library():
         "kz_compress_bound": (c.c_int64, [c.c_int64, c.c_int32]),
         "kz_transform_type": (c.c_uint64, [i32p, c.c_int32]),
         "kz_knz_assemble": (c.c_int64, [c.c_uint64, c.c_uint32, c.c_int32, c.c_int64, c.c_int32, u8p, c.c_int64, i64p, c.c_int32, u8p, c.c_int64]),
+        "kz_knz_writer_open": (vp, [c.c_uint64, c.c_uint32, c.c_int32, c.c_int64, c.c_int32, u8p, c.c_int64]),
+        "kz_knz_writer_add": (c.c_int32, [vp, u8p, c.c_int64]),
+        "kz_knz_writer_close": (c.c_int64, [vp]),
         "kz_knz_index": (c.c_int32, [u8p, c.c_int64, vp, vp, vp, vp, vp, i64p, i64p, c.c_int32]),
         "kz_set_timing": (None, [vp, c.c_int32]),
         "kz_get_stage_count": (c.c_int32, [vp]),
@@ -126,7 +129,7 @@ ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_err
                "kz_transform_forward", "kz_transform_inverse", "kz_transform_max_encoded_len", "kz_host_stage_forward", "kz_host_stage_inverse",
                "kz_entropy_encode", "kz_entropy_decode", "kz_encode_blocks", "kz_decode_blocks",
                "kz_max_block_stream_bytes", "kz_submit_encode_blocks", "kz_submit_decode_blocks", "kz_wait", "kz_poll", "kz_compress", "kz_decompress", "kz_compress_bound", "kz_transform_type",
-               "kz_knz_assemble", "kz_knz_index",
+               "kz_knz_assemble", "kz_knz_index", "kz_knz_writer_open", "kz_knz_writer_add", "kz_knz_writer_close",
                "kz_set_timing", "kz_get_stage_count", "kz_get_stage_ms", "kz_get_stage_alg_bytes", "kz_reset_timing",
                "kz_set_kernel_timing", "kz_get_kernel_count", "kz_get_kernel_name", "kz_get_kernel_ms", "kz_get_kernel_max_ms",
                "kz_get_kernel_launches", "kz_reset_kernel_timing"]
@@ -639,6 +642,33 @@ def knz_assemble(transform, entropy, block_size, input_size, streams, bits, chec
     if rc < 0:
         raise KanziError(-rc, "knz_assemble")
     return dst[:rc].tobytes()
+
+
+class KnzWriter:
+    """Host-only streaming form of knz_assemble (kz_knz_writer_*): add() the block streams in block-id order as they arrive, close()
+    -> the .knz bytes.  capacity: an upper bound of the stream's size (kz_compress_bound of the input is one)."""
+
+    def __init__(self, transform, entropy, block_size, input_size, capacity, checksum=0):
+        self.L = load_library()
+        tt = transform if isinstance(transform, int) else transform_type(transform)
+        et = entropy if isinstance(entropy, int) else ENTROPY_IDS[entropy.upper()]
+        self.dst = np.zeros(int(capacity) + 64, dtype=np.uint8)
+        self.w = self.L.kz_knz_writer_open(tt, et, int(block_size), int(input_size), int(checksum), self.dst.ctypes.data, len(self.dst))
+        if not self.w:
+            raise KanziError(18, "knz writer")
+
+    def add(self, stream, bits):
+        a = np.frombuffer(bytes(stream) + b"\0\0", dtype=np.uint8)
+        rc = self.L.kz_knz_writer_add(self.w, a.ctypes.data, int(bits))
+        if rc < 0:
+            raise KanziError(-rc, "knz writer")
+
+    def close(self):
+        n = self.L.kz_knz_writer_close(self.w)
+        self.w = None
+        if n < 0:
+            raise KanziError(-n, "knz writer")
+        return self.dst[:n].tobytes()
 
 
 def knz_index(data):

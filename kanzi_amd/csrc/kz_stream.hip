@@ -136,6 +136,29 @@ extern "C" int64_t kz_knz_assemble(uint64_t transformType, uint32_t entropyType,
   return (int64_t)((bs.pos + 7) >> 3);
 }
 
+// The same, block by block: a gatherer (rank 0 of a multi-GPU job) appends block streams in block-id order as they arrive instead
+// of holding all of them first; memory is one block plus the destination.
+struct kz_knz_writer { HostBits bs; };
+extern "C" kz_knz_writer* kz_knz_writer_open(uint64_t transformType, uint32_t entropyType, int32_t blockSize, int64_t inputSize,
+                                             int32_t checksumBits, uint8_t* dst, int64_t dstCap) {
+  if (!dst || dstCap < 32 || (checksumBits != 0 && checksumBits != 32 && checksumBits != 64)) return nullptr;
+  kz_knz_writer* w = new kz_knz_writer{HostBits{dst, dstCap, 0, false}};
+  write_stream_header(w->bs, transformType, entropyType, blockSize, inputSize, checksumBits == 32 ? 1 : (checksumBits == 64 ? 2 : 0));
+  return w;
+}
+extern "C" int32_t kz_knz_writer_add(kz_knz_writer* w, const uint8_t* stream, int64_t bits) {
+  if (!w || bits < 0 || (bits > 0 && !stream)) return -KZ_ERR_INVALID_PARAM;
+  if (bits > 0) write_block(w->bs, stream, (uint64_t)bits);
+  return w->bs.overflow ? -KZ_ERR_WRITE_FILE : 0;
+}
+extern "C" int64_t kz_knz_writer_close(kz_knz_writer* w) {          // end marker (:491-492); returns the stream's size in bytes
+  if (!w) return -KZ_ERR_INVALID_PARAM;
+  w->bs.put(0, 5); w->bs.put(0, 3);
+  const int64_t r = w->bs.overflow ? -KZ_ERR_WRITE_FILE : (int64_t)((w->bs.pos + 7) >> 3);
+  delete w;
+  return r;
+}
+
 // Parse the stream header and walk the block length prefixes: blockBitOff[i] = bit offset of block
 // i's private stream inside src, blockBits[i] = its length W.  Returns the number of blocks or <0.
 // Stream header, checked in the reference's order and with its codes (CompressedInputStream.java:359-478).

@@ -70,3 +70,59 @@ def test_round_robin_two_ranks_gloo():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert same and tmax == 2.0 and n > 0
+
+
+def _worker_stream(rank, world, port, q):
+    """4 ranks, 239 blocks (enwik9's count: shares of 60 / 60 / 60 / 59), ragged tail.  Rank 0 does not gather everything first: round
+    r brings blocks r * N .. r * N + N - 1, which go straight into the streaming writer (kz_knz_writer_*)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import kanzi_amd as kz
+    import oracle
+    import datagen
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bs, nblocks = 2048, 239
+    data = datagen.stream(nblocks, bs).tobytes()[:-777]
+    chain, ent = "BWT+RANK+ZRLT", "ANS0"
+    mine = kz.shard_blocks(nblocks, world, rank)
+    assert len(mine) == (60 if rank < 3 else 59)
+    rounds = (nblocks + world - 1) // world
+    writer = kz.KnzWriter(chain, ent, bs, len(data), kz.load_library().kz_compress_bound(len(data), bs)) if rank == 0 else None
+    held = 0
+    for r in range(rounds):
+        i = r * world + rank
+        item = None
+        if i < nblocks:
+            s, w, _, _ = oracle.encode_block(chain, ent, data[i * bs:(i + 1) * bs])
+            item = (i, w, s)
+        got = [None] * world if rank == 0 else None
+        dist.gather_object(item, got, dst=0)
+        if rank == 0:
+            held = max(held, sum(1 for x in got if x is not None))
+            for k, x in enumerate(got):
+                if x is not None:
+                    assert x[0] == r * world + k                      # block-id order without sorting
+                    writer.add(x[2], x[1])
+    if rank == 0:
+        knz = writer.close()
+        ref = oracle.compress(chain, ent, bs, data, jobs=2)
+        q.put((knz == ref, held, len(kz.knz_index(knz)["blocks"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_round_robin_four_ranks_streaming_gather_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_stream, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    same, held, nb = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert same and held == 4 and nb == 239

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Aggregate rocprofv3 --pmc counter_collection CSVs (one pass per counter) into per-kernel HBM traffic.
-Usage: tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <blocks> > profiles/rNN_pmc_traffic.json
+Usage: tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <blocks> [chain entropy] > profiles/rNN_pmc_traffic.json
 Units/corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KiB
 (hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024); on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide
 coalesced streaming read (TCC_EA0_RDREQ x 64 B with 128-B requests) -> doubled here; other access widths and
@@ -34,7 +34,9 @@ def main():
     fetch = agg(sys.argv[1], "FETCH_SIZE")
     write = agg(sys.argv[2], "WRITE_SIZE")
     blocks = int(sys.argv[3])
-    res = {"blocks_per_gpu_per_step": blocks, "steps_profiled": 1,
+    chain = sys.argv[4] if len(sys.argv) > 4 else "BWT+RANK+ZRLT"
+    entropy = sys.argv[5] if len(sys.argv) > 5 else "ANS0"
+    res = {"blocks_per_gpu_per_step": blocks, "chain": chain, "entropy": entropy, "steps_profiled": 1,
            "note": "FETCH_SIZE doubled (gfx950 correction), KiB -> bytes; WRITE_SIZE as measured", "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
