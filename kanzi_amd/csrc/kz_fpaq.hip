@@ -245,7 +245,7 @@ __global__ __launch_bounds__(512) void k_fpaq_enc_wave(const u8* __restrict__ sr
                                                   const int32_t* __restrict__ order, int wavesPerGroup) {
   __shared__ int probsAll[8][1024];
   const int wv = (int)(threadIdx.x >> 6);
-  const int b = order[blockIdx.x * wavesPerGroup + wv];
+  const int b = __builtin_amdgcn_readfirstlane(order[blockIdx.x * wavesPerGroup + __builtin_amdgcn_readfirstlane(wv)]);   // uniform on purpose: the coder state stays on the scalar unit
   if (b < 0) return;
   int* probs = probsAll[wv];
   const int count = d_len[b];
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512) void k_fpaq_dec_wave(const u8* __restrict__ in
                                                   const int32_t* __restrict__ order, int wavesPerGroup, long long* __restrict__ endOut) {
   __shared__ __attribute__((aligned(8))) int probsAll[8][1024];
   const int wv = (int)(threadIdx.x >> 6);
-  const int b = order[blockIdx.x * wavesPerGroup + wv];
+  const int b = __builtin_amdgcn_readfirstlane(order[blockIdx.x * wavesPerGroup + __builtin_amdgcn_readfirstlane(wv)]);   // uniform on purpose: the coder state stays on the scalar unit
   if (b < 0) return;
   int* probs = probsAll[wv];
   const int count = d_len[b];

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(512) void k_srt_inv(const u8* __restrict__ src, u8*
                                                   const int32_t* __restrict__ orderIdx, int wavesPerGroup) {
   __shared__ SrtInvLds LDS[8];
   const int wv = (int)(threadIdx.x >> 6);
-  const int b = orderIdx[blockIdx.x * wavesPerGroup + wv];
+  const int b = __builtin_amdgcn_readfirstlane(orderIdx[blockIdx.x * wavesPerGroup + __builtin_amdgcn_readfirstlane(wv)]);   // uniform on purpose: scalar loads and scalar control flow
   if (b < 0) return;
   SrtInvLds& L = LDS[wv];
   int32_t* freq = L.freq; int32_t* bstart = L.bstart; int32_t* bend = L.bend; int32_t* wbase = L.wbase;
@@ -240,9 +240,9 @@ __global__ __launch_bounds__(512) void k_srt_inv(const u8* __restrict__ src, u8*
   }
   for (int i = lane; i < 256; i += 64) { r2s0[i] = 0; bstart[i] = 0; bend[i] = 0; }
   SRT_SYNC();
-  const int H = L.h;
+  const int H = __builtin_amdgcn_readfirstlane(L.h);               // (LDS values the whole wave agrees on: scalar from here)
   const int count = length - H;
-  if (L.bad || count < 0) { if (lane == 0) { d_len2[b] = 0; d_flag[b] = 0; } return; }
+  if (__builtin_amdgcn_readfirstlane(L.bad) || count < 0) { if (lane == 0) { d_len2[b] = 0; d_flag[b] = 0; } return; }
   const u8* s = in + H;
   // ---- bucket order of the present symbols (freq desc, symbol asc :259-302), bucket ranges ----
   int nbSymbols = 0;
@@ -299,7 +299,8 @@ __global__ __launch_bounds__(512) void k_srt_inv(const u8* __restrict__ src, u8*
 #define SRT_FLUSH() do { if (lane < pendCnt) ring[pendSym][lane] = (u8)vpend; pendSym = -1; SRT_SYNC(); } while (0)
     while (i < count) {
       if (pendSym == c) SRT_FLUSH();
-      const int32_t cur = bstart[c], end = bend[c];
+      // (LDS reads at a uniform address: readfirstlane tells the compiler so, and the step's arithmetic and branches stay scalar)
+      const int32_t cur = __builtin_amdgcn_readfirstlane(bstart[c]), end = __builtin_amdgcn_readfirstlane(bend[c]);
       const u32 v = ring[c][lane];
       const int32_t fend = min(end, (cur & ~63) + 64);
       const int avail = fend - cur;                                  // valid ranks in the ring: 0..64
