@@ -113,11 +113,29 @@ bool utf8_pairs_ok(const int32_t* f0, PairCounts& pc, int64_t* continuation) {
 
 int text_block_mode(const u8* p, int count, bool strict) {
   if (!strict && mm_magic_type(p) != 0) return kNotText;                                             // :272-273
-  PairCounts pc;
-  memset(pc.c.get(), 0, 65536 * sizeof(int32_t));
-  int32_t f0[256] = {0};
-  int prev = 0;
-  for (int i = 0; i < count; i++) { const int c = p[i]; f0[c]++; pc.row(prev)[c]++; prev = c; }
+  // One pass: the order-0 histogram (four interleaved tables: no store-to-load chain on runs) and the handful of pair counts the
+  // text path reads: "&" followed by a / g / l / q (:343-345), CR followed by something else than LF, LF behind something else than
+  // CR (:358-372).  The reference fills a whole 256 x 256 pair table per block (computeStats :283-308); that table is built here
+  // only for blocks that turn out not to be text, where detectType's UTF-8 rules need it.  Like the reference's, the pair
+  // statistics start from a previous byte of 0.
+  int32_t h4[4][256];
+  memset(h4, 0, sizeof(h4));
+  int64_t amp = 0, crOther = 0, otherLf = 0;
+  {
+    int prev = 0, i = 0;
+    for (; i + 4 <= count; i += 4) {
+      const int c0 = p[i], c1 = p[i + 1], c2 = p[i + 2], c3 = p[i + 3];
+      h4[0][c0]++; h4[1][c1]++; h4[2][c2]++; h4[3][c3]++;
+#define KZ_PAIR(A, B) amp += ((A) == '&') & (((B) == 'a') | ((B) == 'g') | ((B) == 'l') | ((B) == 'q')); \
+                      crOther += ((A) == kCR) & ((B) != kLF); otherLf += ((B) == kLF) & ((A) != kCR);
+      KZ_PAIR(prev, c0) KZ_PAIR(c0, c1) KZ_PAIR(c1, c2) KZ_PAIR(c2, c3)
+      prev = c3;
+    }
+    for (; i < count; i++) { const int c = p[i]; h4[0][c]++; KZ_PAIR(prev, c) prev = c; }
+#undef KZ_PAIR
+  }
+  int32_t f0[256];
+  for (int c = 0; c < 256; c++) f0[c] = h4[0][c] + h4[1][c] + h4[2][c] + h4[3][c];
   int64_t letters = f0[kCR] + f0[kLF], ascii = 0;
   for (int c = 0; c < 128; c++) { if (is_text((u8)c)) letters += f0[c]; ascii += f0[c]; }
   const int64_t bin = count - ascii;
@@ -130,6 +148,9 @@ int text_block_mode(const u8* p, int count, bool strict) {
   if (notText) {                                                                                     // detectType
     const int dt = detect_simple_type(count, f0);
     if (dt != KZ_DT_UNDEFINED) return kNotText | dt;
+    PairCounts pc;                                                  // not text: now the pair table (previous byte of the first one: 0)
+    memset(pc.c.get(), 0, 65536 * sizeof(int32_t));
+    { int prev = 0; for (int i = 0; i < count; i++) { const int c = p[i]; pc.row(prev)[c]++; prev = c; } }
     int64_t cont = 0;
     if (!utf8_pairs_ok(f0, pc, &cont)) return kNotText;
     return cont >= count / 8 ? (kNotText | KZ_DT_UTF8) : kNotText;
@@ -137,7 +158,6 @@ int text_block_mode(const u8* p, int count, bool strict) {
   int mode = 0;
   if (bin <= count - count / 10) {                                                                   // :336-356 looks like XML / HTML
     const int lt = f0['<'], gt = f0['>'];
-    const int amp = pc.row('&')['a'] + pc.row('&')['g'] + pc.row('&')['l'] + pc.row('&')['q'];
     const int minFreq = std::max((int)((count - bin) >> 9), 2);
     if (lt >= minFreq && gt >= minFreq && amp > 0) {
       const int lo = std::min(lt, gt), hi = std::max(lt, gt);
@@ -145,10 +165,7 @@ int text_block_mode(const u8* p, int count, bool strict) {
     }
   }
   if (f0[kCR] != 0 && f0[kCR] == f0[kLF]) {                                                          // :358-372 every CR is followed by LF and vice versa
-    mode |= kCRLF;
-    for (int c = 0; c < 256; c++) {
-      if ((c != kLF && pc.row(kCR)[c] != 0) || (c != kCR && pc.row(c)[kLF] != 0)) { mode &= ~kCRLF; break; }
-    }
+    if (crOther == 0 && otherLf == 0) mode |= kCRLF;
   }
   return mode;
 }
