@@ -299,38 +299,53 @@ __global__ __launch_bounds__(512) void k_srt_inv(const u8* __restrict__ src, u8*
 #define SRT_FLUSH() do { if (lane < pendCnt) ring[pendSym][lane] = (u8)vpend; pendSym = -1; SRT_SYNC(); } while (0)
     while (i < count) {
     // Hot loop: while at least 66 outputs remain no step can run past the end (a step emits at most 65), so the common step -- a
-    // non-zero rank inside the ring -- is straight-line code without clamps: one taken branch per step (the loop's).  Everything else
-    // (zeros to the ring's end, exhausted bucket, the block's last outputs) leaves to the complete loop below, one step at a time.
-    while (i + 66 <= count) {
-      if (pendSym >= 0) SRT_FLUSH();                                  // the refill issued by the previous step
-      const int32_t cur = __builtin_amdgcn_readfirstlane(bstart[c]), end = __builtin_amdgcn_readfirstlane(bend[c]);
-      const u32 v = ring[c][lane];
-      const int avail = min(end, (cur & ~63) + 64) - cur;
-      const uint64_t nzm = kz_ballot(v != 0);
-      const int sh = cur & 63;
-      uint64_t rot = (nzm >> sh) | ((nzm << 1) << (63 - sh));         // bit j: rank cur + j is not zero
-      if (avail < 64) rot &= ((1ull << avail) - 1ull);
-      if (__builtin_expect(rot == 0, 0)) break;
-      const int z = (int)__builtin_ctzll(rot);
-      const int r = __builtin_amdgcn_readlane((int)v, (cur + z) & 63);
-      if (lane <= z) o[i + lane] = (u8)c;
-      i += z + 1;
-      const int32_t ncur = cur + z + 1;
-      if (lane == 0) bstart[c] = ncur;
-      if (__builtin_expect((ncur & 63) == 0 && ncur < end, 0)) {      // ring used up, bucket goes on: fetch the next 64 ranks
-        pendCnt = min(64, end - ncur);
-        vpend = (lane < pendCnt) ? (u32)s[ncur + lane] : 0u;
-        pendSym = c;
+    // non-zero rank inside the ring -- is straight-line code without clamps.  It is software pipelined: a non-zero rank moves c
+    // behind position 1, so the NEXT current symbol is the list's position 1 and is known when the step starts; its cursor, end and
+    // ring are requested from LDS at once and arrive while this step's ballot / scalar arithmetic / list move run: no LDS round
+    // trip on the dependent chain.  Everything else (only zeros up to the ring's end, exhausted bucket, the block's last outputs)
+    // leaves to the complete step below, one step at a time.
+    if (i + 66 <= count) {
+      if (pendSym >= 0) SRT_FLUSH();
+      int32_t cur = __builtin_amdgcn_readfirstlane(bstart[c]), end = __builtin_amdgcn_readfirstlane(bend[c]);
+      u32 v = ring[c][lane];
+      for (;;) {
+        const int c2 = (int)(((u32)__builtin_amdgcn_readfirstlane((int)list) >> 8) & 0xFF);
+        if (__builtin_expect((c2 == c) | (pendSym == c2), 0)) {       // (one test on the hot path for two rare cases)
+          if (c2 == c) break;                                         // a list with the same symbol twice (only damaged input has one):
+                                                                      //   its state changes in this step, no reading ahead
+          SRT_FLUSH();                                                // c2's ring is being refilled: write it before it is read
+        }
+        const int32_t cur2 = bstart[c2], end2 = bend[c2];             // (wave-uniform LDS reads; made scalar when they are used)
+        const u32 v2 = ring[c2][lane];
+        const int sh = cur & 63;
+        const int avail = min(end - cur, 64 - sh);                    // valid ranks in the ring
+        const uint64_t nzm = kz_ballot(v != 0);
+        const uint64_t rot = (nzm >> sh) | ((nzm << 1) << (63 - sh)); // bit j: slot of rank cur + j is not zero; slots of consumed
+        const int z = rot ? (int)__builtin_ctzll(rot) : 64;           //   ranks come last in this order, so the first hit is valid
+        if (__builtin_expect(z >= avail, 0)) break;                   //   iff it lies below avail
+        const int r = __builtin_amdgcn_readlane((int)v, (cur + z) & 63);
+        if (lane <= z) o[i + lane] = (u8)c;
+        i += z + 1;
+        const int32_t ncur = cur + z + 1;
+        if (lane == 0) bstart[c] = ncur;
+        if (__builtin_expect((ncur & 63) == 0 && ncur < end, 0)) {    // ring used up, bucket goes on: fetch the next 64 ranks
+          if (pendSym >= 0) SRT_FLUSH();
+          pendCnt = min(64, end - ncur);
+          vpend = (lane < pendCnt) ? (u32)s[ncur + lane] : 0u;
+          pendSym = c;
+        }
+        const u32 nxt = KZ_DPP_SHL1(list);                            // positions 0..r-1 <- 1..r, position r <- c (SRT.java:233-237)
+        const u32 shifted = (list >> 8) | (nxt << 24);
+        const int ec = min(max(r - 4 * lane, 0), 4);                  // bytes with position < r in this lane, branch-free
+        const u32 mask = (u32)((0xFFFFFFFFull << (8 * ec)) >> 32);    // ec low bytes set
+        const u32 nl = (shifted & mask) | (list & ~mask);
+        const int shb = 8 * (r & 3);
+        const u32 put = (nl & ~(0xFFu << shb)) | ((u32)c << shb);
+        list = (lane == (r >> 2)) ? put : nl;
+        c = c2;
+        cur = __builtin_amdgcn_readfirstlane(cur2); end = __builtin_amdgcn_readfirstlane(end2); v = v2;
+        if (__builtin_expect(i + 66 > count, 0)) break;
       }
-      const u32 nxt = KZ_DPP_SHL1(list);                              // positions 0..r-1 <- 1..r, position r <- c (SRT.java:233-237)
-      const u32 shifted = (list >> 8) | (nxt << 24);
-      const int ec = min(max(r - 4 * lane, 0), 4);                    // bytes with position < r in this lane, branch-free
-      const u32 mask = (u32)((0xFFFFFFFFull << (8 * ec)) >> 32);      // ec low bytes set
-      u32 nl = (shifted & mask) | (list & ~mask);
-      const int shb = 8 * (r & 3);
-      const u32 put = (nl & ~(0xFFu << shb)) | ((u32)c << shb);
-      list = (lane == (r >> 2)) ? put : nl;
-      c = (int)(__builtin_amdgcn_readfirstlane((int)list) & 0xFF);
     }
     pendAge = 1;
     if (i < count) {                                                  // ONE complete step, then back to the hot loop
