@@ -21,7 +21,10 @@ typedef uint8_t u8;
 // per-CU L1 is write-through), so a load that follows a store to the same address sees it without s_barrier; a
 // real barrier would also drain every outstanding store (s_waitcnt vmcnt(0)) at each parse step.  Only the compiler
 // has to be kept from reordering.
-#define LZ_ORDER() __builtin_amdgcn_wave_barrier()
+// Round 3: the ordering is now SAID, not just relied on: an acquire-release fence at wavefront scope (lane 0's table store must be
+// visible to the loads the other lanes of the same wave issue next).  At that scope the back end emits no instruction -- the ISA of
+// this file with and without the fence differs in one commuted compare -- so it costs nothing; it is what the memory model asks for.
+#define LZ_ORDER() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #define LZ_SEED 0x1E35A7BDULL
 #define LZ_MAXD1 ((1 << 16) - 2)
 #define LZ_MAXD2 ((1 << 24) - 2)
