@@ -1230,6 +1230,13 @@ def test_pipelined_stream_writer_and_staged_reader(ctx, monkeypatch, chain, ent,
         cos.close()
         assert cos.output == ref, (len(cos.output), len(ref))
         assert kz.CompressedInputStream(ctx, ref).read() == data
+        # the writer's "skipBlocks" option decides copy blocks on the device BEFORE the host stages: the pipeline then leaves the host
+        # stages to the batched call (no pre-staging) and the stream still equals the oracle's
+        skip_ref = oracle.compress(chain, ent, bs, data, jobs=4, checksum=chk, skip_blocks=True)
+        cos3 = kz.CompressedOutputStream(ctx, chain, ent, bs, checksum=chk, skipBlocks=True)
+        cos3.write(data)
+        cos3.close()
+        assert cos3.output == skip_ref and kz.CompressedInputStream(ctx, skip_ref).read() == data
         monkeypatch.setenv("KZ_STREAM_SERIAL", "1")
         cos2 = kz.CompressedOutputStream(ctx, chain, ent, bs, checksum=chk)
         cos2.write(data)
