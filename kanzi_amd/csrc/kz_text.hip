@@ -518,14 +518,24 @@ int utf_forward(int* dataType, const u8* src, int n, u8* dst, int dstCap, int* p
   // gives the same answers
   struct Sym { int32_t key, freq; };
   struct KeyMap {
-    std::vector<uint32_t> key, val; std::vector<uint32_t> used;
-    KeyMap() : key(65536, 0xFFFFFFFFu), val(65536, 0) {}
-    uint32_t& at(uint32_t k) {                                   // the slot of k, claimed (value 0) when new
+    // keys of 1-, 2- and 3-byte sequences are 16 payload bits under a 2-bit size tag: a direct table (3 x 65536 entries; a block
+    // touches a few hundred of them); 4-byte sequences (21 payload bits, rare) go through a 65536-slot open-addressing map
+    std::vector<uint32_t> direct, key, val; std::vector<uint32_t> used;
+    KeyMap() : direct(3 * 65536, 0), key(65536, 0xFFFFFFFFu), val(65536, 0) {}
+    uint32_t& at(uint32_t k) {                                   // the counter / alias of k, claimed (value 0) when new
+      if (k < (4u << 19)) {
+        const uint32_t i = ((k >> 19) << 16) | (k & 0xFFFFu);
+        if (direct[i] == 0) used.push_back(i);                   // (may list an entry twice when it is reset to 0 by the caller: harmless)
+        return direct[i];
+      }
       uint32_t h = (k * 2654435761u) >> 16;
-      while (key[h] != k) { if (key[h] == 0xFFFFFFFFu) { key[h] = k; val[h] = 0; used.push_back(h); break; } h = (h + 1) & 0xFFFF; }
+      while (key[h] != k) { if (key[h] == 0xFFFFFFFFu) { key[h] = k; val[h] = 0; used.push_back(0x80000000u | h); break; } h = (h + 1) & 0xFFFF; }
       return val[h];
     }
-    void clear() { for (uint32_t h : used) key[h] = 0xFFFFFFFFu; used.clear(); }
+    void clear() {
+      for (uint32_t u : used) { if (u & 0x80000000u) key[u & 0xFFFF] = 0xFFFFFFFFu; else direct[u] = 0; }
+      used.clear();
+    }
   };
   static thread_local KeyMap seenMap;
   struct Clean { KeyMap& m; ~Clean() { m.clear(); } } clean_{seenMap};
