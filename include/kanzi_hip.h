@@ -97,6 +97,10 @@ int32_t     kz_ctx_set_block_size(kz_ctx* ctx, int32_t blockSize);
 int32_t     kz_ctx_set_entropy(kz_ctx* ctx, uint32_t entropyType);
 int32_t     kz_ctx_set_data_type(kz_ctx* ctx, int32_t dataType);
 int32_t     kz_ctx_get_data_type(kz_ctx* ctx);
+/* every kz_ctx_set_* value back to a fresh context's (checksum none, skipBlocks off, dataType UNDEFINED, block size unset, entropy
+ * NONE): the values are sticky like the entries of the reference's context map, and a caller leaving through an error path may not
+ * know which ones it had set */
+int32_t     kz_ctx_reset(kz_ctx* ctx);
 /* One process per GPU, N on one host: pin this process (and the threads it creates later: TEXT / UTF stages, bit assembly,
  * staging copies) to the CPUs of the GPU's NUMA node (/sys/bus/pci/devices/<bdf>/local_cpulist).  Returns the number of CPUs
  * in the new mask, 0 if the topology is not visible (nothing changed), <0 on error.  The reference has no equivalent: its

@@ -12,6 +12,7 @@ public final class KanziHip {
   public static native int ctxSetEntropy(long ctx, int entropyType);   // context map key "entropy" (TEXT: TextCodec1 / TextCodec2)
   public static native int ctxSetDataType(long ctx, int dataType);   // Global.DataType as numbered by KZ_DT_* (kanzi_hip.h)
   public static native int ctxGetDataType(long ctx);
+  public static native int ctxReset(long ctx);   // every ctxSet* value back to a fresh context's
   public static native int maxEncodedLength(int type, int n);
   public static native int transform(long ctx, int type, boolean forward, byte[] src, int srcIdx, int n, byte[] dst, int dstIdx, int dstCap);
   public static native long entropyEncode(long ctx, int type, byte[] block, int blkptr, int n, byte[] out);

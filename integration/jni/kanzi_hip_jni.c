@@ -55,6 +55,11 @@ JNIEXPORT jint JNICALL CLS(ctxGetDataType)(JNIEnv* env, jclass c, jlong ctx) {
   return kz_ctx_get_data_type(CTX(ctx));
 }
 
+JNIEXPORT jint JNICALL CLS(ctxReset)(JNIEnv* env, jclass c, jlong ctx) {
+  (void)env; (void)c;
+  return kz_ctx_reset(CTX(ctx));
+}
+
 JNIEXPORT jint JNICALL CLS(maxEncodedLength)(JNIEnv* env, jclass c, jint type, jint n) {
   (void)env; (void)c;
   return kz_transform_max_encoded_len((uint32_t)type, n);

@@ -80,6 +80,7 @@ def load_library():
         "kz_ctx_set_entropy": (c.c_int32, [vp, c.c_uint32]),
         "kz_ctx_set_data_type": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_get_data_type": (c.c_int32, [vp]),
+        "kz_ctx_reset": (c.c_int32, [vp]),
         "kz_transform_forward": (c.c_int32, [vp, c.c_uint32, u8p, c.c_int32, u8p, c.c_int32, i32p]),
         "kz_transform_inverse": (c.c_int32, [vp, c.c_uint32, u8p, c.c_int32, u8p, c.c_int32, i32p]),
         "kz_transform_max_encoded_len": (c.c_int32, [c.c_uint32, c.c_int32]),
@@ -125,7 +126,7 @@ def load_library():
 
 
 ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_error", "kz_ctx_stream", "kz_pin_to_device_numa", "kz_host_cpus", "kz_ctx_set_checksum",
-               "kz_ctx_set_data_type", "kz_ctx_get_data_type", "kz_ctx_set_skip_blocks", "kz_ctx_set_block_size", "kz_ctx_set_entropy",
+               "kz_ctx_set_data_type", "kz_ctx_get_data_type", "kz_ctx_reset", "kz_ctx_set_skip_blocks", "kz_ctx_set_block_size", "kz_ctx_set_entropy",
                "kz_transform_forward", "kz_transform_inverse", "kz_transform_max_encoded_len", "kz_host_stage_forward", "kz_host_stage_inverse",
                "kz_entropy_encode", "kz_entropy_decode", "kz_encode_blocks", "kz_decode_blocks",
                "kz_max_block_stream_bytes", "kz_submit_encode_blocks", "kz_submit_decode_blocks", "kz_wait", "kz_poll", "kz_compress", "kz_decompress", "kz_compress_bound", "kz_transform_type",
@@ -251,6 +252,10 @@ class Context:
         """The context map's "dataType" entry (a DATA_TYPES name or value) that the next transform instance will see."""
         dt = DATA_TYPES[data_type.upper()] if isinstance(data_type, str) else int(data_type)
         self.check(self.lib.kz_ctx_set_data_type(self.h, dt))
+
+    def reset(self):
+        """Every set_* value back to a fresh context's."""
+        self.check(self.lib.kz_ctx_reset(self.h))
 
     def get_data_type(self):
         """What the last forward transform left in the context's "dataType" entry (DATA_TYPES value)."""

@@ -91,6 +91,14 @@ extern "C" int32_t kz_ctx_set_entropy(kz_ctx* ctx, uint32_t entropyType) {
   ctx->entropy = (int)entropyType;
   return 0;
 }
+// every kz_ctx_set_* value back to what a fresh context has (a caller that leaves through an error path need not remember which
+// entries of its "map" it had set)
+extern "C" int32_t kz_ctx_reset(kz_ctx* ctx) {
+  if (!ctx) return -KZ_ERR_INVALID_PARAM;
+  ctx->checksum = 0; ctx->skipBlocks = 0; ctx->dataType = KZ_DT_UNDEFINED;
+  ctx->blockSize = 4 * 1024 * 1024; ctx->blockSizeSet = false; ctx->entropy = KZ_E_NONE;
+  return 0;
+}
 extern "C" int32_t kz_ctx_get_data_type(kz_ctx* ctx) { return ctx ? ctx->dataType : -KZ_ERR_INVALID_PARAM; }
 // N ranks on one host (one process per GPU): keep the process's host threads (TEXT / UTF stages, bit assembly, staging copies)
 // on the CPUs next to its GPU.  Reads /sys/bus/pci/devices/<bdf>/local_cpulist; returns the number of CPUs pinned to, 0 when

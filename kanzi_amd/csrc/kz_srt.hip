@@ -310,11 +310,10 @@ __global__ __launch_bounds__(512) void k_srt_inv(const u8* __restrict__ src, u8*
       u32 v = ring[c][lane];
       for (;;) {
         const int c2 = (int)(((u32)__builtin_amdgcn_readfirstlane((int)list) >> 8) & 0xFF);
-        if (__builtin_expect((c2 == c) | (pendSym == c2), 0)) {       // (one test on the hot path for two rare cases)
-          if (c2 == c) break;                                         // a list with the same symbol twice (only damaged input has one):
-                                                                      //   its state changes in this step, no reading ahead
-          SRT_FLUSH();                                                // c2's ring is being refilled: write it before it is read
-        }
+        // two rare cases leave the hot loop for one complete step (which re-reads everything; a pending refill is then written on
+        // the way back in): c2's ring is still being refilled, or -- damaged input only -- the list holds the same symbol twice, so
+        // that c2's state changes in this very step
+        if (__builtin_expect((c2 == c) | (pendSym == c2), 0)) break;
         const int32_t cur2 = bstart[c2], end2 = bend[c2];             // (wave-uniform LDS reads; made scalar when they are used)
         const u32 v2 = ring[c2][lane];
         const int sh = cur & 63;
