@@ -10,7 +10,10 @@ from test_gpu_parity import _fuzz_input
 ctx = kz.Context(0)
 chains = ["BWT+RANK+ZRLT", "BWT+MTFT+ZRLT", "BWT+SRT+ZRLT", "BWT", "RANK", "MTFT", "ZRLT", "SRT", "LZ", "LZX", "RANK+ZRLT", "LZ+ZRLT", "NONE",
           "PACK", "DNA", "MM", "PACK+MM+LZX", "DNA+LZ", "MM+LZX", "PACK+LZ", "PACK+BWT+RANK+ZRLT", "PACK+ZRLT", "MM+PACK", "DNA+MM+LZX",
-          "LZX+BWT+RANK+ZRLT", "MM+BWT+SRT+ZRLT"]
+          "LZX+BWT+RANK+ZRLT", "MM+BWT+SRT+ZRLT",
+          # round 3: chains led by the host stages (levels 5, 6, 3 and shorter ones); run with KZ_STREAM_CHUNK=8 KZ_HOST_CHUNK=8
+          # KZ_HOST_CHUNK_DEC=8 to send every stream through the pipelines
+          "TEXT+UTF+BWT+RANK+ZRLT", "TEXT+UTF+BWT+SRT+ZRLT", "TEXT+UTF+PACK+MM+LZX", "TEXT+LZ", "UTF+BWT+RANK+ZRLT", "TEXT+UTF"]
 ents = ["ANS0", "HUFFMAN", "FPAQ", "NONE"]
 alias = [d for _, d in refinputs.alias_inputs()]
 seeds = [int(x) for x in os.environ.get("SEEDS", "1,2,3").split(",")]
