@@ -34,6 +34,11 @@ extern "C" kz_ctx* kz_ctx_create(int32_t deviceId) {
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
   if (hipHostMalloc((void**)&ctx->hpin, 1 << 20, hipHostMallocDefault) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return nullptr; }
   ctx->hpinInts = (1 << 20) / 4;
+  {
+    const char* e = getenv("KZ_BLOCKING_WAITS");
+    const int hw = (int)std::thread::hardware_concurrency();
+    ctx->blockingWaits = e ? (atoi(e) ? 1 : 0) : ((hw > 0 && kz_usable_cpus() < hw) ? 1 : 0);
+  }
   return ctx;
 }
 extern "C" void kz_ctx_destroy(kz_ctx* ctx) {
@@ -55,6 +60,7 @@ extern "C" void kz_ctx_destroy(kz_ctx* ctx) {
     if (ctx->devIn[i].p) hipFree(ctx->devIn[i].p);
     if (ctx->devOut[i].p) hipFree(ctx->devOut[i].p);
   }
+  if (ctx->evBlock) hipEventDestroy(ctx->evBlock);
   if (ctx->copyUp) hipStreamDestroy(ctx->copyUp);
   if (ctx->copyDown) hipStreamDestroy(ctx->copyDown);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -139,7 +145,7 @@ extern "C" void* kz_ctx_stream(kz_ctx* ctx) { return ctx ? (void*)ctx->stream : 
 // kz_decode_blocks: 4B + 5B); grown here, never indexed beyond hpinInts
 int kz_hpin_reserve(kz_ctx* ctx, size_t ints) {
   if (ints <= ctx->hpinInts) return 0;
-  KZ_HIP(hipStreamSynchronize(ctx->stream));
+  KZ_HIP(kz_stream_sync(ctx, ctx->stream));
   if (ctx->hpin) { hipHostFree(ctx->hpin); ctx->hpin = nullptr; ctx->hpinInts = 0; }
   ints = kz_align(ints + (ints >> 2), 1 << 16);
   KZ_HIP(hipHostMalloc((void**)&ctx->hpin, ints * 4, hipHostMallocDefault));
@@ -388,7 +394,7 @@ struct Pipe {
 
 static int sync_lengths(kz_ctx* ctx, kz_batch& bt) {
   KZ_HIP(hipMemcpyAsync(ctx->hpin, bt.d_len, (size_t)bt.B * 4, hipMemcpyDeviceToHost, ctx->stream));
-  KZ_HIP(hipStreamSynchronize(ctx->stream));
+  KZ_HIP(kz_stream_sync(ctx, ctx->stream));
   for (int b = 0; b < bt.B; b++) bt.h_len[b] = ctx->hpin[b];
   return 0;
 }
@@ -746,7 +752,7 @@ static int overlap_alloc(kz_ctx* ctx, int B, Overlap& O) {
     G.d_in = d; G.len = d + B; G.len2 = d + 2 * B; G.flag = d + 3 * B; G.old = d + 4 * B;
     KZ_HIP(hipMemcpyAsync(G.d_in, G.in.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
   }
-  KZ_HIP(hipStreamSynchronize(ctx->stream));                        // pageable sources
+  KZ_HIP(kz_stream_sync(ctx, ctx->stream));                        // pageable sources
   return 0;
 }
 static int overlap_view(kz_ctx* ctx, const kz_batch& bt, OverlapGroup& G) {
@@ -777,7 +783,7 @@ static int overlap_streams(kz_ctx* ctx) {
   const char* e = getenv("KZ_WIDE_QUEUES");                         // (read per call: the tests force both schedules)
   if (e) { ctx->wideNow = atoi(e) ? 1 : 0; return 0; }
   if (ctx->wideQueues < 0) {
-    KZ_HIP(hipStreamSynchronize(ctx->stream));
+    KZ_HIP(kz_stream_sync(ctx, ctx->stream));
     hipStream_t q[4] = {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]};
     for (int r = 0; r < 2; r++) {                                   // first round: warm-up (queue creation, code load)
       const auto t0 = std::chrono::steady_clock::now();
@@ -850,7 +856,7 @@ static int overlap_start_rank(kz_ctx* ctx, const kz_batch& bt, int mode, Overlap
   }
   if (g == O.mainGroup) { G.ev = -1; return kz_stage_sbrt_inverse(ctx, G.v, mode); }
   G.ev = k;
-  KZ_HIP(hipStreamSynchronize(ctx->stream));
+  KZ_HIP(kz_stream_sync(ctx, ctx->stream));
   hipStream_t& sd = ctx->side[k];
   std::swap(ctx->stream, sd);
   rc = kz_stage_sbrt_inverse(ctx, G.v, mode);
@@ -1056,7 +1062,7 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
     rc = kz_skip_block_flags(ctx, bt, P.d_applied);
     if (rc) return rc;
     KZ_HIP(hipMemcpyAsync(ctx->hpin, P.d_applied, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    KZ_HIP(hipStreamSynchronize(st));
+    KZ_HIP(kz_stream_sync(ctx, st));
     for (int b = 0; b < B; b++) if (ctx->hpin[b]) h_copy[b] = 1;
   }
   if (hp > 0) {
@@ -1074,12 +1080,12 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
         for (int b = 0; b < B; b++)
           if (lengths[b]) KZ_HIP(hipMemcpyAsync(hostCopy.get() + (size_t)b * maxN, in + (int64_t)b * inStride, (size_t)lengths[b], hipMemcpyDeviceToHost, st));
         hsrc = hostCopy.get(); hstride = maxN;
-        KZ_HIP(hipStreamSynchronize(st));
+        KZ_HIP(kz_stream_sync(ctx, st));
       }
       host_prestage(types, hp, (int)entropyType, blockSize, maxLen, hsrc, hstride, lengths, h_copy.data(), B, mine);
       pre = &mine;
     }
-    KZ_HIP(hipStreamSynchronize(st));                                            // the blocks are in HBM, hashed and tagged: slots may be rewritten
+    KZ_HIP(kz_stream_sync(ctx, st));                                            // the blocks are in HBM, hashed and tagged: slots may be rewritten
     for (int b = 0; b < B; b++) {
       if (h_copy[b]) { bt.h_len[b] = lengths[b]; continue; }                     // (a pre-staged block of <= 15 bytes was left alone as well)
       h_skip[b] = pre->skip[b];
@@ -1089,7 +1095,7 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
     }
     KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     KZ_HIP(hipMemcpyAsync(bt.d_dtype, pre->dtype.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-    KZ_HIP(hipStreamSynchronize(st));                                            // pageable sources; `mine` is a local
+    KZ_HIP(kz_stream_sync(ctx, st));                                            // pageable sources; `mine` is a local
     kz_stage_end(ctx, e0, KZ_STAGE_HOST_FWD, 0);
   }
   for (int i = hp; i < nb; i++) {
@@ -1142,10 +1148,10 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
       if (entropyType == KZ_E_NONE) {
         for (int b = 0; b < B; b++) hb[b] = 8LL * bt.h_len[b];
         KZ_HIP(hipMemcpyAsync(F.bits, hb.data(), (size_t)B * 8, hipMemcpyHostToDevice, st));
-        KZ_HIP(hipStreamSynchronize(st));
+        KZ_HIP(kz_stream_sync(ctx, st));
       } else {
         for (int b = 0; b < B; b++) if (h_copy[b]) { hb[b] = 8LL * bt.h_len[b]; KZ_HIP(hipMemcpyAsync(F.bits + b, &hb[b], 8, hipMemcpyHostToDevice, st)); }
-        KZ_HIP(hipStreamSynchronize(st));                                          // hb is a local
+        KZ_HIP(kz_stream_sync(ctx, st));                                          // hb is a local
       }
     }
     kz_stage_end(ctx, e0, KZ_STAGE_ENTROPY_ENC, inBytes);
@@ -1159,14 +1165,14 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
     kz_stage_end(ctx, e0, KZ_STAGE_FRAME_ENC, 0);
   }
   KZ_HIP(hipMemcpyAsync(results, d_res, (size_t)B * sizeof(kz_block_result), hipMemcpyDeviceToHost, st));
-  KZ_HIP(hipStreamSynchronize(st));
+  KZ_HIP(kz_stream_sync(ctx, st));
   for (int b = 0; b < B; b++) if (h_threw[b]) { results[b].status = -KZ_ERR_PROCESS_BLOCK; results[b].bits = 0; results[b].length = 0; }
   if (host) {
     for (int b = 0; b < B; b++) {
       const size_t nbytes = (size_t)((results[b].bits + 7) >> 3);
       if (nbytes) KZ_HIP(hipMemcpyAsync(out + (int64_t)b * outStride, d_out + (int64_t)b * outStride, nbytes, hipMemcpyDeviceToHost, st));
     }
-    KZ_HIP(hipStreamSynchronize(st));
+    KZ_HIP(kz_stream_sync(ctx, st));
   }
   KZ_HIP(hipGetLastError());
   kz_ktimer_flush(ctx);
@@ -1342,7 +1348,7 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
   KZ_HIP(hipMemcpyAsync(hpb + 2 * B, F.raw, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   KZ_HIP(hipMemcpyAsync(hpb + 3 * B, F.tcopy, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   KZ_HIP(hipMemcpyAsync(hpb + 4 * B, F.status, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-  KZ_HIP(hipStreamSynchronize(st));
+  KZ_HIP(kz_stream_sync(ctx, st));
   kz_stage_end(ctx, e0, KZ_STAGE_FRAME_DEC, 0);
   std::vector<int32_t> h_pre(hpb, hpb + B), h_skip(hpb + B, hpb + 2 * B), h_raw(hpb + 2 * B, hpb + 3 * B), h_tc(hpb + 3 * B, hpb + 4 * B), h_status(hpb + 4 * B, hpb + 5 * B);
   for (int b = 0; b < B; b++) bt.h_len[b] = h_status[b] ? 0 : h_pre[b];
@@ -1373,7 +1379,7 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
     }
     KZ_HIP(hipMemcpyAsync(P.d_mask, h_rawp.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     KZ_LAUNCH(ctx, KID_COPY_PAYLOAD, k_copy_payload, dim3(64, B), dim3(256), d_in, inS, bt.buf[bt.cur], bt.stride, bt.d_len, F.hdrBytes, P.d_mask);
-    KZ_HIP(hipStreamSynchronize(st));                               // h_rawp is a local
+    KZ_HIP(kz_stream_sync(ctx, st));                               // h_rawp is a local
     kz_stage_end(ctx, e1, KZ_STAGE_ENTROPY_DEC, outBytes);
     return 0;
   };
@@ -1477,7 +1483,7 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
     // host stages (UTF, TEXT inverse) behind the GPU stages: blocks that went through one come back to the host, are decoded
     // on host threads and return to their slot
     hipEvent_t e1; kz_stage_begin(ctx, &e1);
-    KZ_HIP(hipStreamSynchronize(st));
+    KZ_HIP(kz_stream_sync(ctx, st));
     HostInv H;
     H.device = ctx->device; H.types = types; H.hp = hp; H.blockSize = blockSize; H.cap = dataCap;
     H.dbuf = bt.buf[bt.cur]; H.dstride = bt.stride; H.slotCap = bt.stride; H.hostMem = false;
@@ -1485,7 +1491,7 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
     kz_parallel_for(B, KZ_HOST_STAGE_THREADS, host_inverse_block, &H);
     if (H.fail) { snprintf(ctx->err, sizeof(ctx->err), "host stage: copy from / to the device failed"); return -KZ_ERR_DEVICE; }
     KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-    KZ_HIP(hipStreamSynchronize(st));
+    KZ_HIP(kz_stream_sync(ctx, st));
     kz_stage_end(ctx, e1, KZ_STAGE_HOST_INV, 0);
   }
   // ---- checksum verification (CompressedInputStream.java:1349-1363) ----
@@ -1495,7 +1501,7 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
     std::vector<u64> h1(B), h2(B);
     KZ_HIP(hipMemcpyAsync(h1.data(), F.hashRef, (size_t)B * 8, hipMemcpyDeviceToHost, st));
     KZ_HIP(hipMemcpyAsync(h2.data(), d_hashOut, (size_t)B * 8, hipMemcpyDeviceToHost, st));
-    KZ_HIP(hipStreamSynchronize(st));
+    KZ_HIP(kz_stream_sync(ctx, st));
     for (int b = 0; b < B; b++) if (!h_status[b] && bt.h_len[b] > 0 && h1[b] != h2[b]) h_status[b] = -KZ_ERR_CRC_CHECK;
   }
   // ---- results ----
@@ -1511,7 +1517,7 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
     KZ_HIP(hipMemcpyAsync(bt.d_len, ctx->hpin, (size_t)B * 4, hipMemcpyHostToDevice, st));
     KZ_LAUNCH(ctx, KID_COPY_BYTES, k_copy_bytes, dim3(64, B), dim3(256), bt.buf[bt.cur], bt.stride, out, outStride, bt.d_len, (const int32_t*)nullptr, (const int32_t*)nullptr);
   }
-  KZ_HIP(hipStreamSynchronize(st));
+  KZ_HIP(kz_stream_sync(ctx, st));
   KZ_HIP(hipGetLastError());
   kz_ktimer_flush(ctx);
   return 0;
@@ -1674,7 +1680,7 @@ static int32_t transform_one(kz_ctx* ctx, uint32_t type, bool forward, const uin
   if (forward) {
     int32_t dt = 0;
     KZ_HIP(hipMemcpyAsync(&dt, bt.d_dtype, 4, hipMemcpyDeviceToHost, st));
-    KZ_HIP(hipStreamSynchronize(st));
+    KZ_HIP(kz_stream_sync(ctx, st));
     ctx->dataType = dt;
   }
   if (applied[0] < 0) { snprintf(ctx->err, sizeof(ctx->err), "transform %u: the reference codec throws on this block (LZ token buffer)", type); return -KZ_ERR_PROCESS_BLOCK; }
@@ -1682,7 +1688,7 @@ static int32_t transform_one(kz_ctx* ctx, uint32_t type, bool forward, const uin
   if (bt.h_len[0] > dstCap) return 0;
   *produced = bt.h_len[0];
   if (bt.h_len[0] > 0) KZ_HIP(hipMemcpyAsync(dst, bt.buf[bt.cur], (size_t)bt.h_len[0], hipMemcpyDeviceToHost, st));
-  KZ_HIP(hipStreamSynchronize(st));
+  KZ_HIP(kz_stream_sync(ctx, st));
   return 1;
 }
 extern "C" int32_t kz_transform_forward(kz_ctx* ctx, uint32_t type, const uint8_t* src, int32_t n, uint8_t* dst, int32_t dstCap, int32_t* produced) {
@@ -1726,7 +1732,7 @@ extern "C" int64_t kz_entropy_encode(kz_ctx* ctx, uint32_t type, const uint8_t* 
     rc = (type == KZ_E_ANS0) ? kz_stage_ans0_encode(ctx, bt, d_out, oS, d_hdr, d_bits) : (type == KZ_E_HUFFMAN) ? kz_stage_huffman_encode(ctx, bt, d_out, oS, d_hdr, d_bits) : kz_stage_fpaq_encode(ctx, bt, d_out, oS, d_hdr, d_bits);
     if (rc) return rc;
     KZ_HIP(hipMemcpyAsync(&bits, d_bits, 8, hipMemcpyDeviceToHost, st));
-    KZ_HIP(hipStreamSynchronize(st));
+    KZ_HIP(kz_stream_sync(ctx, st));
   } else {
     KZ_HIP(hipMemcpyAsync(d_out, bt.buf[0], (size_t)n, hipMemcpyDeviceToDevice, st));
     bits = 8LL * n;
@@ -1734,7 +1740,7 @@ extern "C" int64_t kz_entropy_encode(kz_ctx* ctx, uint32_t type, const uint8_t* 
   const int64_t nbytes = (bits + 7) >> 3;
   if (nbytes > outCapBytes) return -KZ_ERR_WRITE_FILE;
   KZ_HIP(hipMemcpyAsync(out, d_out, (size_t)nbytes, hipMemcpyDeviceToHost, st));
-  KZ_HIP(hipStreamSynchronize(st));
+  KZ_HIP(kz_stream_sync(ctx, st));
   return bits;
 }
 
@@ -1770,7 +1776,7 @@ extern "C" int32_t kz_entropy_decode(kz_ctx* ctx, uint32_t type, const uint8_t* 
     long long used = 0;
     KZ_HIP(hipMemcpyAsync(&flag, bt.d_flag, 4, hipMemcpyDeviceToHost, st));
     KZ_HIP(hipMemcpyAsync(&used, d_off + 2, 8, hipMemcpyDeviceToHost, st));
-    KZ_HIP(hipStreamSynchronize(st));
+    KZ_HIP(kz_stream_sync(ctx, st));
     if (!flag) return -KZ_ERR_PROCESS_BLOCK;
     if (bitsConsumed) *bitsConsumed = (int64_t)used;
     KZ_HIP(hipMemcpyAsync(dst, bt.buf[bt.cur], (size_t)count, hipMemcpyDeviceToHost, st));
@@ -1779,6 +1785,6 @@ extern "C" int32_t kz_entropy_decode(kz_ctx* ctx, uint32_t type, const uint8_t* 
     KZ_HIP(hipMemcpyAsync(dst, d_in, (size_t)count, hipMemcpyDeviceToHost, st));
     if (bitsConsumed) *bitsConsumed = 8LL * count;
   }
-  KZ_HIP(hipStreamSynchronize(st));
+  KZ_HIP(kz_stream_sync(ctx, st));
   return count;
 }

@@ -1015,7 +1015,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
       KZ_LAUNCH(ctx, KID_BUCKET_COUNT_S, k_bucket_count_s, dim3(nBuckets, B), dim3(256), kC, vC, A, bitsR, bitsG, gmax);
       KZ_LAUNCH(ctx, KID_BUCKET_COUNT, k_bucket_count, dim3(nBuckets, B), dim3(1024), kC, vC, A, bitsR, bitsG, gmax);
       KZ_LAUNCH(ctx, KID_BUCKET_SORT, k_bucket_sort, dim3(nBuckets, B), dim3(1024), kC, vC, A, bitsR, bitsG);
-      KZ_HIP(hipStreamSynchronize(st));
+      KZ_HIP(kz_stream_sync(ctx, st));
       wMax = 0;
       for (int b = 0; b < B; b++) if (ctx->hpin[b] > wMax) wMax = ctx->hpin[b];
       windowed = true;
@@ -1056,7 +1056,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
     { u64* tk = kC; kC = kF; kF = tk; u32* tv = vC; vC = vF; vF = tv; }
     // ---- read back the next compact sizes ----
     KZ_HIP(hipMemcpyAsync(ctx->hpin, A.d_m2, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    KZ_HIP(hipStreamSynchronize(st));
+    KZ_HIP(kz_stream_sync(ctx, st));
     mMax = 0;
     for (int b = 0; b < B; b++) if (ctx->hpin[b] > mMax) mMax = ctx->hpin[b];
     if (getenv("KZ_BWT_TRACE")) {                                   // diagnostic: live suffixes left after every doubling round

@@ -67,11 +67,25 @@ struct kz_ctx {
   Stage devIn[2], devOut[2];       // HBM outside the arena (the arena is reset by every batched call)
   Stage hsIn[2], hsOut[2];         // pinned: the host-stage pipeline's copy of a chunk's blocks / the stages' outputs (kz_api.hip)
   hipStream_t copyUp = nullptr, copyDown = nullptr;
+  // waits of the context's own thread: 1 = block on an event (hipEventBlockingSync) instead of hipStreamSynchronize's spin loop.
+  // Chosen at creation: on when the process is CPU-quota limited (a spinning waiter burns a whole CPU of the quota that the
+  // host stages -- or the other ranks of the node -- could use), KZ_BLOCKING_WAITS=0/1 overrides.
+  int blockingWaits = 0;
+  hipEvent_t evBlock = nullptr;
 };
 
 #define KZ_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
   snprintf(ctx->err, sizeof(ctx->err), "%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
   return -KZ_ERR_DEVICE; } } while (0)
+
+// wait for everything queued on `st` (the context's thread only)
+static inline hipError_t kz_stream_sync(kz_ctx* ctx, hipStream_t st) {
+  if (!ctx->blockingWaits) return hipStreamSynchronize(st);
+  if (!ctx->evBlock) { hipError_t e = hipEventCreateWithFlags(&ctx->evBlock, hipEventBlockingSync | hipEventDisableTiming); if (e != hipSuccess) return e; }
+  hipError_t e = hipEventRecord(ctx->evBlock, st);
+  if (e != hipSuccess) return e;
+  return hipEventSynchronize(ctx->evBlock);
+}
 
 #define KZ_MAX_PACKED_BLOCK ((1 << 24) - 257)   // largest block the packed inverse BWT / RANK kernels take
 #define KZ_MAX_BATCH 65535        // blocks per launch: the batched kernels carry the block index in gridDim.y (<= 65535)

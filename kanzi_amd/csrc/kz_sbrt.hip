@@ -694,7 +694,7 @@ int kz_place_blocks(kz_ctx* ctx, const kz_batch& bt, KzPlacement& PL) {
   int32_t* d = (int32_t*)kz_arena_alloc(ctx, order.size() * 4);
   if (!d) { snprintf(ctx->err, sizeof(ctx->err), "placement: arena overflow"); return -KZ_ERR_DEVICE; }
   KZ_HIP(hipMemcpyAsync(d, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  KZ_HIP(hipStreamSynchronize(ctx->stream));                        // order[] is a local
+  KZ_HIP(kz_stream_sync(ctx, ctx->stream));                        // order[] is a local
   PL.d_order = d;
   return 0;
 }
