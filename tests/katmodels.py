@@ -972,3 +972,114 @@ def utf_forward(data, data_type="UNDEFINED"):
     out[1] = i - src_end
     out += src[i:src_end + 4]
     return len(out) < max_target, bytes(out), left
+
+
+# ---- MM = FSDCodec.forward (K/transform/FSDCodec.java:63-246): which step and which coding are CHOICES made from sampled entropies ----
+import math as _math
+
+_LOG2_4096 = [0] + [int(_math.floor(4096.0 * _math.log2(x) + 0.5)) for x in range(1, 257)]   # Global.LOG2_4096 (:103-127) = round(4096 log2 x)
+
+
+def log2_1024(x):
+    """K/Global.java log2_1024 :221-235"""
+    if x < 256:
+        return (_LOG2_4096[x] + 2) >> 2
+    log = x.bit_length() - 1
+    if x & (x - 1) == 0:
+        return log << 10
+    return (log - 7) * 1024 + ((_LOG2_4096[x >> (log - 7)] + 2) >> 2)
+
+
+def first_order_entropy_1024(length, histo):
+    """K/Global.java computeFirstOrderEntropy1024 :440-456 (Java long arithmetic, >> 3 per symbol, integer division at the end)"""
+    if length == 0:
+        return 0
+    ll = log2_1024(length)
+    total = 0
+    for h in histo:
+        if h:
+            total += (h * (ll - log2_1024(h))) >> 3
+    return total // length
+
+
+def magic_type(src):
+    """K/Magic.java getType :154-183"""
+    if len(src) < 4:
+        return 0
+    key = int.from_bytes(src[:4], "big")
+    if key & ~0x0F & 0xFFFFFFFF == 0xFFD8FFE0:
+        return key
+    if (key >> 8) in (0x425A68, 0x494433):
+        return key >> 8
+    if key in (0x47494638, 0x25504446, 0x504B0304, 0x377ABCAF, 0x89504E47, 0x7F454C46, 0xFEEDFACE, 0xCEFAEDFE, 0xFEEDFACF, 0xCFFAEDFE,
+               0x28B52FFD, 0x81CFB2CE, 0x4D534346, 0x52494646, 0x664C6143, 0xFD377A58, 0x4B414E5A, 0x52617221):
+        return key
+    key16 = key >> 16
+    if key16 in (0x1F8B, 0x424D, 0x4D5A):
+        return key16
+    if key16 in (0x5034, 0x5035, 0x5036) and ((key >> 8) & 0xFF) in (0x07, 0x0A, 0x0D, 0x20):
+        return key16
+    return 0
+
+
+def fsd_forward(data, data_type="UNDEFINED"):
+    """K/transform/FSDCodec.java forward :63-246 with a context.  Returns (applied, bytes, dataType left in the context)."""
+    src = bytes(data)
+    count = len(src)
+    if count == 0:
+        return True, b"", data_type
+    if count < 1024:
+        return False, b"", data_type
+    if data_type not in ("UNDEFINED", "MULTIMEDIA", "BIN"):
+        return False, b"", data_type
+    if magic_type(src) not in (0x424D, 0x52494646, 0x5034, 0x5035, 0x5036, 0):
+        return False, b"", data_type
+    dist_of = (0, 1, 2, 3, 4, 8, 16)
+    count10 = count // 10
+    count5 = 2 * count10
+    histo = [[0] * 256 for _ in range(7)]
+    for st in (0, 2 * count5, 4 * count5):
+        for i in range(count10, count5):
+            b = src[st + i]
+            histo[0][b] += 1
+            for k in range(1, 7):
+                histo[k][b ^ src[st + i - dist_of[k]]] += 1
+    ent = [first_order_entropy_1024(3 * count10, h) for h in histo]
+    min_idx = 0
+    for i in range(7):
+        if ent[i] < ent[min_idx]:
+            min_idx = i
+    if ent[min_idx] >= ent[0]:
+        return False, b"", detect_simple_type(3 * count10, histo[0])
+    left = "MULTIMEDIA"
+    dist = dist_of[min_idx]
+    large = 0
+    for i in range(2 * count5, 3 * count5):
+        delta = src[i] - src[i - dist]
+        if delta < -127 or delta > 127:
+            large += 1
+    xor_coding = large > (count5 >> 5)
+    max_len = count + max(64, count >> 4)                                         # getMaxEncodedLength :320-323
+    out = bytearray([1 if xor_coding else 0, dist]) + src[:dist]
+    si = dist
+    if not xor_coding:
+        while si < count and len(out) < max_len - 1:
+            delta = src[si] - src[si - dist]
+            if delta < -127 or delta > 127:
+                out += bytes([255, src[si] ^ src[si - dist]])
+            else:
+                out.append(((delta >> 31) ^ (delta << 1)) & 0xFF)                 # zigzag
+            si += 1
+    else:
+        while si < count:
+            out.append(src[si] ^ src[si - dist])
+            si += 1
+    if si != count:
+        return False, b"", left
+    h = [0] * 256
+    for i in range(count10):
+        h[out[count5 + i]] += 1
+        h[out[3 * count5 + i]] += 1
+    if first_order_entropy_1024(count5, h) >= ent[0]:
+        return False, b"", left
+    return True, bytes(out), left

@@ -512,3 +512,25 @@ def test_utf_forward_known_answers_from_a_python_model(built):
                 assert enc_m == enc_o, (name, dt)
                 applied += 1
     assert applied >= 4
+
+
+def test_mm_forward_known_answers_from_a_python_model(built):
+    """FSDCodec.forward (FSDCodec.java:63-246): the sampled entropies (Global.computeFirstOrderEntropy1024, log2_1024), the step and
+    the coding it picks, escapes, the final sanity check, Magic.getType and the dataType it leaves behind"""
+    import katmodels
+    cases = [("mm%d" % k, refinputs.multimedia_like(k, 60000 + 7 * k, seed=k + 1)) for k in range(5)]
+    cases += [("mm%d_short" % k, refinputs.multimedia_like(k, 1024 + k, seed=9)) for k in range(5)]
+    cases += [("bmp", b"BM" + refinputs.multimedia_like(1, 30000, seed=3)), ("riff", b"RIFF" + refinputs.multimedia_like(0, 30000, seed=4)),
+              ("gif", b"GIF8" + refinputs.multimedia_like(2, 30000, seed=5)), ("ppm", b"P6\n" + refinputs.multimedia_like(1, 30000, seed=6))]
+    cases += [(n, d) for n, d in _model_inputs() if n.startswith(("class", "english", "dna", "digits", "ref1", "ref2"))]
+    applied = 0
+    for name, d in cases:
+        for dt in ("UNDEFINED", "MULTIMEDIA", "TEXT"):
+            ok_m, enc_m, left_m = katmodels.fsd_forward(d, dt)
+            ok_o, enc_o, left_o = oracle.transform_forward("MM", d, data_type=oracle.DT[dt])
+            assert (ok_m, oracle.DT[left_m]) == (ok_o, left_o), (name, dt, ok_m, ok_o, left_m, left_o)
+            if ok_m and len(d):
+                assert enc_m == enc_o, (name, dt)
+                applied += 1
+    assert applied >= 8
+    assert katmodels.log2_1024(1) == 0 and katmodels.log2_1024(3) == 1623 and katmodels.log2_1024(4096) == 12288
