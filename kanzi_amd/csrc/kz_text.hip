@@ -11,6 +11,9 @@
 #include "kz_internal.h"
 #include "kz_magic.h"
 #include "kz_text_dict.h"
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <algorithm>
 #include <memory>
 #include <mutex>
@@ -29,6 +32,27 @@ constexpr int kNotText = 0x80, kCRLF = 0x40, kXml = 0x20, kCodecBit = 0x10, kDtM
 constexpr u32 kIdxMask = 0x0007FFFF;                                                                 // :53
 
 inline bool is_text(u8 c) { const u8 l = c | 0x20; return l >= 'a' && l <= 'z'; }                    // :247-249 (bytes >= 0x80 never are)
+
+// ---- 32 bytes at a time (AVX2; the scalar loops below them are the reference form and the fallback) ----
+// The reference walks a block byte by byte (:694-790); three quarters of the bytes of a text are letters inside words, at which
+// nothing happens.  The host CPUs are what the level-exact chains wait for, so the walks skip them with one compare per
+// 32 bytes: a bit mask of the letters, and only the non-letters are visited.
+#if defined(__x86_64__)
+#define KZ_TEXT_AVX2 1
+__attribute__((target("avx2"))) inline u32 letters32(const u8* p) {                                  // bit k: p[k] is a letter
+  const __m256i v = _mm256_loadu_si256((const __m256i*)p);
+  const __m256i t = _mm256_sub_epi8(_mm256_or_si256(v, _mm256_set1_epi8(0x20)), _mm256_set1_epi8('a'));
+  return (u32)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_max_epu8(t, _mm256_set1_epi8(25)), _mm256_set1_epi8(25)));
+}
+__attribute__((target("avx2"))) inline u32 eq32(const u8* p, char c) {
+  return (u32)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)p), _mm256_set1_epi8(c)));
+}
+__attribute__((target("avx2"))) inline u32 high32(const u8* p) { return (u32)_mm256_movemask_epi8(_mm256_loadu_si256((const __m256i*)p)); }   // bit k: p[k] >= 0x80
+inline bool have_avx2() { static const bool v = __builtin_cpu_supports("avx2"); return v; }
+#else
+#define KZ_TEXT_AVX2 0
+inline bool have_avx2() { return false; }
+#endif
 inline u32 hash_step(u32 h, u8 c) { return h * kHash1 ^ (u32)(int32_t)(int8_t)c * kHash2; }          // :234: Java byte is signed
 
 struct Word { u32 hash; int32_t pos; u32 lenIdx; const u8* text; };       // lenIdx = length << 24 | word number (DictEntry.data)
@@ -111,6 +135,38 @@ bool utf8_pairs_ok(const int32_t* f0, PairCounts& pc, int64_t* continuation) {
   return true;
 }
 
+// pairs (previous byte, byte) the text path asks about; the first byte's previous byte is 0 (as in the reference's pair table)
+#define KZ_PAIR(A, B) { amp += ((A) == '&') & (((B) == 'a') | ((B) == 'g') | ((B) == 'l') | ((B) == 'q')); \
+                        crx += ((A) == kCR) & ((B) != kLF); xlf += ((B) == kLF) & ((A) != kCR); }
+#if KZ_TEXT_AVX2
+__attribute__((target("avx2"))) int pair_counts_avx2(const u8* p, int n, int64_t& amp, int64_t& crx, int64_t& xlf) {
+  int i = 1;
+  const __m256i kAmp = _mm256_set1_epi8('&'), kA = _mm256_set1_epi8('a'), kG = _mm256_set1_epi8('g'), kL = _mm256_set1_epi8('l'),
+                kQ = _mm256_set1_epi8('q'), vCR = _mm256_set1_epi8((char)kCR), vLF = _mm256_set1_epi8((char)kLF);
+  for (; i + 32 <= n; i += 32) {
+    const __m256i prev = _mm256_loadu_si256((const __m256i*)(p + i - 1)), cur = _mm256_loadu_si256((const __m256i*)(p + i));
+    const __m256i aglq = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(cur, kA), _mm256_cmpeq_epi8(cur, kG)),
+                                         _mm256_or_si256(_mm256_cmpeq_epi8(cur, kL), _mm256_cmpeq_epi8(cur, kQ)));
+    const __m256i pcr = _mm256_cmpeq_epi8(prev, vCR), clf = _mm256_cmpeq_epi8(cur, vLF);
+    amp += __builtin_popcount((u32)_mm256_movemask_epi8(_mm256_and_si256(_mm256_cmpeq_epi8(prev, kAmp), aglq)));
+    crx += __builtin_popcount((u32)_mm256_movemask_epi8(_mm256_andnot_si256(clf, pcr)));
+    xlf += __builtin_popcount((u32)_mm256_movemask_epi8(_mm256_andnot_si256(pcr, clf)));
+  }
+  return i;
+}
+#endif
+void pair_counts(const u8* p, int n, int64_t* pamp, int64_t* pcrx, int64_t* pxlf) {
+  int64_t amp = 0, crx = 0, xlf = 0;
+  if (n > 0) KZ_PAIR(0, p[0])
+  int i = 1;
+#if KZ_TEXT_AVX2
+  if (have_avx2() && n >= 64) i = pair_counts_avx2(p, n, amp, crx, xlf);
+#endif
+  for (; i < n; i++) KZ_PAIR(p[i - 1], p[i])
+  *pamp = amp; *pcrx = crx; *pxlf = xlf;
+}
+#undef KZ_PAIR
+
 int text_block_mode(const u8* p, int count, bool strict) {
   if (!strict && mm_magic_type(p) != 0) return kNotText;                                             // :272-273
   // One pass: the order-0 histogram (four interleaved tables: no store-to-load chain on runs) and the handful of pair counts the
@@ -122,18 +178,11 @@ int text_block_mode(const u8* p, int count, bool strict) {
   memset(h4, 0, sizeof(h4));
   int64_t amp = 0, crOther = 0, otherLf = 0;
   {
-    int prev = 0, i = 0;
-    for (; i + 4 <= count; i += 4) {
-      const int c0 = p[i], c1 = p[i + 1], c2 = p[i + 2], c3 = p[i + 3];
-      h4[0][c0]++; h4[1][c1]++; h4[2][c2]++; h4[3][c3]++;
-#define KZ_PAIR(A, B) amp += ((A) == '&') & (((B) == 'a') | ((B) == 'g') | ((B) == 'l') | ((B) == 'q')); \
-                      crOther += ((A) == kCR) & ((B) != kLF); otherLf += ((B) == kLF) & ((A) != kCR);
-      KZ_PAIR(prev, c0) KZ_PAIR(c0, c1) KZ_PAIR(c1, c2) KZ_PAIR(c2, c3)
-      prev = c3;
-    }
-    for (; i < count; i++) { const int c = p[i]; h4[0][c]++; KZ_PAIR(prev, c) prev = c; }
-#undef KZ_PAIR
+    int i = 0;
+    for (; i + 4 <= count; i += 4) { h4[0][p[i]]++; h4[1][p[i + 1]]++; h4[2][p[i + 2]]++; h4[3][p[i + 3]]++; }
+    for (; i < count; i++) h4[0][p[i]]++;
   }
+  pair_counts(p, count, &amp, &crOther, &otherLf);
   int32_t f0[256];
   for (int c = 0; c < 256; c++) f0[c] = h4[0][c] + h4[1][c] + h4[2][c] + h4[3][c];
   int64_t letters = f0[kCR] + f0[kLF], ascii = 0;
@@ -301,21 +350,22 @@ int text_forward(int variant, int ctxBlockSize, int* dataType, const u8* src, in
   if (i >= n) return 0;
   int last = is_text(src[i]) ? i - 1 : i;          // position of the previous non-letter
   bool ok = true;
-  for (; i < n; i++) {
+  // what happens at a non-letter at position i (:704-790); false: the output ran out
+  auto visit = [&](const int i) -> bool {
     const u8 c = src[i];
-    if (is_text(c)) continue;
     if (i > last + 2 && sd.delim[c]) {             // a run of at least two letters closed by a delimiter (:704)
       const int len = i - last - 1;
       if (len <= kMaxWord) {
         const u8* w = src + last + 1;
         u32 h1 = kHash1 * kHash1 ^ (u32)(int32_t)(int8_t)w[0] * kHash2;
-        u32 h2 = kHash1 * kHash1 ^ (u32)(int32_t)(int8_t)(w[0] ^ 0x20) * kHash2;                  // first letter with the other case
-        for (int k = 1; k < len; k++) { const u32 t = (u32)(int32_t)(int8_t)w[k] * kHash2; h1 = h1 * kHash1 ^ t; h2 = h2 * kHash1 ^ t; }
+        for (int k = 1; k < len; k++) h1 = hash_step(h1, w[k]);
         const int s1 = dict.slot(h1);
         int found = -1;
         bool flipped = false;
         if (s1 >= 0 && dict.word(s1).hash == h1 && (int)(dict.word(s1).lenIdx >> 24) == len) found = s1;
-        else {
+        else {                                     // the hash with the first letter's case flipped is only needed now (:712-718)
+          u32 h2 = kHash1 * kHash1 ^ (u32)(int32_t)(int8_t)(w[0] ^ 0x20) * kHash2;
+          for (int k = 1; k < len; k++) h2 = hash_step(h2, w[k]);
           const int s2 = dict.slot(h2);
           if (s2 >= 0 && dict.word(s2).hash == h2 && (int)(dict.word(s2).lenIdx >> 24) == len) { found = s2; flipped = (s2 != s1); }
         }
@@ -328,7 +378,7 @@ int text_forward(int variant, int ctxBlockSize, int* dataType, const u8* src, in
         } else {
           // a single space between two references is implied (:752-754)
           if (pending != last || src[last] != ' ') at = em.plain(src, pending, last + 1, dst, at, end);
-          if (at >= margin) { ok = false; break; }
+          if (at >= margin) { ok = false; return false; }
           const int number = (int)(dict.word(found).lenIdx & kIdxMask);
           if (variant == 1) { dst[at++] = flipped ? kEsc2 : kEsc1; at = Emitter::index1(dst, at, number); }
           else { if (flipped) dst[at++] = 0x80; at = Emitter::index2(dst, at, number); }
@@ -337,6 +387,24 @@ int text_forward(int variant, int ctxBlockSize, int* dataType, const u8* src, in
       }
     }
     last = i;
+    return true;
+  };
+#if KZ_TEXT_AVX2
+  if (have_avx2()) {                               // only the non-letters are visited: one mask per 32 bytes
+    while (ok && i + 32 <= n) {
+      u32 nl = ~letters32(src + i);
+      while (nl) {
+        const int j = __builtin_ctz(nl);
+        nl &= nl - 1;
+        if (!visit(i + j)) break;
+      }
+      i += 32;
+    }
+  }
+#endif
+  for (; ok && i < n; i++) {                        // the reference's walk (and the last bytes of the block)
+    if (is_text(src[i])) continue;
+    if (!visit(i)) break;
   }
   if (ok) {
     const int e = em.plain(src, pending, n, dst, at, end);
