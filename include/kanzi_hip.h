@@ -109,6 +109,10 @@ int32_t     kz_pin_to_device_numa(int32_t deviceId);
 /* host CPUs the library's thread pool (TEXT / UTF stages, staging copies, bit assembly) will use: the process's affinity mask cut
  * down to its cgroup CPU quota, if any */
 int32_t     kz_host_cpus(void);
+/* N processes (one per GPU) under ONE cgroup quota: each takes 1/N of it (rounded up), so that together they stay inside -- a group
+ * that runs more busy threads than its quota is frozen as a whole for the rest of every period, GPU-driving threads included.
+ * ranksOnHost <= 1 restores the whole quota.  Returns the new kz_host_cpus(). */
+int32_t     kz_host_share(int32_t ranksOnHost);
 /* HIP stream the context launches on (as void* = hipStream_t) so callers can bracket it with events */
 void*       kz_ctx_stream(kz_ctx* ctx);
 

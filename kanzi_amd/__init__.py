@@ -74,6 +74,7 @@ def load_library():
         "kz_ctx_stream": (vp, [vp]),
         "kz_pin_to_device_numa": (c.c_int32, [c.c_int32]),
         "kz_host_cpus": (c.c_int32, []),
+        "kz_host_share": (c.c_int32, [c.c_int32]),
         "kz_ctx_set_checksum": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_set_skip_blocks": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_set_block_size": (c.c_int32, [vp, c.c_int32]),
@@ -125,7 +126,7 @@ def load_library():
     return L
 
 
-ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_error", "kz_ctx_stream", "kz_pin_to_device_numa", "kz_host_cpus", "kz_ctx_set_checksum",
+ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_error", "kz_ctx_stream", "kz_pin_to_device_numa", "kz_host_cpus", "kz_host_share", "kz_ctx_set_checksum",
                "kz_ctx_set_data_type", "kz_ctx_get_data_type", "kz_ctx_reset", "kz_ctx_set_skip_blocks", "kz_ctx_set_block_size", "kz_ctx_set_entropy",
                "kz_transform_forward", "kz_transform_inverse", "kz_transform_max_encoded_len", "kz_host_stage_forward", "kz_host_stage_inverse",
                "kz_entropy_encode", "kz_entropy_decode", "kz_encode_blocks", "kz_decode_blocks",
@@ -699,11 +700,13 @@ def usable_cpus():
 
 def pin_host_threads_to_gpu(device, world=2):
     """One process per GPU, `world` of them on one host: keep this process's host threads (TEXT / UTF stages, bit assembly,
-    staging copies) on the CPUs of the GPU's NUMA node.  A single process (world == 1) keeps the whole machine.  Returns the
+    staging copies) on the CPUs of the GPU's NUMA node, and its thread pool inside 1/world of the host's CPU quota.  A single process (world == 1) keeps the whole machine.  Returns the
     number of CPUs pinned to (0: nothing changed)."""
     if world <= 1:
         return 0
-    return max(0, int(load_library().kz_pin_to_device_numa(int(device))))
+    lib = load_library()
+    lib.kz_host_share(int(world))                 # and 1/world of the cgroup CPU quota, if there is one
+    return max(0, int(lib.kz_pin_to_device_numa(int(device))))
 
 
 def shard_blocks(n_blocks, world, rank):

@@ -47,8 +47,11 @@ int quota_cpus() {
   if (quota <= 0 || period <= 0) return 1 << 30;
   return (int)std::max<long long>(1, (quota + period - 1) / period);
 }
+std::atomic<int> g_share{1};      // processes on this host that share the quota (kz_host_share)
 int usable_cpus() {
-  static const int quota = quota_cpus();
+  static const int quota0 = quota_cpus();
+  const int sh = std::max(1, g_share.load(std::memory_order_relaxed));
+  const int quota = quota0 >= (1 << 30) ? quota0 : std::max(1, (quota0 + sh - 1) / sh);
   cpu_set_t set;
   CPU_ZERO(&set);
   int c = 0;
@@ -82,6 +85,7 @@ void worker(Pool* P) {
 // the CPUs this process may run on (N ranks on one host are pinned to their GPU's NUMA node: kz_pin_to_device_numa)
 int kz_usable_cpus() { return usable_cpus(); }
 extern "C" int32_t kz_host_cpus(void) { return usable_cpus(); }
+extern "C" int32_t kz_host_share(int32_t ranksOnHost) { g_share.store(ranksOnHost > 1 ? ranksOnHost : 1); return usable_cpus(); }
 
 // fn(i, arg) for i in [0, n) on up to maxThreads threads (the caller is one of them); returns when all are done.  May be called
 // from several host threads at once.
