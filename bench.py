@@ -505,6 +505,7 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         import oracle
         logical = os.cpu_count() or 1
+        kz.load_library().kz_host_share(1)                             # the other ranks sleep during this leg: the whole quota
         usable = kz.usable_cpus()                                      # affinity mask cut down to the cgroup CPU quota (the MI355X box: 256 logical, quota 16)
         what = "oracle/libkzo.so (C restatement, -O3 -march=x86-64-v3, induced-sorting BWT), %d threads over blocks"
 
@@ -555,7 +556,18 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if dist is not None:
-        barrier()                                                      # the other ranks wait for rank 0's CPU leg
+        # the other ranks wait for rank 0's CPU leg asleep on the rendezvous store's socket, not spinning in a GPU collective (under
+        # one cgroup CPU quota a spinning rank takes a CPU away from the leg being timed); then the ordinary barrier
+        try:
+            import datetime
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                store.set("kz_bench_cpu_leg", "done")
+            else:
+                store.wait(["kz_bench_cpu_leg"], datetime.timedelta(minutes=30))
+        except Exception:
+            pass
+        barrier()
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
