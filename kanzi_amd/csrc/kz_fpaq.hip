@@ -223,12 +223,18 @@ __device__ __forceinline__ void fp_copy(u8* __restrict__ d, const u8* __restrict
 
 // One range-coder step (FPAQEncoder.java:182-199 encodeBit + :208-213 flush), all operands wave-uniform.
 // Written branch-free (selects) except for the rare flush: a taken scalar branch costs a lone wave ~40 cycles.
-#define FPW_ENC_BIT(PP, BIT)                                                                    \
-  { const u64 split = (((high - low) >> 8) * (u64)(u32)(PP)) >> 8;                             \
-    const bool one = (BIT) != 0;                                                               \
-    const u64 nh = low + split, nl = nh + 1;                                                   \
-    high = one ? nh : high; low = one ? low : nl;                                              \
-    while (__builtin_expect(((low ^ high) & FP_M2456) == 0, 0)) {                              \
+// Round 3: the selects and the test of :190 as five scalar instructions (the compiler's form took ten: 32-bit halves, a separate
+// compare per use, the mask in two literals); KBIT = position of the coded bit in VAL.  t == 0: flush (:208-213).
+#define FPW_ENC_BIT(PP, VAL, KBIT)                                                              \
+  { const u64 nh = low + ((((high - low) >> 8) * (u64)(u32)(PP)) >> 8), nl = nh + 1;                        \
+    u64 t;                                                                                     \
+    asm volatile("s_bitcmp1_b32 %[val], " #KBIT "\n\t"                                         \
+                 "s_cselect_b64 %[high], %[nh], %[high]\n\t"                                  \
+                 "s_cselect_b64 %[low], %[low], %[nl]\n\t"                                    \
+                 "s_xor_b64 %[t], %[low], %[high]\n\t"                                        \
+                 "s_and_b64 %[t], %[t], %[mask]"                                               \
+                 : [high] "+s"(high), [low] "+s"(low), [t] "=&s"(t) : [val] "s"(VAL), [nh] "s"(nh), [nl] "s"(nl), [mask] "s"(m2456) : "scc"); \
+    if (__builtin_expect(t == 0, 0)) {              /* never twice in a row: bits 24..31 then differ (00 vs FF) */ \
       if (lane == 0) { const u32 w = (u32)(high >> 24); sba[idx] = (u8)(w >> 24); sba[idx + 1] = (u8)(w >> 16); sba[idx + 2] = (u8)(w >> 8); sba[idx + 3] = (u8)w; } \
       idx += 4;                                                                                \
       low <<= 32;                                                                              \
@@ -258,6 +264,7 @@ __global__ __launch_bounds__(512) void k_fpaq_enc_wave(const u8* __restrict__ sr
   u8* o = out + (int64_t)b * outStride + d_hdrBytes[b];
   int opos = 0;
   u64 low = 0, high = FP_TOP;
+  const u64 m2456 = FP_M2456;
   int startChunk = 0;
   const int kbit = 7 - (lane & 7);                                // lane k codes bit 7-k (MSB first)
   while (startChunk < count) {
@@ -286,8 +293,8 @@ __global__ __launch_bounds__(512) void k_fpaq_enc_wave(const u8* __restrict__ sr
       const int p7 = __builtin_amdgcn_readlane(cur, 0), p6 = __builtin_amdgcn_readlane(cur, 1), p5 = __builtin_amdgcn_readlane(cur, 2),
                 p4 = __builtin_amdgcn_readlane(cur, 3), p3 = __builtin_amdgcn_readlane(cur, 4), p2 = __builtin_amdgcn_readlane(cur, 5),
                 p1 = __builtin_amdgcn_readlane(cur, 6), p0 = __builtin_amdgcn_readlane(cur, 7);
-      FPW_ENC_BIT(p7, curVal & 0x80) FPW_ENC_BIT(p6, curVal & 0x40) FPW_ENC_BIT(p5, curVal & 0x20) FPW_ENC_BIT(p4, curVal & 0x10)
-      FPW_ENC_BIT(p3, curVal & 0x08) FPW_ENC_BIT(p2, curVal & 0x04) FPW_ENC_BIT(p1, curVal & 0x02) FPW_ENC_BIT(p0, curVal & 0x01)
+      FPW_ENC_BIT(p7, curVal, 7) FPW_ENC_BIT(p6, curVal, 6) FPW_ENC_BIT(p5, curVal, 5) FPW_ENC_BIT(p4, curVal, 4)
+      FPW_ENC_BIT(p3, curVal, 3) FPW_ENC_BIT(p2, curVal, 2) FPW_ENC_BIT(p1, curVal, 1) FPW_ENC_BIT(p0, curVal, 0)
     }
     // varint(idx) | bytes   (EntropyUtils.writeVarInt; :164-165)
     { u32 v = (u32)idx; while (v >= 128) { if (lane == 0) o[opos] = (u8)(0x80 | (v & 0x7F)); opos++; v >>= 7; } if (lane == 0) o[opos] = (u8)v; opos++; }
@@ -394,6 +401,131 @@ __global__ __launch_bounds__(512) void k_fpaq_dec_wave(const u8* __restrict__ in
 }
 
 
+// Round 3: the step restated so that a wave issues fewer instructions for it.  A lone wave issues one instruction every ~5.7 cycles
+// whatever unit it goes to (two waves per SIMD interleave at that rate each: 2048 blocks take as long as one), so the cost of a
+// bit is its instruction count.  The probability and its LDS address never leave the vector unit (update: 4 VALU; the address of
+// the node, of its children and of the next node follow from the previous address and the bit: byte address w of probs[tb + ctx]
+// -> 2w - tbBase + 4*bit), only the probability itself is copied to the scalar unit for the 56-bit range arithmetic.  `V` marks
+// values the compiler must treat as per-lane (they are uniform in fact): that keeps them on the VALU.
+typedef __attribute__((address_space(3))) int fpw_lds_int_t;
+__device__ __forceinline__ u32 fpw_lds_addr(const int* p) { return (u32)(size_t)(__attribute__((address_space(3))) const int*)p; }   // what ds_* take
+__device__ __forceinline__ int fpw_lds_int(int addr) { return *(const fpw_lds_int_t*)(size_t)(u32)addr; }
+#define FPW_V(x) asm volatile("" : "+v"(x))
+#define FPW_V64(x) asm volatile("" : "+v"(x))
+// the start of a step for the node at byte address VW with probability VP: request both children (the two candidates for the
+// next node: LDS latency is then covered by the step's arithmetic), copy the probability to the scalar unit
+#define FPW_DEC_OPEN()                                                                          \
+  asm volatile("v_lshl_add_u32 %[ca], %[vw], 1, %[ntb]\n\t"         /* children of ctx: probs[tb + 2 ctx] */ \
+               "ds_read_b32 %[c0], %[ca]\n\t"                                                 \
+               "ds_read_b32 %[c1], %[ca] offset:4"                                             \
+               : [ca] "=&v"(ca), [c0] "=&v"(c0), [c1] "=&v"(c1) : [vw] "v"(vw), [ntb] "v"(vNegTb) : "memory");   \
+  pr = __builtin_amdgcn_readfirstlane(vp)
+#define FPW_DEC_BIT2(LEVEL)                                                                     \
+  { const u64 split = ((((high - low) >> 8) * (u64)(u32)pr) >> 8) + low;                              \
+    const u64 split1 = split + 1;                                                              \
+    u64 onem, t; int tmp;                                                                      \
+    /* the decision (:296-309), the probability update, the next node and the test of :312 in one go; then the next step's start */ \
+    asm volatile("v_cmp_ge_u64 vcc, %[split], %[cur]\n\t"           /* bit = split >= current */ \
+                 "s_and_b64 %[one], vcc, exec\n\t"                  /* SCC = bit */          \
+                 "s_cselect_b64 %[high], %[split], %[high]\n\t"                               \
+                 "s_cselect_b64 %[low], %[low], %[split1]\n\t"                                \
+                 "s_xor_b64 %[t], %[low], %[high]\n\t"                                        \
+                 "s_and_b64 %[t], %[t], %[mask]\n\t"                                          \
+                 "v_cndmask_b32 %[tmp], 0, %[vk], vcc\n\t"          /* p -= (p - (bit ? PSCALE - 64 : 0)) >> 6  (:302 / :307) */ \
+                 "v_sub_u32 %[tmp], %[vp], %[tmp]\n\t"                                        \
+                 "v_ashrrev_i32 %[tmp], 6, %[tmp]\n\t"                                        \
+                 "v_sub_u32 %[tmp], %[vp], %[tmp]\n\t"                                        \
+                 "ds_write_b32 %[vw], %[tmp]\n\t"                                             \
+                 "v_cndmask_b32 %[tmp], 0, %[four], vcc\n\t"                                  \
+                 "v_add_u32 %[vw], %[ca], %[tmp]\n\t"               /* the next node: probs[tb + 2 ctx + bit] */ \
+                 "s_waitcnt lgkmcnt(1)\n\t"                         /* the two reads (LDS returns in order; the write may still be out) */ \
+                 "v_cndmask_b32 %[vp], %[c0], %[c1], vcc"                                      \
+                 : [one] "=&s"(onem), [high] "+s"(high), [low] "+s"(low), [t] "=&s"(t), [tmp] "=&v"(tmp), [vw] "+v"(vw), [vp] "+v"(vp) \
+                 : [cur] "v"(current), [split] "s"(split), [split1] "s"(split1), [mask] "s"(m2456), [vk] "v"(vK), [four] "v"(vFour), [ca] "v"(ca), [c0] "v"(c0), [c1] "v"(c1) \
+                 : "vcc", "scc", "memory");                                                    \
+    if (LEVEL == 1) { const int tbn = ((vw + vNegTb) >> 2) & 3; vRootAddr = (tbn << 10) + vBase4; rootNext = fpw_lds_int(vRootAddr); } \
+    if (LEVEL < 7) FPW_DEC_OPEN();                                                             \
+    if (__builtin_expect(t == 0, 0)) {                              /* never twice in a row: bits 24..31 then differ (00 vs FF) */ \
+      low = (low << 32) & FP_M056;                                                             \
+      high = ((high << 32) | FP_M032) & FP_M056;                                               \
+      if (idx + 4 > bufLimit) { current = (current << 32) & FP_M056; idx = bufLimit + 1; }     \
+      else {                                                                                   \
+        if (idx >= wbase + 256) { wbase = idx; const u8* q = buf + wbase + 4 * lane; win = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3]; } \
+        const u64 val = (u64)(u32)__builtin_amdgcn_readlane((int)win, (idx - wbase) >> 2);     \
+        current = ((current << 32) | val) & FP_M056;                                           \
+        idx += 4;                                                                              \
+      }                                                                                        \
+      FPW_V64(current);                                                                        \
+    } }
+
+__global__ __launch_bounds__(512) void k_fpaq_dec_wave2(const u8* __restrict__ in, int64_t inStride, const int64_t* __restrict__ d_bitOff,
+                                                  const int64_t* __restrict__ d_bitEnd, const int32_t* __restrict__ d_len,
+                                                  u8* __restrict__ dst, int64_t stride, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag,
+                                                  const int32_t* __restrict__ order, int wavesPerGroup, long long* __restrict__ endOut) {
+  __shared__ __attribute__((aligned(8))) int probsAll[8][1024];
+  const int wv = (int)(threadIdx.x >> 6);
+  const int b = __builtin_amdgcn_readfirstlane(order[blockIdx.x * wavesPerGroup + __builtin_amdgcn_readfirstlane(wv)]);   // uniform on purpose: the coder state stays on the scalar unit
+  if (b < 0) return;
+  int* probs = probsAll[wv];
+  const int count = d_len[b];
+  const int lane = kz_lane();
+  if (lane == 0) { d_len2[b] = count; d_flag[b] = 1; }
+  if (count <= 0) { if (endOut && lane == 0) endOut[b] = d_bitOff[b]; return; }
+  for (int i = lane; i < 1024; i += 64) probs[i] = FP_PSCALE >> 1;
+  FPW_SYNC();
+  const u8* p = in + (int64_t)b * inStride + (d_bitOff[b] >> 3);   // payload is byte aligned behind the block header
+  const int64_t avail = (d_bitEnd[b] - d_bitOff[b]) >> 3;
+  u8* o = dst + (int64_t)b * stride;
+  int64_t ipos = 0;
+  u64 low = 0, high = FP_TOP, current = 0;
+  bool bad = ((d_bitOff[b] & 7) != 0);
+  int startChunk = 0;
+  while (startChunk < count && !bad) {
+    // varint (EntropyUtils.readVarInt)
+    u32 v = p[ipos++]; u32 sz = v & 0x7F; int shift = 7;
+    while (v >= 128) { v = p[ipos++]; sz |= (v & 0x7F) << shift; if (shift == 28) break; shift += 7; }
+    const int szBytes = (int)sz;
+    if (szBytes < 0 || szBytes >= 2 * count || ipos + 7 + szBytes > avail) { bad = true; break; }   // :176-177
+    current = 0;
+    for (int k = 0; k < 7; k++) current = (current << 8) | (u64)p[ipos + k];
+    ipos += 7;
+    const u8* buf = p + ipos;
+    const int bufLimit = szBytes;
+    int idx = 0;
+    // 256-byte read window (one big-endian word per lane) over the chunk's byte stream
+    int wbase = 0;
+    u32 win;
+    { const u8* q = buf + 4 * lane; win = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3]; }
+    const int chunkSize = min(FP_CHUNK, count - startChunk);
+    int vBase4 = (int)fpw_lds_addr(&probs[1]);                       // LDS byte address of probs[0 * 256 + 1]
+    int vK = FP_PSCALE - 64;
+    const u64 m2456 = FP_M2456;
+    int vFour = 4;
+    FPW_V(vBase4); FPW_V(vK); FPW_V(vFour); FPW_V64(current);
+    int rootNext = probs[1];
+    int vRootAddr = vBase4;                                         // where rootNext was read: probs[tb + 1]
+    u32 outv = 0;
+    for (int i = startChunk; i < startChunk + chunkSize; i++) {
+      int vp = rootNext;
+      int vw = vRootAddr;                                           // byte address of probs[tb + ctx], ctx = 1
+      const int vNegTb = 4 - vw;                                    // -tbBase (tbBase = address of probs[tb])
+      int ca, c0, c1, pr;
+      FPW_DEC_OPEN();
+      FPW_DEC_BIT2(0) FPW_DEC_BIT2(1) FPW_DEC_BIT2(2) FPW_DEC_BIT2(3) FPW_DEC_BIT2(4) FPW_DEC_BIT2(5) FPW_DEC_BIT2(6) FPW_DEC_BIT2(7)
+      const int ctx = (vw + vNegTb) >> 2;                           // 256 + the byte
+      const int j = (i - startChunk) & 63;
+      { const u32 cb = (u32)__builtin_amdgcn_readfirstlane(ctx & 0xFF); asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(cb), "s"(j) : "m0"); }
+      if (j == 63 || i + 1 == startChunk + chunkSize) { if (lane <= j) o[i - j + lane] = (u8)outv; }
+      if (idx > szBytes) { bad = true; break; }                      // :231-232
+    }
+    ipos += szBytes;
+    startChunk += chunkSize;
+  }
+  if (endOut && lane == 0) endOut[b] = (long long)(d_bitOff[b] + 8LL * ipos);
+  if (bad && lane == 0) d_flag[b] = 0;
+}
+
+
 // which arrangement: one wave per block up to 8 blocks per CU, one lane per block above (KZ_FPAQ_FORCE=lanes|waves
 // overrides, for tests)
 static bool fpaq_use_waves(const kz_ctx* ctx, int B) {
@@ -444,9 +576,15 @@ int kz_stage_fpaq_decode(kz_ctx* ctx, kz_batch& bt, const uint8_t* in, int64_t i
     view.h_cost = bt.h_len;                                         // decoded length ~ coding steps
     KzPlacement PL;
     { const int prc = kz_place_blocks(ctx, view, PL); if (prc) return prc; }
-    for (int rr = 0; rr < PL.R; rr++)
-      KZ_LAUNCH(ctx, KID_FPAQ_DEC, k_fpaq_dec_wave, dim3(PL.G[rr]), dim3(64 * PL.wpg), in, inStride, d_bitOff, d_bitEnd, bt.d_len, dst, bt.stride,
-                bt.d_len2, bt.d_flag, PL.d_order + PL.off[rr], PL.wpg, ctx->d_endBits);
+    static const bool oldStep = getenv("KZ_FPAQ_OLDSTEP") != nullptr;   // A/B: the round-2 bit step
+    for (int rr = 0; rr < PL.R; rr++) {
+      if (oldStep)
+        KZ_LAUNCH(ctx, KID_FPAQ_DEC, k_fpaq_dec_wave, dim3(PL.G[rr]), dim3(64 * PL.wpg), in, inStride, d_bitOff, d_bitEnd, bt.d_len, dst, bt.stride,
+                  bt.d_len2, bt.d_flag, PL.d_order + PL.off[rr], PL.wpg, ctx->d_endBits);
+      else
+        KZ_LAUNCH(ctx, KID_FPAQ_DEC, k_fpaq_dec_wave2, dim3(PL.G[rr]), dim3(64 * PL.wpg), in, inStride, d_bitOff, d_bitEnd, bt.d_len, dst, bt.stride,
+                  bt.d_len2, bt.d_flag, PL.d_order + PL.off[rr], PL.wpg, ctx->d_endBits);
+    }
   } else {
     KZ_LAUNCH(ctx, KID_FPAQ_DEC, k_fpaq_dec, dim3((B + 63) / 64), dim3(64), in, inStride, d_bitOff, d_bitEnd, bt.d_len, dst, bt.stride, bt.d_len2, bt.d_flag, B, ctx->d_endBits);
   }
