@@ -138,7 +138,7 @@ __global__ void k_srt_ffin(const int32_t* __restrict__ d_len, int32_t* __restric
 
 // =================================================================================================
 // inverse: one wave per block
-#define KZ_DPP_SHL1(x) ((u32)__builtin_amdgcn_update_dpp(0, (int)(x), 0x130 /*wave_shl:1*/, 0xF, 0xF, false))
+#define KZ_DPP_SHL1(x) ((u32)__builtin_amdgcn_update_dpp(0, (int)(x), 0x130 /*wave_shl:1*/, 0xF, 0xF, true))   /* lane 63 gets 0 */
 
 // per-wave working set of k_srt_inv (up to 8 waves = 8 blocks per workgroup, see kz_place_blocks)
 struct SrtInvLds {
@@ -313,25 +313,30 @@ __global__ __launch_bounds__(512) void k_srt_inv(const u8* __restrict__ src, u8*
         // two rare cases leave the hot loop for one complete step (which re-reads everything; a pending refill is then written on
         // the way back in): c2's ring is still being refilled, or -- damaged input only -- the list holds the same symbol twice, so
         // that c2's state changes in this very step
-        if (__builtin_expect((c2 == c) | (pendSym == c2), 0)) break;
+        if (__builtin_expect(min((u32)(c2 ^ c), (u32)(c2 ^ pendSym)) == 0u, 0)) break;
         const int32_t cur2 = bstart[c2], end2 = bend[c2];             // (wave-uniform LDS reads; made scalar when they are used)
         const u32 v2 = ring[c2][lane];
         const int sh = cur & 63;
         const int avail = min(end - cur, 64 - sh);                    // valid ranks in the ring
         const uint64_t nzm = kz_ballot(v != 0);
-        const uint64_t rot = (nzm >> sh) | ((nzm << 1) << (63 - sh)); // bit j: slot of rank cur + j is not zero; slots of consumed
-        const int z = rot ? (int)__builtin_ctzll(rot) : 64;           //   ranks come last in this order, so the first hit is valid
-        if (__builtin_expect(z >= avail, 0)) break;                   //   iff it lies below avail
+        const uint64_t rot = nzm >> sh;                               // bit j: slot of rank cur + j is not zero (the ranks of the ring that
+        const int z = rot ? (int)__builtin_ctzll(rot) : 64;           //   count sit in slots sh..63: avail <= 64 - sh, nothing wraps)
+        if (__builtin_expect(z >= avail, 0)) break;                   // the first hit is valid iff it lies below avail
         const int r = __builtin_amdgcn_readlane((int)v, (cur + z) & 63);
-        if (lane <= z) o[i + lane] = (u8)c;
+        // all 64 lanes store: the bytes behind the z + 1 this step owns are written again by the steps that own them (a wave's stores
+        // to one address land in program order, and at least 66 outputs remain), and the cursor goes out without an EXEC round trip:
+        // lane 0 writes bstart[c], the other lanes a slot of their own in the table only the general loop uses
+        o[(u32)i + (u32)lane] = (u8)c;
         i += z + 1;
         const int32_t ncur = cur + z + 1;
-        if (lane == 0) bstart[c] = ncur;
-        if (__builtin_expect((ncur & 63) == 0 && ncur < end, 0)) {    // ring used up, bucket goes on: fetch the next 64 ranks
-          if (pendSym >= 0) SRT_FLUSH();
-          pendCnt = min(64, end - ncur);
-          vpend = (lane < pendCnt) ? (u32)s[ncur + lane] : 0u;
-          pendSym = c;
+        *((lane == 0) ? &bstart[c] : &wbase[lane]) = ncur;
+        if (__builtin_expect((ncur & 63) == 0, 0)) {                  // ring used up (one step in 64: one test on the common path)
+          if (ncur < end) {                                           //   and the bucket goes on: fetch the next 64 ranks
+            if (pendSym >= 0) SRT_FLUSH();
+            pendCnt = min(64, end - ncur);
+            vpend = (lane < pendCnt) ? (u32)s[ncur + lane] : 0u;
+            pendSym = c;
+          }
         }
         const u32 nxt = KZ_DPP_SHL1(list);                            // positions 0..r-1 <- 1..r, position r <- c (SRT.java:233-237)
         const u32 shifted = (list >> 8) | (nxt << 24);
