@@ -276,25 +276,29 @@ __global__ __launch_bounds__(512) void k_fpaq_enc_wave(const u8* __restrict__ sr
     int val = __builtin_amdgcn_readlane((int)rowv, 0);
     int pIdx = 0 + ((kbit == 7) ? 1 : ((val + 256) >> (kbit + 1)));
     int pp = probs[pIdx];
-    for (int i = startChunk; i < chunkEnd; i++) {
-      // update and write back this byte's 8 probabilities (lanes 0..7), fetch the next byte's
-      const int bit = (val >> kbit) & 1;
-      const int np = bit ? pp - ((pp - FP_PSCALE + 64) >> 6) : pp - (pp >> 6);
-      if (lane < 8) probs[pIdx] = np;
-      const int cur = pp;
-      const int curVal = val;
-      const int j1 = (i + 1 - startChunk) & 63;
-      if (i + 1 < chunkEnd) {
-        if (j1 == 0) rowv = (i + 1 + lane < chunkEnd) ? (u32)blk[i + 1 + lane] : 0u;   // 64 bytes per load
-        val = __builtin_amdgcn_readlane((int)rowv, j1);
+    for (int row = startChunk; row < chunkEnd; row += 64) {         // rows of 64 bytes, the next row requested a row ahead
+      const int rowCnt = min(64, chunkEnd - row);
+      const u32 rowNext = (row + 64 + lane < chunkEnd) ? (u32)blk[row + 64 + lane] : 0u;
+      for (int j = 0; j < rowCnt; j++) {
+        // update and write back this byte's 8 probabilities, fetch the next byte's.  Lane l works on bit 7 - (l & 7): the eight
+        // copies of a context hold the same value and store it to the same word, which spares the EXEC round trip of "lanes 0..7".
+        // Behind the last byte of the chunk the fetch reads the contexts of a byte 0 that is never coded.
+        const int bit = (val >> kbit) & 1;
+        const int np = bit ? pp - ((pp - FP_PSCALE + 64) >> 6) : pp - (pp >> 6);
+        probs[pIdx] = np;
+        const int cur = pp;
+        const int curVal = val;
+        const int nx = __builtin_amdgcn_readlane((int)rowv, (j + 1) & 63), nf = __builtin_amdgcn_readlane((int)rowNext, 0);
+        val = (j == 63) ? nf : nx;
         pIdx = ((curVal >> 6) << 8) + ((kbit == 7) ? 1 : ((val + 256) >> (kbit + 1)));    // :161
         pp = probs[pIdx];
+        const int p7 = __builtin_amdgcn_readlane(cur, 0), p6 = __builtin_amdgcn_readlane(cur, 1), p5 = __builtin_amdgcn_readlane(cur, 2),
+                  p4 = __builtin_amdgcn_readlane(cur, 3), p3 = __builtin_amdgcn_readlane(cur, 4), p2 = __builtin_amdgcn_readlane(cur, 5),
+                  p1 = __builtin_amdgcn_readlane(cur, 6), p0 = __builtin_amdgcn_readlane(cur, 7);
+        FPW_ENC_BIT(p7, curVal, 7) FPW_ENC_BIT(p6, curVal, 6) FPW_ENC_BIT(p5, curVal, 5) FPW_ENC_BIT(p4, curVal, 4)
+        FPW_ENC_BIT(p3, curVal, 3) FPW_ENC_BIT(p2, curVal, 2) FPW_ENC_BIT(p1, curVal, 1) FPW_ENC_BIT(p0, curVal, 0)
       }
-      const int p7 = __builtin_amdgcn_readlane(cur, 0), p6 = __builtin_amdgcn_readlane(cur, 1), p5 = __builtin_amdgcn_readlane(cur, 2),
-                p4 = __builtin_amdgcn_readlane(cur, 3), p3 = __builtin_amdgcn_readlane(cur, 4), p2 = __builtin_amdgcn_readlane(cur, 5),
-                p1 = __builtin_amdgcn_readlane(cur, 6), p0 = __builtin_amdgcn_readlane(cur, 7);
-      FPW_ENC_BIT(p7, curVal, 7) FPW_ENC_BIT(p6, curVal, 6) FPW_ENC_BIT(p5, curVal, 5) FPW_ENC_BIT(p4, curVal, 4)
-      FPW_ENC_BIT(p3, curVal, 3) FPW_ENC_BIT(p2, curVal, 2) FPW_ENC_BIT(p1, curVal, 1) FPW_ENC_BIT(p0, curVal, 0)
+      rowv = rowNext;
     }
     // varint(idx) | bytes   (EntropyUtils.writeVarInt; :164-165)
     { u32 v = (u32)idx; while (v >= 128) { if (lane == 0) o[opos] = (u8)(0x80 | (v & 0x7F)); opos++; v >>= 7; } if (lane == 0) o[opos] = (u8)v; opos++; }
@@ -505,18 +509,20 @@ __global__ __launch_bounds__(512) void k_fpaq_dec_wave2(const u8* __restrict__ i
     int rootNext = probs[1];
     int vRootAddr = vBase4;                                         // where rootNext was read: probs[tb + 1]
     u32 outv = 0;
-    for (int i = startChunk; i < startChunk + chunkSize; i++) {
-      int vp = rootNext;
-      int vw = vRootAddr;                                           // byte address of probs[tb + ctx], ctx = 1
-      const int vNegTb = 4 - vw;                                    // -tbBase (tbBase = address of probs[tb])
-      int ca, c0, c1, pr;
-      FPW_DEC_OPEN();
-      FPW_DEC_BIT2(0) FPW_DEC_BIT2(1) FPW_DEC_BIT2(2) FPW_DEC_BIT2(3) FPW_DEC_BIT2(4) FPW_DEC_BIT2(5) FPW_DEC_BIT2(6) FPW_DEC_BIT2(7)
-      const int ctx = (vw + vNegTb) >> 2;                           // 256 + the byte
-      const int j = (i - startChunk) & 63;
-      { const u32 cb = (u32)__builtin_amdgcn_readfirstlane(ctx & 0xFF); asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(cb), "s"(j) : "m0"); }
-      if (j == 63 || i + 1 == startChunk + chunkSize) { if (lane <= j) o[i - j + lane] = (u8)outv; }
-      if (idx > szBytes) { bad = true; break; }                      // :231-232
+    for (int i = startChunk; i < startChunk + chunkSize && !bad; i += 64) {      // rows of 64 bytes: one store per row
+      const int rowCnt = min(64, startChunk + chunkSize - i);
+      for (int j = 0; j < rowCnt; j++) {
+        int vp = rootNext;
+        int vw = vRootAddr;                                         // byte address of probs[tb + ctx], ctx = 1
+        const int vNegTb = 4 - vw;                                  // -tbBase (tbBase = address of probs[tb])
+        int ca, c0, c1, pr;
+        FPW_DEC_OPEN();
+        FPW_DEC_BIT2(0) FPW_DEC_BIT2(1) FPW_DEC_BIT2(2) FPW_DEC_BIT2(3) FPW_DEC_BIT2(4) FPW_DEC_BIT2(5) FPW_DEC_BIT2(6) FPW_DEC_BIT2(7)
+        const u32 cb = (u32)__builtin_amdgcn_readfirstlane((vw + vNegTb) >> 2);   // 256 + the byte (v_writelane takes bits 7..0 below)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(cb), "s"(j) : "m0");
+        if (__builtin_expect(idx > szBytes, 0)) { bad = true; break; }   // :231-232
+      }
+      if (!bad && lane < rowCnt) o[i + lane] = (u8)outv;
     }
     ipos += szBytes;
     startChunk += chunkSize;

@@ -13,7 +13,7 @@ import sys
 
 # kernels the library times under one id (kz_internal.h: KZ_KERNEL_NAMES): the text-sourced first radix pass
 ALIASES = {"k_radix_hist0": "k_radix_hist", "k_radix_scatter0": "k_radix_scatter",
-           "k_fpaq_enc_wave": "k_fpaq_enc", "k_fpaq_dec_wave": "k_fpaq_dec"}   # the one-wave-per-block forms share their ids
+           "k_fpaq_enc_wave": "k_fpaq_enc", "k_fpaq_dec_wave": "k_fpaq_dec", "k_fpaq_dec_wave2": "k_fpaq_dec"}   # the one-wave-per-block forms share their ids
 
 
 def agg(path, counter):
