@@ -223,10 +223,22 @@ __device__ __forceinline__ void fp_copy(u8* __restrict__ d, const u8* __restrict
 
 // One range-coder step (FPAQEncoder.java:182-199 encodeBit + :208-213 flush), all operands wave-uniform.
 // Written branch-free (selects) except for the rare flush: a taken scalar branch costs a lone wave ~40 cycles.
+// ((range >> 8) * p) >> 8 for range < 2^56, p < 2^16 in nine scalar instructions: with range >> 8 = a * 2^32 + b the product is
+// ((a * p + hi32(b * p)) << 32) | lo32(b * p) (a * p < 2^32: a < 2^16).  The empty asm keeps the compiler from re-deriving a as
+// range.hi >> 8 with a shift of its own.
+__device__ __forceinline__ u64 fpw_scale(u64 range, u32 p) {
+  u64 r8 = range >> 8;
+  asm("" : "+s"(r8));
+  const u32 a = (u32)(r8 >> 32), b = (u32)r8;
+  const u64 bp = (u64)b * p;
+  typedef u32 fpw_u32x2 __attribute__((ext_vector_type(2)));
+  const fpw_u32x2 w = {(u32)bp, (u32)(bp >> 32) + a * p};
+  return __builtin_bit_cast(u64, w) >> 8;
+}
 // Round 3: the selects and the test of :190 as five scalar instructions (the compiler's form took ten: 32-bit halves, a separate
 // compare per use, the mask in two literals); KBIT = position of the coded bit in VAL.  t == 0: flush (:208-213).
 #define FPW_ENC_BIT(PP, VAL, KBIT)                                                              \
-  { const u64 nh = low + ((((high - low) >> 8) * (u64)(u32)(PP)) >> 8), nl = nh + 1;                        \
+  { const u64 nh = low + fpw_scale(high - low, (u32)(PP)), nl = nh + 1;                        \
     u64 t;                                                                                     \
     asm volatile("s_bitcmp1_b32 %[val], " #KBIT "\n\t"                                         \
                  "s_cselect_b64 %[high], %[nh], %[high]\n\t"                                  \
@@ -425,7 +437,7 @@ __device__ __forceinline__ int fpw_lds_int(int addr) { return *(const fpw_lds_in
                : [ca] "=&v"(ca), [c0] "=&v"(c0), [c1] "=&v"(c1) : [vw] "v"(vw), [ntb] "v"(vNegTb) : "memory");   \
   pr = __builtin_amdgcn_readfirstlane(vp)
 #define FPW_DEC_BIT2(LEVEL)                                                                     \
-  { const u64 split = ((((high - low) >> 8) * (u64)(u32)pr) >> 8) + low;                              \
+  { const u64 split = fpw_scale(high - low, (u32)pr) + low;                                              \
     const u64 split1 = split + 1;                                                              \
     u64 onem, t; int tmp;                                                                      \
     /* the decision (:296-309), the probability update, the next node and the test of :312 in one go; then the next step's start */ \
