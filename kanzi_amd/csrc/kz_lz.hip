@@ -25,6 +25,13 @@ typedef uint8_t u8;
 // visible to the loads the other lanes of the same wave issue next).  At that scope the back end emits no instruction -- the ISA of
 // this file with and without the fence differs in one commuted compare -- so it costs nothing; it is what the memory model asks for.
 #define LZ_ORDER() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+// per-section cycle counters of block 0 (build with -DKZ_LZ_PROF; tools/README): where a step's time goes
+#ifdef KZ_LZ_PROF
+#include <stdio.h>
+#define LZP(k) { const long long t_ = (long long)__builtin_readcyclecounter(); lzp[k] += t_ - lzt; lzn[k]++; lzt = t_; }
+#else
+#define LZP(k)
+#endif
 #define LZ_SEED 0x1E35A7BDULL
 #define LZ_MAXD1 ((1 << 16) - 2)
 #define LZ_MAXD2 ((1 << 24) - 2)
@@ -69,20 +76,25 @@ __device__ __forceinline__ int lz_emit_length(u8* block, int idx, int length, bo
 }
 __device__ __forceinline__ void lz_copy(u8* d, const u8* s, int n) { for (int i = kz_lane(); i < n; i += 64) d[i] = s[i]; }
 
-__global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8* __restrict__ dstAll, int64_t stride,
+__global__ __launch_bounds__(128) void k_lz_fwd(const u8* __restrict__ srcAll, u8* __restrict__ dstAll, int64_t stride,
                                                 const int32_t* __restrict__ d_len, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag,
                                                 int32_t* __restrict__ hashAll, u8* __restrict__ tmpAll, int64_t tmpStride, int extra,
                                                 const int32_t* __restrict__ d_dtype) {
+  // Two waves per block: wave 0 parses, wave 1 only warms the caches ahead of it (the assist below).
+  __shared__ volatile int progress[2];                            // [0] the parser's position, [1] parser done
   const int b = blockIdx.x;
   const int count = d_len[b];
   const int lane = kz_lane();
-  const bool w = lane == 0;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool w = lane == 0 && wv == 0;
   const u8* src = srcAll + (int64_t)b * stride;
   u8* dst = dstAll + (int64_t)b * stride;
   if (count < LZ_MIN_BLOCK) { if (w) { d_len2[b] = count; d_flag[b] = 0; } return; }      // :313-315 (count==0 handled by caller)
   const int hsize = extra ? (1 << 19) : (1 << 16);
   int32_t* hashes = hashAll + (int64_t)b * hsize;
-  for (int i = lane; i < hsize; i += 64) hashes[i] = 0;
+  for (int i = (int)threadIdx.x; i < hsize; i += 128) hashes[i] = 0;
+  if (threadIdx.x == 0) { progress[0] = 0; progress[1] = 0; }
+  __syncthreads();
   u8* tkBuf = tmpAll + (int64_t)b * tmpStride;
   u8* mBuf = tkBuf + tmpStride / 3;
   u8* mLenBuf = mBuf + tmpStride / 3;
@@ -103,22 +115,37 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
   int repIdx = 0, srcInc = 0;
   bool ok = true;
   // Assist prefetch: the parse itself is one dependent chain (hash entry -> candidate bytes -> decision) with two
-  // cache misses per literal position.  The 64 lanes, which otherwise all execute the same scalar step, touch the
-  // hash-table lines and the candidate lines of the next 64..128 positions ahead of time.  Touching lines never
-  // changes what the parse reads (values are always loaded at their proper time), it only turns HBM misses into
-  // cache hits.
-  int pfPos = 0;
-  u32 pfSink = 0;
-  while (srcIdx < srcEnd) {
-    if (srcIdx + 64 > pfPos) {
-      const int q = max(pfPos, srcIdx) + lane;
-      if (q < srcEnd) {
-        const int rq = hashes[lz_hash(src + q, extra)];
-        pfSink ^= (u32)rq;
-        if (rq > 0 && rq < q) pfSink ^= (u32)src[rq];
-      }
-      pfPos = max(pfPos, srcIdx) + 64;
+  // cache misses per literal position.  Wave 1, which has nothing else to do, touches the hash-table lines and the candidate lines
+  // of the positions 64..192 ahead of the parser, whose position it reads from LDS.  Touching lines never changes what the parse reads
+  // (values are always loaded at their proper time), it only turns HBM misses into cache hits; what the helper sees of the table may
+  // be stale, which costs a hit, never a result.  (Until round 3 the parsing wave did this itself every 64 positions and waited for
+  // the three dependent misses each time: 15 % of a text block's parse, measured with KZ_LZ_PROF.)
+  if (wv != 0) {
+    int pfPos = 0;
+    u32 pfSink = 0;
+    for (;;) {
+      if (__builtin_amdgcn_readfirstlane(progress[1])) break;
+      const int pos = __builtin_amdgcn_readfirstlane(progress[0]);
+      if (pos + 128 > pfPos) {
+        const int q = max(pfPos, pos + 32) + lane;
+        if (q < srcEnd) {
+          const int rq = hashes[lz_hash(src + q, extra)];
+          pfSink ^= (u32)rq;
+          if (rq > 0 && rq < q) pfSink ^= (u32)src[rq];
+        }
+        pfPos = max(pfPos, pos + 32) + 64;
+      } else __builtin_amdgcn_s_sleep(16);
     }
+    asm volatile("" :: "v"(pfSink));                               // keep the prefetch loads alive
+    return;
+  }
+  int pubPos = 0;                                                  // position last published to the helper
+#ifdef KZ_LZ_PROF
+  long long lzp[12] = {0}, lzn[12] = {0}; long long lzt = (long long)__builtin_readcyclecounter();
+#endif
+  while (srcIdx < srcEnd) {
+    if (__builtin_expect(srcIdx >= pubPos + 32, 0)) { pubPos = srcIdx; if (w) progress[0] = srcIdx; }
+    LZP(0)
     // Literal runs, 64 positions per round trip.  After two literal steps in a row (srcInc >= 2, repIdx == 0) the next
     // positions are known in advance as long as they are literal steps too: p(k+1) = p(k) + 1 + ((srcInc + k) >> 6).
     // Lane k tests position p(k) the way the step below does -- repeat candidates, hash-table candidate -- and the
@@ -167,8 +194,10 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
         LZ_ORDER();
         srcIdx = (f < 64) ? __builtin_amdgcn_readlane(pk, f & 63) : (__builtin_amdgcn_readlane(pk, 63) + (int)__builtin_amdgcn_readlane((int)stp, 63));
         srcInc += f;
+        LZP(1)
         continue;
       }
+      LZP(2)
     }
     int bestLen = 0;
     // every load whose address is known up front is issued before the dependent hash-table access: the two repeat
@@ -189,6 +218,7 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
     const int r2e = extra ? hashes[h2e] : 0;
     LZ_ORDER();
     if (w) hashes[h0] = srcIdx;
+    LZP(3)
     int ref = refA;
     if ((ref > minRef) && (wA == own1)) {
       bestLen = lz_find_match(src, srcIdx1, ref, min(srcEnd - srcIdx1, LZ_MAX_MATCH));
@@ -196,6 +226,7 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
       ref = refB;
       if ((ref > minRef) && (wB == own1)) bestLen = lz_find_match(src, srcIdx1, ref, min(srcEnd - srcIdx1, LZ_MAX_MATCH));
     }
+    LZP(4)
     if (bestLen < minMatch) {
       ref = ref0;
       // the reference first compares 4 bytes at the candidate, then measures the match (:377-381); here the measuring
@@ -204,6 +235,7 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
       // (LZ only: with LZX's 8 times larger table most candidates are unrelated and the wide loads cost more than they save)
       if (extra) { if ((ref > minRef) && (lz_le32(src + ref) == (u32)own)) bestLen = lz_find_match(src, srcIdx, ref, min(srcEnd - srcIdx, LZ_MAX_MATCH)); }
       else if (ref > minRef) { const int l0 = lz_find_match(src, srcIdx, ref, min(srcEnd - srcIdx, LZ_MAX_MATCH)); if (l0 >= 4) bestLen = l0; }
+      LZP(5)
       if (bestLen < minMatch) { srcIdx = srcIdx1 + (srcInc >> 6); srcInc++; repIdx = 0; LZ_ORDER(); continue; }
       if ((ref != srcIdx - repd0) && (ref != srcIdx - repd1)) {
         const int h1 = h1e;
@@ -227,6 +259,7 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
           }
         }
       }
+      LZP(6)
       // backward extension (:527-531): up to 8 bytes per round trip instead of one
       while ((srcIdx > anchor) && (ref > minRef)) {
         int ext;
@@ -243,6 +276,7 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
         if (ext < 8) break;
       }
       if (bestLen > LZ_MAX_MATCH) { ref += (bestLen - LZ_MAX_MATCH); srcIdx += (bestLen - LZ_MAX_MATCH); bestLen = LZ_MAX_MATCH; }
+      LZP(7)
     } else {
       if ((bestLen >= LZ_MAX_MATCH) || (src[srcIdx] != src[ref - 1])) {
         srcIdx++;
@@ -252,6 +286,10 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
       } else { bestLen++; ref--; }
     }
     srcInc = 0;
+    // the bytes of the first 64 covered positions (hash fill below) are requested now and used after the match has been written out
+    const int nextPos = srcIdx + bestLen;
+    const int fillP = srcIdx + 1 + lane;
+    const u64 fillRaw = (fillP < nextPos) ? lz_le64(src + fillP) : 0ULL;
     const int dist = srcIdx - ref;
     int token, mLenTh;
     if (dist == repd0) { token = 0x00; mLenTh = 3; }
@@ -283,13 +321,22 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
       lz_copy(dst + dstIdx, src + anchor, litLen);
       dstIdx += litLen;
     }
-    anchor = srcIdx + bestLen;
+    anchor = nextPos;
+    LZP(8)
     LZ_ORDER();
-    // hash fill of the covered positions (:554-565): position-monotone, last writer = highest position
+    // hash fill of the covered positions (:554-565): position-monotone, last writer = highest position.  Short matches (the usual
+    // case) store position by position from lane 0, in order: no question of which lane wins a shared slot.
+    const int nfill = anchor - (srcIdx + 1);
+    if (nfill <= 16) {
+      const int hh0 = (int)(((fillRaw << 24) * LZ_SEED) >> (extra ? 45 : 48));
+      for (int k = 0; k < nfill; k++) { const int hk = __builtin_amdgcn_readlane(hh0, k); if (w) hashes[hk] = srcIdx + 1 + k; }
+      LZ_ORDER();
+    } else
     for (int p0 = srcIdx + 1; p0 < anchor; p0 += 64) {
       const int pp = p0 + lane;
       int hh = 0; bool act = pp < anchor;
-      if (act) hh = lz_hash(src + pp, extra);
+      if (p0 == srcIdx + 1) { if (act) hh = (int)(((fillRaw << 24) * LZ_SEED) >> (extra ? 45 : 48)); }
+      else if (act) hh = lz_hash(src + pp, extra);
       // within the wave several positions may share a slot: only the highest position may win
       for (uint64_t am = kz_ballot(act) & ~1ULL; am; am &= am - 1) {
         const int l = (int)__builtin_ctzll(am);                    // an active lane above lane 0
@@ -300,7 +347,16 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
       LZ_ORDER();
     }
     srcIdx = anchor;
+    LZP(9)
   }
+  if (w) progress[1] = 1;                                          // the helper leaves
+#ifdef KZ_LZ_PROF
+  if (b == 0 && w) {
+    long long tot = 0; for (int k = 0; k < 10; k++) tot += lzp[k];
+    for (int k = 0; k < 10; k++) printf("LZPROF sec %d cycles %lld permille %lld n %lld avg %lld\n", k, lzp[k], lzp[k] * 1000 / tot, lzn[k], lzn[k] ? lzp[k] / lzn[k] : 0LL);
+    printf("LZPROF total %lld count %d tokens %d   (0 assist, 1 / 2 literal batch taken / missed, 3 own + table, 4 repeat candidates, 5 table candidate, 6 lazy, 7 backward, 8 write-out, 9 hash fill)\n", tot, count, tkIdx);
+  }
+#endif
   int res = 0, produced = 0;
   if (ok) {
     const int litLen = count - anchor;
@@ -324,7 +380,6 @@ __global__ __launch_bounds__(64) void k_lz_fwd(const u8* __restrict__ srcAll, u8
       res = (dstIdx <= count - (count / 100)) ? 1 : 0;                                     // :596
     }
   }
-  asm volatile("" :: "v"(pfSink));                               // keep the prefetch loads alive
   if (w) { d_flag[b] = tkOver ? -1 : ((ok && res) ? 1 : 0); d_len2[b] = (!tkOver && ok && res) ? produced : count; }
 }
 
@@ -427,7 +482,7 @@ int kz_stage_lz_forward(kz_ctx* ctx, kz_batch& bt, int extra) {
   const int64_t tmpStride = (int64_t)kz_align((size_t)maxN * 3 + 3072, 256) / 3 * 3;
   u8* tmp = (u8*)kz_arena_alloc(ctx, (size_t)tmpStride * B + 256);
   if (!hashes || !tmp) { snprintf(ctx->err, sizeof(ctx->err), "lz_forward: arena overflow"); return -KZ_ERR_DEVICE; }
-  KZ_LAUNCH(ctx, KID_LZ_FWD, k_lz_fwd, dim3(B), dim3(64), bt.buf[bt.cur], bt.buf[bt.cur ^ 1], bt.stride, bt.d_len, bt.d_len2, bt.d_flag,
+  KZ_LAUNCH(ctx, KID_LZ_FWD, k_lz_fwd, dim3(B), dim3(128), bt.buf[bt.cur], bt.buf[bt.cur ^ 1], bt.stride, bt.d_len, bt.d_len2, bt.d_flag,
             hashes, tmp, tmpStride, extra, bt.d_dtype);
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
