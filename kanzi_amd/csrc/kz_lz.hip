@@ -123,7 +123,7 @@ __global__ __launch_bounds__(128) void k_lz_fwd(const u8* __restrict__ srcAll, u
   if (wv != 0) {
     int pfPos = 0;
     u32 pfSink = 0;
-    for (;;) {
+    for (int polls = 0; polls < (1 << 28); polls++) {              // (bounded: a helper never outlives its kernel by design)
       if (__builtin_amdgcn_readfirstlane(progress[1])) break;
       const int pos = __builtin_amdgcn_readfirstlane(progress[0]);
       if (pos + 128 > pfPos) {
