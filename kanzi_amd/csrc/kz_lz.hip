@@ -383,6 +383,12 @@ __global__ __launch_bounds__(128) void k_lz_fwd(const u8* __restrict__ srcAll, u
   if (w) { d_flag[b] = tkOver ? -1 : ((ok && res) ? 1 : 0); d_len2[b] = (!tkOver && ok && res) ? produced : count; }
 }
 
+// a 64-byte register window over a byte stream that is read front to back (tokens, distance bytes): one load per 64 bytes instead
+// of a memory round trip per byte on the decoder's dependent chain; positions at or past `count` read as 0 (callers bound first)
+__device__ __forceinline__ int lz_win_get(const u8* a, int count, u32& v, int& base, int idx) {
+  if ((u32)(idx - base) >= 64u) { base = idx; const int p = idx + kz_lane(); v = (p < count) ? (u32)a[p] : 0u; }
+  return __builtin_amdgcn_readlane((int)v, idx - base);
+}
 // readLength; reads are bounded by the block length (past it the Java code throws or sees stale bytes: failure)
 __device__ __forceinline__ int lz_read_length(const u8* a, int& idx, int count, bool& bad) {
   if (idx + 4 > count) {
@@ -421,9 +427,10 @@ __global__ __launch_bounds__(64) void k_lz_inv(const u8* __restrict__ srcAll, u8
       const int minMatch = ((src[12] >> 1) & 7) + 2;
       int srcIdx = 13, repd0 = count, repd1 = count;
       bool bad = false;
+      u32 tkWin = 0, mWin = 0; int tkBase = -64, mBase = -64;          // register windows over the token and distance streams
       for (;;) {
         if (tkIdx >= count) { ok = false; break; }
-        const int token = src[tkIdx++];
+        const int token = lz_win_get(src, count, tkWin, tkBase, tkIdx); tkIdx++;
         if (token >= 32) {
           const int litLen = (token >= 0xE0) ? 7 + lz_read_length(src, srcIdx, count, bad) : token >> 5;
           if (bad) { ok = false; break; }
@@ -442,18 +449,18 @@ __global__ __launch_bounds__(64) void k_lz_inv(const u8* __restrict__ srcAll, u8
           mLen = token & 7;
           mLen += (mLen == 7) ? minMatch + lz_read_length(src, mLenIdx, count, bad) : minMatch;
           if (mIdx + ((f == 0x18) ? 3 : (f == 0x10) ? 2 : 1) > count) { ok = false; break; }
-          dist = src[mIdx++];
-          if (f == 0x18) { dist = (dist << 8) | src[mIdx]; dist = (dist << 8) | src[mIdx + 1]; mIdx += 2; }
-          else if (f == 0x10) { dist = (dist << 8) | src[mIdx]; mIdx++; }
+          dist = lz_win_get(src, count, mWin, mBase, mIdx); mIdx++;
+          if (f == 0x18) { dist = (dist << 8) | lz_win_get(src, count, mWin, mBase, mIdx); dist = (dist << 8) | lz_win_get(src, count, mWin, mBase, mIdx + 1); mIdx += 2; }
+          else if (f == 0x10) { dist = (dist << 8) | lz_win_get(src, count, mWin, mBase, mIdx); mIdx++; }
         }
         if (bad) { ok = false; break; }
         repd1 = repd0; repd0 = dist;
         const int mEnd = dstIdx + mLen;
         const int ref = dstIdx - dist;
         if ((ref < 0) || (dist > maxDist) || (mEnd > dstEnd) || dist <= 0) { ok = false; break; }
-        // make the preceding stores of this wave visible to the copy below
+        // the preceding stores of this wave are visible to the copy below in program order (one wave per block: the wavefront-scope
+        // fence of LZ_ORDER says it; a workgroup-scope fence here drained every outstanding store once per token)
         LZ_ORDER();
-        __threadfence_block();
         if (dist >= 64) {
           for (int k = 0; k < mLen; k += 64) { const int i = k + lane; u8 v = 0; if (i < mLen) v = dst[ref + i]; LZ_ORDER(); if (i < mLen) dst[dstIdx + i] = v; LZ_ORDER(); }
         } else {
