@@ -609,17 +609,35 @@ int utf_forward(int* dataType, const u8* src, int n, u8* dst, int dstCap, int* p
   struct Clean { KeyMap& m; ~Clean() { m.clear(); } } clean_{seenMap};
   std::vector<Sym> syms;
   bool ok = true;
-  for (int i = start; i < body;) {
-    u32 key;
-    const int s = utf8_key(src + i, &key);
-    ok = s != 0;
-    if (s == 3) ok = ok && src[i + 2] >= 0x80 && src[i + 2] <= 0xBF;                                  // :140-145
-    if (s == 4) ok = ok && ((((u32)src[i + 2] << 8) | src[i + 3]) & 0xC0C0) == 0x8080;
-    uint32_t& cnt = seenMap.at(key);
-    if (cnt == 0) { syms.push_back(Sym{(int32_t)key, 0}); ok = ok && syms.size() < 32768; }
-    if (!ok) break;
-    cnt++;
-    i += s;
+  {
+    // pass 1: occurrences per code point.  One-, two- and three-byte sequences index the direct table straight from their bytes
+    // (index = size tag << 16 | the key's low 16 bits); the generic path is kept for four-byte sequences and for the error cases.
+    uint32_t* const D = seenMap.direct.data();
+    auto touch = [&](uint32_t idx, uint32_t key) {
+      uint32_t& c = D[idx];
+      if (__builtin_expect(c == 0, 0)) { seenMap.used.push_back(idx); syms.push_back(Sym{(int32_t)key, 0}); if (syms.size() >= 32768) ok = false; }
+      c++;
+    };
+    int i = start;
+    while (i < body && ok) {
+      const u32 b0 = src[i];
+      if (b0 < 0x80) { touch(b0, b0); i++; }
+      else if (b0 >= 0xC0 && b0 < 0xE0) { const u32 lo = (b0 << 8) | src[i + 1]; touch((1u << 16) | lo, (1u << 19) | lo); i += 2; }
+      else if (b0 >= 0xE0 && b0 < 0xF0) {
+        const u32 b1 = src[i + 1], b2 = src[i + 2];
+        if (b2 < 0x80 || b2 > 0xBF) { ok = false; break; }                                            // :140-145
+        const u32 lo = ((b0 & 0x0F) << 12) | ((b1 & 0x3F) << 6) | (b2 & 0x3F);
+        touch((2u << 16) | lo, (2u << 19) | lo); i += 3;
+      } else {
+        u32 key;
+        const int s4 = utf8_key(src + i, &key);
+        if (s4 != 4 || ((((u32)src[i + 2] << 8) | src[i + 3]) & 0xC0C0) != 0x8080) { ok = false; break; }
+        uint32_t& cnt = seenMap.at(key);
+        if (cnt == 0) { syms.push_back(Sym{(int32_t)key, 0}); if (syms.size() >= 32768) { ok = false; break; } }
+        cnt++;
+        i += 4;
+      }
+    }
   }
   const int nsym = (int)syms.size();
   const int maxTarget = n - n / 10;
@@ -640,13 +658,19 @@ int utf_forward(int* dataType, const u8* src, int n, u8* dst, int dstCap, int* p
   if (estimate >= maxTarget) return 0;
   for (int i = 0; i < start; i++) dst[at++] = src[i];
   int i = start;
-  while (i < body) {
-    u32 key;
-    i += utf8_key(src + i, &key);
-    const u32 alias = seenMap.at(key);
-    dst[at++] = (u8)alias;
-    dst[at] = (u8)(alias >> 8);
-    at += alias >> 16;
+  {
+    const uint32_t* const D = seenMap.direct.data();
+    while (i < body) {                                              // pass 2: the alias of every code point (one or two bytes)
+      const u32 b0 = src[i];
+      u32 alias;
+      if (b0 < 0x80) { alias = D[b0]; i++; }
+      else if (b0 < 0xE0) { alias = D[(1u << 16) | (b0 << 8) | src[i + 1]]; i += 2; }
+      else if (b0 < 0xF0) { alias = D[(2u << 16) | ((b0 & 0x0F) << 12) | ((src[i + 1] & 0x3Fu) << 6) | (src[i + 2] & 0x3Fu)]; i += 3; }
+      else { u32 key; i += utf8_key(src + i, &key); alias = seenMap.at(key); }
+      dst[at++] = (u8)alias;
+      dst[at] = (u8)(alias >> 8);
+      at += alias >> 16;
+    }
   }
   dst[0] = (u8)start;
   dst[1] = (u8)(i - body);                         // how far the last code point reached into the four tail bytes
