@@ -468,6 +468,7 @@ typedef struct {
   uint64_t transformType; int entropyType; int blockSize; int chkKind; int nblocks;
   uint8_t** ins; int64_t* bits; uint8_t* dst; int64_t dstCap; int* lens;
   int* next; pthread_mutex_t* mu; int fail;
+  uint8_t** spill;                                                 /* blocks decoded aside (see dec_worker) */
 } dec_job;
 
 static void* dec_worker(void* arg) {
@@ -479,9 +480,17 @@ static void* dec_worker(void* arg) {
     if (b >= j->nblocks) break;
     int64_t off = (int64_t)b * j->blockSize;
     int64_t cap = j->dstCap - off; if (cap > j->blockSize) cap = j->blockSize;
-    if (cap <= 0 && j->bits[b] > 0) {                              /* no room left: only matters if every block before decodes */
-      int hc = decode_block_impl(j->transformType, j->entropyType, j->chkKind, j->blockSize, j->ins[b], j->bits[b], NULL, 0, 1);
-      j->lens[b] = hc < 0 ? hc : -12; j->fail = 1; continue;
+    if (cap < j->blockSize) {
+      /* the destination's tail is shorter than a block.  The reader has no such notion -- it appends what every block produced
+         (CompressedInputStream.java:783-785) -- so a block that comes out longer than its slot here (damaged streams: the blocks in
+         front of it came out short) is decoded aside and placed when the lengths are known; only the TOTAL can be too long */
+      uint8_t* tmpb = (uint8_t*)malloc((size_t)j->blockSize + 64);
+      int r = kzo_decode_block_x(j->transformType, j->entropyType, j->chkKind, j->blockSize, j->ins[b], j->bits[b], tmpb, j->blockSize);
+      j->lens[b] = r;
+      if (r < 0) { j->fail = 1; free(tmpb); }
+      else if (r <= cap) { if (r > 0) memcpy(j->dst + off, tmpb, (size_t)r); free(tmpb); }
+      else j->spill[b] = tmpb;
+      continue;
     }
     int r = kzo_decode_block_x(j->transformType, j->entropyType, j->chkKind, j->blockSize, j->ins[b], j->bits[b], j->dst + off, (int)cap);
     j->lens[b] = r;
@@ -562,7 +571,8 @@ int64_t kzo_decompress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstC
     int* lens = (int*)calloc((size_t)nblocks + 1, sizeof(int));
     pthread_mutex_t mu; pthread_mutex_init(&mu, NULL);
     int next = 0;
-    dec_job job = { transformType, entropyType, blockSize, chkKind, nblocks, ins, bits, dst, dstCap, lens, &next, &mu, 0 };
+    uint8_t** spill = (uint8_t**)calloc((size_t)nblocks + 1, sizeof(uint8_t*));
+    dec_job job = { transformType, entropyType, blockSize, chkKind, nblocks, ins, bits, dst, dstCap, lens, &next, &mu, 0, spill };
     if (jobs < 1) jobs = 1;
     if (jobs > 256) jobs = 256;
     pthread_t th[256];
@@ -573,7 +583,9 @@ int64_t kzo_decompress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstC
          a block that came out short (possible only for corrupted streams without checksums) is closed up */
       ret = 0;
       for (int b = 0; b < nblocks; b++) {
-        if (ret != (int64_t)b * blockSize && lens[b] > 0) memmove(dst + ret, dst + (int64_t)b * blockSize, (size_t)lens[b]);
+        if (ret + lens[b] > dstCap) { ret = -12; break; }            /* destination too small (ERR_WRITE_FILE) */
+        if (spill[b]) memcpy(dst + ret, spill[b], (size_t)lens[b]);
+        else if (ret != (int64_t)b * blockSize && lens[b] > 0) memmove(dst + ret, dst + (int64_t)b * blockSize, (size_t)lens[b]);
         ret += lens[b];
       }
       if (bad && ret >= 0) ret = badCode;                          /* every whole block decoded; the fault is the truncated one after them */
@@ -581,6 +593,8 @@ int64_t kzo_decompress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t dstC
       ret = -13;
       for (int b = 0; b < nblocks; b++) if (lens[b] < 0) { ret = lens[b]; break; }
     }
+    for (int b = 0; b < nblocks; b++) free(spill[b]);
+    free(spill);
     free(lens); pthread_mutex_destroy(&mu);
   }
   for (int b = 0; b < nblocks; b++) free(ins[b]);

@@ -44,7 +44,10 @@ for seed in seeds:
             try: o = ("ok", oracle.decompress(stream, len(data)))
             except oracle.OracleError as e: o = ("err", e.code)
             ok = p == o
-            if not ok: print("DECODE MISMATCH", seed, case, chain, ent, bs, chk, skip, n, p[0], p[1] if p[0] == "err" else len(p[1]), o[0], o[1] if o[0] == "err" else len(o[1]), flush=True)
+            if not ok:
+                print("DECODE MISMATCH", seed, case, chain, ent, bs, chk, skip, n, p[0], p[1] if p[0] == "err" else len(p[1]), o[0], o[1] if o[0] == "err" else len(o[1]), flush=True)
+                os.makedirs(os.path.join(ROOT, "gpurun_out", "fuzz_fail"), exist_ok=True)      # the stream the decoders disagree on, for a replay
+                open(os.path.join(ROOT, "gpurun_out", "fuzz_fail", "stream_%d_%d.knz" % (seed, case)), "wb").write(stream)
         if not ok:
             bad += 1
             print("FAIL seed", seed, "case", case, chain, ent, "bs", bs, "chk", chk, "skip", skip, "n", n, "pick", pick, flush=True)
