@@ -426,9 +426,23 @@ int text_inverse(int ctxBlockSize, const u8* src, int n, u8* dst, int dstCap, in
   int last = is_text(src[i]) ? i - 1 : i;
   bool afterWord = false, ok = true;
   const int end = dstCap;
+#if KZ_TEXT_AVX2
+  const bool avx2 = have_avx2();
+#endif
   while (i < n && at < end) {
     u8 c = src[i];
-    if (is_text(c)) { dst[at++] = c; i++; continue; }
+    if (is_text(c)) {
+#if KZ_TEXT_AVX2
+      if (avx2 && i + 32 <= n && at + 32 <= end) {                  // a run of letters is copied in one piece (they are plain bytes: :880-882)
+        const u32 m = letters32(src + i);
+        const int run = (m == 0xFFFFFFFFu) ? 32 : __builtin_ctz(~m);
+        memcpy(dst + at, src + i, 32);                             // (the bytes behind the run are overwritten by what follows)
+        at += run; i += run;
+        continue;
+      }
+#endif
+      dst[at++] = c; i++; continue;
+    }
     if (i > last + 3 && sd.delim[c]) {             // the decoder learns only words of at least three letters (:891)
       const int len = i - last - 1;
       if (len <= kMaxWord) {
