@@ -1549,10 +1549,15 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     std::vector<std::unique_ptr<HostInv>> jobs;
     std::vector<std::vector<int32_t>> lens(nch), skips(nch), stats(nch);
     int rc = 0;
+    const bool trace = getenv("KZ_TRACE_PIPE") != nullptr;
+    const auto tz = std::chrono::steady_clock::now();
+    auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tz).count(); };
     for (int k = 0; k < nch && !rc; k++) {
       const int b0 = k * CH, cnt = std::min(CH, B - b0);
+      const double tg = ms();
       rc = decode_blocks_impl(ctx, transformType, entropyType, blockSize, in + (int64_t)b0 * inStride, inStride, bitLengths + b0, cnt,
                               out + (int64_t)b0 * outStride, outStride, results + b0, memKind, true);
+      if (trace) fprintf(stderr, "[pipe] decode chunk %d: gpu %.0f ms (at %.0f)\n", k, ms() - tg, ms());
       if (rc) break;
       lens[k].resize(cnt); skips[k].resize(cnt); stats[k].resize(cnt);
       for (int i = 0; i < cnt; i++) { lens[k][i] = results[b0 + i].length; skips[k][i] = results[b0 + i].skipFlags; stats[k][i] = results[b0 + i].status; }
@@ -1561,9 +1566,14 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
       H->device = ctx->device; H->types = types; H->hp = hp; H->blockSize = blockSize; H->cap = dataCap;
       H->dbuf = out + (int64_t)b0 * outStride; H->dstride = outStride; H->slotCap = outStride; H->hostMem = memKind == KZ_MEM_HOST;
       H->len = lens[k].data(); H->skip = skips[k].data(); H->status = stats[k].data();
-      finishers.emplace_back([H, cnt]() { kz_parallel_for(cnt, KZ_HOST_STAGE_THREADS, host_inverse_block, H); });
+      finishers.emplace_back([H, cnt, k, trace, &ms]() {
+        const double t0 = ms();
+        kz_parallel_for(cnt, KZ_HOST_STAGE_THREADS, host_inverse_block, H);
+        if (trace) fprintf(stderr, "[pipe] decode chunk %d: host inverse stages %.0f .. %.0f ms\n", k, t0, ms());
+      });
     }
     for (auto& t : finishers) t.join();
+    if (trace) fprintf(stderr, "[pipe] decode done at %.0f ms\n", ms());
     if (rc) { decode_error_sync(ctx); return rc; }
     for (int k = 0; k < nch; k++) {
       if (jobs[k]->fail) { snprintf(ctx->err, sizeof(ctx->err), "host stage: copy from / to the device failed"); return -KZ_ERR_DEVICE; }
