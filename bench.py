@@ -51,7 +51,7 @@ KERNEL_STAGE = {}
 for _st, _ks in {
     "bwt_fwd": ("k_bwt_init", "k_radix_hist", "k_radix_scan", "k_radix_scatter", "k_seg_reduce", "k_seg_scan", "k_seg_apply",
                 "k_live_count", "k_live_scan", "k_live_emit", "k_bwt_emit", "k_msd_hist", "k_msd_scan", "k_msd_scatter", "k_bucket_sort", "k_bucket_count", "k_bucket_count_s",
-                "k_r0_hist", "k_r0_scan", "k_r0_scatter", "k_r0_sort", "k_r0_plan"),
+                "k_tr_hist16", "k_tr_assign", "k_tr_count", "k_tr_scatter", "k_tr_sort"),
     "sbrt_fwd": ("k_sbrt_last2", "k_sbrt_scan", "k_sbrt_replay"),
     "zrlt_fwd": ("k_zrlt_f1", "k_zrlt_f2", "k_zrlt_f3", "k_zrlt_ffin"),
     "ans_enc": ("k_ans_enc_chunk", "k_ans_enc_scan", "k_ans_enc_concat"),
@@ -164,6 +164,62 @@ def roofline_of(kernels, per_stage_alg, alg_enc, alg_dec, step_bytes, t_enc, t_d
     return r
 
 
+def _r(x, nd=4):
+    """floats to nd significant digits (the printed line must stay small enough for the driver's record)"""
+    if isinstance(x, float):
+        return float("%.*g" % (nd, x))
+    return x
+
+
+def compact_roofline(r):
+    if not r:
+        return None
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "stage", "avg_launch_ms", "launches_per_step",
+            "kernel_ms_per_step", "stage_ms_per_step", "alg_bytes_per_launch", "pipeline_frac", "measured_copy_GBs", "traffic_GBs")
+    return {k: _r(r[k]) for k in keep if k in r}
+
+
+def compact(out):
+    """the ONE printed JSON line: the contract's keys, roofline and cpu_baseline, and for every other BASELINE config
+    (config.chains) and every shaped batch (config.shapes) its rates and the roofline of its dominant kernel"""
+    c = out["config"]
+    cc = {k: _r(v) for k, v in c.items() if k not in ("chains", "shapes")}
+    cc["chains"] = {}
+    for key, ch in c["chains"].items():
+        cc["chains"][key] = {"chain": ch["chain"] + " & " + ch["entropy"], "data": ch["data"], "blocks": ch["blocks_per_gpu_per_step"],
+                             "enc": _r(ch["encode_MBps"]), "dec": _r(ch["decode_MBps"]), "enc_dec": _r(ch["enc_dec_MBps"]),
+                             "ms_per_step": _r(ch["ms_per_step"]), "z": _r(ch["z_post_transform_ratio"]), "c": _r(ch["c_compressed_ratio"]),
+                             "roofline": compact_roofline(ch["roofline"])}
+        if ch.get("host_stage_ms_per_step"):
+            cc["chains"][key]["host_stage_ms"] = {k: _r(v) for k, v in ch["host_stage_ms_per_step"].items()}
+    cc["shapes"] = {}
+    for key, sh in c["shapes"].items():
+        if key == "silesia_by_class":
+            cc["shapes"][key] = {n: _r(v["enc_dec_MBps"]) for n, v in sh.items()}
+            continue
+        row = {k: _r(v) for k, v in sh.items() if k in ("blocks", "bytes", "scaling", "chain")}
+        for a, b in (("encode_MBps", "enc"), ("decode_MBps", "dec"), ("compress_MBps", "enc"), ("decompress_MBps", "dec"), ("enc_dec_MBps", "enc_dec")):
+            if a in sh:
+                row[b] = _r(sh[a])
+        cc["shapes"][key] = row
+    o = {k: _r(v) for k, v in out.items() if k not in ("config", "roofline", "kernels", "cpu_baseline")}
+    o["config"] = cc
+    o["roofline"] = compact_roofline(out["roofline"])
+    if out.get("roofline"):
+        o["roofline"]["stages_ms_GBs"] = {s: [_r(v["ms_per_step"]), _r(v["achieved_GBs"])] for s, v in out["roofline"].get("stages", {}).items()}
+    cb = out.get("cpu_baseline")
+    if cb:
+        o["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind", "sample", "encode_MBps", "decode_MBps", "knz_identical_to_hip") if k in cb}
+        o["cpu_baseline"]["reference_published_enc_dec_MBps"] = REFERENCE_PUBLISHED["enc_dec_MBps"]
+        if "single_thread" in cb:
+            o["cpu_baseline"]["single_thread"] = {k: _r(v) for k, v in cb["single_thread"].items()}
+        o["cpu_baseline"]["usable_cpus"] = cb["host"]["usable_cpus"]
+    else:
+        o["cpu_baseline"] = None
+    o["detail"] = "per-kernel tables and per-stage rooflines: profiles/%s_bench_kernels.json (same run, written by --detail-json)" % out.get("_tag", "r04")
+    return o
+
+
 def load_traffic(path, B, chain, entropy):
     try:
         with open(path) as f:
@@ -220,7 +276,9 @@ def main():
     ap.add_argument("--chain-steps", type=int, default=2, help="timed steps of each config.chains row")
     ap.add_argument("--bulk-host-blocks", type=int, default=2048, help="blocks of the PCIe-inclusive bulk stream (0 = skip)")
     ap.add_argument("--data-class", type=int, default=-1, help="diagnostic: force one class of the synthetic generator (0..4) instead of the mix")
-    ap.add_argument("--profiles-tag", default="r03", help="profiles/<tag>_pmc_traffic*.json: per-kernel HBM bytes from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)")
+    ap.add_argument("--detail-json", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="the full record (per-kernel tables, per-stage rooflines of every chain) is written here; the printed line is the compact form")
+    ap.add_argument("--profiles-tag", default="r04", help="profiles/<tag>_pmc_traffic*.json: per-kernel HBM bytes from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)")
     ap.add_argument("--traffic-json", default="", help="override the PMC traffic file of the headline chain")
     ap.add_argument("--cpu-sample-blocks", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     args = ap.parse_args()
@@ -420,11 +478,11 @@ def main():
     shapes = {"bulk": {"blocks": B * world, "bytes": int(step_bytes) * world, "scaling": "weak",
                        "encode_MBps": head["encode_MBps"], "decode_MBps": head["decode_MBps"], "enc_dec_MBps": value}}
 
-    def shaped(src, total, reps=2):
+    def shaped(src, total, reps=2, chain=None, entropy=None):
         nblk = (total + bs - 1) // bs
         mine = list(range(rank, nblk, world))                         # block g -> rank g mod N
         tail = total - (nblk - 1) * bs if (mine and mine[-1] == nblk - 1) else bs
-        sb = Batch(src, len(mine), args.chain, args.entropy, tail)
+        sb = Batch(src, len(mine), chain or args.chain, entropy or args.entropy, tail)
         sb.step()
         barrier()
         S0 = time.perf_counter()
@@ -444,6 +502,14 @@ def main():
     if not args.no_shapes:
         for name, total in (("silesia", SILESIA_BYTES), ("enwik9", ENWIK9_BYTES)):
             shapes[name] = shaped(d_host, total)
+            torch.cuda.empty_cache()
+        if not args.no_chains:
+            # the metric's own workload at its own size: silesia.tar -l 5 = TEXT+UTF+BWT+RANK+ZRLT & ANS0 (BlockCompressor.java:539-573)
+            # on 51 blocks of the text-heavy mix, TEXT / UTF on host threads inside the timed region
+            d_text = torch.from_numpy(text_mix(min(16, D), bs)).to(dev)
+            shapes["silesia_level5_exact"] = shaped(d_text, SILESIA_BYTES, chain="TEXT+UTF+BWT+RANK+ZRLT", entropy="ANS0")
+            shapes["silesia_level5_exact"]["chain"] = "TEXT+UTF+BWT+RANK+ZRLT & ANS0, text-heavy mix"
+            del d_text
             torch.cuda.empty_cache()
         if args.data == "mix" and args.data_class < 0:
             # the silesia shape one synthetic class at a time: small-batch decode is the serial RANK inverse of the slowest block,
@@ -499,6 +565,7 @@ def main():
                    "chains": chains, "shapes": shapes},
         "roofline": head["roofline"],
         "kernels": head["kernels"][:nk],
+        "_tag": tag,
     }
 
     # ---- CPU baseline: the oracle (C restatement) on this box's host cores, bounded sample; rank 0, once ----
@@ -569,7 +636,15 @@ def main():
             pass
         barrier()
     if rank == 0:
-        print(json.dumps(out))
+        # the full record goes to a file (tools/profile_round.sh copies it to profiles/<tag>_bench_kernels.json); the printed line is
+        # the compact form: every BASELINE config and shape with its rates and its roofline, no per-kernel tables
+        try:
+            os.makedirs(os.path.dirname(args.detail_json), exist_ok=True)
+            with open(args.detail_json, "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError:
+            pass
+        print(json.dumps(compact(out), separators=(",", ":")))
     if dist is not None:
         dist.destroy_process_group()
 

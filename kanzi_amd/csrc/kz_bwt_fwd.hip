@@ -24,6 +24,7 @@
 #include "kz_device.h"
 #include "kz_internal.h"
 #include <stdlib.h>
+#include <algorithm>
 
 #define RS_ITEMS 16
 #define RS_TILE (KZ_WG * RS_ITEMS)   // 4096 elements per workgroup
@@ -892,6 +893,473 @@ __global__ __launch_bounds__(KZ_WG) void k_live_emit(u64* __restrict__ keyN, u32
 }
 
 // ---------------------------------------------------------------------------------------------
+// Round 0 as a TRIE round: count first, move once.
+// The seven LSD passes of the old round 0 moved every suffix seven times (24 B per pass) to learn, for three of
+// the five data classes, that half of the suffixes sit in groups of many thousand equal 7-byte prefixes which no
+// amount of sorting can split.  Here the text is only COUNTED, level by level, until every prefix class is either
+// small enough to be finished in LDS or known to be one large group:
+//   node   = a prefix of d bytes shared by more than TR_CAP suffixes (depth-1 nodes = the 256 first bytes, always
+//            expanded); its 256 children are counted by the next byte (k_tr_hist16 for depth 1: LDS histogram of byte
+//            pairs; k_tr_count for the deeper levels: LDS counters of the level's nodes, one info lookup per suffix);
+//   k_tr_assign turns the counts of a level into child ranges of the suffix array (slots) and classifies each child:
+//            EXPANDED (count > TR_CAP and depth < Dmax: a node of the next level), TERMINAL (count > TR_CAP at depth
+//            Dmax: one group, nothing to sort), or SMALL: consecutive small siblings are merged greedily into buckets
+//            of at most TR_CAP suffixes (a bucket is a contiguous slot range);
+//   k_tr_scatter moves every suffix ONCE: terminal ones just get their group's head slot as rank (a coalesced store in
+//            text order, they are never moved at all); the others go to their bucket as one 8-byte element
+//            (the 64 - bitsG key bits that follow the bucket's common prefix | suffix index), staged per tile in LDS
+//            so that a bucket's elements leave in runs;
+//   k_tr_sort sorts one bucket in LDS (LSD radix over the bits that differ inside the bucket only), finds the groups
+//            of equal keys and writes ranks and final suffixes like k_seg_apply.
+// Depth: a bucket whose common prefix has d >= 1 bytes is sorted to d + (64 - bitsG) / 8 >= 6 bytes (zero padded at the
+// end of the text like the old keys), terminal groups share Dmax >= 6 bytes.  The ranks are therefore a refinement of
+// the 6-byte order and a coarsening of the suffix order, which is all the doubling rounds (h = 6, 12, ...) need: equal
+// rank => equal 6-byte prefix; different rank => the true order.
+#define TR_CAP 7680u             // LDS sort capacity (60 KiB of elements + 16 KiB of counters: two workgroups per CU)
+#define TR_MERGE (TR_CAP / 2)    // siblings above this are a bucket of their own
+#define TR_K_SMALL 1u
+#define TR_K_EXP 2u
+#define TR_K_TERM 3u
+#define TR_META 32               // ints per block: [0] nodes, [1] buckets, [2 + L] first node of depth L, [10 + L] end, [18] error
+#define TR_NODECHUNK 128         // nodes whose counters fit the LDS of k_tr_count
+struct TrieArrays {
+  u32* cnt;        // [B][MN][256] children counts
+  u32* info;       // [B][MN][256] kind << 30 | payload (SMALL: skip << 16 | bucket; EXP: node; TERM: head slot)
+  u32* nodeStart;  // [B][MN] first slot of the node's range
+  u32* bStart;     // [B][MB]
+  u32* bCount;     // [B][MB]
+  u32* bFill;      // [B][MB] elements placed so far (k_tr_scatter)
+  int32_t* meta;   // [B][TR_META]
+  int32_t* err;    // [1] set when a table overflows (cannot happen for blocks the host admits: see tr_max_nodes / tr_max_buckets)
+  int MN, MB;
+};
+
+__device__ __forceinline__ u32 tr_byte(const u8* __restrict__ s, int i, int n) { return i < n ? (u32)s[i] : 0u; }
+
+// level 1: histogram of byte pairs (x[i], x[i+1]), x[n] = 0, one half of the 65536 bins per workgroup
+__global__ __launch_bounds__(1024) void k_tr_hist16(const u8* __restrict__ srcAll, int64_t stride, BwtArrays A, TrieArrays T) {
+  const int b = blockIdx.y;
+  const int n = A.d_n[b];
+  const u32 half = blockIdx.x;
+  __shared__ u32 hist[32768];
+  for (int i = threadIdx.x; i < 32768; i += 1024) hist[i] = 0;
+  __syncthreads();
+  const u8* s = srcAll + (int64_t)b * stride;
+  const int lane = kz_lane();
+  for (int base = 0; base < n; base += 1024 * 16) {
+    const int p = base + threadIdx.x * 16;
+    uint4 q = make_uint4(0, 0, 0, 0);
+    if (p < n) q = *(const uint4*)(s + p);                               // blocks are 256-byte aligned with >= 4 KiB of slack
+    u32 nxt = (u32)__shfl_down((int)(q.x & 0xFFu), 1, 64);
+    if (lane == 63) nxt = (p + 16 < n) ? (u32)s[p + 16] : 0u;
+    const u32 w[5] = {q.x, q.y, q.z, q.w, nxt};
+    u32 runKey = 0xFFFFFFFFu, runCnt = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int i = p + j;
+      const u32 c0 = (w[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+      const u32 c1r = (w[(j + 1) >> 2] >> (((j + 1) & 3) * 8)) & 0xFFu;
+      const u32 c1 = (i + 1 < n) ? c1r : 0u;
+      const u32 key = (c0 << 8) | c1;
+      const bool mine = i < n && (key >> 15) == half;
+      if (mine && key == runKey) runCnt++;
+      else {
+        if (runCnt) atomicAdd(&hist[runKey & 32767u], runCnt);
+        runKey = mine ? key : 0xFFFFFFFFu; runCnt = mine ? 1u : 0u;
+      }
+    }
+    if (runCnt) atomicAdd(&hist[runKey & 32767u], runCnt);
+  }
+  __syncthreads();
+  u32* out = T.cnt + (int64_t)b * T.MN * 256 + half * 32768;
+  for (int i = threadIdx.x; i < 32768; i += 1024) out[i] = hist[i];
+}
+
+// classify the children of the nodes of depth L (thread = node, its 256 children in order)
+__global__ __launch_bounds__(256) void k_tr_assign(BwtArrays A, TrieArrays T, int L, int Dmax) {
+  const int b = blockIdx.x;
+  int32_t* meta = T.meta + (int64_t)b * TR_META;
+  __shared__ u32 sNodes, sBuckets, sErr;
+  __shared__ u32 scan[32];
+  const int lo = (L == 1) ? 0 : meta[2 + L], hi = (L == 1) ? 256 : meta[10 + L];
+  if (threadIdx.x == 0) { sNodes = (L == 1) ? 256u : (u32)meta[0]; sBuckets = (L == 1) ? 0u : (u32)meta[1]; sErr = 0; }
+  __syncthreads();
+  const u32 firstNew = sNodes;
+  u32* cnt = T.cnt + (int64_t)b * T.MN * 256;
+  u32* info = T.info + (int64_t)b * T.MN * 256;
+  u32* nodeStart = T.nodeStart + (int64_t)b * T.MN;
+  u32* bStart = T.bStart + (int64_t)b * T.MB;
+  u32* bCount = T.bCount + (int64_t)b * T.MB;
+  for (int base = lo; base < hi; base += 256) {                          // uniform
+    const int node = base + threadIdx.x;
+    const bool valid = node < hi;
+    u32 start = 0;
+    if (L == 1) {                                                        // depth-1 nodes: their ranges from the byte totals
+      u32 tot = 0;
+      for (int c = 0; c < 256; c += 4) {
+        const uint4 v = *(const uint4*)(cnt + (int64_t)node * 256 + c);
+        tot += v.x + v.y + v.z + v.w;
+      }
+      u32 total;
+      start = kz_wg_excl_sum(tot, scan, &total);
+      nodeStart[node] = start;
+    } else if (valid) start = nodeStart[node];
+    if (!valid) continue;
+    u32 run = start, curCnt = 0;
+    int curB = -1;
+    for (int c4 = 0; c4 < 256; c4 += 4) {
+      const uint4 v4 = *(const uint4*)(cnt + (int64_t)node * 256 + c4);
+      const u32 cc4[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const u32 cc = cc4[j];
+        if (cc == 0) continue;
+        const u32 s0 = run;
+        run += cc;
+        u32 e;
+        if (cc > TR_CAP) {
+          if (curB >= 0) { bCount[curB] = curCnt; curB = -1; }
+          if (L + 1 < Dmax) {
+            const u32 M = atomicAdd(&sNodes, 1u);
+            if (M < (u32)T.MN) { nodeStart[M] = s0; e = (TR_K_EXP << 30) | M; }
+            else { sErr = 1; e = (TR_K_TERM << 30) | s0; }
+          } else e = (TR_K_TERM << 30) | s0;
+        } else if (cc > TR_MERGE) {
+          if (curB >= 0) { bCount[curB] = curCnt; curB = -1; }
+          const u32 id = atomicAdd(&sBuckets, 1u);
+          if (id < (u32)T.MB) { bStart[id] = s0; bCount[id] = cc; } else sErr = 1;
+          e = (TR_K_SMALL << 30) | ((u32)L << 16) | (id & 0xFFFFu);
+        } else {
+          if (curB >= 0 && curCnt + cc <= TR_CAP) curCnt += cc;
+          else {
+            if (curB >= 0) bCount[curB] = curCnt;
+            const u32 id = atomicAdd(&sBuckets, 1u);
+            if (id < (u32)T.MB) { bStart[id] = s0; curB = (int)id; } else { sErr = 1; curB = -1; }
+            curCnt = cc;
+          }
+          e = (TR_K_SMALL << 30) | ((u32)L << 16) | ((u32)curB & 0xFFFFu);
+        }
+        info[(int64_t)node * 256 + c4 + j] = e;
+      }
+    }
+    if (curB >= 0) bCount[curB] = curCnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    meta[0] = (int32_t)min(sNodes, (u32)T.MN); meta[1] = (int32_t)min(sBuckets, (u32)T.MB);
+    meta[2 + L + 1] = (int32_t)firstNew; meta[10 + L + 1] = (int32_t)min(sNodes, (u32)T.MN);
+    if (sErr) { meta[18] = 1; atomicOr(T.err, 1); }
+  }
+}
+
+// level L >= 2: every suffix that is still inside an expanded node of depth L-1 looks its child up; children that were
+// expanded (nodes of depth L) count the suffix's byte L in LDS.  state[i] = the suffix's leaf, or node | depth << 16.
+__global__ __launch_bounds__(1024) void k_tr_count(const u8* __restrict__ srcAll, int64_t stride, u32* __restrict__ stateAll, BwtArrays A, TrieArrays T, int L) {
+  const int b = blockIdx.y;
+  const int32_t* meta = T.meta + (int64_t)b * TR_META;
+  const int lo = meta[2 + L], hi = meta[10 + L];
+  if (hi <= lo) return;                                                  // no node of this depth: the states stay as they are
+  const int n = A.d_n[b];
+  __shared__ u32 lds[TR_NODECHUNK * 256];
+  const u8* s = srcAll + (int64_t)b * stride;
+  u32* state = stateAll + (int64_t)b * A.NS;
+  const u32* info = T.info + (int64_t)b * T.MN * 256;
+  u32* cnt = T.cnt + (int64_t)b * T.MN * 256;
+  const int P = gridDim.x;
+  const int per = (((n + P - 1) / P) + 1023) & ~1023;
+  const int pbeg = blockIdx.x * per, pend = min(n, pbeg + per);
+  const int lane = kz_lane();
+  for (int chunk = 0; lo + chunk * TR_NODECHUNK < hi; chunk++) {
+    for (int i = threadIdx.x; i < TR_NODECHUNK * 256; i += 1024) lds[i] = 0;
+    __syncthreads();
+    const int nlo = lo + chunk * TR_NODECHUNK;
+    for (int i0 = pbeg; i0 < pend; i0 += 1024) {
+      const int i = i0 + threadIdx.x;
+      u32 tgt = 0xFFFFFFFFu;
+      if (i < pend) {
+        u32 st = (L == 2 && chunk == 0) ? (s[i] | (1u << 16)) : state[i];
+        if ((st >> 30) == 0) {
+          const u32 dep = (st >> 16) & 7u;
+          u32 M = 0xFFFFFFFFu;
+          if (dep == (u32)L) M = st & 0xFFFFu;                           // advanced by an earlier chunk of this level
+          else {
+            const u32 e = info[(st & 0xFFFFu) * 256 + tr_byte(s, i + L - 1, n)];
+            if ((e >> 30) == TR_K_EXP) { M = e & 0xFFFFu; st = M | ((u32)L << 16); }
+            else st = e;
+            state[i] = st;
+          }
+          if (M != 0xFFFFFFFFu) {
+            const int k = (int)M - nlo;
+            if (k >= 0 && k < TR_NODECHUNK) tgt = (u32)k * 256 + tr_byte(s, i + L, n);
+          }
+        }
+      }
+      // the row's most frequent kind of target (a long run: everybody hits one counter) is added once
+      const uint64_t act = kz_ballot(tgt != 0xFFFFFFFFu);
+      if (act) {
+        const int l0 = (int)__builtin_ctzll(act);
+        const u32 t0 = (u32)__shfl((int)tgt, l0, 64);
+        const uint64_t same = kz_ballot(tgt == t0);
+        if (lane == l0) atomicAdd(&lds[t0], (u32)__popcll(same));
+        else if (tgt != 0xFFFFFFFFu && tgt != t0) atomicAdd(&lds[tgt], 1u);
+      }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < TR_NODECHUNK * 256; j += 1024) {
+      const u32 v = lds[j];
+      if (v && nlo + (j >> 8) < hi) atomicAdd(&cnt[(int64_t)(nlo + (j >> 8)) * 256 + (j & 255)], v);
+    }
+    __syncthreads();
+  }
+}
+
+// move every suffix once (see above).  Tile = 8192 suffixes in text order.  The tile's count per bucket lives in
+// 16-bit halves of LDS words (a tile holds at most 8192 suffixes), so that TR_MAXB buckets fit next to the staging buffer.
+#define TRS_TILE 8192
+#define TRS_ITEMS (TRS_TILE / 1024)
+#define TR_MAXB 12288
+__global__ __launch_bounds__(1024) void k_tr_scatter(const u8* __restrict__ srcAll, int64_t stride, const u32* __restrict__ stateAll,
+                                                      u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) {
+  const int b = blockIdx.y;
+  const int n = A.d_n[b];
+  const int tile = blockIdx.x;
+  const int tbase = tile * TRS_TILE;
+  if (tbase >= n) return;
+  __shared__ u32 tc2[TR_MAXB / 2];                                       // two 16-bit counters per word
+  __shared__ u32 gdelta[TR_MAXB];
+  __shared__ u64 stage[TRS_TILE];
+  __shared__ uint16_t stageB[TRS_TILE];
+  __shared__ u32 scan[32];
+  const int32_t* meta = T.meta + (int64_t)b * TR_META;
+  const int nB = meta[1];
+  const bool hasState = meta[10 + 2] > meta[2 + 2];                      // a level-2 count pass wrote the states
+  for (int i = threadIdx.x; i < (nB + 1) / 2; i += 1024) tc2[i] = 0;
+  __syncthreads();
+  const u8* s = srcAll + (int64_t)b * stride;
+  const u32* state = stateAll + (int64_t)b * A.NS;
+  const u32* info = T.info + (int64_t)b * T.MN * 256;
+  u32* rank = A.rank + (int64_t)b * A.NS;
+  const u64 lowMask = (1ULL << bitsG) - 1ULL;
+  u64 el[TRS_ITEMS]; u32 bp[TRS_ITEMS];                                  // element, bucket | position in (tile, bucket) << 16
+#pragma unroll
+  for (int r = 0; r < TRS_ITEMS; r++) {
+    const int i = tbase + r * 1024 + threadIdx.x;
+    bp[r] = 0xFFFFFFFFu;
+    el[r] = 0;
+    if (i < n) {
+      u32 st = hasState ? state[i] : ((u32)s[i] | (1u << 16));
+      if ((st >> 30) == 0) st = info[(st & 0xFFFFu) * 256 + tr_byte(s, i + (int)((st >> 16) & 7u), n)];
+      if ((st >> 30) == TR_K_TERM) rank[i] = (st & 0xFFFFFFu) | BW_LIVE;
+      else {
+        const u32 bk = st & 0xFFFFu;
+        const int at = i + (int)((st >> 16) & 7u);
+        u64 k = __builtin_bswap64(*(const bw_u64_unaligned*)(s + at));
+        const int rem = n - at;
+        if (rem < 8) k = rem <= 0 ? 0ULL : (k & (~0ULL << (8 * (8 - rem))));
+        el[r] = (k & ~lowMask) | (u64)(u32)i;
+        const u32 old = atomicAdd(&tc2[bk >> 1], (bk & 1u) ? 65536u : 1u);
+        const u32 pos = (bk & 1u) ? (old >> 16) : (old & 0xFFFFu);
+        bp[r] = bk | (pos << 16);
+      }
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the tile's bucket counts (a thread owns whole words); buckets present reserve their run in the bucket's slot range
+  {
+    const int per = 2 * ((nB + 2047) / 2048);
+    const int j0 = threadIdx.x * per;
+    u32 mine = 0;
+    for (int j = j0; j < j0 + per && j < nB; j += 2) { const u32 w = tc2[j >> 1]; mine += (w & 0xFFFFu) + (w >> 16); }
+    u32 total;
+    u32 run = kz_wg_excl_sum(mine, scan, &total);
+    const u32* bStart = T.bStart + (int64_t)b * T.MB;
+    u32* bFill = T.bFill + (int64_t)b * T.MB;
+    for (int j = j0; j < j0 + per && j < nB; j += 2) {
+      const u32 w = tc2[j >> 1];
+      const u32 c0 = w & 0xFFFFu, c1 = w >> 16;
+      if (c0) gdelta[j] = bStart[j] + atomicAdd(&bFill[j], c0) - run;
+      const u32 r1 = run + c0;
+      if (c1) gdelta[j + 1] = bStart[j + 1] + atomicAdd(&bFill[j + 1], c1) - r1;
+      tc2[j >> 1] = run | (r1 << 16);                                    // tile-local start of both buckets (< 8192 unless the bucket is empty)
+      run = r1 + c1;
+    }
+    if (threadIdx.x == 0) scan[31] = total;
+  }
+  __syncthreads();
+  const u32 total = scan[31];
+#pragma unroll
+  for (int r = 0; r < TRS_ITEMS; r++) {
+    if (bp[r] != 0xFFFFFFFFu) {
+      const u32 bk = bp[r] & 0xFFFFu;
+      const u32 w = tc2[bk >> 1];
+      const u32 slot = ((bk & 1u) ? (w >> 16) : (w & 0xFFFFu)) + (bp[r] >> 16);
+      stage[slot] = el[r]; stageB[slot] = (uint16_t)bk;
+    }
+  }
+  __syncthreads();
+  u64* elem = elemAll + (int64_t)b * A.NS;
+#pragma unroll
+  for (int r = 0; r < TRS_ITEMS; r++) {
+    const u32 slot = (u32)r * 1024 + threadIdx.x;
+    if (slot < total) elem[gdelta[stageB[slot]] + slot] = stage[slot];
+  }
+}
+
+// one bucket at a time in LDS: sort by the key bits that differ, groups of equal keys, ranks and final suffixes
+#define TRQ_WAVES 16
+#define TRQ_ROWS 8
+__global__ __launch_bounds__(1024, 8) void k_tr_sort(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) {
+  const int b = blockIdx.y;
+  const int nB = T.meta[(int64_t)b * TR_META + 1];
+  __shared__ u64 buf[TR_CAP];
+  __shared__ uint16_t cw[TRQ_WAVES][BK_DBINS];
+  __shared__ u32 wsum[BK_DBINS / 64];
+  __shared__ u32 wH[TRQ_WAVES];
+  __shared__ u64 redO[TRQ_WAVES], redA[TRQ_WAVES];
+  __shared__ int skip[8];
+  const int wave = threadIdx.x >> 6, lane = kz_lane();
+  const int64_t off = (int64_t)b * A.NS;
+  const u64* elem = elemAll + off;
+  u32* rank = A.rank + off;
+  u32* sa = A.sa + off;
+  const uint64_t lt = kz_lanemask_lt();
+  const uint64_t le = lt | (1ULL << lane);
+  const u64 vmask = (1ULL << bitsG) - 1ULL;
+  for (int d = blockIdx.x; d < nB; d += gridDim.x) {
+    const int cnt = (int)T.bCount[(int64_t)b * T.MB + d];
+    const u32 bo = T.bStart[(int64_t)b * T.MB + d];
+    const int rows = (cnt + 63) >> 6;
+    const int R = (rows + TRQ_WAVES - 1) / TRQ_WAVES;                    // rows per wave, 1..TRQ_ROWS (uniform)
+    const int base = wave * R * 64;
+    u64 k[TRQ_ROWS]; u32 dr[TRQ_ROWS];
+    u64 vo = 0, va = ~0ULL;
+#pragma unroll
+    for (int r = 0; r < TRQ_ROWS; r++) {
+      const int idx = base + r * 64 + lane;
+      k[r] = ~0ULL;
+      if (r < R && idx < cnt) { k[r] = elem[bo + idx]; vo |= k[r]; va &= k[r]; }
+    }
+    for (int dd = 32; dd > 0; dd >>= 1) { vo |= __shfl_xor(vo, dd, 64); va &= __shfl_xor(va, dd, 64); }
+    if (threadIdx.x < 8) skip[threadIdx.x] = 0;
+    if (lane == 0) { redO[wave] = vo; redA[wave] = va; }
+    __syncthreads();
+    vo = 0; va = ~0ULL;
+#pragma unroll
+    for (int w = 0; w < TRQ_WAVES; w++) { vo |= redO[w]; va &= redA[w]; }
+    const u64 diff = (vo ^ va) >> bitsG;                                 // key bits that differ inside the bucket
+    int passes = 0, lowBit = 0;
+    if (diff) {
+      lowBit = (int)__builtin_ctzll(diff);
+      const int hiBit = 63 - (int)__builtin_clzll(diff);
+      passes = (hiBit - lowBit + BK_DBITS) / BK_DBITS;
+    }
+    for (int p = 0; p < passes; p++) {
+      const int shift = bitsG + lowBit + BK_DBITS * p;
+      for (int i = threadIdx.x; i < TRQ_WAVES * BK_DBINS / 2; i += TRQ_WAVES * 64) ((u32*)&cw[0][0])[i] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < TRQ_ROWS; r++) {
+        if (r < R) {
+          const int idx = base + r * 64 + lane;
+          const bool valid = idx < cnt;
+          const u32 dg = (u32)(k[r] >> shift) & (BK_DBINS - 1);
+          const uint64_t vm = kz_ballot(valid);
+          if (vm == 0) continue;
+          const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)dg);
+          const bool uni = kz_ballot(valid && dg == d0) == vm;
+          const uint64_t peers = uni ? (valid ? vm : 0ULL) : bw_match<BK_DBITS>(dg, valid);
+          u32 pre = 0;
+          if (valid) pre = cw[wave][dg];
+          const u32 rnk = pre + (u32)__popcll(peers & lt);
+          if (valid && (peers >> lane) == 1ULL) cw[wave][dg] = (uint16_t)(pre + (u32)__popcll(peers));
+          dr[r] = dg | (rnk << 16);
+        }
+      }
+      __syncthreads();
+      static_assert(BK_DBINS <= TRQ_WAVES * 64, "one digit per thread");
+      u32 mine = 0;                                                      // thread = digit (the threads behind carry zero)
+      if (threadIdx.x < BK_DBINS) {
+#pragma unroll
+        for (int w = 0; w < TRQ_WAVES; w++) mine += cw[w][threadIdx.x];
+        if (mine == (u32)cnt) skip[p] = 1;
+      }
+      const u32 inc = kz_wave_incl_sum(mine);
+      if (lane == 63 && wave < BK_DBINS / 64) wsum[wave] = inc;
+      __syncthreads();
+      if (skip[p]) continue;                                             // uniform: one digit value for the whole bucket, nothing moves
+      if (threadIdx.x < BK_DBINS) {
+        u32 run = inc - mine;
+        for (int w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+        for (int w = 0; w < TRQ_WAVES; w++) { const u32 cv = cw[w][threadIdx.x]; cw[w][threadIdx.x] = (uint16_t)run; run += cv; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < TRQ_ROWS; r++) {
+        if (r < R) {
+          const int idx = base + r * 64 + lane;
+          if (idx < cnt) buf[cw[wave][dr[r] & 0xFFFF] + (dr[r] >> 16)] = k[r];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < TRQ_ROWS; r++) {
+        if (r < R) {
+          const int idx = base + r * 64 + lane;
+          if (idx < cnt) k[r] = buf[idx];
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < TRQ_ROWS; r++) {
+      if (r < R) {
+        const int idx = base + r * 64 + lane;
+        if (idx < cnt) buf[idx] = k[r];
+      }
+    }
+    __syncthreads();
+    u32 mh = 0;
+#pragma unroll
+    for (int r = 0; r < TRQ_ROWS; r++) {
+      if (r < R) {
+        const int idx = base + r * 64 + lane;
+        const bool valid = idx < cnt;
+        const u64 prev = (valid && idx > 0) ? buf[idx - 1] : 0;
+        const uint64_t hbr = kz_ballot(valid && (idx == 0 || (k[r] >> bitsG) != (prev >> bitsG)));
+        if (hbr) mh = (u32)(base + r * 64 + 63 - (int)__builtin_clzll(hbr)) + 1;
+      }
+    }
+    if (lane == 0) wH[wave] = mh;
+    __syncthreads();
+    u32 carH = 0;
+    for (int w = 0; w < wave; w++) carH = max(carH, wH[w]);
+#pragma unroll
+    for (int r = 0; r < TRQ_ROWS; r++) {
+      if (r < R) {
+        const int rowBase = base + r * 64;
+        const int idx = rowBase + lane;
+        const bool valid = idx < cnt;
+        const u64 prev = (valid && idx > 0) ? buf[idx - 1] : 0;
+        const uint64_t hbr = kz_ballot(valid && (idx == 0 || (k[r] >> bitsG) != (prev >> bitsG)));
+        const uint64_t hbl = hbr & le;
+        const u32 hh = hbl ? (u32)(rowBase + 63 - (int)__builtin_clzll(hbl)) : carH - 1;
+        if (valid) {
+          const u64 nextk = (idx + 1 < cnt) ? buf[idx + 1] : 0;
+          const bool headN = (idx + 1 >= cnt) || ((nextk >> bitsG) != (k[r] >> bitsG));
+          const bool live = !(hh == (u32)idx && headN);
+          const u32 sv = (u32)(k[r] & vmask);
+          rank[sv] = (bo + hh) | (live ? BW_LIVE : 0u);
+          if (!live) sa[bo + (u32)idx] = sv;
+        }
+        if (hbr) carH = (u32)(rowBase + 63 - (int)__builtin_clzll(hbr)) + 1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // emit: header + BWT bytes (BWTBlockCodec.java:90-126, DivSufSort.java:217-224)
 __global__ void k_bwt_emit(const u8* __restrict__ src, int64_t srcStride, u8* __restrict__ dst, int64_t dstStride,
                            BwtArrays A, int32_t* d_lenOut, int32_t* d_flag) {
@@ -935,10 +1403,29 @@ __global__ void k_bwt_emit(const u8* __restrict__ src, int64_t srcStride, u8* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// The trie round is used for blocks of 64 KiB .. 4 MiB (+ slack).  Table bounds (n = block length, C = TR_CAP):
+//   nodes: 256 of depth 1 + at most n / (C + 1) expanded children per level, levels 2 .. TR_DMAX_LIMIT - 1;
+//   buckets: children above TR_MERGE (<= n / (TR_MERGE + 1)) + merged ones: two neighbours of a run hold more than C suffixes
+//   together (<= 2n / C + 1 per run) and a run starts at a node or behind a breaker (nodes + children above TR_MERGE + terminals).
+#define TR_DMAX_LIMIT 7
+#define TR_MIN_N 65536
+#define TR_MAX_N ((4 << 20) + 65536)
+static inline int tr_max_nodes(int maxN) { return 257 + (TR_DMAX_LIMIT - 2) * (maxN / (int)(TR_CAP + 1) + 1); }
+static inline int tr_max_buckets(int maxN) {
+  const int med = maxN / (int)(TR_MERGE + 1) + 1, big = maxN / (int)(TR_CAP + 1) + 1;
+  return med + 2 * (maxN / (int)TR_CAP) + 2 + tr_max_nodes(maxN) + med + (TR_DMAX_LIMIT - 2) * big + big;
+}
+static inline bool tr_applies(int maxN) {
+  const char* e = getenv("KZ_BWT_TRIE");
+  if (e && e[0] == '0') return false;
+  return maxN >= TR_MIN_N && maxN <= TR_MAX_N && tr_max_buckets(maxN) <= TR_MAXB && tr_max_nodes(maxN) <= 65535;
+}
+
 size_t kz_bwt_forward_scratch(int B, int maxN) {
   const int64_t NS = (int64_t)kz_align((size_t)maxN, RS_TILE);
   const int T = (int)(NS / RS_TILE);
   size_t per = (size_t)NS * (8 * 2 + 4 * 2 + 4 + 4) + (size_t)(T + 4) * (256 * 4 + 12) + 2 * MSD_BINS * 4 + 64 + 11 * 256;
+  if (tr_applies(maxN)) per += (size_t)tr_max_nodes(maxN) * (2 * 1024 + 4) + (size_t)TR_MAXB * 12 + TR_META * 4 + 5 * 256;
   return kz_align(per * (size_t)B + 4096 * 16, 4096) + (1 << 20);
 }
 
@@ -969,6 +1456,21 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
   A.d_m = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   A.d_m2 = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   if (!A.d_m2 || !A.tileB || !A.tileLive || !A.sa || !A.d_big || !A.bucketCnt) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: arena overflow"); return -KZ_ERR_DEVICE; }
+  const bool useTrie = tr_applies(maxN);
+  TrieArrays TR;
+  memset(&TR, 0, sizeof(TR));
+  if (useTrie) {
+    TR.MN = tr_max_nodes(maxN); TR.MB = TR_MAXB;
+    TR.cnt = (u32*)kz_arena_alloc(ctx, (size_t)B * TR.MN * 1024);
+    TR.info = (u32*)kz_arena_alloc(ctx, (size_t)B * TR.MN * 1024);
+    TR.nodeStart = (u32*)kz_arena_alloc(ctx, (size_t)B * TR.MN * 4);
+    TR.bStart = (u32*)kz_arena_alloc(ctx, (size_t)B * TR.MB * 4);
+    TR.bCount = (u32*)kz_arena_alloc(ctx, (size_t)B * TR.MB * 4);
+    TR.bFill = (u32*)kz_arena_alloc(ctx, (size_t)B * TR.MB * 4);
+    TR.meta = (int32_t*)kz_arena_alloc(ctx, (size_t)B * TR_META * 4);
+    TR.err = (int32_t*)kz_arena_alloc(ctx, 256);
+    if (!TR.cnt || !TR.info || !TR.nodeStart || !TR.bStart || !TR.bCount || !TR.bFill || !TR.meta || !TR.err) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: arena overflow (trie tables)"); return -KZ_ERR_DEVICE; }
+  }
   A.d_n = bt.d_len;
   hipStream_t st = ctx->stream;
   const u8* src = bt.buf[bt.cur];
@@ -1004,6 +1506,27 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
     const int gshift = (round == 0) ? 64 : bitsR;
     const bool buckets = useBuckets && round > 0 && mMax >= bucketMin;
     int wMax = mMax;                                               // largest LSD window of the batch
+    if (round == 0 && useTrie) {
+      // ---- the trie round: count level by level, move once, finish the buckets in LDS (elements in key[0], states in val[0]) ----
+      const char* ed = getenv("KZ_BWT_DMAX");
+      const int Dmax = (ed && ed[0] >= '6' && ed[0] <= '0' + TR_DMAX_LIMIT) ? ed[0] - '0' : 6;
+      KZ_HIP(hipMemsetAsync(TR.cnt, 0, (size_t)B * TR.MN * 1024, st));
+      KZ_HIP(hipMemsetAsync(TR.bFill, 0, (size_t)B * TR.MB * 4, st));
+      KZ_HIP(hipMemsetAsync(TR.meta, 0, (size_t)B * TR_META * 4, st));
+      KZ_HIP(hipMemsetAsync(TR.err, 0, 4, st));
+      KZ_LAUNCH(ctx, KID_TR_HIST16, k_tr_hist16, dim3(2, B), dim3(1024), src, bt.stride, A, TR);
+      KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, 1, Dmax);
+      const int P = B >= 2048 ? 1 : (B >= 1024 ? 2 : (B >= 256 ? 4 : 8));
+      for (int L = 2; L < Dmax; L++) {
+        KZ_LAUNCH(ctx, KID_TR_COUNT, k_tr_count, dim3(P, B), dim3(1024), src, bt.stride, A.val[0], A, TR, L);
+        KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, L, Dmax);
+      }
+      KZ_LAUNCH(ctx, KID_TR_SCATTER, k_tr_scatter, dim3(gridFor(maxN, TRS_TILE), B), dim3(1024), src, bt.stride, A.val[0], A.key[0], A, TR, bitsG);
+      const int G = std::max(16, std::min(1024, 8192 / B));
+      KZ_LAUNCH(ctx, KID_TR_SORT, k_tr_sort, dim3(G, B), dim3(1024), A.key[0], A, TR, bitsG);
+      KZ_HIP(hipMemcpyAsync(ctx->hpin + B, TR.err, 4, hipMemcpyDeviceToHost, st));
+      wMax = 0;
+    } else
     if (buckets) {
       const int rt = gridFor(mMax, RSORT_TILE);
       const int sh = bitsR + BK_BITS;
@@ -1049,7 +1572,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
       KZ_LAUNCH(ctx, KID_SEG_APPLY, k_seg_apply, dim3(tiles, B), dim3(KZ_WG), kC, vC, A, gshift);
     }
     // ---- text order: compact the live suffixes, keys for the next round ----
-    h = (round == 0) ? K0 : h * 2;
+    h = (round == 0) ? (useTrie ? 6 : K0) : h * 2;
     KZ_LAUNCH(ctx, KID_LIVE_COUNT, k_live_count, dim3(tilesN, B), dim3(KZ_WG), A, round == 0 ? 1 : 0);
     KZ_LAUNCH(ctx, KID_LIVE_SCAN, k_live_scan, dim3(B), dim3(64), A);
     KZ_LAUNCH(ctx, KID_LIVE_EMIT, k_live_emit, dim3(tilesN, B), dim3(KZ_WG), kF, vF, A, h, bitsR);
@@ -1059,6 +1582,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
     KZ_HIP(kz_stream_sync(ctx, st));
     mMax = 0;
     for (int b = 0; b < B; b++) if (ctx->hpin[b] > mMax) mMax = ctx->hpin[b];
+    if (round == 0 && useTrie && ctx->hpin[B] != 0) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: trie tables overflow"); return -KZ_ERR_PROCESS_BLOCK; }
     if (getenv("KZ_BWT_TRACE")) {                                   // diagnostic: live suffixes left after every doubling round
       long long tot = 0, totN = 0; for (int b = 0; b < B; b++) { tot += ctx->hpin[b]; totN += bt.h_len[b]; }
       fprintf(stderr, "[bwt] round %d h=%d: live %lld of %lld (%.1f%%), max per block %d\n", round, h, tot, totN, 100.0 * tot / (totN ? totN : 1), mMax);

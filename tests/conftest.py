@@ -17,6 +17,12 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def built():
+    # PyTorch ships its own copy of the HIP runtime: in a process that uses both, torch has to be loaded before libkanzi_hip.so
+    # (build() loads the library), or torch finds "No HIP GPUs" later.  Some GPU tests use torch for device buffers.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     import __graft_entry__ as g
     g.build()
     return True
