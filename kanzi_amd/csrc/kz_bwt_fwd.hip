@@ -1073,35 +1073,61 @@ __global__ __launch_bounds__(1024) void k_tr_count(const u8* __restrict__ srcAll
     for (int i = threadIdx.x; i < TR_NODECHUNK * 256; i += 1024) lds[i] = 0;
     __syncthreads();
     const int nlo = lo + chunk * TR_NODECHUNK;
-    for (int i0 = pbeg; i0 < pend; i0 += 1024) {
-      const int i = i0 + threadIdx.x;
-      u32 tgt = 0xFFFFFFFFu;
-      if (i < pend) {
-        u32 st = (L == 2 && chunk == 0) ? (s[i] | (1u << 16)) : state[i];
-        if ((st >> 30) == 0) {
-          const u32 dep = (st >> 16) & 7u;
-          u32 M = 0xFFFFFFFFu;
-          if (dep == (u32)L) M = st & 0xFFFFu;                           // advanced by an earlier chunk of this level
-          else {
-            const u32 e = info[(st & 0xFFFFu) * 256 + tr_byte(s, i + L - 1, n)];
-            if ((e >> 30) == TR_K_EXP) { M = e & 0xFFFFu; st = M | ((u32)L << 16); }
-            else st = e;
-            state[i] = st;
-          }
-          if (M != 0xFFFFFFFFu) {
-            const int k = (int)M - nlo;
-            if (k >= 0 && k < TR_NODECHUNK) tgt = (u32)k * 256 + tr_byte(s, i + L, n);
-          }
+    // a thread takes four CONSECUTIVE suffixes: one 16-byte state access and one 8-byte text window serve all four, equal
+    // targets in a row (runs) are added once; two such quads per thread are in flight (the chain state -> info -> counter is latency)
+    for (int i0 = pbeg; i0 < pend; i0 += 2 * 4096) {
+      uint4 st4[2]; u64 win[2]; bool any[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int i = i0 + u * 4096 + threadIdx.x * 4;
+        any[u] = i < pend;
+        st4[u] = make_uint4(0xC0000000u, 0xC0000000u, 0xC0000000u, 0xC0000000u);
+        win[u] = 0;
+        if (any[u]) {
+          if (!(L == 2 && chunk == 0)) st4[u] = *(const uint4*)(state + i);
+          const int at = i + L - 2;                                        // bytes at .. at + 5: previous byte, child byte, counted byte of the four
+          u64 k = __builtin_bswap64(*(const bw_u64_unaligned*)(s + at));
+          const int rem = n - at;
+          if (rem < 8) k = rem <= 0 ? 0ULL : (k & (~0ULL << (8 * (8 - rem))));
+          win[u] = k;
         }
       }
-      // the row's most frequent kind of target (a long run: everybody hits one counter) is added once
-      const uint64_t act = kz_ballot(tgt != 0xFFFFFFFFu);
-      if (act) {
-        const int l0 = (int)__builtin_ctzll(act);
-        const u32 t0 = (u32)__shfl((int)tgt, l0, 64);
-        const uint64_t same = kz_ballot(tgt == t0);
-        if (lane == l0) atomicAdd(&lds[t0], (u32)__popcll(same));
-        else if (tgt != 0xFFFFFFFFu && tgt != t0) atomicAdd(&lds[tgt], 1u);
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (!any[u]) continue;
+        const int i = i0 + u * 4096 + threadIdx.x * 4;
+        u32 stq[4] = {st4[u].x, st4[u].y, st4[u].z, st4[u].w};
+        u32 e[4]; bool look[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (L == 2 && chunk == 0) stq[q] = (i + q < pend) ? ((1u << 16) | (u32)((win[u] >> (56 - 8 * q)) & 0xFFu)) : 0xC0000000u;
+          look[q] = (i + q < pend) && (stq[q] >> 30) == 0 && ((stq[q] >> 16) & 7u) != (u32)L;
+          e[q] = 0;
+          if (look[q]) e[q] = info[(stq[q] & 0xFFFFu) * 256 + (u32)((win[u] >> (48 - 8 * q)) & 0xFFu)];
+        }
+        bool changed = false;
+        u32 runT = 0xFFFFFFFFu, runC = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          u32 tgt = 0xFFFFFFFFu;
+          if ((i + q < pend) && (stq[q] >> 30) == 0) {
+            if (look[q]) {
+              stq[q] = ((e[q] >> 30) == TR_K_EXP) ? ((e[q] & 0xFFFFu) | ((u32)L << 16)) : e[q];
+              changed = true;
+            }
+            if ((stq[q] >> 30) == 0) {                                       // inside a node of depth L now
+              const int k = (int)(stq[q] & 0xFFFFu) - nlo;
+              if (k >= 0 && k < TR_NODECHUNK) tgt = (u32)k * 256 + (u32)((win[u] >> (40 - 8 * q)) & 0xFFu);
+            }
+          }
+          if (tgt == runT) runC++;
+          else {
+            if (runC && runT != 0xFFFFFFFFu) atomicAdd(&lds[runT], runC);
+            runT = tgt; runC = 1;
+          }
+        }
+        if (runC && runT != 0xFFFFFFFFu) atomicAdd(&lds[runT], runC);
+        if (changed) *(uint4*)(state + i) = make_uint4(stq[0], stq[1], stq[2], stq[3]);
       }
     }
     __syncthreads();
@@ -1208,7 +1234,7 @@ __global__ __launch_bounds__(1024) void k_tr_scatter(const u8* __restrict__ srcA
 // one bucket at a time in LDS: sort by the key bits that differ, groups of equal keys, ranks and final suffixes
 #define TRQ_WAVES 16
 #define TRQ_ROWS 8
-__global__ __launch_bounds__(1024, 8) void k_tr_sort(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) {
+__global__ __launch_bounds__(1024, 8) void k_tr_sort(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG, int dbg) {
   const int b = blockIdx.y;
   const int nB = T.meta[(int64_t)b * TR_META + 1];
   __shared__ u64 buf[TR_CAP];
@@ -1253,6 +1279,7 @@ __global__ __launch_bounds__(1024, 8) void k_tr_sort(const u64* __restrict__ ele
       const int hiBit = 63 - (int)__builtin_clzll(diff);
       passes = (hiBit - lowBit + BK_DBITS) / BK_DBITS;
     }
+    if (dbg & 1) passes = 0;
     for (int p = 0; p < passes; p++) {
       const int shift = bitsG + lowBit + BK_DBITS * p;
       for (int i = threadIdx.x; i < TRQ_WAVES * BK_DBINS / 2; i += TRQ_WAVES * 64) ((u32*)&cw[0][0])[i] = 0;
@@ -1349,8 +1376,8 @@ __global__ __launch_bounds__(1024, 8) void k_tr_sort(const u64* __restrict__ ele
           const bool headN = (idx + 1 >= cnt) || ((nextk >> bitsG) != (k[r] >> bitsG));
           const bool live = !(hh == (u32)idx && headN);
           const u32 sv = (u32)(k[r] & vmask);
-          rank[sv] = (bo + hh) | (live ? BW_LIVE : 0u);
-          if (!live) sa[bo + (u32)idx] = sv;
+          if (!(dbg & 2)) rank[sv] = (bo + hh) | (live ? BW_LIVE : 0u);
+          if (!live && !(dbg & 4)) sa[bo + (u32)idx] = sv;
         }
         if (hbr) carH = (u32)(rowBase + 63 - (int)__builtin_clzll(hbr)) + 1;
       }
@@ -1523,7 +1550,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
       }
       KZ_LAUNCH(ctx, KID_TR_SCATTER, k_tr_scatter, dim3(gridFor(maxN, TRS_TILE), B), dim3(1024), src, bt.stride, A.val[0], A.key[0], A, TR, bitsG);
       const int G = std::max(16, std::min(1024, 8192 / B));
-      KZ_LAUNCH(ctx, KID_TR_SORT, k_tr_sort, dim3(G, B), dim3(1024), A.key[0], A, TR, bitsG);
+      KZ_LAUNCH(ctx, KID_TR_SORT, k_tr_sort, dim3(G, B), dim3(1024), A.key[0], A, TR, bitsG, getenv("KZ_TRQ_DBG") ? atoi(getenv("KZ_TRQ_DBG")) : 0);
       KZ_HIP(hipMemcpyAsync(ctx->hpin + B, TR.err, 4, hipMemcpyDeviceToHost, st));
       wMax = 0;
     } else

@@ -1083,3 +1083,406 @@ def fsd_forward(data, data_type="UNDEFINED"):
     if first_order_entropy_1024(count5, h) >= ent[0]:
         return False, b"", left
     return True, bytes(out), left
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# TextCodec (K/transform/TextCodec.java), written from the Java: computeStats :269-384, detectType :387-466, createDictionary
+# :205-236, TextCodec1 (:536-1040: reset :585-616, forward :618-795, expandDictionary :798-812, emitSymbols :815-857,
+# emitWordIndex :860-873), TextCodec2 (:1042-1620: reset :1092-1120, forward :1124-1291, emitSymbols :1310-1380, emitWordIndex
+# :1383-1407) and the wrapper TextCodec.forward :482-509.  Java bytes are signed: the hashes multiply the SIGNED byte.
+_DATA_TYPES = ("UNDEFINED", "TEXT", "MULTIMEDIA", "EXE", "NUMERIC", "BASE64", "DNA", "BIN", "UTF8", "SMALL_ALPHABET")   # Global.java:40-80
+
+
+def _i32(x):
+    x &= 0xFFFFFFFF
+    return x - (1 << 32) if x & 0x80000000 else x
+
+
+def _sb(b):                                                                      # a Java byte
+    return b - 256 if b >= 128 else b
+
+
+_T_HASH1 = 0x7FEB352D
+_T_HASH2 = _i32(0x846CA68B)
+_T_THRESHOLD1, _T_THRESHOLD2, _T_THRESHOLD3, _T_THRESHOLD4 = 128, 128 * 128, 64, 64 * 128
+_T_MAX_DICT_SIZE, _T_MAX_WORD_LENGTH = 1 << 19, 31
+_T_ESC1, _T_ESC2, _T_LF, _T_CR = 0x0F, 0x0E, 0x0A, 0x0D
+_T_MASK_NOT_TEXT, _T_MASK_CRLF, _T_MASK_XML_HTML, _T_MASK_TEXT_CODEC, _T_MASK_DT, _T_MASK_LENGTH = 0x80, 0x40, 0x20, 0x10, 0x0F, 0x0007FFFF
+
+
+def _t_is_text(b):                                                               # :239-251 on an unsigned byte value
+    v = _sb(b | 0x20) if b < 128 else _sb(b)                                      # (byte) (val | 0x20): negative bytes stay negative
+    return 0x61 <= v <= 0x7A
+
+
+def _t_is_upper(b):
+    return 0x41 <= b <= 0x5A
+
+
+_T_DELIMS = [False] * 256
+for _c in range(256):                                                            # initDelimiterChars :57-85
+    if 0x20 <= _c <= 0x2F or 0x3A <= _c <= 0x3F or _c in (0x0A, 0x09, 0x0D, 0x5F, 0x7C, 0x7B, 0x7D, 0x5B, 0x5D):
+        _T_DELIMS[_c] = True
+
+
+class _DictEntry:                                                                # :1622-1633
+    __slots__ = ("buf", "pos", "hash", "data")
+
+    def __init__(self, buf, pos, hsh, idx, length):
+        self.buf, self.pos, self.hash, self.data = buf, pos, hsh, (length << 24) | idx
+
+
+def text_static_dictionary(words_bytes):
+    """createDictionary :205-236 over DICT_EN_1024 (the bytes are lower-cased in place as the words are cut)"""
+    words = bytearray(words_bytes)
+    d = []
+    anchor, h = 0, _T_HASH1
+    for i in range(len(words)):
+        if len(d) >= 1024:
+            break
+        if not _t_is_text(words[i]):
+            continue
+        if _t_is_upper(words[i]):
+            if i > anchor:
+                d.append(_DictEntry(words, anchor, h, len(d), i - anchor))
+                anchor, h = i, _T_HASH1
+            words[i] ^= 0x20
+        h = _i32(_i32(h * _T_HASH1) ^ _i32(_sb(words[i]) * _T_HASH2))
+    if len(d) < 1024:
+        d.append(_DictEntry(words, anchor, h, len(d), len(words) - anchor))
+    return d
+
+
+def text_compute_stats(block, strict):
+    """computeStats :269-384 -> (mode byte, freqs0)"""
+    count = len(block)
+    freqs0 = [0] * 256
+    if not strict and magic_type(block) != 0:                                    # :272-273
+        return _T_MASK_NOT_TEXT, freqs0
+    freqs = {}
+    prv = 0
+    for cur in block:                                                            # :284-306
+        freqs0[cur] += 1
+        freqs[(prv, cur)] = freqs.get((prv, cur), 0) + 1
+        prv = cur
+    f = lambda a, b: freqs.get((a, b), 0)
+    nb_text = freqs0[_T_CR] + freqs0[_T_LF]
+    nb_ascii = 0
+    for i in range(128):                                                         # :311-316
+        if _t_is_text(i):
+            nb_text += freqs0[i]
+        nb_ascii += freqs0[i]
+    nb_bin = count - nb_ascii
+    not_text = nb_bin > (count >> 2)                                             # :320
+    if not not_text:
+        not_text = nb_text < (count // 4)
+        if strict:
+            not_text = not_text or (freqs0[0] >= (count // 100)) or ((nb_ascii // 95) < (count // 100))
+        else:
+            not_text = not_text or (freqs0[32] < (count // 50))
+    if not_text:
+        return _text_detect_type(freqs0, f, count), freqs0
+    res = 0
+    if nb_bin <= count - count // 10:                                            # :337-357
+        f1, f2 = freqs0[0x3C], freqs0[0x3E]
+        f3 = f(0x26, 0x61) + f(0x26, 0x67) + f(0x26, 0x6C) + f(0x26, 0x71)
+        min_freq = max((count - nb_bin) >> 9, 2)
+        if f1 >= min_freq and f2 >= min_freq and f3 > 0:
+            if f1 < f2:
+                if f1 >= f2 - f2 // 100:
+                    res |= _T_MASK_XML_HTML
+            elif f2 < f1:
+                if f2 >= f1 - f1 // 100:
+                    res |= _T_MASK_XML_HTML
+            else:
+                res |= _T_MASK_XML_HTML
+    if freqs0[_T_CR] != 0 and freqs0[_T_CR] == freqs0[_T_LF]:                    # :360-374
+        res |= _T_MASK_CRLF
+        for i in range(256):
+            if i != _T_LF and f(_T_CR, i) != 0:
+                res &= ~_T_MASK_CRLF
+                break
+            if i != _T_CR and f(i, _T_LF) != 0:
+                res &= ~_T_MASK_CRLF
+                break
+    return res, freqs0
+
+
+def _text_detect_type(freqs0, f, count):                                         # :387-466
+    dt = detect_simple_type(count, freqs0)
+    if dt != "UNDEFINED":
+        return _T_MASK_NOT_TEXT | _DATA_TYPES.index(dt)
+    s = freqs0[0xC0] + freqs0[0xC1] + sum(freqs0[i] for i in range(0xF5, 0x100))
+    if s != 0:
+        return _T_MASK_NOT_TEXT
+    sum1 = sum2 = 0
+    for i in range(256):
+        if i < 0xA0 or i > 0xBF:
+            sum1 += f(0xE0, i)
+        if i < 0x80 or i > 0x9F:
+            sum1 += f(0xED, i)
+        if i < 0x90 or i > 0xBF:
+            sum1 += f(0xF0, i)
+        if i < 0x80 or i > 0x8F:
+            sum1 += f(0xF4, i)
+        if i < 0x80 or i > 0xBF:
+            for j in range(0xC2, 0xE0):
+                sum1 += f(j, i)
+            for j in range(0xE1, 0xED):
+                sum1 += f(j, i)
+            sum1 += f(0xF1, i) + f(0xF2, i) + f(0xF3, i) + f(0xEE, i) + f(0xEF, i)
+        else:
+            sum2 += freqs0[i]
+        if sum1 != 0:
+            return _T_MASK_NOT_TEXT
+    return (_T_MASK_NOT_TEXT | _DATA_TYPES.index("UTF8")) if sum2 >= count // 8 else _T_MASK_NOT_TEXT
+
+
+def _ilog2(x):                                                                   # Global.log2 :207-212
+    return x.bit_length() - 1
+
+
+class _TextCodecModel:
+    """state shared by both variants: dictMap (hash & mask -> entry), dictList, dictSize"""
+
+    def __init__(self, variant, block_size, static_dict):
+        self.variant = variant
+        if variant == 1:                                                         # TextCodec1(ctx) :558-582
+            log = max(min(_ilog2(block_size // 8), 26), 13) if block_size >= 8 else 13
+            self.static_size = len(static_dict) + 2
+        else:                                                                    # TextCodec2(ctx) :1067-1090
+            log = max(min(_ilog2(block_size // 32), 24), 13) if block_size >= 32 else 13
+            self.static_size = len(static_dict)
+        self.hash_mask = (1 << log) - 1
+        self.static_dict = static_dict
+        self.is_crlf = False
+
+    def reset(self, count):                                                      # :585-616 / :1092-1120 (a fresh instance per block)
+        log = 13 if count < 1024 else max(min(_ilog2(count // 128), 18), 13)
+        self.dict_size = 1 << log
+        self.dict_map = {}
+        self.dict_list = [None] * self.dict_size
+        n = min(len(self.static_dict), self.dict_size)
+        self.dict_list[:n] = self.static_dict[:n]
+        if self.variant == 1:
+            k = len(self.static_dict)
+            self.dict_list[k] = _DictEntry(bytes([_T_ESC2]), 0, 0, k, 1)
+            self.dict_list[k + 1] = _DictEntry(bytes([_T_ESC1]), 0, 0, k + 1, 1)
+        for i in range(self.static_size):
+            e = self.dict_list[i]
+            self.dict_map[e.hash & self.hash_mask] = e
+        for i in range(self.static_size, self.dict_size):
+            self.dict_list[i] = _DictEntry(None, -1, 0, i, 0)
+
+    def expand(self):                                                            # expandDictionary :798-812 / :1294-1308
+        if self.dict_size >= _T_MAX_DICT_SIZE:
+            return False
+        self.dict_list.extend(_DictEntry(None, -1, 0, i, 0) for i in range(self.dict_size, self.dict_size * 2))
+        self.dict_size <<= 1
+        return True
+
+    # ---- TextCodec1 ----
+    def emit_symbols1(self, src, src_idx, dst, dst_idx, src_end, dst_end):       # :815-857
+        for i in range(src_idx, src_end):
+            if dst_idx >= dst_end:
+                return dst_end + 1
+            cur = src[i]
+            if cur == _T_ESC1 or cur == _T_ESC2:
+                dst[dst_idx] = _T_ESC1
+                dst_idx += 1
+                idx = self.static_size - 1 if cur == _T_ESC1 else self.static_size - 2
+                len_idx = 2
+                if idx >= _T_THRESHOLD2:
+                    len_idx = 3
+                elif idx < _T_THRESHOLD1:
+                    len_idx = 1
+                if dst_idx + len_idx >= dst_end:
+                    return dst_end + 1
+                dst_idx = self.emit_word_index1(dst, dst_idx, idx)
+            elif cur == _T_CR:
+                if not self.is_crlf:
+                    dst[dst_idx] = cur
+                    dst_idx += 1
+            else:
+                dst[dst_idx] = cur
+                dst_idx += 1
+        return dst_idx
+
+    @staticmethod
+    def emit_word_index1(dst, dst_idx, val):                                     # :860-873
+        if val >= _T_THRESHOLD1:
+            if val >= _T_THRESHOLD2:
+                dst[dst_idx] = (0xE0 | (val >> 14)) & 0xFF
+                dst_idx += 1
+            dst[dst_idx] = (0x80 | (val >> 7)) & 0xFF
+            dst[dst_idx + 1] = 0x7F & val
+            return dst_idx + 2
+        dst[dst_idx] = val
+        return dst_idx + 1
+
+    # ---- TextCodec2 ----
+    def emit_symbols2(self, src, src_idx, dst, dst_idx, src_end, dst_end):       # :1310-1380
+        if dst_idx + 2 * (src_end - src_idx) < dst_end:
+            for i in range(src_idx, src_end):
+                cur = src[i]
+                if cur == _T_ESC1:
+                    dst[dst_idx] = _T_ESC1
+                    dst[dst_idx + 1] = _T_ESC1
+                    dst_idx += 2
+                elif cur == _T_CR:
+                    if not self.is_crlf:
+                        dst[dst_idx] = cur
+                        dst_idx += 1
+                else:
+                    dst[dst_idx] = _T_ESC1
+                    dst_idx += 1 if cur >= 128 else 0                            # cur >>> 31 on the sign-extended byte
+                    dst[dst_idx] = cur
+                    dst_idx += 1
+        else:
+            for i in range(src_idx, src_end):
+                cur = src[i]
+                if cur == _T_ESC1:
+                    if dst_idx >= dst_end - 1:
+                        return dst_end + 1
+                    dst[dst_idx] = _T_ESC1
+                    dst[dst_idx + 1] = _T_ESC1
+                    dst_idx += 2
+                elif cur == _T_CR:
+                    if not self.is_crlf:
+                        if dst_idx >= dst_end:
+                            return dst_end + 1
+                        dst[dst_idx] = cur
+                        dst_idx += 1
+                else:
+                    if cur & 0x80:
+                        if dst_idx >= dst_end:
+                            return dst_end + 1
+                        dst[dst_idx] = _T_ESC1
+                        dst_idx += 1
+                    if dst_idx >= dst_end:
+                        return dst_end + 1
+                    dst[dst_idx] = cur
+                    dst_idx += 1
+        return dst_idx
+
+    @staticmethod
+    def emit_word_index2(dst, dst_idx, w_idx):                                   # :1383-1407
+        w_idx += 1
+        if w_idx >= _T_THRESHOLD3:
+            if w_idx >= _T_THRESHOLD4:
+                dst[dst_idx] = (0xF0 | (w_idx >> 16)) & 0xFF
+                dst[dst_idx + 1] = (w_idx >> 8) & 0xFF
+                dst[dst_idx + 2] = w_idx & 0xFF
+                return dst_idx + 3
+            dst[dst_idx] = (0xC0 | (w_idx >> 8)) & 0xFF
+            dst[dst_idx + 1] = w_idx & 0xFF
+            return dst_idx + 2
+        dst[dst_idx] = 0x80 | w_idx
+        return dst_idx + 1
+
+
+def text_forward(data, variant, block_size, static_dict, data_type="UNDEFINED"):
+    """TextCodec.forward :482-509 over TextCodec1.forward :618-795 (variant 1: the FPAQ / TPAQ / CM streams,
+    TransformFactory.java:275-286) or TextCodec2.forward :1124-1291 (variant 2), with a context.
+    Returns (applied, bytes, dataType left in the context)."""
+    src = bytes(data)
+    count = len(src)
+    if count == 0:
+        return True, b"", data_type
+    if count < 1024 or count > (1 << 30):                                        # MIN_BLOCK_SIZE / MAX_BLOCK_SIZE :491-492
+        return False, b"", data_type
+    if data_type not in ("UNDEFINED", "TEXT", "BIN"):                            # :641-649 / :1141-1149
+        return False, b"", data_type
+    m = _TextCodecModel(variant, block_size, static_dict)
+    mode, _freqs0 = text_compute_stats(src, strict=(variant == 1))               # :652 (true) / :1155 (false)
+    if mode & _T_MASK_NOT_TEXT:
+        return False, b"", _DATA_TYPES[mode & _T_MASK_DT]                          # :655-668: the detected type goes to the context
+    data_type = "TEXT"
+    m.reset(count)
+    dst_end = count                                                              # getMaxEncodedLength :1033 / :1614
+    dst_end_guard = dst_end - (4 if variant == 1 else 3)                         # dstEnd4 / dstEnd3
+    dst = bytearray(count + 8)
+    src_idx = dst_idx = 0
+    src_end = count
+    emit_anchor = 0
+    words = m.static_size
+    m.is_crlf = (mode & _T_MASK_CRLF) != 0
+    dst[dst_idx] = mode & 0xFF
+    dst_idx += 1
+    res = True
+    while src_idx < src_end and src[src_idx] == 0x20:                            # :686-690
+        dst[dst_idx] = 0x20
+        dst_idx += 1
+        src_idx += 1
+        emit_anchor += 1
+    delim_anchor = src_idx - 1 if _t_is_text(src[src_idx]) else src_idx          # :692
+    emit_symbols = m.emit_symbols1 if variant == 1 else m.emit_symbols2
+    while src_idx < src_end:
+        cur = src[src_idx]
+        if _t_is_text(cur):
+            src_idx += 1
+            continue
+        if src_idx > delim_anchor + 2 and _T_DELIMS[cur]:                        # at least 2 letters
+            length = src_idx - delim_anchor - 1
+            if length <= _T_MAX_WORD_LENGTH:
+                val = _sb(src[delim_anchor + 1])
+                h1 = _i32(_i32(_T_HASH1 * _T_HASH1) ^ _i32(val * _T_HASH2))      # :710-711
+                h2 = _i32(_i32(_T_HASH1 * _T_HASH1) ^ _i32((val ^ 0x20) * _T_HASH2))
+                for i in range(delim_anchor + 2, src_idx):
+                    h = _i32(_sb(src[i]) * _T_HASH2)
+                    h1 = _i32(_i32(h1 * _T_HASH1) ^ h)
+                    h2 = _i32(_i32(h2 * _T_HASH1) ^ h)
+                e = None
+                e1 = m.dict_map.get(h1 & m.hash_mask)                            # :721-731
+                if e1 is not None and e1.hash == h1 and (e1.data >> 24) == length:
+                    e = e1
+                else:
+                    e2 = m.dict_map.get(h2 & m.hash_mask)
+                    if e2 is not None and e2.hash == h2 and (e2.data >> 24) == length:
+                        e = e2
+                if e is not None:                                                # sameWords :469-479 on all but the first letter
+                    if src[delim_anchor + 2:delim_anchor + 1 + length] != bytes(e.buf[e.pos + 1:e.pos + length]):
+                        e = None
+                if e is None:
+                    if (length > 3 or (length == 3 and words < _T_THRESHOLD2)) and e1 is None:   # :742-762
+                        e = m.dict_list[words]
+                        if (e.data & _T_MASK_LENGTH) >= m.static_size:
+                            if m.dict_map.get(e.hash & m.hash_mask) is not None:
+                                m.dict_map[e.hash & m.hash_mask] = None          # the slot is cleared whoever sits in it
+                            e.buf, e.pos, e.hash, e.data = src, delim_anchor + 1, h1, (length << 24) | words
+                        m.dict_map[h1 & m.hash_mask] = e
+                        words += 1
+                        if words >= m.dict_size:
+                            if not m.expand():
+                                words = m.static_size
+                else:
+                    if emit_anchor != delim_anchor or src[delim_anchor] != 0x20:  # :766-769
+                        dst_idx = emit_symbols(src, emit_anchor, dst, dst_idx, delim_anchor + 1, dst_end)
+                    if dst_idx >= dst_end_guard:
+                        res = False
+                        break
+                    if variant == 1:                                             # :776-778
+                        dst[dst_idx] = _T_ESC1 if e is e1 else _T_ESC2
+                        dst_idx += 1
+                        dst_idx = m.emit_word_index1(dst, dst_idx, e.data & _T_MASK_LENGTH)
+                    else:                                                        # :1262-1265: case flip is encoded as 0x80
+                        dst[dst_idx] = 0x80
+                        dst_idx += 0 if e is e1 else 1
+                        dst_idx = m.emit_word_index2(dst, dst_idx, e.data & _T_MASK_LENGTH)
+                    emit_anchor = delim_anchor + 1 + (e.data >> 24)
+        delim_anchor = src_idx
+        src_idx += 1
+    if res:
+        d_idx = emit_symbols(src, emit_anchor, dst, dst_idx, src_end, dst_end)
+        if d_idx > dst_end:
+            res = False
+        else:
+            dst_idx = d_idx
+        res = res and src_idx == src_end
+    if not res:
+        return False, b"", data_type
+    if variant == 1:                                                             # TextCodec.forward :501-506 (bsVersion 7)
+        dst[0] &= ~_T_MASK_TEXT_CODEC & 0xFF
+    else:
+        dst[0] |= _T_MASK_TEXT_CODEC
+    return True, bytes(dst[:dst_idx]), data_type
