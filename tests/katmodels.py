@@ -1486,3 +1486,399 @@ def text_forward(data, variant, block_size, static_dict, data_type="UNDEFINED"):
     else:
         dst[0] |= _T_MASK_TEXT_CODEC
     return True, bytes(dst[:dst_idx]), data_type
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Bit I/O and the container, written from the Java: DefaultOutputBitStream (K/bitstream/DefaultOutputBitStream.java:103-222,
+# 229-296), the stream header (K/io/CompressedOutputStream.java:236-313), a block (:733-985: copy blocks, skip flags, mode byte,
+# header checksum, raw "transformed copy" fallback), block framing and the end marker (:1024-1035, :489-492), Sequence.forward
+# (K/transform/Sequence.java:56-127), BWTBlockCodec.forward (K/transform/BWTBlockCodec.java:71-128) over the output convention of
+# DivSufSort.computeBWT (:204-227), ZRLT.forward (K/transform/ZRLT.java:54-136).
+class JavaOutputBitStream:
+    """DefaultOutputBitStream with its 64-bit accumulator `current`, `availBits`, the byte buffer and `position`"""
+
+    def __init__(self, buffer_size=16384):
+        self.sink = bytearray()
+        self.buffer = bytearray(buffer_size)
+        self.position = 0
+        self.avail = 64
+        self.current = 0
+        self.written_bits = 0
+        self.closed = False
+
+    def write_bits(self, value, count):                                          # writeBits(long, int) :103-123
+        if count == 0:
+            return 0
+        assert count <= 64
+        value &= M64                                                             # a Java long, two's complement
+        self.current |= ((value << (64 - count)) & M64) >> (64 - self.avail)
+        if count >= self.avail:
+            remaining = count - self.avail
+            self._push_current()
+            if remaining != 0:
+                self.current = (value << (64 - remaining)) & M64
+                self.avail -= remaining
+        else:
+            self.avail -= count
+        return count
+
+    def write_bytes(self, bits, start, count):                                   # writeBits(byte[], int, int) :136-205
+        remaining = count
+        if (self.avail & 7) == 0:
+            while self.avail != 64 and remaining >= 8:
+                self.write_bits(_sb(bits[start]), 8)                             # the signed byte, sign-extended into the long
+                start += 1
+                remaining -= 8
+            max_pos = len(self.buffer) - 8
+            while (remaining >> 3) >= max_pos - self.position:
+                k = max_pos - self.position
+                self.buffer[self.position:self.position + k] = bits[start:start + k]
+                start += k
+                remaining -= k << 3
+                self.position = max_pos
+                self._flush()
+            r = (remaining >> 6) << 3
+            if r > 0:
+                self.buffer[self.position:self.position + r] = bits[start:start + r]
+                self.position += r
+                start += r
+                remaining -= r << 3
+        elif remaining >= 64:
+            r = 64 - self.avail
+            while remaining >= 64:
+                value = int.from_bytes(bits[start:start + 8], "big")
+                self.current |= value >> r
+                self._push_current()
+                self.current = (value << (64 - r)) & M64                          # value << -r: Java masks the shift count to 6 bits
+                start += 8
+                remaining -= 64
+            self.avail -= r
+        while remaining >= 8:
+            self.write_bits(bits[start] & 0xFF, 8)
+            start += 1
+            remaining -= 8
+        if remaining > 0:
+            self.write_bits((bits[start] & 0xFF) >> (8 - remaining), remaining)  # bits[start] >>> (8 - remaining) then masked to `remaining` bits
+        return count
+
+    def _push_current(self):                                                     # :211-220
+        self.buffer[self.position:self.position + 8] = self.current.to_bytes(8, "big")
+        self.avail = 64
+        self.current = 0
+        self.position += 8
+        if self.position >= len(self.buffer) - 8:
+            self._flush()
+
+    def _flush(self):                                                            # :229-243
+        if self.position > 0:
+            self.sink += self.buffer[:self.position]
+            self.written_bits += self.position << 3
+            self.position = 0
+
+    def written(self):                                                           # :318-320
+        return self.written_bits + (self.position << 3) + (64 - self.avail)
+
+    def close(self):                                                             # :253-296: the last byte may be incomplete (zero padded)
+        if self.closed:
+            return
+        shift = 56
+        while self.avail < 64:
+            self.buffer[self.position] = (self.current >> shift) & 0xFF
+            self.position += 1
+            self.avail += 8
+            shift -= 8
+        self.written_bits -= self.avail - 64
+        self.avail = 64
+        self._flush()
+        self.closed = True
+        self.position = 0
+        self.avail = 0
+        self.written_bits -= 64
+
+
+def _mix32(checksum, hsh, value):                                                # CompressedOutputStream.mix32 :89-93
+    checksum ^= (hsh * (~value & 0xFFFFFFFF)) & 0xFFFFFFFF
+    checksum = ((checksum << 13) | (checksum >> 19)) & 0xFFFFFFFF
+    return (checksum * 5 + 0x52DCE729) & 0xFFFFFFFF
+
+
+_TRANSFORM_IDS = {"NONE": 0, "BWT": 1, "BWTS": 2, "LZ": 3, "SNAPPY": 4, "RLT": 5, "ZRLT": 6, "MTFT": 7, "RANK": 8, "EXE": 9, "TEXT": 10,
+                  "ROLZ": 11, "ROLZX": 12, "SRT": 13, "LZP": 14, "MM": 15, "LZX": 16, "UTF": 17, "PACK": 18, "DNA": 19}   # TransformFactory.java:36-58
+_ENTROPY_IDS = {"NONE": 0, "HUFFMAN": 1, "FPAQ": 2, "PAQ": 3, "RANGE": 4, "ANS0": 5, "CM": 6, "TPAQ": 7, "ANS1": 8, "TPAQX": 9}   # EntropyCodecFactory.java
+
+
+def transform_type_word(names):
+    """TransformFactory.getType :132-158: eight 6-bit tokens, the first one in the top bits of a 48-bit word"""
+    w = 0
+    for i, n in enumerate(names):
+        w |= _TRANSFORM_IDS[n] << (42 - 6 * i)
+    return w
+
+
+def suffix_array_by_doubling(data):
+    """suffix array of `data` (shorter suffix first) by rank doubling with numpy sorts: a third suffix sorter, independent of the
+    oracle's induced sorting and of the HIP path's trie / radix rounds"""
+    import numpy as np
+    a = np.frombuffer(bytes(data), dtype=np.uint8).astype(np.int64)
+    n = len(a)
+    rank = a + 1
+    k = 1
+    while True:
+        r2 = np.zeros(n, dtype=np.int64)
+        r2[:n - k] = rank[k:] if k < n else 0
+        key = rank * (n + 2) + r2
+        order = np.argsort(key, kind="stable")
+        ks = key[order]
+        newr = np.empty(n, dtype=np.int64)
+        newr[order] = np.concatenate(([0], np.cumsum(ks[1:] != ks[:-1]))) + 1
+        rank = newr
+        if rank.max() == n or k >= n:
+            return order
+        k *= 2
+
+
+def bwt_block_forward(data):
+    """BWTBlockCodec.forward :71-128: mode byte, the primary indexes (minus one) big endian, then the BWT of DivSufSort.computeBWT
+    :204-227 (out[0] = in[n-1]; the suffix array row of suffix 0 is left out, rows before it shift by one) with
+    primary[k] = ISA[k * step] + 1 (constructBWT :233-325), chunks from BWT.getBWTChunks :561-563"""
+    src = bytes(data)
+    n = len(src)
+    if n == 0:
+        return True, b""
+    log_bs = _ilog2(n)
+    if n & (n - 1):
+        log_bs += 1
+    p_size = (log_bs + 7) >> 3
+    if p_size <= 0 or p_size >= 5:
+        return False, b""
+    chunks = 1 if n < 256 else 8
+    if n == 1:                                                                   # BWT.forward :174-177 copies; the primary index stays 0
+        body = src
+        primaries = [0] * chunks
+    else:
+        sa = suffix_array_by_doubling(src)
+        isa = [0] * n
+        for r, s in enumerate(sa):
+            isa[int(s)] = r
+        p = isa[0]
+        out = bytearray(n)
+        out[0] = src[n - 1]
+        for i in range(n):
+            if i < p:
+                out[1 + i] = src[int(sa[i]) - 1]
+            elif i > p:
+                out[i] = src[int(sa[i]) - 1]
+        body = bytes(out)
+        st = n // chunks
+        step = st + 1 if st * chunks != n else st
+        primaries = [isa[k * step] + 1 if k * step < n else 0 for k in range(chunks)]
+    hdr = bytearray([(_ilog2(chunks) << 2) | (p_size - 1)])
+    for k in range(chunks):
+        hdr += ((primaries[k] - 1) & ((1 << (8 * p_size)) - 1)).to_bytes(p_size, "big")
+    return True, bytes(hdr) + body
+
+
+def zrlt_forward(data):
+    """ZRLT.forward :54-136: the output may not reach the input's length"""
+    src = bytes(data)
+    count = len(src)
+    if count == 0:
+        return True, b""
+    dst = bytearray()
+    dst_end = count
+    i = 0
+    res = True
+    while i < count:
+        if src[i] == 0:
+            run = 1
+            while i + run < count and src[i + run] == 0:
+                run += 1
+            i += run
+            run += 1
+            log2 = _ilog2(run)
+            if len(dst) >= dst_end - log2:
+                res = False
+                break
+            while log2 > 0:
+                log2 -= 1
+                dst.append((run >> log2) & 1)
+            continue
+        val = src[i]
+        if val >= 0xFE:
+            if len(dst) >= dst_end - 1:
+                res = False
+                break
+            dst += bytes([0xFF, val - 0xFE])
+        else:
+            if len(dst) >= dst_end:
+                res = False
+                break
+            dst.append(val + 1)
+        i += 1
+    return res and i == count, bytes(dst)
+
+
+def _magic_class(magic):                                                         # Magic.isCompressed / isMultimedia / isExecutable :185-258
+    compressed = magic in (0xFFD8FFE0, 0x47494638, 0x89504E47, 0x377ABCAF, 0x28B52FFD, 0x81CFB2CE, 0x4D534346, 0x504B0304, 0x1F8B,
+                           0x425A68, 0x664C6143, 0x494433, 0xFD377A58, 0x4B414E5A, 0x52617221)
+    multimedia = magic in (0xFFD8FFE0, 0x47494638, 0x89504E47, 0x52494646, 0x664C6143, 0x494433, 0x424D, 0x5034, 0x5035, 0x5036)
+    executable = magic in (0x7F454C46, 0x4D5A, 0xFEEDFACE, 0xCEFAEDFE, 0xFEEDFACF, 0xCFFAEDFE)
+    return compressed, multimedia, executable
+
+
+def knz_stream(data, names, entropy, block_size, static_words, input_size=0):
+    """the whole .knz a CompressedOutputStream (no checksum, one job; input_size = the "fileSize" context entry, 0 = unknown) writes for `data`:
+    -t names -e entropy -b block_size.  Stages: TEXT, UTF, BWT, RANK, MTFT, SRT, ZRLT; coders: NONE, ANS0, FPAQ."""
+    data = bytes(data)
+    ttype = transform_type_word(names)
+    etype = _ENTROPY_IDS[entropy]
+    obs = JavaOutputBitStream(65536)
+    # ---- writeHeader :236-313 ----
+    obs.write_bits(0x4B414E5A, 32)
+    obs.write_bits(7, 4)
+    chk_size = 0
+    obs.write_bits(chk_size, 2)
+    obs.write_bits(etype, 5)
+    obs.write_bits(ttype, 48)
+    obs.write_bits(block_size >> 4, 28)
+    sz_mask = 0                                                                  # :266-280
+    if input_size != 0 and input_size < (1 << 48):
+        if input_size >= (1 << 32):
+            sz_mask = 3
+        else:
+            isz = input_size
+            if isz > (1 << 30):
+                isz >>= 4
+                sz_mask += 1
+            sz_mask += (_ilog2(isz) >> 4) + 1
+    obs.write_bits(sz_mask, 2)
+    if sz_mask > 0:
+        obs.write_bits(input_size, 16 * sz_mask)
+    obs.write_bits(0, 15)
+    HASH = 0x1E35A7BD
+    ck = (HASH * ((0x01030507 * 7) & 0xFFFFFFFF)) & 0xFFFFFFFF
+    ck = _mix32(ck, HASH, chk_size)
+    ck = _mix32(ck, HASH, etype)
+    ck = _mix32(ck, HASH, (ttype >> 32) & 0xFFFFFFFF)
+    ck = _mix32(ck, HASH, ttype & 0xFFFFFFFF)
+    ck = _mix32(ck, HASH, block_size)
+    if sz_mask > 0:
+        ck = _mix32(ck, HASH, (input_size >> 32) & 0xFFFFFFFF)
+        ck = _mix32(ck, HASH, input_size & 0xFFFFFFFF)
+    ck = (ck >> 23) ^ (ck >> 3)
+    obs.write_bits(ck, 24)
+    # ---- blocks ----
+    for off in range(0, len(data), block_size):
+        block = data[off:off + block_size]
+        blob, written = _knz_block(block, names, entropy, block_size, static_words)
+        lw = 3 if written < 8 else _ilog2(written >> 3) + 4                       # :1024-1035
+        obs.write_bits(lw - 3, 5)
+        obs.write_bits(written, lw)
+        obs.write_bytes(blob, 0, written)
+    obs.write_bits(0, 5)                                                         # close :489-492
+    obs.write_bits(0, 3)
+    obs.close()
+    return bytes(obs.sink)
+
+
+def _knz_block(block, names, entropy, block_size, static_words):
+    """EncodingTask.encodeBlock :733-985 for one non-empty block -> (bytes, bits written)"""
+    n = len(block)
+    mode = 0
+    if n <= 15:                                                                  # SMALL_BLOCK_SIZE :764-767
+        names, entropy = ["NONE"], "NONE"
+        mode |= 0x80
+    # the block's "dataType" context entry :795-804
+    data_type = "UNDEFINED"
+    if n >= 4:
+        c, m, x = _magic_class(magic_type(block))
+        data_type = "BIN" if c else ("MULTIMEDIA" if m else ("EXE" if x else "UNDEFINED"))
+    # ---- Sequence.forward :56-127 ----
+    skip_flags = 0xFF
+    cur = block
+    tc_variant = 1 if entropy in ("FPAQ", "TPAQ", "TPAQX", "CM") else 2          # TransformFactory.java:275-286
+    for i, name in enumerate(names):
+        if name == "NONE":
+            ok, out = True, cur                                                  # NullTransform copies
+        elif name == "TEXT":
+            ok, out, data_type = text_forward(cur, tc_variant, block_size, text_static_dictionary(static_words), data_type)
+        elif name == "UTF":
+            ok, out, data_type = utf_forward(cur, data_type)
+        elif name == "BWT":
+            ok, out = bwt_block_forward(cur)
+        elif name == "RANK":
+            ok, out = True, sbrt_forward(cur, 2)
+        elif name == "MTFT":
+            ok, out = True, sbrt_forward(cur, 1)
+        elif name == "SRT":
+            ok, out = True, srt_forward(cur)
+        elif name == "ZRLT":
+            ok, out = zrlt_forward(cur)
+        else:
+            raise ValueError(name)
+        if not ok:
+            continue
+        skip_flags &= ~(1 << (7 - i)) & 0xFF
+        cur = out
+    post = len(cur)
+    data_size = 1 if post < 256 else (_ilog2(post) >> 3) + 1                     # :825-826
+    nb_functions = len(names)
+    mode |= ((data_size - 1) & 3) << 5
+
+    def header(os, mode_byte, with_flags):
+        os.write_bits(mode_byte, 8)
+        if with_flags:
+            os.write_bits(skip_flags, 8)
+        os.write_bits(post, 8 * data_size)
+        os.write_bits(0, 8)                                                      # the header checksum byte, patched below
+
+    os = JavaOutputBitStream(16384)
+    header_skip_flags = skip_flags
+    if (mode & 0x80) or nb_functions <= 4:                                       # :866-877
+        mode |= skip_flags >> 4
+        header_skip_flags = 0 if (mode & 0x80) else ((mode << 4) | 0x0F) & 0xFF
+        header(os, mode, False)
+        ck_index = 1 + data_size
+    else:
+        mode |= 0x10
+        header(os, mode, True)
+        ck_index = 2 + data_size
+    # ---- entropy coder on the block's private stream :905-921 ----
+    if entropy == "NONE":
+        os.write_bytes(cur, 0, 8 * post)                                         # NullEntropyEncoder.encode :66-81
+    elif entropy == "ANS0":
+        bits, nbits = ans0_encode(cur)
+        os.write_bytes(bits, 0, nbits)
+    elif entropy == "FPAQ":
+        bits = fpaq_encode(cur)
+        os.write_bytes(bits, 0, 8 * len(bits))
+    else:
+        raise ValueError(entropy)
+    os.close()
+    written = os.written()                                                       # :923, read after close(): availBits = 0 and written -= 64 cancel
+    blob = bytearray(os.sink)
+    if not (mode & 0x80) and post < ((written + 7) >> 3):                        # raw "transformed copy" fallback :926-973
+        copy_mode = mode | 0x80 | 0x10
+        os = JavaOutputBitStream(16384)
+        header(os, copy_mode, nb_functions > 4)
+        if nb_functions > 4:
+            ck_index = 2 + data_size
+            header_skip_flags = skip_flags
+        else:
+            ck_index = 1 + data_size
+            header_skip_flags = ((copy_mode << 4) | 0x0F) & 0xFF
+        os.write_bytes(cur, 0, post << 3)
+        os.close()
+        written = os.written()
+        blob = bytearray(os.sink)
+        mode = copy_mode
+    HASH = 0x1E35A7BD                                                            # :975-985
+    ck = (HASH * 0x01030507) & 0xFFFFFFFF
+    ck = _mix32(ck, HASH, mode & 0xFF)
+    ck = _mix32(ck, HASH, header_skip_flags & 0xFF)
+    ck = _mix32(ck, HASH, post)
+    ck = _mix32(ck, HASH, (written >> 32) & 0xFFFFFFFF)
+    ck = _mix32(ck, HASH, written & 0xFFFFFFFF)
+    ck = (ck >> 23) ^ (ck >> 3)
+    blob[ck_index] = ck & 0xFF
+    return bytes(blob), written

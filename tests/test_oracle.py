@@ -534,3 +534,85 @@ def test_mm_forward_known_answers_from_a_python_model(built):
                 applied += 1
     assert applied >= 8
     assert katmodels.log2_1024(1) == 0 and katmodels.log2_1024(3) == 1623 and katmodels.log2_1024(4096) == 12288
+
+
+def _text_static_words():
+    """DICT_EN_1024 (wire-format data: word indexes in coded blocks refer to it) as the generated header holds it"""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "kzo_text_dict.h")).read()
+    return b"".join(m.group(1).encode() for m in re.finditer(r'^\s*"([^"]*)"', src, re.M))
+
+
+def test_text_codec_known_answers_from_a_python_model(built):
+    """TextCodec1.forward / TextCodec2.forward (TextCodec.java:618-870, 1124-1410) with computeStats / detectType (:269-466), the
+    static dictionary (:205-236), both word-index codings, the escapes, CR+LF mode, XML flag, the dictionary doubling up to 2^19
+    entries and wrapping: a second implementation written from the Java (tests/katmodels.py), since a dictionary coder's output is
+    a sequence of CHOICES (which words enter the dictionary, which slot they evict) that a round trip does not pin."""
+    import katmodels
+    import textgen
+    words = _text_static_words()
+    c = textgen.cases()
+    inputs = [(k, bytes(v)[:160000]) for k, v in c.items()]
+    inputs.append(("many_words_4m", textgen.many_words(4 << 20, 21)))            # > 2^19 dictionary entries: doubles, then wraps
+    inputs.append(("class0", datagen.block(0, 70000, 0).tobytes()))
+    inputs.append(("bulk_english", bytes(textgen.bulk_text(300000, 1001, "english"))))
+    inputs.append(("bulk_xml", bytes(textgen.bulk_text(200000, 1002, "xml"))))
+    applied = 0
+    for name, data in inputs:
+        for variant, ent in ((1, "FPAQ"), (2, "ANS0")):
+            for bs in ((4 << 20,) if len(data) > 200000 else (65536, 4 << 20)):
+                sd = katmodels.text_static_dictionary(words)
+                ok_m, out_m, dt_m = katmodels.text_forward(data, variant, bs, sd)
+                oracle.set_transform_ctx(ent, bs)
+                ok_o, out_o, dt_o = oracle.transform_forward("TEXT", data, data_type=oracle.DT["UNDEFINED"])
+                assert ok_m == ok_o, (name, variant, bs)
+                assert oracle.DT[dt_m] == dt_o, (name, variant, bs, dt_m, dt_o)
+                if ok_o:
+                    assert out_m == out_o, (name, variant, bs, len(out_m), len(out_o))
+                    applied += 1
+    oracle.set_transform_ctx("NONE", 4 << 20)
+    assert applied >= 30
+    # the data type filter (:641-649): everything but UNDEFINED / TEXT / BIN declines without looking
+    eng = bytes(c["english"])[:5000]
+    sd = katmodels.text_static_dictionary(words)
+    for tag in ("MULTIMEDIA", "EXE", "NUMERIC", "BASE64", "DNA", "UTF8", "SMALL_ALPHABET"):
+        assert katmodels.text_forward(eng, 2, 65536, sd, tag)[0] is False
+        assert oracle.transform_forward("TEXT", eng, data_type=oracle.DT[tag])[0] is False
+
+
+def test_knz_streams_equal_a_python_model_of_the_container(built):
+    """Levels 5 and 6 (TEXT+UTF+BWT+RANK+ZRLT & ANS0, TEXT+UTF+BWT+SRT+ZRLT & FPAQ) and the core chain: the oracle's whole .knz equals,
+    byte for byte, the stream of tests/katmodels.knz_stream -- DefaultOutputBitStream.writeBits (:103-222), the stream header and
+    its checksum (CompressedOutputStream.java:236-313), Sequence.forward's skip flags, the block header / mode byte / header
+    checksum / raw "transformed copy" fallback (:861-985), the 5 + lw length prefix and the end marker (:1024-1035, :489-492), with
+    every stage a Python model written from the Java (and a third suffix sorter for the BWT).  A misreading of the bit I/O or the
+    framing would now have to be made twice, independently."""
+    import katmodels
+    import textgen
+    words = _text_static_words()
+    c = textgen.cases()
+    data = (bytes(c["english"][:40000]) + bytes(c["utf8"][:30000]) + bytes(c["random"][:9000]) + bytes(c["english_crlf"][:20000])
+            + datagen.block(2, 12000, 2).tobytes() + bytes(c["xml"][:20000]) + b"tail!")
+    short = data[:2 * 16384 + 5]                                                   # the last block is a copy block (<= 15 bytes)
+    for names, ent in ((["TEXT", "UTF", "BWT", "RANK", "ZRLT"], "ANS0"), (["TEXT", "UTF", "BWT", "SRT", "ZRLT"], "FPAQ"),
+                       (["BWT", "RANK", "ZRLT"], "ANS0"), (["BWT", "MTFT", "ZRLT"], "NONE")):
+        for d, bs in ((data, 16384), (data, 65536), (short, 16384)):
+            want = oracle.compress("+".join(names), ent, bs, d, jobs=1)
+            got = katmodels.knz_stream(d, names, ent, bs, words, len(d))
+            assert got == want, (names, ent, bs, len(d), len(got), len(want))
+    # the bit writer alone: unaligned byte-array writes behind odd bit counts, against a plain big-integer model
+    rng = np.random.default_rng(3)
+    os_ = katmodels.JavaOutputBitStream(64)
+    ref = katmodels._Bits()
+    for _ in range(300):
+        k = int(rng.integers(1, 65))
+        v = int(rng.integers(0, 1 << 63)) & ((1 << k) - 1)
+        os_.write_bits(v, k)
+        ref.write(v, k)
+        if rng.random() < 0.3:
+            nb = int(rng.integers(1, 700))
+            raw = rng.integers(0, 256, (nb + 7) // 8, dtype=np.uint8).tobytes()
+            os_.write_bytes(raw, 0, nb)
+            ref.write(int.from_bytes(raw, "big") >> (8 * len(raw) - nb), nb)
+    os_.close()
+    assert os_.written() == ref.n and bytes(os_.sink) == ref.bytes()
