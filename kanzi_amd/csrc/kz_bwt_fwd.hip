@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(1024) void k_tr_scatter(const u8* __restrict__ srcA
 // one bucket at a time in LDS: sort by the key bits that differ, groups of equal keys, ranks and final suffixes
 #define TRQ_WAVES 16
 #define TRQ_ROWS 8
-__global__ __launch_bounds__(1024, 8) void k_tr_sort(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG, int dbg) {
+__device__ __forceinline__ void tr_sort_body(const u64* __restrict__ elemAll, const BwtArrays& A, const TrieArrays& T, int bitsG, int dbg) {
   const int b = blockIdx.y;
   const int nB = T.meta[(int64_t)b * TR_META + 1];
   __shared__ u64 buf[TR_CAP];
@@ -1385,18 +1385,27 @@ __global__ __launch_bounds__(1024, 8) void k_tr_sort(const u64* __restrict__ ele
     __syncthreads();
   }
 }
+__global__ __launch_bounds__(1024, 8) void k_tr_sort(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG, int dbg) { tr_sort_body(elemAll, A, T, bitsG, dbg); }
+__global__ __launch_bounds__(1024, 4) void k_tr_sort1(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG, int dbg) { tr_sort_body(elemAll, A, T, bitsG, dbg); }
 
 // ---------------------------------------------------------------------------------------------
 // emit: header + BWT bytes (BWTBlockCodec.java:90-126, DivSufSort.java:217-224)
+// XCD-aware mapping: the gather s[sa[j] - 1] hits random lines of the block's text, which fits ONE XCD's L2 (4 MiB) but is evicted
+// when every XCD works on every block.  Workgroup w runs on XCD w % 8 (observed dispatch order, a speed matter only), so the
+// workgroups of a super-group of 8 blocks are dealt out block = w % 8: each XCD gathers from one block's text at a time.
 __global__ void k_bwt_emit(const u8* __restrict__ src, int64_t srcStride, u8* __restrict__ dst, int64_t dstStride,
-                           BwtArrays A, int32_t* d_lenOut, int32_t* d_flag) {
-  const int b = blockIdx.y;
+                           BwtArrays A, int32_t* d_lenOut, int32_t* d_flag, int B) {
+  const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int sg = lin / (8 * (int)gridDim.x), r8 = lin % (8 * (int)gridDim.x);
+  const int b = B < 0 ? (int)blockIdx.y : sg * 8 + (r8 & 7);               // B < 0: plain mapping (a grid of B rounded up to 8 rows would not fit)
+  const int chunk = B < 0 ? (int)blockIdx.x : r8 >> 3;
+  if (B >= 0 && b >= B) return;
   const int n = A.d_n[b];
   const u8* s = src + (int64_t)b * srcStride;
   u8* d = dst + (int64_t)b * dstStride;
   const int64_t off = (int64_t)b * A.NS;
   if (n < 2) {   // n==1: pIndexSize==0 -> BWTBlockCodec declines (BWTBlockCodec.java:95-98); n==0 no-op
-    if (blockIdx.x == 0 && threadIdx.x == 0) { d_flag[b] = 0; d_lenOut[b] = n; if (n == 1) d[0] = s[0]; }
+    if (chunk == 0 && threadIdx.x == 0) { d_flag[b] = 0; d_lenOut[b] = n; if (n == 1) d[0] = s[0]; }
     return;
   }
   int logBlockSize = kz_ilog2((u32)n);
@@ -1407,7 +1416,7 @@ __global__ void k_bwt_emit(const u8* __restrict__ src, int64_t srcStride, u8* __
   const u32* rank = A.rank + off;
   const u32* sa = A.sa + off;
   const int p = (int)rank[0];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (chunk == 0 && threadIdx.x == 0) {
     const int logNbChunks = (chunks == 8) ? 3 : 0;
     d[0] = (u8)((logNbChunks << 2) | (pIndexSize - 1));
     const int st = n / chunks;
@@ -1421,7 +1430,7 @@ __global__ void k_bwt_emit(const u8* __restrict__ src, int64_t srcStride, u8* __
     d_lenOut[b] = hdr + n;
     d_flag[b] = 1;
   }
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+  for (int j = chunk * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
     if (j == p) continue;
     const u32 sv = sa[j];
     const u8 c = s[sv - 1];
@@ -1543,14 +1552,17 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
       KZ_HIP(hipMemsetAsync(TR.err, 0, 4, st));
       KZ_LAUNCH(ctx, KID_TR_HIST16, k_tr_hist16, dim3(2, B), dim3(1024), src, bt.stride, A, TR);
       KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, 1, Dmax);
-      const int P = B >= 2048 ? 1 : (B >= 1024 ? 2 : (B >= 256 ? 4 : 8));
+      const char* ep = getenv("KZ_TR_PARTS");
+      const int P = ep ? std::max(1, atoi(ep)) : (B >= 2048 ? 1 : (B >= 1024 ? 2 : 8));
       for (int L = 2; L < Dmax; L++) {
         KZ_LAUNCH(ctx, KID_TR_COUNT, k_tr_count, dim3(P, B), dim3(1024), src, bt.stride, A.val[0], A, TR, L);
         KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, L, Dmax);
       }
       KZ_LAUNCH(ctx, KID_TR_SCATTER, k_tr_scatter, dim3(gridFor(maxN, TRS_TILE), B), dim3(1024), src, bt.stride, A.val[0], A.key[0], A, TR, bitsG);
       const int G = std::max(16, std::min(1024, 8192 / B));
-      KZ_LAUNCH(ctx, KID_TR_SORT, k_tr_sort, dim3(G, B), dim3(1024), A.key[0], A, TR, bitsG, getenv("KZ_TRQ_DBG") ? atoi(getenv("KZ_TRQ_DBG")) : 0);
+      const int dbgq = getenv("KZ_TRQ_DBG") ? atoi(getenv("KZ_TRQ_DBG")) : 0;
+      if (getenv("KZ_TRQ_OCC1")) KZ_LAUNCH(ctx, KID_TR_SORT, k_tr_sort1, dim3(G, B), dim3(1024), A.key[0], A, TR, bitsG, dbgq);
+      else KZ_LAUNCH(ctx, KID_TR_SORT, k_tr_sort, dim3(G, B), dim3(1024), A.key[0], A, TR, bitsG, dbgq);
       KZ_HIP(hipMemcpyAsync(ctx->hpin + B, TR.err, 4, hipMemcpyDeviceToHost, st));
       wMax = 0;
     } else
@@ -1617,7 +1629,11 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
     int32_t* tm = A.d_m; A.d_m = A.d_m2; A.d_m2 = tm;
   }
   if (mMax > 0) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: suffix sort did not converge"); return -KZ_ERR_PROCESS_BLOCK; }
-  KZ_LAUNCH(ctx, KID_BWT_EMIT, k_bwt_emit, dim3(gridFor(maxN, 256 * 8), B), dim3(256), src, bt.stride, dst, bt.stride, A, bt.d_len2, bt.d_flag);
+  {
+    const int rows8 = (B + 7) / 8 * 8;
+    const bool xcd = rows8 <= KZ_MAX_BATCH;
+    KZ_LAUNCH(ctx, KID_BWT_EMIT, k_bwt_emit, dim3(gridFor(maxN, 256 * 8), xcd ? rows8 : B), dim3(256), src, bt.stride, dst, bt.stride, A, bt.d_len2, bt.d_flag, xcd ? B : -1);
+  }
   KZ_HIP(hipGetLastError());
   bt.cur ^= 1;
   { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }

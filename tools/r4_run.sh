@@ -1,5 +1,1 @@
-mkdir -p gpurun_out/r04g
-timeout 600 python tools/bwt_diag.py quick > gpurun_out/r04g/diag.log 2>&1; tail -2 gpurun_out/r04g/diag.log
-echo "== text"; timeout 300 python tools/chain_probe.py BWT NONE 357 0 2>&1 | grep -E "k_tr_|rep 2" | head -8
-echo "== sparse"; timeout 300 python tools/chain_probe.py BWT NONE 357 4 2>&1 | grep -E "k_tr_|rep 2" | head -8
-echo "== mix"; timeout 300 python tools/chain_probe.py BWT NONE 714 2>&1 | grep -E "k_tr_|rep 2" | head -8
+for c in 3 0; do for v in "" 1; do echo "== class $c OCC1=$v"; env ${v:+KZ_TRQ_OCC1=1} timeout 300 python tools/chain_probe.py BWT NONE 357 $c 2>&1 | grep -E "k_tr_sort|rep 2" | head -3; done; done
