@@ -57,6 +57,8 @@ extern "C" void kz_ctx_destroy(kz_ctx* ctx) {
     if (ctx->pinOut[i].p) hipHostFree(ctx->pinOut[i].p);
     if (ctx->hsIn[i].p) hipHostFree(ctx->hsIn[i].p);
     if (ctx->hsOut[i].p) hipHostFree(ctx->hsOut[i].p);
+    if (ctx->hiAux[i].p) hipFree(ctx->hiAux[i].p);
+    if (ctx->hiStream[i]) hipStreamDestroy(ctx->hiStream[i]);
     if (ctx->devIn[i].p) hipFree(ctx->devIn[i].p);
     if (ctx->devOut[i].p) hipFree(ctx->devOut[i].p);
   }
@@ -563,6 +565,7 @@ struct HostPre {
   std::vector<uint8_t> changed;
   std::unique_ptr<uint8_t[]> own;                   // the slots' memory when the caller gave none
   uint8_t* store = nullptr;
+  bool pinned = false;                              // store is pinned host memory (a kernel can read it: one gather instead of a copy per block)
   int64_t slot = 0;
   const uint8_t* data(int b) const { return store + (int64_t)b * slot; }
 };
@@ -609,7 +612,7 @@ static void host_prestage(const int* types, int hp, int entropy, int blockSize, 
                           const int32_t* lengths, const int32_t* copy, int B, HostPre& P, uint8_t* store = nullptr) {
   P.outLen.assign(B, 0); P.skip.assign(B, 0xFF); P.dtype.assign(B, 0); P.changed.assign(B, 0);
   P.slot = host_pre_slot(cap);
-  if (store) P.store = store;
+  if (store) { P.store = store; P.pinned = true; }
   else { P.own.reset(new uint8_t[(size_t)P.slot * (size_t)B + 64]); P.store = P.own.get(); }   // uninitialised: only the bytes a stage writes are touched
   HostFwd H;
   H.types = types; H.hp = hp; H.entropy = entropy; H.cap = cap; H.blockSize = blockSize;
@@ -638,6 +641,7 @@ struct HostInv {
   int device; const int* types; int hp; int blockSize; int cap;
   uint8_t* dbuf; int64_t dstride; int64_t slotCap; bool hostMem;        // the blocks' slots: in HBM (copied over and back) or in host memory
   int32_t* len; const int32_t* skip; int32_t* status; std::atomic<int> fail{0};
+  uint8_t* pin = nullptr; int64_t pinSlot = 0;                          // staged form: the chunk's blocks were gathered into pinned slots
 };
 static void host_inverse_block(int b, void* arg) {
   HostInv& H = *(HostInv*)arg;
@@ -649,22 +653,71 @@ static void host_inverse_block(int b, void* arg) {
   static thread_local std::vector<uint8_t> bufA, bufB;
   const size_t need = (size_t)std::max(H.cap, len) + 64;
   if (bufA.size() < need) { bufA.resize(need); bufB.resize(need); }
-  uint8_t* slot = H.dbuf + (int64_t)b * H.dstride;
-  if (H.hostMem) memcpy(bufA.data(), slot, (size_t)len);
-  else if (hipSetDevice(H.device) != hipSuccess || hipMemcpy(bufA.data(), slot, (size_t)len, hipMemcpyDeviceToHost) != hipSuccess) { H.fail = 1; return; }
+  uint8_t* slot = H.pin ? H.pin + (int64_t)b * H.pinSlot : H.dbuf + (int64_t)b * H.dstride;
+  const bool hostSlot = H.hostMem || H.pin != nullptr;
   uint8_t* cur = bufA.data();
   uint8_t* out = bufB.data();
+  if (H.pin) { cur = slot; out = bufA.data(); }                         // read the pinned slot in place, first output to a private buffer
+  else if (H.hostMem) memcpy(bufA.data(), slot, (size_t)len);
+  else if (hipSetDevice(H.device) != hipSuccess || hipMemcpy(bufA.data(), slot, (size_t)len, hipMemcpyDeviceToHost) != hipSuccess) { H.fail = 1; return; }
   for (int i = H.hp - 1; i >= 0; i--) {                                 // Sequence.inverse: last applied first
     if (H.skip[b] & (1 << (7 - i))) continue;
     int produced = 0;
     if (!kz_host_transform_inverse(H.types[i], H.blockSize, cur, len, out, H.cap, &produced)) { H.status[b] = -KZ_ERR_PROCESS_BLOCK; H.len[b] = 0; return; }
     len = produced;
-    std::swap(cur, out);
+    if (cur == slot) { cur = out; out = bufB.data(); }                  // (staged form) the slot itself is never an output buffer
+    else std::swap(cur, out);
   }
   if ((int64_t)len > H.slotCap) { H.status[b] = -KZ_ERR_PROCESS_BLOCK; H.len[b] = 0; return; }   // more than a block: "incorrectly decompressed"
-  if (H.hostMem) memcpy(slot, cur, (size_t)len);
+  if (hostSlot) { if (cur != slot) memcpy(slot, cur, (size_t)len); }
   else if (hipMemcpy(slot, cur, (size_t)len, hipMemcpyHostToDevice) != hipSuccess) { H.fail = 1; return; }
   H.len[b] = len;
+}
+// The host inverse stages of one chunk whose blocks live in HBM: ONE gather kernel brings the blocks a host stage applies to into
+// pinned slots (exact lengths), the host pool decodes them there, ONE scatter kernel puts the results back.  Runs on its own stream
+// beside the main stream's next chunk.  (Before: a synchronous D2H and H2D copy per block.)
+struct HostInvSub { HostInv* H; int b0; };
+static void host_inverse_block_sub(int i, void* arg) { HostInvSub& S = *(HostInvSub*)arg; host_inverse_block(S.b0 + i, S.H); }
+static void host_inverse_chunk_staged(kz_ctx* ctx, HostInv* H, int cnt, int ring) {
+  // d_aux: [0, cnt) lengths in, [cnt, 2 cnt) mask in, [2 cnt, 3 cnt) lengths out, [3 cnt, 4 cnt) mask out
+  std::vector<int32_t> hm((size_t)cnt * 4);
+  int any = 0;
+  for (int b = 0; b < cnt; b++) {
+    bool need = !H->status[b] && H->len[b] > 0;
+    if (need) { bool a = false; for (int i = 0; i < H->hp; i++) a |= !(H->skip[b] & (1 << (7 - i))); need = a; }
+    hm[b] = H->len[b]; hm[cnt + b] = need ? 1 : 0; any |= need ? 1 : 0;
+  }
+  if (!any) return;
+  hipStream_t hs = ctx->hiStream[ring];
+  int32_t* d_aux = (int32_t*)ctx->hiAux[ring].p;
+  if (hipSetDevice(ctx->device) != hipSuccess ||
+      hipMemcpyAsync(d_aux, hm.data(), (size_t)cnt * 8, hipMemcpyHostToDevice, hs) != hipSuccess) { H->fail = 1; return; }
+  // sub-chunks: the gather of sub-chunk j + 1 and the scatter of sub-chunk j - 1 run under the host stages of sub-chunk j
+  const int SUB = 64;
+  const int nsub = (cnt + SUB - 1) / SUB;
+  std::vector<hipEvent_t> ev((size_t)nsub, nullptr);
+  auto gather = [&](int j) {
+    const int j0 = j * SUB, c = std::min(SUB, cnt - j0);
+    hipLaunchKernelGGL(k_copy_bytes, dim3(32, c), dim3(256), 0, hs, H->dbuf + (int64_t)j0 * H->dstride, H->dstride, H->pin + (int64_t)j0 * H->pinSlot, H->pinSlot,
+                       d_aux + j0, (const int32_t*)nullptr, d_aux + cnt + j0);
+    if (hipEventCreateWithFlags(&ev[j], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[j], hs) != hipSuccess) H->fail = 1;
+  };
+  gather(0);
+  for (int j = 0; j < nsub && !H->fail; j++) {
+    const int j0 = j * SUB, c = std::min(SUB, cnt - j0);
+    if (j + 1 < nsub) gather(j + 1);
+    if (H->fail || hipEventSynchronize(ev[j]) != hipSuccess) { H->fail = 1; break; }
+    HostInvSub S{H, j0};
+    kz_parallel_for(c, KZ_HOST_STAGE_THREADS, host_inverse_block_sub, &S);
+    if (H->fail) break;
+    for (int b = j0; b < j0 + c; b++) { hm[2 * cnt + b] = H->len[b]; hm[3 * cnt + b] = (hm[cnt + b] && !H->status[b]) ? 1 : 0; }
+    if (hipMemcpyAsync(d_aux + 2 * cnt + j0, hm.data() + 2 * cnt + j0, (size_t)c * 4, hipMemcpyHostToDevice, hs) != hipSuccess ||
+        hipMemcpyAsync(d_aux + 3 * cnt + j0, hm.data() + 3 * cnt + j0, (size_t)c * 4, hipMemcpyHostToDevice, hs) != hipSuccess) { H->fail = 1; break; }
+    hipLaunchKernelGGL(k_copy_bytes, dim3(32, c), dim3(256), 0, hs, H->pin + (int64_t)j0 * H->pinSlot, H->pinSlot, H->dbuf + (int64_t)j0 * H->dstride, H->dstride,
+                       d_aux + 2 * cnt + j0, (const int32_t*)nullptr, d_aux + 3 * cnt + j0);
+  }
+  if (hipStreamSynchronize(hs) != hipSuccess) H->fail = 1;
+  for (auto e : ev) if (e) hipEventDestroy(e);
 }
 
 // ---- decoder: RANK / MTFT inverse and BWT inverse of a large batch, overlapped -------------------------------------------
@@ -952,16 +1005,25 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
     const size_t perBlock = pipeline_scratch(1, maxLen, false, noBwt) + (size_t)maxLen * 2 + 8192 + (size_t)(memKind == KZ_MEM_HOST ? outStride : 0) + (1 << 16);
     const size_t avail = hasBwt ? kz_arena_budget() / 2 : kz_arena_budget();      // the other half: suffix-sort groups
     const int maxB = (int)std::min<size_t>(KZ_MAX_BATCH, std::max<size_t>(1, avail / perBlock));   // grid.y carries the block index
-    if (B > maxB && !pre) {
+    if (B > maxB) {
       for (int b0 = 0; b0 < B; b0 += maxB) {
         const int cnt = std::min(maxB, B - b0);
-        int rc = encode_blocks_bs(ctx, transformType, entropyType, blockSize, in + (int64_t)b0 * inStride, inStride, lengths + b0, cnt,
-                                  out + (int64_t)b0 * outStride, outStride, results + b0, memKind);
+        HostPre view;                                                 // a pre-staged batch is split like any other: every sub-batch sees its
+        if (pre) {                                                    // share of the host stages' results (the slots stay where they are)
+          view.outLen.assign(pre->outLen.begin() + b0, pre->outLen.begin() + b0 + cnt);
+          view.skip.assign(pre->skip.begin() + b0, pre->skip.begin() + b0 + cnt);
+          view.dtype.assign(pre->dtype.begin() + b0, pre->dtype.begin() + b0 + cnt);
+          view.changed.assign(pre->changed.begin() + b0, pre->changed.begin() + b0 + cnt);
+          view.store = pre->store + (int64_t)b0 * pre->slot;
+          view.slot = pre->slot;
+          view.pinned = pre->pinned;
+        }
+        int rc = kz_encode_blocks_pre(ctx, transformType, entropyType, blockSize, in + (int64_t)b0 * inStride, inStride, lengths + b0, cnt,
+                                      out + (int64_t)b0 * outStride, outStride, results + b0, memKind, pre ? &view : nullptr);
         if (rc) return rc;
       }
       return 0;
     }
-    if (B > maxB) { snprintf(ctx->err, sizeof(ctx->err), "encode: a pre-staged batch of %d blocks exceeds the arena budget (%d)", B, maxB); return -KZ_ERR_INVALID_PARAM; }
   }
   // ---- chains led by TEXT / UTF on large batches: the host stages of chunk k+1 run on a helper thread (and the host pool) while
   //      the GPU codes chunk k.  Blocks are independent, so chunking changes nothing in the output.  (With "skipBlocks" the copy
@@ -1087,13 +1149,20 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
     }
     KZ_HIP(kz_stream_sync(ctx, st));                                            // the blocks are in HBM, hashed and tagged: slots may be rewritten
     for (int b = 0; b < B; b++) {
+      h_mask[b] = 0;
       if (h_copy[b]) { bt.h_len[b] = lengths[b]; continue; }                     // (a pre-staged block of <= 15 bytes was left alone as well)
       h_skip[b] = pre->skip[b];
       bt.h_len[b] = pre->outLen[b];
-      if (pre->changed[b] && pre->outLen[b] > 0)
-        KZ_HIP(hipMemcpyAsync(bt.buf[0] + (int64_t)b * bt.stride, pre->data(b), (size_t)pre->outLen[b], hipMemcpyHostToDevice, st));
+      if (pre->changed[b] && pre->outLen[b] > 0) {
+        if (pre->pinned) h_mask[b] = 1;
+        else KZ_HIP(hipMemcpyAsync(bt.buf[0] + (int64_t)b * bt.stride, pre->data(b), (size_t)pre->outLen[b], hipMemcpyHostToDevice, st));
+      }
     }
     KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    if (pre->pinned) {                                                          // the stages' outputs sit in pinned slots: one gather kernel reads them in place
+      KZ_HIP(hipMemcpyAsync(P.d_mask, h_mask.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+      KZ_LAUNCH(ctx, KID_COPY_BYTES, k_copy_bytes, dim3(64, B), dim3(256), pre->store, pre->slot, bt.buf[0], bt.stride, bt.d_len, (const int32_t*)nullptr, P.d_mask);
+    }
     KZ_HIP(hipMemcpyAsync(bt.d_dtype, pre->dtype.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     KZ_HIP(kz_stream_sync(ctx, st));                                            // pageable sources; `mine` is a local
     kz_stage_end(ctx, e0, KZ_STAGE_HOST_FWD, 0);
@@ -1566,13 +1635,29 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
       H->device = ctx->device; H->types = types; H->hp = hp; H->blockSize = blockSize; H->cap = dataCap;
       H->dbuf = out + (int64_t)b0 * outStride; H->dstride = outStride; H->slotCap = outStride; H->hostMem = memKind == KZ_MEM_HOST;
       H->len = lens[k].data(); H->skip = skips[k].data(); H->status = stats[k].data();
-      finishers.emplace_back([H, cnt, k, trace, &ms]() {
+      // KZ_HOST_INV_STAGED=1: the chunk's blocks go through pinned slots with one gather / scatter kernel per sub-chunk instead of a
+      // copy pair per block.  Measured slower on the level-exact bench row (1 200 vs 1 066 ms per 2 048-block decode: the extra
+      // streams' kernels slow the main stream's chunk 217 -> 252 ms and the sub-chunk joins cost the host pool 14 %), so it is opt-in.
+      static const bool stagedOn = getenv("KZ_HOST_INV_STAGED") && getenv("KZ_HOST_INV_STAGED")[0] == '1';
+      const bool staged = stagedOn && memKind != KZ_MEM_HOST;
+      if (staged) {                                                   // ring of two pinned slot sets: chunk k - 2 must be done with its set
+        if (k >= 2 && finishers[k - 2].joinable()) finishers[k - 2].join();
+        const int64_t pslot = (int64_t)kz_align((size_t)std::max<int64_t>(outStride, dataCap) + 64, 64);
+        int r2 = kz_stage_reserve(ctx, ctx->hsIn[k & 1], (size_t)pslot * (size_t)CH + 64, true);
+        if (!r2) r2 = kz_stage_reserve(ctx, ctx->hiAux[k & 1], (size_t)CH * 16 + 64, false);
+        if (!r2 && !ctx->hiStream[k & 1] && hipStreamCreateWithFlags(&ctx->hiStream[k & 1], hipStreamNonBlocking) != hipSuccess) r2 = -KZ_ERR_DEVICE;
+        if (r2) { rc = r2; break; }
+        H->pin = ctx->hsIn[k & 1].p; H->pinSlot = pslot;
+      }
+      kz_ctx* cx = ctx;
+      finishers.emplace_back([H, cnt, k, trace, &ms, staged, cx]() {
         const double t0 = ms();
-        kz_parallel_for(cnt, KZ_HOST_STAGE_THREADS, host_inverse_block, H);
+        if (staged) host_inverse_chunk_staged(cx, H, cnt, k & 1);
+        else kz_parallel_for(cnt, KZ_HOST_STAGE_THREADS, host_inverse_block, H);
         if (trace) fprintf(stderr, "[pipe] decode chunk %d: host inverse stages %.0f .. %.0f ms\n", k, t0, ms());
       });
     }
-    for (auto& t : finishers) t.join();
+    for (auto& t : finishers) if (t.joinable()) t.join();
     if (trace) fprintf(stderr, "[pipe] decode done at %.0f ms\n", ms());
     if (rc) { decode_error_sync(ctx); return rc; }
     for (int k = 0; k < nch; k++) {

@@ -67,6 +67,8 @@ struct kz_ctx {
   Stage devIn[2], devOut[2];       // HBM outside the arena (the arena is reset by every batched call)
   Stage hsIn[2], hsOut[2];         // pinned: the host-stage pipeline's copy of a chunk's blocks / the stages' outputs (kz_api.hip)
   hipStream_t copyUp = nullptr, copyDown = nullptr;
+  Stage hiAux[2];                  // HBM: per-block lengths / masks of the decoder's host-inverse chunks (kz_api.hip)
+  hipStream_t hiStream[2] = {nullptr, nullptr};   // their gather / scatter kernels run beside the main stream's next chunk
   // waits of the context's own thread: 1 = block on an event (hipEventBlockingSync) instead of hipStreamSynchronize's spin loop.
   // Chosen at creation: on when the process is CPU-quota limited (a spinning waiter burns a whole CPU of the quota that the
   // host stages -- or the other ranks of the node -- could use), KZ_BLOCKING_WAITS=0/1 overrides.

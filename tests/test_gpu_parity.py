@@ -1266,3 +1266,29 @@ def test_pipelined_stream_writer_and_staged_reader(ctx, monkeypatch, chain, ent,
     finally:
         ctx.set_checksum(0)
         ctx.set_block_size(4 * 1024 * 1024)
+
+
+def test_prestaged_batches_larger_than_the_arena_are_split(ctx, tmp_path):
+    """kz_compress always pre-stages the host stages of a TEXT / UTF chain per chunk; a chunk larger than the arena budget
+    allows (little free HBM, KZ_ARENA_BUDGET_GB, a large KZ_STREAM_CHUNK) used to fail with ERR_INVALID_PARAM where the plain
+    path splits.  The budget is read once per process, so the small-budget run is a subprocess: 72 blocks of 1 MiB, chunks of
+    64, a 1 GiB budget; its stream must equal this process's."""
+    import subprocess
+    import sys
+    bs = 1 << 20
+    blocks = [bytes(textgen.bulk_text(bs, 2000 + i, ("english", "xml", "utf8")[i % 3])) for i in range(6)]
+    data = b"".join(blocks[i % 6] for i in range(72)) + b"the tail of the stream"
+    src = tmp_path / "in.bin"
+    src.write_bytes(data)
+    chain, ent = kz.level_chain(5)
+    cos = kz.CompressedOutputStream(ctx, chain, ent, bs)
+    cos.write(data)
+    cos.close()
+    prog = ("import os, sys\nsys.path.insert(0, %r)\nimport torch\nimport kanzi_amd as kz\nc = kz.Context(0)\n"
+            "d = open(%r, 'rb').read()\ncos = kz.CompressedOutputStream(c, %r, %r, %d)\ncos.write(d)\ncos.close()\n"
+            "open(%r, 'wb').write(cos.output)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(src), chain, ent, bs, str(tmp_path / "out.knz"))
+    env = dict(os.environ, KZ_ARENA_BUDGET_GB="1", KZ_STREAM_CHUNK="64", GPU_MAX_HW_QUEUES="8")
+    r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert (tmp_path / "out.knz").read_bytes() == cos.output
+    assert kz.CompressedInputStream(ctx, cos.output).read() == data

@@ -1,1 +1,3 @@
-for c in 3 0; do for v in "" 1; do echo "== class $c OCC1=$v"; env ${v:+KZ_TRQ_OCC1=1} timeout 300 python tools/chain_probe.py BWT NONE 357 $c 2>&1 | grep -E "k_tr_sort|rep 2" | head -3; done; done
+mkdir -p gpurun_out/r04j
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -k "level_exact or host_stage_pipeline or prestaged or pipelined_stream or level5 or text_block_size or async_batches" 2>&1 | tail -6
+KZ_TRACE_PIPE=1 timeout 600 python tools/level5_probe.py 2048 > gpurun_out/r04j/level5.log 2>&1; grep -E "rep|decode done|decode chunk . : host" gpurun_out/r04j/level5.log | tail -14
