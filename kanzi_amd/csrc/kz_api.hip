@@ -1638,7 +1638,7 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
       // KZ_HOST_INV_STAGED=1: the chunk's blocks go through pinned slots with one gather / scatter kernel per sub-chunk instead of a
       // copy pair per block.  Measured slower on the level-exact bench row (1 200 vs 1 066 ms per 2 048-block decode: the extra
       // streams' kernels slow the main stream's chunk 217 -> 252 ms and the sub-chunk joins cost the host pool 14 %), so it is opt-in.
-      static const bool stagedOn = getenv("KZ_HOST_INV_STAGED") && getenv("KZ_HOST_INV_STAGED")[0] == '1';
+      const bool stagedOn = getenv("KZ_HOST_INV_STAGED") && getenv("KZ_HOST_INV_STAGED")[0] == '1';
       const bool staged = stagedOn && memKind != KZ_MEM_HOST;
       if (staged) {                                                   // ring of two pinned slot sets: chunk k - 2 must be done with its set
         if (k >= 2 && finishers[k - 2].joinable()) finishers[k - 2].join();

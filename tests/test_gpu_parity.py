@@ -1209,6 +1209,14 @@ def test_host_stage_pipeline_gives_the_same_blocks(ctx, monkeypatch, level):
         for i in range(nb):
             assert res2[i].status == 0 and res3[i].status == 0 and res2[i].length == lens[i] == res3[i].length, i
             assert np.array_equal(dec_h[i, :lens[i]], blocks[i, :lens[i]]) and np.array_equal(dec_d[i, :lens[i]], blocks[i, :lens[i]]), i
+        # the opt-in staged form of the host inverse (pinned slots, one gather / scatter kernel per sub-chunk) gives the same blocks
+        monkeypatch.setenv("KZ_HOST_INV_STAGED", "1")
+        d_dec.zero_()
+        res5 = kz.decode_blocks(ctx, chain, ent, bs, d_out.data_ptr(), ostride, bits, d_dec.data_ptr(), bs, kz.MEM_DEVICE)
+        monkeypatch.delenv("KZ_HOST_INV_STAGED")
+        dec_s = d_dec.cpu().numpy()
+        for i in range(nb):
+            assert res5[i].status == 0 and res5[i].length == lens[i] and np.array_equal(dec_s[i, :lens[i]], blocks[i, :lens[i]]), i
         # a damaged TEXT block in the middle of a chunk fails alone (ERR_PROCESS_BLOCK), its neighbours decode
         if level == 5:
             bad = out_h.copy()

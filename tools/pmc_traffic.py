@@ -37,7 +37,8 @@ def main():
     blocks = int(sys.argv[3])
     chain = sys.argv[4] if len(sys.argv) > 4 else "BWT+RANK+ZRLT"
     entropy = sys.argv[5] if len(sys.argv) > 5 else "ANS0"
-    res = {"blocks_per_gpu_per_step": blocks, "chain": chain, "entropy": entropy, "steps_profiled": 1,
+    res = {"blocks_per_gpu_per_step": blocks, "chain": chain, "entropy": entropy, "steps_profiled": 2,   # bench.py --steps 1 --warmup 0 runs one timed and one instrumented step: every kernel appears twice per step's launches
+           
            "note": "FETCH_SIZE doubled (gfx950 correction), KiB -> bytes; WRITE_SIZE as measured", "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):

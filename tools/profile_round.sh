@@ -9,7 +9,7 @@
 # 4. bench.py defaults with the measured traffic attached                -> bench_default.json
 # Copy the files you want judged to profiles/<tag>_*.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -43,6 +43,9 @@ mv $OUT/pmc_traffic_head.json $OUT/pmc_traffic.json
 # final bench line with the measured traffic attached: bench.py reads profiles/<tag>_pmc_traffic*.json
 mkdir -p profiles
 for f in $OUT/pmc_traffic*.json; do cp $f profiles/${TAG}_$(basename $f); done
-timeout 1200 python bench.py --profiles-tag $TAG > $OUT/bench_default.json 2>> $OUT/bench.err
+timeout 1200 python bench.py --profiles-tag $TAG --detail-json $OUT/bench_kernels.json > $OUT/bench_default.json 2>> $OUT/bench.err
+cp $OUT/bench_kernels.json profiles/${TAG}_bench_kernels.json
+cp $OUT/bench_default.json profiles/${TAG}_bench_default.json
+for f in $OUT/kernel_stats*.csv; do cp $f profiles/${TAG}_$(basename $f); done
 cat $OUT/bench_default.json | cut -c1-600
 head -8 $OUT/kernel_stats.csv | cut -c1-160
