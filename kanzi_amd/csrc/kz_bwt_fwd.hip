@@ -920,6 +920,7 @@ __global__ __launch_bounds__(KZ_WG) void k_live_emit(u64* __restrict__ keyN, u32
 #define TR_K_SMALL 1u
 #define TR_K_EXP 2u
 #define TR_K_TERM 3u
+#define TR_UNCHANGED (1u << 29)     // key rounds, terminal child: the new group keeps the old group's head slot (its members' ranks stay)
 #define TR_META 32               // ints per block: [0] nodes, [1] buckets, [2 + L] first node of depth L, [10 + L] end, [18] error
 #define TR_NODECHUNK 128         // nodes whose counters fit the LDS of k_tr_count
 struct TrieArrays {
@@ -929,6 +930,10 @@ struct TrieArrays {
   u32* bStart;     // [B][MB]
   u32* bCount;     // [B][MB]
   u32* bFill;      // [B][MB] elements placed so far (k_tr_scatter)
+  u32* bAux;       // [B][MB] key rounds: skip >= 3: slot of the bucket's first element (g + bStart - group start); skip < 3: the bucket's prefix bytes
+  u32* bG;         // [B][MB] key rounds, skip >= 3: the old group g all elements of the bucket belong to
+  u32* nodePfx;    // [B][MN] key rounds: the node's prefix bytes (depth < 3) or its old group g (depth >= 3)
+  u32* nodeGS;     // [B][MN] key rounds, depth >= 3: position of the old group's first element in the sorted window
   int32_t* meta;   // [B][TR_META]
   int32_t* err;    // [1] set when a table overflows (cannot happen for blocks the host admits: see tr_max_nodes / tr_max_buckets)
   int MN, MB;
@@ -976,7 +981,7 @@ __global__ __launch_bounds__(1024) void k_tr_hist16(const u8* __restrict__ srcAl
 }
 
 // classify the children of the nodes of depth L (thread = node, its 256 children in order)
-__global__ __launch_bounds__(256) void k_tr_assign(BwtArrays A, TrieArrays T, int L, int Dmax) {
+__global__ __launch_bounds__(256) void k_tr_assign(BwtArrays A, TrieArrays T, int L, int Dmax, int keys) {
   const int b = blockIdx.x;
   int32_t* meta = T.meta + (int64_t)b * TR_META;
   __shared__ u32 sNodes, sBuckets, sErr;
@@ -990,6 +995,11 @@ __global__ __launch_bounds__(256) void k_tr_assign(BwtArrays A, TrieArrays T, in
   u32* nodeStart = T.nodeStart + (int64_t)b * T.MN;
   u32* bStart = T.bStart + (int64_t)b * T.MB;
   u32* bCount = T.bCount + (int64_t)b * T.MB;
+  u32* bAux = T.bAux + (int64_t)b * T.MB;
+  u32* bG = T.bG + (int64_t)b * T.MB;
+  u32* nodePfx = T.nodePfx + (int64_t)b * T.MN;
+  u32* nodeGS = T.nodeGS + (int64_t)b * T.MN;
+  const u32 skipTag = (u32)L << 16;                                      // packed next to a bucket's count (k_tr_sort reads it)
   for (int base = lo; base < hi; base += 256) {                          // uniform
     const int node = base + threadIdx.x;
     const bool valid = node < hi;
@@ -1003,10 +1013,15 @@ __global__ __launch_bounds__(256) void k_tr_assign(BwtArrays A, TrieArrays T, in
       u32 total;
       start = kz_wg_excl_sum(tot, scan, &total);
       nodeStart[node] = start;
+      if (keys) nodePfx[node] = (u32)node;
     } else if (valid) start = nodeStart[node];
     if (!valid) continue;
     u32 run = start, curCnt = 0;
     int curB = -1;
+    // key rounds (see k_trk_*): the first three key bytes are the old group g; a node of depth >= 3 knows g and where g's elements start
+    const u32 pfxN = keys ? nodePfx[node] : 0u;
+    const u32 gsN = (keys && L >= 3) ? nodeGS[node] : 0u;
+    const u32 auxSmall = !keys ? 0u : (L >= 3 ? pfxN - gsN : pfxN);      // skip >= 3: slot = aux + position; skip < 3: the prefix bytes
     for (int c4 = 0; c4 < 256; c4 += 4) {
       const uint4 v4 = *(const uint4*)(cnt + (int64_t)node * 256 + c4);
       const u32 cc4[4] = {v4.x, v4.y, v4.z, v4.w};
@@ -1017,24 +1032,30 @@ __global__ __launch_bounds__(256) void k_tr_assign(BwtArrays A, TrieArrays T, in
         const u32 s0 = run;
         run += cc;
         u32 e;
+        const u32 cbyte = (u32)(c4 + j);
         if (cc > TR_CAP) {
-          if (curB >= 0) { bCount[curB] = curCnt; curB = -1; }
+          if (curB >= 0) { bCount[curB] = curCnt | skipTag; curB = -1; }
           if (L + 1 < Dmax) {
             const u32 M = atomicAdd(&sNodes, 1u);
-            if (M < (u32)T.MN) { nodeStart[M] = s0; e = (TR_K_EXP << 30) | M; }
-            else { sErr = 1; e = (TR_K_TERM << 30) | s0; }
+            if (M < (u32)T.MN) {
+              nodeStart[M] = s0; e = (TR_K_EXP << 30) | M;
+              if (keys) { nodePfx[M] = (L < 3) ? ((pfxN << 8) | cbyte) : pfxN; nodeGS[M] = (L + 1 == 3) ? s0 : gsN; }
+            } else { sErr = 1; e = (TR_K_TERM << 30) | s0; }
+          } else if (keys) {                                              // all key bytes equal: one new group; its head slot = g + (s0 - group start)
+            const u32 head = pfxN + (s0 - gsN);
+            e = (TR_K_TERM << 30) | (s0 == gsN ? TR_UNCHANGED : 0u) | (head & 0xFFFFFFu);
           } else e = (TR_K_TERM << 30) | s0;
         } else if (cc > TR_MERGE) {
-          if (curB >= 0) { bCount[curB] = curCnt; curB = -1; }
+          if (curB >= 0) { bCount[curB] = curCnt | skipTag; curB = -1; }
           const u32 id = atomicAdd(&sBuckets, 1u);
-          if (id < (u32)T.MB) { bStart[id] = s0; bCount[id] = cc; } else sErr = 1;
+          if (id < (u32)T.MB) { bStart[id] = s0; bCount[id] = cc | skipTag; bAux[id] = (keys && L >= 3) ? auxSmall + s0 : auxSmall; bG[id] = pfxN; } else sErr = 1;
           e = (TR_K_SMALL << 30) | ((u32)L << 16) | (id & 0xFFFFu);
         } else {
           if (curB >= 0 && curCnt + cc <= TR_CAP) curCnt += cc;
           else {
-            if (curB >= 0) bCount[curB] = curCnt;
+            if (curB >= 0) bCount[curB] = curCnt | skipTag;
             const u32 id = atomicAdd(&sBuckets, 1u);
-            if (id < (u32)T.MB) { bStart[id] = s0; curB = (int)id; } else { sErr = 1; curB = -1; }
+            if (id < (u32)T.MB) { bStart[id] = s0; curB = (int)id; bAux[id] = (keys && L >= 3) ? auxSmall + s0 : auxSmall; bG[id] = pfxN; } else { sErr = 1; curB = -1; }
             curCnt = cc;
           }
           e = (TR_K_SMALL << 30) | ((u32)L << 16) | ((u32)curB & 0xFFFFu);
@@ -1042,7 +1063,7 @@ __global__ __launch_bounds__(256) void k_tr_assign(BwtArrays A, TrieArrays T, in
         info[(int64_t)node * 256 + c4 + j] = e;
       }
     }
-    if (curB >= 0) bCount[curB] = curCnt;
+    if (curB >= 0) bCount[curB] = curCnt | skipTag;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1234,13 +1255,14 @@ __global__ __launch_bounds__(1024) void k_tr_scatter(const u8* __restrict__ srcA
 // one bucket at a time in LDS: sort by the key bits that differ, groups of equal keys, ranks and final suffixes
 #define TRQ_WAVES 16
 #define TRQ_ROWS 8
+template <bool KEYS>
 __device__ __forceinline__ void tr_sort_body(const u64* __restrict__ elemAll, const BwtArrays& A, const TrieArrays& T, int bitsG, int dbg) {
   const int b = blockIdx.y;
   const int nB = T.meta[(int64_t)b * TR_META + 1];
   __shared__ u64 buf[TR_CAP];
   __shared__ uint16_t cw[TRQ_WAVES][BK_DBINS];
   __shared__ u32 wsum[BK_DBINS / 64];
-  __shared__ u32 wH[TRQ_WAVES];
+  __shared__ u32 wH[TRQ_WAVES], wS[TRQ_WAVES];
   __shared__ u64 redO[TRQ_WAVES], redA[TRQ_WAVES];
   __shared__ int skip[8];
   const int wave = threadIdx.x >> 6, lane = kz_lane();
@@ -1252,8 +1274,12 @@ __device__ __forceinline__ void tr_sort_body(const u64* __restrict__ elemAll, co
   const uint64_t le = lt | (1ULL << lane);
   const u64 vmask = (1ULL << bitsG) - 1ULL;
   for (int d = blockIdx.x; d < nB; d += gridDim.x) {
-    const int cnt = (int)T.bCount[(int64_t)b * T.MB + d];
+    const u32 bcs = T.bCount[(int64_t)b * T.MB + d];
+    const int cnt = (int)(bcs & 0xFFFFu);
+    const int skipB = (int)(bcs >> 16);                                  // bytes of common prefix in front of the bucket's key fragment
     const u32 bo = T.bStart[(int64_t)b * T.MB + d];
+    const u32 aux = KEYS ? T.bAux[(int64_t)b * T.MB + d] : 0u;
+    const u32 gOne = KEYS ? T.bG[(int64_t)b * T.MB + d] : 0u;
     const int rows = (cnt + 63) >> 6;
     const int R = (rows + TRQ_WAVES - 1) / TRQ_WAVES;                    // rows per wave, 1..TRQ_ROWS (uniform)
     const int base = wave * R * 64;
@@ -1346,21 +1372,30 @@ __device__ __forceinline__ void tr_sort_body(const u64* __restrict__ elemAll, co
       }
     }
     __syncthreads();
-    u32 mh = 0;
+    // groups of equal keys; key rounds with skip < 3 also need the OLD groups (the first 3 - skip key bytes): an element's slot
+    // is g + its index inside its old group, a new group's rank g + the index of its first element inside the old group
+    const bool segs = KEYS && skipB < 3;
+    const int gsh = 64 - 8 * (3 - skipB);                                 // element >> gsh = the bytes of g the fragment holds
+    u32 mh = 0, ms = 0;
 #pragma unroll
     for (int r = 0; r < TRQ_ROWS; r++) {
       if (r < R) {
         const int idx = base + r * 64 + lane;
         const bool valid = idx < cnt;
         const u64 prev = (valid && idx > 0) ? buf[idx - 1] : 0;
-        const uint64_t hbr = kz_ballot(valid && (idx == 0 || (k[r] >> bitsG) != (prev >> bitsG)));
+        const bool head = valid && (idx == 0 || (k[r] >> bitsG) != (prev >> bitsG));
+        const uint64_t hbr = kz_ballot(head);
         if (hbr) mh = (u32)(base + r * 64 + 63 - (int)__builtin_clzll(hbr)) + 1;
+        if (segs) {
+          const uint64_t sbr = kz_ballot(head && (idx == 0 || (k[r] >> gsh) != (prev >> gsh)));
+          if (sbr) ms = (u32)(base + r * 64 + 63 - (int)__builtin_clzll(sbr)) + 1;
+        }
       }
     }
-    if (lane == 0) wH[wave] = mh;
+    if (lane == 0) { wH[wave] = mh; wS[wave] = ms; }
     __syncthreads();
-    u32 carH = 0;
-    for (int w = 0; w < wave; w++) carH = max(carH, wH[w]);
+    u32 carH = 0, carS = 0;
+    for (int w = 0; w < wave; w++) { carH = max(carH, wH[w]); carS = max(carS, wS[w]); }
 #pragma unroll
     for (int r = 0; r < TRQ_ROWS; r++) {
       if (r < R) {
@@ -1368,25 +1403,238 @@ __device__ __forceinline__ void tr_sort_body(const u64* __restrict__ elemAll, co
         const int idx = rowBase + lane;
         const bool valid = idx < cnt;
         const u64 prev = (valid && idx > 0) ? buf[idx - 1] : 0;
-        const uint64_t hbr = kz_ballot(valid && (idx == 0 || (k[r] >> bitsG) != (prev >> bitsG)));
+        const bool head = valid && (idx == 0 || (k[r] >> bitsG) != (prev >> bitsG));
+        const uint64_t hbr = kz_ballot(head);
         const uint64_t hbl = hbr & le;
         const u32 hh = hbl ? (u32)(rowBase + 63 - (int)__builtin_clzll(hbl)) : carH - 1;
+        uint64_t sbr = 0;
+        u32 ss = 0;
+        if (segs) {
+          sbr = kz_ballot(head && (idx == 0 || (k[r] >> gsh) != (prev >> gsh)));
+          const uint64_t sbl = sbr & le;
+          ss = sbl ? (u32)(rowBase + 63 - (int)__builtin_clzll(sbl)) : carS - 1;
+        }
         if (valid) {
           const u64 nextk = (idx + 1 < cnt) ? buf[idx + 1] : 0;
           const bool headN = (idx + 1 >= cnt) || ((nextk >> bitsG) != (k[r] >> bitsG));
           const bool live = !(hh == (u32)idx && headN);
           const u32 sv = (u32)(k[r] & vmask);
-          if (!(dbg & 2)) rank[sv] = (bo + hh) | (live ? BW_LIVE : 0u);
-          if (!live && !(dbg & 4)) sa[bo + (u32)idx] = sv;
+          if (!KEYS) {
+            if (!(dbg & 2)) rank[sv] = (bo + hh) | (live ? BW_LIVE : 0u);
+            if (!live && !(dbg & 4)) sa[bo + (u32)idx] = sv;
+          } else {
+            u32 g, headSlot, slot;
+            if (segs) {
+              g = (aux << (8 * (3 - skipB))) | (u32)(k[r] >> gsh);
+              headSlot = g + (hh - ss); slot = g + ((u32)idx - ss);
+            } else { g = gOne; headSlot = aux + hh; slot = aux + (u32)idx; }
+            // the first new group of an old group keeps the old head slot: while it stays LIVE its members' ranks do not change
+            if (!(live && headSlot == g)) rank[sv] = headSlot | (live ? BW_LIVE : 0u);
+            if (!live) sa[slot] = sv;
+          }
         }
         if (hbr) carH = (u32)(rowBase + 63 - (int)__builtin_clzll(hbr)) + 1;
+        if (sbr) carS = (u32)(rowBase + 63 - (int)__builtin_clzll(sbr)) + 1;
       }
     }
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(1024, 8) void k_tr_sort(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG, int dbg) { tr_sort_body(elemAll, A, T, bitsG, dbg); }
-__global__ __launch_bounds__(1024, 4) void k_tr_sort1(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG, int dbg) { tr_sort_body(elemAll, A, T, bitsG, dbg); }
+__global__ __launch_bounds__(1024, 8) void k_tr_sort(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG, int dbg) { tr_sort_body<false>(elemAll, A, T, bitsG, dbg); }
+__global__ __launch_bounds__(1024, 4) void k_tr_sort1(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG, int dbg) { tr_sort_body<false>(elemAll, A, T, bitsG, dbg); }
+__global__ __launch_bounds__(1024, 8) void k_trk_sort(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) { tr_sort_body<true>(elemAll, A, T, bitsG, 0); }
+
+// ---------------------------------------------------------------------------------------------
+// KEY rounds: the same trie round over the WINDOW of a doubling round -- the compact pairs (old group g << bitsR | secondary key r2,
+// suffix) of the buckets too large for the LDS kernels (groups of many thousand suffixes: six full LSD passes over HBM and the
+// k_seg_* kernels until round 3).  The digits are the six bytes of K48 = g : 24 | r2 : 24; the first three bytes are the old
+// group, so a child of depth 3 IS an old group and its start in the sorted window is where the group's elements begin: an
+// element at sorted position pos of group g takes slot g + (pos - group start).  A child that is still large after all six
+// bytes holds equal keys only: one new group, no sorting (terminal).  Buckets of merged small siblings above depth 3 hold whole
+// old groups (k_trk_sort finds their boundaries in the sorted fragment), buckets below depth 3 lie inside one group.
+struct KeySrc { const u64* key; const u32* val; int bitsR; };
+__device__ __forceinline__ u64 trk_k48(u64 key, int bitsR) { return ((key >> bitsR) << 24) | (key & ((1ULL << bitsR) - 1ULL)); }
+
+__global__ __launch_bounds__(1024) void k_trk_hist16(KeySrc X, BwtArrays A, TrieArrays T) {
+  const int b = blockIdx.y;
+  const int w0 = A.d_w[b];
+  const int W = A.d_m[b] - w0;
+  if (W <= 0) return;
+  const u32 half = blockIdx.x;
+  __shared__ u32 hist[32768];
+  for (int i = threadIdx.x; i < 32768; i += 1024) hist[i] = 0;
+  __syncthreads();
+  const u64* key = X.key + (int64_t)b * A.NS + w0;
+  const int lane = kz_lane();
+  for (int j0 = 0; j0 < W; j0 += 1024) {
+    const int j = j0 + threadIdx.x;
+    u32 tgt = 0xFFFFFFFFu;
+    if (j < W) {
+      const u32 pair = (u32)(trk_k48(key[j], X.bitsR) >> 32);
+      if ((pair >> 15) == half) tgt = pair & 32767u;
+    }
+    const uint64_t am = kz_ballot(tgt != 0xFFFFFFFFu);                   // the window is grouped by bucket: most rows hit one counter
+    if (am) {
+      const int l0 = (int)__builtin_ctzll(am);
+      const u32 t0 = (u32)__shfl((int)tgt, l0, 64);
+      const uint64_t same = kz_ballot(tgt == t0);
+      if (lane == l0) atomicAdd(&hist[t0], (u32)__popcll(same));
+      else if (tgt != 0xFFFFFFFFu && tgt != t0) atomicAdd(&hist[tgt], 1u);
+    }
+  }
+  __syncthreads();
+  u32* out = T.cnt + (int64_t)b * T.MN * 256 + half * 32768;
+  for (int i = threadIdx.x; i < 32768; i += 1024) out[i] = hist[i];
+}
+
+__global__ __launch_bounds__(1024) void k_trk_count(KeySrc X, u32* __restrict__ stateAll, BwtArrays A, TrieArrays T, int L) {
+  const int b = blockIdx.y;
+  const int32_t* meta = T.meta + (int64_t)b * TR_META;
+  const int lo = meta[2 + L], hi = meta[10 + L];
+  if (hi <= lo) return;
+  const int w0 = A.d_w[b];
+  const int W = A.d_m[b] - w0;
+  __shared__ u32 lds[TR_NODECHUNK * 256];
+  const u64* key = X.key + (int64_t)b * A.NS + w0;
+  u32* state = stateAll + (int64_t)b * A.NS;
+  const u32* info = T.info + (int64_t)b * T.MN * 256;
+  u32* cnt = T.cnt + (int64_t)b * T.MN * 256;
+  const int P = gridDim.x;
+  const int per = (((W + P - 1) / P) + 1023) & ~1023;
+  const int pbeg = blockIdx.x * per, pend = min(W, pbeg + per);
+  const int lane = kz_lane();
+  for (int chunk = 0; lo + chunk * TR_NODECHUNK < hi; chunk++) {
+    for (int i = threadIdx.x; i < TR_NODECHUNK * 256; i += 1024) lds[i] = 0;
+    __syncthreads();
+    const int nlo = lo + chunk * TR_NODECHUNK;
+    for (int i0 = pbeg; i0 < pend; i0 += 2 * 1024) {                       // two items per thread in flight
+      u32 tg[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int i = i0 + u * 1024 + threadIdx.x;
+        tg[u] = 0xFFFFFFFFu;
+        if (i < pend) {
+          const u64 k48 = trk_k48(key[i], X.bitsR);
+          u32 st = (L == 2 && chunk == 0) ? ((1u << 16) | (u32)(k48 >> 40)) : state[i];
+          if ((st >> 30) == 0) {
+            if (((st >> 16) & 7u) != (u32)L) {
+              const u32 e = info[(st & 0xFFFFu) * 256 + (u32)((k48 >> (40 - 8 * (L - 1))) & 0xFFu)];
+              st = ((e >> 30) == TR_K_EXP) ? ((e & 0xFFFFu) | ((u32)L << 16)) : e;
+              state[i] = st;
+            }
+            if ((st >> 30) == 0) {
+              const int k = (int)(st & 0xFFFFu) - nlo;
+              if (k >= 0 && k < TR_NODECHUNK) tg[u] = (u32)k * 256 + (u32)((k48 >> (40 - 8 * L)) & 0xFFu);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const u32 tgt = tg[u];
+        const uint64_t am = kz_ballot(tgt != 0xFFFFFFFFu);
+        if (am) {
+          const int l0 = (int)__builtin_ctzll(am);
+          const u32 t0 = (u32)__shfl((int)tgt, l0, 64);
+          const uint64_t same = kz_ballot(tgt == t0);
+          if (lane == l0) atomicAdd(&lds[t0], (u32)__popcll(same));
+          else if (tgt != 0xFFFFFFFFu && tgt != t0) atomicAdd(&lds[tgt], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < TR_NODECHUNK * 256; j += 1024) {
+      const u32 v = lds[j];
+      if (v && nlo + (j >> 8) < hi) atomicAdd(&cnt[(int64_t)(nlo + (j >> 8)) * 256 + (j & 255)], v);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_trk_scatter(KeySrc X, const u32* __restrict__ stateAll, u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) {
+  const int b = blockIdx.y;
+  const int w0 = A.d_w[b];
+  const int W = A.d_m[b] - w0;
+  const int tbase = blockIdx.x * TRS_TILE;
+  if (tbase >= W) return;
+  __shared__ u32 tc2[TR_MAXB / 2];
+  __shared__ u32 gdelta[TR_MAXB];
+  __shared__ u64 stage[TRS_TILE];
+  __shared__ uint16_t stageB[TRS_TILE];
+  __shared__ u32 scan[32];
+  const int32_t* meta = T.meta + (int64_t)b * TR_META;
+  const int nB = meta[1];
+  const bool hasState = meta[10 + 2] > meta[2 + 2];
+  for (int i = threadIdx.x; i < (nB + 1) / 2; i += 1024) tc2[i] = 0;
+  __syncthreads();
+  const u64* key = X.key + (int64_t)b * A.NS + w0;
+  const u32* val = X.val + (int64_t)b * A.NS + w0;
+  const u32* state = stateAll + (int64_t)b * A.NS;
+  const u32* info = T.info + (int64_t)b * T.MN * 256;
+  u32* rank = A.rank + (int64_t)b * A.NS;
+  const u64 lowMask = (1ULL << bitsG) - 1ULL;
+  u64 el[TRS_ITEMS]; u32 bp[TRS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < TRS_ITEMS; r++) {
+    const int i = tbase + r * 1024 + threadIdx.x;
+    bp[r] = 0xFFFFFFFFu;
+    el[r] = 0;
+    if (i < W) {
+      const u64 k48 = trk_k48(key[i], X.bitsR);
+      const u32 sv = val[i];
+      u32 st = hasState ? state[i] : ((1u << 16) | (u32)(k48 >> 40));
+      if ((st >> 30) == 0) st = info[(st & 0xFFFFu) * 256 + (u32)((k48 >> (40 - 8 * (int)((st >> 16) & 7u))) & 0xFFu)];
+      if ((st >> 30) == TR_K_TERM) {                                       // a new group of equal keys: its members' ranks, nothing to sort
+        if (!(st & TR_UNCHANGED)) rank[sv] = (st & 0xFFFFFFu) | BW_LIVE;
+      } else {
+        const u32 bk = st & 0xFFFFu;
+        const int skip = (int)((st >> 16) & 7u);
+        el[r] = (((k48 << 16) << (8 * skip)) & ~lowMask) | (u64)sv;
+        const u32 old = atomicAdd(&tc2[bk >> 1], (bk & 1u) ? 65536u : 1u);
+        bp[r] = bk | (((bk & 1u) ? (old >> 16) : (old & 0xFFFFu)) << 16);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int per = 2 * ((nB + 2047) / 2048);
+    const int j0 = threadIdx.x * per;
+    u32 mine = 0;
+    for (int j = j0; j < j0 + per && j < nB; j += 2) { const u32 w = tc2[j >> 1]; mine += (w & 0xFFFFu) + (w >> 16); }
+    u32 total;
+    u32 run = kz_wg_excl_sum(mine, scan, &total);
+    const u32* bStart = T.bStart + (int64_t)b * T.MB;
+    u32* bFill = T.bFill + (int64_t)b * T.MB;
+    for (int j = j0; j < j0 + per && j < nB; j += 2) {
+      const u32 w = tc2[j >> 1];
+      const u32 c0 = w & 0xFFFFu, c1 = w >> 16;
+      if (c0) gdelta[j] = bStart[j] + atomicAdd(&bFill[j], c0) - run;
+      const u32 r1 = run + c0;
+      if (c1) gdelta[j + 1] = bStart[j + 1] + atomicAdd(&bFill[j + 1], c1) - r1;
+      tc2[j >> 1] = run | (r1 << 16);
+      run = r1 + c1;
+    }
+    if (threadIdx.x == 0) scan[31] = total;
+  }
+  __syncthreads();
+  const u32 total = scan[31];
+#pragma unroll
+  for (int r = 0; r < TRS_ITEMS; r++) {
+    if (bp[r] != 0xFFFFFFFFu) {
+      const u32 bk = bp[r] & 0xFFFFu;
+      const u32 w = tc2[bk >> 1];
+      const u32 slot = ((bk & 1u) ? (w >> 16) : (w & 0xFFFFu)) + (bp[r] >> 16);
+      stage[slot] = el[r]; stageB[slot] = (uint16_t)bk;
+    }
+  }
+  __syncthreads();
+  u64* elem = elemAll + (int64_t)b * A.NS;
+#pragma unroll
+  for (int r = 0; r < TRS_ITEMS; r++) {
+    const u32 slot = (u32)r * 1024 + threadIdx.x;
+    if (slot < total) elem[gdelta[stageB[slot]] + slot] = stage[slot];
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // emit: header + BWT bytes (BWTBlockCodec.java:90-126, DivSufSort.java:217-224)
@@ -1461,7 +1709,7 @@ size_t kz_bwt_forward_scratch(int B, int maxN) {
   const int64_t NS = (int64_t)kz_align((size_t)maxN, RS_TILE);
   const int T = (int)(NS / RS_TILE);
   size_t per = (size_t)NS * (8 * 2 + 4 * 2 + 4 + 4) + (size_t)(T + 4) * (256 * 4 + 12) + 2 * MSD_BINS * 4 + 64 + 11 * 256;
-  if (tr_applies(maxN)) per += (size_t)tr_max_nodes(maxN) * (2 * 1024 + 4) + (size_t)TR_MAXB * 12 + TR_META * 4 + 5 * 256;
+  if (tr_applies(maxN)) per += (size_t)tr_max_nodes(maxN) * (2 * 1024 + 12) + (size_t)TR_MAXB * 20 + TR_META * 4 + 9 * 256;
   return kz_align(per * (size_t)B + 4096 * 16, 4096) + (1 << 20);
 }
 
@@ -1503,9 +1751,13 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
     TR.bStart = (u32*)kz_arena_alloc(ctx, (size_t)B * TR.MB * 4);
     TR.bCount = (u32*)kz_arena_alloc(ctx, (size_t)B * TR.MB * 4);
     TR.bFill = (u32*)kz_arena_alloc(ctx, (size_t)B * TR.MB * 4);
+    TR.bAux = (u32*)kz_arena_alloc(ctx, (size_t)B * TR.MB * 4);
+    TR.bG = (u32*)kz_arena_alloc(ctx, (size_t)B * TR.MB * 4);
+    TR.nodePfx = (u32*)kz_arena_alloc(ctx, (size_t)B * TR.MN * 4);
+    TR.nodeGS = (u32*)kz_arena_alloc(ctx, (size_t)B * TR.MN * 4);
     TR.meta = (int32_t*)kz_arena_alloc(ctx, (size_t)B * TR_META * 4);
     TR.err = (int32_t*)kz_arena_alloc(ctx, 256);
-    if (!TR.cnt || !TR.info || !TR.nodeStart || !TR.bStart || !TR.bCount || !TR.bFill || !TR.meta || !TR.err) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: arena overflow (trie tables)"); return -KZ_ERR_DEVICE; }
+    if (!TR.cnt || !TR.info || !TR.nodeStart || !TR.bStart || !TR.bCount || !TR.bFill || !TR.bAux || !TR.bG || !TR.nodePfx || !TR.nodeGS || !TR.meta || !TR.err) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: arena overflow (trie tables)"); return -KZ_ERR_DEVICE; }
   }
   A.d_n = bt.d_len;
   hipStream_t st = ctx->stream;
@@ -1551,12 +1803,12 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
       KZ_HIP(hipMemsetAsync(TR.meta, 0, (size_t)B * TR_META * 4, st));
       KZ_HIP(hipMemsetAsync(TR.err, 0, 4, st));
       KZ_LAUNCH(ctx, KID_TR_HIST16, k_tr_hist16, dim3(2, B), dim3(1024), src, bt.stride, A, TR);
-      KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, 1, Dmax);
+      KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, 1, Dmax, 0);
       const char* ep = getenv("KZ_TR_PARTS");
       const int P = ep ? std::max(1, atoi(ep)) : (B >= 2048 ? 1 : (B >= 1024 ? 2 : 8));
       for (int L = 2; L < Dmax; L++) {
         KZ_LAUNCH(ctx, KID_TR_COUNT, k_tr_count, dim3(P, B), dim3(1024), src, bt.stride, A.val[0], A, TR, L);
-        KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, L, Dmax);
+        KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, L, Dmax, 0);
       }
       KZ_LAUNCH(ctx, KID_TR_SCATTER, k_tr_scatter, dim3(gridFor(maxN, TRS_TILE), B), dim3(1024), src, bt.stride, A.val[0], A.key[0], A, TR, bitsG);
       const int G = std::max(16, std::min(1024, 8192 / B));
@@ -1589,6 +1841,24 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
       KZ_HIP(hipMemsetAsync(A.d_w, 0, (size_t)B * 4, st));
       windowed = false;
     }
+    const bool trieWindow = useTrie && buckets && wMax > 0 && bitsR <= 24 && bitsG <= 24 && !(getenv("KZ_BWT_TRIEWIN") && getenv("KZ_BWT_TRIEWIN")[0] == '0');
+    if (trieWindow) {
+      // ---- the window of oversized buckets through a KEY trie round (k_trk_*): count by key byte, move once, finish in LDS ----
+      const KeySrc XK = {kC, vC, bitsR};
+      KZ_HIP(hipMemsetAsync(TR.cnt, 0, (size_t)B * TR.MN * 1024, st));
+      KZ_HIP(hipMemsetAsync(TR.bFill, 0, (size_t)B * TR.MB * 4, st));
+      KZ_HIP(hipMemsetAsync(TR.meta, 0, (size_t)B * TR_META * 4, st));
+      KZ_LAUNCH(ctx, KID_TR_HIST16, k_trk_hist16, dim3(2, B), dim3(1024), XK, A, TR);
+      KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, 1, 6, 1);
+      const int PW = B >= 1024 ? 1 : (B >= 256 ? 2 : 4);
+      for (int L = 2; L < 6; L++) {
+        KZ_LAUNCH(ctx, KID_TR_COUNT, k_trk_count, dim3(PW, B), dim3(1024), XK, vF, A, TR, L);
+        KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, L, 6, 1);
+      }
+      KZ_LAUNCH(ctx, KID_TR_SCATTER, k_trk_scatter, dim3(gridFor(wMax, TRS_TILE), B), dim3(1024), XK, vF, kF, A, TR, bitsG);
+      const int G = std::max(16, std::min(1024, 8192 / B));
+      KZ_LAUNCH(ctx, KID_TR_SORT, k_trk_sort, dim3(G, B), dim3(1024), kF, A, TR, bitsG);
+    } else
     if (wMax > 0) {
       const int tiles = gridFor(wMax, RS_TILE);
       const int rtiles = gridFor(wMax, RSORT_TILE);
