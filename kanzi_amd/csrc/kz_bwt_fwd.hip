@@ -1507,40 +1507,46 @@ __global__ __launch_bounds__(1024) void k_trk_count(KeySrc X, u32* __restrict__ 
     for (int i = threadIdx.x; i < TR_NODECHUNK * 256; i += 1024) lds[i] = 0;
     __syncthreads();
     const int nlo = lo + chunk * TR_NODECHUNK;
-    for (int i0 = pbeg; i0 < pend; i0 += 2 * 1024) {                       // two items per thread in flight
-      u32 tg[2];
+    // a thread takes four CONSECUTIVE items (two 16-byte key loads, one 16-byte state access); equal targets in a row are added once
+    for (int i0 = pbeg; i0 < pend; i0 += 4096) {
+      const int i = i0 + threadIdx.x * 4;
+      if (i >= pend) continue;
+      u64 kq[4]; u32 stq[4];
+      if (i + 4 <= pend && ((((uintptr_t)(key + i)) & 15) == 0)) {
+        const uint4 a = *(const uint4*)(key + i), c = *(const uint4*)(key + i + 2);
+        kq[0] = ((u64)a.y << 32) | a.x; kq[1] = ((u64)a.w << 32) | a.z; kq[2] = ((u64)c.y << 32) | c.x; kq[3] = ((u64)c.w << 32) | c.z;
+      } else {
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const int i = i0 + u * 1024 + threadIdx.x;
-        tg[u] = 0xFFFFFFFFu;
-        if (i < pend) {
-          const u64 k48 = trk_k48(key[i], X.bitsR);
-          u32 st = (L == 2 && chunk == 0) ? ((1u << 16) | (u32)(k48 >> 40)) : state[i];
-          if ((st >> 30) == 0) {
-            if (((st >> 16) & 7u) != (u32)L) {
-              const u32 e = info[(st & 0xFFFFu) * 256 + (u32)((k48 >> (40 - 8 * (L - 1))) & 0xFFu)];
-              st = ((e >> 30) == TR_K_EXP) ? ((e & 0xFFFFu) | ((u32)L << 16)) : e;
-              state[i] = st;
-            }
-            if ((st >> 30) == 0) {
-              const int k = (int)(st & 0xFFFFu) - nlo;
-              if (k >= 0 && k < TR_NODECHUNK) tg[u] = (u32)k * 256 + (u32)((k48 >> (40 - 8 * L)) & 0xFFu);
-            }
+        for (int q = 0; q < 4; q++) kq[q] = (i + q < pend) ? key[i + q] : 0ULL;
+      }
+      if (L == 2 && chunk == 0) { stq[0] = stq[1] = stq[2] = stq[3] = 0; }
+      else { const uint4 sv = *(const uint4*)(state + i); stq[0] = sv.x; stq[1] = sv.y; stq[2] = sv.z; stq[3] = sv.w; }
+      u32 e[4]; bool look[4]; u64 k48[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        k48[q] = trk_k48(kq[q], X.bitsR);
+        if (L == 2 && chunk == 0) stq[q] = (i + q < pend) ? ((1u << 16) | (u32)(k48[q] >> 40)) : 0xC0000000u;
+        look[q] = (i + q < pend) && (stq[q] >> 30) == 0 && ((stq[q] >> 16) & 7u) != (u32)L;
+        e[q] = 0;
+        if (look[q]) e[q] = info[(stq[q] & 0xFFFFu) * 256 + (u32)((k48[q] >> (40 - 8 * (L - 1))) & 0xFFu)];
+      }
+      bool changed = false;
+      u32 runT = 0xFFFFFFFFu, runC = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        u32 tgt = 0xFFFFFFFFu;
+        if ((i + q < pend) && (stq[q] >> 30) == 0) {
+          if (look[q]) { stq[q] = ((e[q] >> 30) == TR_K_EXP) ? ((e[q] & 0xFFFFu) | ((u32)L << 16)) : e[q]; changed = true; }
+          if ((stq[q] >> 30) == 0) {
+            const int k = (int)(stq[q] & 0xFFFFu) - nlo;
+            if (k >= 0 && k < TR_NODECHUNK) tgt = (u32)k * 256 + (u32)((k48[q] >> (40 - 8 * L)) & 0xFFu);
           }
         }
+        if (tgt == runT) runC++;
+        else { if (runC && runT != 0xFFFFFFFFu) atomicAdd(&lds[runT], runC); runT = tgt; runC = 1; }
       }
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const u32 tgt = tg[u];
-        const uint64_t am = kz_ballot(tgt != 0xFFFFFFFFu);
-        if (am) {
-          const int l0 = (int)__builtin_ctzll(am);
-          const u32 t0 = (u32)__shfl((int)tgt, l0, 64);
-          const uint64_t same = kz_ballot(tgt == t0);
-          if (lane == l0) atomicAdd(&lds[t0], (u32)__popcll(same));
-          else if (tgt != 0xFFFFFFFFu && tgt != t0) atomicAdd(&lds[tgt], 1u);
-        }
-      }
+      if (runC && runT != 0xFFFFFFFFu) atomicAdd(&lds[runT], runC);
+      if (changed) *(uint4*)(state + i) = make_uint4(stq[0], stq[1], stq[2], stq[3]);
     }
     __syncthreads();
     for (int j = threadIdx.x; j < TR_NODECHUNK * 256; j += 1024) {

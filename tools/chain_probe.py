@@ -37,5 +37,5 @@ for rep in range(3):
     print("%s & %s B=%d rep %d: enc %.3f s (%.0f MB/s) dec %.3f s (%.0f MB/s) enc+dec %.0f MB/s" % (chain, ent, B, rep, t1 - t0, B * bs / (t1 - t0) / 1e6, t2 - t1, B * bs / (t2 - t1) / 1e6, B * bs / (t2 - t0) / 1e6), flush=True)
 assert torch.equal(d_in, d_dec)
 kt = ctx.kernel_times()
-for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])[:10]:
+for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])[:24]:
     print("  %-18s %9.1f ms %5d launches (longest %.1f)" % (k, v["ms"], v["launches"], v["max_ms"]))

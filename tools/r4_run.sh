@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/r04k
-for c in -1 5; do echo "== BWT 2048 class $c"; KZ_BWT_TRACE=0 timeout 600 python tools/chain_probe.py BWT NONE 2048 $c 2>&1 | grep -E "rep [12]" ; done
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -6
+timeout 900 python tools/bwt_diag.py quick 2>&1 | tail -1
+for c in 0 4; do echo "== class $c"; timeout 300 python tools/chain_probe.py BWT NONE 357 $c 2>&1 | grep -E "rep 2|k_tr_count" | head -3; done
+echo "== mix 682"; timeout 300 python tools/chain_probe.py BWT NONE 682 2>&1 | grep -E "rep 2" 
