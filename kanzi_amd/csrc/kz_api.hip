@@ -889,6 +889,17 @@ static void overlap_plan(kz_ctx* ctx, Overlap& O, const std::vector<int32_t>& zl
     if (tb < bestT - 1e-9) { bestT = tb; best = perm; O.bwtOrder = byEnd; }
   } while (std::next_permutation(perm.begin(), perm.end()));
   O.launchOrder = best;
+  if (const char* eo = getenv("KZ_OVERLAP_ORDER")) {                  // experiments: launch order of the classes as digits, e.g. "201"
+    std::vector<int> forced;
+    for (const char* c = eo; *c; c++) if (*c >= '0' && *c < '0' + n && std::find(forced.begin(), forced.end(), *c - '0') == forced.end()) forced.push_back(*c - '0');
+    if ((int)forced.size() == n) {
+      O.launchOrder = forced;
+      double t = 0, endR[KZ_OVERLAP_MAXG];
+      for (int i = 0; i < n; i++) { t += O.groups[forced[i]].tPre; endR[forced[i]] = t + O.groups[forced[i]].tRank; }
+      O.bwtOrder = forced;
+      std::sort(O.bwtOrder.begin(), O.bwtOrder.end(), [&](int a, int b) { return endR[a] < endR[b]; });
+    }
+  }
   if (getenv("KZ_TRACE_SCHED")) {
     fprintf(stderr, "[sched] plan %.0f ms: launch", bestT * 1e3);
     for (int g : O.launchOrder) fprintf(stderr, " %d(pre %.0f rank %.0f bwt %.0f)", g, O.groups[g].tPre * 1e3, O.groups[g].tRank * 1e3, O.groups[g].tBwt * 1e3);

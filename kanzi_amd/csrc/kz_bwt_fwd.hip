@@ -1746,9 +1746,10 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
   A.d_m = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   A.d_m2 = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   if (!A.d_m2 || !A.tileB || !A.tileLive || !A.sa || !A.d_big || !A.bucketCnt) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: arena overflow"); return -KZ_ERR_DEVICE; }
-  const bool useTrie = tr_applies(maxN);
+  bool useTrie = tr_applies(maxN);
   TrieArrays TR;
   memset(&TR, 0, sizeof(TR));
+  const size_t markTrie = ctx->arenaTop;
   if (useTrie) {
     TR.MN = tr_max_nodes(maxN); TR.MB = TR_MAXB;
     TR.cnt = (u32*)kz_arena_alloc(ctx, (size_t)B * TR.MN * 1024);
@@ -1763,7 +1764,12 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
     TR.nodeGS = (u32*)kz_arena_alloc(ctx, (size_t)B * TR.MN * 4);
     TR.meta = (int32_t*)kz_arena_alloc(ctx, (size_t)B * TR_META * 4);
     TR.err = (int32_t*)kz_arena_alloc(ctx, 256);
-    if (!TR.cnt || !TR.info || !TR.nodeStart || !TR.bStart || !TR.bCount || !TR.bFill || !TR.bAux || !TR.bG || !TR.nodePfx || !TR.nodeGS || !TR.meta || !TR.err) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: arena overflow (trie tables)"); return -KZ_ERR_DEVICE; }
+    if (!TR.cnt || !TR.info || !TR.nodeStart || !TR.bStart || !TR.bCount || !TR.bFill || !TR.bAux || !TR.bG || !TR.nodePfx || !TR.nodeGS || !TR.meta || !TR.err) {
+      // the caller sized the arena for the longest block the CHAIN can hand over, which may lie outside the trie rounds' range while
+      // this batch's blocks are inside: the LSD rounds need no tables
+      ctx->arenaTop = markTrie;
+      useTrie = false;
+    }
   }
   A.d_n = bt.d_len;
   hipStream_t st = ctx->stream;

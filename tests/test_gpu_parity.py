@@ -1300,3 +1300,56 @@ def test_prestaged_batches_larger_than_the_arena_are_split(ctx, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert (tmp_path / "out.knz").read_bytes() == cos.output
     assert kz.CompressedInputStream(ctx, cos.output).read() == data
+
+
+def _trie_inputs():
+    """Inputs of 64 KiB and more (the trie rounds of kz_bwt_fwd.hip apply from 64 KiB up): every synthetic class around the size
+    threshold, long runs, periods, tiny alphabets, a few huge groups, text that ends in zeros (padding vs real zero bytes)."""
+    rng = np.random.default_rng(5)
+
+    def repeats(n, nwords, wlen):
+        words = rng.integers(0, 256, (nwords, wlen), dtype=np.uint8)
+        return words[rng.integers(0, nwords, n // wlen + 1)].reshape(-1)[:n].tobytes()
+
+    ins = []
+    for n in (65536, 65537, 100000):
+        for c in range(5):
+            ins.append(datagen.block(c, n, c).tobytes())
+    ins += [bytes(300000), bytes(65536), b"ab" * 200000, (b"abcdefghijklmnopqrstuvwxy" * 20000)[:499979],
+            rng.integers(0, 3, 300000, dtype=np.uint8).tobytes(), rng.integers(0, 2, 200000, dtype=np.uint8).tobytes(),
+            repeats(700000, 3, 33), repeats(1 << 19, 12, 40), repeats(300000, 900, 16),
+            rng.integers(0, 256, 200000, dtype=np.uint8).tobytes() + bytes(70000), bytes(99999) + b"\x01",
+            b"\xff" * 150000 + rng.integers(0, 256, 50000, dtype=np.uint8).tobytes()]
+    return ins
+
+
+@pytest.mark.parametrize("switch", ["default", "KZ_BWT_DMAX=7", "KZ_BWT_TRIEWIN=0", "KZ_BWT_TRIE=0"])
+def test_bwt_forward_trie_rounds_match_oracle(ctx, monkeypatch, switch):
+    """Round 0 as a trie round (count by byte, move once, finish buckets in LDS) and the key trie round over the window of oversized
+    buckets in the doubling rounds, against the oracle's induced-sorting BWT (the BWT is unique): default depth 6, depth 7, the
+    LSD window instead of the key round, and the whole old path."""
+    if switch != "default":
+        k, v = switch.split("=")
+        monkeypatch.setenv(k, v)
+    for d in _trie_inputs():
+        ok_o, enc_o = oracle.transform_forward("BWT", d)
+        ok_g, enc_g = _fwd(ctx, kz.BWT_TYPE, d)
+        assert ok_g == ok_o and enc_g == enc_o, (switch, len(d))
+    if switch == "default":
+        # one ragged batch: blocks of 64 KiB .. 4 MiB and two short ones in the same call (the tables follow the longest block)
+        blocks = [datagen.block(c, 4 << 20, c).tobytes() for c in (0, 4)] + [_trie_inputs()[k] for k in (3, 15, 21)] + [b"short block", b""]
+        bs = 4 << 20
+        B = len(blocks)
+        inp = np.zeros((B, bs), dtype=np.uint8)
+        lens = np.array([len(d) for d in blocks], dtype=np.int32)
+        for i, d in enumerate(blocks):
+            inp[i, :len(d)] = np.frombuffer(d, dtype=np.uint8)
+        ostride = kz.max_block_stream_bytes(bs)
+        out = np.zeros((B, ostride), dtype=np.uint8)
+        res = kz.encode_blocks(ctx, "BWT", "NONE", inp, bs, lens, out, ostride)
+        for i, d in enumerate(blocks):
+            if len(d) == 0:
+                continue
+            so, w, sf, pl = oracle.encode_block("BWT", "NONE", d)
+            assert res[i].status == 0 and (res[i].bits, res[i].skipFlags, res[i].length) == (w, sf, pl), len(d)
+            assert out[i, :(w + 7) // 8].tobytes() == so, len(d)
