@@ -36,6 +36,7 @@ __device__ __forceinline__ void bw_put(BitW& w, u32 v, int count) {
 }
 
 typedef u16 __attribute__((aligned(1))) ans_u16_unaligned;
+typedef u64 __attribute__((aligned(1))) ans_u64_unaligned;
 
 // =================================================================================================
 // encode: one wave per chunk
@@ -241,21 +242,37 @@ __global__ __launch_bounds__(64) void k_ans_enc_chunk(const u8* __restrict__ src
   u32 st = ANS_TOP;
   int idx = n;
   if (lane < 4) {
-    for (int i = end4 - 1; i > 0; i -= 4) {
-      const u32 c = data[i - lane];
-      const uint4 sy = symTab[c];
-      const bool x = st >= sy.x;                                    // (int) compare: both < 2^31
-      const uint64_t bal = kz_ballot(x) & 0xFULL;
-      const int pre = (int)__popcll(bal & kz_lanemask_lt());
-      if (x) {                                                      // scr[e] = low byte, scr[e - 1] = next byte: one 2-byte store
-        const int e = idx - 2 * pre;
-        *(ans_u16_unaligned*)(scr + e - 1) = (u16)(((st & 0xFFu) << 8) | ((st >> 8) & 0xFFu));
-        st >>= 16;
-      }
-      idx -= 2 * (int)__popcll(bal);
-      const u32 q = (u32)(((u64)st * (u64)sy.y) >> (sy.w >> 16));
-      st = st + sy.z + q * (sy.w & 0xFFFFu);
+    // the step for source dword w (bytes 4w .. 4w+3; lane l codes byte 4w + 3 - l = data[i - l] for i = 4w + 3)
+#define ANS_ENC_STEP(WD)                                                                                      \
+    { const u32 c = ((WD) >> (8 * (3 - lane))) & 0xFFu;                                                       \
+      const uint4 sy = symTab[c];                                                                             \
+      const bool x = st >= sy.x;                                    /* (int) compare: both < 2^31 */           \
+      const uint64_t bal = kz_ballot(x) & 0xFULL;                                                             \
+      const int pre = (int)__popcll(bal & kz_lanemask_lt());                                                  \
+      if (x) {                                                      /* scr[e] = low byte, scr[e - 1] = next byte: one 2-byte store */ \
+        const int e = idx - 2 * pre;                                                                          \
+        *(ans_u16_unaligned*)(scr + e - 1) = (u16)(((st & 0xFFu) << 8) | ((st >> 8) & 0xFFu));                \
+        st >>= 16;                                                                                            \
+      }                                                                                                       \
+      idx -= 2 * (int)__popcll(bal);                                                                          \
+      const u32 q = (u32)(((u64)st * (u64)sy.y) >> (sy.w >> 16));                                             \
+      st = st + sy.z + q * (sy.w & 0xFFFFu); }
+    // the source is read 16 bytes at a time (chunks start 16-byte aligned), the next group requested while this one is coded:
+    // the byte loads used to sit on the loop's dependent chain (one L1 round trip per step)
+    const int T = end4 >> 2;                                         // dwords to code, from T - 1 down to 0
+    const uint4* d16 = (const uint4*)data;
+    int g = (T - 1) >> 2;
+    uint4 cur = (T > 0) ? d16[g] : make_uint4(0, 0, 0, 0);
+    for (; g >= 0; g--) {
+      const uint4 nxt = (g > 0) ? d16[g - 1] : make_uint4(0, 0, 0, 0);
+      const int top = min(3, T - 1 - 4 * g);                         // the highest group may be partial
+      if (top >= 3) ANS_ENC_STEP(cur.w)
+      if (top >= 2) ANS_ENC_STEP(cur.z)
+      if (top >= 1) ANS_ENC_STEP(cur.y)
+      ANS_ENC_STEP(cur.x)
+      cur = nxt;
     }
+#undef ANS_ENC_STEP
   }
   idx = __shfl(idx, 0, 64);
   n = idx + 1;
@@ -570,7 +587,25 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
   const int end4 = len & -4;
   u32 n = 0;
   if (lane < 4) {
+    // The payload (bit-unaligned in the stream) is read through a 16-byte register window [rHi | rLo] of raw stream bytes that
+    // slides 8 bytes at a time; the next 8 bytes are requested when the window slides, a step or more before anything in them is
+    // used.  A step consumes at most 8 payload bytes, so with n <= wbase + 7 at its start every byte pair it may read lies inside the
+    // window.  (Before: two 4-byte bit peeks per lane at the END of the step's dependent chain.)
+    const u64 payByte = payloadBit >> 3;
+    const u32 payShift = (u32)(payloadBit & 7);
+    const bool winOk = payByte + (u64)sz + 40 <= (u64)inStride;          // the window never reads past the block's slot
+    u32 wbase = 0;
+    u64 rHi = 0, rLo = 0, rNx = 0;
+    if (winOk) {
+      rHi = __builtin_bswap64(*(const ans_u64_unaligned*)(p + payByte));
+      rLo = __builtin_bswap64(*(const ans_u64_unaligned*)(p + payByte + 8));
+      rNx = __builtin_bswap64(*(const ans_u64_unaligned*)(p + payByte + 16));
+    }
     for (int i = 0; i < end4; i += 4) {
+      if (winOk && n > wbase + 7) {                                     // uniform over the four lanes (n is)
+        rHi = rLo; rLo = rNx; wbase += 8;
+        rNx = __builtin_bswap64(*(const ans_u64_unaligned*)(p + payByte + wbase + 16));
+      }
       u32 cur;
       if (!wide) cur = f2s[st & mask];
       else {                                                      // last symbol whose cumulative frequency is <= the slot
@@ -585,9 +620,16 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
       const bool need = (int)st < (int)ANS_TOP;
       const uint64_t bal = kz_ballot(need) & 0xFULL;
       if (need) {
-        const u32 at = n + 2u * (u32)__popcll(bal & kz_lanemask_lt());
-        const u32 hi = (at < sz) ? kz_peek(p, payloadBit + 8ULL * at, 8) : 0;
-        const u32 lo = (at + 1 < sz) ? kz_peek(p, payloadBit + 8ULL * (at + 1), 8) : 0;
+        const u32 off = 2u * (u32)__popcll(bal & kz_lanemask_lt());
+        const u32 at = n + off;
+        u32 hi, lo;
+        if (winOk) {
+          const u32 bp = 8u * (at - wbase) + payShift;                    // bit position of the pair inside the window: < 112
+          const u64 v = (bp < 64) ? ((rHi << bp) | (bp ? (rLo >> (64 - bp)) : 0ULL)) : (rLo << (bp - 64));
+          const u32 two = (u32)(v >> 48);
+          hi = (at < sz) ? (two >> 8) : 0u; lo = (at + 1 < sz) ? (two & 0xFFu) : 0u;
+        }
+        else { hi = (at < sz) ? kz_peek(p, payloadBit + 8ULL * at, 8) : 0; lo = (at + 1 < sz) ? kz_peek(p, payloadBit + 8ULL * (at + 1), 8) : 0; }
         st = (st << 16) | (hi << 8) | lo;
       }
       n += 2u * (u32)__popcll(bal);
