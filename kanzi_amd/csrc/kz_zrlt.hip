@@ -17,8 +17,12 @@
 typedef uint32_t u32;
 typedef uint8_t u8;
 
-#define ZR_PER 16
-#define ZR_TILE (KZ_WG * ZR_PER)      // 4096 bytes per workgroup
+#ifndef ZR_PER
+#define ZR_PER 16                     // forward: bytes per thread (64 was measured: f3 39 -> 97 ms, f1 20 -> 31 ms per 8 GiB: a lane
+#endif                                // reading 64 consecutive bytes strides the wave over 64 cache lines per load)
+#define ZR_TILE (KZ_WG * ZR_PER)      // bytes per workgroup, forward
+#define ZI_PER 16                     // inverse: tokens are classified byte by byte with look-back
+#define ZI_TILE (KZ_WG * ZI_PER)
 
 struct ZrScratch {
   u32* tLastNz;   // [B][T]  abs position+1 of the last non-zero byte of the tile (0 = none)
@@ -31,9 +35,14 @@ struct ZrScratch {
   int T;
 };
 
-__device__ __forceinline__ void zr_load16(const u8* s, int pos, int n, u8* v) {
-  if (pos + 16 <= n) { uint4 q = *(const uint4*)(s + pos); memcpy(v, &q, 16); }
-  else { for (int k = 0; k < 16; k++) v[k] = (pos + k < n) ? s[pos + k] : 1; }   // pad non-zero (never emitted)
+__device__ __forceinline__ void zr_load(const u8* s, int pos, int n, u8* v) {
+  if (pos + ZR_PER <= n) {
+#pragma unroll
+    for (int q4 = 0; q4 < ZR_PER / 16; q4++) { uint4 q = *(const uint4*)(s + pos + 16 * q4); memcpy(v + 16 * q4, &q, 16); }
+  } else {
+#pragma unroll
+    for (int k = 0; k < ZR_PER; k++) v[k] = (pos + k < n) ? s[pos + k] : 1;   // pad non-zero (never emitted)
+  }
 }
 
 // size of the tokens a thread emits for its 16-byte chunk, given `carry` zeros pending before it.
@@ -41,7 +50,9 @@ __device__ __forceinline__ void zr_load16(const u8* s, int pos, int n, u8* v) {
 __device__ __forceinline__ u32 zr_chunk_size(const u8* v, int cnt, u32 carry, bool firstKnown, bool isBlockEnd) {
   u32 out = 0, run = carry;
   bool first = true;
-  for (int k = 0; k < cnt; k++) {
+#pragma unroll
+  for (int k = 0; k < ZR_PER; k++) {
+    if (k >= cnt) break;
     if (v[k] == 0) { run++; continue; }
     if (run > 0) { if (!first || firstKnown) out += (u32)kz_ilog2(run + 1); run = 0; }
     first = false;
@@ -60,10 +71,14 @@ __global__ __launch_bounds__(KZ_WG) void k_zrlt_f1(const u8* __restrict__ src, i
   __shared__ u32 lds[32];
   const u8* s = src + (int64_t)b * stride;
   const int pos = tstart + threadIdx.x * ZR_PER;
-  u8 v[16];
+  u8 v[ZR_PER];
   int cnt = 0;
   u32 lastnz = 0;
-  if (pos < n) { zr_load16(s, pos, n, v); cnt = min(16, n - pos); for (int k = 0; k < cnt; k++) if (v[k]) lastnz = (u32)(pos + k + 1); }
+  if (pos < n) {
+    zr_load(s, pos, n, v); cnt = min(ZR_PER, n - pos);
+#pragma unroll
+    for (int k = 0; k < ZR_PER; k++) if (k < cnt && v[k]) lastnz = (u32)(pos + k + 1);
+  }
   u32 tot;
   u32 inc = kz_wg_incl_max(lastnz, lds, &tot);
   // exclusive max over previous threads
@@ -90,7 +105,10 @@ __global__ __launch_bounds__(KZ_WG) void k_zrlt_f1(const u8* __restrict__ src, i
   }
   // first non-zero position (min-reduce) -> tLead
   u32 firstnz = 0xFFFFFFFFu;
-  if (cnt > 0) for (int k = cnt - 1; k >= 0; k--) if (v[k]) firstnz = (u32)(pos + k);
+  if (cnt > 0) {
+#pragma unroll
+    for (int k = ZR_PER - 1; k >= 0; k--) if (k < cnt && v[k]) firstnz = (u32)(pos + k);
+  }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { u32 o = __shfl_xor(firstnz, d, 64); firstnz = o < firstnz ? o : firstnz; }
   __shared__ u32 wf[4];
@@ -158,10 +176,14 @@ __global__ __launch_bounds__(KZ_WG) void k_zrlt_f3(const u8* __restrict__ src, u
   const u8* s = src + (int64_t)b * stride;
   u8* d = dst + (int64_t)b * stride;
   const int pos = tstart + threadIdx.x * ZR_PER;
-  u8 v[16];
+  u8 v[ZR_PER];
   int cnt = 0;
   u32 lastnz = 0;
-  if (pos < n) { zr_load16(s, pos, n, v); cnt = min(16, n - pos); for (int k = 0; k < cnt; k++) if (v[k]) lastnz = (u32)(pos + k + 1); }
+  if (pos < n) {
+    zr_load(s, pos, n, v); cnt = min(ZR_PER, n - pos);
+#pragma unroll
+    for (int k = 0; k < ZR_PER; k++) if (k < cnt && v[k]) lastnz = (u32)(pos + k + 1);
+  }
   u32 tot;
   u32 inc = kz_wg_incl_max(lastnz, lds, &tot);
   u32 prev = __shfl_up(inc, 1, 64);
@@ -180,8 +202,10 @@ __global__ __launch_bounds__(KZ_WG) void k_zrlt_f3(const u8* __restrict__ src, u
   const u32 dstEnd = (u32)n;
   u32 run = carry;
   bool fail = false;
-  for (int k = 0; k <= cnt; k++) {
-    if (k < cnt && v[k] == 0) { run++; continue; }
+#pragma unroll
+  for (int k = 0; k <= ZR_PER; k++) {
+    if (k > cnt) break;
+    if (k < cnt && v[k < ZR_PER ? k : 0] == 0) { run++; continue; }
     if (k == cnt && !blockEnd) break;
     if (run > 0) {
       const u32 rl = run + 1;
@@ -191,7 +215,7 @@ __global__ __launch_bounds__(KZ_WG) void k_zrlt_f3(const u8* __restrict__ src, u
       run = 0;
     }
     if (k == cnt) break;
-    const u32 val = v[k];
+    const u32 val = v[k < ZR_PER ? k : 0];
     if (val >= 0xFE) {
       if (off + 1 >= dstEnd) fail = true;                        // :111
       else { d[off] = 0xFF; d[off + 1] = (u8)(val - 0xFE); }
@@ -268,13 +292,13 @@ struct ZiScratch { u32* tSum; u32* tOff; int32_t* total; int32_t* fail; int T; }
 __global__ __launch_bounds__(KZ_WG) void k_zrlt_i1(const u8* __restrict__ src, int64_t stride, const int32_t* __restrict__ d_len, ZiScratch S) {
   const int b = blockIdx.y, t = blockIdx.x;
   const int n = d_len[b];
-  const int tstart = t * ZR_TILE;
+  const int tstart = t * ZI_TILE;
   if (tstart >= n) return;
   __shared__ __attribute__((aligned(8))) u32 lds[32];
   const u8* s = src + (int64_t)b * stride;
-  const int pos = tstart + threadIdx.x * ZR_PER;
+  const int pos = tstart + threadIdx.x * ZI_PER;
   unsigned long long sz = 0; bool bad = false;
-  for (int k = 0; k < ZR_PER; k++) if (pos + k < n) sz += zr_inv_token(s, pos + k, n, &bad);
+  for (int k = 0; k < ZI_PER; k++) if (pos + k < n) sz += zr_inv_token(s, pos + k, n, &bad);
   // tile total, saturated: wrapped run counts can be anything below 2^31
   for (int d = 1; d < 64; d <<= 1) sz += __shfl_xor(sz, d, 64);
   unsigned long long* l64 = (unsigned long long*)lds;
@@ -290,7 +314,7 @@ __global__ __launch_bounds__(KZ_WG) void k_zrlt_i1(const u8* __restrict__ src, i
 __global__ __launch_bounds__(64) void k_zrlt_i2(const int32_t* __restrict__ d_len, ZiScratch S, int dstCap) {
   const int b = blockIdx.x;
   const int n = d_len[b];
-  const int tiles = (n + ZR_TILE - 1) / ZR_TILE;
+  const int tiles = (n + ZI_TILE - 1) / ZI_TILE;
   const int64_t o = (int64_t)b * S.T;
   const int lane = kz_lane();
   unsigned long long carry = 0;
@@ -322,17 +346,17 @@ __global__ __launch_bounds__(KZ_WG) void k_zrlt_i3(const u8* __restrict__ src, u
                                                     const int32_t* __restrict__ d_len, ZiScratch S) {
   const int b = blockIdx.y, t = blockIdx.x;
   const int n = d_len[b];
-  const int tstart = t * ZR_TILE;
+  const int tstart = t * ZI_TILE;
   if (tstart >= n || S.fail[b]) return;
   __shared__ u32 lds[32];
   const u8* s = src + (int64_t)b * stride;
   u8* d = dst + (int64_t)b * stride;
-  const int pos = tstart + threadIdx.x * ZR_PER;
-  u32 sz[ZR_PER]; u32 sum = 0; bool bad = false;
-  for (int k = 0; k < ZR_PER; k++) { sz[k] = (pos + k < n) ? zr_inv_token(s, pos + k, n, &bad) : 0; sum += sz[k]; }
+  const int pos = tstart + threadIdx.x * ZI_PER;
+  u32 sz[ZI_PER]; u32 sum = 0; bool bad = false;
+  for (int k = 0; k < ZI_PER; k++) { sz[k] = (pos + k < n) ? zr_inv_token(s, pos + k, n, &bad) : 0; sum += sz[k]; }
   u32 total;
   u32 off = kz_wg_excl_sum(sum, lds, &total) + S.tOff[(int64_t)b * S.T + t];
-  for (int k = 0; k < ZR_PER; k++) {
+  for (int k = 0; k < ZI_PER; k++) {
     const int i = pos + k;
     if (i >= n) break;
     const u32 v = s[i];
@@ -350,7 +374,7 @@ __global__ void k_zrlt_ifin(const int32_t* __restrict__ d_len, int32_t* __restri
 }
 
 size_t kz_zrlt_scratch(int B, int maxN) {
-  const int T = (maxN + 64 + ZR_TILE - 1) / ZR_TILE + 1;
+  const int T = (maxN + 64 + ZI_TILE - 1) / ZI_TILE + 1;      // the inverse's (smaller) tiles
   return (size_t)B * T * 4 * 6 + (size_t)B * 16 + 8192;
 }
 
@@ -391,7 +415,7 @@ int kz_stage_zrlt_inverse(kz_ctx* ctx, kz_batch& bt, int dstCap) {
   int maxN = 0;
   for (int b = 0; b < B; b++) if (bt.h_len[b] > maxN) maxN = bt.h_len[b];
   ZiScratch S;
-  S.T = (maxN + ZR_TILE - 1) / ZR_TILE + 1;
+  S.T = (maxN + ZI_TILE - 1) / ZI_TILE + 1;
   S.tSum = (u32*)kz_arena_alloc(ctx, (size_t)B * S.T * 4);
   S.tOff = (u32*)kz_arena_alloc(ctx, (size_t)B * S.T * 4);
   S.fail = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
@@ -404,7 +428,7 @@ int kz_stage_zrlt_inverse(kz_ctx* ctx, kz_batch& bt, int dstCap) {
   KZ_HIP(hipMemsetAsync(S.fail, 0, (size_t)B * 4, st));
   KZ_HIP(hipMemsetAsync(S.total, 0, (size_t)B * 4, st));
   if (maxN > 0) {
-    const int tiles = (maxN + ZR_TILE - 1) / ZR_TILE;
+    const int tiles = (maxN + ZI_TILE - 1) / ZI_TILE;
     KZ_LAUNCH(ctx, KID_ZRLT_I1, k_zrlt_i1, dim3(tiles, B), dim3(KZ_WG), src, bt.stride, bt.d_len, S);
     KZ_LAUNCH(ctx, KID_ZRLT_I2, k_zrlt_i2, dim3(B), dim3(64), bt.d_len, S, dstCap);
     KZ_LAUNCH(ctx, KID_ZRLT_I2, k_zrlt_izero, dim3(64, B), dim3(256), dst, bt.stride, bt.d_len, S);
