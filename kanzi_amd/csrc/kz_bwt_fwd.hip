@@ -805,59 +805,22 @@ __global__ __launch_bounds__(1024) void k_bucket_count(const u64* __restrict__ k
 
 // ---------------------------------------------------------------------------------------------
 // step 1 (text order): compact the LIVE suffixes and build their keys from sequential rank reads
-__global__ __launch_bounds__(KZ_WG) void k_live_count(BwtArrays A, int first) {
+// The compact list need not be in text order (its only readers partition it by group: k_msd_* / the key trie round), so a tile
+// reserves its slice with ONE returning atomic on the block's counter instead of a count kernel + a scan kernel + a second read of
+// every rank (k_live_count / k_live_scan until round 4: 36 ms and 122 GB of rank reads per 8 GiB).  Inside a tile the order stays
+// the text order.  tileLive[tile] = live suffixes of the tile after the previous round (0 stays 0: suffixes only become final).
+__global__ __launch_bounds__(KZ_WG) void k_live_emit(u64* __restrict__ keyN, u32* __restrict__ valN, BwtArrays A, int h, int bitsR, int first) {
   const int b = blockIdx.y;
   const int n = A.d_n[b];
   const int tile = blockIdx.x;
   if ((int64_t)tile * RS_TILE >= n) return;
-  __shared__ u32 lds[32];
-  if (!first && A.tileLive[(int64_t)b * A.T + tile] == 0) {        // nothing left to count here
-    if (threadIdx.x == 0) A.tileA[(int64_t)b * A.T + tile] = 0;
-    return;
-  }
-  const u32* rank = A.rank + (int64_t)b * A.NS;
-  u32 cnt = 0;
-#pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
-    const int s = tile * RS_TILE + r * KZ_WG + threadIdx.x;          // coalesced
-    if (s < n && (rank[s] & BW_LIVE)) cnt++;
-  }
-  u32 tot;
-  kz_wg_excl_sum(cnt, lds, &tot);
-  if (threadIdx.x == 0) { A.tileA[(int64_t)b * A.T + tile] = tot; A.tileLive[(int64_t)b * A.T + tile] = tot; }
-}
-__global__ void k_live_scan(BwtArrays A) {
-  const int b = blockIdx.x;
-  const int n = A.d_n[b];
-  const int tiles = (n + RS_TILE - 1) / RS_TILE;
-  u32* ta = A.tileA + (int64_t)b * A.T;
-  u32 ca = 0;
-  for (int base = 0; base < tiles; base += 64) {
-    const int i = base + threadIdx.x;
-    const u32 va = (i < tiles) ? ta[i] : 0;
-    const u32 ia = kz_wave_incl_sum(va);
-    if (i < tiles) ta[i] = ca + ia - va;
-    ca += __shfl(ia, 63, 64);
-  }
-  if (threadIdx.x == 0) A.d_m2[b] = (int32_t)ca;
-}
-__global__ __launch_bounds__(KZ_WG) void k_live_emit(u64* __restrict__ keyN, u32* __restrict__ valN, BwtArrays A, int h, int bitsR) {
-  const int b = blockIdx.y;
-  const int n = A.d_n[b];
-  const int tile = blockIdx.x;
-  if ((int64_t)tile * RS_TILE >= n) return;
+  if (!first && A.tileLive[(int64_t)b * A.T + tile] == 0) return;     // nothing left here: neither read nor written
   __shared__ u32 rowCnt[RS_ITEMS * 4 + 1];   // live suffixes per (wave, row), then exclusive prefix
-  {                                          // late rounds: a tile without a live suffix has nothing to read or write
-    const int tiles = (n + RS_TILE - 1) / RS_TILE;
-    const u32* ta = A.tileA + (int64_t)b * A.T;
-    const u32 here = ta[tile], next = (tile + 1 < tiles) ? ta[tile + 1] : (u32)A.d_m2[b];
-    if (next == here) return;
-  }
+  __shared__ u32 tileBase;
   const int64_t off = (int64_t)b * A.NS;
   const u32* rank = A.rank + off;
   const int wave = threadIdx.x >> 6, lane = kz_lane();
-  // wave w owns the 1024 consecutive suffixes [w*1024, (w+1)*1024): rows of 64 -> every access is coalesced and the
-  // compact order stays the text order
+  // wave w owns the 1024 consecutive suffixes [w*1024, (w+1)*1024): rows of 64 -> every access is coalesced
   const int base = tile * RS_TILE + wave * (64 * RS_ITEMS);
   u32 rk[RS_ITEMS];
   uint64_t bal[RS_ITEMS];
@@ -873,9 +836,14 @@ __global__ __launch_bounds__(KZ_WG) void k_live_emit(u64* __restrict__ keyN, u32
     const u32 v = rowCnt[threadIdx.x];
     const u32 inc = kz_wave_incl_sum(v);
     rowCnt[threadIdx.x] = inc - v;
+    if (threadIdx.x == 63) {
+      const u32 tot = inc;
+      A.tileLive[(int64_t)b * A.T + tile] = tot;
+      tileBase = tot ? (u32)atomicAdd(&A.d_m2[b], (int32_t)tot) : 0u;
+    }
   }
   __syncthreads();
-  const u32 tbase = A.tileA[(int64_t)b * A.T + tile];
+  const u32 tbase = tileBase;
   const uint64_t lt = kz_lanemask_lt();
   const u32 hcap = (u32)min(h, n);
 #pragma unroll
@@ -1256,7 +1224,7 @@ __global__ __launch_bounds__(1024) void k_tr_scatter(const u8* __restrict__ srcA
 #define TRQ_WAVES 16
 #define TRQ_ROWS 8
 template <bool KEYS>
-__device__ __forceinline__ void tr_sort_body(const u64* __restrict__ elemAll, const BwtArrays& A, const TrieArrays& T, int bitsG, int dbg) {
+__device__ __forceinline__ void tr_sort_body(const u64* __restrict__ elemAll, const BwtArrays& A, const TrieArrays& T, int bitsG) {
   const int b = blockIdx.y;
   const int nB = T.meta[(int64_t)b * TR_META + 1];
   __shared__ u64 buf[TR_CAP];
@@ -1305,7 +1273,6 @@ __device__ __forceinline__ void tr_sort_body(const u64* __restrict__ elemAll, co
       const int hiBit = 63 - (int)__builtin_clzll(diff);
       passes = (hiBit - lowBit + BK_DBITS) / BK_DBITS;
     }
-    if (dbg & 1) passes = 0;
     for (int p = 0; p < passes; p++) {
       const int shift = bitsG + lowBit + BK_DBITS * p;
       for (int i = threadIdx.x; i < TRQ_WAVES * BK_DBINS / 2; i += TRQ_WAVES * 64) ((u32*)&cw[0][0])[i] = 0;
@@ -1420,8 +1387,8 @@ __device__ __forceinline__ void tr_sort_body(const u64* __restrict__ elemAll, co
           const bool live = !(hh == (u32)idx && headN);
           const u32 sv = (u32)(k[r] & vmask);
           if (!KEYS) {
-            if (!(dbg & 2)) rank[sv] = (bo + hh) | (live ? BW_LIVE : 0u);
-            if (!live && !(dbg & 4)) sa[bo + (u32)idx] = sv;
+            rank[sv] = (bo + hh) | (live ? BW_LIVE : 0u);
+            if (!live) sa[bo + (u32)idx] = sv;
           } else {
             u32 g, headSlot, slot;
             if (segs) {
@@ -1440,9 +1407,9 @@ __device__ __forceinline__ void tr_sort_body(const u64* __restrict__ elemAll, co
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(1024, 8) void k_tr_sort(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG, int dbg) { tr_sort_body<false>(elemAll, A, T, bitsG, dbg); }
-__global__ __launch_bounds__(1024, 4) void k_tr_sort1(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG, int dbg) { tr_sort_body<false>(elemAll, A, T, bitsG, dbg); }
-__global__ __launch_bounds__(1024, 8) void k_trk_sort(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) { tr_sort_body<true>(elemAll, A, T, bitsG, 0); }
+// (two workgroups per CU at 64 VGPRs with 16 registers spilled beat one workgroup without spills: 45 vs 50 ms per 357 uniform blocks)
+__global__ __launch_bounds__(1024, 8) void k_tr_sort(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) { tr_sort_body<false>(elemAll, A, T, bitsG); }
+__global__ __launch_bounds__(1024, 8) void k_trk_sort(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) { tr_sort_body<true>(elemAll, A, T, bitsG); }
 
 // ---------------------------------------------------------------------------------------------
 // KEY rounds: the same trie round over the WINDOW of a doubling round -- the compact pairs (old group g << bitsR | secondary key r2,
@@ -1824,9 +1791,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
       }
       KZ_LAUNCH(ctx, KID_TR_SCATTER, k_tr_scatter, dim3(gridFor(maxN, TRS_TILE), B), dim3(1024), src, bt.stride, A.val[0], A.key[0], A, TR, bitsG);
       const int G = std::max(16, std::min(1024, 8192 / B));
-      const int dbgq = getenv("KZ_TRQ_DBG") ? atoi(getenv("KZ_TRQ_DBG")) : 0;
-      if (getenv("KZ_TRQ_OCC1")) KZ_LAUNCH(ctx, KID_TR_SORT, k_tr_sort1, dim3(G, B), dim3(1024), A.key[0], A, TR, bitsG, dbgq);
-      else KZ_LAUNCH(ctx, KID_TR_SORT, k_tr_sort, dim3(G, B), dim3(1024), A.key[0], A, TR, bitsG, dbgq);
+      KZ_LAUNCH(ctx, KID_TR_SORT, k_tr_sort, dim3(G, B), dim3(1024), A.key[0], A, TR, bitsG);
       KZ_HIP(hipMemcpyAsync(ctx->hpin + B, TR.err, 4, hipMemcpyDeviceToHost, st));
       wMax = 0;
     } else
@@ -1894,9 +1859,8 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
     }
     // ---- text order: compact the live suffixes, keys for the next round ----
     h = (round == 0) ? (useTrie ? 6 : K0) : h * 2;
-    KZ_LAUNCH(ctx, KID_LIVE_COUNT, k_live_count, dim3(tilesN, B), dim3(KZ_WG), A, round == 0 ? 1 : 0);
-    KZ_LAUNCH(ctx, KID_LIVE_SCAN, k_live_scan, dim3(B), dim3(64), A);
-    KZ_LAUNCH(ctx, KID_LIVE_EMIT, k_live_emit, dim3(tilesN, B), dim3(KZ_WG), kF, vF, A, h, bitsR);
+    KZ_HIP(hipMemsetAsync(A.d_m2, 0, (size_t)B * 4, st));
+    KZ_LAUNCH(ctx, KID_LIVE_EMIT, k_live_emit, dim3(tilesN, B), dim3(KZ_WG), kF, vF, A, h, bitsR, round == 0 ? 1 : 0);
     { u64* tk = kC; kC = kF; kF = tk; u32* tv = vC; vC = vF; vF = tv; }
     // ---- read back the next compact sizes ----
     KZ_HIP(hipMemcpyAsync(ctx->hpin, A.d_m2, (size_t)B * 4, hipMemcpyDeviceToHost, st));

@@ -616,3 +616,15 @@ def test_knz_streams_equal_a_python_model_of_the_container(built):
             ref.write(int.from_bytes(raw, "big") >> (8 * len(raw) - nb), nb)
     os_.close()
     assert os_.written() == ref.n and bytes(os_.sink) == ref.bytes()
+
+
+def test_trie_round_model_reproduces_suffix_arrays():
+    """The algorithm of the forward BWT's round 0 (kz_bwt_fwd.hip: count by byte level, classify children as expanded / terminal /
+    small, merge small siblings into buckets, sort a bucket by the key bits behind its common prefix) followed by rank doubling from
+    h = 6 gives the true suffix array although buckets are resolved to different depths: numpy model in tools/trie_sim.py."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("trie_sim", os.path.join(root, "tools", "trie_sim.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.check(trials=18)

@@ -1,2 +1,4 @@
-timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -k "transform_forward or block_streams or corrupted_input or full_size or fuzz_streams_match" 2>&1 | tail -3
-timeout 300 python tools/chain_probe.py BWT+RANK+ZRLT ANS0 2048 2>&1 | grep -E "rep 2|k_zrlt" 
+timeout 900 python tools/bwt_diag.py 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "trie_rounds or bwt_forward_group or large_blocks" 2>&1 | tail -2
+for c in 0 3; do echo "== class $c"; timeout 300 python tools/chain_probe.py BWT NONE 357 $c 2>&1 | grep -E "rep 2|k_live" | head -3; done
+echo "== mix 682"; timeout 300 python tools/chain_probe.py BWT NONE 682 2>&1 | grep -E "rep 2" 
