@@ -1479,6 +1479,11 @@ __global__ __launch_bounds__(1024) void k_trk_count(KeySrc X, u32* __restrict__ 
       const int i = i0 + threadIdx.x * 4;
       if (i >= pend) continue;
       u64 kq[4]; u32 stq[4];
+      if (!(L == 2 && chunk == 0)) {                                     // settled items (most of a late level's window) cost one state read
+        const uint4 sv = *(const uint4*)(state + i);
+        stq[0] = sv.x; stq[1] = sv.y; stq[2] = sv.z; stq[3] = sv.w;
+        if ((stq[0] >> 30) && (stq[1] >> 30) && (stq[2] >> 30) && (stq[3] >> 30)) continue;
+      }
       if (i + 4 <= pend && ((((uintptr_t)(key + i)) & 15) == 0)) {
         const uint4 a = *(const uint4*)(key + i), c = *(const uint4*)(key + i + 2);
         kq[0] = ((u64)a.y << 32) | a.x; kq[1] = ((u64)a.w << 32) | a.z; kq[2] = ((u64)c.y << 32) | c.x; kq[3] = ((u64)c.w << 32) | c.z;
@@ -1487,7 +1492,6 @@ __global__ __launch_bounds__(1024) void k_trk_count(KeySrc X, u32* __restrict__ 
         for (int q = 0; q < 4; q++) kq[q] = (i + q < pend) ? key[i + q] : 0ULL;
       }
       if (L == 2 && chunk == 0) { stq[0] = stq[1] = stq[2] = stq[3] = 0; }
-      else { const uint4 sv = *(const uint4*)(state + i); stq[0] = sv.x; stq[1] = sv.y; stq[2] = sv.z; stq[3] = sv.w; }
       u32 e[4]; bool look[4]; u64 k48[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
