@@ -1,6 +1,7 @@
 // kz_api.hip -- C-ABI entry points (include/kanzi_hip.h), the per-batch pipeline driver that plays
 // the role of K/transform/Sequence.java + the codec span of EncodingTask.encodeBlock /
 // DecodingTask.decodeBlock, the block-header kernels, and the host-side .knz stream framing.
+#include <dirent.h>
 #include "kz_device.h"
 #include "kz_internal.h"
 #include <stdlib.h>
@@ -137,7 +138,18 @@ extern "C" int32_t kz_pin_to_device_numa(int32_t deviceId) {
     if (*p == ',') p++;
   }
   if (count == 0) return 0;
-  if (sched_setaffinity(0, sizeof(set), &set) != 0) return 0;
+  // every thread the process has at this moment (sched_setaffinity(0, ..) alone would pin the caller and the threads it creates
+  // later, leaving a context's job worker or an already running host pool where they were: ADVICE r3); threads created afterwards
+  // inherit their creator's mask
+  int pinned = 0;
+  if (DIR* dir = opendir("/proc/self/task")) {
+    while (struct dirent* de = readdir(dir)) {
+      const long tid = strtol(de->d_name, nullptr, 10);
+      if (tid > 0 && sched_setaffinity((pid_t)tid, sizeof(set), &set) == 0) pinned++;
+    }
+    closedir(dir);
+  }
+  if (pinned == 0 && sched_setaffinity(0, sizeof(set), &set) != 0) return 0;
   return count;
 }
 extern "C" const char* kz_last_error(kz_ctx* ctx) { return ctx ? ctx->err : "null context"; }

@@ -11,6 +11,9 @@
 // table (2^16 / 2^19 ints) lives in HBM/L2.  Throughput comes from blocks in flight; a wave-speculative
 // parse is the planned replacement.
 #include "kz_device.h"
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "k_lz_inv relies on the in-order vmcnt store -> load visibility of one wave on gfx9 / CDNA (no separate store counter): see the note at its match copy"
+#endif
 #include "kz_internal.h"
 
 typedef unsigned long long u64;

@@ -525,17 +525,19 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
         if (at[good] + res[good].length > dstCap) { code = -KZ_ERR_WRITE_FILE; break; }
         at[good + 1] = at[good] + res[good].length;
       }
-      if (code) return code;
-      const int pieces = (cnt + P - 1) / P;
+      // a failing block ends the stream, but the blocks in front of it are delivered first, as the unstaged path and the
+      // reference's reader do: dst holds the same bytes on error whatever the batch size
+      const int ncopy = code ? good : cnt;
+      const int pieces = (ncopy + P - 1) / P;
       auto fetch = [&](int p) -> hipError_t {
-        const int i0 = p * P, c = std::min(P, cnt - i0);
+        const int i0 = p * P, c = std::min(P, ncopy - i0);
         return hipMemcpyAsync(ctx->pinOut[p & 1].p, ctx->devOut[0].p + (size_t)i0 * blockSize, (size_t)c * blockSize, hipMemcpyDeviceToHost, ctx->copyDown);
       };
-      KZ_HIP(fetch(0));
+      if (pieces > 0) KZ_HIP(fetch(0));
       for (int p = 0; p < pieces; p++) {
         KZ_HIP(hipStreamSynchronize(ctx->copyDown));
         if (p + 1 < pieces) KZ_HIP(fetch(p + 1));                       // the next piece travels while this one is put in place
-        const int i0 = p * P, c = std::min(P, cnt - i0);
+        const int i0 = p * P, c = std::min(P, ncopy - i0);
         const uint8_t* ring = ctx->pinOut[p & 1].p;
         parallel_blocks(c * 4, [&](int q) {                             // four copies per block
           const int i = i0 + (q >> 2);
@@ -543,6 +545,7 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
           if (b > a) memcpy(dst + at[i] + a, ring + (size_t)(i - i0) * blockSize + a, (size_t)(b - a));
         });
       }
+      if (code) return code;
       produced = at[cnt];
       continue;
     }
