@@ -1007,6 +1007,8 @@ __global__ __launch_bounds__(256) void k_tr_assign(BwtArrays A, TrieArrays T, in
             const u32 M = atomicAdd(&sNodes, 1u);
             if (M < (u32)T.MN) {
               nodeStart[M] = s0; e = (TR_K_EXP << 30) | M;
+              uint4* z = (uint4*)(cnt + (int64_t)M * 256);                // the new node's counters start at zero (no memset of the whole table)
+              for (int q = 0; q < 64; q++) z[q] = make_uint4(0, 0, 0, 0);
               if (keys) { nodePfx[M] = (L < 3) ? ((pfxN << 8) | cbyte) : pfxN; nodeGS[M] = (L + 1 == 3) ? s0 : gsN; }
             } else { sErr = 1; e = (TR_K_TERM << 30) | s0; }
           } else if (keys) {                                              // all key bytes equal: one new group; its head slot = g + (s0 - group start)
@@ -1425,8 +1427,7 @@ __device__ __forceinline__ u64 trk_k48(u64 key, int bitsR) { return ((key >> bit
 __global__ __launch_bounds__(1024) void k_trk_hist16(KeySrc X, BwtArrays A, TrieArrays T) {
   const int b = blockIdx.y;
   const int w0 = A.d_w[b];
-  const int W = A.d_m[b] - w0;
-  if (W <= 0) return;
+  const int W = max(0, A.d_m[b] - w0);                                  // an empty window still writes its (zero) counts: k_tr_assign reads them
   const u32 half = blockIdx.x;
   __shared__ u32 hist[32768];
   for (int i = threadIdx.x; i < 32768; i += 1024) hist[i] = 0;
@@ -1781,7 +1782,6 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
       // ---- the trie round: count level by level, move once, finish the buckets in LDS (elements in key[0], states in val[0]) ----
       const char* ed = getenv("KZ_BWT_DMAX");
       const int Dmax = (ed && ed[0] >= '6' && ed[0] <= '0' + TR_DMAX_LIMIT) ? ed[0] - '0' : 6;
-      KZ_HIP(hipMemsetAsync(TR.cnt, 0, (size_t)B * TR.MN * 1024, st));
       KZ_HIP(hipMemsetAsync(TR.bFill, 0, (size_t)B * TR.MB * 4, st));
       KZ_HIP(hipMemsetAsync(TR.meta, 0, (size_t)B * TR_META * 4, st));
       KZ_HIP(hipMemsetAsync(TR.err, 0, 4, st));
@@ -1826,7 +1826,6 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
     if (trieWindow) {
       // ---- the window of oversized buckets through a KEY trie round (k_trk_*): count by key byte, move once, finish in LDS ----
       const KeySrc XK = {kC, vC, bitsR};
-      KZ_HIP(hipMemsetAsync(TR.cnt, 0, (size_t)B * TR.MN * 1024, st));
       KZ_HIP(hipMemsetAsync(TR.bFill, 0, (size_t)B * TR.MB * 4, st));
       KZ_HIP(hipMemsetAsync(TR.meta, 0, (size_t)B * TR_META * 4, st));
       KZ_LAUNCH(ctx, KID_TR_HIST16, k_trk_hist16, dim3(2, B), dim3(1024), XK, A, TR);
