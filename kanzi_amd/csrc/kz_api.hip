@@ -834,8 +834,9 @@ static int overlap_view(kz_ctx* ctx, const kz_batch& bt, OverlapGroup& G) {
 }
 // Does this process get as many concurrent hardware queues as the wide schedule needs (main + three side streams)?  HIP
 // multiplexes its streams over GPU_MAX_HW_QUEUES hardware queues (4 unless the variable says otherwise when the runtime
-// starts; kz_ctx_create sets it to 8 when it is unset, which only helps if no HIP call was made before), and two streams on
-// one queue run one after the other.  Measured once per context: four 2 ms spin kernels on the four streams take 2 ms or 4+.
+// starts: the APPLICATION exports GPU_MAX_HW_QUEUES=8 before its first HIP call, the library never touches the environment;
+// a caller that forgets it gets the three-stream form below, which this measurement selects), and two streams on one queue run
+// one after the other.  Measured once per context: four 2 ms spin kernels on the four streams take 2 ms or 4+.
 __global__ void k_spin(long long ticks) {
   const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
   while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
