@@ -989,7 +989,14 @@ static int overlapped_rank_bwt_inverse(kz_ctx* ctx, Pipe& P, int mode, const std
 int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
                              const uint8_t* in, int64_t inStride, const int32_t* lengths, int32_t nBlocks,
                              uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind, const HostPre* pre);
-static int host_chunk_blocks() { const char* e = getenv("KZ_HOST_CHUNK"); const int v = e ? atoi(e) : 256; return v < 8 ? 8 : v; }
+// blocks per step of the encoder's host-stage pipeline: 256 for bulk batches; batches of a few dozen blocks (the silesia shape: 51)
+// take thirds, so that the TEXT / UTF stages of all but the first third run under the GPU work of the third before
+static int host_chunk_blocks(int B) {
+  const char* e = getenv("KZ_HOST_CHUNK");
+  if (e) { const int v = atoi(e); return v < 8 ? 8 : v; }
+  if (B >= 512) return 256;
+  return std::max(12, (B + 2) / 3);
+}
 static int32_t encode_blocks_bs(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
                                 const uint8_t* in, int64_t inStride, const int32_t* lengths, int32_t nBlocks,
                                 uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind) {
@@ -1052,8 +1059,8 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
   // ---- chains led by TEXT / UTF on large batches: the host stages of chunk k+1 run on a helper thread (and the host pool) while
   //      the GPU codes chunk k.  Blocks are independent, so chunking changes nothing in the output.  (With "skipBlocks" the copy
   //      decision comes from the device and precedes the host stages: that case takes the one-pass path below.) ----
-  if (hp > 0 && !pre && !ctx->skipBlocks && B >= 2 * host_chunk_blocks()) {
-    const int CH = host_chunk_blocks();
+  if (hp > 0 && !pre && !ctx->skipBlocks && B >= 2 * host_chunk_blocks(B)) {
+    const int CH = host_chunk_blocks(B);
     const int nch = (B + CH - 1) / CH;
     const bool hostIn = memKind == KZ_MEM_HOST;
     struct Chunk { HostPre P; int rc = 0; };

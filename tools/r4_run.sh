@@ -1,4 +1,2 @@
-timeout 900 python tools/bwt_diag.py 2>&1 | tail -1
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "trie_rounds or bwt_forward_group or full_size or large_blocks or 45_blocks" 2>&1 | tail -2
-echo "== mix 682"; timeout 300 python tools/chain_probe.py BWT NONE 682 2>&1 | grep -E "rep 2" 
-echo "== full 2048"; timeout 300 python tools/chain_probe.py BWT+RANK+ZRLT ANS0 2048 2>&1 | grep -E "rep 2" 
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -k "level_exact or host_stage_pipeline or level5 or prestaged" 2>&1 | tail -3
+for ch in 256 0; do echo "== B=51 KZ_HOST_CHUNK=$ch"; env $( [ $ch != 0 ] && echo KZ_HOST_CHUNK=$ch ) timeout 300 python tools/level5_probe.py 51 2>&1 | grep -E "TEXT.*rep 1"; done
