@@ -1059,7 +1059,6 @@ __global__ __launch_bounds__(1024) void k_tr_count(const u8* __restrict__ srcAll
   const int P = gridDim.x;
   const int per = (((n + P - 1) / P) + 1023) & ~1023;
   const int pbeg = blockIdx.x * per, pend = min(n, pbeg + per);
-  const int lane = kz_lane();
   for (int chunk = 0; lo + chunk * TR_NODECHUNK < hi; chunk++) {
     for (int i = threadIdx.x; i < TR_NODECHUNK * 256; i += 1024) lds[i] = 0;
     __syncthreads();
@@ -1470,7 +1469,6 @@ __global__ __launch_bounds__(1024) void k_trk_count(KeySrc X, u32* __restrict__ 
   const int P = gridDim.x;
   const int per = (((W + P - 1) / P) + 1023) & ~1023;
   const int pbeg = blockIdx.x * per, pend = min(W, pbeg + per);
-  const int lane = kz_lane();
   for (int chunk = 0; lo + chunk * TR_NODECHUNK < hi; chunk++) {
     for (int i = threadIdx.x; i < TR_NODECHUNK * 256; i += 1024) lds[i] = 0;
     __syncthreads();
