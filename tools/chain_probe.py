@@ -31,11 +31,12 @@ for rep in range(3):
     res = kz.encode_blocks(ctx, chain, ent, d_in.data_ptr(), bs, lens, d_enc.data_ptr(), os_, kz.MEM_DEVICE)
     t1 = time.perf_counter()
     bits = np.array([r.bits for r in res], dtype=np.int64)
-    res2 = kz.decode_blocks(ctx, chain, ent, bs, d_enc.data_ptr(), os_, bits, d_dec.data_ptr(), bs, kz.MEM_DEVICE)
+    enc_only = os.environ.get("KZ_PROBE_ENC_ONLY") == "1"          # timing experiments whose output is deliberately wrong
+    res2 = [] if enc_only else kz.decode_blocks(ctx, chain, ent, bs, d_enc.data_ptr(), os_, bits, d_dec.data_ptr(), bs, kz.MEM_DEVICE)
     t2 = time.perf_counter()
     assert all(r.status == 0 for r in res) and all(r.status == 0 for r in res2)
     print("%s & %s B=%d rep %d: enc %.3f s (%.0f MB/s) dec %.3f s (%.0f MB/s) enc+dec %.0f MB/s" % (chain, ent, B, rep, t1 - t0, B * bs / (t1 - t0) / 1e6, t2 - t1, B * bs / (t2 - t1) / 1e6, B * bs / (t2 - t0) / 1e6), flush=True)
-assert torch.equal(d_in, d_dec)
+assert enc_only or torch.equal(d_in, d_dec)
 kt = ctx.kernel_times()
 for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])[:24]:
     print("  %-18s %9.1f ms %5d launches (longest %.1f)" % (k, v["ms"], v["launches"], v["max_ms"]))
