@@ -800,7 +800,14 @@ static bool overlap_classify(int B, const std::vector<int32_t>& h_mask, const st
   for (int c = 0; c < nClasses; c++) if (cnt[c] > 0) order[n++] = c;
   if (n < 2) return false;
   O.groups.resize(n);
-  for (int g = 0; g < n; g++) { O.groups[g].in.assign(B, 0); O.groups[g].prio = (g == n - 1) ? 2 : (g > 0 ? 1 : 0); }
+  // issue priority of the classes' RANK-inverse waves (s_setprio 3 / 1 / 0).  KZ_OVERLAP_PRIO = one digit per class, cheapest first
+  // (0, 1 or 2), overrides the default "the more expensive, the higher" for experiments
+  const char* ep = getenv("KZ_OVERLAP_PRIO");
+  for (int g = 0; g < n; g++) {
+    O.groups[g].in.assign(B, 0);
+    O.groups[g].prio = (g == n - 1) ? 2 : (g > 0 ? 1 : 0);
+    if (ep && (int)strlen(ep) >= n && ep[g] >= '0' && ep[g] <= '2') O.groups[g].prio = ep[g] - '0';
+  }
   for (int b = 0; b < B; b++) {
     if (cls[b] < 0) continue;
     const int c = to[cls[b]];
