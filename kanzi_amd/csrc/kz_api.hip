@@ -461,7 +461,9 @@ struct ChainSpec { int types[8]; int nb; int entropy; };
 static int bwt_group_blocks(int B, int maxLen) {
   const size_t per = kz_bwt_forward_scratch(1, maxLen);
   const int g = (int)std::max<size_t>(1, (kz_arena_budget() / 2) / per);
-  return std::min(g, B);
+  if (g >= B) return B;
+  const int groups = (B + g - 1) / g;                                // equal groups: 2 048 blocks at 341 per group used to end with a
+  return (B + groups - 1) / groups;                                  // seventh group of TWO blocks paying every round's launches
 }
 static size_t pipeline_scratch(int B, int maxLen, bool decode, const ChainSpec& C) {
   size_t s = 65536;
