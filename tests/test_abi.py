@@ -4,6 +4,7 @@ fails loudly when no GPU is present."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -187,3 +188,23 @@ def test_patch_hooks_exist_in_the_java_adapters():
         src = re.sub(r'"(\\.|[^"\\])*"|//[^\n]*|/\*.*?\*/', "", open(os.path.join(jdir, f)).read(), flags=re.S)
         for a, b in ("()", "{}", "[]"):
             assert src.count(a) == src.count(b), (f, a)
+
+
+def test_fpaq_inline_asm_lds_reads_are_waited_for():
+    """kz_fpaq.hip issues ds_read_b32 from one inline-asm statement and waits for it in a later one; the compiler does not track
+    that.  Walk the device assembly this hipcc produces and make sure nothing touches those registers before the s_waitcnt."""
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import asm_lds_hazards as H
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc")
+    # the checker itself: a copy between the read and the wait is reported, the same copy behind the wait is not
+    bad, reads = H.hazards("ds_read_b32 v5, v1\nv_mov_b32 v9, v5\ns_waitcnt lgkmcnt(0)\nv_mov_b32 v8, v5")
+    assert reads == 1 and [b[0] for b in bad] == [1]
+    bad, _ = H.hazards("ds_read_b32 v5, v1\nds_read_b32 v6, v1 offset:4\nds_write_b32 v2, v3\ns_waitcnt lgkmcnt(1)\nv_cndmask_b32 v7, v5, v6, vcc")
+    assert bad == []
+    text = H.device_asm(os.path.join(ROOT, "kanzi_amd", "csrc", "kz_fpaq.hip"), hipcc)
+    for name in H.DEFAULT_KERNELS:
+        bad, reads = H.hazards(H.kernel_body(text, name))
+        assert reads > 0 and bad == [], (name, bad[:5])
