@@ -16,7 +16,9 @@ print("seed", seed, flush=True)
 
 
 def piece(n):
-    k = int(rng.integers(0, 11))
+    if n <= 0:
+        return np.zeros(0, np.uint8)
+    k = int(rng.integers(0, 13))
     if k < 5:
         return datagen.block(int(rng.integers(0, 1 << 20)), n, k)
     if k == 5:
@@ -35,12 +37,46 @@ def piece(n):
         m = max(1, n // int(rng.integers(5, 5000)))
         x[rng.integers(0, n, m)] = rng.integers(1, 256, m, dtype=np.uint8)
         return x
-    a = piece(n // 2)
-    return np.concatenate([a, a[:n - len(a)]])                 # the second half repeats the first: repeats of n / 2
+    if k == 10:
+        a = piece(n // 2)
+        return np.concatenate([a, a[:n - len(a)]])             # the second half repeats the first: repeats of n / 2
+    return structured(n)
+
+
+def structured(n):
+    """strings that are hard for a sort by prefix doubling: every group stays large for many rounds"""
+    if n <= 0:
+        return np.zeros(0, np.uint8)
+    k = int(rng.integers(0, 5))
+    a, b = (int(v) for v in rng.choice(256, 2, replace=False))
+    if k == 0:                                                  # Fibonacci word
+        x, y = np.array([a], np.uint8), np.array([a, b], np.uint8)
+        while len(y) < n: x, y = y, np.concatenate([y, x])
+        return y[:n]
+    if k == 1:                                                  # Thue-Morse
+        i = np.arange(n, dtype=np.uint32)
+        bits = i ^ (i >> 16); bits ^= bits >> 8; bits ^= bits >> 4; bits ^= bits >> 2; bits ^= bits >> 1
+        return np.where(bits & 1, b, a).astype(np.uint8)
+    if k == 2:                                                  # runs whose lengths sit around the sorter's capacities and powers of two
+        out, left = [], n
+        while left > 0:
+            L = int(rng.choice([1, 2, 3, 5, 6, 7, 63, 64, 65, 255, 256, 3839, 3840, 7679, 7680, 7681, 8192, 65535, 65536, 100000]))
+            L = min(L + int(rng.integers(0, 2)), left)
+            out.append(np.full(L, rng.choice([a, b, 0, 255]), np.uint8)); left -= L
+        return np.concatenate(out)
+    if k == 3:                                                  # a long period with sparse mutations
+        per = int(rng.integers(2, 70000))
+        x = np.resize(rng.integers(0, int(rng.integers(2, 257)), per, dtype=np.uint8), n).copy()
+        m = int(rng.integers(0, 1 + n // 1000))
+        if m: x[rng.integers(0, n, m)] ^= np.uint8(1)
+        return x
+    x = np.resize(np.arange(int(rng.integers(2, 257)), dtype=np.uint8), n).copy()   # a counter (every bigram distinct, every period equal)
+    return x[::-1].copy() if rng.random() < 0.5 else x
 
 
 def block():
-    n = int(rng.choice([rng.integers(1, 70000), rng.integers(60000, 300000), rng.integers(300000, (4 << 20) + 60000)], p=[0.15, 0.45, 0.4]))
+    n = int(rng.choice([rng.integers(1, 70000), rng.integers(60000, 300000), rng.integers(300000, (4 << 20) + 60000),
+                        rng.choice([65535, 65536, 65537, (4 << 20) - 1, 4 << 20, (4 << 20) + 1, (4 << 20) + 65536, (4 << 20) + 65537])], p=[0.15, 0.4, 0.35, 0.1]))
     parts, left = [], n
     while left > 0:
         m = left if rng.random() < 0.5 else int(rng.integers(1, left + 1))
