@@ -144,12 +144,18 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
     const uint64_t R = E & ((E << 1) | carryE);
     carryE = E >> 63;
     uint64_t N = valid & ~R;
+    uint64_t F = N & (R << 1);                                        // ranked positions right behind a skipped stretch: repair the key first
+    int jf;
+    asm("s_ff1_i32_b64 %0, %1" : "=s"(jf) : "s"(F));                   // next of them (-1: none)
     u32 outv = 0;
-    int prev = -1;
     while (N) {
       const int j = (int)__builtin_ctzll(N);
-      N &= N - 1;
-      if (j - prev - 1 > 0) KZ_SBRT_FIX_RUN(cp, row + j - 1)
+      asm("s_bitset0_b64 %0, %1" : "+s"(N) : "s"(j));                  // (N &= N - 1 costs three scalar instructions)
+      if (__builtin_expect(j == jf, 0)) {
+        KZ_SBRT_FIX_RUN(cp, row + j - 1)
+        asm("s_bitset0_b64 %0, %1" : "+s"(F) : "s"(j));
+        asm("s_ff1_i32_b64 %0, %1" : "=s"(jf) : "s"(F));
+      }
       const u32 c = (u32)__builtin_amdgcn_readlane((int)cur, j);
       const int cl = (int)(c & 63u), cs = (int)(c >> 6);
       const u64 ok = K[cs];
@@ -164,9 +170,8 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
       K[cs] = (lane == cl) ? nk : ok;
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(cntv), "s"(j) : "m0");   // outv[lane j] = rank
       cp = c;
-      prev = j;
     }
-    if (cnt - prev - 1 > 0) KZ_SBRT_FIX_RUN(cp, row + cnt - 1)
+    if ((R >> (cnt - 1)) & 1ULL) KZ_SBRT_FIX_RUN(cp, row + cnt - 1)    // the row ends inside a skipped stretch
     if (lane < cnt) d[row + lane] = (u8)outv;
     cur = nxt;
   }
