@@ -480,6 +480,28 @@ __global__ void k_ans_dec_index(const u8* __restrict__ in, int64_t inStride, con
   D.hdrOnly[b] = hdrOnly;
 }
 
+// freq2sym (the reverse mapping of ANSRangeDecoder.java:529-538) by SLOT: lane L fills slots [64 L, 64 L + 64) of the 2^lr <= 4096,
+// walking the cumulative table from the symbol that owns its first slot (binary search: the last symbol whose cumulative frequency is
+// <= the slot; symbols of frequency 0 share their successor's value and are stepped over).  By symbol -- every lane writing the run
+// of its symbol -- the wave waits for the most frequent symbol, a third of the table behind ZRLT: ~1 500 iterations per chunk.
+__device__ __forceinline__ void ans_fill_f2s(const u16* __restrict__ cumf, u8* __restrict__ f2s, int scale, int lane) {
+  const int x0 = lane * 64;
+  if (x0 >= scale) return;
+  int lo = 0, hi = 256;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)cumf[mid] <= x0) lo = mid; else hi = mid; }
+  int sy = lo;
+  int nextAt = (sy + 1 < 256) ? (int)cumf[sy + 1] : 0x7FFFFFFF;
+  for (int x = x0; x < x0 + 64; x += 4) {                          // (scale is a power of two >= 256: whole groups of four)
+    u32 w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      while (nextAt <= x + k) { sy++; nextAt = (sy + 1 < 256) ? (int)cumf[sy + 1] : 0x7FFFFFFF; }
+      w |= (u32)sy << (8 * k);
+    }
+    *(u32*)(f2s + x) = w;
+  }
+}
+
 // chunk decode: one wave per chunk
 __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in, int64_t inStride, const int64_t* __restrict__ d_bitOff,
                                                        const int32_t* __restrict__ d_len, AnsDec D, u8* __restrict__ dst, int64_t stride) {
@@ -499,7 +521,7 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
   __shared__ u16 freq[256];
   __shared__ u16 cumf[256];
   __shared__ u8 alpha[256];
-  __shared__ u8 f2s[4096];
+  __shared__ __attribute__((aligned(4))) u8 f2s[4096];
   __shared__ int sh_asz, sh_lr, sh_bad;
   __shared__ u64 sh_pos;
   for (int i = lane; i < 256; i += 64) freq[i] = 0;
@@ -563,14 +585,7 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
   // the encoder never goes above logRange 12 (ANSRangeEncoder.java:38); a header may still say up to 15, which the
   // reference accepts (:453-458): those chunks look symbols up by searching the cumulative table instead of f2s
   const bool wide = lr > 12;
-  if (!wide) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int s = q * 64 + lane;
-      const int fv = freq[s], c0 = cumf[s];
-      for (int j = 0; j < fv; j++) f2s[c0 + j] = (u8)s;
-    }
-  }
+  if (!wide) ans_fill_f2s(cumf, f2s, 1 << lr, lane);
   __syncthreads();
   // decodeChunkV2 :357-440
   u64 pos = sh_pos;
@@ -593,18 +608,24 @@ __global__ __launch_bounds__(64) void k_ans_dec_chunk(const u8* __restrict__ in,
     // window.  (Before: two 4-byte bit peeks per lane at the END of the step's dependent chain.)
     const u64 payByte = payloadBit >> 3;
     const u32 payShift = (u32)(payloadBit & 7);
-    const bool winOk = payByte + (u64)sz + 40 <= (u64)inStride;          // the window never reads past the block's slot
+    const bool winOk = payByte + (u64)sz + 48 <= (u64)inStride;          // the window never reads past the block's slot
     u32 wbase = 0;
-    u64 rHi = 0, rLo = 0, rNx = 0;
+    u64 rHi = 0, rLo = 0, rNx = 0, rNx2 = 0;                             // rNx, rNx2: raw words (byte-swapped when they enter the window)
     if (winOk) {
       rHi = __builtin_bswap64(*(const ans_u64_unaligned*)(p + payByte));
       rLo = __builtin_bswap64(*(const ans_u64_unaligned*)(p + payByte + 8));
-      rNx = __builtin_bswap64(*(const ans_u64_unaligned*)(p + payByte + 16));
+      rNx = *(const ans_u64_unaligned*)(p + payByte + 16);
+      rNx2 = *(const ans_u64_unaligned*)(p + payByte + 24);
     }
     for (int i = 0; i < end4; i += 4) {
       if (winOk && n > wbase + 7) {                                     // uniform over the four lanes (n is)
-        rHi = rLo; rLo = rNx; wbase += 8;
-        rNx = __builtin_bswap64(*(const ans_u64_unaligned*)(p + payByte + wbase + 16));
+        rHi = rLo; rLo = __builtin_bswap64(rNx); rNx = rNx2; wbase += 8;
+        // A malformed chunk may consume more than its size says: the address stops at the chunk's end (those bytes are never used).
+        // (The compiler copies the loaded word into the loop-carried register at once, i.e. waits for the load right here; the ~29
+        // waves per CU hide that.  Four or eight chunks per wave with the load issued from an asm statement and the stores batched at
+        // the slides were built and measured slower, 62 .. 100 ms against 67: the chunks of a wave slide at different steps, so the
+        // wave meets a wait for a just-issued operation on nearly every step.  DESIGN 5.0.)
+        rNx2 = *(const ans_u64_unaligned*)(p + payByte + min(wbase, sz) + 24);
       }
       u32 cur;
       if (!wide) cur = f2s[st & mask];

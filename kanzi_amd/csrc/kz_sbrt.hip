@@ -167,7 +167,9 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
       const u32 iv = (u32)(row + j);
       const u32 qc = (MODE == 2) ? ((iv + pc) >> 1) : ((MODE == 1 || MODE == 4) ? iv : pc);
       const u64 nk = ((u64)qc << 32) | (u64)(iv + 256u);
-      K[cs] = (lane == cl) ? nk : ok;
+      u64 upd = (lane == cl) ? nk : ok;
+      asm volatile("" : "+v"(upd));                                 // one 64-bit value: one indexed store (the halves took a gpr_idx region each)
+      K[cs] = upd;
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(cntv), "s"(j) : "m0");   // outv[lane j] = rank
       cp = c;
     }
