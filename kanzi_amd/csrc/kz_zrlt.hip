@@ -6,20 +6,18 @@
 //  expand"): run needs dstIdx < dstEnd-log2 (:94), escape dstIdx < dstEnd-1 (:111), literal
 //  dstIdx < dstEnd (:120); any violation => forward returns false (transform skipped).
 //
-// Parallel form: a token is emitted by the thread that owns the byte where it ENDS.  The length of
-// a zero run reaching back across threads/tiles is (own start) - (position after the last non-zero
-// byte before it), which is an exclusive MAX-scan of "last non-zero position + 1" -- done per
-// workgroup with wave shuffles + LDS and per block over tile summaries.  Output offsets are an
-// exclusive SUM-scan of token sizes over the same hierarchy.
+// Parallel form: a token is emitted by the lane that owns the byte where it ENDS (forward: one lane per
+// byte, rows of 64).  The length of a zero run reaching back across rows / waves / tiles is (own position) -
+// (position after the last non-zero byte before it), an exclusive MAX-scan of "last non-zero position + 1":
+// ballot masks inside a row, LDS between the waves of a tile, tile summaries over the block
+// (k_zrlt_f2).  Output offsets are an exclusive SUM-scan of token sizes over the same hierarchy.
 #include "kz_device.h"
 #include "kz_internal.h"
 
 typedef uint32_t u32;
 typedef uint8_t u8;
 
-#ifndef ZR_PER
-#define ZR_PER 16                     // forward: bytes per thread (64 was measured: f3 39 -> 97 ms, f1 20 -> 31 ms per 8 GiB: a lane
-#endif                                // reading 64 consecutive bytes strides the wave over 64 cache lines per load)
+#define ZR_PER 16                     // forward: bytes per thread of the tile's load (one 16-byte access)
 #define ZR_TILE (KZ_WG * ZR_PER)      // bytes per workgroup, forward
 #define ZI_PER 16                     // inverse: tokens are classified byte by byte with look-back
 #define ZI_TILE (KZ_WG * ZI_PER)
@@ -34,92 +32,6 @@ struct ZrScratch {
   int32_t* total; // [B]
   int T;
 };
-
-__device__ __forceinline__ void zr_load(const u8* s, int pos, int n, u8* v) {
-  if (pos + ZR_PER <= n) {
-#pragma unroll
-    for (int q4 = 0; q4 < ZR_PER / 16; q4++) { uint4 q = *(const uint4*)(s + pos + 16 * q4); memcpy(v + 16 * q4, &q, 16); }
-  } else {
-#pragma unroll
-    for (int k = 0; k < ZR_PER; k++) v[k] = (pos + k < n) ? s[pos + k] : 1;   // pad non-zero (never emitted)
-  }
-}
-
-// size of the tokens a thread emits for its 16-byte chunk, given `carry` zeros pending before it.
-// firstKnown=false: the run ending at the first non-zero byte is NOT counted (size unknown yet).
-__device__ __forceinline__ u32 zr_chunk_size(const u8* v, int cnt, u32 carry, bool firstKnown, bool isBlockEnd) {
-  u32 out = 0, run = carry;
-  bool first = true;
-#pragma unroll
-  for (int k = 0; k < ZR_PER; k++) {
-    if (k >= cnt) break;
-    if (v[k] == 0) { run++; continue; }
-    if (run > 0) { if (!first || firstKnown) out += (u32)kz_ilog2(run + 1); run = 0; }
-    first = false;
-    out += (v[k] >= 0xFE) ? 2u : 1u;
-  }
-  if (isBlockEnd && run > 0 && (!first || firstKnown)) out += (u32)kz_ilog2(run + 1);
-  return out;
-}
-
-// ---- forward 1/3 ------------------------------------------------------------------------------
-__global__ __launch_bounds__(KZ_WG) void k_zrlt_f1(const u8* __restrict__ src, int64_t stride, const int32_t* __restrict__ d_len, ZrScratch S) {
-  const int b = blockIdx.y, t = blockIdx.x;
-  const int n = d_len[b];
-  const int tstart = t * ZR_TILE;
-  if (tstart >= n) return;
-  __shared__ u32 lds[32];
-  const u8* s = src + (int64_t)b * stride;
-  const int pos = tstart + threadIdx.x * ZR_PER;
-  u8 v[ZR_PER];
-  int cnt = 0;
-  u32 lastnz = 0;
-  if (pos < n) {
-    zr_load(s, pos, n, v); cnt = min(ZR_PER, n - pos);
-#pragma unroll
-    for (int k = 0; k < ZR_PER; k++) if (k < cnt && v[k]) lastnz = (u32)(pos + k + 1);
-  }
-  u32 tot;
-  u32 inc = kz_wg_incl_max(lastnz, lds, &tot);
-  // exclusive max over previous threads
-  __shared__ u32 wl[4];
-  u32 prev = __shfl_up(inc, 1, 64);
-  if (kz_lane() == 63) wl[threadIdx.x >> 6] = inc;
-  __syncthreads();
-  if (kz_lane() == 0) prev = (threadIdx.x >> 6) ? wl[(threadIdx.x >> 6) - 1] : 0;
-  u32 sz = 0;
-  if (cnt > 0) {
-    const bool known = prev > 0;                       // a non-zero byte precedes us inside the tile
-    const u32 carry = known ? (u32)pos - prev : 0;
-    const bool blockEnd = (pos + cnt == n);
-    sz = zr_chunk_size(v, cnt, carry, known, blockEnd);
-    // a block-end trailing run whose start is unknown here (tile all zero) is added in f2
-  }
-  u32 total;
-  kz_wg_excl_sum(sz, lds, &total);
-  // leading zeros of the tile
-  if (threadIdx.x == 0) {
-    const int64_t o = (int64_t)b * S.T + t;
-    S.tLastNz[o] = tot;
-    S.tInner[o] = total;
-  }
-  // first non-zero position (min-reduce) -> tLead
-  u32 firstnz = 0xFFFFFFFFu;
-  if (cnt > 0) {
-#pragma unroll
-    for (int k = ZR_PER - 1; k >= 0; k--) if (k < cnt && v[k]) firstnz = (u32)(pos + k);
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) { u32 o = __shfl_xor(firstnz, d, 64); firstnz = o < firstnz ? o : firstnz; }
-  __shared__ u32 wf[4];
-  if (kz_lane() == 0) wf[threadIdx.x >> 6] = firstnz;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    u32 f = min(min(wf[0], wf[1]), min(wf[2], wf[3]));
-    const int tlen = min(ZR_TILE, n - tstart);
-    S.tLead[(int64_t)b * S.T + t] = (f == 0xFFFFFFFFu) ? (u32)tlen : f - (u32)tstart;
-  }
-}
 
 // ---- forward 2/3: per block scan over tiles (one wave) ----------------------------------------
 __global__ __launch_bounds__(64) void k_zrlt_f2(const int32_t* __restrict__ d_len, ZrScratch S) {
@@ -164,69 +76,193 @@ __global__ __launch_bounds__(64) void k_zrlt_f2(const int32_t* __restrict__ d_le
   if (lane == 0) { S.total[b] = (int32_t)carrySum; S.fail[b] = 0; }
 }
 
-// ---- forward 3/3: emit ----------------------------------------------------------------------------
-__global__ __launch_bounds__(KZ_WG) void k_zrlt_f3(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
-                                                    const int32_t* __restrict__ d_len, ZrScratch S) {
+// ---- forward 1/3 and 3/3, one LANE per byte ----------------------------------------------------------------------------------
+// Until round 4 every thread took 16 consecutive bytes and walked them with per-lane control flow (zero? run ends? how many
+// digits?): ~4 300 instructions per wave and kilobyte, most of them exec-mask bookkeeping, and sixteen scattered one-byte stores per
+// lane (k_zrlt_f3 37 ms per 8 GiB; now 16).  Here a wave takes its kilobyte as 16 rows of 64 bytes, one byte per lane: the non-zero bytes of a row are a ballot mask, the zero run in front of a non-zero
+// byte is the distance to the previous set bit (or to the last non-zero byte of the rows / waves / tiles before), output offsets are
+// a wave scan per row.  The tile summaries are the ones k_zrlt_f2 expects (same definitions as above).
+#define ZR_WROWS 16                  // rows of 64 bytes per wave: KZ_WG / 64 waves x 16 x 64 = ZR_TILE
+static_assert(ZR_TILE == (KZ_WG / 64) * ZR_WROWS * 64, "ZRLT forward tile geometry");
+
+// the tile enters LDS with one 16-byte load per thread (zeros behind the block's end); the rows are read from there
+#define ZR_LOAD_ROWS(INB)                                                                                \
+  {                                                                                                      \
+    const int p16 = tstart + 16 * (int)threadIdx.x;                                                      \
+    uint4 q = make_uint4(0u, 0u, 0u, 0u);                                                                \
+    if (p16 + 16 <= n) q = *(const uint4*)(s + p16);                                                     \
+    else if (p16 < n) { u8 tb[16]; for (int k = 0; k < 16; k++) tb[k] = (p16 + k < n) ? s[p16 + k] : (u8)0; memcpy(&q, tb, 16); } \
+    ((uint4*)(INB))[threadIdx.x] = q;                                                                    \
+  }                                                                                                      \
+  __syncthreads();                                                                                       \
+  u32 v[ZR_WROWS]; uint64_t nz[ZR_WROWS];                                                                \
+  u32 myLast = 0, myFirst = 0xFFFFFFFFu;                      /* abs position + 1 of the wave's last / abs position of its first non-zero byte */ \
+  _Pragma("unroll") for (int r = 0; r < ZR_WROWS; r++) {                                                 \
+    v[r] = (u32)(INB)[wave * (64 * ZR_WROWS) + 64 * r + lane];                                           \
+    nz[r] = kz_ballot(v[r] != 0u);                                                                       \
+    if (nz[r]) {                                                                                         \
+      myLast = (u32)(wbase + 64 * r + 64 - (int)__builtin_clzll(nz[r]));                                 \
+      if (myFirst == 0xFFFFFFFFu) myFirst = (u32)(wbase + 64 * r + (int)__builtin_ctzll(nz[r]));         \
+    }                                                                                                    \
+  }
+
+__global__ __launch_bounds__(KZ_WG) void k_zrlt_f1(const u8* __restrict__ src, int64_t stride, const int32_t* __restrict__ d_len, ZrScratch S) {
   const int b = blockIdx.y, t = blockIdx.x;
   const int n = d_len[b];
   const int tstart = t * ZR_TILE;
   if (tstart >= n) return;
-  __shared__ u32 lds[32];
-  __shared__ u32 wl[4];
+  const u8* s = src + (int64_t)b * stride;
+  const int wave = threadIdx.x >> 6, lane = kz_lane();
+  const int wbase = tstart + wave * (64 * ZR_WROWS);
+  __shared__ u32 wLast[KZ_WG / 64], wFirst[KZ_WG / 64], wSum[KZ_WG / 64];
+  __shared__ __attribute__((aligned(16))) u8 inb[ZR_TILE];
+  ZR_LOAD_ROWS(inb)
+  if (lane == 0) { wLast[wave] = myLast; wFirst[wave] = myFirst; }
+  __syncthreads();
+  u32 carryLast = 0;                                            // abs position + 1 of the last non-zero byte before the row, INSIDE the tile (0: none)
+  for (int w = 0; w < wave; w++) carryLast = max(carryLast, wLast[w]);
+  const uint64_t lt = kz_lanemask_lt();
+  u32 sum = 0;
+#pragma unroll
+  for (int r = 0; r < ZR_WROWS; r++) {
+    const uint64_t m = nz[r];
+    if (m == 0) continue;                                       // uniform
+    const int pos = wbase + 64 * r + lane;
+    const uint64_t below = m & lt;
+    const u32 prevp1 = below ? (u32)(wbase + 64 * r + 64 - (int)__builtin_clzll(below)) : carryLast;
+    if ((m >> lane) & 1ULL) {
+      u32 tok = (v[r] >= 0xFEu) ? 2u : 1u;
+      // the run in front of the tile's first non-zero byte starts in an earlier tile: k_zrlt_f2 adds its digits
+      if (prevp1 > 0u && (u32)pos > prevp1) tok += (u32)kz_ilog2((u32)pos - prevp1 + 1u);
+      sum += tok;
+    }
+    carryLast = (u32)(wbase + 64 * r + 64 - (int)__builtin_clzll(m));
+  }
+  const u32 inc = kz_wave_incl_sum(sum);
+  if (lane == 63) wSum[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 tileLast = 0, tileFirst = 0xFFFFFFFFu, total = 0;
+    for (int w = 0; w < KZ_WG / 64; w++) { tileLast = max(tileLast, wLast[w]); tileFirst = min(tileFirst, wFirst[w]); total += wSum[w]; }
+    const int tend = min(tstart + ZR_TILE, n);
+    // the block's trailing run is counted here when a non-zero byte precedes it inside the tile (else in k_zrlt_f2)
+    if (tend == n && tileLast > 0u && (u32)n > tileLast) total += (u32)kz_ilog2((u32)n - tileLast + 1u);
+    const int64_t o = (int64_t)b * S.T + t;
+    S.tLastNz[o] = tileLast;
+    S.tInner[o] = total;
+    S.tLead[o] = (tileFirst == 0xFFFFFFFFu) ? (u32)(tend - tstart) : tileFirst - (u32)tstart;
+  }
+}
+
+__global__ __launch_bounds__(KZ_WG) void k_zrlt_f3(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                                                     const int32_t* __restrict__ d_len, ZrScratch S) {
+  const int b = blockIdx.y, t = blockIdx.x;
+  const int n = d_len[b];
+  const int tstart = t * ZR_TILE;
+  if (tstart >= n) return;
   const u8* s = src + (int64_t)b * stride;
   u8* d = dst + (int64_t)b * stride;
-  const int pos = tstart + threadIdx.x * ZR_PER;
-  u8 v[ZR_PER];
-  int cnt = 0;
-  u32 lastnz = 0;
-  if (pos < n) {
-    zr_load(s, pos, n, v); cnt = min(ZR_PER, n - pos);
-#pragma unroll
-    for (int k = 0; k < ZR_PER; k++) if (k < cnt && v[k]) lastnz = (u32)(pos + k + 1);
-  }
-  u32 tot;
-  u32 inc = kz_wg_incl_max(lastnz, lds, &tot);
-  u32 prev = __shfl_up(inc, 1, 64);
-  if (kz_lane() == 63) wl[threadIdx.x >> 6] = inc;
+  const int wave = threadIdx.x >> 6, lane = kz_lane();
+  const int wbase = tstart + wave * (64 * ZR_WROWS);
+  __shared__ u32 wLast[KZ_WG / 64], wSum[KZ_WG / 64];
+  // The tile's tokens are contiguous in the output ([tileBase, tileBase + total)): they are put together in LDS, at the output's
+  // alignment modulo 16, and copied out in aligned 16-byte pieces.  At most two bytes per input byte plus one long run: 2 ZR_TILE + 32.
+  __shared__ __attribute__((aligned(16))) u8 stage[2 * ZR_TILE + 64];
+  ZR_LOAD_ROWS(stage)                                           // (the staging buffer holds the input first: nothing is staged before the next barrier)
+  (void)myFirst;
+  if (lane == 0) wLast[wave] = myLast;
   __syncthreads();
-  if (kz_lane() == 0) prev = (threadIdx.x >> 6) ? wl[(threadIdx.x >> 6) - 1] : 0;
-  const u32 tileP = S.tP[(int64_t)b * S.T + t];
-  const u32 P = prev > tileP ? prev : tileP;
-  const u32 carry = (cnt > 0) ? (u32)pos - P : 0;
-  const bool blockEnd = (cnt > 0) && (pos + cnt == n);
-  u32 sz = (cnt > 0) ? zr_chunk_size(v, cnt, carry, true, blockEnd) : 0;
-  u32 total;
-  u32 off = kz_wg_excl_sum(sz, lds, &total) + S.tOff[(int64_t)b * S.T + t];
-  if (cnt == 0) return;
-  // emit with the reference's bound checks; dstEnd = n
+  const u32 tileP = S.tP[(int64_t)b * S.T + t];               // abs position + 1 of the last non-zero byte before the tile (0: none)
+  const u32 tileBase = S.tOff[(int64_t)b * S.T + t];
+  const u32 base16 = tileBase & ~15u;
+  u32 carry0 = tileP;
+  for (int w = 0; w < wave; w++) carry0 = max(carry0, wLast[w]);
+  const uint64_t lt = kz_lanemask_lt();
+  // pass 1: token sizes (run digits + 1 or 2), the run's length + 1 kept for pass 2
+  u32 tokv[ZR_WROWS], rlv[ZR_WROWS];
+  u32 sum = 0;
+  {
+    u32 carryLast = carry0;
+#pragma unroll
+    for (int r = 0; r < ZR_WROWS; r++) {
+      const uint64_t m = nz[r];
+      tokv[r] = 0; rlv[r] = 1;
+      if (m == 0) continue;                                     // uniform
+      const int pos = wbase + 64 * r + lane;
+      const uint64_t below = m & lt;
+      const u32 prevp1 = below ? (u32)(wbase + 64 * r + 64 - (int)__builtin_clzll(below)) : carryLast;
+      if ((m >> lane) & 1ULL) {
+        const u32 rl = (u32)pos - prevp1 + 1u;                  // zero run in front of this byte, + 1
+        rlv[r] = rl;
+        tokv[r] = ((v[r] >= 0xFEu) ? 2u : 1u) + (u32)kz_ilog2(rl);
+        sum += tokv[r];
+      }
+      carryLast = (u32)(wbase + 64 * r + 64 - (int)__builtin_clzll(m));
+    }
+  }
+  {
+    const u32 inc = kz_wave_incl_sum(sum);
+    if (lane == 63) wSum[wave] = inc;
+  }
+  __syncthreads();
+  u32 off0 = tileBase, inner = 0, tileLast = 0;
+  for (int w = 0; w < KZ_WG / 64; w++) { if (w < wave) off0 += wSum[w]; inner += wSum[w]; tileLast = max(tileLast, wLast[w]); }
+  // pass 2: emit with the reference's bound checks; dstEnd = n
   const u32 dstEnd = (u32)n;
-  u32 run = carry;
   bool fail = false;
 #pragma unroll
-  for (int k = 0; k <= ZR_PER; k++) {
-    if (k > cnt) break;
-    if (k < cnt && v[k < ZR_PER ? k : 0] == 0) { run++; continue; }
-    if (k == cnt && !blockEnd) break;
-    if (run > 0) {
-      const u32 rl = run + 1;
-      int lg = kz_ilog2(rl);
-      if (off + (u32)lg >= dstEnd) { fail = true; off += (u32)lg; }      // ZRLT.java:94  dstIdx >= dstEnd - log2
-      else { while (lg > 0) { lg--; d[off++] = (u8)((rl >> lg) & 1); } }
-      run = 0;
+  for (int r = 0; r < ZR_WROWS; r++) {
+    if (nz[r] == 0) continue;                                   // uniform
+    const u32 tok = tokv[r];
+    const u32 inc = kz_wave_incl_sum(tok);
+    u32 off = off0 + inc - tok;
+    off0 += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+    const u32 rl = rlv[r];
+    const int lg = kz_ilog2(rl);
+    const bool runBad = (lg > 0) && (off + (u32)lg >= dstEnd);            // ZRLT.java:94  dstIdx >= dstEnd - log2
+    fail |= runBad;
+    for (int dg = 0; kz_ballot(dg < lg) != 0; dg++)
+      if (dg < lg && !runBad) stage[off + (u32)dg - base16] = (u8)((rl >> (lg - 1 - dg)) & 1u);
+    off += (u32)lg;
+    if (tok != 0u) {
+      const u32 val = v[r];
+      if (val >= 0xFEu) {
+        if (off + 1u >= dstEnd) fail = true;                               // :111
+        else { stage[off - base16] = 0xFF; stage[off + 1u - base16] = (u8)(val - 0xFEu); }
+      } else {
+        if (off >= dstEnd) fail = true;                                    // :120
+        else stage[off - base16] = (u8)(val + 1u);
+      }
     }
-    if (k == cnt) break;
-    const u32 val = v[k < ZR_PER ? k : 0];
-    if (val >= 0xFE) {
-      if (off + 1 >= dstEnd) fail = true;                        // :111
-      else { d[off] = 0xFF; d[off + 1] = (u8)(val - 0xFE); }
-      off += 2;
-    } else {
-      if (off >= dstEnd) fail = true;                            // :120
-      else d[off] = (u8)(val + 1);
-      off += 1;
+  }
+  // the block's trailing run (:217-228 of the forward loop's tail): behind every other token of the last tile
+  u32 total = inner;
+  {
+    const int tend = min(tstart + ZR_TILE, n);
+    const u32 lastAll = max(tileP, tileLast);
+    if (tend == n && (u32)n > lastAll) {
+      const u32 rl = (u32)n - lastAll + 1u;
+      const int lg = kz_ilog2(rl);
+      if (threadIdx.x == 0) {
+        const u32 off = tileBase + inner;
+        if (off + (u32)lg >= dstEnd) fail = true;
+        else for (int dg = 0; dg < lg; dg++) stage[off + (u32)dg - base16] = (u8)((rl >> (lg - 1 - dg)) & 1u);
+      }
+      total += (u32)lg;
     }
   }
   if (fail) atomicOr(&S.fail[b], 1);
+  __syncthreads();
+  // (a block that failed a check is declined and its output discarded, k_zrlt_ffin: nothing is written at or behind dstEnd)
+  const u32 endLim = min(tileBase + total, dstEnd);
+  const bool al = (((uintptr_t)d) & 15) == 0;                      // (the batch buffers are: 256-byte aligned slots)
+  for (u32 g0 = base16 + 16u * threadIdx.x; g0 < endLim; g0 += 16u * KZ_WG) {
+    if (al && g0 >= tileBase && g0 + 16 <= endLim) *(uint4*)(d + g0) = *(const uint4*)(stage + (g0 - base16));
+    else {
+#pragma unroll
+      for (int k = 0; k < 16; k++) { const u32 g = g0 + k; if (g >= tileBase && g < endLim) d[g] = stage[g - base16]; }
+    }
+  }
 }
 
 // finalize: applied -> length = total ; declined -> copy input through (Sequence.java:95-105)
