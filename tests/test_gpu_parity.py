@@ -87,6 +87,57 @@ def _group_shape_inputs():
 
 
 @pytest.mark.gpu
+def test_zrlt_forward_seams_match_oracle(ctx):
+    """The forward ZRLT works on rows of 64 bytes, waves of 1 KiB and tiles of 4 KiB: zero runs of every length class across those
+    seams, dense escapes (the transform declines), all-zero blocks, ragged batches (tools/zrlt_fuzz.py is the long form)."""
+    rng = np.random.default_rng(20260929)
+    runs = [1, 2, 3, 7, 8, 62, 63, 64, 65, 127, 128, 1023, 1024, 1025, 4095, 4096, 4097, 8192, 70000]
+
+    def block(n, kind):
+        if kind == 0:
+            out, left = [], n
+            while left > 0:
+                L = min(int(rng.choice(runs)), left)
+                out.append(np.zeros(L, np.uint8)); left -= L
+                m = min(int(rng.integers(1, 5)), left)
+                lit = rng.integers(1, 256, m, dtype=np.uint8)
+                lit[rng.random(m) < 0.3] = 0xFF
+                out.append(lit); left -= m
+            return np.concatenate(out)[:n]
+        if kind == 1:
+            x = np.zeros(n, np.uint8)
+            x[rng.integers(0, n, max(1, n // 700))] = 0xFE
+            return x
+        if kind == 2:
+            return rng.choice(np.array([0xFE, 0xFF, 1, 0], np.uint8), n, p=[0.4, 0.4, 0.1, 0.1])
+        x = np.zeros(n, np.uint8)
+        if kind == 3:
+            x[-1] = 7
+        return x
+
+    sizes = [63, 64, 65, 1023, 1024, 1025, 4095, 4096, 4097, 8192, 12289, 65536, 200001, 1 << 20]
+    blocks = [np.ascontiguousarray(block(n, k)) for n in sizes for k in range(5)]
+    for b0 in range(0, len(blocks), 7):
+        bl = blocks[b0:b0 + 7]
+        bs = max(len(b) for b in bl)
+        inp = np.zeros((len(bl), bs), np.uint8)
+        lens = np.array([len(b) for b in bl], np.int32)
+        for i, b in enumerate(bl):
+            inp[i, :len(b)] = b
+        ostride = kz.max_block_stream_bytes(bs)
+        out = np.zeros((len(bl), ostride), np.uint8)
+        res = kz.encode_blocks(ctx, "ZRLT", "NONE", inp, bs, lens, out, ostride)
+        bits = np.array([r.bits for r in res], np.int64)
+        dec = np.zeros((len(bl), bs), np.uint8)
+        res2 = kz.decode_blocks(ctx, "ZRLT", "NONE", bs, out, ostride, bits, dec, bs)
+        for i, b in enumerate(bl):
+            so, w, sf, pl = oracle.encode_block("ZRLT", "NONE", b)
+            assert res[i].status == 0 and (res[i].bits, res[i].skipFlags, res[i].length) == (w, sf, pl), (len(b), b0 + i)
+            assert out[i, :(w + 7) // 8].tobytes() == so, (len(b), b0 + i)
+            assert res2[i].status == 0 and dec[i, :len(b)].tobytes() == b.tobytes()
+
+
+@pytest.mark.gpu
 def test_bwt_forward_group_shapes_match_oracle(ctx, monkeypatch):
     """BWT is unique: every path of the suffix sort must give the oracle's bytes and primary indexes.
     The same inputs are run with the bucket path switched off (KZ_BWT_BUCKETS=0: LSD passes only), batched."""
