@@ -296,8 +296,8 @@ __device__ __forceinline__ bool zr_is_payload(const u8* s, int i) {
 // encoder writes -- wrap, and the reference then emits the wrapped count (or nothing when it is <= 0).  A run that
 // reaches the end of the input goes through the trailing branch (:217-228), whose test differs at INT_MIN only.
 // A count that cannot fit fails later through the total (every such case dies in the reference as well).
-__device__ __forceinline__ u32 zr_inv_token(const u8* s, int i, int n, bool* bad) {
-  (void)bad;
+// *end (optional): the input position behind the token, set when it starts here.
+__device__ __forceinline__ u32 zr_inv_token(const u8* s, int i, int n, int* end) {
   const u32 v = s[i];
   const bool payload = zr_is_payload(s, i);
   if (payload) return 0;
@@ -315,15 +315,17 @@ __device__ __forceinline__ u32 zr_inv_token(const u8* s, int i, int n, bool* bad
         k += 8;
       }
     }
+    if (end) *end = k;
     if (k >= n) return ((int32_t)rl > 0) ? rl - 1u : 0u;
     const int32_t r = (int32_t)(rl - 1u);
     return (r > 0) ? (u32)r : 0u;
   }
+  if (end) *end = (v == 0xFF) ? i + 2 : i + 1;
   if (v == 0xFF) return (i + 1 < n) ? 1u : 0u;
   return 1u;
 }
 
-struct ZiScratch { u32* tSum; u32* tOff; int32_t* total; int32_t* fail; int T; };
+struct ZiScratch { u32* tSum; u32* tOff; u32* tEnd; int32_t* total; int32_t* fail; int T; };   // tEnd: input position behind the tile's last token that produces output (0: none)
 
 __global__ __launch_bounds__(KZ_WG) void k_zrlt_i1(const u8* __restrict__ src, int64_t stride, const int32_t* __restrict__ d_len, ZiScratch S) {
   const int b = blockIdx.y, t = blockIdx.x;
@@ -333,17 +335,21 @@ __global__ __launch_bounds__(KZ_WG) void k_zrlt_i1(const u8* __restrict__ src, i
   __shared__ __attribute__((aligned(8))) u32 lds[32];
   const u8* s = src + (int64_t)b * stride;
   const int pos = tstart + threadIdx.x * ZI_PER;
-  unsigned long long sz = 0; bool bad = false;
-  for (int k = 0; k < ZI_PER; k++) if (pos + k < n) sz += zr_inv_token(s, pos + k, n, &bad);
+  unsigned long long sz = 0;
+  int lastEnd = 0;                                                // behind the last token of this thread that produces output
+  for (int k = 0; k < ZI_PER; k++) if (pos + k < n) { int e = 0; const u32 one = zr_inv_token(s, pos + k, n, &e); sz += one; if (one) lastEnd = e; }
   // tile total, saturated: wrapped run counts can be anything below 2^31
-  for (int d = 1; d < 64; d <<= 1) sz += __shfl_xor(sz, d, 64);
+  for (int d = 1; d < 64; d <<= 1) { sz += __shfl_xor(sz, d, 64); lastEnd = max(lastEnd, __shfl_xor(lastEnd, d, 64)); }
   unsigned long long* l64 = (unsigned long long*)lds;
-  if ((threadIdx.x & 63) == 0) l64[threadIdx.x >> 6] = sz;
+  __shared__ int wEnd[KZ_WG / 64];
+  if ((threadIdx.x & 63) == 0) { l64[threadIdx.x >> 6] = sz; wEnd[threadIdx.x >> 6] = lastEnd; }
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned long long total = 0;
-    for (int w = 0; w < KZ_WG / 64; w++) total += l64[w];
+    int e = 0;
+    for (int w = 0; w < KZ_WG / 64; w++) { total += l64[w]; e = max(e, wEnd[w]); }
     S.tSum[(int64_t)b * S.T + t] = (total > 0xFFFFFFFFull) ? 0xFFFFFFFFu : (u32)total;
+    S.tEnd[(int64_t)b * S.T + t] = (u32)e;
   }
 }
 
@@ -354,16 +360,22 @@ __global__ __launch_bounds__(64) void k_zrlt_i2(const int32_t* __restrict__ d_le
   const int64_t o = (int64_t)b * S.T;
   const int lane = kz_lane();
   unsigned long long carry = 0;
+  u32 lastOut = 0;                                                  // input position behind the block's last token that produces output
   for (int base = 0; base < tiles; base += 64) {
     const int t = base + lane;
     const u32 v = (t < tiles) ? S.tSum[o + t] : 0;
+    lastOut = max(lastOut, (t < tiles) ? S.tEnd[o + t] : 0u);
     unsigned long long inc = v;                                     // 64-bit: tile totals may be saturated
     for (int d = 1; d < 64; d <<= 1) { const unsigned long long up = __shfl_up(inc, d, 64); if (lane >= d) inc += up; }
     if (t < tiles) S.tOff[o + t] = (u32)(carry + inc - v);          // only used when the total fits
     carry += __shfl(inc, 63, 64);
   }
+  for (int d = 1; d < 64; d <<= 1) lastOut = max(lastOut, (u32)__shfl_xor((int)lastOut, d, 64));
   if (lane == 0) {
-    if (carry > (unsigned long long)dstCap) { S.fail[b] = 1; S.total[b] = 0; }
+    // ZRLT.java:166-233 leaves its loop as soon as the output is full (dstIdx >= dstEnd, :214; a run that would end AT dstEnd, :184) and
+    // then reports whether the input was used up: an output that fits exactly is an error when input is left behind the token that
+    // filled it -- a lone escape at the end, an over-long run whose wrapped count is <= 0 (both produce nothing).
+    if (carry > (unsigned long long)dstCap || (carry == (unsigned long long)dstCap && lastOut < (u32)n)) { S.fail[b] = 1; S.total[b] = 0; }
     else S.total[b] = (int32_t)carry;
   }
 }
@@ -388,8 +400,8 @@ __global__ __launch_bounds__(KZ_WG) void k_zrlt_i3(const u8* __restrict__ src, u
   const u8* s = src + (int64_t)b * stride;
   u8* d = dst + (int64_t)b * stride;
   const int pos = tstart + threadIdx.x * ZI_PER;
-  u32 sz[ZI_PER]; u32 sum = 0; bool bad = false;
-  for (int k = 0; k < ZI_PER; k++) { sz[k] = (pos + k < n) ? zr_inv_token(s, pos + k, n, &bad) : 0; sum += sz[k]; }
+  u32 sz[ZI_PER]; u32 sum = 0;
+  for (int k = 0; k < ZI_PER; k++) { sz[k] = (pos + k < n) ? zr_inv_token(s, pos + k, n, nullptr) : 0; sum += sz[k]; }
   u32 total;
   u32 off = kz_wg_excl_sum(sum, lds, &total) + S.tOff[(int64_t)b * S.T + t];
   for (int k = 0; k < ZI_PER; k++) {
@@ -454,6 +466,7 @@ int kz_stage_zrlt_inverse(kz_ctx* ctx, kz_batch& bt, int dstCap) {
   S.T = (maxN + ZI_TILE - 1) / ZI_TILE + 1;
   S.tSum = (u32*)kz_arena_alloc(ctx, (size_t)B * S.T * 4);
   S.tOff = (u32*)kz_arena_alloc(ctx, (size_t)B * S.T * 4);
+  S.tEnd = (u32*)kz_arena_alloc(ctx, (size_t)B * S.T * 4);
   S.fail = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   S.total = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   if (!S.total) { snprintf(ctx->err, sizeof(ctx->err), "zrlt_inverse: arena overflow"); return -KZ_ERR_DEVICE; }

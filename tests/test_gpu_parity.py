@@ -138,6 +138,30 @@ def test_zrlt_forward_seams_match_oracle(ctx):
 
 
 @pytest.mark.gpu
+def test_zrlt_inverse_output_that_fits_exactly(ctx):
+    """ZRLT.java:166-233 leaves its loop the moment the output is full and then reports whether the input was used up: with a
+    lone escape (or a run that wraps to nothing) left behind the token that filled the buffer, an output that fits EXACTLY is an
+    error, one byte more of room makes it a success (found by tools/zrlt_inv_fuzz.py; tools/tightcap_fuzz.py does this for every
+    inverse transform)."""
+    cases = [bytes([5, 7, 0xFF]), bytes([9, 0, 1, 3, 0xFF]), bytes([2] * 70 + [0xFF]), bytes([0xFF, 1, 0, 0, 0, 8, 0xFF]),
+             bytes([3, 0xFF, 0xFF, 0xFF]), bytes([7] * 4100 + [0xFF])]
+    for data in cases:
+        ok_big, full = oracle.transform_inverse("ZRLT", data, 1 << 16)
+        assert ok_big
+        for cap in (len(full) - 1, len(full), len(full) + 1):
+            if cap < 1:
+                continue
+            ok_o, o = oracle.transform_inverse("ZRLT", data, cap)
+            src = kz.SliceByteArray(np.frombuffer(data, dtype=np.uint8).copy(), len(data), 0)
+            dst = kz.SliceByteArray(np.zeros(cap, dtype=np.uint8), cap, 0)
+            ok_p = kz.ZRLT(ctx).inverse(src, dst)
+            assert bool(ok_p) == bool(ok_o), (data[:8], cap)
+            if ok_o:
+                assert bytes(dst.array[:dst.index]) == o
+        assert not oracle.transform_inverse("ZRLT", data, len(full))[0] and oracle.transform_inverse("ZRLT", data, len(full) + 1)[0]
+
+
+@pytest.mark.gpu
 def test_bwt_forward_group_shapes_match_oracle(ctx, monkeypatch):
     """BWT is unique: every path of the suffix sort must give the oracle's bytes and primary indexes.
     The same inputs are run with the bucket path switched off (KZ_BWT_BUCKETS=0: LSD passes only), batched."""
