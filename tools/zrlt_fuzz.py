@@ -21,7 +21,20 @@ RUNS = [1, 2, 3, 4, 7, 8, 15, 16, 31, 62, 63, 64, 65, 127, 128, 129, 1023, 1024,
 def block():
     n = int(rng.choice([rng.integers(16, 300), rng.integers(300, 9000), rng.integers(9000, 200000), rng.integers(200000, 1 << 21),
                         rng.choice([63, 64, 65, 1023, 1024, 1025, 4095, 4096, 4097, 8192, 12288, 65536])]))
-    kind = int(rng.integers(0, 6))
+    kind = int(rng.integers(0, 8))
+    if kind >= 6:                                   # output length within a few bytes of n: the forward's three bound checks decide
+        x = rng.integers(1, 0xFE, n, dtype=np.uint8)                    # n literals -> n bytes
+        e = int(rng.integers(0, 6))                                      # e escapes: + e
+        z = int(rng.integers(0, 6))                                      # z runs of 2..3 zeros: - 1 each
+        where = rng.permutation(max(1, n // 4))[:e + z] * 4              # disjoint slots of 4 bytes
+        early = kind == 7                                                # escapes first, runs last: the offset runs ahead of the input
+        slots = np.sort(where)
+        if not early: slots = rng.permutation(slots)
+        for j, p0 in enumerate(slots):
+            if p0 + 3 >= n: continue
+            if j < e: x[p0] = rng.choice([0xFE, 0xFF])
+            else: x[p0:p0 + int(rng.integers(2, 4))] = 0
+        return np.ascontiguousarray(x)
     if kind == 0:                                   # runs of chosen lengths separated by a few literals
         out, left = [], n
         esc = rng.random() < 0.5
