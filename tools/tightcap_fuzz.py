@@ -50,6 +50,25 @@ while time.time() - t0 < budget:
     if len(pre) < 16: continue
     ok, good = oracle.transform_forward(name, pre)
     if not ok: continue
+    # forward with the output buffer at, just below and just above the reference's getMaxEncodedLength and the actual output length
+    mx = codec(name).getMaxEncodedLength(len(pre))
+    for cap in sorted(set(max(1, c) for c in (mx - 1, mx, mx + 1, len(good) - 1, len(good), len(good) + 1, len(pre)))):
+        try:
+            ok_o, o = oracle.transform_forward(name, pre, cap)
+        except oracle.TransformThrows:
+            continue
+        src = kz.SliceByteArray(np.frombuffer(pre, dtype=np.uint8).copy(), len(pre), 0)
+        dst = kz.SliceByteArray(np.zeros(cap, dtype=np.uint8), cap, 0)
+        ctx.set_data_type(0)                              # the block's "dataType" entry: LZ / MM read it, MM and others leave theirs behind
+        try:
+            ok_p = codec(name).forward(src, dst)
+        except kz.KanziError:
+            ok_p = False
+        cases += 1; per[name + ">"] = per.get(name + ">", 0) + 1
+        if not (bool(ok_p) == bool(ok_o) and (not ok_o or bytes(dst.array[:dst.index]) == o)):
+            bad += 1
+            np.save(os.path.join(ROOT, "gpurun_out", "tightcap_fwd_fail_%s_%d_%d.npy" % (name, seed, cases)), np.frombuffer(pre, np.uint8))
+            print("MISMATCH forward", name, "n", len(pre), "max", mx, "out", len(good), "cap", cap, "oracle", ok_o, (len(o) if ok_o else -1), "hip", bool(ok_p), dst.index, flush=True)
     data = good if rng.random() < 0.4 else bytes(refinputs.corrupt(rng, good, int(rng.integers(0, 8))))
     if len(data) == 0: continue
     okL, outL = oracle.transform_inverse(name, data, 4 * len(pre) + 65536)
