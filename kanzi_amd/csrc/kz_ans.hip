@@ -473,7 +473,10 @@ __global__ void k_ans_dec_index(const u8* __restrict__ in, int64_t inStride, con
       pos += 128 + 8ULL * sz;
       if (pos > endBits) { nIdx = c; event = c * 4 + ANS_EV_FAIL; break; }
     }
-  } else pos += 8ULL * (u64)(count > 0 ? count : 0);
+  } else {                                                          // :193-196 bulk read of the raw bytes: past the block's bits it throws
+    pos += 8ULL * (u64)(count > 0 ? count : 0);
+    if (pos > endBits) event = ANS_EV_FAIL;                          // (chunk 0)
+  }
   if (endOut) endOut[b] = (long long)pos;                          // bits consumed (EntropyDecoder contract)
   D.event[b] = event;
   D.nIdx[b] = nIdx;

@@ -406,16 +406,31 @@ __device__ __forceinline__ u32 huf_peek(const u8* __restrict__ p, u64 pos, int c
   acc <<= (pos & 7);
   return count ? (acc >> (32 - count)) : 0;
 }
-__device__ __forceinline__ int huf_eg_get(const u8* __restrict__ p, u64& pos, u64 endBits, bool& bad) {   // ExpGolombDecoder.java:41-58
+// ExpGolombDecoder.java:41-58 (signed) as Java computes it on ANY input: the zeros are counted until a 1 arrives (running off the
+// block's bits throws), readBits takes 1..64 bits (more: IllegalArgumentException, DefaultInputBitStream.java:98-99), `1 << log2`
+// is an int shift (count mod 32) and the result is cast to BYTE: a damaged header may decode to a small delta after 13 or 40 zeros,
+// and the reference then goes on.  Only the low 9 bits of the (log2 + 1)-bit field reach the byte.
+__device__ __forceinline__ int huf_eg_get(const u8* __restrict__ p, u64& pos, u64 endBits, bool& bad) {
+  if (pos + 1 > endBits) { bad = true; return 0; }
   if (huf_peek(p, pos, 1) == 1) { pos += 1; return 0; }
   pos += 1;
   int log2 = 1;
-  while (huf_peek(p, pos, 1) == 0) { pos += 1; log2++; if (log2 > 12 || pos > endBits) { bad = true; return 0; } }
-  pos += 1;
-  int res = (int)huf_peek(p, pos, log2 + 1); pos += log2 + 1;
-  const int sgn = res & 1;
-  res = (res >> 1) + (1 << log2) - 1;
-  return sgn ? -res : res;
+  for (;;) {
+    if (pos + 1 > endBits) { bad = true; return 0; }
+    const u32 bit = huf_peek(p, pos, 1);
+    pos += 1;
+    if (bit) break;
+    log2++;
+  }
+  if (log2 + 1 > 64 || pos + (u64)(log2 + 1) > endBits) { bad = true; return 0; }
+  const int take = min(9, log2 + 1);
+  const u32 v = huf_peek(p, pos + (u64)(log2 + 1 - take), take);      // the field's last bits
+  pos += (u64)(log2 + 1);
+  const u32 sgn = v & 1u;
+  const u32 k8 = ((log2 & 31) < 8) ? (1u << (log2 & 31)) : 0u;          // low byte of (int)(1 << log2)
+  const u32 t = (v >> 1) + k8 - 1u;
+  const u32 r = sgn ? ~(t - 1u) : t;                                   // (res - sgn) ^ -sgn, low byte
+  return (int)(int8_t)(u8)r;
 }
 __device__ __forceinline__ u32 huf_varint(const u8* __restrict__ p, u64& pos) {
   u32 v = huf_peek(p, pos, 8); pos += 8;
@@ -438,7 +453,11 @@ __global__ void k_huf_dec_index(const u8* __restrict__ in, int64_t inStride, con
   for (int c = 0; c < chunks && !status; c++) {
     D.chunkBit[(int64_t)b * D.C + c] = pos;
     const int size = min(ANS_CHUNK, count - c * ANS_CHUNK);
-    if (size < 32) { pos += 8ULL * size; continue; }
+    if (size < 32) {                                                // :364-366 bulk read of the raw bytes: past the block's bits it throws
+      pos += 8ULL * size;
+      if (pos > endBits) status = -KZ_ERR_PROCESS_BLOCK;
+      continue;
+    }
     if (pos + 2 > endBits) { status = -KZ_ERR_PROCESS_BLOCK; break; }
     int asz;
     if (huf_peek(p, pos, 1) == 0) { asz = (huf_peek(p, pos + 1, 1) == 1) ? 0 : 256; pos += 2; }

@@ -23,14 +23,19 @@ static void eg_put(kzo_obs* bs, int v) {
   uint32_t bits = (1u << (k + 1)) | ((uint32_t)m << 1) | (v < 0 ? 1u : 0u);
   kzo_obs_write(bs, bits, 2 * k + 2);
 }
-static int eg_get(kzo_ibs* bs) {                       /* ExpGolombDecoder.java:41-58 (signed) */
+/* ExpGolombDecoder.java:41-58 (signed), as Java computes it on ANY input: the zeros are counted until a 1 arrives (the end of the
+ * stream throws), readBits takes 1..64 bits (more: IllegalArgumentException), `1 << log2` is an int shift (count mod 32, sign
+ * extended) and the result is cast to byte.  A damaged header can therefore decode to a small delta after 13 or 40 zeros. */
+static int eg_get(kzo_ibs* bs) {
   if (kzo_ibs_read(bs, 1) == 1) return 0;
   int log2 = 1;
-  while (kzo_ibs_read(bs, 1) == 0) { log2++; if (bs->error || log2 > 30) return 0; }
-  int64_t res = (int64_t)kzo_ibs_read(bs, log2 + 1);
-  int64_t sgn = res & 1;
-  res = (res >> 1) + (1LL << log2) - 1;
-  return (int)(int8_t)((res - sgn) ^ -sgn);
+  while (kzo_ibs_read(bs, 1) == 0) { log2++; if (bs->error) return 0; }
+  if (bs->error) return 0;
+  if (log2 + 1 > 64) { bs->error = 1; return 0; }       /* DefaultInputBitStream.java:98-99 */
+  uint64_t res = kzo_ibs_read(bs, log2 + 1);
+  uint64_t sgn = res & 1;
+  res = (res >> 1) + (uint64_t)(int64_t)(int32_t)(1u << (log2 & 31)) - 1;
+  return (int)(int8_t)((res - sgn) ^ (0 - sgn));
 }
 
 static int cmp_int(const void* a, const void* b) { int x = *(const int*)a, y = *(const int*)b; return (x > y) - (x < y); }

@@ -680,6 +680,39 @@ def test_entropy_decoders_follow_the_reference_on_corrupted_input(ctx, ent):
                 assert bytes(buf) == o, (ent, src_kind, trial)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ent", ["ANS0", "HUFFMAN", "FPAQ", "NONE"])
+def test_entropy_decoders_with_wrong_count_or_cut_bits(ctx, ent):
+    """A damaged block header asks the decoder for a symbol count the payload was not written for, or the payload is shorter than
+    the decoder needs: the raw tails (Huffman chunks below 32 symbols, ANS blocks up to 32) are bulk reads that throw past the
+    block's bits (HuffmanDecoder.java:364-366, ANSRangeDecoder.java:193-196), and a zeroed tail sends the Exp-Golomb length
+    decoder through Java's int shift and byte cast (ExpGolombDecoder.java:41-58).  Verdict and bytes are the oracle's
+    (tools/entropy_count_fuzz.py is the long form: 234 000 cases)."""
+    dec = {"ANS0": kz.ANSRangeDecoder, "HUFFMAN": kz.HuffmanDecoder, "FPAQ": kz.FPAQDecoder, "NONE": kz.NullEntropyDecoder}[ent]
+    rng = np.random.default_rng(9)
+    compared = 0
+    for n in (27, 33, 180, 16384, 16386, 32770):
+        for kind in (0, 1):
+            data = datagen.block(n + kind, n, kind).tobytes()
+            good, nbits = oracle.entropy_encode(ent, data)
+            streams = [good]
+            if len(good) > 16:
+                z = bytearray(good); z[len(z) // 8:] = bytes(len(z) - len(z) // 8); streams.append(bytes(z))     # zeroed tail
+                streams.append(bytes(refinputs.corrupt(rng, good, 0)))
+            for st in streams:
+                nbmax = min(nbits, len(st) * 8)
+                for count in sorted(set(max(1, c) for c in (n - 1, n, n + 1, 32, 33, n + 16384))):
+                    for nb in sorted(set(max(0, b) for b in (nbmax, nbmax - 1, nbmax - 8, nbmax // 2))):
+                        r, o, _ = oracle.entropy_decode(ent, st, nb, count)
+                        buf = np.zeros(count, dtype=np.uint8)
+                        ok_p = dec(ctx, st, nb).decode(buf, 0, count) == count
+                        assert ok_p == (r == count), (ent, n, kind, count, nb, nbits)
+                        if ok_p:
+                            assert bytes(buf) == o, (ent, n, kind, count, nb)
+                        compared += 1
+    assert compared > 400
+
+
 @pytest.mark.parametrize("chain,ent", [("BWT+RANK+ZRLT", "ANS0"), ("BWT+SRT+ZRLT", "FPAQ"), ("PACK+MM+LZX", "HUFFMAN")])
 def test_batched_decode_isolates_corrupted_blocks(ctx, chain, ent):
     """kz_decode_blocks on a batch where a few blocks are corrupted: every block gets the status (or the bytes) the
