@@ -175,7 +175,7 @@ def compact_roofline(r):
     if not r:
         return None
     keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "stage", "avg_launch_ms", "launches_per_step",
-            "kernel_ms_per_step", "stage_ms_per_step", "alg_bytes_per_launch", "pipeline_frac", "measured_copy_GBs", "traffic_GBs")
+            "kernel_ms_per_step", "stage_ms_per_step", "alg_bytes_per_launch", "pipeline_frac", "measured_copy_GBs", "traffic_GBs", "traffic_source")
     return {k: _r(r[k]) for k in keep if k in r}
 
 
@@ -192,12 +192,14 @@ def compact(out):
                              "roofline": compact_roofline(ch["roofline"])}
         if ch.get("host_stage_ms_per_step"):
             cc["chains"][key]["host_stage_ms"] = {k: _r(v) for k, v in ch["host_stage_ms_per_step"].items()}
+        if ch.get("host_share8"):
+            cc["chains"][key]["host_share8"] = {k: _r(v) for k, v in ch["host_share8"].items() if k != "what"}
     cc["shapes"] = {}
     for key, sh in c["shapes"].items():
         if key == "silesia_by_class":
             cc["shapes"][key] = {n: _r(v["enc_dec_MBps"]) for n, v in sh.items()}
             continue
-        row = {k: _r(v) for k, v in sh.items() if k in ("blocks", "bytes", "scaling", "chain")}
+        row = {k: _r(v) for k, v in sh.items() if k in ("blocks", "bytes", "scaling", "chain", "file", "knz_bytes", "knz_bytes_reference", "vs_reference_published")}
         for a, b in (("encode_MBps", "enc"), ("decode_MBps", "dec"), ("compress_MBps", "enc"), ("decompress_MBps", "dec"), ("enc_dec_MBps", "enc_dec")):
             if a in sh:
                 row[b] = _r(sh[a])
@@ -216,7 +218,7 @@ def compact(out):
         o["cpu_baseline"]["usable_cpus"] = cb["host"]["usable_cpus"]
     else:
         o["cpu_baseline"] = None
-    o["detail"] = "per-kernel tables and per-stage rooflines: profiles/%s_bench_kernels.json (same run, written by --detail-json)" % out.get("_tag", "r04")
+    o["detail"] = "per-kernel tables and per-stage rooflines: profiles/%s_bench_kernels.json (same run, written by --detail-json)" % out.get("_tag", "r05")
     return o
 
 
@@ -228,7 +230,9 @@ def load_traffic(path, B, chain, entropy):
         return None
     if tj.get("blocks_per_gpu_per_step") != B or tj.get("chain", "BWT+RANK+ZRLT") != chain or tj.get("entropy", "ANS0") != entropy:
         return None
-    tj["_path"] = os.path.relpath(path, ROOT)
+    # where the PMC bytes come from: the committed profile and the commit it was measured at (tools/profile_round.sh stamps
+    # KZ_GIT_SHA into the file; the kernel TIMES next to it are this run's own)
+    tj["_path"] = "%s @ %s" % (os.path.relpath(path, ROOT), tj.get("git_sha") or "unstamped")
     return tj
 
 
@@ -259,6 +263,38 @@ def text_mix(D, bs):
     return out
 
 
+# silesia.tar by member, in 4 MiB blocks (211 957 760 B): dickens 2.4, webster 9.9, reymont 1.6, samba 5.1, xml 1.3 (text, source,
+# mark-up: 20) + nci 8.0 (chemical database text, highly redundant); mozilla 12.2, ooffice 1.5 (executables: 14); mr 2.4, sao 1.7,
+# x-ray 2.0 (poorly compressible binary: 6); osdb 2.4 (database records).  The stand-in keeps those proportions:
+SILESIA_MIX = (("text-like (english / source / xml / utf-8)", 24), ("executable-like, mid entropy", 14), ("poorly compressible binary", 7),
+               ("64-byte records", 3), ("highly redundant (90% zeros)", 3))
+
+
+def silesia_mix(bs):
+    """51 blocks in silesia.tar's member proportions, members kept together as in the tar"""
+    import textgen
+    import datagen
+    out = np.empty((51, bs), dtype=np.uint8)
+    i = 0
+    for k in range(24):
+        kind = "xml" if k in (9, 10) else ("utf8" if k in (11, 12) else "english")
+        out[i] = textgen.bulk_text(bs, 2000 + k, kind)
+        i += 1
+    for k in range(14):
+        out[i] = datagen.exe_like(bs, 3000 + k)
+        i += 1
+    for k in range(7):
+        out[i] = datagen.sensor_like(bs, 4000 + k)
+        i += 1
+    for k in range(3):
+        out[i] = datagen.block(5000 + k, bs, 2)
+        i += 1
+    for k in range(3):
+        out[i] = datagen.block(6000 + k, bs, 4)
+        i += 1
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,6 +306,8 @@ def main():
     ap.add_argument("--chain", default="BWT+RANK+ZRLT")
     ap.add_argument("--entropy", default="ANS0")
     ap.add_argument("--data", default="mix", choices=("mix", "text"), help="mix = SURVEY 8d generator; text = the text-heavy mix of the level-exact rows")
+    ap.add_argument("--input", default="", help="a corpus file (silesia.tar, enwik9 ...): the headline, every chain and every shape read ITS bytes in "
+                    "--block-size blocks instead of the synthetic generator, and shapes.input reports the level-exact .knz size next to the README's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shapes", action="store_true", help="skip the silesia / enwik9 shaped batches and the host-buffer rates")
     ap.add_argument("--no-chains", action="store_true", help="skip config.chains (the other BASELINE configs)")
@@ -278,7 +316,7 @@ def main():
     ap.add_argument("--data-class", type=int, default=-1, help="diagnostic: force one class of the synthetic generator (0..4) instead of the mix")
     ap.add_argument("--detail-json", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
                     help="the full record (per-kernel tables, per-stage rooflines of every chain) is written here; the printed line is the compact form")
-    ap.add_argument("--profiles-tag", default="r04", help="profiles/<tag>_pmc_traffic*.json: per-kernel HBM bytes from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)")
+    ap.add_argument("--profiles-tag", default="r05", help="profiles/<tag>_pmc_traffic*.json: per-kernel HBM bytes from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)")
     ap.add_argument("--traffic-json", default="", help="override the PMC traffic file of the headline chain")
     ap.add_argument("--cpu-sample-blocks", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     args = ap.parse_args()
@@ -332,7 +370,22 @@ def main():
     ctx.set_block_size(bs)                                             # the stream's "blockSize" entry (TEXT sizes its hash map by it)
     # ---- synthetic stream: the D distinct blocks of global ids i*world + rank (round-robin over ranks), tiled ----
     D = min(args.distinct, B)
-    if args.data == "text":
+    input_bytes = None
+    if args.input:
+        raw = np.fromfile(args.input, dtype=np.uint8)
+        if raw.size == 0:
+            raise SystemExit("--input %s is empty" % args.input)
+        input_bytes = int(raw.size)
+        nfile = (raw.size + bs - 1) // bs
+        # this rank's share of the file's blocks (block g -> rank g mod N), the ragged last block zero padded for the tiled batches
+        # (shapes.input codes the exact bytes)
+        mine = list(range(rank, nfile, world)) or [0]
+        D = len(mine)
+        host = np.zeros((D, bs), dtype=np.uint8)
+        for j, g in enumerate(mine):
+            blk = raw[g * bs:(g + 1) * bs]
+            host[j, :blk.size] = blk
+    elif args.data == "text":
         host = text_mix(D, bs)
     else:
         host = np.empty((D, bs), dtype=np.uint8)
@@ -464,13 +517,22 @@ def main():
                 ("bwt_srt_zrlt_fpaq", "BWT+SRT+ZRLT", "FPAQ", "mix", "configs[4]: synthetic 8 GiB mixed-entropy stream, the level-6 core chain (HBM-roofline report)"),
                 ("level5_exact", "TEXT+UTF+BWT+RANK+ZRLT", "ANS0", "text", "level-exact -l 5 (BlockCompressor.java:539-573) on a text-heavy mix; TEXT / UTF run on host threads inside the timed region")):
             if data == "text" and d_text is None:
-                d_text = torch.from_numpy(text_mix(min(16, D), bs)).to(dev)
+                d_text = d_host if args.input else torch.from_numpy(text_mix(min(16, D), bs)).to(dev)
             r = timed_pass(d_text if data == "text" else d_host, B, chain, entropy, args.chain_steps, 1, prof("pmc_traffic_%s.json" % key))
-            chains[key] = {"what": what, "chain": chain, "entropy": entropy, "data": "synthetic %s" % data,
+            chains[key] = {"what": what, "chain": chain, "entropy": entropy, "data": ("file %s" % os.path.basename(args.input)) if args.input else "synthetic %s" % data,
                            "blocks_per_gpu_per_step": B, "steps": r["steps"], "warmup": r["warmup"], "ms_per_step": r["ms_per_step"],
                            "encode_MBps": r["encode_MBps"], "decode_MBps": r["decode_MBps"], "enc_dec_MBps": r["enc_dec_MBps"],
                            "z_post_transform_ratio": r["z"], "c_compressed_ratio": r["c"], "round_trip_ok": True,
                            "host_stage_ms_per_step": r["host_stage_ms_per_step"], "roofline": r["roofline"], "kernels": r["kernels"][:6]}
+            if key == "level5_exact":
+                # what ONE of eight ranks on a node gets: the host pool capped to 1/8 of the box's CPUs (TEXT / UTF run on the host;
+                # VERDICT r4 item 4).  One timed step, same batch.
+                lib = kz.load_library()
+                cpus8 = int(lib.kz_host_share(8))
+                r8 = timed_pass(d_text, B, chain, entropy, 1, 0, "")
+                lib.kz_host_share(max(world, 1))
+                chains[key]["host_share8"] = {"host_cpus": cpus8, "encode_MBps": r8["encode_MBps"], "decode_MBps": r8["decode_MBps"], "enc_dec_MBps": r8["enc_dec_MBps"],
+                                              "what": "the same row with the library's host pool capped to 1/8 of this box's usable CPUs (kz_host_share(8)): one rank's share on an 8-GPU node"}
         del d_text
         torch.cuda.empty_cache()
 
@@ -478,10 +540,12 @@ def main():
     shapes = {"bulk": {"blocks": B * world, "bytes": int(step_bytes) * world, "scaling": "weak",
                        "encode_MBps": head["encode_MBps"], "decode_MBps": head["decode_MBps"], "enc_dec_MBps": value}}
 
-    def shaped(src, total, reps=2, chain=None, entropy=None):
+    def shaped(src, total, reps=2, chain=None, entropy=None, by_id=False):
         nblk = (total + bs - 1) // bs
         mine = list(range(rank, nblk, world))                         # block g -> rank g mod N
         tail = total - (nblk - 1) * bs if (mine and mine[-1] == nblk - 1) else bs
+        if by_id and mine:                                            # src holds the stream's blocks by global id (not this rank's tiles)
+            src = src[[g % src.shape[0] for g in mine]]
         sb = Batch(src, len(mine), chain or args.chain, entropy or args.entropy, tail)
         sb.step()
         barrier()
@@ -499,19 +563,58 @@ def main():
         return {"blocks": nblk, "bytes": total, "scaling": "strong", "blocks_on_rank0": len(mine),
                 "encode_MBps": total * reps / se / 1e6, "decode_MBps": total * reps / sd / 1e6, "enc_dec_MBps": total * reps / sel / 1e6}
 
-    if not args.no_shapes:
+    def knz_size(hdata, chain, entropy):
+        """the .knz this library writes for a host buffer (rank 0, untimed): the aggregate known-answer of a corpus run"""
+        cap = int(ctx.lib.kz_compress_bound(hdata.size, bs))
+        knz = np.empty(cap, dtype=np.uint8)
+        return int(ctx.check(ctx.lib.kz_compress(ctx.h, kz.transform_type(chain), kz.ENTROPY_IDS[entropy.upper()], bs, hdata.ctypes.data, hdata.size, knz.ctypes.data, cap)))
+
+    L5 = ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0")
+    if not args.no_shapes and args.input:
+        # the corpus at its own size: the core chain and the level-exact -l 5 chain on the file's exact bytes (ragged tail included)
+        d_file = torch.from_numpy(np.fromfile(args.input, dtype=np.uint8))
+        nfile = (input_bytes + bs - 1) // bs
+        pad = torch.zeros(nfile * bs, dtype=torch.uint8)
+        pad[:input_bytes] = d_file
+        d_file = pad.view(nfile, bs).to(dev)
+        shapes["input"] = shaped(d_file, input_bytes, by_id=True)
+        shapes["input"]["file"] = os.path.basename(args.input)
+        if not args.no_chains:
+            shapes["input_level5_exact"] = shaped(d_file, input_bytes, chain=L5[0], entropy=L5[1], by_id=True)
+            shapes["input_level5_exact"]["chain"] = "%s & %s on %s" % (L5[0], L5[1], os.path.basename(args.input))
+            if rank == 0:
+                raw = np.fromfile(args.input, dtype=np.uint8)
+                shapes["input_level5_exact"]["knz_bytes"] = knz_size(raw, *L5)
+                shapes["input_level5_exact"]["knz_bytes_reference"] = ({"silesia.tar -l 5 -b 4m (README.md:86)": 53853702} if input_bytes == SILESIA_BYTES else None)
+                del raw
+        del d_file, pad
+        torch.cuda.empty_cache()
+    if not args.no_shapes and not args.input:
         for name, total in (("silesia", SILESIA_BYTES), ("enwik9", ENWIK9_BYTES)):
             shapes[name] = shaped(d_host, total)
             torch.cuda.empty_cache()
         if not args.no_chains:
             # the metric's own workload at its own size: silesia.tar -l 5 = TEXT+UTF+BWT+RANK+ZRLT & ANS0 (BlockCompressor.java:539-573)
-            # on 51 blocks of the text-heavy mix, TEXT / UTF on host threads inside the timed region
+            # on 51 blocks, TEXT / UTF on host threads inside the timed region.  Two mixes: silesia.tar's member proportions (the row to
+            # quote against the README's 85.8 MB/s) and the text-heavy mix of rounds 3 / 4 (7/8 text: the cheap class)
+            h_mix = silesia_mix(bs)
+            d_mix = torch.from_numpy(h_mix).to(dev)
+            mixdesc = ", ".join("%d %s" % (cnt, nm) for nm, cnt in SILESIA_MIX)
+            shapes["silesia_mix"] = shaped(d_mix, SILESIA_BYTES, by_id=True)
+            shapes["silesia_mix"]["chain"] = "%s & %s; 51 blocks: %s" % (args.chain, args.entropy, mixdesc)
+            shapes["silesia_mix_level5_exact"] = shaped(d_mix, SILESIA_BYTES, chain=L5[0], entropy=L5[1], by_id=True)
+            shapes["silesia_mix_level5_exact"]["chain"] = "%s & %s; 51 blocks: %s" % (L5[0], L5[1], mixdesc)
+            shapes["silesia_mix_level5_exact"]["vs_reference_published"] = shapes["silesia_mix_level5_exact"]["enc_dec_MBps"] / REFERENCE_PUBLISHED["enc_dec_MBps"]
+            if rank == 0:
+                shapes["silesia_mix_level5_exact"]["knz_bytes"] = knz_size(h_mix.reshape(-1)[:SILESIA_BYTES], *L5)
+            del d_mix, h_mix
             d_text = torch.from_numpy(text_mix(min(16, D), bs)).to(dev)
-            shapes["silesia_level5_exact"] = shaped(d_text, SILESIA_BYTES, chain="TEXT+UTF+BWT+RANK+ZRLT", entropy="ANS0")
-            shapes["silesia_level5_exact"]["chain"] = "TEXT+UTF+BWT+RANK+ZRLT & ANS0, text-heavy mix"
+            shapes["silesia_level5_exact"] = shaped(d_text, SILESIA_BYTES, chain=L5[0], entropy=L5[1])
+            shapes["silesia_level5_exact"]["chain"] = "TEXT+UTF+BWT+RANK+ZRLT & ANS0, text-heavy mix (7/8 text: not silesia's composition)"
             del d_text
             torch.cuda.empty_cache()
-        if args.data == "mix" and args.data_class < 0:
+    if not args.no_shapes:
+        if args.data == "mix" and args.data_class < 0 and not args.input:
             # the silesia shape one synthetic class at a time: small-batch decode is the serial RANK inverse of the slowest block,
             # so the worst class sets the mixed row
             names = ("text-like", "geometric skew", "64-byte records", "uniform random", "90% zeros")
@@ -548,7 +651,7 @@ def main():
                 best["what"] = "kz_compress / kz_decompress on host buffers: H2D, codec, D2H and host bit assembly inside the timed region; one GPU"
                 return best
 
-            shapes["silesia_host_pcie"] = host_rate(SILESIA_BYTES, 2)
+            shapes["input_host_pcie" if args.input else "silesia_host_pcie"] = host_rate(input_bytes if args.input else SILESIA_BYTES, 2)
             if args.bulk_host_blocks > 0:
                 shapes["bulk_host_pcie"] = host_rate(args.bulk_host_blocks * bs, 2)
         barrier()
@@ -557,8 +660,8 @@ def main():
         "metric": "encode+decode MB/s, 4 MiB-block synthetic stream, %s & %s (level-5 core chain), bit-exact .knz" % (args.chain, args.entropy),
         "value": value, "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "configs[2]: %s & %s, %d x %d B blocks per GPU per step (%d distinct synthetic blocks per GPU, SURVEY 8d generator standing in for silesia.tar, tiled), blocks round-robin over ranks" % (args.chain, args.entropy, B, bs, D),
+        "vs_baseline": None, "dtype": "u8", "data": ("file %s (%d B)" % (os.path.basename(args.input), input_bytes)) if args.input else "synthetic",
+        "config": {"workload": "configs[2]: %s & %s, %d x %d B blocks per GPU per step (%s, tiled), blocks round-robin over ranks" % (args.chain, args.entropy, B, bs, ("the %d blocks of %s on this rank" % (D, os.path.basename(args.input))) if args.input else ("%d distinct synthetic blocks per GPU, SURVEY 8d generator standing in for silesia.tar" % D)),
                    "block_size": bs, "blocks_per_gpu_per_step": B, "parallelism": "blocks%%%d" % world,
                    "encode_MBps": head["encode_MBps"], "decode_MBps": head["decode_MBps"],
                    "z_post_transform_ratio": z, "c_compressed_ratio": c, "round_trip_ok": True,

@@ -48,7 +48,7 @@ struct BwtInv {
   int GS;           // walker stride per block (grid points + 1)
 };
 #define BI_END 0xFFFFFFu
-#define BI_CH 256          // bytes per recording chunk
+#define BI_CH 128          // bytes per recording chunk (segments average 256 bytes since round 5)
 #define BI_SUSPECT 1       // status: not stitched, k_bwti_literal decides
 #define BI_HEADS 8         // walkers G..G+7 start at the primary indexes (only head 0 records bytes)
 
@@ -105,6 +105,11 @@ __global__ void k_bwti_parse(const u8* __restrict__ src, int64_t stride, const i
   V.status[b] = status;
 }
 
+// tile histogram: a thread takes 16 consecutive bytes (one unaligned 16-byte load; the payload starts behind a 25-byte header) and
+// adds every RUN of equal bytes once -- after a BWT most bytes sit in runs, so a thread issues a handful of LDS atomics instead of
+// the row's eight match-any ballots (round 5: the stage runs beside the other classes' RANK inverses and is issue bound there)
+typedef u32 bi_u32x4 __attribute__((ext_vector_type(4)));
+typedef bi_u32x4 __attribute__((aligned(1))) bi_u32x4_unaligned;
 __global__ __launch_bounds__(KZ_WG) void k_bwti_hist(const u8* __restrict__ src, int64_t stride, BwtInv V) {
   const int b = blockIdx.y, tile = blockIdx.x;
   const int n = V.n[b];
@@ -113,14 +118,25 @@ __global__ __launch_bounds__(KZ_WG) void k_bwti_hist(const u8* __restrict__ src,
   hist[threadIdx.x] = 0;
   __syncthreads();
   const u8* s = src + (int64_t)b * stride + V.hdr[b];
-  const int base = tile * BI_TILE;
-#pragma unroll 4
-  for (int r = 0; r < BI_ITEMS; r++) {
-    const int idx = base + r * KZ_WG + threadIdx.x;
-    const bool valid = idx < n;
-    const u32 d = valid ? s[idx] : 0;
-    const uint64_t peers = kz_match8(d, valid);
-    if (valid && (peers & kz_lanemask_lt()) == 0) atomicAdd(&hist[d], (u32)__popcll(peers));
+  const int p = tile * BI_TILE + (int)threadIdx.x * 16;
+  static_assert(BI_TILE == KZ_WG * 16, "one 16-byte piece per thread");
+  if (p < n) {
+    const int cnt = min(16, n - p);
+    bi_u32x4 q = {0, 0, 0, 0};
+    if (cnt == 16) q = *(const bi_u32x4_unaligned*)(s + p);              // (slots have >= 4 KiB of slack, but the tail may be poisoned: read it bytewise)
+    else for (int j = 0; j < cnt; j++) { const u32 c = s[p + j]; const u32 w = (u32)j >> 2; const u32 sh = 8u * ((u32)j & 3u);
+                                          if (w == 0) q.x |= c << sh; else if (w == 1) q.y |= c << sh; else if (w == 2) q.z |= c << sh; else q.w |= c << sh; }
+    const u32 w[4] = {q.x, q.y, q.z, q.w};
+    u32 runKey = w[0] & 0xFFu, runCnt = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const u32 c = (w[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+      if (j < cnt) {
+        if (c == runKey) runCnt++;
+        else { atomicAdd(&hist[runKey], runCnt); runKey = c; runCnt = 1; }
+      }
+    }
+    if (runCnt) atomicAdd(&hist[runKey], runCnt);
   }
   __syncthreads();
   V.tileHist[((int64_t)V.ord[b] * V.T + tile) * 256 + threadIdx.x] = hist[threadIdx.x];
@@ -162,7 +178,11 @@ __global__ __launch_bounds__(KZ_WG) void k_bwti_scatter(const u8* __restrict__ s
     const int idx = base + r * 64 + lane;
     const bool valid = idx < n;
     const u32 d = valid ? s[idx] : 0;
-    const uint64_t peers = kz_match8(d, valid);
+    // a row of one symbol (the usual case in the long runs behind a BWT) needs no match-any
+    const uint64_t vm = kz_ballot(valid);
+    const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
+    const bool uni = kz_ballot(valid && d == d0) == vm;
+    const uint64_t peers = uni ? (valid ? vm : 0ULL) : kz_match8(d, valid);
     u32 pre = 0;
     if (valid) pre = cnt[wave][d];
     const u32 rnk = pre + (u32)__popcll(peers & lt);
@@ -252,58 +272,118 @@ __global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V, int b0) {
   V.segNext[(int64_t)V.ord[b] * V.GS + w] = nxt;
 }
 
-// per block: suffix sums along the segment chain by pointer jumping in LDS -> text offsets
-#define BI_MAXSEG 4112
-__global__ __launch_bounds__(256) void k_bwti_resolve(BwtInv V, int b0) {
+// per block: the segments' text offsets = suffix sums of the segment lengths along the chain head -> ... -> END.
+// List ranking by a ruling set (round 5: up to 16 K segments of ~256 bytes; plain pointer jumping over all of them took 15
+// rounds of a 131 KB workgroup): every 16th grid segment and every head is a SPLITTER; a thread walks from its splitter to the
+// next one summing lengths (~16 dependent LDS reads), the ~1000 splitters are ranked by pointer jumping (11 rounds, one or two
+// per thread), and a second walk hands every segment its distance to the end of the text.
+#define BI_MAXSEG 16448
+#define BI_RES_WG 1024
+#define BI_SPL 16
+#define BI_MAXSPL ((BI_MAXSEG + BI_SPL - 1) / BI_SPL + BI_HEADS + 4)
+#define BI_NONE 0xFFFFu
+__global__ __launch_bounds__(BI_RES_WG) void k_bwti_resolve(BwtInv V, int b0) {
   const int b = blockIdx.x + b0;
   const int n = V.n[b];
   if (n < 2 || V.status[b] != 0) return;
   const int S = 1 << V.logS;
   const int G = (n + S - 1) >> V.logS;
   const int M = G + BI_HEADS;
-  __shared__ u32 R[BI_MAXSEG];
-  __shared__ int NX[BI_MAXSEG];
+  __shared__ u32 R[BI_MAXSEG];              // segment lengths, then (in place) bytes from the segment's start to the end of the text
+  __shared__ uint16_t NX[BI_MAXSEG];        // next segment, BI_NONE = end of text
+  __shared__ u32 spT[BI_MAXSPL];            // splitter: bytes of its sublist, then its suffix sum
+  __shared__ uint16_t spN[BI_MAXSPL];       // splitter: next splitter (index into the splitter list), BI_NONE = end of text
+  __shared__ int bad;
   const int64_t o = (int64_t)V.ord[b] * V.GS;
-  for (int i = threadIdx.x; i < M; i += 256) { R[i] = V.segLen[o + i]; NX[i] = V.segNext[o + i]; }
+  for (int i = threadIdx.x; i < M; i += BI_RES_WG) {
+    R[i] = V.segLen[o + i];
+    const int nx = V.segNext[o + i];
+    NX[i] = (nx < 0 || nx >= M) ? (uint16_t)BI_NONE : (uint16_t)nx;
+  }
+  if (threadIdx.x == 0) bad = 0;
   __syncthreads();
-  for (int round = 0; round < 13; round++) {
-    u32 r2[17]; int n2[17];
-    int k = 0;
-    for (int i = threadIdx.x; i < M; i += 256, k++) {
-      const int nx = NX[i];
-      r2[k] = (nx >= 0) ? R[i] + R[nx] : R[i];
-      n2[k] = (nx >= 0) ? NX[nx] : -1;
+  const int NG = (G + BI_SPL - 1) / BI_SPL;              // splitters among the grid segments: 0, 16, 32, ...
+  const int NSP = NG + BI_HEADS;                         // ... and the heads G .. G+7
+  // 1. sublist sums
+  for (int k = threadIdx.x; k < NSP; k += BI_RES_WG) {
+    int v = k < NG ? k * BI_SPL : G + (k - NG);
+    u32 sum = 0, next = BI_NONE;
+    for (int steps = 0;; steps++) {
+      sum += R[v];
+      const u32 nx = NX[v];
+      if (nx == BI_NONE) break;
+      if ((int)nx >= G || (nx % BI_SPL) == 0) { next = (int)nx >= G ? (u32)NG + (nx - (u32)G) : nx / BI_SPL; break; }
+      if (steps > M) { bad = 1; break; }                  // a cycle that holds no splitter: not a text path
+      v = (int)nx;
+    }
+    spT[k] = sum; spN[k] = (uint16_t)next;
+  }
+  __syncthreads();
+  // 2. suffix sums over the splitters (pointer jumping; NSP <= 2 * BI_RES_WG)
+  static_assert(BI_MAXSPL <= 2 * BI_RES_WG, "two splitters per thread");
+  int rounds = 1;
+  while ((1 << rounds) < NSP) rounds++;
+  for (int round = 0; round < rounds; round++) {
+    u32 t2[2]; u32 n2[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int k = (int)threadIdx.x + q * BI_RES_WG;
+      if (k < NSP) {
+        const u32 nx = spN[k];
+        t2[q] = nx != BI_NONE ? spT[k] + spT[nx] : spT[k];
+        n2[q] = nx != BI_NONE ? (u32)spN[nx] : (u32)BI_NONE;
+      }
     }
     __syncthreads();
-    k = 0;
-    for (int i = threadIdx.x; i < M; i += 256, k++) { R[i] = r2[k]; NX[i] = n2[k]; }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int k = (int)threadIdx.x + q * BI_RES_WG;
+      if (k < NSP) { spT[k] = t2[q]; spN[k] = (uint16_t)n2[q]; }
+    }
     __syncthreads();
   }
+  // 3. every segment of a sublist: bytes to the end of the text
+  for (int k = threadIdx.x; k < NSP; k += BI_RES_WG) {
+    int v = k < NG ? k * BI_SPL : G + (k - NG);
+    u32 running = spT[k];
+    for (int steps = 0;; steps++) {
+      const u32 len = R[v];
+      R[v] = running;
+      running -= len;
+      const u32 nx = NX[v];
+      if (nx == BI_NONE || (int)nx >= G || (nx % BI_SPL) == 0 || steps > M) break;
+      v = (int)nx;
+    }
+  }
+  __syncthreads();
   // R[i] = bytes from the start of segment i to the end of the text.  Stitching is right when head 0 reaches END
   // after exactly n steps (then every link is on that path) and, with 8 primary indexes, head k sits k*ckSize steps
   // into it (BWT.java:296-314); otherwise the literal walkers take over.
   if (threadIdx.x < BI_HEADS) {
     const int k = threadIdx.x;
+    const bool atEnd = spN[NG + k] == BI_NONE;             // its chain of splitters ends at END (not in a cycle)
     bool good = true;
-    if (k == 0) good = (R[G] == (u32)n && NX[G] == -1);
+    if (k == 0) good = (R[G] == (u32)n && atEnd && !bad);
     else if (n >= 256) {
       const u32 ckSize = (u32)(((n & 7) == 0) ? (n >> 3) : (n >> 3) + 1);
-      good = (NX[G + k] == -1 && R[G + k] <= (u32)n && (u32)n - R[G + k] == (u32)k * ckSize);
+      good = (atEnd && R[G + k] <= (u32)n && (u32)n - R[G + k] == (u32)k * ckSize);
     }
     if (!good) atomicCAS(&V.status[b], 0, BI_SUSPECT);
   }
-  for (int i = threadIdx.x; i < M; i += 256) V.segOff[o + i] = (R[i] <= (u32)n) ? (u32)n - R[i] : 0xFFFFFFFFu;
+  for (int i = threadIdx.x; i < M; i += BI_RES_WG) V.segOff[o + i] = (R[i] <= (u32)n) ? (u32)n - R[i] : 0xFFFFFFFFu;
 }
 
-// move every recorded chunk to its place in the text: one wave per chunk, 4 bytes per lane
+// move every recorded chunk to its place in the text: BI_CH / 4 lanes per chunk, 4 bytes per lane
 typedef u32 __attribute__((aligned(1))) bi_u32_unaligned;
+#define BI_CPL (BI_CH / 4)                 // lanes per chunk
+#define BI_CPW (256 / BI_CPL)              // chunks per workgroup
 __global__ __launch_bounds__(256) void k_bwti_copy(u8* __restrict__ dst, int64_t stride, BwtInv V, int b0) {
   const int b = blockIdx.y + b0;
   const int n = V.n[b];
   if (n < 2 || V.status[b] != 0) return;
-  const u32 id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const u32 id = blockIdx.x * BI_CPW + (threadIdx.x / BI_CPL);
   if (id >= V.chunkCount[b] || id >= (u32)V.maxChunks) return;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x % BI_CPL;
   const uint2 m = V.chunkMeta[(int64_t)V.ord[b] * V.maxChunks + id];
   const u32 len = V.segLen[(int64_t)V.ord[b] * V.GS + m.x];
   const u32 off = V.segOff[(int64_t)V.ord[b] * V.GS + m.x];
@@ -387,7 +467,7 @@ int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
   V.prim = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 32);
   V.status = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   V.logS = 6;
-  while (((maxN + (1 << V.logS) - 1) >> V.logS) > 4096) V.logS++;
+  while (((maxN + (1 << V.logS) - 1) >> V.logS) > BI_MAXSEG - BI_HEADS - 8) V.logS++;
   V.GS = ((maxN + (1 << V.logS) - 1) >> V.logS) + BI_HEADS;
   V.segLen = (u32*)kz_arena_alloc(ctx, (size_t)A * V.GS * 4);
   V.segNext = (int32_t*)kz_arena_alloc(ctx, (size_t)A * V.GS * 4);
@@ -421,8 +501,8 @@ int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
     for (int b0 = 0; b0 < B; b0 += group) {
       const int nb = (B - b0 < group) ? B - b0 : group;
       KZ_LAUNCH(ctx, KID_BWTI_WALK1, k_bwti_walk1, dim3((V.GS + 63) / 64, nb), dim3(64), V, b0);
-      KZ_LAUNCH(ctx, KID_BWTI_RESOLVE, k_bwti_resolve, dim3(nb), dim3(256), V, b0);
-      KZ_LAUNCH(ctx, KID_BWTI_COPY, k_bwti_copy, dim3((V.maxChunks + 3) / 4, nb), dim3(256), dst, bt.stride, V, b0);
+      KZ_LAUNCH(ctx, KID_BWTI_RESOLVE, k_bwti_resolve, dim3(nb), dim3(BI_RES_WG), V, b0);
+      KZ_LAUNCH(ctx, KID_BWTI_COPY, k_bwti_copy, dim3((V.maxChunks + BI_CPW - 1) / BI_CPW, nb), dim3(256), dst, bt.stride, V, b0);
     }
     KZ_LAUNCH(ctx, KID_BWTI_LITERAL, k_bwti_literal, dim3(B), dim3(64), dst, bt.stride, V);
   }

@@ -329,6 +329,243 @@ def huffman_encode(data):
     return bs.bytes(), bs.n
 
 
+# ---- round 5: the Huffman code-length passes themselves, from the Java ----
+def normalize_frequencies_java(freqs, alen, total, scale):
+    """EntropyUtils.normalizeFrequencies :141-250 with an alphabet array of `alen` entries (HuffmanEncoder.java:252-262 calls it
+    with compacted arrays of `count` entries, ANSRangeEncoder with 256).  freqs is modified in place; returns the alphabet list.
+    The `totalFreq == scale` shortcut reads freqs[0..255] whatever alen is (:159-165): an IndexError here is Java's
+    ArrayIndexOutOfBoundsException."""
+    if alen == 0 or total == 0:
+        return []
+    if total == scale:
+        return [i for i in range(256) if freqs[i] != 0]
+    alphabet, sum_scaled, sum_freq, idx_max = [], 0, 0, 0
+    for i in range(alen):
+        f = freqs[i]
+        if f == 0:
+            continue
+        sf = f * scale
+        scaled = 1 if sf <= total else (sf + (total >> 1)) // total
+        alphabet.append(i)
+        sum_scaled += scaled
+        freqs[i] = scaled
+        sum_freq += f
+        if scaled > freqs[idx_max]:
+            idx_max = i
+        if sum_freq >= total:
+            break
+    if not alphabet:
+        return []
+    if len(alphabet) == 1:
+        freqs[alphabet[0]] = scale
+        return alphabet
+    if sum_scaled == scale:
+        return alphabet
+    delta = sum_scaled - scale
+    err_thr = freqs[idx_max] >> 4
+    if abs(delta) <= err_thr:
+        freqs[idx_max] -= delta
+        return alphabet
+    if delta < 0:
+        delta += err_thr
+        freqs[idx_max] += err_thr
+    else:
+        delta -= err_thr
+        freqs[idx_max] -= err_thr
+    inc = -1 if delta > 0 else 1
+    delta = abs(delta)
+    rnd = 0
+    while True:
+        rnd += 1
+        if not (rnd < 6 and delta > 0):
+            break
+        adjustments = 0
+        for idx in alphabet:
+            if freqs[idx] <= 2:
+                continue
+            freqs[idx] += inc
+            adjustments += 1
+            delta -= 1
+            if delta == 0:
+                break
+        if adjustments == 0:
+            break
+    freqs[idx_max] = max(freqs[idx_max] - delta, 1)
+    return alphabet
+
+
+def huffman_phase1(data, n):                                                  # computeInPlaceSizesPhase1 :317-339
+    s = r = 0
+    for t in range(n - 1):
+        total = 0
+        for _ in range(2):
+            if s >= n or (r < t and data[r] < data[s]):
+                total += data[r]
+                data[r] = t
+                r += 1
+                continue
+            total += data[s]
+            if s > t:
+                data[s] = 0
+            s += 1
+        data[t] = total
+
+
+def huffman_phase2(data, n):                                                  # computeInPlaceSizesPhase2 :349-376
+    if n < 2:
+        return 0
+    level_top, depth, i, total_nodes = n - 2, 1, n, 2
+    while i > 0:
+        k = level_top
+        while k > 0 and data[k - 1] >= level_top:
+            k -= 1
+        internal = level_top - k
+        leaves = total_nodes - internal
+        for _ in range(leaves):
+            i -= 1
+            data[i] = depth
+        total_nodes = internal << 1
+        level_top = k
+        depth += 1
+    return depth - 1
+
+
+def huffman_compute_code_lengths(sizes, ranks, count):                        # computeCodeLengths :285-308
+    ranks[:count] = sorted(ranks[:count])                                     # Arrays.sort(int[]): (freq << 8) | symbol ascending
+    freqs = [0] * 256
+    for i in range(count):
+        freqs[i] = ranks[i] >> 8
+        ranks[i] &= 0xFF
+        if freqs[i] == 0:
+            return 0
+    huffman_phase1(freqs, count)
+    max_len = huffman_phase2(freqs, count)
+    for i in range(count):
+        sizes[ranks[i]] = freqs[i]
+    return max_len
+
+
+def huffman_limit_code_lengths(alphabet, freqs, sizes, ranks, count):         # limitCodeLengths :191-273
+    MAXLEN = 12                                                               # HuffmanCommon.MAX_SYMBOL_SIZE_V4
+    n = debt = 0
+    while sizes[ranks[n]] >= MAXLEN:                                          # (ranks has 256 entries: index `count` exists, :126)
+        debt += sizes[ranks[n]] - MAXLEN
+        sizes[ranks[n]] = MAXLEN
+        n += 1
+    ll = [[] for _ in range(6)]                                               # LinkedList: add at the tail, removeFirst
+    while n < count:
+        idx = MAXLEN - 1 - sizes[ranks[n]]
+        if idx >= len(ll) or debt < (1 << idx):
+            break
+        ll[idx].append(ranks[n])
+        n += 1
+    idx = len(ll) - 1
+    while debt > 0 and idx >= 0:
+        if not ll[idx] or debt < (1 << idx):
+            idx -= 1
+            continue
+        r = ll[idx].pop(0)
+        sizes[r] += 1
+        debt -= 1 << idx
+    idx = 0
+    while debt > 0 and idx < len(ll):
+        if not ll[idx]:
+            idx += 1
+            continue
+        r = ll[idx].pop(0)
+        sizes[r] += 1
+        debt -= 1 << idx
+    if debt > 0:                                                              # :250-270
+        f = [freqs[alphabet[i]] for i in range(count)]
+        total = sum(f)
+        normalize_frequencies_java(f, count, total, 16384 >> 3)               # HuffmanCommon.MAX_CHUNK_SIZE >> 3
+        for i in range(count):
+            freqs[alphabet[i]] = f[i]
+            ranks[i] = (f[i] << 8) | alphabet[i]
+        return huffman_compute_code_lengths(sizes, ranks, count)
+    return MAXLEN
+
+
+def huffman_sizes_and_codes(freqs):
+    """updateFrequencies :103-160 for a chunk's 256 counts: (alphabet, sizes[256], codes[256]) exactly as the encoder derives them:
+    in-place Moffat-Katajainen lengths, the 12-bit limiter with its linked lists and its renormalising fallback, the 8-bit flat
+    code when even that fails, canonical codes (HuffmanCommon.generateCanonicalCodes :71-111)."""
+    freqs = list(freqs)
+    alphabet = [i for i in range(256) if freqs[i] > 0]
+    count = len(alphabet)
+    sizes, codes = [0] * 256, [0] * 256
+    if count == 0:
+        return alphabet, sizes, codes
+    if count == 1:
+        sizes[alphabet[0]] = 1
+        return alphabet, sizes, codes
+    ranks = [0] * 256
+    for i in range(count):
+        ranks[i] = (freqs[alphabet[i]] << 8) | alphabet[i]
+    max_len = huffman_compute_code_lengths(sizes, ranks, count)
+    if max_len == 0:
+        raise JavaException("Could not generate Huffman codes: invalid code length 0")
+    if max_len > 12:
+        max_len = huffman_limit_code_lengths(alphabet, freqs, sizes, ranks, count)
+        if max_len == 0:
+            raise JavaException("Could not generate Huffman codes: invalid code length 0")
+    if max_len > 12:                                                          # :146-155
+        for n, a in enumerate(alphabet):
+            codes[a] = n
+            sizes[a] = 8
+    else:                                                                     # generateCanonicalCodes: symbols by (length, symbol)
+        order = sorted(ranks[:count], key=lambda x: (sizes[x], x))
+        code, cur = 0, sizes[order[0]]
+        for a in order:
+            if sizes[a] > 12 or sizes[a] < 1:
+                raise JavaException("invalid code length")
+            code <<= sizes[a] - cur
+            cur = sizes[a]
+            codes[a] = code
+            code += 1
+    return alphabet, sizes, codes
+
+
+def huffman_encode_exact(data):
+    """HuffmanEncoder.encode :380-416 on ANY block: 16 KiB chunks, code lengths from huffman_sizes_and_codes.  (bytes, bits)."""
+    bs = _Bits()
+    pos, end = 0, len(data)
+    while pos < end:
+        size = min(16384, end - pos)
+        chunk = data[pos:pos + size]
+        if size < 32:
+            for b in chunk:
+                bs.write(b, 8)
+        else:
+            freqs = [0] * 256
+            for b in chunk:
+                freqs[b] += 1
+            alphabet, sizes, codes = huffman_sizes_and_codes(freqs)
+            _encode_alphabet(bs, alphabet)
+            prev = 2
+            for a in alphabet:
+                d = sizes[a] - prev
+                _exp_golomb_signed(bs, d - 256 if d > 127 else d)             # (byte) cast
+                prev = sizes[a]
+            if len(alphabet) > 1:
+                frag = size // 4
+                parts = []
+                for j in range(4):
+                    fb = _Bits()
+                    for b in chunk[j * frag:(j + 1) * frag]:
+                        fb.write(codes[b], sizes[b])
+                    parts.append(fb)
+                for fb in parts:
+                    _write_varint(bs, fb.n)
+                for fb in parts:
+                    if fb.n:
+                        bs.write(fb.v, fb.n)
+                for b in chunk[4 * frag:]:
+                    bs.write(b, 8)
+        pos += size
+    return bs.bytes(), bs.n
+
+
 def lz_decode(src, out_cap):
     """K/transform/LZCodec.java inverseV6 :617-756 + readLength :241-258, as a pure-Python reader of the LZ / LZX frame: three little-
     endian lengths (offset of the token stream = 13 + literal bytes, token bytes, match-index bytes; the match lengths fill the rest), a flag byte (bit 0: the 2^24 window, bits 1..3:

@@ -1461,3 +1461,21 @@ def test_bwt_forward_trie_rounds_match_oracle(ctx, monkeypatch, switch):
             so, w, sf, pl = oracle.encode_block("BWT", "NONE", d)
             assert res[i].status == 0 and (res[i].bits, res[i].skipFlags, res[i].length) == (w, sf, pl), len(d)
             assert out[i, :(w + 7) // 8].tobytes() == so, len(d)
+
+
+# ---- round 5: the differential fuzz tools of round 4 as a driver-run test ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("tool,seconds,seed", [("bwt_fuzz", 7, 5001), ("zrlt_fuzz", 6, 5002), ("tightcap_fuzz", 6, 5003), ("entropy_count_fuzz", 6, 5004)])
+def test_differential_fuzz_tools_bounded(tool, seconds, seed):
+    """tools/bwt_fuzz.py (forward BWT on structured and degenerate strings, ragged batches), tools/zrlt_fuzz.py (row / wave / tile
+    seams of the ZRLT kernels), tools/tightcap_fuzz.py (every inverse transform with the buffer cut to the byte) and
+    tools/entropy_count_fuzz.py (decoders asked for the wrong count or given cut bits): a fixed seed and a few seconds each, so the
+    first cases of every campaign run wherever the GPU suite runs.  Each tool compares HIP with the oracle case by case and exits
+    non-zero on the first campaign with a difference."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)          # the tools keep failing inputs there
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", tool + ".py"), str(seconds), str(seed)], capture_output=True, text=True, timeout=300)
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, tail

@@ -628,3 +628,114 @@ def test_trie_round_model_reproduces_suffix_arrays():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     assert m.check(trials=18)
+
+
+# ---- round 5: the last single-sourced encoder surface ----
+def _counts_to_chunk(counts, seed):
+    """a chunk (<= 16 KiB) holding symbol v exactly counts[v] times, shuffled"""
+    rng = np.random.default_rng(seed)
+    return bytes(rng.permutation(np.repeat(np.arange(len(counts), dtype=np.uint8), counts)))
+
+
+def _fib(n):
+    f = [1, 1]
+    while len(f) < n:
+        f.append(f[-1] + f[-2])
+    return f[:n]
+
+
+def test_huffman_code_length_passes_from_a_python_model_of_the_reference():
+    """HuffmanEncoder's in-place Moffat-Katajainen passes, `limitCodeLengths` with its linked lists AND its renormalising slow
+    path, and the canonical codes (tests/katmodels.huffman_encode_exact, written from HuffmanEncoder.java:191-376, not from
+    oracle/kzo_huffman.c) on inputs where ties between equal weights decide the lengths and where the optimal code is deeper
+    than 12 bits: the C oracle must write the same bits."""
+    import katmodels
+    rng = np.random.default_rng(21)
+    cases = []
+    # ties everywhere: flat alphabets of every size class, two-level weights, all-ones plus one heavy symbol
+    for k in (2, 3, 5, 17, 100, 255, 256):
+        cases.append(("flat%d" % k, _counts_to_chunk([40] * k if 40 * k <= 16384 else [16384 // k] * k, k)))
+    cases.append(("two_levels", _counts_to_chunk([8] * 100 + [64] * 100, 1)))
+    cases.append(("ones_and_heavy", _counts_to_chunk([1] * 200 + [9000], 2)))
+    cases.append(("pairs_of_ties", _counts_to_chunk([c for c in range(1, 90) for _ in (0, 1)], 3)))
+    # deeper than 12 bits: Fibonacci weights (the worst case of Huffman depth), with and without ties, scaled
+    for n in (14, 16, 19, 20):
+        cases.append(("fib%d" % n, _counts_to_chunk(_fib(n), n)))
+    cases.append(("fib19_twice", _counts_to_chunk(sorted(_fib(17) + _fib(17)), 4)))
+    cases.append(("fib_and_ones", _counts_to_chunk(_fib(18) + [1] * 150, 5)))
+    cases.append(("powers", _counts_to_chunk([1, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8190], 6)))
+    cases.append(("geometric_tail", _counts_to_chunk([max(1, int(12000 * 0.55 ** i)) for i in range(40)] + [1] * 100, 7)))
+    # several chunks, a tail below 32 bytes, a tail chunk with one symbol
+    cases.append(("multi_chunk", datagen.block(1, 40000).tobytes() + b"\x07" * 50 + b"tail"))
+    cases.append(("text_class", datagen.block(0, 50000).tobytes()))
+    for i in range(40):                                               # random skewed histograms: whatever path they take
+        k = int(rng.integers(2, 257))
+        w = rng.random(k) ** float(rng.uniform(1, 14))
+        counts = np.maximum(1, (w / w.sum() * 16000).astype(np.int64))
+        while counts.sum() > 16384:
+            counts[np.argmax(counts)] -= counts.sum() - 16384
+        cases.append(("rand%d" % i, _counts_to_chunk(list(counts), 100 + i)))
+    paths = {"limit": 0, "slow": 0, "flat8": 0}
+    orig_limit, orig_norm = katmodels.huffman_limit_code_lengths, katmodels.normalize_frequencies_java
+
+    def limit_spy(*a):
+        paths["limit"] += 1
+        return orig_limit(*a)
+
+    def norm_spy(*a):
+        paths["slow"] += 1
+        return orig_norm(*a)
+
+    katmodels.huffman_limit_code_lengths, katmodels.normalize_frequencies_java = limit_spy, norm_spy
+    try:
+        for name, data in cases:
+            model, nbits = katmodels.huffman_encode_exact(data)
+            enc, obits = oracle.entropy_encode("HUFFMAN", data)
+            assert obits == nbits and enc[:len(model)] == model, (name, len(data), nbits, obits)
+            r, back, _ = oracle.entropy_decode("HUFFMAN", enc, obits, len(data))
+            assert r == len(data) and back == data, name
+    finally:
+        katmodels.huffman_limit_code_lengths, katmodels.normalize_frequencies_java = orig_limit, orig_norm
+    # the inputs must have reached the limiter, and its slow path
+    assert paths["limit"] >= 8 and paths["slow"] >= 1, paths
+    # the tie-free model of round 1 and the exact one agree where the first is defined
+    dyadic = bytes([97] * 32 + [98] * 16 + [99] * 8 + [100] * 4 + [101] * 2 + [102, 103])
+    assert katmodels.huffman_encode_exact(dyadic) == katmodels.huffman_encode(dyadic)
+
+
+def test_normalize_frequencies_from_a_python_model_of_the_reference():
+    """EntropyUtils.normalizeFrequencies (tests/katmodels.normalize_frequencies_java, from EntropyUtils.java:141-250) against the
+    oracle's kzo_normalize_freqs on tie-heavy, Fibonacci and random histograms at every scale the codecs use (2^8 .. 2^16):
+    both rounding paths, the fast correction of the maximum and the slow spreading loop with its five rounds."""
+    import ctypes
+    import katmodels
+    L = oracle.lib()
+    L.kzo_normalize_freqs.restype = ctypes.c_int
+    L.kzo_normalize_freqs.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int]
+    rng = np.random.default_rng(5)
+    hists = [[7] * 256, [1] * 255 + [100000], [3] * 100 + [0] * 156, _fib(24) + [0] * 232, [1] * 128 + [2] * 128, [0] * 255 + [5],
+             [1, 0, 1] + [0] * 253, [16384] + [1] * 255, [100] * 3 + [0] * 253]
+    for i in range(300):
+        k = int(rng.integers(1, 257))
+        h = np.zeros(256, dtype=np.int64)
+        idx = rng.permutation(256)[:k]
+        w = rng.random(k) ** float(rng.uniform(0.2, 12))
+        h[idx] = np.maximum(1, (w / w.sum() * int(rng.integers(k, 70000))).astype(np.int64))
+        if i % 3 == 0:
+            h[idx] = (h[idx] // 8 + 1) * 8                              # ties
+        hists.append([int(v) for v in h])
+    slow = 0
+    for h in hists:
+        total = sum(h)
+        for lg in (8, 10, 11, 12, 13, 16):
+            scale = 1 << lg
+            f = list(h)
+            alpha = katmodels.normalize_frequencies_java(f, 256, total, scale)
+            cf = (ctypes.c_int * 257)(*h)
+            ca = (ctypes.c_int * 256)()
+            n = L.kzo_normalize_freqs(cf, ca, total, scale)
+            assert n == len(alpha) and list(ca[:n]) == alpha and list(cf[:256]) == f, (h[:8], lg)
+            if total != scale and len(alpha) > 1:
+                assert sum(f) == scale or min(v for v in f if v) <= 2, (lg, sum(f))
+                slow += 1
+    assert slow > 500

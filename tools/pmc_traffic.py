@@ -3,10 +3,18 @@
 Usage: tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <blocks> [chain entropy] > profiles/rNN_pmc_traffic.json
 Units/corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KiB
 (hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024); on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide
-coalesced streaming read (TCC_EA0_RDREQ x 64 B with 128-B requests) -> doubled here; other access widths and
-WRITE_SIZE are uncalibrated (reported as measured)."""
+coalesced streaming read (TCC_EA0_RDREQ x 64 B with 128-B requests) -> doubled for STREAMING kernels.
+Calibrated per access class in round 5 (tools/ubench_gather.hip, tools/pmc_calibrate.sh -> profiles/r05_pmc_calibration.json):
+  coalesced 16 B / lane reads   : FETCH_SIZE =  8 B per 16-B access  -> x2 (the guide's case, confirmed)
+  scattered 4-byte loads        : FETCH_SIZE = 64 B per access (gather and dependent chase alike) at 54.5 G accesses / s; doubled,
+                                  that would be 7.0 TB/s, above the 5.4 TB/s the same box streams -> a scattered access moves ONE
+                                  64-byte request, the counter is right as it stands -> x1 for the kernels in SCATTERED below
+  coalesced 16 B / lane writes  : WRITE_SIZE = 16 B per 16-B access  -> x1
+  scattered 4-byte stores       : WRITE_SIZE = 32 B per store         -> x1 (a 32-byte sector per store)
+Kernels that mix both patterns (k_bwt_emit: a streamed suffix array + gathered text bytes) keep the x2: an upper bound."""
 import csv
 import json
+import os
 import re
 import sys
 
@@ -14,6 +22,10 @@ import sys
 # kernels the library times under one id (kz_internal.h: KZ_KERNEL_NAMES): the text-sourced first radix pass
 ALIASES = {"k_radix_hist0": "k_radix_hist", "k_radix_scatter0": "k_radix_scatter",
            "k_fpaq_enc_wave": "k_fpaq_enc", "k_fpaq_dec_wave": "k_fpaq_dec", "k_fpaq_dec_wave2": "k_fpaq_dec"}   # the one-wave-per-block forms share their ids
+
+
+# kernels whose loads are scattered 4-byte accesses (one 64-byte request each): FETCH_SIZE taken as counted
+SCATTERED = {"k_bwti_walk1", "k_bwti_literal", "k_lz_fwd"}
 
 
 def agg(path, counter):
@@ -37,19 +49,21 @@ def main():
     blocks = int(sys.argv[3])
     chain = sys.argv[4] if len(sys.argv) > 4 else "BWT+RANK+ZRLT"
     entropy = sys.argv[5] if len(sys.argv) > 5 else "ANS0"
-    res = {"blocks_per_gpu_per_step": blocks, "chain": chain, "entropy": entropy, "steps_profiled": 2,   # bench.py --steps 1 --warmup 0 runs one timed and one instrumented step: every kernel appears twice per step's launches
+    res = {"blocks_per_gpu_per_step": blocks, "chain": chain, "entropy": entropy, "git_sha": os.environ.get("KZ_GIT_SHA") or None, "steps_profiled": 2,   # bench.py --steps 1 --warmup 0 runs one timed and one instrumented step: every kernel appears twice per step's launches
            
-           "note": "FETCH_SIZE doubled (gfx950 correction), KiB -> bytes; WRITE_SIZE as measured", "kernels": {}}
+           "note": "FETCH_SIZE x2 for streaming kernels (gfx950 correction), x1 for the scattered-load kernels (fetch_factor says which; profiles/r05_pmc_calibration.json), KiB -> bytes; WRITE_SIZE as measured",
+           "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue
         f = fetch.get(k, {"launches": 0, "sum": 0.0})
         w = write.get(k, {"launches": 0, "sum": 0.0})
         n = max(f["launches"], w["launches"], 1)
-        res["kernels"][k] = {"launches": n,
-                             "fetch_bytes_per_launch": 2.0 * f["sum"] * 1024.0 / n,
+        ff = 1.0 if k in SCATTERED else 2.0
+        res["kernels"][k] = {"launches": n, "fetch_factor": ff,
+                             "fetch_bytes_per_launch": ff * f["sum"] * 1024.0 / n,
                              "write_bytes_per_launch": w["sum"] * 1024.0 / n,
-                             "hbm_bytes_per_launch": (2.0 * f["sum"] + w["sum"]) * 1024.0 / n}
+                             "hbm_bytes_per_launch": (ff * f["sum"] + w["sum"]) * 1024.0 / n}
     json.dump(res, sys.stdout, indent=1)
 
 

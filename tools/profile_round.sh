@@ -9,13 +9,14 @@
 # 4. bench.py defaults with the measured traffic attached                -> bench_default.json
 # Copy the files you want judged to profiles/<tag>_*.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$(pwd)
 BLOCKS=${BLOCKS:-2048}
-PMC_CHAINS=${PMC_CHAINS:-"head lz_ans0 bwt_srt_zrlt_fpaq"}
+PMC_CHAINS=${PMC_CHAINS:-"head lz_ans0 bwt_srt_zrlt_fpaq level5_exact"}
+# KZ_GIT_SHA=<commit> in the environment is stamped into the traffic files (there is no .git on the GPU box)
 timeout 1200 python bench.py --profiles-tag none > $OUT/bench_nopmc.json 2> $OUT/bench.err
 cd /tmp
 # (bench.py runs one extra instrumented step behind the timed ones: every kernel of the step shows up --steps + 1 times)
