@@ -103,8 +103,11 @@ int32_t     kz_ctx_get_data_type(kz_ctx* ctx);
 int32_t     kz_ctx_reset(kz_ctx* ctx);
 /* One process per GPU, N on one host: pin this process (and the threads it creates later: TEXT / UTF stages, bit assembly,
  * staging copies) to the CPUs of the GPU's NUMA node (/sys/bus/pci/devices/<bdf>/local_cpulist).  Returns the number of CPUs
- * in the new mask, 0 if the topology is not visible (nothing changed), <0 on error.  The reference has no equivalent: its
- * task pool is one JVM on one socket (K/app/BlockCompressor.java:199-206). */
+ * in the new mask, 0 if the topology is not visible (nothing changed), <0 on error.  PROCESS-WIDE: every thread of the process
+ * that exists at the time of the call is re-pinned (HIP's helpers, the application's own threads, the workers of contexts bound
+ * to other GPUs), so it assumes ONE GPU PER PROCESS; a process that drives several devices must not call it (the last call would
+ * move everything to one NUMA node).  The reference has no equivalent: its task pool is one JVM on one socket
+ * (K/app/BlockCompressor.java:199-206). */
 int32_t     kz_pin_to_device_numa(int32_t deviceId);
 /* host CPUs the library's thread pool (TEXT / UTF stages, staging copies, bit assembly) will use: the process's affinity mask cut
  * down to its cgroup CPU quota, if any */

@@ -1027,13 +1027,9 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
   int maxN = 0;
   for (int b = 0; b < B; b++) { if (lengths[b] < 0) return -KZ_ERR_INVALID_PARAM; maxN = std::max(maxN, lengths[b]); }
   const int maxLen = seq_max_len(types, nb, maxN);
-  // the inverse stages of BWT and RANK/MTFT keep 24-bit positions packed next to a byte (kz_bwt_inv.hip, kz_sbrt.hip): refuse
-  // up front what this library's own decoder could not take back (the reference goes to 1 GiB blocks)
-  for (int i = 0; i < nb; i++)
-    if ((types[i] == KZ_T_BWT || types[i] == KZ_T_RANK || types[i] == KZ_T_MTFT) && maxLen > KZ_MAX_PACKED_BLOCK) {
-      snprintf(ctx->err, sizeof(ctx->err), "block of %d bytes: BWT / RANK / MTFT chains take blocks up to %d bytes (16 MiB block size)", maxN, KZ_MAX_PACKED_BLOCK - 33);
-      return -KZ_ERR_BLOCK_SIZE;
-    }
+  // blocks go up to the reference's 1 GiB (BWT.java:59); BWT / RANK / MTFT blocks of 2^24 bytes and more take the wide forms of the
+  // inverse kernels (8-byte links in kz_bwt_inv.hip, the plain list in kz_sbrt.hip: round 5), slower but the same bytes
+  if (maxLen > KZ_MAX_BLOCK) { snprintf(ctx->err, sizeof(ctx->err), "block of %d bytes: blocks go up to %d bytes", maxN, KZ_MAX_BLOCK - 1057); return -KZ_ERR_BLOCK_SIZE; }
   ChainSpec CS; CS.nb = nb; CS.entropy = (int)entropyType; for (int i = 0; i < nb; i++) CS.types[i] = types[i];
   {
     // bound the scratch arena: the suffix sort needs ~43 B per input byte, so very large batches are

@@ -883,6 +883,9 @@ __global__ __launch_bounds__(KZ_WG) void k_live_emit(u64* __restrict__ keyN, u32
 // end of the text like the old keys), terminal groups share Dmax >= 6 bytes.  The ranks are therefore a refinement of
 // the 6-byte order and a coarsening of the suffix order, which is all the doubling rounds (h = 6, 12, ...) need: equal
 // rank => equal 6-byte prefix; different rank => the true order.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the trie rounds are sized for gfx950's 160 KiB of LDS per workgroup (k_tr_hist16 128 KiB, k_tr_scatter / k_trk_scatter 152 KiB, the bucket sorts 77 KiB)"
+#endif
 #define TR_CAP 7680u             // LDS sort capacity (60 KiB of elements + 16 KiB of counters: two workgroups per CU)
 #define TR_MERGE (TR_CAP / 2)    // siblings above this are a bucket of their own
 #define TR_K_SMALL 1u
@@ -1691,7 +1694,8 @@ size_t kz_bwt_forward_scratch(int B, int maxN) {
 
 static inline int gridFor(int n, int per) { int g = (n + per - 1) / per; return g < 1 ? 1 : g; }
 
-int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
+// one pass of the stage; *trieOverflow is set (and nothing of the batch changed) when a trie table overflowed in any round
+static int bwt_forward_run(kz_ctx* ctx, kz_batch& bt, bool allowTrie, bool* trieOverflow) {
   const int B = bt.B;
   int maxN = 0;
   for (int b = 0; b < B; b++) if (bt.h_len[b] > maxN) maxN = bt.h_len[b];
@@ -1716,7 +1720,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
   A.d_m = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   A.d_m2 = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   if (!A.d_m2 || !A.tileB || !A.tileLive || !A.sa || !A.d_big || !A.bucketCnt) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: arena overflow"); return -KZ_ERR_DEVICE; }
-  bool useTrie = tr_applies(maxN);
+  bool useTrie = allowTrie && tr_applies(maxN);
   TrieArrays TR;
   memset(&TR, 0, sizeof(TR));
   const size_t markTrie = ctx->arenaTop;
@@ -1768,6 +1772,16 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
   const char* eg = getenv("KZ_BWT_GMAX");
   const u32 gmax = eg ? (u32)atoi(eg) : (u32)BK_GMAX;
   const int tilesN = gridFor(maxN, RS_TILE);
+  // experiment switches: read once per call (the tests flip them between calls), not per round
+  const char* ed = getenv("KZ_BWT_DMAX");
+  const int Dmax = (ed && ed[0] >= '6' && ed[0] <= '0' + TR_DMAX_LIMIT) ? ed[0] - '0' : 6;
+  const char* ep = getenv("KZ_TR_PARTS");
+  const char* etw = getenv("KZ_BWT_TRIEWIN");
+  const bool trieWinOff = etw && etw[0] == '0';
+  const bool trace = getenv("KZ_BWT_TRACE") != nullptr;
+  const char* eo = getenv("KZ_BWT_TEST_TRIE_OVERFLOW");              // tests: pretend the tables overflowed in round <digit>
+  const int forceOvfRound = (eo && eo[0] >= '0' && eo[0] <= '9') ? eo[0] - '0' : -1;
+  if (useTrie) KZ_HIP(hipMemsetAsync(TR.err, 0, 4, st));
   for (int round = 0; round < 64 && mMax > 0; round++) {
     // ---- sort (kC,vC) and apply.  Later rounds of blocks up to 4 MiB: bucket partition + one LDS sort per bucket, the
     //      LSD passes only for the window of oversized buckets; otherwise LSD radix over the whole compact list ----
@@ -1778,14 +1792,10 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
     int wMax = mMax;                                               // largest LSD window of the batch
     if (round == 0 && useTrie) {
       // ---- the trie round: count level by level, move once, finish the buckets in LDS (elements in key[0], states in val[0]) ----
-      const char* ed = getenv("KZ_BWT_DMAX");
-      const int Dmax = (ed && ed[0] >= '6' && ed[0] <= '0' + TR_DMAX_LIMIT) ? ed[0] - '0' : 6;
       KZ_HIP(hipMemsetAsync(TR.bFill, 0, (size_t)B * TR.MB * 4, st));
       KZ_HIP(hipMemsetAsync(TR.meta, 0, (size_t)B * TR_META * 4, st));
-      KZ_HIP(hipMemsetAsync(TR.err, 0, 4, st));
       KZ_LAUNCH(ctx, KID_TR_HIST16, k_tr_hist16, dim3(2, B), dim3(1024), src, bt.stride, A, TR);
       KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, 1, Dmax, 0);
-      const char* ep = getenv("KZ_TR_PARTS");
       const int P = ep ? std::max(1, atoi(ep)) : (B >= 2048 ? 1 : (B >= 1024 ? 2 : 8));
       for (int L = 2; L < Dmax; L++) {
         KZ_LAUNCH(ctx, KID_TR_COUNT, k_tr_count, dim3(P, B), dim3(1024), src, bt.stride, A.val[0], A, TR, L);
@@ -1794,7 +1804,6 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
       KZ_LAUNCH(ctx, KID_TR_SCATTER, k_tr_scatter, dim3(gridFor(maxN, TRS_TILE), B), dim3(1024), src, bt.stride, A.val[0], A.key[0], A, TR, bitsG);
       const int G = std::max(16, std::min(1024, 8192 / B));
       KZ_LAUNCH(ctx, KID_TR_SORT, k_tr_sort, dim3(G, B), dim3(1024), A.key[0], A, TR, bitsG);
-      KZ_HIP(hipMemcpyAsync(ctx->hpin + B, TR.err, 4, hipMemcpyDeviceToHost, st));
       wMax = 0;
     } else
     if (buckets) {
@@ -1812,7 +1821,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
       wMax = 0;
       for (int b = 0; b < B; b++) if (ctx->hpin[b] > wMax) wMax = ctx->hpin[b];
       windowed = true;
-      if (getenv("KZ_BWT_TRACE")) {
+      if (trace) {
         long long tot = 0; for (int b = 0; b < B; b++) tot += ctx->hpin[b];
         fprintf(stderr, "[bwt] round %d: %lld suffixes in oversized buckets, max per block %d\n", round, tot, wMax);
       }
@@ -1820,7 +1829,7 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
       KZ_HIP(hipMemsetAsync(A.d_w, 0, (size_t)B * 4, st));
       windowed = false;
     }
-    const bool trieWindow = useTrie && buckets && wMax > 0 && bitsR <= 24 && bitsG <= 24 && !(getenv("KZ_BWT_TRIEWIN") && getenv("KZ_BWT_TRIEWIN")[0] == '0');
+    const bool trieWindow = useTrie && buckets && wMax > 0 && bitsR <= 24 && bitsG <= 24 && !trieWinOff;
     if (trieWindow) {
       // ---- the window of oversized buckets through a KEY trie round (k_trk_*): count by key byte, move once, finish in LDS ----
       const KeySrc XK = {kC, vC, bitsR};
@@ -1865,11 +1874,15 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
     { u64* tk = kC; kC = kF; kF = tk; u32* tv = vC; vC = vF; vF = tv; }
     // ---- read back the next compact sizes ----
     KZ_HIP(hipMemcpyAsync(ctx->hpin, A.d_m2, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    // the trie tables' overflow flag rides along, every round that ran a trie (round 0 and the key rounds of the window): an
+    // overflow dropped buckets, the ranks of this pass are void (the bounds of tr_max_nodes / tr_max_buckets say it cannot happen)
+    ctx->hpin[B] = 0;
+    if (useTrie) KZ_HIP(hipMemcpyAsync(ctx->hpin + B, TR.err, 4, hipMemcpyDeviceToHost, st));
     KZ_HIP(kz_stream_sync(ctx, st));
     mMax = 0;
     for (int b = 0; b < B; b++) if (ctx->hpin[b] > mMax) mMax = ctx->hpin[b];
-    if (round == 0 && useTrie && ctx->hpin[B] != 0) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: trie tables overflow"); return -KZ_ERR_PROCESS_BLOCK; }
-    if (getenv("KZ_BWT_TRACE")) {                                   // diagnostic: live suffixes left after every doubling round
+    if (useTrie && (ctx->hpin[B] != 0 || round == forceOvfRound)) { *trieOverflow = true; return 0; }
+    if (trace) {                                   // diagnostic: live suffixes left after every doubling round
       long long tot = 0, totN = 0; for (int b = 0; b < B; b++) { tot += ctx->hpin[b]; totN += bt.h_len[b]; }
       fprintf(stderr, "[bwt] round %d h=%d: live %lld of %lld (%.1f%%), max per block %d\n", round, h, tot, totN, 100.0 * tot / (totN ? totN : 1), mMax);
     }
@@ -1885,4 +1898,16 @@ int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
   bt.cur ^= 1;
   { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }
   return 0;
+}
+
+int kz_stage_bwt_forward(kz_ctx* ctx, kz_batch& bt) {
+  const size_t mark = ctx->arenaTop;
+  bool overflow = false;
+  int rc = bwt_forward_run(ctx, bt, true, &overflow);
+  if (rc == 0 && overflow) {                                       // redo the batch on the LSD rounds (no tables to overflow); the input buffer is untouched
+    ctx->arenaTop = mark;
+    overflow = false;
+    rc = bwt_forward_run(ctx, bt, false, &overflow);
+  }
+  return rc;
 }

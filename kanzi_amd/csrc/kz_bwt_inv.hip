@@ -15,13 +15,16 @@
 // that; a block that fails the check (corrupted input) is marked BI_SUSPECT and redone by k_bwti_literal, which runs
 // the reference's 8 walkers literally (BWT.java:295-368, including its dummy link 0xFF behind row 0), so the bytes
 // and the verdict match the reference on ANY input -- slowly, but only for blocks no encoder produced.
-// Limit: n < 2^24-1 (the packed form; the reference switches to biPSIv2 above 8 MiB with the same
-// output) -- larger blocks return -KZ_ERR_BLOCK_SIZE.
+// Blocks of 2^24-1 bytes and more (round 5; the reference switches to inverseBiPSIv2 above 8 MiB, BWT.java:384-544, with the same
+// output) take the same kernels with 8-byte links ((next << 8) | byte with a 32-bit next): template parameter WIDE.  A pair
+// table like biPSIv2's would not halve the fetches here: with thousands of walkers that stop at grid ROWS, a two-step link splits
+// the text into an even and an odd path and the walkers started on the grid cover both (n hops in total again).
 #include "kz_device.h"
 #include "kz_internal.h"
 #define BI_LD(p) __builtin_nontemporal_load(p)   // link loads: every line is used for one 4-byte link per visit
 
 typedef uint32_t u32;
+typedef uint64_t u64;
 typedef uint8_t u8;
 
 #define BI_ITEMS 16
@@ -29,7 +32,8 @@ typedef uint8_t u8;
 
 struct BwtInv {
   const int32_t* ord; // [B] dense index of the block among the blocks of this call that have data (the [A] arrays below)
-  u32* data;        // [A][NS]
+  void* data;       // [A][NS] links: u32 (next << 8 | byte, next < 2^24-1) or, for batches with a block of 2^24-1 bytes or more, u64
+  int wide;
   u32* tileHist;    // [A][T][256]
   u32* bucket;      // [B][256]
   int32_t* n;       // [B] payload length
@@ -48,6 +52,20 @@ struct BwtInv {
   int GS;           // walker stride per block (grid points + 1)
 };
 #define BI_END 0xFFFFFFu
+// link formats: make(next, byte), next(link), END = the next of the row behind the last text byte
+template <bool WIDE> struct BiLink;
+template <> struct BiLink<false> {
+  typedef u32 T;
+  static constexpr u32 END = BI_END;
+  static __device__ __forceinline__ T make(u32 nx, u32 c) { return (nx << 8) | c; }
+  static __device__ __forceinline__ u32 next(T v) { return v >> 8; }
+};
+template <> struct BiLink<true> {
+  typedef u64 T;
+  static constexpr u32 END = 0xFFFFFFFFu;
+  static __device__ __forceinline__ T make(u32 nx, u32 c) { return ((u64)nx << 8) | (u64)c; }
+  static __device__ __forceinline__ u32 next(T v) { return (u32)(v >> 8); }
+};
 #define BI_CH 128          // bytes per recording chunk (segments average 256 bytes since round 5)
 #define BI_SUSPECT 1       // status: not stitched, k_bwti_literal decides
 #define BI_HEADS 8         // walkers G..G+7 start at the primary indexes (only head 0 records bytes)
@@ -83,7 +101,7 @@ __global__ void k_bwti_parse(const u8* __restrict__ src, int64_t stride, const i
     else {
       n = blockSize - headerSize;
       if (chunks != ((n < 256) ? 1 : 8)) status = -KZ_ERR_PROCESS_BLOCK;               // :158-159
-      else if (n >= (1 << 24) - 1) status = -KZ_ERR_BLOCK_SIZE;
+      else if (!V.wide && n >= (1 << 24) - 1) status = -KZ_ERR_BLOCK_SIZE;
       else {
         int pos = 1;
         for (int i = 0; i < chunks; i++) {
@@ -159,7 +177,9 @@ __global__ __launch_bounds__(256) void k_bwti_scan(BwtInv V) {
   V.bucket[b * 256 + threadIdx.x] = ex;
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(KZ_WG) void k_bwti_scatter(const u8* __restrict__ src, int64_t stride, BwtInv V) {
+  typedef BiLink<WIDE> LK;
   const int b = blockIdx.y, tile = blockIdx.x;
   const int n = V.n[b];
   if ((int64_t)tile * BI_TILE >= n) return;
@@ -167,7 +187,7 @@ __global__ __launch_bounds__(KZ_WG) void k_bwti_scatter(const u8* __restrict__ s
   for (int i = threadIdx.x; i < 1024; i += KZ_WG) (&cnt[0][0])[i] = 0;
   __syncthreads();
   const u8* s = src + (int64_t)b * stride + V.hdr[b];
-  u32* data = V.data + (int64_t)V.ord[b] * V.NS;
+  typename LK::T* data = (typename LK::T*)V.data + (int64_t)V.ord[b] * V.NS;
   const int pIdx = V.prim[b * 8];
   const int wave = threadIdx.x >> 6, lane = kz_lane();
   const int base = tile * BI_TILE + wave * (64 * BI_ITEMS);
@@ -205,8 +225,7 @@ __global__ __launch_bounds__(KZ_WG) void k_bwti_scatter(const u8* __restrict__ s
       const u32 pos = cnt[wave][c] + (dr[r] >> 8);
       // BWT.java:273-293: i<pIdx -> (i-1)<<8|c ; else i<<8|c.  i==0 is the row of the last text byte:
       // the reference stores a dummy link (0xFF00|c); an explicit END marker is stored here instead.
-      const u32 v = (i == 0) ? ((BI_END << 8) | c) : (((u32)(i < pIdx ? i - 1 : i) << 8) | c);
-      data[pos] = v;
+      data[pos] = LK::make((i == 0) ? LK::END : (u32)(i < pIdx ? i - 1 : i), c);
     }
   }
 }
@@ -216,7 +235,9 @@ __global__ __launch_bounds__(KZ_WG) void k_bwti_scatter(const u8* __restrict__ s
 // after k_bwti_resolve, so they are recorded into chunks of BI_CH bytes taken from a per-block pool (8 bytes
 // per store; chunkMeta = (walker, sequence number)); k_bwti_copy then moves every chunk to its place with
 // coalesced accesses.  A second walk would cost another cache line per byte.
+template <bool WIDE>
 __global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V, int b0) {
+  typedef BiLink<WIDE> LK;
   const int b = blockIdx.y + b0;
   const int n = V.n[b];
   if (n < 2 || V.status[b] != 0) return;
@@ -227,7 +248,7 @@ __global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V, int b0) {
   const int head = w - G;                                       // >= 0: starts at primary index `head`
   if (head > 0 && n < 256) { V.segLen[(int64_t)V.ord[b] * V.GS + w] = 0; V.segNext[(int64_t)V.ord[b] * V.GS + w] = -1; return; }   // one primary index only
   const bool rec = head <= 0;
-  const u32* data = V.data + (int64_t)V.ord[b] * V.NS;
+  const typename LK::T* data = (const typename LK::T*)V.data + (int64_t)V.ord[b] * V.NS;
   u8* pool = V.pool + (int64_t)V.ord[b] * V.maxChunks * BI_CH;
   uint2* meta = V.chunkMeta + (int64_t)V.ord[b] * V.maxChunks;
   u32 t = (head < 0) ? (u32)w << V.logS : (u32)(V.prim[b * 8 + head] - 1);
@@ -238,11 +259,11 @@ __global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V, int b0) {
   u8* cp = nullptr;
   bool full = false;
   // Segment lengths are geometric with mean S; a walk this long without meeting a grid point is not a text path.
-  const u32 cap = min((u32)n, 1u << 20);
+  const u32 cap = min((u32)n, max(1u << 20, (u32)S << 5));           // (32 x the mean: e^-32 of the segments of a well-formed block)
   while (steps <= cap) {
     if (t >= (u32)n) break;                                   // corrupt link
-    const u32 ptr = BI_LD(&data[t]);
-    acc |= (unsigned long long)(ptr & 0xFFu) << (8 * (steps & 7u));
+    const typename LK::T ptr = BI_LD(&data[t]);
+    acc |= (unsigned long long)((u32)ptr & 0xFFu) << (8 * (steps & 7u));
     steps++;
     if (rec && (steps & 7u) == 0) {
       if (fill == BI_CH) {
@@ -255,8 +276,8 @@ __global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V, int b0) {
       *(unsigned long long*)(cp + fill) = acc;
       fill += 8; acc = 0;
     }
-    t = ptr >> 8;
-    if (t == BI_END) { nxt = -1; break; }
+    t = LK::next(ptr);
+    if (t == LK::END) { nxt = -1; break; }
     if ((t & (u32)(S - 1)) == 0) { nxt = (int)(t >> V.logS); break; }
   }
   if (rec && (steps & 7u) != 0 && !full && nxt != -2) {       // partial tail
@@ -273,14 +294,16 @@ __global__ __launch_bounds__(64) void k_bwti_walk1(BwtInv V, int b0) {
 }
 
 // per block: the segments' text offsets = suffix sums of the segment lengths along the chain head -> ... -> END.
-// List ranking by a ruling set (round 5: up to 16 K segments of ~256 bytes; plain pointer jumping over all of them took 15
-// rounds of a 131 KB workgroup): every 16th grid segment and every head is a SPLITTER; a thread walks from its splitter to the
-// next one summing lengths (~16 dependent LDS reads), the ~1000 splitters are ranked by pointer jumping (11 rounds, one or two
-// per thread), and a second walk hands every segment its distance to the end of the text.
+// List ranking by a ruling set (round 5: up to 16 K segments of ~256 bytes): every 16th grid segment and every head is a
+// SPLITTER; a thread walks from its splitter to the next one summing lengths (~16 dependent loads from the block's 200 KB of
+// segment tables, L2 resident), the ~1000 splitters are ranked by pointer jumping in LDS (11 rounds), and a second walk hands
+// every segment its offset.  (Plain pointer jumping over all segments needs them in LDS: a 131 KB, 1024-thread workgroup per
+// block took 20 ms per class beside the other classes' RANK inverses; this form keeps 6 KB.)
 #define BI_MAXSEG 16448
-#define BI_RES_WG 1024
+#define BI_RES_WG 256
 #define BI_SPL 16
 #define BI_MAXSPL ((BI_MAXSEG + BI_SPL - 1) / BI_SPL + BI_HEADS + 4)
+#define BI_RES_ITEMS ((BI_MAXSPL + BI_RES_WG - 1) / BI_RES_WG)
 #define BI_NONE 0xFFFFu
 __global__ __launch_bounds__(BI_RES_WG) void k_bwti_resolve(BwtInv V, int b0) {
   const int b = blockIdx.x + b0;
@@ -289,18 +312,15 @@ __global__ __launch_bounds__(BI_RES_WG) void k_bwti_resolve(BwtInv V, int b0) {
   const int S = 1 << V.logS;
   const int G = (n + S - 1) >> V.logS;
   const int M = G + BI_HEADS;
-  __shared__ u32 R[BI_MAXSEG];              // segment lengths, then (in place) bytes from the segment's start to the end of the text
-  __shared__ uint16_t NX[BI_MAXSEG];        // next segment, BI_NONE = end of text
-  __shared__ u32 spT[BI_MAXSPL];            // splitter: bytes of its sublist, then its suffix sum
+  __shared__ u32 spT[BI_MAXSPL];            // splitter: bytes of its sublist, then bytes from its start to the end of the text
   __shared__ uint16_t spN[BI_MAXSPL];       // splitter: next splitter (index into the splitter list), BI_NONE = end of text
   __shared__ int bad;
   const int64_t o = (int64_t)V.ord[b] * V.GS;
-  for (int i = threadIdx.x; i < M; i += BI_RES_WG) {
-    R[i] = V.segLen[o + i];
-    const int nx = V.segNext[o + i];
-    NX[i] = (nx < 0 || nx >= M) ? (uint16_t)BI_NONE : (uint16_t)nx;
-  }
+  const u32* __restrict__ segLen = V.segLen + o;
+  const int32_t* __restrict__ segNext = V.segNext + o;
+  u32* __restrict__ segOff = V.segOff + o;
   if (threadIdx.x == 0) bad = 0;
+  for (int i = threadIdx.x; i < M; i += BI_RES_WG) segOff[i] = 0xFFFFFFFFu;   // segments no splitter reaches are not on the text path
   __syncthreads();
   const int NG = (G + BI_SPL - 1) / BI_SPL;              // splitters among the grid segments: 0, 16, 32, ...
   const int NSP = NG + BI_HEADS;                         // ... and the heads G .. G+7
@@ -309,24 +329,23 @@ __global__ __launch_bounds__(BI_RES_WG) void k_bwti_resolve(BwtInv V, int b0) {
     int v = k < NG ? k * BI_SPL : G + (k - NG);
     u32 sum = 0, next = BI_NONE;
     for (int steps = 0;; steps++) {
-      sum += R[v];
-      const u32 nx = NX[v];
-      if (nx == BI_NONE) break;
-      if ((int)nx >= G || (nx % BI_SPL) == 0) { next = (int)nx >= G ? (u32)NG + (nx - (u32)G) : nx / BI_SPL; break; }
+      sum += segLen[v];
+      const int nx = segNext[v];
+      if (nx < 0 || nx >= M) break;
+      if (nx >= G || (nx % BI_SPL) == 0) { next = nx >= G ? (u32)(NG + (nx - G)) : (u32)(nx / BI_SPL); break; }
       if (steps > M) { bad = 1; break; }                  // a cycle that holds no splitter: not a text path
-      v = (int)nx;
+      v = nx;
     }
     spT[k] = sum; spN[k] = (uint16_t)next;
   }
   __syncthreads();
-  // 2. suffix sums over the splitters (pointer jumping; NSP <= 2 * BI_RES_WG)
-  static_assert(BI_MAXSPL <= 2 * BI_RES_WG, "two splitters per thread");
+  // 2. suffix sums over the splitters (pointer jumping)
   int rounds = 1;
   while ((1 << rounds) < NSP) rounds++;
   for (int round = 0; round < rounds; round++) {
-    u32 t2[2]; u32 n2[2];
+    u32 t2[BI_RES_ITEMS]; u32 n2[BI_RES_ITEMS];
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < BI_RES_ITEMS; q++) {
       const int k = (int)threadIdx.x + q * BI_RES_WG;
       if (k < NSP) {
         const u32 nx = spN[k];
@@ -336,41 +355,40 @@ __global__ __launch_bounds__(BI_RES_WG) void k_bwti_resolve(BwtInv V, int b0) {
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
+    for (int q = 0; q < BI_RES_ITEMS; q++) {
       const int k = (int)threadIdx.x + q * BI_RES_WG;
       if (k < NSP) { spT[k] = t2[q]; spN[k] = (uint16_t)n2[q]; }
     }
     __syncthreads();
   }
-  // 3. every segment of a sublist: bytes to the end of the text
+  // 3. every segment of a sublist: its text offset.  (Heads 1..7 start inside another splitter's sublist -- the grid segments
+  //    behind them are that splitter's to number; every writer of a shared segment would store the same value anyway.)
   for (int k = threadIdx.x; k < NSP; k += BI_RES_WG) {
     int v = k < NG ? k * BI_SPL : G + (k - NG);
-    u32 running = spT[k];
+    u32 running = spT[k];                                 // bytes from the start of v to the end of the text
     for (int steps = 0;; steps++) {
-      const u32 len = R[v];
-      R[v] = running;
-      running -= len;
-      const u32 nx = NX[v];
-      if (nx == BI_NONE || (int)nx >= G || (nx % BI_SPL) == 0 || steps > M) break;
-      v = (int)nx;
+      segOff[v] = running <= (u32)n ? (u32)n - running : 0xFFFFFFFFu;
+      if (k > NG) break;                                  // heads 1..7: only their own offset (for the check below)
+      running -= segLen[v];
+      const int nx = segNext[v];
+      if (nx < 0 || nx >= G || (nx % BI_SPL) == 0 || steps > M) break;
+      v = nx;
     }
   }
-  __syncthreads();
-  // R[i] = bytes from the start of segment i to the end of the text.  Stitching is right when head 0 reaches END
-  // after exactly n steps (then every link is on that path) and, with 8 primary indexes, head k sits k*ckSize steps
-  // into it (BWT.java:296-314); otherwise the literal walkers take over.
+  // Stitching is right when head 0 reaches END after exactly n steps (then every link is on that path) and, with 8 primary
+  // indexes, head k sits k*ckSize steps into it (BWT.java:296-314); otherwise the literal walkers take over.
   if (threadIdx.x < BI_HEADS) {
     const int k = threadIdx.x;
     const bool atEnd = spN[NG + k] == BI_NONE;             // its chain of splitters ends at END (not in a cycle)
+    const u32 Rk = spT[NG + k];
     bool good = true;
-    if (k == 0) good = (R[G] == (u32)n && atEnd && !bad);
+    if (k == 0) good = (Rk == (u32)n && atEnd && !bad);
     else if (n >= 256) {
       const u32 ckSize = (u32)(((n & 7) == 0) ? (n >> 3) : (n >> 3) + 1);
-      good = (atEnd && R[G + k] <= (u32)n && (u32)n - R[G + k] == (u32)k * ckSize);
+      good = (atEnd && Rk <= (u32)n && (u32)n - Rk == (u32)k * ckSize);
     }
     if (!good) atomicCAS(&V.status[b], 0, BI_SUSPECT);
   }
-  for (int i = threadIdx.x; i < M; i += BI_RES_WG) V.segOff[o + i] = (R[i] <= (u32)n) ? (u32)n - R[i] : 0xFFFFFFFFu;
 }
 
 // move every recorded chunk to its place in the text: BI_CH / 4 lanes per chunk, 4 bytes per lane
@@ -401,12 +419,14 @@ __global__ __launch_bounds__(256) void k_bwti_copy(u8* __restrict__ dst, int64_t
 // The reference's walkers, literally (BWT.java:295-368): lane k follows the links from primary index k for its
 // share of the text; the link behind row 0 is the reference's dummy 0xFF (stored as BI_END here).  Only for blocks
 // k_bwti_resolve would not stitch.
+template <bool WIDE>
 __global__ __launch_bounds__(64) void k_bwti_literal(u8* __restrict__ dst, int64_t stride, BwtInv V) {
+  typedef BiLink<WIDE> LK;
   const int b = blockIdx.x;
   if (V.status[b] != BI_SUSPECT) return;
   const int n = V.n[b];
   const int lane = threadIdx.x;
-  const u32* data = V.data + (int64_t)V.ord[b] * V.NS;
+  const typename LK::T* data = (const typename LK::T*)V.data + (int64_t)V.ord[b] * V.NS;
   u8* o = dst + (int64_t)b * stride;
   bool fail = false;
   const int walkers = (n < 256) ? 1 : 8;
@@ -417,10 +437,10 @@ __global__ __launch_bounds__(64) void k_bwti_literal(u8* __restrict__ dst, int64
     u8* q = o + (int64_t)lane * ckSize;
     for (int i = 0; i < steps; i++) {
       if (t >= (u32)n) { fail = true; break; }                 // Java: data[t] out of range throws
-      const u32 ptr = data[t];
+      const typename LK::T ptr = data[t];
       q[i] = (u8)ptr;
-      t = ptr >> 8;
-      if (t == BI_END) t = 0xFF;
+      t = LK::next(ptr);
+      if (t == LK::END) t = 0xFF;
     }
   }
   const bool anyFail = kz_ballot(fail) != 0;
@@ -442,7 +462,7 @@ size_t kz_bwt_inverse_scratch(int B, int maxN) {
   const int64_t NS = (int64_t)kz_align((size_t)maxN + 64, BI_TILE);
   const int T = (int)(NS / BI_TILE);
   const size_t maxChunks = (size_t)NS / BI_CH + BI_MAXSEG + 8;
-  return (size_t)B * ((size_t)NS * 4 + (size_t)T * 1024 + 1024 + 64 * 4 + (size_t)BI_MAXSEG * 12 + maxChunks * (BI_CH + 8) + 512) + 16384;
+  return (size_t)B * ((size_t)NS * (maxN >= (1 << 24) - 1 ? 8 : 4) + (size_t)T * 1024 + 1024 + 64 * 4 + (size_t)BI_MAXSEG * 12 + maxChunks * (BI_CH + 8) + 512) + 16384;
 }
 
 int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
@@ -459,7 +479,8 @@ int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
   if (A < 1) A = 1;
   int32_t* d_ord = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   V.ord = d_ord;
-  V.data = (u32*)kz_arena_alloc(ctx, (size_t)V.NS * A * 4);
+  V.wide = maxN >= (1 << 24) - 1 ? 1 : 0;                            // (maxN counts the header: a block this long may hold n >= 2^24-1)
+  V.data = kz_arena_alloc(ctx, (size_t)V.NS * A * (V.wide ? 8 : 4));
   V.tileHist = (u32*)kz_arena_alloc(ctx, (size_t)V.T * A * 1024);
   V.bucket = (u32*)kz_arena_alloc(ctx, (size_t)B * 1024);
   V.n = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
@@ -487,7 +508,8 @@ int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
   if (tiles > 0) {
     KZ_LAUNCH(ctx, KID_BWTI_HIST, k_bwti_hist, dim3(tiles, B), dim3(KZ_WG), src, bt.stride, V);
     KZ_LAUNCH(ctx, KID_BWTI_SCAN, k_bwti_scan, dim3(B), dim3(256), V);
-    KZ_LAUNCH(ctx, KID_BWTI_SCATTER, k_bwti_scatter, dim3(tiles, B), dim3(KZ_WG), src, bt.stride, V);
+    if (V.wide) { KZ_LAUNCH(ctx, KID_BWTI_SCATTER, k_bwti_scatter<true>, dim3(tiles, B), dim3(KZ_WG), src, bt.stride, V); }
+    else { KZ_LAUNCH(ctx, KID_BWTI_SCATTER, k_bwti_scatter<false>, dim3(tiles, B), dim3(KZ_WG), src, bt.stride, V); }
   }
   if (maxN >= 2) {
     // The walks are dependent random 4-byte loads over a 4n-byte link array per block: bandwidth bound at one
@@ -500,11 +522,13 @@ int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
     if (group > B) group = B;
     for (int b0 = 0; b0 < B; b0 += group) {
       const int nb = (B - b0 < group) ? B - b0 : group;
-      KZ_LAUNCH(ctx, KID_BWTI_WALK1, k_bwti_walk1, dim3((V.GS + 63) / 64, nb), dim3(64), V, b0);
+      if (V.wide) { KZ_LAUNCH(ctx, KID_BWTI_WALK1, k_bwti_walk1<true>, dim3((V.GS + 63) / 64, nb), dim3(64), V, b0); }
+      else { KZ_LAUNCH(ctx, KID_BWTI_WALK1, k_bwti_walk1<false>, dim3((V.GS + 63) / 64, nb), dim3(64), V, b0); }
       KZ_LAUNCH(ctx, KID_BWTI_RESOLVE, k_bwti_resolve, dim3(nb), dim3(BI_RES_WG), V, b0);
       KZ_LAUNCH(ctx, KID_BWTI_COPY, k_bwti_copy, dim3((V.maxChunks + BI_CPW - 1) / BI_CPW, nb), dim3(256), dst, bt.stride, V, b0);
     }
-    KZ_LAUNCH(ctx, KID_BWTI_LITERAL, k_bwti_literal, dim3(B), dim3(64), dst, bt.stride, V);
+    if (V.wide) { KZ_LAUNCH(ctx, KID_BWTI_LITERAL, k_bwti_literal<true>, dim3(B), dim3(64), dst, bt.stride, V); }
+    else { KZ_LAUNCH(ctx, KID_BWTI_LITERAL, k_bwti_literal<false>, dim3(B), dim3(64), dst, bt.stride, V); }
   }
   KZ_LAUNCH(ctx, KID_BWTI_FIN, k_bwti_fin, dim3((B + 255) / 256), dim3(256), src, dst, bt.stride, V, bt.d_len2, bt.d_flag, B);
   KZ_HIP(hipGetLastError());

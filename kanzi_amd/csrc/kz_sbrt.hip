@@ -603,6 +603,70 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
   }
 }
 
+// Blocks of 2^24-256 bytes and more (round 5): the packed (q << 8 | symbol) list of k_sbrt_inverse holds 24-bit timestamps, so
+// longer blocks take this plain form of SBRT.inverse (SBRT.java:154-214): one wave per block, the list BY POSITION in LDS
+// (symbol, q, p of the entry at position j), a step = the reference's bubble loop done at once: the entry at rank r moves up to
+// rp = 1 + the highest position below r whose q is above the new qc, the entries of [rp, r) move down by one.  Zero ranks (most
+// of a transformed block) only touch position 0.  ~200 ns per non-zero rank: a fallback for rare block sizes, not a fast path.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_sbrt_inverse_wide(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride, const int32_t* __restrict__ d_len, int B) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int n = d_len[b];
+  if (n <= 0) return;
+  __shared__ u32 S[256], Q[256], P[256];
+  const int lane = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { S[k * 64 + lane] = (u32)(k * 64 + lane); Q[k * 64 + lane] = 0; P[k * 64 + lane] = 0; }
+  __syncthreads();
+  const u8* in = src + (int64_t)b * stride;
+  u8* out = dst + (int64_t)b * stride;
+  constexpr u32 m1 = (MODE == 3) ? 0u : 0xFFFFFFFFu;     // MODE_TIMESTAMP
+  constexpr u32 m2 = (MODE == 1) ? 0u : 0xFFFFFFFFu;     // MODE_MTF
+  constexpr int sh = (MODE == 2) ? 1 : 0;                // MODE_RANK
+  for (int base = 0; base < n; base += 64) {
+    const int cnt = min(64, n - base);
+    const u32 rv = lane < cnt ? (u32)in[base + lane] : 0u;
+    u32 ov = 0;
+    for (int t = 0; t < cnt; t++) {
+      const int r = __builtin_amdgcn_readlane((int)rv, t);
+      const u32 i = (u32)(base + t);
+      const u32 c = S[r], pc = P[r];                      // uniform addresses: broadcast reads
+      const u32 qc = ((i & m1) + (pc & m2)) >> sh;
+      if (lane == t) ov = c;
+      int rp = 0;
+      if (r > 0) {
+        // highest position j < r with Q[j] > qc (the bubble loop stops there: SBRT.java:203)
+        int hi = -1;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+          const int j = k * 64 + lane;
+          const uint64_t g = kz_ballot(j < r && Q[j] > qc);
+          if (g && hi < 0) hi = k * 64 + 63 - (int)__builtin_clzll(g);
+        }
+        rp = hi + 1;
+        if (rp < r) {
+          u32 ts[4], tq[4], tp[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int j = k * 64 + lane;
+            const bool mv = j > rp && j <= r;
+            ts[k] = mv ? S[j - 1] : 0; tq[k] = mv ? Q[j - 1] : 0; tp[k] = mv ? P[j - 1] : 0;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int j = k * 64 + lane;
+            if (j > rp && j <= r) { S[j] = ts[k]; Q[j] = tq[k]; P[j] = tp[k]; }
+          }
+        }
+      }
+      if (lane == 0) { S[rp] = c; Q[rp] = qc; P[rp] = i; }
+      __syncthreads();                                      // one wave: orders lane 0's entry before the next step's reads
+    }
+    if (lane < cnt) out[base + lane] = (u8)ov;
+  }
+}
+
 __global__ void k_copy_len(const int32_t* a, int32_t* o, int32_t* flag, int B) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) { o[b] = a[b]; flag[b] = 1; }
@@ -708,13 +772,21 @@ int kz_place_blocks(kz_ctx* ctx, const kz_batch& bt, KzPlacement& PL) {
 
 int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
   const int B = bt.B;
-  for (int b = 0; b < B; b++) if (bt.h_len[b] >= (1 << 24) - 256) {
-    snprintf(ctx->err, sizeof(ctx->err), "sbrt_inverse: block of %d bytes exceeds the packed-key limit 2^24-256", bt.h_len[b]);
-    return -KZ_ERR_BLOCK_SIZE;
-  }
   hipStream_t st = ctx->stream;
   const u8* src = bt.buf[bt.cur];
   u8* dst = bt.buf[bt.cur ^ 1];
+  bool wide = false;
+  for (int b = 0; b < B; b++) wide |= bt.h_len[b] >= (1 << 24) - 256;
+  if (wide) {                                                      // a block beyond the packed list's 24-bit timestamps: the plain form for the whole call
+    if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse_wide<2>, dim3(B), dim3(64), src, dst, bt.stride, bt.d_len, B); }
+    else if (mode == 1) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse_wide<1>, dim3(B), dim3(64), src, dst, bt.stride, bt.d_len, B); }
+    else { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse_wide<3>, dim3(B), dim3(64), src, dst, bt.stride, bt.d_len, B); }
+    KZ_LAUNCH(ctx, KID_COPY_LEN, k_copy_len, dim3((B + 255) / 256), dim3(256), bt.d_len, bt.d_len2, bt.d_flag, B);
+    KZ_HIP(hipGetLastError());
+    bt.cur ^= 1;
+    { int32_t* t = bt.d_len; bt.d_len = bt.d_len2; bt.d_len2 = t; }
+    return 0;
+  }
   KzPlacement PL;
   { const int prc = kz_place_blocks(ctx, bt, PL); if (prc) return prc; }
   const int wpg = PL.wpg, R = PL.R;

@@ -890,6 +890,24 @@ def test_large_blocks_match_oracle(ctx):
         assert kz.CompressedInputStream(ctx, ref).read() == data
 
 
+def test_blocks_above_16_mib_match_oracle(ctx):
+    """Blocks of 2^24 bytes and more (round 5; the reference goes to 1 GiB and switches its inverse BWT to inverseBiPSIv2 above
+    8 MiB, BWT.java:231-234,384-544, with the same output): 8-byte links in the inverse BWT, the plain by-position list in the
+    RANK / MTFT inverse.  A 32 MiB block + ragged tail through the level-5 core chain, a 20 MiB block size through MTFT."""
+    rng = np.random.default_rng(6)
+    words = [bytes(rng.integers(97, 123, int(rng.integers(2, 10)), dtype=np.uint8)) for _ in range(800)]
+    text = b" ".join(words[int(i)] for i in rng.integers(0, 800, 5_000_000))
+    data = text[:30 * 1024 * 1024] + bytes(rng.integers(0, 256, 1_500_000, dtype=np.uint8)) + bytes(700000) + datagen.block(2, 3_000_000).tobytes() + text[:1234567]
+    assert len(data) > 32 * 1024 * 1024 + 1000000
+    for bs, chain, ent in ((32 * 1024 * 1024, "BWT+RANK+ZRLT", "ANS0"), (20 * 1024 * 1024, "BWT+MTFT+ZRLT", "HUFFMAN")):
+        ref = oracle.compress(chain, ent, bs, data, jobs=2)
+        cos = kz.CompressedOutputStream(ctx, chain, ent, bs)
+        cos.write(data)
+        cos.close()
+        assert cos.output == ref, (bs, chain)
+        assert kz.CompressedInputStream(ctx, ref).read() == data
+
+
 def test_levels_1_to_3_tail_at_4mib_blocks(ctx):
     """The reference's level 1 (LZX & NONE), level 2 (DNA+LZ & HUFFMAN) and the tail of level 3 (PACK+MM+LZX &
     HUFFMAN) at the default 4 MiB block size, on a stream whose blocks take every route: text (digram aliases), DNA
@@ -1479,3 +1497,17 @@ def test_differential_fuzz_tools_bounded(tool, seconds, seed):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", tool + ".py"), str(seconds), str(seed)], capture_output=True, text=True, timeout=300)
     tail = (r.stdout + r.stderr)[-1500:]
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, tail
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("at_round", ["0", "1"])
+def test_bwt_forward_falls_back_when_the_trie_tables_overflow(ctx, monkeypatch, at_round):
+    """an overflow of the trie tables (round 0 or a key round of the window; the table bounds say it cannot happen) must
+    not fail the batch nor leave mis-ranked suffixes behind: the stage is redone on the LSD rounds.  The overflow is simulated
+    (KZ_BWT_TEST_TRIE_OVERFLOW=<round>)."""
+    monkeypatch.setenv("KZ_BWT_TEST_TRIE_OVERFLOW", at_round)
+    for i, c in enumerate((0, 2, 4, 1)):
+        d = datagen.block(i, 300000, c).tobytes()
+        ok_o, enc_o = oracle.transform_forward("BWT", d)
+        ok_g, enc_g = _fwd(ctx, kz.BWT_TYPE, d)
+        assert ok_g == ok_o and enc_g == enc_o, (at_round, c)
