@@ -6,6 +6,8 @@
 //   chase4geo : the same with geometric chain lengths per lane (mean = steps)      (k_bwti_walk1 as it is: lanes idle behind the longest)
 //   scatter4  : random 4-byte stores                                              (rank / suffix-array stores of the suffix sort)
 //   stream16w : coalesced 16 B / lane streaming write
+//   chaseblk  : ONE lane per wave follows a dependent chain inside its own 2 MiB region (waves = blocks): the latency of a
+//               serial per-block coder that probes a per-block hash map in HBM (what a TEXT inverse on the GPU would do per word)
 // Usage: ubench_gather <kernel> [array MiB = 4096] [steps per lane = 256] [waves = 65536]
 // Prints one line: kernel, elapsed ms, accesses, G accesses / s, useful GB/s.  Run it under
 //   rocprofv3 --pmc FETCH_SIZE -- ...   and   rocprofv3 --pmc WRITE_SIZE -- ...
@@ -59,6 +61,15 @@ __global__ void k_chase4(const u32* __restrict__ a, u64 n, int steps, int geo, u
     if ((threadIdx.x & 63) == 0) atomicAdd(total, s);
   }
 }
+__global__ void k_chaseblk(const u32* __restrict__ a, u64 n, int steps, u32* sink) {
+  const u64 region = 512 * 1024;                                // 2 MiB of u32 per wave
+  const u64 base = ((u64)blockIdx.x * region) % (n - region);
+  u32 p = (u32)(mix(blockIdx.x) % region);
+  if (threadIdx.x == 0) {
+    for (int j = 0; j < steps; j++) p = __builtin_nontemporal_load(&a[base + p]) % (u32)region;
+    sink[blockIdx.x & 15] = p;                                  // (keeps the chain alive)
+  }
+}
 __global__ void k_scatter4(u32* __restrict__ a, u64 n, int steps) {
   const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   for (int j = 0; j < steps; j++) a[mix(t * 1000003ULL + (u64)j) % n] = (u32)j;
@@ -83,11 +94,13 @@ int main(int argc, char** argv) {
     else if (!strcmp(k, "gather4")) { hipLaunchKernelGGL(k_gather4, dim3(waves / 4), dim3(256), 0, 0, a, n, steps, sink); acc = (double)waves * 64 * steps; useful = acc * 4; }
     else if (!strcmp(k, "chase4")) { hipLaunchKernelGGL(k_chase4, dim3(waves), dim3(64), 0, 0, a, n, steps, 0, sink, total); acc = (double)waves * 64 * steps; useful = acc * 4; }
     else if (!strcmp(k, "chase4geo")) { hipLaunchKernelGGL(k_chase4, dim3(waves), dim3(64), 0, 0, a, n, steps, 1, sink, total); }
+    else if (!strcmp(k, "chaseblk")) { hipLaunchKernelGGL(k_chaseblk, dim3(waves), dim3(64), 0, 0, a, n, steps, sink); acc = (double)waves * steps; useful = acc * 4; }
     else if (!strcmp(k, "scatter4")) { hipLaunchKernelGGL(k_scatter4, dim3(waves / 4), dim3(256), 0, 0, a, n, steps); acc = (double)waves * 64 * steps; useful = acc * 4; }
     else { fprintf(stderr, "unknown kernel %s\n", k); return 2; }
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     if (!strcmp(k, "chase4geo")) { unsigned long long t; CK(hipMemcpy(&t, total, 8, hipMemcpyDeviceToHost)); acc = (double)t; useful = acc * 4; }
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep == 1 && !strcmp(k, "chaseblk")) printf("chaseblk: %.1f ns per dependent load of one lane, %d waves side by side\n", ms * 1e6 / steps, waves);
     if (rep == 1) printf("%s array %llu MiB steps %d waves %d: %.2f ms, %.0f accesses, %.2f G accesses/s, %.1f useful GB/s\n", k, (unsigned long long)mib, steps, waves, ms, acc, acc / ms / 1e6, useful / ms / 1e6);
   }
   return 0;
