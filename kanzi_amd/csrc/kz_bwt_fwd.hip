@@ -1048,6 +1048,7 @@ __global__ __launch_bounds__(256) void k_tr_assign(BwtArrays A, TrieArrays T, in
 
 // level L >= 2: every suffix that is still inside an expanded node of depth L-1 looks its child up; children that were
 // expanded (nodes of depth L) count the suffix's byte L in LDS.  state[i] = the suffix's leaf, or node | depth << 16.
+#define TRC_U 4                  // quads of suffixes a thread keeps in flight
 __global__ __launch_bounds__(1024) void k_tr_count(const u8* __restrict__ srcAll, int64_t stride, u32* __restrict__ stateAll, BwtArrays A, TrieArrays T, int L) {
   const int b = blockIdx.y;
   const int32_t* meta = T.meta + (int64_t)b * TR_META;
@@ -1068,10 +1069,10 @@ __global__ __launch_bounds__(1024) void k_tr_count(const u8* __restrict__ srcAll
     const int nlo = lo + chunk * TR_NODECHUNK;
     // a thread takes four CONSECUTIVE suffixes: one 16-byte state access and one 8-byte text window serve all four, equal
     // targets in a row (runs) are added once; two such quads per thread are in flight (the chain state -> info -> counter is latency)
-    for (int i0 = pbeg; i0 < pend; i0 += 2 * 4096) {
-      uint4 st4[2]; u64 win[2]; bool any[2];
+    for (int i0 = pbeg; i0 < pend; i0 += TRC_U * 4096) {
+      uint4 st4[TRC_U]; u64 win[TRC_U]; bool any[TRC_U];
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < TRC_U; u++) {
         const int i = i0 + u * 4096 + threadIdx.x * 4;
         any[u] = i < pend;
         st4[u] = make_uint4(0xC0000000u, 0xC0000000u, 0xC0000000u, 0xC0000000u);
@@ -1085,19 +1086,27 @@ __global__ __launch_bounds__(1024) void k_tr_count(const u8* __restrict__ srcAll
           win[u] = k;
         }
       }
+      // the info lookups of ALL the quads are issued before any of them is used: one workgroup per CU (128 KiB of counters)
+      // hides the chain state -> info -> counter only by what a thread keeps in flight
+      u32 stqA[TRC_U][4]; u32 eA[TRC_U][4]; bool lookA[TRC_U][4];
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
-        if (!any[u]) continue;
+      for (int u = 0; u < TRC_U; u++) {
         const int i = i0 + u * 4096 + threadIdx.x * 4;
-        u32 stq[4] = {st4[u].x, st4[u].y, st4[u].z, st4[u].w};
-        u32 e[4]; bool look[4];
+        stqA[u][0] = st4[u].x; stqA[u][1] = st4[u].y; stqA[u][2] = st4[u].z; stqA[u][3] = st4[u].w;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          if (L == 2 && chunk == 0) stq[q] = (i + q < pend) ? ((1u << 16) | (u32)((win[u] >> (56 - 8 * q)) & 0xFFu)) : 0xC0000000u;
-          look[q] = (i + q < pend) && (stq[q] >> 30) == 0 && ((stq[q] >> 16) & 7u) != (u32)L;
-          e[q] = 0;
-          if (look[q]) e[q] = info[(stq[q] & 0xFFFFu) * 256 + (u32)((win[u] >> (48 - 8 * q)) & 0xFFu)];
+          if (L == 2 && chunk == 0) stqA[u][q] = (any[u] && i + q < pend) ? ((1u << 16) | (u32)((win[u] >> (56 - 8 * q)) & 0xFFu)) : 0xC0000000u;
+          lookA[u][q] = any[u] && (i + q < pend) && (stqA[u][q] >> 30) == 0 && ((stqA[u][q] >> 16) & 7u) != (u32)L;
+          eA[u][q] = 0;
+          if (lookA[u][q]) eA[u][q] = info[(stqA[u][q] & 0xFFFFu) * 256 + (u32)((win[u] >> (48 - 8 * q)) & 0xFFu)];
         }
+      }
+#pragma unroll
+      for (int u = 0; u < TRC_U; u++) {
+        if (!any[u]) continue;
+        const int i = i0 + u * 4096 + threadIdx.x * 4;
+        u32 (&stq)[4] = stqA[u];
+        u32 (&e)[4] = eA[u]; bool (&look)[4] = lookA[u];
         bool changed = false;
         u32 runT = 0xFFFFFFFFu, runC = 0;
 #pragma unroll
@@ -1160,22 +1169,51 @@ __global__ __launch_bounds__(1024) void k_tr_scatter(const u8* __restrict__ srcA
   u32* rank = A.rank + (int64_t)b * A.NS;
   const u64 lowMask = (1ULL << bitsG) - 1ULL;
   u64 el[TRS_ITEMS]; u32 bp[TRS_ITEMS];                                  // element, bucket | position in (tile, bucket) << 16
+  // three rounds of loads for the tile's eight items per thread, each round issued for all items before its results are used
+  // (state -> info -> text is a dependent chain; one item after the other was 24 memory round trips per thread, the kernel's time)
+  u32 stv[TRS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < TRS_ITEMS; r++) {
+    const int i = tbase + r * 1024 + threadIdx.x;
+    stv[r] = 0xC0000000u;
+    if (i < n) stv[r] = hasState ? state[i] : ((u32)s[i] | (1u << 16));
+  }
+  u32 cb[TRS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < TRS_ITEMS; r++) {
+    const int i = tbase + r * 1024 + threadIdx.x;
+    cb[r] = 0;
+    if (i < n && (stv[r] >> 30) == 0) cb[r] = tr_byte(s, i + (int)((stv[r] >> 16) & 7u), n);
+  }
+#pragma unroll
+  for (int r = 0; r < TRS_ITEMS; r++) {
+    const int i = tbase + r * 1024 + threadIdx.x;
+    if (i < n && (stv[r] >> 30) == 0) stv[r] = info[(stv[r] & 0xFFFFu) * 256 + cb[r]];
+  }
+  u64 kv[TRS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < TRS_ITEMS; r++) {
+    const int i = tbase + r * 1024 + threadIdx.x;
+    kv[r] = 0;
+    if (i < n && (stv[r] >> 30) != TR_K_TERM) {
+      const int at = i + (int)((stv[r] >> 16) & 7u);
+      u64 k = __builtin_bswap64(*(const bw_u64_unaligned*)(s + at));
+      const int rem = n - at;
+      if (rem < 8) k = rem <= 0 ? 0ULL : (k & (~0ULL << (8 * (8 - rem))));
+      kv[r] = k;
+    }
+  }
 #pragma unroll
   for (int r = 0; r < TRS_ITEMS; r++) {
     const int i = tbase + r * 1024 + threadIdx.x;
     bp[r] = 0xFFFFFFFFu;
     el[r] = 0;
     if (i < n) {
-      u32 st = hasState ? state[i] : ((u32)s[i] | (1u << 16));
-      if ((st >> 30) == 0) st = info[(st & 0xFFFFu) * 256 + tr_byte(s, i + (int)((st >> 16) & 7u), n)];
+      const u32 st = stv[r];
       if ((st >> 30) == TR_K_TERM) rank[i] = (st & 0xFFFFFFu) | BW_LIVE;
       else {
         const u32 bk = st & 0xFFFFu;
-        const int at = i + (int)((st >> 16) & 7u);
-        u64 k = __builtin_bswap64(*(const bw_u64_unaligned*)(s + at));
-        const int rem = n - at;
-        if (rem < 8) k = rem <= 0 ? 0ULL : (k & (~0ULL << (8 * (8 - rem))));
-        el[r] = (k & ~lowMask) | (u64)(u32)i;
+        el[r] = (kv[r] & ~lowMask) | (u64)(u32)i;
         const u32 old = atomicAdd(&tc2[bk >> 1], (bk & 1u) ? 65536u : 1u);
         const u32 pos = (bk & 1u) ? (old >> 16) : (old & 0xFFFFu);
         bp[r] = bk | (pos << 16);
@@ -1476,50 +1514,65 @@ __global__ __launch_bounds__(1024) void k_trk_count(KeySrc X, u32* __restrict__ 
     for (int i = threadIdx.x; i < TR_NODECHUNK * 256; i += 1024) lds[i] = 0;
     __syncthreads();
     const int nlo = lo + chunk * TR_NODECHUNK;
-    // a thread takes four CONSECUTIVE items (two 16-byte key loads, one 16-byte state access); equal targets in a row are added once
-    for (int i0 = pbeg; i0 < pend; i0 += 4096) {
-      const int i = i0 + threadIdx.x * 4;
-      if (i >= pend) continue;
-      u64 kq[4]; u32 stq[4];
-      if (!(L == 2 && chunk == 0)) {                                     // settled items (most of a late level's window) cost one state read
-        const uint4 sv = *(const uint4*)(state + i);
-        stq[0] = sv.x; stq[1] = sv.y; stq[2] = sv.z; stq[3] = sv.w;
-        if ((stq[0] >> 30) && (stq[1] >> 30) && (stq[2] >> 30) && (stq[3] >> 30)) continue;
-      }
-      if (i + 4 <= pend && ((((uintptr_t)(key + i)) & 15) == 0)) {
-        const uint4 a = *(const uint4*)(key + i), c = *(const uint4*)(key + i + 2);
-        kq[0] = ((u64)a.y << 32) | a.x; kq[1] = ((u64)a.w << 32) | a.z; kq[2] = ((u64)c.y << 32) | c.x; kq[3] = ((u64)c.w << 32) | c.z;
-      } else {
+    // a thread takes four CONSECUTIVE items (two 16-byte key loads, one 16-byte state access); equal targets in a row are added once;
+    // TRC_U such quads are in flight per thread: all their loads, then all their info lookups, then the counters
+    for (int i0 = pbeg; i0 < pend; i0 += TRC_U * 4096) {
+      u64 kq[TRC_U][4]; u32 stq[TRC_U][4]; bool act[TRC_U];
 #pragma unroll
-        for (int q = 0; q < 4; q++) kq[q] = (i + q < pend) ? key[i + q] : 0ULL;
-      }
-      if (L == 2 && chunk == 0) { stq[0] = stq[1] = stq[2] = stq[3] = 0; }
-      u32 e[4]; bool look[4]; u64 k48[4];
+      for (int u = 0; u < TRC_U; u++) {
+        const int i = i0 + u * 4096 + (int)threadIdx.x * 4;
+        act[u] = i < pend;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        k48[q] = trk_k48(kq[q], X.bitsR);
-        if (L == 2 && chunk == 0) stq[q] = (i + q < pend) ? ((1u << 16) | (u32)(k48[q] >> 40)) : 0xC0000000u;
-        look[q] = (i + q < pend) && (stq[q] >> 30) == 0 && ((stq[q] >> 16) & 7u) != (u32)L;
-        e[q] = 0;
-        if (look[q]) e[q] = info[(stq[q] & 0xFFFFu) * 256 + (u32)((k48[q] >> (40 - 8 * (L - 1))) & 0xFFu)];
-      }
-      bool changed = false;
-      u32 runT = 0xFFFFFFFFu, runC = 0;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        u32 tgt = 0xFFFFFFFFu;
-        if ((i + q < pend) && (stq[q] >> 30) == 0) {
-          if (look[q]) { stq[q] = ((e[q] >> 30) == TR_K_EXP) ? ((e[q] & 0xFFFFu) | ((u32)L << 16)) : e[q]; changed = true; }
-          if ((stq[q] >> 30) == 0) {
-            const int k = (int)(stq[q] & 0xFFFFu) - nlo;
-            if (k >= 0 && k < TR_NODECHUNK) tgt = (u32)k * 256 + (u32)((k48[q] >> (40 - 8 * L)) & 0xFFu);
-          }
+        for (int q = 0; q < 4; q++) { stq[u][q] = 0xC0000000u; kq[u][q] = 0; }
+        if (!act[u]) continue;
+        if (!(L == 2 && chunk == 0)) {                                     // settled items (most of a late level's window) cost one state read
+          const uint4 sv = *(const uint4*)(state + i);
+          stq[u][0] = sv.x; stq[u][1] = sv.y; stq[u][2] = sv.z; stq[u][3] = sv.w;
+          if ((stq[u][0] >> 30) && (stq[u][1] >> 30) && (stq[u][2] >> 30) && (stq[u][3] >> 30)) { act[u] = false; continue; }
         }
-        if (tgt == runT) runC++;
-        else { if (runC && runT != 0xFFFFFFFFu) atomicAdd(&lds[runT], runC); runT = tgt; runC = 1; }
+        if (i + 4 <= pend && ((((uintptr_t)(key + i)) & 15) == 0)) {
+          const uint4 a = *(const uint4*)(key + i), c = *(const uint4*)(key + i + 2);
+          kq[u][0] = ((u64)a.y << 32) | a.x; kq[u][1] = ((u64)a.w << 32) | a.z; kq[u][2] = ((u64)c.y << 32) | c.x; kq[u][3] = ((u64)c.w << 32) | c.z;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; q++) kq[u][q] = (i + q < pend) ? key[i + q] : 0ULL;
+        }
       }
-      if (runC && runT != 0xFFFFFFFFu) atomicAdd(&lds[runT], runC);
-      if (changed) *(uint4*)(state + i) = make_uint4(stq[0], stq[1], stq[2], stq[3]);
+      u32 e[TRC_U][4]; bool look[TRC_U][4]; u64 k48[TRC_U][4];
+#pragma unroll
+      for (int u = 0; u < TRC_U; u++) {
+        const int i = i0 + u * 4096 + (int)threadIdx.x * 4;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          k48[u][q] = trk_k48(kq[u][q], X.bitsR);
+          if (L == 2 && chunk == 0) stq[u][q] = (act[u] && i + q < pend) ? ((1u << 16) | (u32)(k48[u][q] >> 40)) : 0xC0000000u;
+          look[u][q] = act[u] && (i + q < pend) && (stq[u][q] >> 30) == 0 && ((stq[u][q] >> 16) & 7u) != (u32)L;
+          e[u][q] = 0;
+          if (look[u][q]) e[u][q] = info[(stq[u][q] & 0xFFFFu) * 256 + (u32)((k48[u][q] >> (40 - 8 * (L - 1))) & 0xFFu)];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TRC_U; u++) {
+        if (!act[u]) continue;
+        const int i = i0 + u * 4096 + (int)threadIdx.x * 4;
+        bool changed = false;
+        u32 runT = 0xFFFFFFFFu, runC = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          u32 tgt = 0xFFFFFFFFu;
+          if ((i + q < pend) && (stq[u][q] >> 30) == 0) {
+            if (look[u][q]) { stq[u][q] = ((e[u][q] >> 30) == TR_K_EXP) ? ((e[u][q] & 0xFFFFu) | ((u32)L << 16)) : e[u][q]; changed = true; }
+            if ((stq[u][q] >> 30) == 0) {
+              const int k = (int)(stq[u][q] & 0xFFFFu) - nlo;
+              if (k >= 0 && k < TR_NODECHUNK) tgt = (u32)k * 256 + (u32)((k48[u][q] >> (40 - 8 * L)) & 0xFFu);
+            }
+          }
+          if (tgt == runT) runC++;
+          else { if (runC && runT != 0xFFFFFFFFu) atomicAdd(&lds[runT], runC); runT = tgt; runC = 1; }
+        }
+        if (runC && runT != 0xFFFFFFFFu) atomicAdd(&lds[runT], runC);
+        if (changed) *(uint4*)(state + i) = make_uint4(stq[u][0], stq[u][1], stq[u][2], stq[u][3]);
+      }
     }
     __syncthreads();
     for (int j = threadIdx.x; j < TR_NODECHUNK * 256; j += 1024) {
@@ -1553,16 +1606,32 @@ __global__ __launch_bounds__(1024) void k_trk_scatter(KeySrc X, const u32* __res
   u32* rank = A.rank + (int64_t)b * A.NS;
   const u64 lowMask = (1ULL << bitsG) - 1ULL;
   u64 el[TRS_ITEMS]; u32 bp[TRS_ITEMS];
+  // loads in rounds, as in k_tr_scatter: keys / suffixes / states of all items, then all info lookups
+  u64 k48v[TRS_ITEMS]; u32 svv[TRS_ITEMS], stv[TRS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < TRS_ITEMS; r++) {
+    const int i = tbase + r * 1024 + threadIdx.x;
+    k48v[r] = 0; svv[r] = 0; stv[r] = 0xC0000000u;
+    if (i < W) {
+      k48v[r] = trk_k48(key[i], X.bitsR);
+      svv[r] = val[i];
+      stv[r] = hasState ? state[i] : ((1u << 16) | (u32)(k48v[r] >> 40));
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < TRS_ITEMS; r++) {
+    const int i = tbase + r * 1024 + threadIdx.x;
+    if (i < W && (stv[r] >> 30) == 0) stv[r] = info[(stv[r] & 0xFFFFu) * 256 + (u32)((k48v[r] >> (40 - 8 * (int)((stv[r] >> 16) & 7u))) & 0xFFu)];
+  }
 #pragma unroll
   for (int r = 0; r < TRS_ITEMS; r++) {
     const int i = tbase + r * 1024 + threadIdx.x;
     bp[r] = 0xFFFFFFFFu;
     el[r] = 0;
     if (i < W) {
-      const u64 k48 = trk_k48(key[i], X.bitsR);
-      const u32 sv = val[i];
-      u32 st = hasState ? state[i] : ((1u << 16) | (u32)(k48 >> 40));
-      if ((st >> 30) == 0) st = info[(st & 0xFFFFu) * 256 + (u32)((k48 >> (40 - 8 * (int)((st >> 16) & 7u))) & 0xFFu)];
+      const u64 k48 = k48v[r];
+      const u32 sv = svv[r];
+      const u32 st = stv[r];
       if ((st >> 30) == TR_K_TERM) {                                       // a new group of equal keys: its members' ranks, nothing to sort
         if (!(st & TR_UNCHANGED)) rank[sv] = (st & 0xFFFFFFu) | BW_LIVE;
       } else {

@@ -66,7 +66,7 @@ __global__ void k_chaseblk(const u32* __restrict__ a, u64 n, int steps, u32* sin
   const u64 base = ((u64)blockIdx.x * region) % (n - region);
   u32 p = (u32)(mix(blockIdx.x) % region);
   if (threadIdx.x == 0) {
-    for (int j = 0; j < steps; j++) p = __builtin_nontemporal_load(&a[base + p]) % (u32)region;
+    for (int j = 0; j < steps; j++) p = (__builtin_nontemporal_load(&a[base + p]) + (u32)j * 2654435761u) % (u32)region;   // (+ j: a plain x -> f(x) walk falls into a cycle of a few hundred lines)
     sink[blockIdx.x & 15] = p;                                  // (keeps the chain alive)
   }
 }
