@@ -284,26 +284,7 @@ __global__ void k_zrlt_ffin(const u8* __restrict__ src, u8* __restrict__ dst, in
 // =================================================================================================
 // inverse
 // classification of input byte i (ZRLT.java:167-214): payload = byte following an escape 0xFF
-// Source bytes of the inverse kernels: the workgroup's tile (+ 64 bytes in front and behind) staged in LDS with 16-byte loads
-// (round 5: every thread used to fetch its 16 bytes, and whatever its look-back / look-ahead touched, one byte per load from
-// global memory); what lies outside the window (a long run of digits or of 0xFF) is read from the block itself.
-#define ZI_HALO 64
-struct ZiSrc {
-  const u8* g; const u8* l; int lo, hi;
-  __device__ __forceinline__ u8 operator[](int i) const { return (i >= lo && i < hi) ? l[i - lo] : g[i]; }
-};
-__device__ __forceinline__ ZiSrc zi_stage(const u8* s, int tstart, int n, u8* lds) {
-  // lds: ZI_TILE + 2 * ZI_HALO bytes.  Blocks start 256-byte aligned and tiles are multiples of 16 bytes: aligned 16-byte loads;
-  // the slack behind a block (>= 4 KiB) makes the last load safe, bytes >= n are never looked at (hi = n)
-  const int lo = max(0, tstart - ZI_HALO);
-  const int hiw = min(n, tstart + ZI_TILE + ZI_HALO);
-  for (int p = lo + (int)threadIdx.x * 16; p < hiw; p += KZ_WG * 16) *(uint4*)(lds + (p - lo)) = *(const uint4*)(s + p);
-  __syncthreads();
-  ZiSrc r; r.g = s; r.l = lds; r.lo = lo; r.hi = hiw;
-  return r;
-}
-template <typename SRC>
-__device__ __forceinline__ bool zr_is_payload(const SRC& s, int i) {
+__device__ __forceinline__ bool zr_is_payload(const u8* s, int i) {
   int k = 0;
   while (i - 1 - k >= 0 && s[i - 1 - k] == 0xFF) k++;
   return (k & 1) != 0;
@@ -316,8 +297,7 @@ __device__ __forceinline__ bool zr_is_payload(const SRC& s, int i) {
 // reaches the end of the input goes through the trailing branch (:217-228), whose test differs at INT_MIN only.
 // A count that cannot fit fails later through the total (every such case dies in the reference as well).
 // *end (optional): the input position behind the token, set when it starts here.
-template <typename SRC>
-__device__ __forceinline__ u32 zr_inv_token(const SRC& s, const u8* g, int i, int n, int* end) {
+__device__ __forceinline__ u32 zr_inv_token(const u8* s, int i, int n, int* end) {
   const u32 v = s[i];
   const bool payload = zr_is_payload(s, i);
   if (payload) return 0;
@@ -329,7 +309,7 @@ __device__ __forceinline__ u32 zr_inv_token(const SRC& s, const u8* g, int i, in
       rl = (rl << 1) | s[k]; k++;
       // long runs (corrupted input only): 8 digits per step; blocks start 256-byte aligned
       while ((k & 7) == 0 && k + 8 <= n) {
-        const unsigned long long w = *(const unsigned long long*)(g + k);
+        const unsigned long long w = *(const unsigned long long*)(s + k);
         if (w & 0xFEFEFEFEFEFEFEFEull) break;
         rl = (rl << 8) | (u32)((w * 0x8040201008040201ull) >> 56);         // byte j of w -> bit 7-j
         k += 8;
@@ -353,13 +333,11 @@ __global__ __launch_bounds__(KZ_WG) void k_zrlt_i1(const u8* __restrict__ src, i
   const int tstart = t * ZI_TILE;
   if (tstart >= n) return;
   __shared__ __attribute__((aligned(8))) u32 lds[32];
-  const u8* sg = src + (int64_t)b * stride;
-  __shared__ __attribute__((aligned(16))) u8 tileBuf[ZI_TILE + 2 * ZI_HALO];
-  const ZiSrc s = zi_stage(sg, tstart, n, tileBuf);
+  const u8* s = src + (int64_t)b * stride;
   const int pos = tstart + threadIdx.x * ZI_PER;
   unsigned long long sz = 0;
   int lastEnd = 0;                                                // behind the last token of this thread that produces output
-  for (int k = 0; k < ZI_PER; k++) if (pos + k < n) { int e = 0; const u32 one = zr_inv_token(s, sg, pos + k, n, &e); sz += one; if (one) lastEnd = e; }
+  for (int k = 0; k < ZI_PER; k++) if (pos + k < n) { int e = 0; const u32 one = zr_inv_token(s, pos + k, n, &e); sz += one; if (one) lastEnd = e; }
   // tile total, saturated: wrapped run counts can be anything below 2^31
   for (int d = 1; d < 64; d <<= 1) { sz += __shfl_xor(sz, d, 64); lastEnd = max(lastEnd, __shfl_xor(lastEnd, d, 64)); }
   unsigned long long* l64 = (unsigned long long*)lds;
@@ -419,13 +397,11 @@ __global__ __launch_bounds__(KZ_WG) void k_zrlt_i3(const u8* __restrict__ src, u
   const int tstart = t * ZI_TILE;
   if (tstart >= n || S.fail[b]) return;
   __shared__ u32 lds[32];
-  const u8* sg = src + (int64_t)b * stride;
-  __shared__ __attribute__((aligned(16))) u8 tileBuf[ZI_TILE + 2 * ZI_HALO];
-  const ZiSrc s = zi_stage(sg, tstart, n, tileBuf);
+  const u8* s = src + (int64_t)b * stride;
   u8* d = dst + (int64_t)b * stride;
   const int pos = tstart + threadIdx.x * ZI_PER;
   u32 sz[ZI_PER]; u32 sum = 0;
-  for (int k = 0; k < ZI_PER; k++) { sz[k] = (pos + k < n) ? zr_inv_token(s, sg, pos + k, n, nullptr) : 0; sum += sz[k]; }
+  for (int k = 0; k < ZI_PER; k++) { sz[k] = (pos + k < n) ? zr_inv_token(s, pos + k, n, nullptr) : 0; sum += sz[k]; }
   u32 total;
   u32 off = kz_wg_excl_sum(sum, lds, &total) + S.tOff[(int64_t)b * S.T + t];
   for (int k = 0; k < ZI_PER; k++) {
