@@ -51,7 +51,7 @@ KERNEL_STAGE = {}
 for _st, _ks in {
     "bwt_fwd": ("k_bwt_init", "k_radix_hist", "k_radix_scan", "k_radix_scatter", "k_seg_reduce", "k_seg_scan", "k_seg_apply",
                 "k_live_emit", "k_bwt_emit", "k_msd_hist", "k_msd_scan", "k_msd_scatter", "k_bucket_sort", "k_bucket_count", "k_bucket_count_s",
-                "k_tr_hist16", "k_tr_assign", "k_tr_count", "k_tr_scatter", "k_tr_sort"),
+                "k_tr_hist16", "k_tr_assign", "k_tr_count", "k_tr_scatter", "k_tr_sort", "k_trk_hist16", "k_trk_count", "k_trk_scatter", "k_trk_sort"),
     "sbrt_fwd": ("k_sbrt_last2", "k_sbrt_scan", "k_sbrt_replay"),
     "zrlt_fwd": ("k_zrlt_f1", "k_zrlt_f2", "k_zrlt_f3", "k_zrlt_ffin"),
     "ans_enc": ("k_ans_enc_chunk", "k_ans_enc_scan", "k_ans_enc_concat"),

@@ -21,6 +21,7 @@ import sys
 
 # kernels the library times under one id (kz_internal.h: KZ_KERNEL_NAMES): the text-sourced first radix pass
 ALIASES = {"k_radix_hist0": "k_radix_hist", "k_radix_scatter0": "k_radix_scatter",
+           "k_trk_hist16": "k_tr_hist16", "k_trk_count": "k_tr_count", "k_trk_scatter": "k_tr_scatter", "k_trk_sort": "k_tr_sort",   # the key trie rounds share the trie rounds' ids
            "k_fpaq_enc_wave": "k_fpaq_enc", "k_fpaq_dec_wave": "k_fpaq_dec", "k_fpaq_dec_wave2": "k_fpaq_dec"}   # the one-wave-per-block forms share their ids
 
 
