@@ -1655,6 +1655,20 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
     std::vector<std::vector<int32_t>> lens(nch), skips(nch), stats(nch);
     int rc = 0;
     const bool trace = getenv("KZ_TRACE_PIPE") != nullptr;
+    // KZ_HOST_INV_STAGED=1 (read once per call): the chunk's blocks go through pinned slots with one gather / scatter kernel per
+    // sub-chunk instead of a copy pair per block.  Measured slower on the level-exact bench row (1 200 vs 1 066 ms per 2 048-block
+    // decode), so it is opt-in.
+    const char* est = getenv("KZ_HOST_INV_STAGED");
+    const bool staged = est && est[0] == '1' && memKind != KZ_MEM_HOST;
+    const int64_t pslot = (int64_t)kz_align((size_t)std::max<int64_t>(outStride, dataCap) + 64, 64);
+    if (staged) {                                                     // everything that can fail, before the first chunk is in flight
+      for (int q = 0; q < 2 && !rc; q++) {
+        rc = kz_stage_reserve(ctx, ctx->hsIn[q], (size_t)pslot * (size_t)CH + 64, true);
+        if (!rc) rc = kz_stage_reserve(ctx, ctx->hiAux[q], (size_t)CH * 16 + 64, false);
+        if (!rc && !ctx->hiStream[q] && hipStreamCreateWithFlags(&ctx->hiStream[q], hipStreamNonBlocking) != hipSuccess) rc = -KZ_ERR_DEVICE;
+      }
+      if (rc) return rc;
+    }
     const auto tz = std::chrono::steady_clock::now();
     auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tz).count(); };
     for (int k = 0; k < nch && !rc; k++) {
@@ -1671,18 +1685,8 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
       H->device = ctx->device; H->types = types; H->hp = hp; H->blockSize = blockSize; H->cap = dataCap;
       H->dbuf = out + (int64_t)b0 * outStride; H->dstride = outStride; H->slotCap = outStride; H->hostMem = memKind == KZ_MEM_HOST;
       H->len = lens[k].data(); H->skip = skips[k].data(); H->status = stats[k].data();
-      // KZ_HOST_INV_STAGED=1: the chunk's blocks go through pinned slots with one gather / scatter kernel per sub-chunk instead of a
-      // copy pair per block.  Measured slower on the level-exact bench row (1 200 vs 1 066 ms per 2 048-block decode: the extra
-      // streams' kernels slow the main stream's chunk 217 -> 252 ms and the sub-chunk joins cost the host pool 14 %), so it is opt-in.
-      const bool stagedOn = getenv("KZ_HOST_INV_STAGED") && getenv("KZ_HOST_INV_STAGED")[0] == '1';
-      const bool staged = stagedOn && memKind != KZ_MEM_HOST;
       if (staged) {                                                   // ring of two pinned slot sets: chunk k - 2 must be done with its set
         if (k >= 2 && finishers[k - 2].joinable()) finishers[k - 2].join();
-        const int64_t pslot = (int64_t)kz_align((size_t)std::max<int64_t>(outStride, dataCap) + 64, 64);
-        int r2 = kz_stage_reserve(ctx, ctx->hsIn[k & 1], (size_t)pslot * (size_t)CH + 64, true);
-        if (!r2) r2 = kz_stage_reserve(ctx, ctx->hiAux[k & 1], (size_t)CH * 16 + 64, false);
-        if (!r2 && !ctx->hiStream[k & 1] && hipStreamCreateWithFlags(&ctx->hiStream[k & 1], hipStreamNonBlocking) != hipSuccess) r2 = -KZ_ERR_DEVICE;
-        if (r2) { rc = r2; break; }
         H->pin = ctx->hsIn[k & 1].p; H->pinSlot = pslot;
       }
       kz_ctx* cx = ctx;
