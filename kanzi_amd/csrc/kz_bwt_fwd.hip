@@ -1146,17 +1146,24 @@ __global__ __launch_bounds__(1024) void k_tr_count(const u8* __restrict__ srcAll
 #define TRS_TILE 8192
 #define TRS_ITEMS (TRS_TILE / 1024)
 #define TR_MAXB 12288
-__global__ __launch_bounds__(1024) void k_tr_scatter(const u8* __restrict__ srcAll, int64_t stride, const u32* __restrict__ stateAll,
-                                                      u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) {
+// Two sizes of the same kernel (round 5): blocks with at most TRS_FASTB buckets (every block measured: 456 .. 790) take tiles of 4096
+// suffixes with 52 KiB of LDS -- three workgroups per CU to hide the state -> info -> text chain -- the others the full tables
+// (152 KiB, one workgroup per CU).  Both are launched; a block's workgroups of the form that is not its own return at once.
+#define TRS_FASTB 2048
+template <int TILE_, int MAXB_, bool FAST>
+__device__ __forceinline__ void tr_scatter_body(const u8* __restrict__ srcAll, int64_t stride, const u32* __restrict__ stateAll,
+                                                u64* __restrict__ elemAll, const BwtArrays& A, const TrieArrays& T, int bitsG) {
+  constexpr int ITEMS_ = TILE_ / 1024;
+  if ((T.meta[(int64_t)blockIdx.y * TR_META + 1] <= TRS_FASTB) != FAST) return;
   const int b = blockIdx.y;
   const int n = A.d_n[b];
   const int tile = blockIdx.x;
-  const int tbase = tile * TRS_TILE;
+  const int tbase = tile * TILE_;
   if (tbase >= n) return;
-  __shared__ u32 tc2[TR_MAXB / 2];                                       // two 16-bit counters per word
-  __shared__ u32 gdelta[TR_MAXB];
-  __shared__ u64 stage[TRS_TILE];
-  __shared__ uint16_t stageB[TRS_TILE];
+  __shared__ u32 tc2[MAXB_ / 2];                                       // two 16-bit counters per word
+  __shared__ u32 gdelta[MAXB_];
+  __shared__ u64 stage[TILE_];
+  __shared__ uint16_t stageB[TILE_];
   __shared__ u32 scan[32];
   const int32_t* meta = T.meta + (int64_t)b * TR_META;
   const int nB = meta[1];
@@ -1168,31 +1175,31 @@ __global__ __launch_bounds__(1024) void k_tr_scatter(const u8* __restrict__ srcA
   const u32* info = T.info + (int64_t)b * T.MN * 256;
   u32* rank = A.rank + (int64_t)b * A.NS;
   const u64 lowMask = (1ULL << bitsG) - 1ULL;
-  u64 el[TRS_ITEMS]; u32 bp[TRS_ITEMS];                                  // element, bucket | position in (tile, bucket) << 16
+  u64 el[ITEMS_]; u32 bp[ITEMS_];                                  // element, bucket | position in (tile, bucket) << 16
   // three rounds of loads for the tile's eight items per thread, each round issued for all items before its results are used
   // (state -> info -> text is a dependent chain; one item after the other was 24 memory round trips per thread, the kernel's time)
-  u32 stv[TRS_ITEMS];
+  u32 stv[ITEMS_];
 #pragma unroll
-  for (int r = 0; r < TRS_ITEMS; r++) {
+  for (int r = 0; r < ITEMS_; r++) {
     const int i = tbase + r * 1024 + threadIdx.x;
     stv[r] = 0xC0000000u;
     if (i < n) stv[r] = hasState ? state[i] : ((u32)s[i] | (1u << 16));
   }
-  u32 cb[TRS_ITEMS];
+  u32 cb[ITEMS_];
 #pragma unroll
-  for (int r = 0; r < TRS_ITEMS; r++) {
+  for (int r = 0; r < ITEMS_; r++) {
     const int i = tbase + r * 1024 + threadIdx.x;
     cb[r] = 0;
     if (i < n && (stv[r] >> 30) == 0) cb[r] = tr_byte(s, i + (int)((stv[r] >> 16) & 7u), n);
   }
 #pragma unroll
-  for (int r = 0; r < TRS_ITEMS; r++) {
+  for (int r = 0; r < ITEMS_; r++) {
     const int i = tbase + r * 1024 + threadIdx.x;
     if (i < n && (stv[r] >> 30) == 0) stv[r] = info[(stv[r] & 0xFFFFu) * 256 + cb[r]];
   }
-  u64 kv[TRS_ITEMS];
+  u64 kv[ITEMS_];
 #pragma unroll
-  for (int r = 0; r < TRS_ITEMS; r++) {
+  for (int r = 0; r < ITEMS_; r++) {
     const int i = tbase + r * 1024 + threadIdx.x;
     kv[r] = 0;
     if (i < n && (stv[r] >> 30) != TR_K_TERM) {
@@ -1204,7 +1211,7 @@ __global__ __launch_bounds__(1024) void k_tr_scatter(const u8* __restrict__ srcA
     }
   }
 #pragma unroll
-  for (int r = 0; r < TRS_ITEMS; r++) {
+  for (int r = 0; r < ITEMS_; r++) {
     const int i = tbase + r * 1024 + threadIdx.x;
     bp[r] = 0xFFFFFFFFu;
     el[r] = 0;
@@ -1245,7 +1252,7 @@ __global__ __launch_bounds__(1024) void k_tr_scatter(const u8* __restrict__ srcA
   __syncthreads();
   const u32 total = scan[31];
 #pragma unroll
-  for (int r = 0; r < TRS_ITEMS; r++) {
+  for (int r = 0; r < ITEMS_; r++) {
     if (bp[r] != 0xFFFFFFFFu) {
       const u32 bk = bp[r] & 0xFFFFu;
       const u32 w = tc2[bk >> 1];
@@ -1256,11 +1263,16 @@ __global__ __launch_bounds__(1024) void k_tr_scatter(const u8* __restrict__ srcA
   __syncthreads();
   u64* elem = elemAll + (int64_t)b * A.NS;
 #pragma unroll
-  for (int r = 0; r < TRS_ITEMS; r++) {
+  for (int r = 0; r < ITEMS_; r++) {
     const u32 slot = (u32)r * 1024 + threadIdx.x;
     if (slot < total) elem[gdelta[stageB[slot]] + slot] = stage[slot];
   }
 }
+
+__global__ __launch_bounds__(1024) void k_tr_scatter(const u8* __restrict__ srcAll, int64_t stride, const u32* __restrict__ stateAll,
+                                                      u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) { tr_scatter_body<TRS_TILE, TR_MAXB, false>(srcAll, stride, stateAll, elemAll, A, T, bitsG); }
+__global__ __launch_bounds__(1024) void k_tr_scatter_f(const u8* __restrict__ srcAll, int64_t stride, const u32* __restrict__ stateAll,
+                                                        u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) { tr_scatter_body<TRS_TILE / 2, TRS_FASTB, true>(srcAll, stride, stateAll, elemAll, A, T, bitsG); }
 
 // one bucket at a time in LDS: sort by the key bits that differ, groups of equal keys, ranks and final suffixes
 #define TRQ_WAVES 16
@@ -1583,16 +1595,19 @@ __global__ __launch_bounds__(1024) void k_trk_count(KeySrc X, u32* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(1024) void k_trk_scatter(KeySrc X, const u32* __restrict__ stateAll, u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) {
+template <int TILE_, int MAXB_, bool FAST>
+__device__ __forceinline__ void trk_scatter_body(const KeySrc& X, const u32* __restrict__ stateAll, u64* __restrict__ elemAll, const BwtArrays& A, const TrieArrays& T, int bitsG) {
+  constexpr int ITEMS_ = TILE_ / 1024;
+  if ((T.meta[(int64_t)blockIdx.y * TR_META + 1] <= TRS_FASTB) != FAST) return;
   const int b = blockIdx.y;
   const int w0 = A.d_w[b];
   const int W = A.d_m[b] - w0;
-  const int tbase = blockIdx.x * TRS_TILE;
+  const int tbase = blockIdx.x * TILE_;
   if (tbase >= W) return;
-  __shared__ u32 tc2[TR_MAXB / 2];
-  __shared__ u32 gdelta[TR_MAXB];
-  __shared__ u64 stage[TRS_TILE];
-  __shared__ uint16_t stageB[TRS_TILE];
+  __shared__ u32 tc2[MAXB_ / 2];
+  __shared__ u32 gdelta[MAXB_];
+  __shared__ u64 stage[TILE_];
+  __shared__ uint16_t stageB[TILE_];
   __shared__ u32 scan[32];
   const int32_t* meta = T.meta + (int64_t)b * TR_META;
   const int nB = meta[1];
@@ -1605,11 +1620,11 @@ __global__ __launch_bounds__(1024) void k_trk_scatter(KeySrc X, const u32* __res
   const u32* info = T.info + (int64_t)b * T.MN * 256;
   u32* rank = A.rank + (int64_t)b * A.NS;
   const u64 lowMask = (1ULL << bitsG) - 1ULL;
-  u64 el[TRS_ITEMS]; u32 bp[TRS_ITEMS];
+  u64 el[ITEMS_]; u32 bp[ITEMS_];
   // loads in rounds, as in k_tr_scatter: keys / suffixes / states of all items, then all info lookups
-  u64 k48v[TRS_ITEMS]; u32 svv[TRS_ITEMS], stv[TRS_ITEMS];
+  u64 k48v[ITEMS_]; u32 svv[ITEMS_], stv[ITEMS_];
 #pragma unroll
-  for (int r = 0; r < TRS_ITEMS; r++) {
+  for (int r = 0; r < ITEMS_; r++) {
     const int i = tbase + r * 1024 + threadIdx.x;
     k48v[r] = 0; svv[r] = 0; stv[r] = 0xC0000000u;
     if (i < W) {
@@ -1619,12 +1634,12 @@ __global__ __launch_bounds__(1024) void k_trk_scatter(KeySrc X, const u32* __res
     }
   }
 #pragma unroll
-  for (int r = 0; r < TRS_ITEMS; r++) {
+  for (int r = 0; r < ITEMS_; r++) {
     const int i = tbase + r * 1024 + threadIdx.x;
     if (i < W && (stv[r] >> 30) == 0) stv[r] = info[(stv[r] & 0xFFFFu) * 256 + (u32)((k48v[r] >> (40 - 8 * (int)((stv[r] >> 16) & 7u))) & 0xFFu)];
   }
 #pragma unroll
-  for (int r = 0; r < TRS_ITEMS; r++) {
+  for (int r = 0; r < ITEMS_; r++) {
     const int i = tbase + r * 1024 + threadIdx.x;
     bp[r] = 0xFFFFFFFFu;
     el[r] = 0;
@@ -1667,7 +1682,7 @@ __global__ __launch_bounds__(1024) void k_trk_scatter(KeySrc X, const u32* __res
   __syncthreads();
   const u32 total = scan[31];
 #pragma unroll
-  for (int r = 0; r < TRS_ITEMS; r++) {
+  for (int r = 0; r < ITEMS_; r++) {
     if (bp[r] != 0xFFFFFFFFu) {
       const u32 bk = bp[r] & 0xFFFFu;
       const u32 w = tc2[bk >> 1];
@@ -1678,11 +1693,14 @@ __global__ __launch_bounds__(1024) void k_trk_scatter(KeySrc X, const u32* __res
   __syncthreads();
   u64* elem = elemAll + (int64_t)b * A.NS;
 #pragma unroll
-  for (int r = 0; r < TRS_ITEMS; r++) {
+  for (int r = 0; r < ITEMS_; r++) {
     const u32 slot = (u32)r * 1024 + threadIdx.x;
     if (slot < total) elem[gdelta[stageB[slot]] + slot] = stage[slot];
   }
 }
+
+__global__ __launch_bounds__(1024) void k_trk_scatter(KeySrc X, const u32* __restrict__ stateAll, u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) { trk_scatter_body<TRS_TILE, TR_MAXB, false>(X, stateAll, elemAll, A, T, bitsG); }
+__global__ __launch_bounds__(1024) void k_trk_scatter_f(KeySrc X, const u32* __restrict__ stateAll, u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) { trk_scatter_body<TRS_TILE / 2, TRS_FASTB, true>(X, stateAll, elemAll, A, T, bitsG); }
 
 // ---------------------------------------------------------------------------------------------
 // emit: header + BWT bytes (BWTBlockCodec.java:90-126, DivSufSort.java:217-224)
@@ -1870,6 +1888,7 @@ static int bwt_forward_run(kz_ctx* ctx, kz_batch& bt, bool allowTrie, bool* trie
         KZ_LAUNCH(ctx, KID_TR_COUNT, k_tr_count, dim3(P, B), dim3(1024), src, bt.stride, A.val[0], A, TR, L);
         KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, L, Dmax, 0);
       }
+      KZ_LAUNCH(ctx, KID_TR_SCATTER, k_tr_scatter_f, dim3(gridFor(maxN, TRS_TILE / 2), B), dim3(1024), src, bt.stride, A.val[0], A.key[0], A, TR, bitsG);
       KZ_LAUNCH(ctx, KID_TR_SCATTER, k_tr_scatter, dim3(gridFor(maxN, TRS_TILE), B), dim3(1024), src, bt.stride, A.val[0], A.key[0], A, TR, bitsG);
       const int G = std::max(16, std::min(1024, 8192 / B));
       KZ_LAUNCH(ctx, KID_TR_SORT, k_tr_sort, dim3(G, B), dim3(1024), A.key[0], A, TR, bitsG);
@@ -1911,6 +1930,7 @@ static int bwt_forward_run(kz_ctx* ctx, kz_batch& bt, bool allowTrie, bool* trie
         KZ_LAUNCH(ctx, KID_TR_COUNT, k_trk_count, dim3(PW, B), dim3(1024), XK, vF, A, TR, L);
         KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, L, 6, 1);
       }
+      KZ_LAUNCH(ctx, KID_TR_SCATTER, k_trk_scatter_f, dim3(gridFor(wMax, TRS_TILE / 2), B), dim3(1024), XK, vF, kF, A, TR, bitsG);
       KZ_LAUNCH(ctx, KID_TR_SCATTER, k_trk_scatter, dim3(gridFor(wMax, TRS_TILE), B), dim3(1024), XK, vF, kF, A, TR, bitsG);
       const int G = std::max(16, std::min(1024, 8192 / B));
       KZ_LAUNCH(ctx, KID_TR_SORT, k_trk_sort, dim3(G, B), dim3(1024), kF, A, TR, bitsG);
