@@ -748,6 +748,9 @@ __global__ void k_merge_group(const int32_t* __restrict__ in, const int32_t* __r
   lenOut[b] = flag[b] > 0 ? len[b] : old[b];
   applied[b] = flag[b] > 0 ? 1 : 0;
 }
+// the TEXT inverse on the device (kz_text_gpu.hip) instead of the host stage: opt-in, KZ_TEXT_GPU=1 (read per call)
+static bool text_gpu_on() { const char* e = getenv("KZ_TEXT_GPU"); return e && e[0] == '1'; }
+
 static int fuse_min_blocks() {                                      // batches below this take the stages one after the other
   const char* e = getenv("KZ_FUSE_MIN_BLOCKS");                     // (read per call: the tests force both schedules)
   return e ? atoi(e) : 32;
@@ -1394,8 +1397,10 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
   // larger (corrupt) length is rejected with the same error code.
   const int maxLen = std::min(maxTL, dataCap + 1024);
   ChainSpec CS; CS.nb = nb; CS.entropy = (int)entropyType; for (int i = 0; i < nb; i++) CS.types[i] = types[i];
+  const bool textGpu = hp > 0 && !deferHost && types[0] == KZ_T_TEXT && text_gpu_on();
   {
-    const size_t perBlock = pipeline_scratch(1, maxLen, true, CS) + (size_t)maxLen * 2 + (size_t)(host ? maxInBytes : 0) + (1 << 16);
+    const size_t perBlock = pipeline_scratch(1, maxLen, true, CS) + (size_t)maxLen * 2 + (size_t)(host ? maxInBytes : 0) + (1 << 16) +
+                            (textGpu ? kz_text_gpu_scratch_per_block(blockSize) : 0);
     int maxB = (int)std::min<size_t>(KZ_MAX_BATCH, std::max<size_t>(1, kz_arena_budget() / perBlock));   // grid.y carries the block index
     // the serial-per-block inverse stages like whole multiples of 8 blocks per CU (one wave per block, two per SIMD)
     const int unit = 8 * (ctx->numCUs > 0 ? ctx->numCUs : 256);
@@ -1414,7 +1419,8 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
   const int64_t inS = host ? (int64_t)kz_align((size_t)maxInBytes + 64, 256) : inStride;
   // (the expensive-blocks-first schedule runs the entropy and ZRLT stages once per group: a second set of their small scratch)
   const int64_t extra = (host ? inS * B : 0) + (int64_t)B * (sizeof(kz_block_result) + 128) + (int64_t)B * 32 + 8192 +
-                        (int64_t)kz_zrlt_scratch(B, maxLen) + (int64_t)B * ((int64_t)(maxLen / 16384 + 4) * 8 + 64) + 65536 + (int64_t)B * 64;
+                        (int64_t)kz_zrlt_scratch(B, maxLen) + (int64_t)B * ((int64_t)(maxLen / 16384 + 4) * 8 + 64) + 65536 + (int64_t)B * 64 +
+                        (textGpu ? (int64_t)B * (int64_t)kz_text_gpu_scratch_per_block(blockSize) + (int64_t)B * 16 + (1 << 16) : 0);
   int rc = pipe_setup(ctx, P, B, maxLen, extra, true, CS);
   if (rc) return rc;
   kz_batch& bt = P.bt;
@@ -1584,6 +1590,21 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
     if (rc) return rc;
   }
   }
+  std::vector<int32_t> h_skipHost(h_skip);                         // the host stages' view: TEXT counts as skipped for the blocks the device took
+  if (textGpu) {
+    // blocks whose only host stage left is TEXT (every other host stage skipped for the block): its inverse on the device
+    std::vector<int32_t> take(B, 0), done;
+    for (int b = 0; b < B; b++) {
+      bool t = !h_status[b] && bt.h_len[b] > 0 && !(h_skip[b] & 0x80);
+      for (int i = 1; i < hp && t; i++) t = (h_skip[b] & (1 << (7 - i))) != 0;
+      take[b] = t ? 1 : 0;
+    }
+    hipEvent_t e0; kz_stage_begin(ctx, &e0);
+    rc = kz_stage_text_inverse_gpu(ctx, bt, blockSize, dataCap, entropyType == KZ_E_FPAQ, take, done);
+    if (rc) return rc;
+    kz_stage_end(ctx, e0, KZ_STAGE_HOST_INV, 0);
+    for (int b = 0; b < B; b++) if (done[b]) h_skipHost[b] |= 0x80;
+  }
   if (hp > 0 && !deferHost) {
     // host stages (UTF, TEXT inverse) behind the GPU stages: blocks that went through one come back to the host, are decoded
     // on host threads and return to their slot
@@ -1592,7 +1613,7 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
     HostInv H;
     H.device = ctx->device; H.types = types; H.hp = hp; H.blockSize = blockSize; H.cap = dataCap;
     H.dbuf = bt.buf[bt.cur]; H.dstride = bt.stride; H.slotCap = bt.stride; H.hostMem = false;
-    H.len = bt.h_len.data(); H.skip = h_skip.data(); H.status = h_status.data();
+    H.len = bt.h_len.data(); H.skip = h_skipHost.data(); H.status = h_status.data();
     kz_parallel_for(B, KZ_HOST_STAGE_THREADS, host_inverse_block, &H);
     if (H.fail) { snprintf(ctx->err, sizeof(ctx->err), "host stage: copy from / to the device failed"); return -KZ_ERR_DEVICE; }
     KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
@@ -1647,7 +1668,7 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   // ---- chains led by TEXT / UTF on large batches: the host inverse stages of chunk k run on a helper thread (and the host pool)
   //      while the GPU decodes chunk k+1.  (Block checksums are verified on the device AFTER the host stages: that case takes the
   //      one-pass path.) ----
-  if (hp > 0 && ctx->checksum == 0 && nBlocks >= 2 * CH) {
+  if (hp > 0 && ctx->checksum == 0 && nBlocks >= 2 * CH && !(types[0] == KZ_T_TEXT && text_gpu_on())) {
     const int B = nBlocks, nch = (B + CH - 1) / CH;
     const int dataCap = blockSize + std::max(512, blockSize >> 4);
     std::vector<std::thread> finishers;

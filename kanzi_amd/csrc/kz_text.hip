@@ -731,6 +731,22 @@ int utf_inverse(const u8* src, int n, u8* dst, int dstCap, int* produced) {
 
 }  // namespace
 
+// ---- the static dictionary as flat tables, for the device form of the TEXT inverse (kz_text_gpu.hip) ----
+// words: sd.count static words, then TextCodec1's two escape words (:600-603); text: the lower-cased dictionary text + the two escape bytes
+void kz_text_static_tables(std::vector<uint32_t>& hash, std::vector<int32_t>& pos, std::vector<uint32_t>& lenIdx, std::vector<uint8_t>& text,
+                           std::vector<uint8_t>& delim, int* count) {
+  const StaticDict& sd = static_dict();
+  *count = sd.count;
+  hash.assign((size_t)sd.count + 2, 0); pos.assign((size_t)sd.count + 2, 0); lenIdx.assign((size_t)sd.count + 2, 0);
+  for (int i = 0; i < sd.count; i++) { hash[i] = sd.words[i].hash; pos[i] = sd.words[i].pos; lenIdx[i] = sd.words[i].lenIdx; }
+  text.assign(sd.text, sd.text + KZ_DICT_EN_1024_LEN);
+  text.push_back(kEsc2); text.push_back(kEsc1);
+  hash[sd.count] = 0; pos[sd.count] = KZ_DICT_EN_1024_LEN; lenIdx[sd.count] = (1u << 24) | (u32)sd.count;
+  hash[sd.count + 1] = 0; pos[sd.count + 1] = KZ_DICT_EN_1024_LEN + 1; lenIdx[sd.count + 1] = (1u << 24) | (u32)(sd.count + 1);
+  delim.assign(256, 0);
+  for (int c = 0; c < 256; c++) delim[c] = sd.delim[c] ? 1 : 0;
+}
+
 // ---- entry points used by kz_api.hip / kz_stream.hip ----
 bool kz_is_host_transform(int type) { return type == KZ_T_TEXT || type == KZ_T_UTF; }
 

@@ -1,0 +1,301 @@
+// kz_text_gpu.hip -- TEXT inverse on the device (round 5, first form): K/transform/TextCodec.java:873-1100 (TextCodec1.inverse) and
+// :1413-1600 (TextCodec2.inverse) for the blocks of a decoded batch that are still in HBM.
+//
+// The host form (kz_text.hip: text_inverse) stays the reference of this file and the fallback: every block this kernel does not
+// finish cleanly (malformed input, output that does not fit, a variant the call did not size its tables for) is reported as
+// "not done" and goes through the host stage, which gives the reference's verdict.  So the device form only has to be exact on
+// what it accepts.
+//
+// One wave per block, the reference's token walk with wave-uniform control flow: the coded bytes come through a 64-byte row
+// register (one coalesced load per row, the next row requested a row ahead), runs of letters are copied by the lanes of the row,
+// dictionary words by the lanes of the word; the dictionary (hash slots + word table, Dictionary in kz_text.hip: same rules, same
+// quirks) lives in the block's scratch in HBM and is read with uniform loads.  A token is one to three dependent loads (382 ns each
+// with 2 048 blocks side by side, tools/ubench_gather chaseblk), so a block takes a few hundred ms -- all blocks of the batch side
+// by side; what it buys is a decoder that does not wait for host CPUs.
+#include "kz_device.h"
+#include "kz_internal.h"
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+
+void kz_text_static_tables(std::vector<uint32_t>& hash, std::vector<int32_t>& pos, std::vector<uint32_t>& lenIdx, std::vector<uint8_t>& text,
+                           std::vector<uint8_t>& delim, int* count);   // kz_text.hip
+
+#define TG_T1 128            // TextCodec.java:32-35
+#define TG_T2 (128 * 128)
+#define TG_MAXDICT (1 << 19)
+#define TG_MAXWORD 31
+#define TG_LF 0x0Au
+#define TG_CR 0x0Du
+#define TG_ESC1 0x0Fu
+#define TG_ESC2 0x0Eu
+#define TG_HASH1 0x7FEB352Du
+#define TG_HASH2 0x846CA68Bu
+#define TG_CRLF 0x40u
+#define TG_CODEC2 0x10u
+#define TG_IDXMASK 0x0007FFFFu
+#define TG_STATIC 0x00800000u    // word record: its text is the static dictionary's (else the block's coded bytes)
+
+struct TgWord { u32 hash; int32_t pos; u32 lenIdx; };
+
+struct TextGpu {
+  const u32* sHash; const int32_t* sPos; const u32* sLenIdx; const u8* sText; const u8* delim; int sCount;   // static tables (device)
+  int32_t* slots;       // [A][slotsPer]
+  TgWord* words;        // [A][TG_MAXDICT]
+  const int32_t* ord;   // [B] dense index of the blocks this call takes, -1: not taken
+  int32_t* outLen;      // [B] produced bytes, -1: not done (host stage)
+  int64_t slotsPer;
+  int logV1, logV2;     // hash map sizes of the two variants for the stream's block size
+  int variantCap;       // largest variant the slots were sized for (1: both)
+  int llog;             // initial size of the word list
+  int dstCap;
+};
+
+__device__ __forceinline__ bool tg_is_text(u32 c) { const u32 l = c | 0x20u; return l >= 'a' && l <= 'z' && c < 0x80u; }
+__device__ __forceinline__ u32 tg_u(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+
+__global__ __launch_bounds__(64) void k_text_inv(const u8* __restrict__ srcAll, u8* __restrict__ dstAll, int64_t stride, const int32_t* __restrict__ d_len, TextGpu G, int B) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int a = G.ord[b];
+  if (a < 0) return;
+  const int lane = kz_lane();
+  const int n = d_len[b];
+  const u8* src = srcAll + (int64_t)b * stride;
+  u8* dst = dstAll + (int64_t)b * stride;
+  if (n <= 0) { if (lane == 0) G.outLen[b] = -1; return; }
+  const u32 mode = tg_u(src[0]);
+  const int variant = (mode & TG_CODEC2) ? 2 : 1;
+  if (variant == 1 && G.variantCap < 1) { if (lane == 0) G.outLen[b] = -1; return; }
+  const bool crlf = (mode & TG_CRLF) != 0;
+  volatile int32_t* slots = G.slots + (int64_t)a * G.slotsPer;
+  volatile TgWord* words = G.words + (int64_t)a * TG_MAXDICT;
+  const u32 mask = (1u << (variant == 1 ? G.logV1 : G.logV2)) - 1u;
+  const int fixed = G.sCount + (variant == 1 ? 2 : 0);
+  int size = 1 << G.llog;
+  int next = fixed;
+  // ---- dictionary of the block (Dictionary::Dictionary): empty map, the static words, empty records behind them ----
+  for (u32 i = (u32)lane; i <= mask; i += 64) slots[i] = -1;
+  for (int i = lane; i < size; i += 64) {
+    TgWord w;
+    if (i < fixed) { w.hash = G.sHash[i]; w.pos = G.sPos[i]; w.lenIdx = G.sLenIdx[i] | TG_STATIC; }
+    else { w.hash = 0; w.pos = -1; w.lenIdx = (u32)i; }
+    words[i].hash = w.hash; words[i].pos = w.pos; words[i].lenIdx = w.lenIdx;
+  }
+  __syncthreads();
+  if (lane == 0) for (int i = 0; i < fixed; i++) slots[G.sHash[i] & mask] = i;          // in order: a later word takes a shared slot
+  __syncthreads();
+  const int end = G.dstCap;
+  int i = 1, at = 0;
+  bool ok = true, afterWord = false;
+  if (i < n) {
+    // row register: coded bytes [rowBase, rowBase + 64), one per lane; nxtRow = the row behind it
+    int rowBase = 0;
+    u32 row = (lane < n) ? (u32)src[lane] : 0u;
+    u32 nxtRow = (64 + lane < n) ? (u32)src[64 + lane] : 0u;
+#define TG_BYTE(idx) (((idx) - rowBase) < 64 ? (u32)__builtin_amdgcn_readlane((int)row, (idx) - rowBase) \
+                      : (((idx) - rowBase) < 128 ? (u32)__builtin_amdgcn_readlane((int)nxtRow, (idx) - rowBase - 64) : tg_u((u32)src[idx])))
+#define TG_ADVANCE_ROW()                                                                              \
+    while (i - rowBase >= 64) { rowBase += 64; row = nxtRow; nxtRow = (rowBase + 64 + lane < n) ? (u32)src[rowBase + 64 + lane] : 0u; }
+    int last = tg_is_text(TG_BYTE(1)) ? 0 : 1;
+    while (i < n && at < end) {
+      TG_ADVANCE_ROW()
+      const int off = i - rowBase;
+      u32 c = (u32)__builtin_amdgcn_readlane((int)row, off);
+      if (tg_is_text(c)) {
+        // a run of letters inside the row: plain bytes (:880-882), copied by their lanes
+        const uint64_t nt = kz_ballot(!tg_is_text(row) || rowBase + lane >= n);
+        const uint64_t m = nt >> off;
+        int run = m ? (int)__builtin_ctzll(m) : 64 - off;
+        run = min(run, end - at);
+        if (lane >= off && lane < off + run) dst[at + lane - off] = (u8)row;
+        at += run; i += run;
+        continue;
+      }
+      if (i > last + 3 && G.delim[c]) {                                     // the decoder learns only words of at least three letters (:891)
+        const int len = i - last - 1;
+        if (len <= TG_MAXWORD) {
+          const u32 wb = (lane < len) ? (u32)src[last + 1 + lane] : 0u;       // the word's letters, one per lane
+          u32 h = TG_HASH1;
+          for (int k = 0; k < len; k++) {
+            const u32 ch = (u32)__builtin_amdgcn_readlane((int)wb, k);
+            h = h * TG_HASH1 ^ (u32)(int32_t)(int8_t)ch * TG_HASH2;
+          }
+          const int s1 = (int)tg_u((u32)slots[h & mask]);
+          bool known = false;
+          if (s1 >= 0) {
+            const u32 eh = tg_u(words[s1].hash), eli = tg_u(words[s1].lenIdx);
+            if (eh == h && (int)(eli >> 24) == len) {
+              const int epos = (int)tg_u((u32)words[s1].pos);
+              const u8* et = (eli & TG_STATIC) ? G.sText : src;
+              const bool diff = (lane >= 1 && lane < len) && (u32)et[epos + lane] != wb;
+              known = kz_ballot(diff) == 0;
+            }
+          }
+          if (!known && (len > 3 || next < TG_T2) && s1 < 0) {                // Dictionary::learn
+            const u32 oli = tg_u(words[next].lenIdx);
+            if ((int)(oli & TG_IDXMASK) >= fixed) {
+              const u32 oh = tg_u(words[next].hash);
+              if (lane == 0) {
+                slots[oh & mask] = -1;
+                words[next].hash = h; words[next].pos = last + 1; words[next].lenIdx = ((u32)len << 24) | (u32)next;
+              }
+            }
+            if (lane == 0) slots[h & mask] = next;
+            next++;
+            if (next >= size) {
+              if (size >= TG_MAXDICT) next = fixed;
+              else {
+                for (int q = size + lane; q < 2 * size; q += 64) { words[q].hash = 0; words[q].pos = -1; words[q].lenIdx = (u32)q; }
+                size *= 2;
+              }
+            }
+            __syncthreads();                                                  // one wave: the stores above are ordered before what follows
+          }
+        }
+      }
+      i++;
+      const bool ref = (variant == 1) ? (c == TG_ESC1 || c == TG_ESC2) : (c & 0x80u) != 0;
+      if (!ref) {
+        if (variant == 2 && c == TG_ESC1) {                                   // escaped byte >= 0x80 or a literal 0x0F (:1577-1578)
+          if (i >= n) { ok = false; break; }
+          const u32 lit = TG_BYTE(i);
+          if (lane == 0) dst[at] = (u8)lit;
+          at++; i++;
+        } else {
+          if (crlf && c == TG_LF) { if (lane == 0) dst[at] = (u8)TG_CR; at++; if (at >= end) { ok = false; break; } }
+          if (lane == 0) dst[at] = (u8)c;
+          at++;
+        }
+        afterWord = false;
+        last = i - 1;
+        continue;
+      }
+      int number;
+      u32 flip = 0;
+      if (variant == 1) {                                                     // :945-961
+        if (i >= n) { ok = false; break; }
+        number = (int)TG_BYTE(i); i++;
+        if (number >= 128) {
+          number &= 0x7F;
+          if (i >= n) { ok = false; break; }
+          int b2 = (int)(int8_t)TG_BYTE(i); i++;
+          if (b2 & 0x80) {
+            number = ((number & 0x1F) << 7) | (b2 & 0x7F);
+            if (i >= n) { ok = false; break; }
+            b2 = (int)(TG_BYTE(i) & 0x7Fu); i++;
+          }
+          number = (number << 7) | b2;
+          if (number >= size) { ok = false; break; }
+        }
+        flip = (c == TG_ESC2) ? 0x20u : 0u;
+      } else {                                                                // :1503-1537
+        if (c == 0x80u) { flip = 0x20u; if (i >= n) { ok = false; break; } c = TG_BYTE(i); i++; }
+        number = (int)(c & 0x7Fu);
+        if (number >= 64) {
+          if (number >= 112) { if (i + 2 > n) { ok = false; break; } number = ((number & 0x0F) << 16) | (int)(TG_BYTE(i) << 8) | (int)TG_BYTE(i + 1); i += 2; }
+          else { if (i >= n) { ok = false; break; } number = ((number & 0x1F) << 8) | (int)TG_BYTE(i); i++; }
+          if (number > size) { ok = false; break; }
+        } else if (number == 0) { ok = false; break; }
+        number--;
+      }
+      if (number < 0 || number >= size) { ok = false; break; }
+      const u32 eli = tg_u(words[number].lenIdx);
+      const int epos = (int)tg_u((u32)words[number].pos);
+      const int len = (int)(eli >> 24) & 0xFF;
+      if (afterWord && len > 1) { if (at >= end) { ok = false; break; } if (lane == 0) dst[at] = (u8)' '; at++; }   // the implied space (:970-971)
+      if (epos < 0 || at + len >= end) { ok = false; break; }                 // :974-977
+      const u8* et = (eli & TG_STATIC) ? G.sText : src;
+      if (lane < len) dst[at + lane] = (u8)((u32)et[epos + lane] ^ (lane == 0 ? flip : 0u));
+      at += len;
+      if (len > 1) { afterWord = true; last = i; } else { afterWord = false; last = i - 1; }
+    }
+#undef TG_BYTE
+#undef TG_ADVANCE_ROW
+  }
+  if (lane == 0) G.outLen[b] = (ok && i == n) ? at : -1;
+}
+
+// copy the finished blocks back to their slots (16 bytes per lane: slots are 256-byte aligned)
+__global__ __launch_bounds__(256) void k_text_copy_back(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride, const int32_t* __restrict__ len, const int32_t* __restrict__ cond) {
+  const int b = blockIdx.y;
+  if (!cond[b]) return;
+  const int n16 = (len[b] + 15) >> 4;
+  const uint4* s = (const uint4*)(src + (int64_t)b * stride);
+  uint4* d = (uint4*)(dst + (int64_t)b * stride);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+// bytes of scratch per block taken (kz_api.hip sizes the arena with it)
+size_t kz_text_gpu_scratch_per_block(int blockSize) {
+  int l1 = 13; if (blockSize >= 8) { l1 = 31 - __builtin_clz((unsigned)(blockSize / 8)); l1 = l1 > 26 ? 26 : (l1 < 13 ? 13 : l1); }
+  return ((size_t)4 << l1) + (size_t)TG_MAXDICT * sizeof(TgWord) + 1024;
+}
+
+// TEXT inverse of the blocks with take[b] != 0: reads bt.buf[cur] (lengths bt.h_len), leaves the result of the blocks it finished in
+// the same slots (bt.h_len / bt.d_len updated) and sets done[b] = 1 for them; every other block is untouched (the host stage takes
+// it).  variant1 = the stream's entropy coder asks for TextCodec1 (larger hash map).  Returns 0 or a negative error.
+int kz_stage_text_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, int dstCap, bool variant1, const std::vector<int32_t>& take, std::vector<int32_t>& done) {
+  const int B = bt.B;
+  done.assign(B, 0);
+  std::vector<int32_t> ord(B, -1);
+  int A = 0;
+  for (int b = 0; b < B; b++) if (take[b] && bt.h_len[b] > 0) ord[b] = A++;
+  if (A == 0) return 0;
+  TextGpu G;
+  G.logV1 = 13; if (blockSize >= 8) G.logV1 = std::max(std::min(31 - __builtin_clz((unsigned)(blockSize / 8)), 26), 13);      // TextCodec.java:561-575
+  G.logV2 = 13; if (blockSize >= 32) G.logV2 = std::max(std::min(31 - __builtin_clz((unsigned)(blockSize / 32)), 24), 13);    // :1068-1081
+  G.variantCap = variant1 ? 1 : 0;
+  G.slotsPer = (int64_t)1 << (variant1 ? G.logV1 : G.logV2);
+  G.llog = 13; if (dstCap >= 1024) G.llog = std::max(std::min(31 - __builtin_clz((unsigned)(dstCap / 128)), 18), 13);          // :578-582
+  G.dstCap = dstCap;
+  static std::vector<uint32_t> hHash, hLenIdx; static std::vector<int32_t> hPos; static std::vector<uint8_t> hText, hDelim; static int hCount = -1;
+  static std::once_flag once;
+  std::call_once(once, [] { kz_text_static_tables(hHash, hPos, hLenIdx, hText, hDelim, &hCount); });
+  const size_t mark = ctx->arenaTop;
+  const int NW = hCount + 2;
+  u32* dHash = (u32*)kz_arena_alloc(ctx, (size_t)NW * 4);
+  int32_t* dPos = (int32_t*)kz_arena_alloc(ctx, (size_t)NW * 4);
+  u32* dLenIdx = (u32*)kz_arena_alloc(ctx, (size_t)NW * 4);
+  u8* dText = (u8*)kz_arena_alloc(ctx, hText.size() + 64);
+  u8* dDelim = (u8*)kz_arena_alloc(ctx, 256);
+  int32_t* dOrd = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  int32_t* dOut = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  int32_t* dCond = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  G.slots = (int32_t*)kz_arena_alloc(ctx, (size_t)A * (size_t)G.slotsPer * 4);
+  G.words = (TgWord*)kz_arena_alloc(ctx, (size_t)A * TG_MAXDICT * sizeof(TgWord));
+  if (!dHash || !dPos || !dLenIdx || !dText || !dDelim || !dOrd || !dOut || !dCond || !G.slots || !G.words) { ctx->arenaTop = mark; return 0; }   // no room: the host stage takes them all
+  hipStream_t st = ctx->stream;
+  KZ_HIP(hipMemcpyAsync(dHash, hHash.data(), (size_t)NW * 4, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemcpyAsync(dPos, hPos.data(), (size_t)NW * 4, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemcpyAsync(dLenIdx, hLenIdx.data(), (size_t)NW * 4, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemcpyAsync(dText, hText.data(), hText.size(), hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemcpyAsync(dDelim, hDelim.data(), 256, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemcpyAsync(dOrd, ord.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemsetAsync(dOut, 0xFF, (size_t)B * 4, st));
+  KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+  G.sHash = dHash; G.sPos = dPos; G.sLenIdx = dLenIdx; G.sText = dText; G.delim = dDelim; G.sCount = hCount; G.ord = dOrd; G.outLen = dOut;
+  hipLaunchKernelGGL(k_text_inv, dim3(B), dim3(64), 0, st, bt.buf[bt.cur], bt.buf[bt.cur ^ 1], bt.stride, bt.d_len, G, B);
+  std::vector<int32_t> outLen(B);
+  KZ_HIP(hipMemcpyAsync(outLen.data(), dOut, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  KZ_HIP(kz_stream_sync(ctx, st));
+  std::vector<int32_t> cond(B, 0), newLen(bt.h_len);
+  int any = 0;
+  for (int b = 0; b < B; b++) if (ord[b] >= 0 && outLen[b] >= 0) { cond[b] = 1; newLen[b] = outLen[b]; done[b] = 1; any = 1; }
+  if (getenv("KZ_TEXT_GPU_TRACE")) { int nd = 0; for (int b = 0; b < B; b++) nd += done[b]; fprintf(stderr, "[textgpu] took %d blocks, finished %d\n", A, nd); }
+  if (any) {
+    // the finished blocks go back to the slots the rest of the decoder reads (the untouched ones are still there)
+    KZ_HIP(hipMemcpyAsync(dCond, cond.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    KZ_HIP(hipMemcpyAsync(dOut, newLen.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_text_copy_back, dim3(64, B), dim3(256), 0, st, bt.buf[bt.cur ^ 1], bt.buf[bt.cur], bt.stride, dOut, dCond);
+    for (int b = 0; b < B; b++) bt.h_len[b] = newLen[b];
+    KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    KZ_HIP(kz_stream_sync(ctx, st));
+  }
+  KZ_HIP(hipGetLastError());
+  ctx->arenaTop = mark;
+  return 0;
+}

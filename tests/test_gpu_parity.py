@@ -1511,3 +1511,39 @@ def test_bwt_forward_falls_back_when_the_trie_tables_overflow(ctx, monkeypatch, 
         ok_o, enc_o = oracle.transform_forward("BWT", d)
         ok_g, enc_g = _fwd(ctx, kz.BWT_TYPE, d)
         assert ok_g == ok_o and enc_g == enc_o, (at_round, c)
+
+
+# ---- round 5: the TEXT inverse on the device (kz_text_gpu.hip, opt-in KZ_TEXT_GPU=1) ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("chain,ent", [("TEXT", "NONE"), ("TEXT", "FPAQ"), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0"), ("TEXT+UTF+BWT+SRT+ZRLT", "FPAQ")])
+def test_text_inverse_on_the_device(ctx, chain, ent, monkeypatch, capfd):
+    """Streams written by the oracle (TextCodec2 for NONE / ANS0, TextCodec1 for FPAQ; English, CRLF, XML, escape bytes, a dictionary
+    that doubles and wraps, UTF-8, binary and short blocks) are decoded with the TEXT inverse running on the device: same bytes as the
+    input (= what the oracle's and the host stage's decoders give), corrupted copies get the oracle's verdict (the device form hands
+    whatever it cannot finish to the host stage), and the trace shows that the device did take blocks."""
+    monkeypatch.setenv("KZ_TEXT_GPU", "1")
+    monkeypatch.setenv("KZ_TEXT_GPU_TRACE", "1")
+    c = textgen.cases()
+    data = (c["english"][:150000] + c["utf8"][:30000] + c["random"][:40000] + c["english_crlf"][:70000] + c["xml"][:60000] + c["english_escapes"][:50000]
+            + c["many_words"][:300000] + datagen.stream(2, 30000).tobytes() + c["gif_magic_text"] + c["spaces_then_text"] + c["short"] + c["min"])
+    rng = np.random.default_rng(17)
+    for bs in (32768, 1 << 20):
+        ref = oracle.compress(chain, ent, bs, data, jobs=4)
+        assert kz.CompressedInputStream(ctx, ref).read() == data, (chain, ent, bs)
+        for _ in range(6):                                        # corrupted copies: the verdict of the oracle's decoder
+            bad = bytearray(ref)
+            pos = int(rng.integers(40, len(bad) - 8))
+            bad[pos] ^= 1 << int(rng.integers(0, 8))
+            try:
+                want = oracle.decompress(bytes(bad), len(data) + 4 * bs, jobs=2)
+            except Exception:
+                want = None
+            try:
+                got = kz.CompressedInputStream(ctx, bytes(bad)).read()
+            except Exception:
+                got = None
+            assert (got is None) == (want is None) and (got is None or got == want), (chain, ent, bs, pos)
+    err = capfd.readouterr().err
+    took = [int(l.split()[2]) for l in err.splitlines() if l.startswith("[textgpu]")]
+    fin = [int(l.split()[5]) for l in err.splitlines() if l.startswith("[textgpu]")]
+    assert took and sum(fin) > 0 and sum(fin) >= sum(took) // 2, err[-400:]
