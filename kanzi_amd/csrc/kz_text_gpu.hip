@@ -37,12 +37,15 @@ void kz_text_static_tables(std::vector<uint32_t>& hash, std::vector<int32_t>& po
 #define TG_CRLF 0x40u
 #define TG_CODEC2 0x10u
 #define TG_IDXMASK 0x0007FFFFu
+#define TG_RING 2048            // output ring in LDS (bytes)
+#define TG_SMAX 1032            // static words (1024) + TextCodec1's two escape words, rounded up
+#define TG_STEXT 6400           // their text
 #define TG_STATIC 0x00800000u    // word record: its text is the static dictionary's (else the block's coded bytes)
 
 struct TgWord { u32 hash; int32_t pos; u32 lenIdx; };
 
 struct TextGpu {
-  const u32* sHash; const int32_t* sPos; const u32* sLenIdx; const u8* sText; const u8* delim; int sCount;   // static tables (device)
+  const u32* sHash; const int32_t* sPos; const u32* sLenIdx; const u8* sText; const u8* delim; int sCount; int sTextLen;   // static tables (device)
   int32_t* slots;       // [A][slotsPer]
   TgWord* words;        // [A][TG_MAXDICT]
   const int32_t* ord;   // [B] dense index of the blocks this call takes, -1: not taken
@@ -88,6 +91,26 @@ __global__ __launch_bounds__(64) void k_text_inv(const u8* __restrict__ srcAll, 
   __syncthreads();
   if (lane == 0) for (int i = 0; i < fixed; i++) slots[G.sHash[i] & mask] = i;          // in order: a later word takes a shared slot
   __syncthreads();
+  // the delimiter set as four 64-bit masks, the static dictionary (records and text) in LDS: most references of a text go there
+  const uint64_t dm0 = kz_ballot(G.delim[lane] != 0), dm1 = kz_ballot(G.delim[64 + lane] != 0), dm2 = kz_ballot(G.delim[128 + lane] != 0), dm3 = kz_ballot(G.delim[192 + lane] != 0);
+#define TG_DELIM(cc) ((((cc) < 64u ? dm0 : ((cc) < 128u ? dm1 : ((cc) < 192u ? dm2 : dm3))) >> ((cc) & 63u)) & 1ULL)
+  __shared__ u32 sRec[TG_SMAX * 2];          // pos | len << 24 ... per static word: [2k] = pos, [2k+1] = lenIdx
+  __shared__ u8 sTxt[TG_STEXT];
+  for (int k = lane; k < fixed; k += 64) { sRec[2 * k] = (u32)G.sPos[k]; sRec[2 * k + 1] = G.sLenIdx[k] | TG_STATIC; }
+  for (int k = lane; k < G.sTextLen; k += 64) sTxt[k] = G.sText[k];
+  __syncthreads();
+  // output through an LDS ring, written out 1 KiB at a time with 16-byte stores: a global store per token would put a memory
+  // round trip in front of the token's next load (loads and stores share vmcnt on gfx9: the wait for a load covers the stores before it)
+  __shared__ __attribute__((aligned(16))) u8 obuf[TG_RING];
+  int flushed = 0;
+#define TG_OUT(pos, v) obuf[(pos) & (TG_RING - 1)] = (u8)(v)
+#define TG_FLUSH()                                                                                   \
+  while (at - flushed >= 1024) {                                                                      \
+    __syncthreads();                                                                                  \
+    *(uint4*)(dst + flushed + 16 * lane) = *(const uint4*)(obuf + ((flushed + 16 * lane) & (TG_RING - 1)));  \
+    flushed += 1024;                                                                                  \
+    __syncthreads();                                                                                  \
+  }
   const int end = G.dstCap;
   int i = 1, at = 0;
   bool ok = true, afterWord = false;
@@ -111,11 +134,12 @@ __global__ __launch_bounds__(64) void k_text_inv(const u8* __restrict__ srcAll, 
         const uint64_t m = nt >> off;
         int run = m ? (int)__builtin_ctzll(m) : 64 - off;
         run = min(run, end - at);
-        if (lane >= off && lane < off + run) dst[at + lane - off] = (u8)row;
+        if (lane >= off && lane < off + run) TG_OUT(at + lane - off, row);
         at += run; i += run;
+        TG_FLUSH()
         continue;
       }
-      if (i > last + 3 && G.delim[c]) {                                     // the decoder learns only words of at least three letters (:891)
+      if (i > last + 3 && TG_DELIM(c)) {                                     // the decoder learns only words of at least three letters (:891)
         const int len = i - last - 1;
         if (len <= TG_MAXWORD) {
           const u32 wb = (lane < len) ? (u32)src[last + 1 + lane] : 0u;       // the word's letters, one per lane
@@ -163,15 +187,16 @@ __global__ __launch_bounds__(64) void k_text_inv(const u8* __restrict__ srcAll, 
         if (variant == 2 && c == TG_ESC1) {                                   // escaped byte >= 0x80 or a literal 0x0F (:1577-1578)
           if (i >= n) { ok = false; break; }
           const u32 lit = TG_BYTE(i);
-          if (lane == 0) dst[at] = (u8)lit;
+          if (lane == 0) TG_OUT(at, lit);
           at++; i++;
         } else {
-          if (crlf && c == TG_LF) { if (lane == 0) dst[at] = (u8)TG_CR; at++; if (at >= end) { ok = false; break; } }
-          if (lane == 0) dst[at] = (u8)c;
+          if (crlf && c == TG_LF) { if (lane == 0) TG_OUT(at, TG_CR); at++; if (at >= end) { ok = false; break; } }
+          if (lane == 0) TG_OUT(at, c);
           at++;
         }
         afterWord = false;
         last = i - 1;
+        TG_FLUSH()
         continue;
       }
       int number;
@@ -203,19 +228,25 @@ __global__ __launch_bounds__(64) void k_text_inv(const u8* __restrict__ srcAll, 
         number--;
       }
       if (number < 0 || number >= size) { ok = false; break; }
-      const u32 eli = tg_u(words[number].lenIdx);
-      const int epos = (int)tg_u((u32)words[number].pos);
+      const bool isStat = number < fixed;
+      const u32 eli = isStat ? tg_u(sRec[2 * number + 1]) : tg_u(words[number].lenIdx);
+      const int epos = isStat ? (int)tg_u(sRec[2 * number]) : (int)tg_u((u32)words[number].pos);
       const int len = (int)(eli >> 24) & 0xFF;
-      if (afterWord && len > 1) { if (at >= end) { ok = false; break; } if (lane == 0) dst[at] = (u8)' '; at++; }   // the implied space (:970-971)
+      if (afterWord && len > 1) { if (at >= end) { ok = false; break; } if (lane == 0) TG_OUT(at, ' '); at++; }   // the implied space (:970-971)
       if (epos < 0 || at + len >= end) { ok = false; break; }                 // :974-977
-      const u8* et = (eli & TG_STATIC) ? G.sText : src;
-      if (lane < len) dst[at + lane] = (u8)((u32)et[epos + lane] ^ (lane == 0 ? flip : 0u));
+      if (lane < len) {
+        const u32 ch = isStat ? (u32)sTxt[epos + lane] : (u32)src[epos + lane];
+        TG_OUT(at + lane, ch ^ (lane == 0 ? flip : 0u));
+      }
       at += len;
+      TG_FLUSH()
       if (len > 1) { afterWord = true; last = i; } else { afterWord = false; last = i - 1; }
     }
 #undef TG_BYTE
 #undef TG_ADVANCE_ROW
   }
+  __syncthreads();
+  for (int p = flushed + lane; p < at; p += 64) dst[p] = obuf[p & (TG_RING - 1)];        // the ring's last bytes
   if (lane == 0) G.outLen[b] = (ok && i == n) ? at : -1;
 }
 
@@ -255,6 +286,7 @@ int kz_stage_text_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, int dstC
   static std::vector<uint32_t> hHash, hLenIdx; static std::vector<int32_t> hPos; static std::vector<uint8_t> hText, hDelim; static int hCount = -1;
   static std::once_flag once;
   std::call_once(once, [] { kz_text_static_tables(hHash, hPos, hLenIdx, hText, hDelim, &hCount); });
+  if (hCount + 2 > TG_SMAX || (int)hText.size() > TG_STEXT) return 0;      // (cannot happen: the dictionary is a fixed table)
   const size_t mark = ctx->arenaTop;
   const int NW = hCount + 2;
   u32* dHash = (u32*)kz_arena_alloc(ctx, (size_t)NW * 4);
@@ -277,8 +309,8 @@ int kz_stage_text_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, int dstC
   KZ_HIP(hipMemcpyAsync(dOrd, ord.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
   KZ_HIP(hipMemsetAsync(dOut, 0xFF, (size_t)B * 4, st));
   KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-  G.sHash = dHash; G.sPos = dPos; G.sLenIdx = dLenIdx; G.sText = dText; G.delim = dDelim; G.sCount = hCount; G.ord = dOrd; G.outLen = dOut;
-  hipLaunchKernelGGL(k_text_inv, dim3(B), dim3(64), 0, st, bt.buf[bt.cur], bt.buf[bt.cur ^ 1], bt.stride, bt.d_len, G, B);
+  G.sHash = dHash; G.sPos = dPos; G.sLenIdx = dLenIdx; G.sText = dText; G.delim = dDelim; G.sCount = hCount; G.sTextLen = (int)hText.size(); G.ord = dOrd; G.outLen = dOut;
+  KZ_LAUNCH(ctx, KID_TEXT_INV, k_text_inv, dim3(B), dim3(64), bt.buf[bt.cur], bt.buf[bt.cur ^ 1], bt.stride, bt.d_len, G, B);
   std::vector<int32_t> outLen(B);
   KZ_HIP(hipMemcpyAsync(outLen.data(), dOut, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   KZ_HIP(kz_stream_sync(ctx, st));
