@@ -751,7 +751,8 @@ __global__ void k_merge_group(const int32_t* __restrict__ in, const int32_t* __r
 // the TEXT inverse on the device (kz_text_gpu.hip) instead of the host stage: opt-in, KZ_TEXT_GPU=1 (read per call).  Its first
 // form is one serial walk per block: 1.07 s for 1 536 text blocks of 4 MiB side by side -- and as long for 384 of them -- where 16
 // host CPUs need 0.87 s under the GPU's next chunk; it pays only where the host has next to no CPUs for the process.
-static bool text_gpu_on() { const char* e = getenv("KZ_TEXT_GPU"); return e && e[0] == '1'; }
+static int text_gpu_form() { const char* e = getenv("KZ_TEXT_GPU"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }   // 1: row form, 2: serial form
+static bool text_gpu_on() { return text_gpu_form() != 0; }
 
 static int fuse_min_blocks() {                                      // batches below this take the stages one after the other
   const char* e = getenv("KZ_FUSE_MIN_BLOCKS");                     // (read per call: the tests force both schedules)
@@ -1602,7 +1603,7 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
       take[b] = t ? 1 : 0;
     }
     hipEvent_t e0; kz_stage_begin(ctx, &e0);
-    rc = kz_stage_text_inverse_gpu(ctx, bt, blockSize, dataCap, entropyType == KZ_E_FPAQ, take, done);
+    rc = kz_stage_text_inverse_gpu(ctx, bt, blockSize, dataCap, entropyType == KZ_E_FPAQ, take, done, text_gpu_form());
     if (rc) return rc;
     kz_stage_end(ctx, e0, KZ_STAGE_HOST_INV, 0);
     for (int b = 0; b < B; b++) if (done[b]) h_skipHost[b] |= 0x80;

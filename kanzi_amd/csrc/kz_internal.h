@@ -176,7 +176,7 @@ int kz_host_transform_forward(int type, int entropyType, int blockSize, int* dat
 int kz_host_transform_inverse(int type, int blockSize, const uint8_t* src, int n, uint8_t* dst, int dstCap, int* produced);
 // kz_text_gpu.hip: the TEXT inverse of blocks that are still in HBM (done[b] = 1 for the blocks it finished; the others: host stage)
 size_t kz_text_gpu_scratch_per_block(int blockSize);
-int kz_stage_text_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, int dstCap, bool variant1, const std::vector<int32_t>& take, std::vector<int32_t>& done);
+int kz_stage_text_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, int dstCap, bool variant1, const std::vector<int32_t>& take, std::vector<int32_t>& done, int form);
 // run fn(i) for i in [0, n) on host threads (blocks are independent)
 void kz_parallel_for(int n, int maxThreads, void (*fn)(int, void*), void* arg);   // kz_host.hip: persistent pool
 int kz_usable_cpus();

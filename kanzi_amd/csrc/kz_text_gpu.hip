@@ -250,6 +250,220 @@ __global__ __launch_bounds__(64) void k_text_inv(const u8* __restrict__ srcAll, 
   if (lane == 0) G.outLen[b] = (ok && i == n) ? at : -1;
 }
 
+// ---- second form: a ROW of 64 coded bytes at a time (TextCodec2 blocks) ------------------------------------------------------
+// The token boundaries of TextCodec2 depend on the coded bytes alone, and so does the delimiter anchor (the only dictionary
+// words of one letter are static ones, known from LDS), so a row's tokens are found and classified by its lanes; what is
+// serial is kept short: (1) the walk over the row's multi-byte-capable lead bytes (>= 0x80 or the escape) that decides which
+// bytes start tokens, (2) the dictionary update for the row's literal-word candidates (a few thousand per block: hash, slot probe,
+// tail compare, learn: the code of the first form), (3) the carry between rows (bytes owned by the previous row's last token, the
+// anchor, the "after a word" flag, the output position).  References are resolved by their lanes (static words from LDS, learned
+// words with one gather of the records and one 16-byte gather of the text each), output sizes are a wave scan, bytes go through the
+// LDS ring.  A reference to a word learned LATER in the stream is what a serial decoder would have refused: the learn position of a
+// record is pos + length, a reference in front of it -- like every other anomaly: a token cut by the block's end, a number out of
+// range, an output that may not fit, a dictionary that wraps at 2^19 words -- gives the block to the host stage.
+#define TG2_RING 8192
+__global__ __launch_bounds__(64) void k_text_inv2(const u8* __restrict__ srcAll, u8* __restrict__ dstAll, int64_t stride, const int32_t* __restrict__ d_len, TextGpu G, int B) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int a = G.ord[b];
+  if (a < 0) return;
+  const int lane = kz_lane();
+  const int n = d_len[b];
+  const u8* src = srcAll + (int64_t)b * stride;
+  u8* dst = dstAll + (int64_t)b * stride;
+  if (n <= 1) { if (lane == 0) G.outLen[b] = -1; return; }
+  const u32 mode = tg_u(src[0]);
+  if (!(mode & TG_CODEC2)) { if (lane == 0) G.outLen[b] = -1; return; }      // TextCodec1 blocks: the first form / the host
+  const bool crlf = (mode & TG_CRLF) != 0;
+  volatile int32_t* slots = G.slots + (int64_t)a * G.slotsPer;
+  volatile TgWord* words = G.words + (int64_t)a * TG_MAXDICT;
+  const u32 mask = (1u << G.logV2) - 1u;
+  const int fixed = G.sCount;
+  int size = 1 << G.llog;
+  int next = fixed;
+  for (u32 i = (u32)lane; i <= mask; i += 64) slots[i] = -1;
+  for (int i = lane; i < size; i += 64) {
+    if (i < fixed) { words[i].hash = G.sHash[i]; words[i].pos = G.sPos[i]; words[i].lenIdx = G.sLenIdx[i] | TG_STATIC; }
+    else { words[i].hash = 0; words[i].pos = -1; words[i].lenIdx = (u32)i; }
+  }
+  __syncthreads();
+  if (lane == 0) for (int i = 0; i < fixed; i++) slots[G.sHash[i] & mask] = i;
+  const uint64_t dm0 = kz_ballot(G.delim[lane] != 0), dm1 = kz_ballot(G.delim[64 + lane] != 0);   // delimiters are ASCII: two masks
+  __shared__ u32 sRec[TG_SMAX * 2];
+  __shared__ u8 sTxt[TG_STEXT];
+  __shared__ __attribute__((aligned(16))) u8 wtxt[64 * 32];          // the row's learned-word texts, 32 bytes per lane
+  __shared__ __attribute__((aligned(16))) u8 obuf[TG2_RING];
+  for (int k = lane; k < fixed; k += 64) { sRec[2 * k] = (u32)G.sPos[k]; sRec[2 * k + 1] = G.sLenIdx[k] | TG_STATIC; }
+  for (int k = lane; k < G.sTextLen; k += 64) sTxt[k] = G.sText[k];
+  __syncthreads();
+  const int end = G.dstCap;
+  int at = 0, flushed = 0;
+  int skip = 1;                                  // leading bytes of the row that belong to a token of the row before (byte 0: the mode byte)
+  int last = tg_is_text(tg_u((u32)src[1])) ? 0 : 1;
+  bool afterWord = false, bad = false;
+  const uint64_t ltm = kz_lanemask_lt();
+  u32 nxt = (lane < n) ? (u32)src[lane] : 0u;
+  for (int rowBase = 0; rowBase < n && !bad; rowBase += 64) {
+    const u32 row = nxt;
+    nxt = (rowBase + 64 + lane < n) ? (u32)src[rowBase + 64 + lane] : 0u;
+    const int pabs = rowBase + lane;
+    const uint64_t validM = kz_ballot(pabs < n);
+    // the three bytes behind every byte (the next row's first bytes for the last lanes)
+    u32 b1 = (u32)__shfl_down((int)row, 1, 64), b2 = (u32)__shfl_down((int)row, 2, 64), b3 = (u32)__shfl_down((int)row, 3, 64);
+    { const u32 n0 = (u32)__builtin_amdgcn_readlane((int)nxt, 0), n1 = (u32)__builtin_amdgcn_readlane((int)nxt, 1), n2 = (u32)__builtin_amdgcn_readlane((int)nxt, 2);
+      if (lane == 63) { b1 = n0; b2 = n1; b3 = n2; } else if (lane == 62) { b2 = n0; b3 = n1; } else if (lane == 61) b3 = n0; }
+    const bool isT = tg_is_text(row);
+    const bool hi = (row & 0x80u) != 0;
+    const bool pre = row == 0x80u;
+    const u32 c2 = pre ? b1 : row;
+    const u32 idx7 = c2 & 0x7Fu;
+    const int ext = idx7 >= 112u ? 2 : (idx7 >= 64u ? 1 : 0);
+    const int L = isT ? 1 : (hi ? (pre ? 2 : 1) + ext : (row == TG_ESC1 ? 2 : 1));
+    // which bytes start tokens: walk the multi-byte-capable lead bytes in order, every other byte is a token of its own
+    uint64_t consumed = skip >= 64 ? ~0ULL : ((1ULL << skip) - 1ULL);
+    int newSkip = skip >= 64 ? skip - 64 : 0;
+    uint64_t Cw = kz_ballot((hi || row == TG_ESC1) && pabs < n) & ~consumed;
+    while (Cw) {
+      const int p = (int)__builtin_ctzll(Cw);
+      const int Lp = __builtin_amdgcn_readlane(L, p);
+      const uint64_t m = (Lp >= 64 ? ~0ULL : ((1ULL << Lp) - 1ULL)) << p;
+      consumed |= m & ~(1ULL << p);
+      if (p + Lp > 64) newSkip = p + Lp - 64;
+      Cw &= ~m;
+    }
+    const uint64_t starts = validM & ~consumed;
+    const bool st = (starts >> lane) & 1ULL;
+    if (kz_ballot(st && pabs + L > n)) { bad = true; break; }                // a token cut by the end of the block
+    const bool isRef = st && hi, isEsc = st && !isT && !hi && row == TG_ESC1, isLit = st && !isT && !hi && row != TG_ESC1;
+    const uint64_t NT = kz_ballot(st && !isT);                               // non-letter tokens: they move the anchor
+    // ---- references: their numbers; static ones know their word at once ----
+    int num = -1; u32 flip = pre ? 0x20u : 0u;
+    bool numBad = false;
+    if (isRef) {
+      const u32 nb1 = pre ? b2 : b1, nb2 = pre ? b3 : b2;
+      int v = (int)idx7;
+      if (ext == 2) v = (int)(((idx7 & 0x0Fu) << 16) | (nb1 << 8) | nb2);
+      else if (ext == 1) v = (int)(((idx7 & 0x1Fu) << 8) | nb1);
+      if (v == 0) numBad = true;                                             // (numbers past the dictionary: checked below, after the row's own words are in)
+      num = v - 1;
+    }
+    const bool isStatRef = isRef && num >= 0 && num < fixed;
+    u32 wLenIdx = 0; int wPos = -1;
+    if (isStatRef) { wPos = (int)sRec[2 * num]; wLenIdx = sRec[2 * num + 1]; }
+    int wlen = isStatRef ? (int)(wLenIdx >> 24) : (isRef ? 3 : 0);           // learned words have three letters or more: enough for the anchor
+    // anchor behind every non-letter token; the anchor a token sees = that of the non-letter token before it (or the row's carry)
+    const int anchorAfter = (isRef && wlen > 1) ? pabs + L : pabs + L - 1;
+    const uint64_t below = NT & ltm;
+    const int q = below ? 63 - (int)__builtin_clzll(below) : -1;
+    const int qAnchor = __shfl(anchorAfter, q < 0 ? 0 : q, 64);
+    const int myLast = q < 0 ? last : qAnchor;
+    // ---- literal-word candidates of the row, in order: the dictionary update of the first form ----
+    uint64_t cand = kz_ballot(isLit && row < 128u && (((row < 64u ? dm0 : dm1) >> (row & 63u)) & 1ULL) && pabs > myLast + 3);
+    while (cand) {
+      const int p = (int)__builtin_ctzll(cand);
+      cand &= cand - 1;
+      const int ci = rowBase + p;
+      const int clast = __builtin_amdgcn_readlane(myLast, p);
+      const int len = ci - clast - 1;
+      if (len > TG_MAXWORD) continue;
+      const u32 wb = (lane < len) ? (u32)src[clast + 1 + lane] : 0u;
+      u32 h = TG_HASH1;
+      for (int k = 0; k < len; k++) {
+        const u32 ch = (u32)__builtin_amdgcn_readlane((int)wb, k);
+        h = h * TG_HASH1 ^ (u32)(int32_t)(int8_t)ch * TG_HASH2;
+      }
+      const int s1 = (int)tg_u((u32)slots[h & mask]);
+      bool known = false;
+      if (s1 >= 0) {
+        const u32 eh = tg_u(words[s1].hash), eli = tg_u(words[s1].lenIdx);
+        if (eh == h && (int)(eli >> 24) == len) {
+          const int epos = (int)tg_u((u32)words[s1].pos);
+          const u8* et = (eli & TG_STATIC) ? G.sText : src;
+          const bool diff = (lane >= 1 && lane < len) && (u32)et[epos + lane] != wb;
+          known = kz_ballot(diff) == 0;
+        }
+      }
+      if (!known && (len > 3 || next < TG_T2) && s1 < 0) {
+        const u32 oli = tg_u(words[next].lenIdx);
+        if ((int)(oli & TG_IDXMASK) >= fixed) {
+          const u32 oh = tg_u(words[next].hash);
+          if (lane == 0) {
+            slots[oh & mask] = -1;
+            words[next].hash = h; words[next].pos = clast + 1; words[next].lenIdx = ((u32)len << 24) | (u32)next;
+          }
+        }
+        if (lane == 0) slots[h & mask] = next;
+        next++;
+        if (next >= size) {
+          if (size >= TG_MAXDICT) { bad = true; break; }                      // the numbering would restart: records change under references
+          for (int k = size + lane; k < 2 * size; k += 64) { words[k].hash = 0; words[k].pos = -1; words[k].lenIdx = (u32)k; }
+          size *= 2;
+        }
+        __syncthreads();
+      }
+    }
+    if (bad) break;
+    // ---- learned words: one gather of the records, validity as a serial decoder would have seen it ----
+    const bool isDynRef = isRef && !isStatRef;
+    if (isDynRef) {
+      if (num < 0 || num >= size) numBad = true;
+      else {
+        wLenIdx = words[num].lenIdx; wPos = words[num].pos;
+        wlen = (int)(wLenIdx >> 24);
+        if (wPos < 0 || wPos + wlen >= pabs || wlen < 3 || wlen > TG_MAXWORD) numBad = true;   // not learned yet at this point of the stream
+      }
+    }
+    if (kz_ballot(numBad)) { bad = true; break; }
+    // ---- output sizes: a letter, a literal (CR LF for LF in CRLF mode), an escaped byte, a word with its implied space ----
+    const bool qIsWord = __shfl((int)(isRef && wlen > 1), q < 0 ? 0 : q, 64) != 0;
+    const bool afterW = q < 0 ? afterWord : qIsWord;
+    const int sp = (isRef && afterW && wlen > 1) ? 1 : 0;
+    int olen = 0;
+    if (st) olen = isRef ? wlen + sp : ((isLit && crlf && row == TG_LF) ? 2 : 1);
+    const u32 inc = kz_wave_incl_sum((u32)olen);
+    const int total = (int)__builtin_amdgcn_readlane((int)inc, 63);
+    if (at + total + 2 >= end) { bad = true; break; }                          // may not fit: the host stage decides
+    const int o = at + (int)inc - olen;
+    // texts of the learned words: 16 bytes per lane in one gather (a second one for longer words), parked in LDS
+    if (isDynRef) {
+      typedef u32 tg_u32x4 __attribute__((ext_vector_type(4)));
+      typedef tg_u32x4 __attribute__((aligned(1))) tg_u32x4_u;
+      *(tg_u32x4*)(wtxt + lane * 32) = *(const tg_u32x4_u*)(src + wPos);     // (slots have >= 4 KiB of slack behind the block)
+      if (wlen > 16) *(tg_u32x4*)(wtxt + lane * 32 + 16) = *(const tg_u32x4_u*)(src + wPos + 16);
+    }
+    if (st && !isRef) {
+      if (isEsc) obuf[o & (TG2_RING - 1)] = (u8)b1;
+      else if (olen == 2) { obuf[o & (TG2_RING - 1)] = (u8)TG_CR; obuf[(o + 1) & (TG2_RING - 1)] = (u8)row; }
+      else obuf[o & (TG2_RING - 1)] = (u8)row;
+    }
+    if (isRef && sp) obuf[o & (TG2_RING - 1)] = (u8)' ';
+    {
+      const u32 mxv = kz_wave_incl_max((u32)(isRef ? wlen : 0));
+      const int mxAll = __builtin_amdgcn_readlane((int)mxv, 63);
+      const u8* wsrc = isStatRef ? (sTxt + wPos) : (wtxt + lane * 32);
+      for (int k = 0; k < mxAll; k++)
+        if (isRef && k < wlen) obuf[(o + sp + k) & (TG2_RING - 1)] = (u8)((u32)wsrc[k] ^ (k == 0 ? flip : 0u));
+    }
+    at += total;
+    // ---- carries into the next row ----
+    if (NT) {
+      const int hq = 63 - (int)__builtin_clzll(NT);
+      last = __builtin_amdgcn_readlane(anchorAfter, hq);
+      afterWord = __builtin_amdgcn_readlane((int)(isRef && wlen > 1), hq) != 0;
+    }
+    skip = newSkip;
+    while (at - flushed >= 1024) {
+      __syncthreads();
+      *(uint4*)(dst + flushed + 16 * lane) = *(const uint4*)(obuf + ((flushed + 16 * lane) & (TG2_RING - 1)));
+      flushed += 1024;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  if (!bad) for (int p = flushed + lane; p < at; p += 64) dst[p] = obuf[p & (TG2_RING - 1)];
+  if (lane == 0) G.outLen[b] = (!bad && skip == 0) ? at : -1;
+}
+
 // copy the finished blocks back to their slots (16 bytes per lane: slots are 256-byte aligned)
 __global__ __launch_bounds__(256) void k_text_copy_back(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride, const int32_t* __restrict__ len, const int32_t* __restrict__ cond) {
   const int b = blockIdx.y;
@@ -268,8 +482,9 @@ size_t kz_text_gpu_scratch_per_block(int blockSize) {
 
 // TEXT inverse of the blocks with take[b] != 0: reads bt.buf[cur] (lengths bt.h_len), leaves the result of the blocks it finished in
 // the same slots (bt.h_len / bt.d_len updated) and sets done[b] = 1 for them; every other block is untouched (the host stage takes
-// it).  variant1 = the stream's entropy coder asks for TextCodec1 (larger hash map).  Returns 0 or a negative error.
-int kz_stage_text_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, int dstCap, bool variant1, const std::vector<int32_t>& take, std::vector<int32_t>& done) {
+// it).  variant1 = the stream's entropy coder asks for TextCodec1 (larger hash map).  form: 1 = a row of 64 coded bytes at a time
+// (TextCodec2 blocks; the others are left to the host), 2 = the serial token walk (both variants).  Returns 0 or a negative error.
+int kz_stage_text_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, int dstCap, bool variant1, const std::vector<int32_t>& take, std::vector<int32_t>& done, int form) {
   const int B = bt.B;
   done.assign(B, 0);
   std::vector<int32_t> ord(B, -1);
@@ -310,7 +525,8 @@ int kz_stage_text_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, int dstC
   KZ_HIP(hipMemsetAsync(dOut, 0xFF, (size_t)B * 4, st));
   KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
   G.sHash = dHash; G.sPos = dPos; G.sLenIdx = dLenIdx; G.sText = dText; G.delim = dDelim; G.sCount = hCount; G.sTextLen = (int)hText.size(); G.ord = dOrd; G.outLen = dOut;
-  KZ_LAUNCH(ctx, KID_TEXT_INV, k_text_inv, dim3(B), dim3(64), bt.buf[bt.cur], bt.buf[bt.cur ^ 1], bt.stride, bt.d_len, G, B);
+  if (form == 2) { KZ_LAUNCH(ctx, KID_TEXT_INV, k_text_inv, dim3(B), dim3(64), bt.buf[bt.cur], bt.buf[bt.cur ^ 1], bt.stride, bt.d_len, G, B); }
+  else { KZ_LAUNCH(ctx, KID_TEXT_INV, k_text_inv2, dim3(B), dim3(64), bt.buf[bt.cur], bt.buf[bt.cur ^ 1], bt.stride, bt.d_len, G, B); }
   std::vector<int32_t> outLen(B);
   KZ_HIP(hipMemcpyAsync(outLen.data(), dOut, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   KZ_HIP(kz_stream_sync(ctx, st));

@@ -1515,13 +1515,14 @@ def test_bwt_forward_falls_back_when_the_trie_tables_overflow(ctx, monkeypatch, 
 
 # ---- round 5: the TEXT inverse on the device (kz_text_gpu.hip, opt-in KZ_TEXT_GPU=1) ----
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["1", "2"])
 @pytest.mark.parametrize("chain,ent", [("TEXT", "NONE"), ("TEXT", "FPAQ"), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0"), ("TEXT+UTF+BWT+SRT+ZRLT", "FPAQ")])
-def test_text_inverse_on_the_device(ctx, chain, ent, monkeypatch, capfd):
+def test_text_inverse_on_the_device(ctx, chain, ent, form, monkeypatch, capfd):
     """Streams written by the oracle (TextCodec2 for NONE / ANS0, TextCodec1 for FPAQ; English, CRLF, XML, escape bytes, a dictionary
     that doubles and wraps, UTF-8, binary and short blocks) are decoded with the TEXT inverse running on the device: same bytes as the
     input (= what the oracle's and the host stage's decoders give), corrupted copies get the oracle's verdict (the device form hands
     whatever it cannot finish to the host stage), and the trace shows that the device did take blocks."""
-    monkeypatch.setenv("KZ_TEXT_GPU", "1")
+    monkeypatch.setenv("KZ_TEXT_GPU", form)                        # 1: a row of 64 coded bytes at a time (TextCodec2 blocks), 2: the serial walk
     monkeypatch.setenv("KZ_TEXT_GPU_TRACE", "1")
     c = textgen.cases()
     data = (c["english"][:150000] + c["utf8"][:30000] + c["random"][:40000] + c["english_crlf"][:70000] + c["xml"][:60000] + c["english_escapes"][:50000]
@@ -1546,4 +1547,5 @@ def test_text_inverse_on_the_device(ctx, chain, ent, monkeypatch, capfd):
     err = capfd.readouterr().err
     took = [int(l.split()[2]) for l in err.splitlines() if l.startswith("[textgpu]")]
     fin = [int(l.split()[5]) for l in err.splitlines() if l.startswith("[textgpu]")]
-    assert took and sum(fin) > 0 and sum(fin) >= sum(took) // 2, err[-400:]
+    if form == "2" or ent != "FPAQ":                                # (the row form leaves TextCodec1 blocks to the host)
+        assert took and sum(fin) > 0 and sum(fin) >= sum(took) // 2, err[-400:]

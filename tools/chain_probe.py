@@ -12,12 +12,18 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
 cls = int(sys.argv[4]) if len(sys.argv) > 4 else -1
 bs = 4 << 20
 D = min(64, B)
-host = np.stack([datagen.block(i, bs, None if (cls < 0 or cls > 4) else cls) for i in range(D)])
+if cls == 6:                  # the text-heavy mix of bench.py's level-exact rows
+    sys.path.insert(0, ROOT)
+    import bench
+    D = min(16, B)
+    host = bench.text_mix(D, bs)
+else:
+    host = np.stack([datagen.block(i, bs, None if (cls < 0 or cls > 4) else cls) for i in range(D)])
 if cls == 5:                  # the synthetic mix with ONE all-zero block in the batch (the slowest possible block of a suffix sort by doubling)
     host = np.concatenate([host, np.zeros((1, bs), dtype=np.uint8)])
     D += 1
 ctx = kz.Context(0); ctx.set_block_size(bs)
-d_in = torch.from_numpy(host[:64]).cuda().repeat((B + 63) // 64, 1)[:B].contiguous()
+d_in = torch.from_numpy(host[:64]).cuda().repeat((B + min(D, 64) - 1) // min(D, 64), 1)[:B].contiguous()
 if cls == 5:
     d_in[B // 2] = 0
 os_ = kz.max_block_stream_bytes(bs)
