@@ -751,7 +751,7 @@ __global__ void k_merge_group(const int32_t* __restrict__ in, const int32_t* __r
 // the TEXT inverse on the device (kz_text_gpu.hip) instead of the host stage: opt-in, KZ_TEXT_GPU=1 (read per call).  Its first
 // form is one serial walk per block: 1.07 s for 1 536 text blocks of 4 MiB side by side -- and as long for 384 of them -- where 16
 // host CPUs need 0.87 s under the GPU's next chunk; it pays only where the host has next to no CPUs for the process.
-static int text_gpu_form() { const char* e = getenv("KZ_TEXT_GPU"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }   // 1: row form, 2: serial form
+static int text_gpu_form() { const char* e = getenv("KZ_TEXT_GPU"); return (e && (e[0] >= '1' && e[0] <= '3')) ? e[0] - '0' : 0; }   // 1: row form, 2: serial form
 static bool text_gpu_on() { return text_gpu_form() != 0; }
 
 static int fuse_min_blocks() {                                      // batches below this take the stages one after the other

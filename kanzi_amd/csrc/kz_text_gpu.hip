@@ -261,7 +261,13 @@ __global__ __launch_bounds__(64) void k_text_inv(const u8* __restrict__ srcAll, 
 // LDS ring.  A reference to a word learned LATER in the stream is what a serial decoder would have refused: the learn position of a
 // record is pos + length, a reference in front of it -- like every other anomaly: a token cut by the block's end, a number out of
 // range, an output that may not fit, a dictionary that wraps at 2^19 words -- gives the block to the host stage.
-#define TG2_RING 8192
+#define TG2_RING 4096
+#ifdef TG_PROF
+__device__ unsigned long long g_tgprof[8];
+#define TG_T(k) { const long long t_ = clock64(); tacc[k] += t_ - tprev; tprev = t_; }
+#else
+#define TG_T(k)
+#endif
 __global__ __launch_bounds__(64) void k_text_inv2(const u8* __restrict__ srcAll, u8* __restrict__ dstAll, int64_t stride, const int32_t* __restrict__ d_len, TextGpu G, int B) {
   const int b = blockIdx.x;
   if (b >= B) return;
@@ -289,12 +295,14 @@ __global__ __launch_bounds__(64) void k_text_inv2(const u8* __restrict__ srcAll,
   __syncthreads();
   if (lane == 0) for (int i = 0; i < fixed; i++) slots[G.sHash[i] & mask] = i;
   const uint64_t dm0 = kz_ballot(G.delim[lane] != 0), dm1 = kz_ballot(G.delim[64 + lane] != 0);   // delimiters are ASCII: two masks
-  __shared__ u32 sRec[TG_SMAX * 2];
-  __shared__ u8 sTxt[TG_STEXT];
-  __shared__ __attribute__((aligned(16))) u8 wtxt[64 * 32];          // the row's learned-word texts, 32 bytes per lane
+  __shared__ __attribute__((aligned(16))) u8 sT16[TG_SMAX * 16];     // the static words, 16 bytes each (the longest has 14 letters)
+  __shared__ u8 sLen8[TG_SMAX];
   __shared__ __attribute__((aligned(16))) u8 obuf[TG2_RING];
-  for (int k = lane; k < fixed; k += 64) { sRec[2 * k] = (u32)G.sPos[k]; sRec[2 * k + 1] = G.sLenIdx[k] | TG_STATIC; }
-  for (int k = lane; k < G.sTextLen; k += 64) sTxt[k] = G.sText[k];
+  for (int k = lane; k < fixed; k += 64) {
+    const int wl = (int)(G.sLenIdx[k] >> 24), wp = G.sPos[k];
+    sLen8[k] = (u8)wl;
+    for (int j = 0; j < 16; j++) sT16[16 * k + j] = j < wl ? G.sText[wp + j] : (u8)0;
+  }
   __syncthreads();
   const int end = G.dstCap;
   int at = 0, flushed = 0;
@@ -303,9 +311,15 @@ __global__ __launch_bounds__(64) void k_text_inv2(const u8* __restrict__ srcAll,
   bool afterWord = false, bad = false;
   const uint64_t ltm = kz_lanemask_lt();
   u32 nxt = (lane < n) ? (u32)src[lane] : 0u;
+  u32 nxt2 = (64 + lane < n) ? (u32)src[64 + lane] : 0u;                       // two rows ahead: a row's last lanes look into the next one
+#ifdef TG_PROF
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tprev = clock64();
+#endif
   for (int rowBase = 0; rowBase < n && !bad; rowBase += 64) {
+    TG_T(7)
     const u32 row = nxt;
-    nxt = (rowBase + 64 + lane < n) ? (u32)src[rowBase + 64 + lane] : 0u;
+    nxt = nxt2;
+    nxt2 = (rowBase + 128 + lane < n) ? (u32)src[rowBase + 128 + lane] : 0u;
     const int pabs = rowBase + lane;
     const uint64_t validM = kz_ballot(pabs < n);
     // the three bytes behind every byte (the next row's first bytes for the last lanes)
@@ -331,6 +345,7 @@ __global__ __launch_bounds__(64) void k_text_inv2(const u8* __restrict__ srcAll,
       if (p + Lp > 64) newSkip = p + Lp - 64;
       Cw &= ~m;
     }
+    TG_T(0)
     const uint64_t starts = validM & ~consumed;
     const bool st = (starts >> lane) & 1ULL;
     if (kz_ballot(st && pabs + L > n)) { bad = true; break; }                // a token cut by the end of the block
@@ -349,8 +364,7 @@ __global__ __launch_bounds__(64) void k_text_inv2(const u8* __restrict__ srcAll,
     }
     const bool isStatRef = isRef && num >= 0 && num < fixed;
     u32 wLenIdx = 0; int wPos = -1;
-    if (isStatRef) { wPos = (int)sRec[2 * num]; wLenIdx = sRec[2 * num + 1]; }
-    int wlen = isStatRef ? (int)(wLenIdx >> 24) : (isRef ? 3 : 0);           // learned words have three letters or more: enough for the anchor
+    int wlen = isStatRef ? (int)sLen8[num] : (isRef ? 3 : 0);           // learned words have three letters or more: enough for the anchor
     // anchor behind every non-letter token; the anchor a token sees = that of the non-letter token before it (or the row's carry)
     const int anchorAfter = (isRef && wlen > 1) ? pabs + L : pabs + L - 1;
     const uint64_t below = NT & ltm;
@@ -358,6 +372,7 @@ __global__ __launch_bounds__(64) void k_text_inv2(const u8* __restrict__ srcAll,
     const int qAnchor = __shfl(anchorAfter, q < 0 ? 0 : q, 64);
     const int myLast = q < 0 ? last : qAnchor;
     // ---- literal-word candidates of the row, in order: the dictionary update of the first form ----
+    TG_T(1)
     uint64_t cand = kz_ballot(isLit && row < 128u && (((row < 64u ? dm0 : dm1) >> (row & 63u)) & 1ULL) && pabs > myLast + 3);
     while (cand) {
       const int p = (int)__builtin_ctzll(cand);
@@ -403,6 +418,7 @@ __global__ __launch_bounds__(64) void k_text_inv2(const u8* __restrict__ srcAll,
       }
     }
     if (bad) break;
+    TG_T(2)
     // ---- learned words: one gather of the records, validity as a serial decoder would have seen it ----
     const bool isDynRef = isRef && !isStatRef;
     if (isDynRef) {
@@ -414,6 +430,7 @@ __global__ __launch_bounds__(64) void k_text_inv2(const u8* __restrict__ srcAll,
       }
     }
     if (kz_ballot(numBad)) { bad = true; break; }
+    TG_T(3)
     // ---- output sizes: a letter, a literal (CR LF for LF in CRLF mode), an escaped byte, a word with its implied space ----
     const bool qIsWord = __shfl((int)(isRef && wlen > 1), q < 0 ? 0 : q, 64) != 0;
     const bool afterW = q < 0 ? afterWord : qIsWord;
@@ -424,13 +441,16 @@ __global__ __launch_bounds__(64) void k_text_inv2(const u8* __restrict__ srcAll,
     const int total = (int)__builtin_amdgcn_readlane((int)inc, 63);
     if (at + total + 2 >= end) { bad = true; break; }                          // may not fit: the host stage decides
     const int o = at + (int)inc - olen;
-    // texts of the learned words: 16 bytes per lane in one gather (a second one for longer words), parked in LDS
-    if (isDynRef) {
-      typedef u32 tg_u32x4 __attribute__((ext_vector_type(4)));
-      typedef tg_u32x4 __attribute__((aligned(1))) tg_u32x4_u;
-      *(tg_u32x4*)(wtxt + lane * 32) = *(const tg_u32x4_u*)(src + wPos);     // (slots have >= 4 KiB of slack behind the block)
-      if (wlen > 16) *(tg_u32x4*)(wtxt + lane * 32 + 16) = *(const tg_u32x4_u*)(src + wPos + 16);
+    // texts: 16 bytes per lane from the static table in LDS or in one gather from the block (a second one for longer words)
+    typedef u32 tg_u32x4 __attribute__((ext_vector_type(4)));
+    typedef tg_u32x4 __attribute__((aligned(1))) tg_u32x4_u;
+    tg_u32x4 ta = {0, 0, 0, 0}, tb = {0, 0, 0, 0};
+    if (isStatRef) ta = *(const tg_u32x4*)(sT16 + 16 * num);
+    else if (isDynRef) {
+      ta = *(const tg_u32x4_u*)(src + wPos);                                    // (slots have >= 4 KiB of slack behind the block)
+      if (wlen > 16) tb = *(const tg_u32x4_u*)(src + wPos + 16);
     }
+    TG_T(4)
     if (st && !isRef) {
       if (isEsc) obuf[o & (TG2_RING - 1)] = (u8)b1;
       else if (olen == 2) { obuf[o & (TG2_RING - 1)] = (u8)TG_CR; obuf[(o + 1) & (TG2_RING - 1)] = (u8)row; }
@@ -440,11 +460,19 @@ __global__ __launch_bounds__(64) void k_text_inv2(const u8* __restrict__ srcAll,
     {
       const u32 mxv = kz_wave_incl_max((u32)(isRef ? wlen : 0));
       const int mxAll = __builtin_amdgcn_readlane((int)mxv, 63);
-      const u8* wsrc = isStatRef ? (sTxt + wPos) : (wtxt + lane * 32);
-      for (int k = 0; k < mxAll; k++)
-        if (isRef && k < wlen) obuf[(o + sp + k) & (TG2_RING - 1)] = (u8)((u32)wsrc[k] ^ (k == 0 ? flip : 0u));
+      const int ob = o + sp;
+      const int wl = isRef ? wlen : 0;
+      ta.x ^= flip;
+      const u32 tw[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+      for (int kk = 0; kk < 8; kk++) {
+        if (kk * 4 >= mxAll) break;
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (kk * 4 + j < wl) obuf[(ob + kk * 4 + j) & (TG2_RING - 1)] = (u8)(tw[kk] >> (8 * j));
+      }
     }
     at += total;
+    TG_T(5)
     // ---- carries into the next row ----
     if (NT) {
       const int hq = 63 - (int)__builtin_clzll(NT);
@@ -458,10 +486,321 @@ __global__ __launch_bounds__(64) void k_text_inv2(const u8* __restrict__ srcAll,
       flushed += 1024;
       __syncthreads();
     }
+    TG_T(6)
   }
+#ifdef TG_PROF
+  if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_tgprof[k], (unsigned long long)tacc[k]);
+#endif
   __syncthreads();
   if (!bad) for (int p = flushed + lane; p < at; p += 64) dst[p] = obuf[p & (TG2_RING - 1)];
   if (lane == 0) G.outLen[b] = (!bad && skip == 0) ? at : -1;
+}
+
+// ---- third form: the row form as three waves in lockstep, one step (barrier) per row --------------------------------------------
+// wave 0 finds the token starts of row t, wave 1 does the anchors, the dictionary update and the record gather of row t-1 and
+// completes row t-2 (whose records have arrived by then), wave 2 sizes row t-3 and fetches its texts, and writes row t-4 (whose
+// texts have arrived).  What the waves hand on goes through LDS, two buffers deep: a 64-bit mask of token starts, then two words per
+// lane (the token's class, its length, the static word's number or the learned word's position).  The barrier waits for LDS only,
+// so that the gathers stay in flight across it.  The token starts are the fixed point of "a lead byte of a multi-byte token starts
+// one unless an earlier one covers it", iterated on 64-bit masks: one more token of a chain of overlapping candidates is right per
+// iteration, two or three iterations for most rows.
+#define TG3_ST 0x00200000u
+#define TG3_REF 0x00400000u
+#define TG3_ESC 0x00800000u
+#define TG3_STAT 0x01000000u
+#define TG3_SP 0x02000000u
+#define TG3_FLIP 0x04000000u
+#define TG3_LF2 0x08000000u
+__device__ __forceinline__ void tg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__global__ __launch_bounds__(192) void k_text_inv3(const u8* __restrict__ srcAll, u8* __restrict__ dstAll, int64_t stride, const int32_t* __restrict__ d_len, TextGpu G, int B) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int a = G.ord[b];
+  if (a < 0) return;
+  const int tid = (int)threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (wave: uniform, so that what each role carries stays in scalar registers)
+  const int n = d_len[b];
+  const u8* src = srcAll + (int64_t)b * stride;
+  u8* dst = dstAll + (int64_t)b * stride;
+  if (n <= 1) { if (tid == 0) G.outLen[b] = -1; return; }
+  const u32 mode = tg_u(src[0]);
+  if (!(mode & TG_CODEC2)) { if (tid == 0) G.outLen[b] = -1; return; }       // TextCodec1 blocks: the first form / the host
+  const bool crlf = (mode & TG_CRLF) != 0;
+  volatile int32_t* slots = G.slots + (int64_t)a * G.slotsPer;
+  volatile TgWord* words = G.words + (int64_t)a * TG_MAXDICT;
+  const u32 mask = (1u << G.logV2) - 1u;
+  const int fixed = G.sCount;
+  for (u32 i = (u32)tid; i <= mask; i += 192) slots[i] = -1;
+  for (int i = tid; i < (1 << G.llog); i += 192) {
+    if (i < fixed) { words[i].hash = G.sHash[i]; words[i].pos = G.sPos[i]; words[i].lenIdx = G.sLenIdx[i] | TG_STATIC; }
+    else { words[i].hash = 0; words[i].pos = -1; words[i].lenIdx = (u32)i; }
+  }
+  __shared__ __attribute__((aligned(16))) u8 sT16[TG_SMAX * 16];     // the static words, 16 bytes each (the longest has 14 letters)
+  __shared__ u8 sLen8[TG_SMAX];
+  __shared__ __attribute__((aligned(16))) u8 obuf[TG2_RING + 64];    // (+ a spare byte per lane)
+  __shared__ uint64_t qStarts[2];
+  __shared__ u32 qA[2][64], qB[2][64];
+  __shared__ int sBad[2];
+  for (int k = tid; k < fixed; k += 192) {
+    const int wl = (int)(G.sLenIdx[k] >> 24), wp = G.sPos[k];
+    sLen8[k] = (u8)wl;
+    for (int j = 0; j < 16; j++) sT16[16 * k + j] = j < wl ? G.sText[wp + j] : (u8)0;
+  }
+  if (tid < 2) sBad[tid] = 0;
+  __syncthreads();
+  if (tid == 0) for (int i = 0; i < fixed; i++) slots[G.sHash[i] & mask] = i;
+  __syncthreads();
+  const int R = (n + 63) >> 6;
+  const uint64_t ltm = kz_lanemask_lt();
+  typedef u32 tg_u32x4 __attribute__((ext_vector_type(4)));
+  typedef tg_u32x4 __attribute__((aligned(1))) tg_u32x4_u;
+  // wave 0
+  int skip = 1;                                  // leading bytes of the row that belong to a token of the row before (byte 0: the mode byte)
+  // waves 0 and 1: the row and the two behind it (wave 1 runs one row late)
+  u32 nxt = 0, nxt2 = 0;
+  if (wave < 2) { nxt = (lane < n) ? (u32)src[lane] : 0u; nxt2 = (64 + lane < n) ? (u32)src[64 + lane] : 0u; }
+  // wave 1
+  const uint64_t dm0 = kz_ballot(G.delim[lane] != 0), dm1 = kz_ballot(G.delim[64 + lane] != 0);   // delimiters are ASCII: two masks
+  int size = 1 << G.llog, next = fixed;
+  int last = tg_is_text(tg_u((u32)src[1])) ? 0 : 1;
+  bool afterWord = false;
+  bool pHave = false;                            // the row whose records are in flight
+  u32 pA = 0, pLenIdx = 0; int pNum = -1, pPos = -1, pPabs = 0; bool pDyn = false, pNumBad = false, pAfterW = false;
+  // wave 2
+  const int end = G.dstCap;
+  int at = 0, done = 0, flushed = 0;             // sized up to / written up to / stored up to
+  bool wHave = false;                            // the row whose texts are in flight
+  u32 wA = 0; int wO = 0; tg_u32x4 wTa = {0, 0, 0, 0}, wTb = {0, 0, 0, 0}; int wEnd = 0;
+  bool bad = false;
+#ifdef TG_PROF
+  long long tBody = 0, tWait = 0, tprev = clock64();
+#endif
+  for (int t = 0; t < R + 5; t++) {
+    bool myBad = false;
+#ifdef TG_PROF
+    { const long long t_ = clock64(); tWait += t_ - tprev; tprev = t_; }
+#endif
+    if (wave < 2) {
+      if (wave == 1 && pHave) {
+        // ---- complete row t-2: its learned words as a serial decoder would have seen them ----
+        int wlen = (int)((pA >> 16) & 31u);
+        bool numBad = pNumBad;
+        if (pDyn && !numBad) {
+          wlen = (int)(pLenIdx >> 24);
+          if (pPos < 0 || pPos + wlen >= pPabs || wlen < 3 || wlen > TG_MAXWORD) numBad = true;    // not learned yet at this point of the stream
+        }
+        if (kz_ballot(numBad)) myBad = true;
+        u32 A = (pA & ~(31u << 16)) | ((u32)(wlen & 31) << 16);
+        if ((A & TG3_REF) && pAfterW && wlen > 1) A |= TG3_SP;
+        const int rp = t - 2;
+        qA[rp & 1][lane] = A;
+        qB[rp & 1][lane] = (A & TG3_STAT) ? (u32)pNum : (u32)pPos;
+        pHave = false;
+      }
+      const int r = t - wave;
+      if (r >= 0 && r < R) {
+        const int rowBase = r << 6;
+        const u32 row = nxt;
+        nxt = nxt2;
+        nxt2 = (rowBase + 128 + lane < n) ? (u32)src[rowBase + 128 + lane] : 0u;
+        const int pabs = rowBase + lane;
+        u32 b1 = (u32)__shfl_down((int)row, 1, 64), b2 = (u32)__shfl_down((int)row, 2, 64), b3 = (u32)__shfl_down((int)row, 3, 64);
+        { const u32 n0 = (u32)__builtin_amdgcn_readlane((int)nxt, 0), n1 = (u32)__builtin_amdgcn_readlane((int)nxt, 1), n2 = (u32)__builtin_amdgcn_readlane((int)nxt, 2);
+          if (lane == 63) { b1 = n0; b2 = n1; b3 = n2; } else if (lane == 62) { b2 = n0; b3 = n1; } else if (lane == 61) b3 = n0; }
+        const bool isT = tg_is_text(row);
+        const bool hi = (row & 0x80u) != 0;
+        const bool pre = row == 0x80u;
+        const u32 c2 = pre ? b1 : row;
+        const u32 idx7 = c2 & 0x7Fu;
+        const int ext = idx7 >= 112u ? 2 : (idx7 >= 64u ? 1 : 0);
+        const int L = isT ? 1 : (hi ? (pre ? 2 : 1) + ext : (row == TG_ESC1 ? 2 : 1));
+        if (wave == 0) {
+          // which bytes start tokens: a lead byte of a multi-byte token starts one unless an earlier token covers it
+          const uint64_t validM = kz_ballot(pabs < n);
+          const uint64_t M2 = kz_ballot(L == 2 && pabs < n), M3 = kz_ballot(L == 3 && pabs < n), M4 = kz_ballot(L == 4 && pabs < n);
+          const uint64_t M = M2 | M3 | M4;
+          const uint64_t carry = skip >= 64 ? ~0ULL : ((1ULL << skip) - 1ULL);
+          uint64_t Rl = M & ~carry, C;
+          for (;;) {
+            const uint64_t r34 = Rl & (M3 | M4), r4 = Rl & M4;
+            C = carry | (Rl << 1) | (r34 << 2) | (r4 << 3);
+            const uint64_t Rn = M & ~C;
+            if (Rn == Rl) break;
+            Rl = Rn;
+          }
+          const u32 t4 = (u32)((Rl & M4) >> 61), t3 = (u32)((Rl & M3) >> 62), t2 = (u32)((Rl & M2) >> 63);   // tokens that run into the next row
+          skip = (t4 & 4u) ? 3 : (((t4 & 2u) | (t3 & 2u)) ? 2 : (((t4 & 1u) | (t3 & 1u) | t2) ? 1 : 0));
+          const uint64_t starts = validM & ~C;
+          const bool st = (starts >> lane) & 1ULL;
+          if (kz_ballot(st && pabs + L > n)) myBad = true;                     // a token cut by the end of the block
+          if (lane == 0) qStarts[r & 1] = starts;
+        } else {
+          const uint64_t starts = qStarts[r & 1];
+          const bool st = (starts >> lane) & 1ULL;
+          const bool isRef = st && hi, isEsc = st && !isT && !hi && row == TG_ESC1, isLit = st && !isT && !hi && row != TG_ESC1;
+          const uint64_t NT = kz_ballot(st && !isT);                           // non-letter tokens: they move the anchor
+          int num = -1;
+          bool numBad = false;
+          if (isRef) {
+            const u32 nb1 = pre ? b2 : b1, nb2 = pre ? b3 : b2;
+            int v = (int)idx7;
+            if (ext == 2) v = (int)(((idx7 & 0x0Fu) << 16) | (nb1 << 8) | nb2);
+            else if (ext == 1) v = (int)(((idx7 & 0x1Fu) << 8) | nb1);
+            if (v == 0) numBad = true;                                         // (numbers past the dictionary: checked below, after the row's own words are in)
+            num = v - 1;
+          }
+          const bool isStatRef = isRef && num >= 0 && num < fixed;
+          const int wlen = isStatRef ? (int)sLen8[num] : (isRef ? 3 : 0);      // learned words have three letters or more: enough for the anchor
+          const int anchorAfter = (isRef && wlen > 1) ? pabs + L : pabs + L - 1;
+          const uint64_t below = NT & ltm;
+          const int q = below ? 63 - (int)__builtin_clzll(below) : -1;
+          const int qAnchor = __shfl(anchorAfter, q < 0 ? 0 : q, 64);
+          const int myLast = q < 0 ? last : qAnchor;
+          const bool qIsWord = __shfl((int)(isRef && wlen > 1), q < 0 ? 0 : q, 64) != 0;
+          const bool afterW = q < 0 ? afterWord : qIsWord;
+          // literal-word candidates of the row, in order: the dictionary update of the first form
+          uint64_t cand = kz_ballot(isLit && row < 128u && (((row < 64u ? dm0 : dm1) >> (row & 63u)) & 1ULL) && pabs > myLast + 3);
+          while (cand) {
+            const int p = (int)__builtin_ctzll(cand);
+            cand &= cand - 1;
+            const int ci = rowBase + p;
+            const int clast = __builtin_amdgcn_readlane(myLast, p);
+            const int len = ci - clast - 1;
+            if (len > TG_MAXWORD) continue;
+            const u32 wb = (lane < len) ? (u32)src[clast + 1 + lane] : 0u;
+            u32 h = TG_HASH1;
+            for (int k = 0; k < len; k++) {
+              const u32 ch = (u32)__builtin_amdgcn_readlane((int)wb, k);
+              h = h * TG_HASH1 ^ (u32)(int32_t)(int8_t)ch * TG_HASH2;
+            }
+            const int s1 = (int)tg_u((u32)slots[h & mask]);
+            bool known = false;
+            if (s1 >= 0) {
+              const u32 eh = tg_u(words[s1].hash), eli = tg_u(words[s1].lenIdx);
+              if (eh == h && (int)(eli >> 24) == len) {
+                const int epos = (int)tg_u((u32)words[s1].pos);
+                const u8* et = (eli & TG_STATIC) ? G.sText : src;
+                const bool diff = (lane >= 1 && lane < len) && (u32)et[epos + lane] != wb;
+                known = kz_ballot(diff) == 0;
+              }
+            }
+            if (!known && (len > 3 || next < TG_T2) && s1 < 0) {
+              const u32 oli = tg_u(words[next].lenIdx);
+              if ((int)(oli & TG_IDXMASK) >= fixed) {
+                const u32 oh = tg_u(words[next].hash);
+                if (lane == 0) {
+                  slots[oh & mask] = -1;
+                  words[next].hash = h; words[next].pos = clast + 1; words[next].lenIdx = ((u32)len << 24) | (u32)next;
+                }
+              }
+              if (lane == 0) slots[h & mask] = next;
+              next++;
+              if (next >= size) {
+                if (size >= TG_MAXDICT) { myBad = true; break; }                // the numbering would restart: records change under references
+                for (int k = size + lane; k < 2 * size; k += 64) { words[k].hash = 0; words[k].pos = -1; words[k].lenIdx = (u32)k; }
+                size *= 2;
+              }
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");             // one wave: the stores above are done before the loads that follow (no cache maintenance: the loads are volatile)
+            }
+          }
+          // learned words: one gather of the records, looked at a step later
+          pDyn = isRef && !isStatRef;
+          pNumBad = numBad;
+          if (pDyn) {
+            if (num < 0 || num >= size) pNumBad = true;
+            else { pLenIdx = words[num].lenIdx; pPos = words[num].pos; }
+          }
+          u32 A = (row & 0xFFu) | ((b1 & 0xFFu) << 8) | ((u32)(wlen & 31) << 16);
+          if (st) A |= TG3_ST;
+          if (isRef) A |= TG3_REF;
+          if (isEsc) A |= TG3_ESC;
+          if (isStatRef) A |= TG3_STAT;
+          if (isRef && pre) A |= TG3_FLIP;
+          if (isLit && crlf && row == TG_LF) A |= TG3_LF2;
+          pA = A; pNum = num; pPabs = pabs; pAfterW = afterW; pHave = true;
+          if (NT) {
+            const int hq = 63 - (int)__builtin_clzll(NT);
+            last = __builtin_amdgcn_readlane(anchorAfter, hq);
+            afterWord = __builtin_amdgcn_readlane((int)(isRef && wlen > 1), hq) != 0;
+          }
+        }
+      }
+    } else {
+      if (wHave) {
+        // ---- write row t-4: its texts have arrived ----
+        const bool st = (wA & TG3_ST) != 0, isRef = (wA & TG3_REF) != 0;
+        const int wlen = (int)((wA >> 16) & 31u);
+        const int sp = (wA & TG3_SP) ? 1 : 0;
+        const int o = wO;
+        if (st && !isRef) {
+          if (wA & TG3_ESC) obuf[o & (TG2_RING - 1)] = (u8)(wA >> 8);
+          else if (wA & TG3_LF2) { obuf[o & (TG2_RING - 1)] = (u8)TG_CR; obuf[(o + 1) & (TG2_RING - 1)] = (u8)wA; }
+          else obuf[o & (TG2_RING - 1)] = (u8)wA;
+        }
+        if (isRef && sp) obuf[o & (TG2_RING - 1)] = (u8)' ';
+        const u32 mxv = kz_wave_incl_max((u32)(isRef ? wlen : 0));
+        const int mxAll = __builtin_amdgcn_readlane((int)mxv, 63);
+        const int ob = o + sp;
+        const int wl = isRef ? wlen : 0;
+        if (wA & TG3_FLIP) wTa.x ^= 0x20u;
+        const u32 tw[8] = {wTa.x, wTa.y, wTa.z, wTa.w, wTb.x, wTb.y, wTb.z, wTb.w};
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) {                                       // (bytes past a word's end go to a spare byte of the lane: no branches)
+          if (kk * 4 >= mxAll) break;
+#pragma unroll
+          for (int j = 0; j < 4; j++) obuf[(kk * 4 + j < wl) ? ((ob + kk * 4 + j) & (TG2_RING - 1)) : (TG2_RING + lane)] = (u8)(tw[kk] >> (8 * j));
+        }
+        done = wEnd;
+        while (done - flushed >= 1024) {                                       // (the ring is this wave's alone)
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local");
+          *(uint4*)(dst + flushed + 16 * lane) = *(const uint4*)(obuf + ((flushed + 16 * lane) & (TG2_RING - 1)));
+          flushed += 1024;
+        }
+        wHave = false;
+      }
+      const int r = t - 3;
+      if (r >= 0 && r < R) {
+        // ---- size row t-3 and fetch its texts ----
+        const u32 A = qA[r & 1][lane], Bv = qB[r & 1][lane];
+        const bool st = (A & TG3_ST) != 0, isRef = (A & TG3_REF) != 0;
+        const int wlen = (int)((A >> 16) & 31u);
+        const int sp = (A & TG3_SP) ? 1 : 0;
+        int olen = 0;
+        if (st) olen = isRef ? wlen + sp : ((A & TG3_LF2) ? 2 : 1);
+        const u32 inc = kz_wave_incl_sum((u32)olen);
+        const int total = (int)__builtin_amdgcn_readlane((int)inc, 63);
+        if (at + total + 2 >= end) myBad = true;                               // may not fit: the host stage decides
+        // (the ring: < 1024 bytes not stored yet + this row's, 2048 at most)
+        else {
+          wTa = tg_u32x4{0, 0, 0, 0}; wTb = tg_u32x4{0, 0, 0, 0};
+          if (isRef) {
+            if (A & TG3_STAT) wTa = *(const tg_u32x4*)(sT16 + 16 * Bv);
+            else {
+              wTa = *(const tg_u32x4_u*)(src + (int)Bv);                       // (slots have >= 4 KiB of slack behind the block)
+              if (wlen > 16) wTb = *(const tg_u32x4_u*)(src + (int)Bv + 16);
+            }
+          }
+          wA = A; wO = at + (int)inc - olen;
+          at += total;
+          wEnd = at;
+          wHave = true;
+        }
+      }
+    }
+    if (myBad && lane == 0) sBad[t & 1] = 1;
+#ifdef TG_PROF
+    { const long long t_ = clock64(); tBody += t_ - tprev; tprev = t_; }
+#endif
+    tg_lds_barrier();
+    if (sBad[t & 1]) { bad = true; break; }
+  }
+#ifdef TG_PROF
+  if (lane == 0) { atomicAdd(&g_tgprof[wave], (unsigned long long)tBody); atomicAdd(&g_tgprof[3 + wave], (unsigned long long)tWait); }
+#endif
+  __syncthreads();
+  if (wave == 2) {
+    if (!bad) for (int p = flushed + lane; p < at; p += 64) dst[p] = obuf[p & (TG2_RING - 1)];
+    if (lane == 0) G.outLen[b] = bad ? -1 : at;
+  }
 }
 
 // copy the finished blocks back to their slots (16 bytes per lane: slots are 256-byte aligned)
@@ -526,7 +865,8 @@ int kz_stage_text_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, int dstC
   KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
   G.sHash = dHash; G.sPos = dPos; G.sLenIdx = dLenIdx; G.sText = dText; G.delim = dDelim; G.sCount = hCount; G.sTextLen = (int)hText.size(); G.ord = dOrd; G.outLen = dOut;
   if (form == 2) { KZ_LAUNCH(ctx, KID_TEXT_INV, k_text_inv, dim3(B), dim3(64), bt.buf[bt.cur], bt.buf[bt.cur ^ 1], bt.stride, bt.d_len, G, B); }
-  else { KZ_LAUNCH(ctx, KID_TEXT_INV, k_text_inv2, dim3(B), dim3(64), bt.buf[bt.cur], bt.buf[bt.cur ^ 1], bt.stride, bt.d_len, G, B); }
+  else if (form == 3) { KZ_LAUNCH(ctx, KID_TEXT_INV, k_text_inv2, dim3(B), dim3(64), bt.buf[bt.cur], bt.buf[bt.cur ^ 1], bt.stride, bt.d_len, G, B); }
+  else { KZ_LAUNCH(ctx, KID_TEXT_INV, k_text_inv3, dim3(B), dim3(192), bt.buf[bt.cur], bt.buf[bt.cur ^ 1], bt.stride, bt.d_len, G, B); }
   std::vector<int32_t> outLen(B);
   KZ_HIP(hipMemcpyAsync(outLen.data(), dOut, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   KZ_HIP(kz_stream_sync(ctx, st));
@@ -543,6 +883,12 @@ int kz_stage_text_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, int dstC
     KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     KZ_HIP(kz_stream_sync(ctx, st));
   }
+#ifdef TG_PROF
+  { unsigned long long h[8]; KZ_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tgprof), sizeof h));
+    fprintf(stderr, "[textgpu-prof] clocks per block (row form, one wave: walk anchors words records sizes+text write flush loop; three waves: busy 0 1 2, waiting 0 1 2): %llu %llu %llu %llu %llu %llu %llu %llu\n",
+            h[0] / A, h[1] / A, h[2] / A, h[3] / A, h[4] / A, h[5] / A, h[6] / A, h[7] / A);
+    memset(h, 0, sizeof h); KZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_tgprof), h, sizeof h)); }
+#endif
   KZ_HIP(hipGetLastError());
   ctx->arenaTop = mark;
   return 0;
