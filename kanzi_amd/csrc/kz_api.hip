@@ -751,8 +751,18 @@ __global__ void k_merge_group(const int32_t* __restrict__ in, const int32_t* __r
 // the TEXT inverse on the device (kz_text_gpu.hip) instead of the host stage: opt-in, KZ_TEXT_GPU=1 (read per call).  Its first
 // form is one serial walk per block: 1.07 s for 1 536 text blocks of 4 MiB side by side -- and as long for 384 of them -- where 16
 // host CPUs need 0.87 s under the GPU's next chunk; it pays only where the host has next to no CPUs for the process.
-static int text_gpu_form() { const char* e = getenv("KZ_TEXT_GPU"); return (e && (e[0] >= '1' && e[0] <= '3')) ? e[0] - '0' : 0; }   // 1: row form, 2: serial form
-static bool text_gpu_on() { return text_gpu_form() != 0; }
+// TEXT inverse on the device (kz_text_gpu.hip).  KZ_TEXT_GPU: unset = the row form (three waves per block) for streams whose entropy
+// coder selects TextCodec2 (every coder but FPAQ / the CM family, TextCodec.java:73-88) in batches of KZ_TEXT_GPU_MIN blocks or more
+// (512: a block takes the kernel ~0.1 s however few there are, the host stage ~10 ms per block and thread), else the host stage;
+// 0 = host stage only; 1 = row form, three waves; 2 = serial token walk (both codecs); 3 = row form, one wave (1-3: any batch).
+static int text_gpu_form(uint32_t entropyType, int nBlocks) {
+  const char* e = getenv("KZ_TEXT_GPU");
+  if (e && e[0] >= '0' && e[0] <= '3') return e[0] - '0';
+  const char* m = getenv("KZ_TEXT_GPU_MIN");
+  const int minBlocks = m ? atoi(m) : 512;
+  return (entropyType == KZ_E_FPAQ || nBlocks < minBlocks) ? 0 : 1;
+}
+static bool text_gpu_on(uint32_t entropyType, int nBlocks) { return text_gpu_form(entropyType, nBlocks) != 0; }
 
 static int fuse_min_blocks() {                                      // batches below this take the stages one after the other
   const char* e = getenv("KZ_FUSE_MIN_BLOCKS");                     // (read per call: the tests force both schedules)
@@ -1400,7 +1410,7 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
   // larger (corrupt) length is rejected with the same error code.
   const int maxLen = std::min(maxTL, dataCap + 1024);
   ChainSpec CS; CS.nb = nb; CS.entropy = (int)entropyType; for (int i = 0; i < nb; i++) CS.types[i] = types[i];
-  const bool textGpu = hp > 0 && !deferHost && types[0] == KZ_T_TEXT && text_gpu_on();
+  const bool textGpu = hp > 0 && !deferHost && types[0] == KZ_T_TEXT && text_gpu_on((uint32_t)entropyType, B);
   {
     const size_t perBlock = pipeline_scratch(1, maxLen, true, CS) + (size_t)maxLen * 2 + (size_t)(host ? maxInBytes : 0) + (1 << 16) +
                             (textGpu ? kz_text_gpu_scratch_per_block(blockSize) : 0);
@@ -1603,7 +1613,7 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
       take[b] = t ? 1 : 0;
     }
     hipEvent_t e0; kz_stage_begin(ctx, &e0);
-    rc = kz_stage_text_inverse_gpu(ctx, bt, blockSize, dataCap, entropyType == KZ_E_FPAQ, take, done, text_gpu_form());
+    rc = kz_stage_text_inverse_gpu(ctx, bt, blockSize, dataCap, entropyType == KZ_E_FPAQ, take, done, text_gpu_form((uint32_t)entropyType, B));
     if (rc) return rc;
     kz_stage_end(ctx, e0, KZ_STAGE_HOST_INV, 0);
     for (int b = 0; b < B; b++) if (done[b]) h_skipHost[b] |= 0x80;
@@ -1671,7 +1681,7 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   // ---- chains led by TEXT / UTF on large batches: the host inverse stages of chunk k run on a helper thread (and the host pool)
   //      while the GPU decodes chunk k+1.  (Block checksums are verified on the device AFTER the host stages: that case takes the
   //      one-pass path.) ----
-  if (hp > 0 && ctx->checksum == 0 && nBlocks >= 2 * CH && !(types[0] == KZ_T_TEXT && text_gpu_on())) {
+  if (hp > 0 && ctx->checksum == 0 && nBlocks >= 2 * CH && !(types[0] == KZ_T_TEXT && text_gpu_on((uint32_t)entropyType, nBlocks))) {
     const int B = nBlocks, nch = (B + CH - 1) / CH;
     const int dataCap = blockSize + std::max(512, blockSize >> 4);
     std::vector<std::thread> finishers;

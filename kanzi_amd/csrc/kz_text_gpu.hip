@@ -511,6 +511,9 @@ __global__ __launch_bounds__(64) void k_text_inv2(const u8* __restrict__ srcAll,
 #define TG3_SP 0x02000000u
 #define TG3_FLIP 0x04000000u
 #define TG3_LF2 0x08000000u
+// dictionary accesses of the wave that owns it: relaxed device-scope atomics (served by L2, no wait of their own: volatile ones are waited for one by one)
+__device__ __forceinline__ u32 tg_ld(const volatile void* p) { return __hip_atomic_load((const u32*)(uintptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tg_st(volatile void* p, u32 v) { __hip_atomic_store((u32*)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void tg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __global__ __launch_bounds__(192) void k_text_inv3(const u8* __restrict__ srcAll, u8* __restrict__ dstAll, int64_t stride, const int32_t* __restrict__ d_len, TextGpu G, int B) {
   const int b = blockIdx.x;
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(192) void k_text_inv3(const u8* __restrict__ srcAll
   }
   __shared__ __attribute__((aligned(16))) u8 sT16[TG_SMAX * 16];     // the static words, 16 bytes each (the longest has 14 letters)
   __shared__ u8 sLen8[TG_SMAX];
-  __shared__ __attribute__((aligned(16))) u8 obuf[TG2_RING + 64];    // (+ a spare byte per lane)
+  __shared__ __attribute__((aligned(16))) u8 obuf[TG2_RING + 256];   // (+ a spare word per lane)
   __shared__ uint64_t qStarts[2];
   __shared__ u32 qA[2][64], qB[2][64];
   __shared__ int sBad[2];
@@ -672,34 +675,33 @@ __global__ __launch_bounds__(192) void k_text_inv3(const u8* __restrict__ srcAll
               const u32 ch = (u32)__builtin_amdgcn_readlane((int)wb, k);
               h = h * TG_HASH1 ^ (u32)(int32_t)(int8_t)ch * TG_HASH2;
             }
-            const int s1 = (int)tg_u((u32)slots[h & mask]);
+            const u32 oli = tg_ld(&words[next].lenIdx), oh = tg_ld(&words[next].hash);          // (the record a new word would take)
+            const int s1 = (int)tg_u(tg_ld(&slots[h & mask]));
             bool known = false;
             if (s1 >= 0) {
-              const u32 eh = tg_u(words[s1].hash), eli = tg_u(words[s1].lenIdx);
-              if (eh == h && (int)(eli >> 24) == len) {
-                const int epos = (int)tg_u((u32)words[s1].pos);
-                const u8* et = (eli & TG_STATIC) ? G.sText : src;
-                const bool diff = (lane >= 1 && lane < len) && (u32)et[epos + lane] != wb;
+              const u32 eh = tg_ld(&words[s1].hash), eli = tg_ld(&words[s1].lenIdx);
+              const int epos = (int)tg_ld(&words[s1].pos);
+              if (tg_u(eh) == h && (int)(tg_u(eli) >> 24) == len) {
+                const u8* et = (tg_u(eli) & TG_STATIC) ? G.sText : src;
+                const bool diff = (lane >= 1 && lane < len) && (u32)et[(int)tg_u((u32)epos) + lane] != wb;
                 known = kz_ballot(diff) == 0;
               }
             }
             if (!known && (len > 3 || next < TG_T2) && s1 < 0) {
-              const u32 oli = tg_u(words[next].lenIdx);
-              if ((int)(oli & TG_IDXMASK) >= fixed) {
-                const u32 oh = tg_u(words[next].hash);
+              if ((int)(tg_u(oli) & TG_IDXMASK) >= fixed) {
                 if (lane == 0) {
-                  slots[oh & mask] = -1;
-                  words[next].hash = h; words[next].pos = clast + 1; words[next].lenIdx = ((u32)len << 24) | (u32)next;
+                  tg_st(&slots[tg_u(oh) & mask], (u32)-1);
+                  tg_st(&words[next].hash, h); tg_st(&words[next].pos, (u32)(clast + 1)); tg_st(&words[next].lenIdx, ((u32)len << 24) | (u32)next);
                 }
               }
-              if (lane == 0) slots[h & mask] = next;
+              if (lane == 0) tg_st(&slots[h & mask], (u32)next);
               next++;
               if (next >= size) {
                 if (size >= TG_MAXDICT) { myBad = true; break; }                // the numbering would restart: records change under references
-                for (int k = size + lane; k < 2 * size; k += 64) { words[k].hash = 0; words[k].pos = -1; words[k].lenIdx = (u32)k; }
+                for (int k = size + lane; k < 2 * size; k += 64) { tg_st(&words[k].hash, 0u); tg_st(&words[k].pos, (u32)-1); tg_st(&words[k].lenIdx, (u32)k); }
                 size *= 2;
               }
-              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");             // one wave: the stores above are done before the loads that follow (no cache maintenance: the loads are volatile)
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");             // one wave: the stores above are done before the loads that follow
             }
           }
           // learned words: one gather of the records, looked at a step later
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(192) void k_text_inv3(const u8* __restrict__ srcAll
           pNumBad = numBad;
           if (pDyn) {
             if (num < 0 || num >= size) pNumBad = true;
-            else { pLenIdx = words[num].lenIdx; pPos = words[num].pos; }
+            else { pLenIdx = tg_ld(&words[num].lenIdx); pPos = (int)tg_ld(&words[num].pos); }
           }
           u32 A = (row & 0xFFu) | ((b1 & 0xFFu) << 8) | ((u32)(wlen & 31) << 16);
           if (st) A |= TG3_ST;
@@ -747,7 +749,7 @@ __global__ __launch_bounds__(192) void k_text_inv3(const u8* __restrict__ srcAll
         for (int kk = 0; kk < 8; kk++) {                                       // (bytes past a word's end go to a spare byte of the lane: no branches)
           if (kk * 4 >= mxAll) break;
 #pragma unroll
-          for (int j = 0; j < 4; j++) obuf[(kk * 4 + j < wl) ? ((ob + kk * 4 + j) & (TG2_RING - 1)) : (TG2_RING + lane)] = (u8)(tw[kk] >> (8 * j));
+          for (int j = 0; j < 4; j++) obuf[(kk * 4 + j < wl) ? ((ob + kk * 4 + j) & (TG2_RING - 1)) : (TG2_RING + 4 * lane)] = (u8)(tw[kk] >> (8 * j));
         }
         done = wEnd;
         while (done - flushed >= 1024) {                                       // (the ring is this wave's alone)

@@ -1515,14 +1515,19 @@ def test_bwt_forward_falls_back_when_the_trie_tables_overflow(ctx, monkeypatch, 
 
 # ---- round 5: the TEXT inverse on the device (kz_text_gpu.hip, opt-in KZ_TEXT_GPU=1) ----
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["1", "2", "3"])
+@pytest.mark.parametrize("form", ["", "1", "2", "3"])
 @pytest.mark.parametrize("chain,ent", [("TEXT", "NONE"), ("TEXT", "FPAQ"), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0"), ("TEXT+UTF+BWT+SRT+ZRLT", "FPAQ")])
 def test_text_inverse_on_the_device(ctx, chain, ent, form, monkeypatch, capfd):
     """Streams written by the oracle (TextCodec2 for NONE / ANS0, TextCodec1 for FPAQ; English, CRLF, XML, escape bytes, a dictionary
     that doubles and wraps, UTF-8, binary and short blocks) are decoded with the TEXT inverse running on the device: same bytes as the
     input (= what the oracle's and the host stage's decoders give), corrupted copies get the oracle's verdict (the device form hands
     whatever it cannot finish to the host stage), and the trace shows that the device did take blocks."""
-    monkeypatch.setenv("KZ_TEXT_GPU", form)                        # 1: rows of 64 coded bytes, three waves in lockstep (TextCodec2 blocks), 2: the serial walk, 3: rows, one wave
+    if form:
+        monkeypatch.setenv("KZ_TEXT_GPU", form)
+    else:
+        monkeypatch.delenv("KZ_TEXT_GPU", raising=False)            # the default: the row form for TextCodec2 streams, the host stage for FPAQ's
+        monkeypatch.setenv("KZ_TEXT_GPU_MIN", "1")                  # (... in batches of 512 blocks or more: any batch here)
+    # 1: rows of 64 coded bytes, three waves in lockstep (TextCodec2 blocks), 2: the serial walk, 3: rows, one wave
     monkeypatch.setenv("KZ_TEXT_GPU_TRACE", "1")
     c = textgen.cases()
     data = (c["english"][:150000] + c["utf8"][:30000] + c["random"][:40000] + c["english_crlf"][:70000] + c["xml"][:60000] + c["english_escapes"][:50000]
