@@ -62,7 +62,7 @@ for _st, _ks in {
     "sbrt_inv": ("k_sbrt_inverse",),
     "srt_fwd": ("k_srt_hist", "k_srt_prep", "k_srt_scatter"), "srt_inv": ("k_srt_inv",),
     "lz_fwd": ("k_lz_fwd",), "lz_inv": ("k_lz_inv",),
-    "text_inv": ("k_text_inv",),                      # the TEXT inverse on the device (all three forms share the kernel id)
+    "text_inv": ("k_text_inv", "k_utf_inv"),          # the TEXT / UTF inverses on the device (their forms and passes share a kernel id each)
     "bwt_inv": ("k_bwti_parse", "k_bwti_hist", "k_bwti_scan", "k_bwti_scatter", "k_bwti_walk1", "k_bwti_resolve", "k_bwti_copy",
                 "k_bwti_literal", "k_bwti_fin", "k_bwti_ord"),
 }.items():

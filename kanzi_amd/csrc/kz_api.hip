@@ -763,6 +763,8 @@ static int text_gpu_form(uint32_t entropyType, int nBlocks) {
   return (entropyType == KZ_E_FPAQ || nBlocks < minBlocks) ? 0 : 1;
 }
 static bool text_gpu_on(uint32_t entropyType, int nBlocks) { return text_gpu_form(entropyType, nBlocks) != 0; }
+// UTF inverse on the device (kz_text_gpu.hip: parallel inside a block, so for any batch); KZ_UTF_GPU=0 keeps it on the host
+static bool utf_gpu_on() { const char* e = getenv("KZ_UTF_GPU"); return !(e && e[0] == '0'); }
 
 static int fuse_min_blocks() {                                      // batches below this take the stages one after the other
   const char* e = getenv("KZ_FUSE_MIN_BLOCKS");                     // (read per call: the tests force both schedules)
@@ -1411,9 +1413,11 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
   const int maxLen = std::min(maxTL, dataCap + 1024);
   ChainSpec CS; CS.nb = nb; CS.entropy = (int)entropyType; for (int i = 0; i < nb; i++) CS.types[i] = types[i];
   const bool textGpu = hp > 0 && !deferHost && types[0] == KZ_T_TEXT && text_gpu_on((uint32_t)entropyType, B);
+  const int iu = (hp > 0 && types[hp - 1] == KZ_T_UTF) ? hp - 1 : -1;      // UTF as the host stage undone first
+  const bool utfGpu = iu >= 0 && !deferHost && utf_gpu_on();
   {
     const size_t perBlock = pipeline_scratch(1, maxLen, true, CS) + (size_t)maxLen * 2 + (size_t)(host ? maxInBytes : 0) + (1 << 16) +
-                            (textGpu ? kz_text_gpu_scratch_per_block(blockSize) : 0);
+                            (textGpu ? kz_text_gpu_scratch_per_block(blockSize) : 0) + (utfGpu ? kz_utf_gpu_scratch_per_block(maxLen) : 0);
     int maxB = (int)std::min<size_t>(KZ_MAX_BATCH, std::max<size_t>(1, kz_arena_budget() / perBlock));   // grid.y carries the block index
     // the serial-per-block inverse stages like whole multiples of 8 blocks per CU (one wave per block, two per SIMD)
     const int unit = 8 * (ctx->numCUs > 0 ? ctx->numCUs : 256);
@@ -1433,7 +1437,8 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
   // (the expensive-blocks-first schedule runs the entropy and ZRLT stages once per group: a second set of their small scratch)
   const int64_t extra = (host ? inS * B : 0) + (int64_t)B * (sizeof(kz_block_result) + 128) + (int64_t)B * 32 + 8192 +
                         (int64_t)kz_zrlt_scratch(B, maxLen) + (int64_t)B * ((int64_t)(maxLen / 16384 + 4) * 8 + 64) + 65536 + (int64_t)B * 64 +
-                        (textGpu ? (int64_t)B * (int64_t)kz_text_gpu_scratch_per_block(blockSize) + (int64_t)B * 16 + (1 << 16) : 0);
+                        (textGpu ? (int64_t)B * (int64_t)kz_text_gpu_scratch_per_block(blockSize) + (int64_t)B * 16 + (1 << 16) : 0) +
+                        (utfGpu ? (int64_t)B * (int64_t)kz_utf_gpu_scratch_per_block(maxLen) + (int64_t)B * 16 + (1 << 16) : 0);
   int rc = pipe_setup(ctx, P, B, maxLen, extra, true, CS);
   if (rc) return rc;
   kz_batch& bt = P.bt;
@@ -1604,12 +1609,22 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
   }
   }
   std::vector<int32_t> h_skipHost(h_skip);                         // the host stages' view: TEXT counts as skipped for the blocks the device took
+  if (utfGpu) {
+    // blocks that went through UTF (the host stage undone first): its inverse on the device
+    std::vector<int32_t> take(B, 0), done;
+    for (int b = 0; b < B; b++) take[b] = (!h_status[b] && bt.h_len[b] > 0 && !(h_skip[b] & (1 << (7 - iu)))) ? 1 : 0;
+    hipEvent_t e0; kz_stage_begin(ctx, &e0);
+    rc = kz_stage_utf_inverse_gpu(ctx, bt, dataCap, take, done);
+    if (rc) return rc;
+    kz_stage_end(ctx, e0, KZ_STAGE_HOST_INV, 0);
+    for (int b = 0; b < B; b++) if (done[b]) h_skipHost[b] |= 1 << (7 - iu);
+  }
   if (textGpu) {
-    // blocks whose only host stage left is TEXT (every other host stage skipped for the block): its inverse on the device
+    // blocks whose only host stage left is TEXT (every other host stage skipped for the block, or done above): its inverse on the device
     std::vector<int32_t> take(B, 0), done;
     for (int b = 0; b < B; b++) {
       bool t = !h_status[b] && bt.h_len[b] > 0 && !(h_skip[b] & 0x80);
-      for (int i = 1; i < hp && t; i++) t = (h_skip[b] & (1 << (7 - i))) != 0;
+      for (int i = 1; i < hp && t; i++) t = (h_skipHost[b] & (1 << (7 - i))) != 0;
       take[b] = t ? 1 : 0;
     }
     hipEvent_t e0; kz_stage_begin(ctx, &e0);

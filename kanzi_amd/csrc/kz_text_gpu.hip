@@ -895,3 +895,209 @@ int kz_stage_text_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, int dstC
   ctx->arenaTop = mark;
   return 0;
 }
+
+// ==== UTF inverse on the device (UTFCodec.java:224-330; host form: kz_text.hip utf_inverse) ==========================================
+// The coded block: start & 3, adjust & 3, the symbol count, 3 bytes per symbol (the code points by rank), `start` raw bytes, then
+// aliases of one byte (rank < 128) or two (0x80 | rank & 0x7F, rank >> 7) up to `body` = n - 4 + adjust, then the tail bytes as they
+// are.  A byte >= 0x80 takes the byte behind it whatever that is, so whether a byte starts an alias is the PARITY of the run of
+// bytes >= 0x80 right in front of it: nothing serial.  Four small kernels: the table of code points (`k_utf_map`), output bytes per
+// tile of 2 048 coded bytes (`k_utf_tiles<false>`), the tile offsets and the block's verdict (`k_utf_scan`), the bytes
+// (`k_utf_tiles<true>`).  A block the reference refuses (a rank past the table, a malformed entry, an alias cut by the end, an
+// output that does not fit) is left alone with outLen = -1: the host stage gives it the reference's verdict.
+#define UG_MAXSYM 32768
+#define UG_TILE 2048
+struct UtfGpu {
+  const int32_t* ord;   // [B] index among the blocks taken, -1 = leave alone
+  int32_t* outLen;      // [B]
+  int32_t* fail;        // [A]
+  u32* map;             // [A][UG_MAXSYM] the UTF-8 bytes of a rank, little endian in a word (the first byte tells how many)
+  int32_t* tileOut;     // [A][maxTiles] output bytes per tile, then their exclusive prefix
+  int maxTiles, dstCap;
+};
+__device__ __forceinline__ int ug_len(u32 le) { const u32 c = le & 0xFFu; return c < 0x80u ? 1 : (c < 0xE0u ? 2 : (c < 0xF0u ? 3 : 4)); }
+__global__ __launch_bounds__(256) void k_utf_map(const u8* __restrict__ srcAll, int64_t stride, const int32_t* __restrict__ d_len, UtfGpu G, int B) {
+  const int b = blockIdx.y;
+  const int a = G.ord[b];
+  if (a < 0) return;
+  const int n = d_len[b];
+  const u8* src = srcAll + (int64_t)b * stride;
+  if (n < 4) { if (blockIdx.x == 0 && threadIdx.x == 0) G.fail[a] = 1; return; }
+  const int start = src[0] & 3, adjust = src[1] & 3;
+  const int nsym = ((int)src[2] << 8) | (int)src[3];
+  const int i0 = 4 + 3 * nsym + start, body = n - 4 + adjust;
+  if (nsym == 0 || nsym >= UG_MAXSYM || 3 * nsym >= n || i0 > n || i0 > body) { if (blockIdx.x == 0 && threadIdx.x == 0) G.fail[a] = 1; return; }
+  for (int r = blockIdx.x * 256 + (int)threadIdx.x; r < nsym; r += gridDim.x * 256) {
+    const u8* q = src + 4 + 3 * r;
+    const u32 key = ((u32)q[0] << 16) | ((u32)q[1] << 8) | (u32)q[2];
+    u32 le = 0; bool ok = true;
+    switch (key >> 19) {                                                       // unpackV1 (:514-548)
+      case 0: le = key; break;
+      case 1: le = ((key & 0xFFu) << 8) | ((key >> 8) & 0xFFu); break;
+      case 2: le = (((key >> 12) & 0x0Fu) | 0xE0u) | ((((key >> 6) & 0x3Fu) | 0x80u) << 8) | (((key & 0x3Fu) | 0x80u) << 16); break;
+      case 4: case 5: case 6: case 7:
+        le = (((key >> 18) & 0x07u) | 0xF0u) | ((((key >> 12) & 0x3Fu) | 0x80u) << 8) | ((((key >> 6) & 0x3Fu) | 0x80u) << 16) | (((key & 0x3Fu) | 0x80u) << 24); break;
+      default: ok = false; break;
+    }
+    // (the count of bytes is read back from the first one: a one-byte entry >= 0x80 or a two-byte entry outside 0xC0-0xDF cannot be told apart later)
+    const int want = (key >> 19) == 0 ? 1 : ((key >> 19) == 1 ? 2 : ((key >> 19) == 2 ? 3 : 4));
+    if (!ok || ug_len(le) != want) G.fail[a] = 1;
+    G.map[(int64_t)a * UG_MAXSYM + r] = le;
+  }
+}
+// one tile: the aliases that start in [i0 + t * UG_TILE, + UG_TILE) below `body`; WRITE = false: count their output bytes
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_utf_tiles(const u8* __restrict__ srcAll, u8* __restrict__ dstAll, int64_t stride, const int32_t* __restrict__ d_len, UtfGpu G, int B) {
+  const int b = blockIdx.y;
+  const int a = G.ord[b];
+  if (a < 0) return;
+  if (__syncthreads_or(G.fail[a])) return;                                     // (one answer for the workgroup: other tiles may be setting it)
+  const int n = d_len[b];
+  const u8* src = srcAll + (int64_t)b * stride;
+  const int start = src[0] & 3, adjust = src[1] & 3;
+  const int nsym = ((int)src[2] << 8) | (int)src[3];
+  const int i0 = 4 + 3 * nsym + start, body = n - 4 + adjust;
+  const int t = blockIdx.x;
+  const int t0 = i0 + t * UG_TILE;
+  if (t0 >= body) return;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const u32* map = G.map + (int64_t)a * UG_MAXSYM;
+  u8* dst = dstAll + (int64_t)b * stride;
+  __shared__ int wsum[4];
+  __shared__ int sBase;
+  int base = WRITE ? start + G.tileOut[(int64_t)a * G.maxTiles + t] : 0;     // output position of the tile's first alias
+  int total = 0;
+  bool bad = false;
+  const uint64_t ltm = kz_lanemask_lt();
+  for (int s0 = t0; s0 < min(t0 + UG_TILE, body); s0 += 256) {
+    const int p = s0 + tid, wbase = s0 + wave * 64;
+    const u32 c = p < n ? (u32)src[p] : 0u;
+    const u32 c1 = p + 1 < n ? (u32)src[p + 1] : 0u;
+    const bool in = p < body;
+    const uint64_t hiM = kz_ballot(in && c >= 0x80u);
+    // bytes >= 0x80 right in front of the wave's first byte (not past i0): their count's parity carries in
+    int carry = 0;
+    for (int k = 0;; k += 64) {
+      const int q = wbase - 1 - k - lane;
+      const uint64_t m = kz_ballot(q >= i0 && (u32)src[q < 0 ? 0 : q] >= 0x80u);
+      const int cnt = ~m ? (int)__builtin_ctzll(~m) : 64;
+      carry += cnt;
+      if (cnt < 64) break;
+    }
+    const uint64_t z = ~hiM & ltm;                                             // bytes < 0x80 below this lane
+    const int run = z ? lane - 1 - (63 - (int)__builtin_clzll(z)) : lane + carry;
+    const bool st = in && (run & 1) == 0;
+    int len = 0; u32 le = 0;
+    if (st) {
+      int alias = (int)c;
+      if (c >= 0x80u) { if (p + 1 >= body) bad = true; alias = (int)(c1 << 7) + (int)(c & 0x7Fu); }   // (p + 1 == body: the alias runs into the tail, refused at :296-297)
+      if (alias >= nsym) bad = true;
+      else { le = map[alias]; len = ug_len(le); }
+    }
+    // exclusive scan of len over the 256 threads
+    const u32 inc = kz_wave_incl_sum((u32)len);
+    if (lane == 63) wsum[wave] = (int)inc;
+    __syncthreads();
+    int before = 0, all = 0;
+    for (int w = 0; w < 4; w++) { const int v = wsum[w]; if (w < wave) before += v; all += v; }
+    if (WRITE && len) {
+      u8* o = dst + base + total + before + (int)inc - len;
+      o[0] = (u8)le;
+      if (len > 1) o[1] = (u8)(le >> 8);
+      if (len > 2) o[2] = (u8)(le >> 16);
+      if (len > 3) o[3] = (u8)(le >> 24);
+    }
+    total += all;
+    __syncthreads();
+  }
+  if (!WRITE) {
+    if (__syncthreads_or(bad ? 1 : 0)) { if (tid == 0) G.fail[a] = 1; }
+    if (tid == 0) G.tileOut[(int64_t)a * G.maxTiles + t] = total;
+  }
+}
+// per block: the tiles' offsets, the verdict, the raw bytes in front of and behind the aliases
+__global__ __launch_bounds__(256) void k_utf_scan(const u8* __restrict__ srcAll, u8* __restrict__ dstAll, int64_t stride, const int32_t* __restrict__ d_len, UtfGpu G, int B) {
+  const int b = blockIdx.x;
+  const int a = G.ord[b];
+  if (a < 0) return;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (G.fail[a]) { if (tid == 0) G.outLen[b] = -1; return; }
+  const int n = d_len[b];
+  const u8* src = srcAll + (int64_t)b * stride;
+  u8* dst = dstAll + (int64_t)b * stride;
+  const int start = src[0] & 3, adjust = src[1] & 3;
+  const int nsym = ((int)src[2] << 8) | (int)src[3];
+  const int i0 = 4 + 3 * nsym + start, body = n - 4 + adjust;
+  const int tiles = (body - i0 + UG_TILE - 1) / UG_TILE;
+  int32_t* to = G.tileOut + (int64_t)a * G.maxTiles;
+  __shared__ int wsum[4];
+  int run = 0;
+  for (int t0 = 0; t0 < tiles; t0 += 256) {
+    const int t = t0 + tid;
+    const int v = t < tiles ? to[t] : 0;
+    const u32 inc = kz_wave_incl_sum((u32)v);
+    if (lane == 63) wsum[wave] = (int)inc;
+    __syncthreads();
+    int before = 0, all = 0;
+    for (int w = 0; w < 4; w++) { const int x = wsum[w]; if (w < wave) before += x; all += x; }
+    if (t < tiles) to[t] = run + before + (int)inc - v;
+    run += all;
+    __syncthreads();
+  }
+  const int at = start + run, tail = n - body;
+  const int end = G.dstCap - 4;
+  if (at >= end - tail) { if (tid == 0) { G.outLen[b] = -1; G.fail[a] = 1; } return; }     // :290-291 (and the loop's own `at < end`)
+  if (tid < start) dst[tid] = src[4 + 3 * nsym + tid];
+  if (tid < tail) dst[at + tid] = src[body + tid];
+  if (tid == 0) G.outLen[b] = at + tail;
+}
+
+size_t kz_utf_gpu_scratch_per_block(int maxLen) { return (size_t)UG_MAXSYM * 4 + (size_t)(maxLen / UG_TILE + 2) * 4 + 256; }
+
+// UTF inverse of the blocks with take[b] != 0, like kz_stage_text_inverse_gpu: finished blocks are left in their slots (lengths
+// updated) with done[b] = 1, every other block is untouched.
+int kz_stage_utf_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int dstCap, const std::vector<int32_t>& take, std::vector<int32_t>& done) {
+  const int B = bt.B;
+  done.assign(B, 0);
+  std::vector<int32_t> ord(B, -1);
+  int A = 0, maxLen = 0;
+  for (int b = 0; b < B; b++) if (take[b] && bt.h_len[b] > 0) { ord[b] = A++; maxLen = std::max(maxLen, bt.h_len[b]); }
+  if (A == 0) return 0;
+  UtfGpu G;
+  G.maxTiles = maxLen / UG_TILE + 2; G.dstCap = dstCap;
+  const size_t mark = ctx->arenaTop;
+  int32_t* dOrd = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  int32_t* dOut = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  int32_t* dCond = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  G.fail = (int32_t*)kz_arena_alloc(ctx, (size_t)A * 4);
+  G.map = (u32*)kz_arena_alloc(ctx, (size_t)A * UG_MAXSYM * 4);
+  G.tileOut = (int32_t*)kz_arena_alloc(ctx, (size_t)A * (size_t)G.maxTiles * 4);
+  if (!dOrd || !dOut || !dCond || !G.fail || !G.map || !G.tileOut) { ctx->arenaTop = mark; return 0; }     // no room: the host stage takes them all
+  G.ord = dOrd; G.outLen = dOut;
+  hipStream_t st = ctx->stream;
+  KZ_HIP(hipMemcpyAsync(dOrd, ord.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemsetAsync(dOut, 0xFF, (size_t)B * 4, st));
+  KZ_HIP(hipMemsetAsync(G.fail, 0, (size_t)A * 4, st));
+  const u8* src = bt.buf[bt.cur]; u8* dst = bt.buf[bt.cur ^ 1];
+  KZ_LAUNCH(ctx, KID_UTF_INV, k_utf_map, dim3(16, B), dim3(256), src, bt.stride, bt.d_len, G, B);
+  KZ_LAUNCH(ctx, KID_UTF_INV, k_utf_tiles<false>, dim3(G.maxTiles, B), dim3(256), src, dst, bt.stride, bt.d_len, G, B);
+  KZ_LAUNCH(ctx, KID_UTF_INV, k_utf_scan, dim3(B), dim3(256), src, dst, bt.stride, bt.d_len, G, B);
+  KZ_LAUNCH(ctx, KID_UTF_INV, k_utf_tiles<true>, dim3(G.maxTiles, B), dim3(256), src, dst, bt.stride, bt.d_len, G, B);
+  std::vector<int32_t> outLen(B);
+  KZ_HIP(hipMemcpyAsync(outLen.data(), dOut, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  KZ_HIP(kz_stream_sync(ctx, st));
+  std::vector<int32_t> cond(B, 0), newLen(bt.h_len);
+  int any = 0, nd = 0;
+  for (int b = 0; b < B; b++) if (ord[b] >= 0 && outLen[b] >= 0) { cond[b] = 1; newLen[b] = outLen[b]; done[b] = 1; any = 1; nd++; }
+  if (getenv("KZ_TEXT_GPU_TRACE")) fprintf(stderr, "[utfgpu] took %d blocks, finished %d\n", A, nd);
+  if (any) {
+    KZ_HIP(hipMemcpyAsync(dCond, cond.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    KZ_HIP(hipMemcpyAsync(dOut, newLen.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_text_copy_back, dim3(64, B), dim3(256), 0, st, bt.buf[bt.cur ^ 1], bt.buf[bt.cur], bt.stride, dOut, dCond);
+    for (int b = 0; b < B; b++) bt.h_len[b] = newLen[b];
+    KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    KZ_HIP(kz_stream_sync(ctx, st));
+  }
+  KZ_HIP(hipGetLastError());
+  ctx->arenaTop = mark;
+  return 0;
+}

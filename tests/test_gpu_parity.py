@@ -1554,3 +1554,41 @@ def test_text_inverse_on_the_device(ctx, chain, ent, form, monkeypatch, capfd):
     fin = [int(l.split()[5]) for l in err.splitlines() if l.startswith("[textgpu]")]
     if form == "2" or ent != "FPAQ":                                # (the row form leaves TextCodec1 blocks to the host)
         assert took and sum(fin) > 0 and sum(fin) >= sum(took) // 2, err[-400:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chain,ent", [("UTF", "NONE"), ("TEXT+UTF", "NONE"), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0"), ("UTF+LZ", "HUFFMAN")])
+def test_utf_inverse_on_the_device(ctx, chain, ent, monkeypatch, capfd):
+    """Streams written by the oracle from UTF-8 text (Cyrillic with and without a BOM, more than 128 distinct code points so that
+    two-byte aliases occur, English and binary blocks that UTF declines, short blocks) are decoded with the UTF inverse running on
+    the device (the parity of the run of bytes >= 0x80 in front of a byte says whether it starts an alias: `k_utf_*`): same bytes as
+    the input, corrupted copies get the oracle's verdict (a block the device form refuses goes to the host stage), and the trace
+    shows that the device took and finished blocks."""
+    monkeypatch.delenv("KZ_UTF_GPU", raising=False)
+    monkeypatch.setenv("KZ_TEXT_GPU_MIN", "1")
+    monkeypatch.setenv("KZ_TEXT_GPU_TRACE", "1")
+    c = textgen.cases()
+    rng = np.random.default_rng(23)
+    cps = [0x400 + i for i in range(200)] + [0x4E00 + 7 * i for i in range(300)] + [0x1F600 + i for i in range(40)] + list(range(0x20, 0x7F))
+    wide = "".join(chr(cps[int(i)]) for i in rng.integers(0, len(cps), 60000)).encode("utf-8")      # 3- and 4-byte code points, > 128 symbols
+    data = (c["utf8"][:200000] + textgen.utf8(150000, 5, bom=True) + wide + c["english"][:60000] + c["random"][:30000] + c["utf8"][:3000] + c["short"])
+    for bs in (65536, 1 << 20):
+        ref = oracle.compress(chain, ent, bs, data, jobs=4)
+        assert kz.CompressedInputStream(ctx, ref).read() == data, (chain, ent, bs)
+        for _ in range(8):                                        # corrupted copies: the verdict of the oracle's decoder
+            bad = bytearray(ref)
+            pos = int(rng.integers(40, len(bad) - 8))
+            bad[pos] ^= 1 << int(rng.integers(0, 8))
+            try:
+                want = oracle.decompress(bytes(bad), len(data) + 4 * bs, jobs=2)
+            except Exception:
+                want = None
+            try:
+                got = kz.CompressedInputStream(ctx, bytes(bad)).read()
+            except Exception:
+                got = None
+            assert (got is None) == (want is None) and (got is None or got == want), (chain, ent, bs, pos)
+    err = capfd.readouterr().err
+    took = [int(l.split()[2]) for l in err.splitlines() if l.startswith("[utfgpu]")]
+    fin = [int(l.split()[5]) for l in err.splitlines() if l.startswith("[utfgpu]")]
+    assert took and sum(fin) > 0 and sum(fin) >= sum(took) // 2, err[-400:]

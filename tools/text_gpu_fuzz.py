@@ -1,4 +1,4 @@
-"""The device forms of the TEXT inverse against the oracle's decoder on damaged streams (needs a GPU).  Streams of the chain TEXT (and
+"""The device forms of the TEXT inverse (and the device UTF inverse) against the oracle's decoder on damaged streams (needs a GPU).  Streams of the chain TEXT (and
 TEXT+UTF) with entropy NONE carry the TEXT-coded bytes as they are, so flipped bits land in tokens, numbers and escapes; every copy
 is decoded with KZ_TEXT_GPU = 1 / 2 / 3 (and the host stage, 0) and must give the oracle's verdict and bytes.
    python tools/text_gpu_fuzz.py [seconds] [seed]"""
@@ -17,20 +17,20 @@ print("seed", seed, flush=True)
 ctx = kz.Context(0)
 t0 = time.time(); cases = bad = refused = 0
 while time.time() - t0 < budget:
-    chain = "TEXT" if rng.random() < 0.7 else "TEXT+UTF"
+    chain = ["TEXT", "TEXT+UTF", "UTF"][int(rng.choice(3, p=[0.5, 0.25, 0.25]))]
     ent = "NONE" if rng.random() < 0.8 else "FPAQ"
     bs = int(rng.choice([32768, 65536, 1 << 18, 1 << 20]))
     parts = []
     for _ in range(int(rng.integers(1, 5))):
         n = int(rng.integers(2000, 3 * bs))
-        k = int(rng.integers(0, 7)); s = int(rng.integers(0, 1 << 30))
+        k = int(rng.integers(0, 7)) if chain != "UTF" else int(rng.choice([0, 6, 6, 6])); s = int(rng.integers(0, 1 << 30))
         if k == 0: parts.append(textgen.english(n, s))
         elif k == 1: parts.append(textgen.english(n, s, crlf=True))
         elif k == 2: parts.append(textgen.xml(n, s))
         elif k == 3: parts.append(textgen.many_words(n, s, alphabet=int(rng.integers(4, 26))))
         elif k == 4: parts.append(textgen.english(n, s, sprinkle=bytes([0x0F, 0x0E, 0x80, 0xFF])))
         elif k == 5: parts.append(textgen.english(n, s, invented=int(rng.integers(10, 20000))))
-        else: parts.append(textgen.utf8(n, s))
+        else: parts.append(textgen.utf8(n, s, bom=bool(s & 1)))
     data = b"".join(bytes(p) for p in parts)
     ref = oracle.compress(chain, ent, bs, data, jobs=4)
     copies = [ref]
