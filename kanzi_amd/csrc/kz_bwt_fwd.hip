@@ -54,7 +54,11 @@ struct BwtArrays {
   int64_t NS;        // element stride per block
   int T;             // tile stride per block
   int64_t HS;        // tileHist stride per block: radix tiles x MSD_BINS
+  const int32_t* act; // later rounds: the blocks that still have live suffixes, one grid row each (nullptr: row = block)
 };
+// A block whose suffixes are all final takes no part in the later rounds: their grids have one row per block that is still live
+// (a mixed batch used to carry the uniform / geometric blocks' empty workgroups through every round).
+__device__ __forceinline__ int bw_row_block(const BwtArrays& A, unsigned row) { return A.act ? A.act[row] : (int)row; }
 
 // ---------------------------------------------------------------------------------------------
 // round 0 keys: the first 7 bytes, zero padded at the end of the text.  A truncated suffix can therefore share a
@@ -81,7 +85,7 @@ __global__ void k_bwt_init(BwtArrays A, int B) {
 #define MSD_BINS 1024
 template <int BINS, bool MSD, bool TEXT>
 __device__ __forceinline__ void radix_hist_body(const u64* __restrict__ keyIn, const BwtArrays& A, int shift, TextSrc X) {
-  const int b = blockIdx.y;
+  const int b = bw_row_block(A, blockIdx.y);
   const int w0 = MSD ? 0 : A.d_w[b];
   const int m = A.d_m[b] - w0;
   const int tile = blockIdx.x;
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(KZ_WG) void k_msd_hist(const u64* __restrict__ keyI
 // radix pass 2/3: per block, thread d walks the tiles (coalesced across d) -> exclusive tile
 // offsets per digit, then an exclusive scan over digit totals.
 __global__ __launch_bounds__(256) void k_radix_scan(BwtArrays A) {
-  const int b = blockIdx.x;
+  const int b = bw_row_block(A, blockIdx.x);
   const int m = A.d_m[b] - A.d_w[b];
   const int tiles = (m + RSORT_TILE - 1) / RSORT_TILE;
   __shared__ u32 lds[32];
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void k_radix_scan(BwtArrays A) {
 #define BK_CAP 6144            // 4096 slots + an overhang of 2048: 48 KiB of LDS, two workgroups per CU
 #define BK_BIG 0x80000000u
 __global__ __launch_bounds__(MSD_BINS) void k_msd_scan(BwtArrays A) {
-  const int b = blockIdx.x;
+  const int b = bw_row_block(A, blockIdx.x);
   const int m = A.d_m[b];
   const int tiles = (m + RSORT_TILE - 1) / RSORT_TILE;
   __shared__ u32 lds[32];
@@ -184,7 +188,7 @@ template <int BINS, int NBITS, bool MSD, typename CNT, bool TEXT>
 __device__ __forceinline__ void radix_scatter_body(const u64* __restrict__ keyIn, const u32* __restrict__ valIn,
                                                    u64* __restrict__ keyOut, u32* __restrict__ valOut,
                                                    const BwtArrays& A, int shift, TextSrc X) {
-  const int b = blockIdx.y;
+  const int b = bw_row_block(A, blockIdx.y);
   const int w0 = MSD ? 0 : A.d_w[b];
   const int m = A.d_m[b] - w0;
   const int tile = blockIdx.x;
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(RSC_WG) void k_radix_scatter0(u64* __restrict__ key
 __global__ __launch_bounds__(RSC_WG) void k_msd_scatter(const u64* __restrict__ keyIn, const u32* __restrict__ valIn,
                                                          u64* __restrict__ keyOut, u32* __restrict__ valOut,
                                                          BwtArrays A, int shift) {
-  const int b = blockIdx.y;
+  const int b = bw_row_block(A, blockIdx.y);
   const int m = A.d_m[b];
   const int tile = blockIdx.x;
   if ((int64_t)tile * RSORT_TILE >= m) return;
@@ -396,7 +400,7 @@ __device__ __forceinline__ void bw_row_flags(const u64* __restrict__ key, int ba
 
 // per tile: (last index+1 where the old group changes, last index+1 where the key changes)
 __global__ __launch_bounds__(KZ_WG) void k_seg_reduce(const u64* __restrict__ keyS, BwtArrays A, int gshift) {
-  const int b = blockIdx.y;
+  const int b = bw_row_block(A, blockIdx.y);
   const int w0 = A.d_w[b];
   const int m = A.d_m[b] - w0;
   const int tile = blockIdx.x;
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(KZ_WG) void k_seg_reduce(const u64* __restrict__ ke
 }
 // per block: exclusive max-scans over the tiles -- one wave per block
 __global__ void k_seg_scan(BwtArrays A) {
-  const int b = blockIdx.x;
+  const int b = bw_row_block(A, blockIdx.x);
   const int m = A.d_m[b] - A.d_w[b];
   const int tiles = (m + RS_TILE - 1) / RS_TILE;
   u32* ta = A.tileA + (int64_t)b * A.T;
@@ -443,7 +447,7 @@ __global__ void k_seg_scan(BwtArrays A) {
 // apply: slot = g + (c - segment start); new rank = g + (new-group start - segment start); LIVE unless the new
 // group is a singleton, in which case the suffix is final
 __global__ __launch_bounds__(KZ_WG) void k_seg_apply(const u64* __restrict__ keyS, const u32* __restrict__ valS, BwtArrays A, int gshift) {
-  const int b = blockIdx.y;
+  const int b = bw_row_block(A, blockIdx.y);
   const int w0 = A.d_w[b];
   const int m = A.d_m[b] - w0;
   const int tile = blockIdx.x;
@@ -512,7 +516,7 @@ static_assert(RSC_WG == MSD_BINS, "k_msd_scatter geometry");
 
 template <int WAVES, int ROWS>
 __device__ __forceinline__ void bucket_body(const u64* __restrict__ keyS, const u32* __restrict__ valS, const BwtArrays& A, int bitsR, int bitsG) {
-  const int b = blockIdx.y;
+  const int b = bw_row_block(A, blockIdx.y);
   const u32 d = blockIdx.x;
   const u32 bc0 = A.bucketCnt[b * MSD_BINS + d];
   if ((bc0 & (BK_SORT | BK_BIG)) != BK_SORT) return;          // only the buckets k_bucket_count left behind
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(1024, 8) void k_bucket_sort(const u64* __restrict__
 #define BK_SLOTS (1 << BK_BITS)
 template <int WAVES, int ROWS, int LO, int HI, typename CNT>
 __device__ __forceinline__ void bucket_count_body(const u64* __restrict__ keyS, const u32* __restrict__ valS, const BwtArrays& A, int bitsR, int bitsG, u32 gmax) {
-  const int b = blockIdx.y;
+  const int b = bw_row_block(A, blockIdx.y);
   const u32 d = blockIdx.x;
   const u32 bc = A.bucketCnt[b * MSD_BINS + d];
   if (bc <= (u32)LO || bc > (u32)HI) return;
@@ -810,7 +814,7 @@ __global__ __launch_bounds__(1024) void k_bucket_count(const u64* __restrict__ k
 // every rank (k_live_count / k_live_scan until round 4: 36 ms and 122 GB of rank reads per 8 GiB).  Inside a tile the order stays
 // the text order.  tileLive[tile] = live suffixes of the tile after the previous round (0 stays 0: suffixes only become final).
 __global__ __launch_bounds__(KZ_WG) void k_live_emit(u64* __restrict__ keyN, u32* __restrict__ valN, BwtArrays A, int h, int bitsR, int first) {
-  const int b = blockIdx.y;
+  const int b = bw_row_block(A, blockIdx.y);
   const int n = A.d_n[b];
   const int tile = blockIdx.x;
   if ((int64_t)tile * RS_TILE >= n) return;
@@ -953,7 +957,7 @@ __global__ __launch_bounds__(1024) void k_tr_hist16(const u8* __restrict__ srcAl
 
 // classify the children of the nodes of depth L (thread = node, its 256 children in order)
 __global__ __launch_bounds__(256) void k_tr_assign(BwtArrays A, TrieArrays T, int L, int Dmax, int keys) {
-  const int b = blockIdx.x;
+  const int b = bw_row_block(A, blockIdx.x);
   int32_t* meta = T.meta + (int64_t)b * TR_META;
   __shared__ u32 sNodes, sBuckets, sErr;
   __shared__ u32 scan[32];
@@ -1279,7 +1283,7 @@ __global__ __launch_bounds__(1024) void k_tr_scatter_f(const u8* __restrict__ sr
 #define TRQ_ROWS 8
 template <bool KEYS>
 __device__ __forceinline__ void tr_sort_body(const u64* __restrict__ elemAll, const BwtArrays& A, const TrieArrays& T, int bitsG) {
-  const int b = blockIdx.y;
+  const int b = bw_row_block(A, blockIdx.y);
   const int nB = T.meta[(int64_t)b * TR_META + 1];
   __shared__ u64 buf[TR_CAP];
   __shared__ uint16_t cw[TRQ_WAVES][BK_DBINS];
@@ -1477,7 +1481,7 @@ struct KeySrc { const u64* key; const u32* val; int bitsR; };
 __device__ __forceinline__ u64 trk_k48(u64 key, int bitsR) { return ((key >> bitsR) << 24) | (key & ((1ULL << bitsR) - 1ULL)); }
 
 __global__ __launch_bounds__(1024) void k_trk_hist16(KeySrc X, BwtArrays A, TrieArrays T) {
-  const int b = blockIdx.y;
+  const int b = bw_row_block(A, blockIdx.y);
   const int w0 = A.d_w[b];
   const int W = max(0, A.d_m[b] - w0);                                  // an empty window still writes its (zero) counts: k_tr_assign reads them
   const u32 half = blockIdx.x;
@@ -1508,7 +1512,7 @@ __global__ __launch_bounds__(1024) void k_trk_hist16(KeySrc X, BwtArrays A, Trie
 }
 
 __global__ __launch_bounds__(1024) void k_trk_count(KeySrc X, u32* __restrict__ stateAll, BwtArrays A, TrieArrays T, int L) {
-  const int b = blockIdx.y;
+  const int b = bw_row_block(A, blockIdx.y);
   const int32_t* meta = T.meta + (int64_t)b * TR_META;
   const int lo = meta[2 + L], hi = meta[10 + L];
   if (hi <= lo) return;
@@ -1598,8 +1602,8 @@ __global__ __launch_bounds__(1024) void k_trk_count(KeySrc X, u32* __restrict__ 
 template <int TILE_, int MAXB_, bool FAST>
 __device__ __forceinline__ void trk_scatter_body(const KeySrc& X, const u32* __restrict__ stateAll, u64* __restrict__ elemAll, const BwtArrays& A, const TrieArrays& T, int bitsG) {
   constexpr int ITEMS_ = TILE_ / 1024;
-  if ((T.meta[(int64_t)blockIdx.y * TR_META + 1] <= TRS_FASTB) != FAST) return;
-  const int b = blockIdx.y;
+  const int b = bw_row_block(A, blockIdx.y);
+  if ((T.meta[(int64_t)b * TR_META + 1] <= TRS_FASTB) != FAST) return;
   const int w0 = A.d_w[b];
   const int W = A.d_m[b] - w0;
   const int tbase = blockIdx.x * TILE_;
@@ -1806,7 +1810,9 @@ static int bwt_forward_run(kz_ctx* ctx, kz_batch& bt, bool allowTrie, bool* trie
   A.tileLive = (u32*)kz_arena_alloc(ctx, (size_t)T * B * 4);
   A.d_m = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   A.d_m2 = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
-  if (!A.d_m2 || !A.tileB || !A.tileLive || !A.sa || !A.d_big || !A.bucketCnt) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: arena overflow"); return -KZ_ERR_DEVICE; }
+  int32_t* d_act = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  A.act = nullptr;
+  if (!d_act || !A.d_m2 || !A.tileB || !A.tileLive || !A.sa || !A.d_big || !A.bucketCnt) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: arena overflow"); return -KZ_ERR_DEVICE; }
   bool useTrie = allowTrie && tr_applies(maxN);
   TrieArrays TR;
   memset(&TR, 0, sizeof(TR));
@@ -1863,12 +1869,16 @@ static int bwt_forward_run(kz_ctx* ctx, kz_batch& bt, bool allowTrie, bool* trie
   const char* ed = getenv("KZ_BWT_DMAX");
   const int Dmax = (ed && ed[0] >= '6' && ed[0] <= '0' + TR_DMAX_LIMIT) ? ed[0] - '0' : 6;
   const char* ep = getenv("KZ_TR_PARTS");
+  const char* ert = getenv("KZ_BWT_RETIRE");
+  const bool noRetire = ert && ert[0] == '0';                        // A/B switch: every block rides through every round, as before
   const char* etw = getenv("KZ_BWT_TRIEWIN");
   const bool trieWinOff = etw && etw[0] == '0';
   const bool trace = getenv("KZ_BWT_TRACE") != nullptr;
   const char* eo = getenv("KZ_BWT_TEST_TRIE_OVERFLOW");              // tests: pretend the tables overflowed in round <digit>
   const int forceOvfRound = (eo && eo[0] >= '0' && eo[0] <= '9') ? eo[0] - '0' : -1;
   if (useTrie) KZ_HIP(hipMemsetAsync(TR.err, 0, 4, st));
+  int nAct = B;                                                      // grid rows of the later rounds: blocks with live suffixes (A.act)
+  int32_t* const h_act = ctx->hpin + B + 16;                         // their indices, host side (pipe_setup reserves 9 B + 64 ints)
   for (int round = 0; round < 64 && mMax > 0; round++) {
     // ---- sort (kC,vC) and apply.  Later rounds of blocks up to 4 MiB: bucket partition + one LDS sort per bucket, the
     //      LSD passes only for the window of oversized buckets; otherwise LSD radix over the whole compact list ----
@@ -1897,20 +1907,20 @@ static int bwt_forward_run(kz_ctx* ctx, kz_batch& bt, bool allowTrie, bool* trie
     if (buckets) {
       const int rt = gridFor(mMax, RSORT_TILE);
       const int sh = bitsR + BK_BITS;
-      KZ_LAUNCH(ctx, KID_MSD_HIST, k_msd_hist, dim3(rt, B), dim3(KZ_WG), kC, A, sh);
-      KZ_LAUNCH(ctx, KID_MSD_SCAN, k_msd_scan, dim3(B), dim3(MSD_BINS), A);
+      KZ_LAUNCH(ctx, KID_MSD_HIST, k_msd_hist, dim3(rt, nAct), dim3(KZ_WG), kC, A, sh);
+      KZ_LAUNCH(ctx, KID_MSD_SCAN, k_msd_scan, dim3(nAct), dim3(MSD_BINS), A);
       KZ_HIP(hipMemcpyAsync(ctx->hpin, A.d_big, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-      KZ_LAUNCH(ctx, KID_MSD_SCATTER, k_msd_scatter, dim3(rt, B), dim3(RSC_WG), kC, vC, kF, vF, A, sh);
+      KZ_LAUNCH(ctx, KID_MSD_SCATTER, k_msd_scatter, dim3(rt, nAct), dim3(RSC_WG), kC, vC, kF, vF, A, sh);
       { u64* tk = kC; kC = kF; kF = tk; u32* tv = vC; vC = vF; vF = tv; }
-      KZ_LAUNCH(ctx, KID_BUCKET_COUNT_S, k_bucket_count_s, dim3(nBuckets, B), dim3(256), kC, vC, A, bitsR, bitsG, gmax);
-      KZ_LAUNCH(ctx, KID_BUCKET_COUNT, k_bucket_count, dim3(nBuckets, B), dim3(1024), kC, vC, A, bitsR, bitsG, gmax);
-      KZ_LAUNCH(ctx, KID_BUCKET_SORT, k_bucket_sort, dim3(nBuckets, B), dim3(1024), kC, vC, A, bitsR, bitsG);
+      KZ_LAUNCH(ctx, KID_BUCKET_COUNT_S, k_bucket_count_s, dim3(nBuckets, nAct), dim3(256), kC, vC, A, bitsR, bitsG, gmax);
+      KZ_LAUNCH(ctx, KID_BUCKET_COUNT, k_bucket_count, dim3(nBuckets, nAct), dim3(1024), kC, vC, A, bitsR, bitsG, gmax);
+      KZ_LAUNCH(ctx, KID_BUCKET_SORT, k_bucket_sort, dim3(nBuckets, nAct), dim3(1024), kC, vC, A, bitsR, bitsG);
       KZ_HIP(kz_stream_sync(ctx, st));
-      wMax = 0;
-      for (int b = 0; b < B; b++) if (ctx->hpin[b] > wMax) wMax = ctx->hpin[b];
+      wMax = 0;                                                      // (a retired block's d_big is stale: only the live rows count)
+      for (int r = 0; r < nAct; r++) { const int b = A.act ? h_act[r] : r; if (ctx->hpin[b] > wMax) wMax = ctx->hpin[b]; }
       windowed = true;
       if (trace) {
-        long long tot = 0; for (int b = 0; b < B; b++) tot += ctx->hpin[b];
+        long long tot = 0; for (int r = 0; r < nAct; r++) tot += ctx->hpin[A.act ? h_act[r] : r];
         fprintf(stderr, "[bwt] round %d: %lld suffixes in oversized buckets, max per block %d\n", round, tot, wMax);
       }
     } else if (windowed) {
@@ -1923,43 +1933,43 @@ static int bwt_forward_run(kz_ctx* ctx, kz_batch& bt, bool allowTrie, bool* trie
       const KeySrc XK = {kC, vC, bitsR};
       KZ_HIP(hipMemsetAsync(TR.bFill, 0, (size_t)B * TR.MB * 4, st));
       KZ_HIP(hipMemsetAsync(TR.meta, 0, (size_t)B * TR_META * 4, st));
-      KZ_LAUNCH(ctx, KID_TR_HIST16, k_trk_hist16, dim3(2, B), dim3(1024), XK, A, TR);
-      KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, 1, 6, 1);
-      const int PW = B >= 1024 ? 1 : (B >= 256 ? 2 : 4);
+      KZ_LAUNCH(ctx, KID_TR_HIST16, k_trk_hist16, dim3(2, nAct), dim3(1024), XK, A, TR);
+      KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(nAct), dim3(256), A, TR, 1, 6, 1);
+      const int PW = nAct >= 1024 ? 1 : (nAct >= 256 ? 2 : 4);
       for (int L = 2; L < 6; L++) {
-        KZ_LAUNCH(ctx, KID_TR_COUNT, k_trk_count, dim3(PW, B), dim3(1024), XK, vF, A, TR, L);
-        KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, L, 6, 1);
+        KZ_LAUNCH(ctx, KID_TR_COUNT, k_trk_count, dim3(PW, nAct), dim3(1024), XK, vF, A, TR, L);
+        KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(nAct), dim3(256), A, TR, L, 6, 1);
       }
-      KZ_LAUNCH(ctx, KID_TR_SCATTER, k_trk_scatter_f, dim3(gridFor(wMax, TRS_TILE / 2), B), dim3(1024), XK, vF, kF, A, TR, bitsG);
-      KZ_LAUNCH(ctx, KID_TR_SCATTER, k_trk_scatter, dim3(gridFor(wMax, TRS_TILE), B), dim3(1024), XK, vF, kF, A, TR, bitsG);
-      const int G = std::max(16, std::min(1024, 8192 / B));
-      KZ_LAUNCH(ctx, KID_TR_SORT, k_trk_sort, dim3(G, B), dim3(1024), kF, A, TR, bitsG);
+      KZ_LAUNCH(ctx, KID_TR_SCATTER, k_trk_scatter_f, dim3(gridFor(wMax, TRS_TILE / 2), nAct), dim3(1024), XK, vF, kF, A, TR, bitsG);
+      KZ_LAUNCH(ctx, KID_TR_SCATTER, k_trk_scatter, dim3(gridFor(wMax, TRS_TILE), nAct), dim3(1024), XK, vF, kF, A, TR, bitsG);
+      const int G = std::max(16, std::min(1024, 8192 / nAct));
+      KZ_LAUNCH(ctx, KID_TR_SORT, k_trk_sort, dim3(G, nAct), dim3(1024), kF, A, TR, bitsG);
     } else
     if (wMax > 0) {
       const int tiles = gridFor(wMax, RS_TILE);
       const int rtiles = gridFor(wMax, RSORT_TILE);
       for (int p = 0; p < passes; p++) {
         if (round == 0 && p == 0) {                                  // keys straight from the text
-          KZ_LAUNCH(ctx, KID_RADIX_HIST, k_radix_hist0, dim3(rtiles, B), dim3(KZ_WG), A, X0);
-          KZ_LAUNCH(ctx, KID_RADIX_SCAN, k_radix_scan, dim3(B), dim3(256), A);
-          KZ_LAUNCH(ctx, KID_RADIX_SCATTER, k_radix_scatter0, dim3(rtiles, B), dim3(RSC_WG), kF, vF, A, X0);
+          KZ_LAUNCH(ctx, KID_RADIX_HIST, k_radix_hist0, dim3(rtiles, nAct), dim3(KZ_WG), A, X0);
+          KZ_LAUNCH(ctx, KID_RADIX_SCAN, k_radix_scan, dim3(nAct), dim3(256), A);
+          KZ_LAUNCH(ctx, KID_RADIX_SCATTER, k_radix_scatter0, dim3(rtiles, nAct), dim3(RSC_WG), kF, vF, A, X0);
         } else {
-        KZ_LAUNCH(ctx, KID_RADIX_HIST, k_radix_hist, dim3(rtiles, B), dim3(KZ_WG), kC, A, p * 8);
-        KZ_LAUNCH(ctx, KID_RADIX_SCAN, k_radix_scan, dim3(B), dim3(256), A);
-        KZ_LAUNCH(ctx, KID_RADIX_SCATTER, k_radix_scatter, dim3(rtiles, B), dim3(RSC_WG), kC, vC, kF, vF, A, p * 8);
+        KZ_LAUNCH(ctx, KID_RADIX_HIST, k_radix_hist, dim3(rtiles, nAct), dim3(KZ_WG), kC, A, p * 8);
+        KZ_LAUNCH(ctx, KID_RADIX_SCAN, k_radix_scan, dim3(nAct), dim3(256), A);
+        KZ_LAUNCH(ctx, KID_RADIX_SCATTER, k_radix_scatter, dim3(rtiles, nAct), dim3(RSC_WG), kC, vC, kF, vF, A, p * 8);
         }
         u64* tk = kC; kC = kF; kF = tk;
         u32* tv = vC; vC = vF; vF = tv;
       }
       // ---- SA order: new groups, ranks, final suffixes ----
-      KZ_LAUNCH(ctx, KID_SEG_REDUCE, k_seg_reduce, dim3(tiles, B), dim3(KZ_WG), kC, A, gshift);
-      KZ_LAUNCH(ctx, KID_SEG_SCAN, k_seg_scan, dim3(B), dim3(64), A);
-      KZ_LAUNCH(ctx, KID_SEG_APPLY, k_seg_apply, dim3(tiles, B), dim3(KZ_WG), kC, vC, A, gshift);
+      KZ_LAUNCH(ctx, KID_SEG_REDUCE, k_seg_reduce, dim3(tiles, nAct), dim3(KZ_WG), kC, A, gshift);
+      KZ_LAUNCH(ctx, KID_SEG_SCAN, k_seg_scan, dim3(nAct), dim3(64), A);
+      KZ_LAUNCH(ctx, KID_SEG_APPLY, k_seg_apply, dim3(tiles, nAct), dim3(KZ_WG), kC, vC, A, gshift);
     }
     // ---- text order: compact the live suffixes, keys for the next round ----
     h = (round == 0) ? (useTrie ? 6 : K0) : h * 2;
     KZ_HIP(hipMemsetAsync(A.d_m2, 0, (size_t)B * 4, st));
-    KZ_LAUNCH(ctx, KID_LIVE_EMIT, k_live_emit, dim3(tilesN, B), dim3(KZ_WG), kF, vF, A, h, bitsR, round == 0 ? 1 : 0);
+    KZ_LAUNCH(ctx, KID_LIVE_EMIT, k_live_emit, dim3(tilesN, nAct), dim3(KZ_WG), kF, vF, A, h, bitsR, round == 0 ? 1 : 0);
     { u64* tk = kC; kC = kF; kF = tk; u32* tv = vC; vC = vF; vF = tv; }
     // ---- read back the next compact sizes ----
     KZ_HIP(hipMemcpyAsync(ctx->hpin, A.d_m2, (size_t)B * 4, hipMemcpyDeviceToHost, st));
@@ -1976,6 +1986,16 @@ static int bwt_forward_run(kz_ctx* ctx, kz_batch& bt, bool allowTrie, bool* trie
       fprintf(stderr, "[bwt] round %d h=%d: live %lld of %lld (%.1f%%), max per block %d\n", round, h, tot, totN, 100.0 * tot / (totN ? totN : 1), mMax);
     }
     int32_t* tm = A.d_m; A.d_m = A.d_m2; A.d_m2 = tm;
+    // ---- retire the blocks that are done: the next round's grids get one row per block that still has live suffixes ----
+    if (mMax > 0 && !noRetire) {
+      int cnt = 0;
+      for (int b = 0; b < B; b++) if (ctx->hpin[b] > 0) h_act[cnt++] = b;     // (hpin[0 .. B) is read before the next copy lands: in-order stream)
+      if (cnt < B) {
+        KZ_HIP(hipMemcpyAsync(d_act, h_act, (size_t)cnt * 4, hipMemcpyHostToDevice, st));
+        A.act = d_act;
+        nAct = cnt;
+      }
+    }
   }
   if (mMax > 0) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: suffix sort did not converge"); return -KZ_ERR_PROCESS_BLOCK; }
   {

@@ -1449,11 +1449,11 @@ def _trie_inputs():
     return ins
 
 
-@pytest.mark.parametrize("switch", ["default", "KZ_BWT_DMAX=7", "KZ_BWT_TRIEWIN=0", "KZ_BWT_TRIE=0"])
+@pytest.mark.parametrize("switch", ["default", "KZ_BWT_DMAX=7", "KZ_BWT_TRIEWIN=0", "KZ_BWT_TRIE=0", "KZ_BWT_RETIRE=0"])
 def test_bwt_forward_trie_rounds_match_oracle(ctx, monkeypatch, switch):
     """Round 0 as a trie round (count by byte, move once, finish buckets in LDS) and the key trie round over the window of oversized
     buckets in the doubling rounds, against the oracle's induced-sorting BWT (the BWT is unique): default depth 6, depth 7, the
-    LSD window instead of the key round, and the whole old path."""
+    LSD window instead of the key round, the whole old path, and the later rounds without retiring finished blocks."""
     if switch != "default":
         k, v = switch.split("=")
         monkeypatch.setenv(k, v)
@@ -1461,9 +1461,13 @@ def test_bwt_forward_trie_rounds_match_oracle(ctx, monkeypatch, switch):
         ok_o, enc_o = oracle.transform_forward("BWT", d)
         ok_g, enc_g = _fwd(ctx, kz.BWT_TYPE, d)
         assert ok_g == ok_o and enc_g == enc_o, (switch, len(d))
-    if switch == "default":
-        # one ragged batch: blocks of 64 KiB .. 4 MiB and two short ones in the same call (the tables follow the longest block)
-        blocks = [datagen.block(c, 4 << 20, c).tobytes() for c in (0, 4)] + [_trie_inputs()[k] for k in (3, 15, 21)] + [b"short block", b""]
+    if switch in ("default", "KZ_BWT_RETIRE=0"):
+        # one ragged batch: blocks of 64 KiB .. 4 MiB and two short ones in the same call (the tables follow the longest block); the
+        # uniform and geometric blocks are done after round 0 / 1 and leave the later rounds' grids (rows = blocks still live: the
+        # list has holes), the text-like and sparse ones stay to the end; KZ_BWT_RETIRE=0 = every block in every round, as before
+        blocks = ([datagen.block(3, 1 << 20, 3).tobytes(), datagen.block(0, 4 << 20, 0).tobytes(), datagen.block(1, 4 << 20, 1).tobytes(),
+                   datagen.block(3, 4 << 20, 3).tobytes(), datagen.block(4, 4 << 20, 4).tobytes()]
+                  + [_trie_inputs()[k] for k in (3, 15, 21)] + [b"short block", b"", datagen.block(8, 300000, 3).tobytes(), datagen.block(2, 1 << 21, 2).tobytes()])
         bs = 4 << 20
         B = len(blocks)
         inp = np.zeros((B, bs), dtype=np.uint8)
