@@ -62,6 +62,7 @@ for _st, _ks in {
     "sbrt_inv": ("k_sbrt_inverse",),
     "srt_fwd": ("k_srt_hist", "k_srt_prep", "k_srt_scatter"), "srt_inv": ("k_srt_inv",),
     "lz_fwd": ("k_lz_fwd",), "lz_inv": ("k_lz_inv",),
+    "text_fwd": ("k_text_fwd", "k_text_walk"),        # the TEXT forward on the device (statistics / emit passes, the dictionary walk)
     "text_inv": ("k_text_inv", "k_utf_inv"),          # the TEXT / UTF inverses on the device (their forms and passes share a kernel id each)
     "bwt_inv": ("k_bwti_parse", "k_bwti_hist", "k_bwti_scan", "k_bwti_scatter", "k_bwti_walk1", "k_bwti_resolve", "k_bwti_copy",
                 "k_bwti_literal", "k_bwti_fin", "k_bwti_ord"),
@@ -200,7 +201,7 @@ def compact(out):
         if key == "silesia_by_class":
             cc["shapes"][key] = {n: _r(v["enc_dec_MBps"]) for n, v in sh.items()}
             continue
-        row = {k: _r(v) for k, v in sh.items() if k in ("blocks", "bytes", "scaling", "chain", "file", "knz_bytes", "knz_bytes_reference", "vs_reference_published")}
+        row = {k: _r(v) for k, v in sh.items() if k in ("blocks", "bytes", "scaling", "chain", "file", "knz_bytes", "knz_bytes_reference", "vs_reference_published", "steps", "ms_per_step")}
         for a, b in (("encode_MBps", "enc"), ("decode_MBps", "dec"), ("compress_MBps", "enc"), ("decompress_MBps", "dec"), ("enc_dec_MBps", "enc_dec")):
             if a in sh:
                 row[b] = _r(sh[a])
@@ -312,6 +313,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shapes", action="store_true", help="skip the silesia / enwik9 shaped batches and the host-buffer rates")
     ap.add_argument("--no-chains", action="store_true", help="skip config.chains (the other BASELINE configs)")
+    ap.add_argument("--no-two-streams", action="store_true", help="skip shapes.bulk_two_streams (a second context: encode of step k+1 under the decode of step k)")
     ap.add_argument("--chain-steps", type=int, default=2, help="timed steps of each config.chains row")
     ap.add_argument("--bulk-host-blocks", type=int, default=2048, help="blocks of the PCIe-inclusive bulk stream (0 = skip)")
     ap.add_argument("--data-class", type=int, default=-1, help="diagnostic: force one class of the synthetic generator (0..4) instead of the mix")
@@ -509,6 +511,81 @@ def main():
     value = head["enc_dec_MBps"]
     nk = int(os.environ.get("KZ_BENCH_KERNELS", "12"))
 
+    # ================= two independent streams on one GPU: encode of batch k+1 under the decode of batch k =================
+    def two_streams(src, nb, steps):
+        """The decoder is one serial RANK chain per block (two waves per SIMD) and leaves most of the GPU's issue slots idle, the encoder
+        is throughput-bound: a second context encodes step k+1 while the first decodes step k (two host threads, two contexts, two
+        encoded buffers).  Every step is still one encode and one decode of the whole batch; the row is the rate of `steps` such steps.
+        NOT the headline (whose steps run one after the other): what a service that compresses one stream while it expands another gets."""
+        import threading
+        ctx2 = kz.Context(local_rank)
+        ctx2.set_block_size(bs)
+        bt = Batch(src, nb, args.chain, args.entropy)
+        encs = [bt.d_enc, torch.zeros_like(bt.d_enc)]
+        errs = []
+
+        def enc(k):
+            res = kz.encode_blocks(ctx2, bt.chain, bt.entropy, bt.d_in.data_ptr(), bs, bt.lengths, encs[k & 1].data_ptr(), o_stride, kz.MEM_DEVICE)
+            if any(r.status for r in res):
+                raise RuntimeError("encode status")
+            return np.array([r.bits for r in res], dtype=np.int64)
+
+        def dec(k, bits):
+            res = kz.decode_blocks(ctx, bt.chain, bt.entropy, bs, encs[k & 1].data_ptr(), o_stride, bits, bt.d_dec.data_ptr(), bs, kz.MEM_DEVICE)
+            if any(r.status or r.length != bt.lengths[j] for j, r in enumerate(res)):
+                raise RuntimeError("decode status")
+
+        dec(0, enc(0))                                                 # warm-up: both contexts size their arenas
+        encoded = [threading.Event() for _ in range(steps)]
+        decoded = [threading.Event() for _ in range(steps)]
+        bits_of = [None] * steps
+
+        def thread_e():
+            try:
+                for k in range(steps):
+                    if k >= 2:
+                        decoded[k - 2].wait()                          # the buffer of step k-2 is free again
+                    bits_of[k] = enc(k)
+                    encoded[k].set()
+            except Exception as e:                                     # noqa: BLE001 -- reported after the join
+                errs.append(e)
+                for ev in encoded:
+                    ev.set()
+
+        def thread_d():
+            try:
+                for k in range(steps):
+                    encoded[k].wait()
+                    if errs:
+                        return
+                    dec(k, bits_of[k])
+                    decoded[k].set()
+            except Exception as e:                                     # noqa: BLE001
+                errs.append(e)
+                for ev in decoded:
+                    ev.set()
+
+        barrier()
+        S0 = time.perf_counter()
+        te_, td_ = threading.Thread(target=thread_e), threading.Thread(target=thread_d)
+        te_.start(); td_.start(); te_.join(); td_.join()
+        barrier()
+        S1 = time.perf_counter()
+        if errs:
+            raise SystemExit("two-stream pass failed: %r" % errs[0])
+        if not bt.round_trip_ok():
+            raise SystemExit("round trip mismatch in the two-stream pass")
+        ctx2.close()
+        (sel,) = max_over_ranks([S1 - S0])
+        return {"blocks": nb * world, "bytes": int(bt.nbytes) * world, "scaling": "weak", "steps": steps, "ms_per_step": sel / steps * 1e3,
+                "enc_dec_MBps": bt.nbytes * world * steps / sel / 1e6,
+                "chain": "%s & %s; two contexts on one GPU, the encode of step k+1 under the decode of step k (not the headline's schedule)" % (args.chain, args.entropy)}
+
+    two = None
+    if not args.no_two_streams and not args.no_shapes:
+        two = two_streams(d_host, B, 4)
+        torch.cuda.empty_cache()
+
     # ================= config.chains: the other BASELINE configs, same harness, one short pass each =================
     chains = {}
     if not args.no_chains:
@@ -541,6 +618,8 @@ def main():
     # ================= shaped batches: the sizes the metric names, split over the ranks (strong scaling) =================
     shapes = {"bulk": {"blocks": B * world, "bytes": int(step_bytes) * world, "scaling": "weak",
                        "encode_MBps": head["encode_MBps"], "decode_MBps": head["decode_MBps"], "enc_dec_MBps": value}}
+    if two:
+        shapes["bulk_two_streams"] = two
 
     def shaped(src, total, reps=2, chain=None, entropy=None, by_id=False):
         nblk = (total + bs - 1) // bs

@@ -763,6 +763,18 @@ static int text_gpu_form(uint32_t entropyType, int nBlocks) {
   return (entropyType == KZ_E_FPAQ || nBlocks < minBlocks) ? 0 : 1;
 }
 static bool text_gpu_on(uint32_t entropyType, int nBlocks) { return text_gpu_form(entropyType, nBlocks) != 0; }
+// TEXT forward on the device (kz_text_fwd_gpu.hip): TextCodec2 streams (every entropy coder but FPAQ) in batches of KZ_TEXT_FWD_GPU_MIN
+// blocks (512) or more -- a block's dictionary walk takes the kernel ~0.1 s however few there are, so small batches stay on the host's
+// chunk pipeline.  KZ_TEXT_FWD_GPU=0: host stage, =1: any batch size.  (Read per call: the tests force both.)
+static bool text_fwd_gpu_on(uint32_t entropyType, int nBlocks) {
+  const bool type2 = entropyType == KZ_E_NONE || entropyType == KZ_E_ANS0 || entropyType == KZ_E_HUFFMAN;
+  if (!type2) return false;
+  const char* e = getenv("KZ_TEXT_FWD_GPU");
+  if (e && e[0] == '0') return false;
+  if (e && e[0] == '1') return true;
+  const char* m = getenv("KZ_TEXT_FWD_GPU_MIN");
+  return nBlocks >= (m ? atoi(m) : 512);
+}
 // UTF inverse on the device (kz_text_gpu.hip: parallel inside a block, so for any batch); KZ_UTF_GPU=0 keeps it on the host
 static bool utf_gpu_on() { const char* e = getenv("KZ_UTF_GPU"); return !(e && e[0] == '0'); }
 
@@ -1082,7 +1094,8 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
   // ---- chains led by TEXT / UTF on large batches: the host stages of chunk k+1 run on a helper thread (and the host pool) while
   //      the GPU codes chunk k.  Blocks are independent, so chunking changes nothing in the output.  (With "skipBlocks" the copy
   //      decision comes from the device and precedes the host stages: that case takes the one-pass path below.) ----
-  if (hp > 0 && !pre && !ctx->skipBlocks && B >= 2 * host_chunk_blocks(B)) {
+  const bool textFwdGpu = hp > 0 && !pre && types[0] == KZ_T_TEXT && (hp == 1 || types[1] == KZ_T_UTF) && text_fwd_gpu_on(entropyType, B);
+  if (hp > 0 && !pre && !ctx->skipBlocks && B >= 2 * host_chunk_blocks(B) && !textFwdGpu) {
     const int CH = host_chunk_blocks(B);
     const int nch = (B + CH - 1) / CH;
     const bool hostIn = memKind == KZ_MEM_HOST;
@@ -1135,7 +1148,11 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
   if (outStride < needOut || (outStride & 3)) { snprintf(ctx->err, sizeof(ctx->err), "outStride %lld < %lld or not a multiple of 4", (long long)outStride, (long long)needOut); return -KZ_ERR_INVALID_PARAM; }
   const bool host = memKind == KZ_MEM_HOST;
   Pipe P;
-  const int64_t extra = (host ? (int64_t)outStride * B : 0) + (int64_t)B * (sizeof(kz_block_result) + 64) + (int64_t)B * 32 + 8192;
+  int64_t extra = (host ? (int64_t)outStride * B : 0) + (int64_t)B * (sizeof(kz_block_result) + 64) + (int64_t)B * 32 + 8192;
+  if (textFwdGpu) {                     // the device TEXT forward runs first and gives its scratch back: it needs the larger of the two, not the sum
+    const int64_t tf = (int64_t)kz_text_fwd_gpu_scratch(B, blockSize, maxLen), rest = (int64_t)pipeline_scratch(B, maxLen, false, CS);
+    if (tf > rest) extra += tf - rest;
+  }
   int rc = pipe_setup(ctx, P, B, maxLen, extra, false, CS);
   if (rc) return rc;
   kz_batch& bt = P.bt;
@@ -1187,24 +1204,36 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
     // there) go on to the GPU stages
     hipEvent_t e0; kz_stage_begin(ctx, &e0);
     HostPre mine;
+    // TEXT forward on the device for the blocks it takes and finishes (they are rewritten in their slots; hashes and Magic tags were
+    // taken from the original bytes above, on the same stream); whatever it leaves goes through the host stages as before
+    std::vector<int32_t> gpuDone(B, 0);
+    if (textFwdGpu) {
+      std::vector<int32_t> take(B);
+      for (int b = 0; b < B; b++) take[b] = (!h_copy[b] && lengths[b] > 0) ? 1 : 0;
+      rc = kz_stage_text_forward_gpu(ctx, bt, blockSize, take, gpuDone);
+      if (rc) return rc;
+    }
     if (!pre) {
+      std::vector<int32_t> notHost(h_copy);                                       // blocks the host stages leave alone
+      for (int b = 0; b < B; b++) if (gpuDone[b]) notHost[b] = 1;
       std::unique_ptr<uint8_t[]> hostCopy;
       const uint8_t* hsrc = in;
       int64_t hstride = inStride;
       if (!host) {
         hostCopy.reset(new uint8_t[(size_t)B * (size_t)maxN + 64]);
         for (int b = 0; b < B; b++)
-          if (lengths[b]) KZ_HIP(hipMemcpyAsync(hostCopy.get() + (size_t)b * maxN, in + (int64_t)b * inStride, (size_t)lengths[b], hipMemcpyDeviceToHost, st));
+          if (lengths[b] && !notHost[b]) KZ_HIP(hipMemcpyAsync(hostCopy.get() + (size_t)b * maxN, in + (int64_t)b * inStride, (size_t)lengths[b], hipMemcpyDeviceToHost, st));
         hsrc = hostCopy.get(); hstride = maxN;
         KZ_HIP(kz_stream_sync(ctx, st));
       }
-      host_prestage(types, hp, (int)entropyType, blockSize, maxLen, hsrc, hstride, lengths, h_copy.data(), B, mine);
+      host_prestage(types, hp, (int)entropyType, blockSize, maxLen, hsrc, hstride, lengths, notHost.data(), B, mine);
       pre = &mine;
     }
     KZ_HIP(kz_stream_sync(ctx, st));                                            // the blocks are in HBM, hashed and tagged: slots may be rewritten
     for (int b = 0; b < B; b++) {
       h_mask[b] = 0;
       if (h_copy[b]) { bt.h_len[b] = lengths[b]; continue; }                     // (a pre-staged block of <= 15 bytes was left alone as well)
+      if (gpuDone[b]) { h_skip[b] = 0xFF & ~(1 << 7); continue; }                // TEXT applied on the device (length set there); UTF declines a block tagged TEXT (UTFCodec.java:93-101)
       h_skip[b] = pre->skip[b];
       bt.h_len[b] = pre->outLen[b];
       if (pre->changed[b] && pre->outLen[b] > 0) {
@@ -1217,8 +1246,10 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
       KZ_HIP(hipMemcpyAsync(P.d_mask, h_mask.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
       KZ_LAUNCH(ctx, KID_COPY_BYTES, k_copy_bytes, dim3(64, B), dim3(256), pre->store, pre->slot, bt.buf[0], bt.stride, bt.d_len, (const int32_t*)nullptr, P.d_mask);
     }
-    KZ_HIP(hipMemcpyAsync(bt.d_dtype, pre->dtype.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-    KZ_HIP(kz_stream_sync(ctx, st));                                            // pageable sources; `mine` is a local
+    std::vector<int32_t> dts(pre->dtype);
+    for (int b = 0; b < B; b++) if (gpuDone[b]) dts[b] = KZ_DT_TEXT;             // TextCodec.java:667
+    KZ_HIP(hipMemcpyAsync(bt.d_dtype, dts.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    KZ_HIP(kz_stream_sync(ctx, st));                                            // pageable sources; `mine` and `dts` are locals
     kz_stage_end(ctx, e0, KZ_STAGE_HOST_FWD, 0);
   }
   for (int i = hp; i < nb; i++) {

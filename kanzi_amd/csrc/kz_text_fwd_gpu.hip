@@ -1,0 +1,480 @@
+// kz_text_fwd_gpu.hip -- TEXT forward (TextCodec2) on the device: K/transform/TextCodec.java:1124-1300 (TextCodec2.forward),
+// :269-384 (computeStats, the text branch), :1304-1394 (emitSymbols / emitWordIndex) for blocks that sit in HBM.
+//
+// The host form (kz_text.hip: text_forward) stays the reference of this file and the fallback: a block the device does not take or
+// does not finish cleanly (not text by the order-0 rules -- detectType then wants the whole pair table --, a Magic number in front, fewer
+// than 1 024 bytes, a word list that would wrap at 2^19 words, an output within 8 bytes of the block's length) is left untouched and
+// goes through the host stage, which gives the reference's verdict, bytes and "dataType" entry.  The device form only has to be
+// exact on what it accepts.
+//
+// What the forward depends on, and what that allows:
+//   * word boundaries, the two hashes of a word (as written / first letter's case flipped) and the cost of every plain byte depend on
+//     the block's bytes alone;
+//   * the dictionary changes only when a word is LEARNED: not found, eligible by length, and the hash slot of the word as written
+//     EMPTY (TextCodec.java:725: `e1 == null`) -- a few thousand times per block against a million lookups; a lookup never writes;
+//   * a found word replaces its letters by a 1 - 3 byte number (+ 0x80 when the case of the first letter was flipped), the bytes
+//     between two found words go out as plain bytes, a single space between two found words is implied.
+// So: k_tf_stats / k_tf_decide = computeStats' text branch (order-0 histogram and the four pair counts it reads);
+//     k_tf_walk  = one wave per block walks rows of 64 bytes: every lane that closes a word hashes it and looks it up on its own
+//                  (map entry = hash | length | number | position, 16 bytes, two loads in flight per lane); rows in which some word
+//                  could be learned replay their words one by one from that word on, with the dictionary updated in between;
+//                  a found word leaves (number + 1 | length << 24 | flip << 31) at its first letter in `tok`;
+//     k_tf_emit<false> / k_tf_scan / k_tf_emit<true> = output bytes per 1 024 positions, offsets and the verdict, the bytes.
+#include "kz_device.h"
+#include "kz_internal.h"
+#include "kz_magic.h"
+#include <algorithm>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef unsigned long long u64;
+
+void kz_text_static_tables(std::vector<uint32_t>& hash, std::vector<int32_t>& pos, std::vector<uint32_t>& lenIdx, std::vector<uint8_t>& text,
+                           std::vector<uint8_t>& delim, int* count);   // kz_text.hip
+
+#define TF_T2 (128 * 128)        // TextCodec.java:32-35
+#define TF_T3 64
+#define TF_T4 (64 * 128)
+#define TF_MAXDICT (1 << 19)
+#define TF_MAXWORD 31
+#define TF_MINBLOCK 1024
+#define TF_MAXBLOCK (1 << 24)    // larger blocks: host stage (the token word keeps the word number in 24 bits, positions in 31)
+#define TF_LF 0x0Au
+#define TF_CR 0x0Du
+#define TF_ESC1 0x0Fu
+#define TF_HASH1 0x7FEB352Du
+#define TF_HASH2 0x846CA68Bu
+#define TF_CRLF 0x40
+#define TF_XML 0x20
+#define TF_CODEC2 0x10
+#define TF_STATS 264             // ints per block: 256 byte counts, "&" + a/g/l/q, CR + not LF, not CR + LF
+#define TF_TILE 1024             // positions per wave of the emit passes
+#define TF_MARGIN 8
+
+struct TextFwd {
+  const u8* sText; const u8* delim; const u64* sMap; int sMapN; int sCount;   // static dictionary: text, delimiter set, (slot, e0, e1) triples
+  u64* map;            // [A][slotsPer][2]: hash | (length << 24 | number) << 32,  position | valid << 32 | static << 33
+  u32* tok;            // [A][NS]
+  int32_t* tileSum;    // [A][maxTiles] output bytes per tile, then their exclusive prefix
+  int32_t* stats;      // [A][TF_STATS]
+  int32_t* mode;       // [A] the block's mode byte (TextCodec.java:48-52), -1: not for the device
+  int32_t* fail;       // [A] the walk gave up
+  const int32_t* ord;  // [B] dense index of the blocks this launch takes, -1: not taken
+  int32_t* outLen;     // [B] produced bytes, -1: not done (host stage)
+  int64_t slotsPer, NS;
+  int maxTiles;
+  u32 mask;
+};
+
+__device__ __forceinline__ bool tf_is_text(u32 c) { const u32 l = c | 0x20u; return l >= 'a' && l <= 'z'; }     // (c < 256: bytes >= 0x80 never are)
+__device__ __forceinline__ u32 tf_sx(u32 c) { return (u32)(int32_t)(int8_t)c; }                                 // Java's bytes are signed
+__device__ __forceinline__ u64 tf_ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tf_st(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ---- computeStats, text branch (:269-384): the order-0 histogram and the pair counts the text path reads ----
+__global__ __launch_bounds__(256) void k_tf_stats(const u8* __restrict__ srcAll, int64_t stride, const int32_t* __restrict__ d_len, TextFwd G, int B) {
+  const int b = blockIdx.y;
+  const int a = G.ord[b];
+  if (a < 0) return;
+  const int n = d_len[b];
+  __shared__ u32 hist[4][256];
+  for (int i = threadIdx.x; i < 1024; i += 256) (&hist[0][0])[i] = 0;
+  __syncthreads();
+  const u8* src = srcAll + (int64_t)b * stride;
+  const int per = (((n + (int)gridDim.x - 1) / (int)gridDim.x) + 255) & ~255;
+  const int beg = blockIdx.x * per, end = min(n, beg + per);
+  const int wave = threadIdx.x >> 6, lane = kz_lane();
+  u32 amp = 0, crx = 0, xlf = 0;
+  for (int i = beg + threadIdx.x; i < end + 255; i += 256) {
+    const bool valid = i < end;
+    const u32 c = valid ? (u32)src[i] : 0u;
+    const u32 p = (valid && i > 0) ? (u32)src[i - 1] : 0u;                          // the first byte's previous byte is 0 (:283)
+    // one LDS atomic per distinct byte of the row would be ideal; rows of one byte (spaces, runs) are the expensive case: add once
+    const uint64_t vm = kz_ballot(valid);
+    if (vm == 0) break;
+    const u32 c0 = (u32)__builtin_amdgcn_readfirstlane((int)c);
+    if (kz_ballot(valid && c == c0) == vm) { if (lane == (int)__builtin_ctzll(vm)) atomicAdd(&hist[wave][c0], (u32)__popcll(vm)); }
+    else if (valid) atomicAdd(&hist[wave][c], 1u);
+    if (valid) {
+      amp += (p == '&') & ((c == 'a') | (c == 'g') | (c == 'l') | (c == 'q'));
+      crx += (p == TF_CR) & (c != TF_LF);
+      xlf += (c == TF_LF) & (p != TF_CR);
+    }
+  }
+  amp = kz_wave_sum(amp); crx = kz_wave_sum(crx); xlf = kz_wave_sum(xlf);
+  int32_t* st = G.stats + (int64_t)a * TF_STATS;
+  if (lane == 0) { if (amp) atomicAdd(&st[256], (int32_t)amp); if (crx) atomicAdd(&st[257], (int32_t)crx); if (xlf) atomicAdd(&st[258], (int32_t)xlf); }
+  __syncthreads();
+  const u32 v = hist[0][threadIdx.x] + hist[1][threadIdx.x] + hist[2][threadIdx.x] + hist[3][threadIdx.x];
+  if (v) atomicAdd(&st[threadIdx.x], (int32_t)v);
+}
+
+// one thread per block: text or not (:310-331), the mode byte (:333-381)
+__global__ __launch_bounds__(64) void k_tf_decide(const u8* __restrict__ srcAll, int64_t stride, const int32_t* __restrict__ d_len, TextFwd G, int B) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const int a = G.ord[b];
+  if (a < 0) return;
+  const int n = d_len[b];
+  const int32_t* f = G.stats + (int64_t)a * TF_STATS;
+  int mode = -1;
+  if (n >= TF_MINBLOCK && n < TF_MAXBLOCK && mm_magic_type(srcAll + (int64_t)b * stride) == 0) {       // :272-273, :491-492
+    long long letters = (long long)f[TF_CR] + f[TF_LF], ascii = 0;
+    for (int c = 0; c < 128; c++) { if (tf_is_text((u32)c)) letters += f[c]; ascii += f[c]; }
+    const long long bin = n - ascii;
+    bool notText = bin > (n >> 2);
+    if (!notText) notText = letters < n / 4 || f[32] < n / 50;                                         // :321, :326 (not strict)
+    if (!notText) {
+      int m = 0;
+      if (bin <= n - n / 10) {                                                                           // :336-356
+        const int lt = f['<'], gt = f['>'];
+        const int minFreq = max((int)((n - bin) >> 9), 2);
+        if (lt >= minFreq && gt >= minFreq && f[256] > 0) {
+          const int lo = min(lt, gt), hi = max(lt, gt);
+          if (lo == hi || lo >= hi - hi / 100) m |= TF_XML;
+        }
+      }
+      if (f[TF_CR] != 0 && f[TF_CR] == f[TF_LF] && f[257] == 0 && f[258] == 0) m |= TF_CRLF;           // :358-372
+      mode = m;
+    }
+  }
+  G.mode[a] = mode;
+}
+
+// the static dictionary's map entries (the map itself was cleared by the host call)
+__global__ __launch_bounds__(256) void k_tf_init(TextFwd G, int B) {
+  const int b = blockIdx.y;
+  const int a = G.ord[b];
+  if (a < 0 || G.mode[a] < 0) return;
+  u64* map = G.map + (int64_t)a * G.slotsPer * 2;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < G.sMapN; i += gridDim.x * 256) {
+    const u64 slot = G.sMap[3 * i];
+    map[2 * slot] = G.sMap[3 * i + 1];
+    map[2 * slot + 1] = G.sMap[3 * i + 2];
+  }
+}
+
+#define TF_VALID (1ULL << 32)
+#define TF_STATIC (1ULL << 33)
+
+// ---- the walk: which words are found, under which number ----
+__global__ __launch_bounds__(64) void k_tf_walk(const u8* __restrict__ srcAll, int64_t stride, const int32_t* __restrict__ d_len, TextFwd G, int B) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int a = G.ord[b];
+  if (a < 0 || G.mode[a] < 0) return;
+  const int lane = kz_lane();
+  const int n = d_len[b];
+  const u8* src = srcAll + (int64_t)b * stride;
+  u64* map = G.map + (int64_t)a * G.slotsPer * 2;
+  u32* tok = G.tok + (int64_t)a * G.NS;
+  const u32 mask = G.mask;
+  __shared__ u8 ring[128];                        // the previous row and this one: a word is at most 31 letters
+  const uint64_t dm0 = kz_ballot(G.delim[lane] != 0), dm1 = kz_ballot(G.delim[64 + lane] != 0), dm2 = kz_ballot(G.delim[128 + lane] != 0), dm3 = kz_ballot(G.delim[192 + lane] != 0);
+#define TF_DELIM(cc) ((((cc) < 64u ? dm0 : ((cc) < 128u ? dm1 : ((cc) < 192u ? dm2 : dm3))) >> ((cc) & 63u)) & 1ULL)
+  const uint64_t lt = kz_lanemask_lt();
+  int words = G.sCount;                           // the next word number (TextCodec2: the static words, nothing else fixed)
+  int carry = -1;                                 // position of the last non-letter in front of the row (:694: a letter first = -1 / the last leading space)
+  bool failed = false;
+  u32 cNext = (lane < n) ? (u32)src[lane] : 0u;
+  for (int row = 0; row < n && !failed; row += 64) {
+    const u32 c = cNext;
+    const int p = row + lane;
+    cNext = (row + 64 + lane < n) ? (u32)src[row + 64 + lane] : 0u;
+    __syncthreads();
+    ring[p & 127] = (u8)c;
+    __syncthreads();
+    const bool inb = p < n;
+    const bool isT = inb && tf_is_text(c);
+    const uint64_t NT = ~kz_ballot(isT);
+    const uint64_t below = NT & lt;
+    const int anchor = below ? row + 63 - (int)__builtin_clzll(below) : carry;
+    const int len = p - anchor - 1;
+    const bool cand = inb && !isT && TF_DELIM(c) && len >= 2 && len <= TF_MAXWORD;                       // :704, :708
+    if (NT) carry = row + 63 - (int)__builtin_clzll(NT);
+    const uint64_t candM = kz_ballot(cand);
+    if (candM == 0) continue;
+    const int ws = anchor + 1;
+    // ---- both hashes of every word the row closes (:709-718) ----
+    u32 h1 = 0, h2 = 0;
+    if (cand) {
+      const u32 w0 = ring[ws & 127];
+      h1 = TF_HASH1 * TF_HASH1 ^ tf_sx(w0) * TF_HASH2;
+      h2 = TF_HASH1 * TF_HASH1 ^ tf_sx(w0 ^ 0x20u) * TF_HASH2;
+    }
+    for (int k = 1; k < TF_MAXWORD; k++) {
+      const bool act = cand && k < len;
+      if (kz_ballot(act) == 0) break;
+      if (act) { const u32 t = tf_sx(ring[(ws + k) & 127]) * TF_HASH2; h1 = h1 * TF_HASH1 ^ t; h2 = h2 * TF_HASH1 ^ t; }
+    }
+    // ---- lookups, every lane on its own ----
+    u64 a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    if (cand) {
+      const u32 s1 = h1 & mask, s2 = h2 & mask;
+      a0 = tf_ld(map + 2 * (u64)s1); a1 = tf_ld(map + 2 * (u64)s1 + 1);
+      b0 = tf_ld(map + 2 * (u64)s2); b1 = tf_ld(map + 2 * (u64)s2 + 1);
+    }
+    const bool v1 = (a1 & TF_VALID) != 0, v2 = (b1 & TF_VALID) != 0;
+    const bool m1 = cand && v1 && (u32)a0 == h1 && (int)(a0 >> 56) == len;
+    const bool m2 = cand && !m1 && v2 && (u32)b0 == h2 && (int)(b0 >> 56) == len;
+    const u64 e0 = m1 ? a0 : b0, e1 = m1 ? a1 : b1;
+    bool have = m1 || m2;
+    {                                             // sameWords on everything but the first letter (:720-723)
+      const u8* base = ((e1 & TF_STATIC) ? G.sText : src) + (int64_t)(u32)e1;
+      bool neq = false;
+      for (int k = 1; k < TF_MAXWORD; k++) {
+        const bool act = have && k < len;
+        if (kz_ballot(act) == 0) break;
+        if (act) neq |= ring[(ws + k) & 127] != base[k];
+      }
+      have = have && !neq;
+    }
+    bool found = have;
+    u32 number = (u32)(e0 >> 32) & 0x00FFFFFFu;
+    bool flip = m2 && !(v1 && ((u32)(a0 >> 32) & 0x00FFFFFFu) == number);                               // :761 `e == e1`: the same entry through both slots
+    // ---- rows that can learn a word: from that word on, one word at a time ----
+    const uint64_t learnM = kz_ballot(cand && !found && !v1 && (len > 3 || (len == 3 && words < TF_T2)));
+    if (learnM) {
+      uint64_t rest = candM & ~((1ULL << (int)__builtin_ctzll(learnM)) - 1ULL);
+      while (rest) {
+        const int j = (int)__builtin_ctzll(rest);
+        rest &= rest - 1;
+        const u32 uh1 = (u32)__builtin_amdgcn_readlane((int)h1, j), uh2 = (u32)__builtin_amdgcn_readlane((int)h2, j);
+        const int ulen = __builtin_amdgcn_readlane(len, j), uws = __builtin_amdgcn_readlane(ws, j);
+        const u32 us1 = uh1 & mask, us2 = uh2 & mask;
+        const u64 ua0 = tf_ld(map + 2 * (u64)us1), ua1 = tf_ld(map + 2 * (u64)us1 + 1);
+        const u64 ub0 = tf_ld(map + 2 * (u64)us2), ub1 = tf_ld(map + 2 * (u64)us2 + 1);
+        const bool uv1 = (ua1 & TF_VALID) != 0, uv2 = (ub1 & TF_VALID) != 0;
+        const bool um1 = uv1 && (u32)ua0 == uh1 && (int)(ua0 >> 56) == ulen;
+        const bool um2 = !um1 && uv2 && (u32)ub0 == uh2 && (int)(ub0 >> 56) == ulen;
+        const u64 ue0 = um1 ? ua0 : ub0, ue1 = um1 ? ua1 : ub1;
+        bool ufound = um1 || um2;
+        if (ufound) {                             // the letters behind the first, one per lane
+          const u8* base = ((ue1 & TF_STATIC) ? G.sText : src) + (int64_t)(u32)ue1;
+          const bool d = lane >= 1 && lane < ulen && ring[(uws + lane) & 127] != base[lane];
+          ufound = kz_ballot(d) == 0;
+        }
+        const u32 unum = (u32)(ue0 >> 32) & 0x00FFFFFFu;
+        const bool uflip = um2 && !(uv1 && ((u32)(ua0 >> 32) & 0x00FFFFFFu) == unum);
+        if (!ufound && !uv1 && (ulen > 3 || (ulen == 3 && words < TF_T2))) {                             // :725-747
+          // the word takes the next number; that number's record is a fresh one (hash 0): its "old" slot, slot 0, leaves the map (:729-731)
+          if (lane == 0) {
+            tf_st(map + 1, 0ULL);
+            tf_st(map + 2 * (u64)us1, (u64)uh1 | ((u64)(((u32)ulen << 24) | (u32)words) << 32));
+            tf_st(map + 2 * (u64)us1 + 1, (u64)(u32)uws | TF_VALID);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          words++;
+          if (words >= TF_MAXDICT - 1) { failed = true; break; }                                         // the numbering would restart (:742-746): host stage
+        }
+        if (lane == j) { found = ufound; number = unum; flip = uflip; }
+      }
+    }
+    if (found && cand) tok[ws] = (number + 1u) | ((u32)len << 24) | (flip ? 0x80000000u : 0u);
+  }
+  if (lane == 0) G.fail[a] = failed ? 1 : 0;
+#undef TF_DELIM
+}
+
+// ---- output: sizes per tile, then the bytes (:752-771 between the words, emitSymbols :1304-1367, emitWordIndex :1370-1394) ----
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_tf_emit(const u8* __restrict__ srcAll, u8* __restrict__ dstAll, int64_t stride, const int32_t* __restrict__ d_len, TextFwd G, int B) {
+  const int b = blockIdx.y;
+  const int a = G.ord[b];
+  if (a < 0) return;
+  const int mode = G.mode[a];
+  if (mode < 0) return;
+  if (WRITE && G.outLen[b] < 0) return;
+  const int n = d_len[b];
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int base = t * TF_TILE;
+  if (base >= n) return;
+  const int lane = kz_lane();
+  const u8* src = srcAll + (int64_t)b * stride;
+  u8* dst = dstAll + (int64_t)b * stride;
+  const u32* tok = G.tok + (int64_t)a * G.NS;
+  const bool crlf = (mode & TF_CRLF) != 0;
+  const uint64_t le = kz_lanemask_lt() | (1ULL << lane);
+  u32 off = WRITE ? 1u + (u32)G.tileSum[(int64_t)a * G.maxTiles + t] : 0u;
+  if (WRITE && t == 0 && lane == 0) dst[0] = (u8)(mode | TF_CODEC2);                                  // TextCodec.java:496-501
+  u32 tPrev = (base >= 64) ? tok[base - 64 + lane] : 0u;
+  for (int r = 0; r < TF_TILE / 64; r++) {
+    const int row = base + r * 64;
+    if (row >= n) break;
+    const int p = row + lane;
+    const bool inb = p < n;
+    const u32 tCur = inb ? tok[p] : 0u;
+    const u32 tNxt = (p + 1 < n) ? tok[p + 1] : 0u;
+    const u32 c = inb ? (u32)src[p] : 0u;
+    const uint64_t curM = kz_ballot(tCur != 0), prevM = kz_ballot(tPrev != 0);
+    // the last found word that starts at or in front of p: does it cover p, does it end right in front of p
+    const uint64_t m = curM & le;
+    const int sl = m ? 63 - (int)__builtin_clzll(m) : (prevM ? 63 - (int)__builtin_clzll(prevM) : 0);
+    const u32 tA = (u32)__shfl((int)tCur, sl, 64), tB = (u32)__shfl((int)tPrev, sl, 64);
+    const u32 tS = m ? tA : (prevM ? tB : 0u);
+    const int sPos = m ? row + sl : row - 64 + sl;
+    const int L = (int)((tS >> 24) & 31u);
+    const bool cov = tS != 0 && p < sPos + L;
+    const bool ends = tS != 0 && p == sPos + L;
+    const bool skipSp = ends && c == ' ' && tNxt != 0;                                                  // :752: a single space between two references
+    u32 lit = 0;
+    if (inb && !cov && !skipSp) lit = (c == TF_ESC1) ? 2u : ((c == TF_CR) ? (crlf ? 0u : 1u) : 1u + (c >> 7));
+    const u32 v = tCur & 0x00FFFFFFu;
+    const u32 code = tCur ? ((tCur >> 31) + (v >= TF_T4 ? 3u : (v >= TF_T3 ? 2u : 1u))) : 0u;
+    const u32 sz = lit + code;
+    const u32 incl = kz_wave_incl_sum(sz);
+    if (WRITE && sz) {
+      u8* o = dst + off + incl - sz;
+      if (tCur) {
+        if (tCur >> 31) *o++ = 0x80;
+        if (v >= TF_T4) { o[0] = (u8)(0xF0u | (v >> 16)); o[1] = (u8)(v >> 8); o[2] = (u8)v; }
+        else if (v >= TF_T3) { o[0] = (u8)(0xC0u | (v >> 8)); o[1] = (u8)v; }
+        else o[0] = (u8)(0x80u | v);
+      } else if (c == TF_ESC1) { o[0] = (u8)TF_ESC1; o[1] = (u8)TF_ESC1; }
+      else if (c & 0x80u) { o[0] = (u8)TF_ESC1; o[1] = (u8)c; }
+      else o[0] = (u8)c;
+    }
+    off += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+    tPrev = tCur;
+  }
+  if (!WRITE && lane == 0) G.tileSum[(int64_t)a * G.maxTiles + t] = (int32_t)off;
+}
+
+// tile offsets and the verdict: the reference gives up when the output comes within 3 bytes of the block's length at a word
+// (:756) or runs over it at the end (:797); a block that ends at least TF_MARGIN bytes short of its length never meets either
+__global__ __launch_bounds__(256) void k_tf_scan(const int32_t* __restrict__ d_len, TextFwd G, int B) {
+  const int b = blockIdx.x;
+  const int a = G.ord[b];
+  if (a < 0) return;
+  if (G.mode[a] < 0) { if (threadIdx.x == 0) G.outLen[b] = -1; return; }
+  const int n = d_len[b];
+  const int nt = (n + TF_TILE - 1) / TF_TILE;
+  const int per = (nt + 255) / 256;
+  int32_t* ts = G.tileSum + (int64_t)a * G.maxTiles;
+  __shared__ u32 lds[32];
+  u32 run = 0;
+  for (int i = 0; i < per; i++) { const int t = threadIdx.x * per + i; if (t < nt) run += (u32)ts[t]; }
+  u32 total;
+  u32 ex = kz_wg_excl_sum(run, lds, &total);
+  for (int i = 0; i < per; i++) { const int t = threadIdx.x * per + i; if (t < nt) { const u32 v = (u32)ts[t]; ts[t] = (int32_t)ex; ex += v; } }
+  if (threadIdx.x == 0) G.outLen[b] = (!G.fail[a] && (long long)total + 1 <= (long long)n - TF_MARGIN) ? (int32_t)(total + 1) : -1;
+}
+
+__global__ __launch_bounds__(256) void k_tf_copy_back(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride, const int32_t* __restrict__ len, const int32_t* __restrict__ cond) {
+  const int b = blockIdx.y;
+  if (!cond[b]) return;
+  const int n16 = (len[b] + 15) >> 4;
+  const uint4* s = (const uint4*)(src + (int64_t)b * stride);
+  uint4* d = (uint4*)(dst + (int64_t)b * stride);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+static int tf_log_v2(int blockSize) { int l = 13; if (blockSize >= 32) l = std::max(std::min(31 - __builtin_clz((unsigned)(blockSize / 32)), 24), 13); return l; }   // :1068-1081
+#define TF_CHUNK 1024            // blocks per pass: 4 bytes of `tok` per input byte and 16 bytes per hash slot are scratch
+
+// bytes of scratch the stage wants for a batch of B blocks of at most maxLen bytes (kz_api.hip sizes the arena with it)
+size_t kz_text_fwd_gpu_scratch(int B, int blockSize, int maxLen) {
+  const size_t ch = (size_t)std::min(B, TF_CHUNK);
+  const size_t NS = kz_align((size_t)maxLen + 64, 256);
+  return ch * (NS * 4 + ((size_t)32 << tf_log_v2(blockSize)) + (size_t)(maxLen / TF_TILE + 2) * 4 + TF_STATS * 4 + 64) + (size_t)B * 16 + (1 << 20);
+}
+
+// TEXT forward (TextCodec2) of the blocks with take[b] != 0: reads bt.buf[cur] (lengths bt.h_len / bt.d_len), leaves the result of the
+// blocks it finished in the same slots (bt.h_len / bt.d_len updated) and sets done[b] = 1 for them -- their skip bit, and "dataType" =
+// TEXT, are the caller's; every other block is untouched (the host stage takes it).  Returns 0 or a negative error.
+int kz_stage_text_forward_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, const std::vector<int32_t>& take, std::vector<int32_t>& done) {
+  const int B = bt.B;
+  done.assign(B, 0);
+  std::vector<int32_t> ordAll(B, -1);
+  int A = 0, maxLen = 0;
+  for (int b = 0; b < B; b++) if (take[b] && bt.h_len[b] >= TF_MINBLOCK && bt.h_len[b] < TF_MAXBLOCK) { ordAll[b] = A++; maxLen = std::max(maxLen, bt.h_len[b]); }
+  if (A == 0) return 0;
+  static std::vector<uint32_t> hHash, hLenIdx; static std::vector<int32_t> hPos; static std::vector<uint8_t> hText, hDelim; static int hCount = -1;
+  static std::once_flag once;
+  std::call_once(once, [] { kz_text_static_tables(hHash, hPos, hLenIdx, hText, hDelim, &hCount); });
+  TextFwd G;
+  const int logV2 = tf_log_v2(blockSize);
+  G.slotsPer = (int64_t)1 << logV2; G.mask = (u32)(G.slotsPer - 1);
+  G.NS = (int64_t)kz_align((size_t)maxLen + 64, 256);
+  G.maxTiles = maxLen / TF_TILE + 2;
+  G.sCount = hCount;
+  // the static words' map entries for this map size: the words take their slots in order, a later word takes a shared slot (:1109-1113)
+  std::vector<u64> sMap;
+  {
+    std::unordered_map<u32, int> owner;
+    for (int i = 0; i < hCount; i++) owner[hHash[i] & G.mask] = i;
+    for (const auto& kv : owner) {
+      const int i = kv.second;
+      sMap.push_back((u64)kv.first);
+      sMap.push_back((u64)hHash[i] | ((u64)hLenIdx[i] << 32));
+      sMap.push_back((u64)(u32)hPos[i] | TF_VALID | TF_STATIC);
+    }
+  }
+  G.sMapN = (int)(sMap.size() / 3);
+  hipStream_t st = ctx->stream;
+  const bool trace = getenv("KZ_TEXT_GPU_TRACE") != nullptr;
+  int nDone = 0;
+  for (int c0 = 0; c0 < A; c0 += TF_CHUNK) {
+    const int CA = std::min(TF_CHUNK, A - c0);
+    std::vector<int32_t> ord(B, -1);
+    for (int b = 0; b < B; b++) if (ordAll[b] >= c0 && ordAll[b] < c0 + CA) ord[b] = ordAll[b] - c0;
+    const size_t mark = ctx->arenaTop;
+    u8* dText = (u8*)kz_arena_alloc(ctx, hText.size() + 64);
+    u8* dDelim = (u8*)kz_arena_alloc(ctx, 256);
+    u64* dSMap = (u64*)kz_arena_alloc(ctx, sMap.size() * 8 + 64);
+    int32_t* dOrd = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+    int32_t* dOut = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+    int32_t* dCond = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+    G.mode = (int32_t*)kz_arena_alloc(ctx, (size_t)CA * 4);
+    G.fail = (int32_t*)kz_arena_alloc(ctx, (size_t)CA * 4);
+    G.stats = (int32_t*)kz_arena_alloc(ctx, (size_t)CA * TF_STATS * 4);
+    G.tileSum = (int32_t*)kz_arena_alloc(ctx, (size_t)CA * (size_t)G.maxTiles * 4);
+    G.map = (u64*)kz_arena_alloc(ctx, (size_t)CA * (size_t)G.slotsPer * 16);
+    G.tok = (u32*)kz_arena_alloc(ctx, (size_t)CA * (size_t)G.NS * 4);
+    if (!dText || !dDelim || !dSMap || !dOrd || !dOut || !dCond || !G.mode || !G.fail || !G.stats || !G.tileSum || !G.map || !G.tok) {
+      ctx->arenaTop = mark;                       // no room: the host stage takes the rest
+      if (trace) fprintf(stderr, "[textfwd] no scratch for %d blocks: host stage\n", CA);
+      break;
+    }
+    KZ_HIP(hipMemcpyAsync(dText, hText.data(), hText.size(), hipMemcpyHostToDevice, st));
+    KZ_HIP(hipMemcpyAsync(dDelim, hDelim.data(), 256, hipMemcpyHostToDevice, st));
+    KZ_HIP(hipMemcpyAsync(dSMap, sMap.data(), sMap.size() * 8, hipMemcpyHostToDevice, st));
+    KZ_HIP(hipMemcpyAsync(dOrd, ord.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    KZ_HIP(hipMemsetAsync(dOut, 0xFF, (size_t)B * 4, st));
+    KZ_HIP(hipMemsetAsync(G.stats, 0, (size_t)CA * TF_STATS * 4, st));
+    KZ_HIP(hipMemsetAsync(G.fail, 0, (size_t)CA * 4, st));
+    KZ_HIP(hipMemsetAsync(G.tileSum, 0, (size_t)CA * (size_t)G.maxTiles * 4, st));
+    KZ_HIP(hipMemsetAsync(G.map, 0, (size_t)CA * (size_t)G.slotsPer * 16, st));
+    KZ_HIP(hipMemsetAsync(G.tok, 0, (size_t)CA * (size_t)G.NS * 4, st));
+    G.sText = dText; G.delim = dDelim; G.sMap = dSMap; G.ord = dOrd; G.outLen = dOut;
+    const u8* src = bt.buf[bt.cur]; u8* dst = bt.buf[bt.cur ^ 1];
+    KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_stats, dim3(16, B), dim3(256), src, bt.stride, bt.d_len, G, B);
+    KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_decide, dim3((B + 63) / 64), dim3(64), src, bt.stride, bt.d_len, G, B);
+    KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_init, dim3(2, B), dim3(256), G, B);
+    KZ_LAUNCH(ctx, KID_TEXT_WALK, k_tf_walk, dim3(B), dim3(64), src, bt.stride, bt.d_len, G, B);
+    KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_emit<false>, dim3((G.maxTiles + 3) / 4, B), dim3(256), src, dst, bt.stride, bt.d_len, G, B);
+    KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_scan, dim3(B), dim3(256), bt.d_len, G, B);
+    KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_emit<true>, dim3((G.maxTiles + 3) / 4, B), dim3(256), src, dst, bt.stride, bt.d_len, G, B);
+    std::vector<int32_t> outLen(B);
+    KZ_HIP(hipMemcpyAsync(outLen.data(), dOut, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    KZ_HIP(kz_stream_sync(ctx, st));
+    std::vector<int32_t> cond(B, 0), newLen(bt.h_len);
+    int any = 0;
+    for (int b = 0; b < B; b++) if (ord[b] >= 0 && outLen[b] >= 0) { cond[b] = 1; newLen[b] = outLen[b]; done[b] = 1; any = 1; nDone++; }
+    if (any) {
+      KZ_HIP(hipMemcpyAsync(dCond, cond.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+      KZ_HIP(hipMemcpyAsync(dOut, newLen.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_tf_copy_back, dim3(64, B), dim3(256), 0, st, bt.buf[bt.cur ^ 1], bt.buf[bt.cur], bt.stride, dOut, dCond);
+      for (int b = 0; b < B; b++) bt.h_len[b] = newLen[b];
+      KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+      KZ_HIP(kz_stream_sync(ctx, st));
+    }
+    KZ_HIP(hipGetLastError());
+    ctx->arenaTop = mark;
+  }
+  if (trace) fprintf(stderr, "[textfwd] took %d blocks, finished %d\n", A, nDone);
+  return 0;
+}

@@ -1596,3 +1596,48 @@ def test_utf_inverse_on_the_device(ctx, chain, ent, monkeypatch, capfd):
     took = [int(l.split()[2]) for l in err.splitlines() if l.startswith("[utfgpu]")]
     fin = [int(l.split()[5]) for l in err.splitlines() if l.startswith("[utfgpu]")]
     assert took and sum(fin) > 0 and sum(fin) >= sum(took) // 2, err[-400:]
+
+
+# ---- round 5: the TEXT forward on the device (kz_text_fwd_gpu.hip) ----
+def _text_fwd_blocks(bs):
+    c = textgen.cases()
+    data = (c["english"][:400000] + c["utf8"][:50000] + c["random"][:40000] + c["english_crlf"][:150000] + c["xml"][:200000] + c["english_escapes"][:120000]
+            + c["many_words"][:600000] + datagen.stream(2, 30000).tobytes() + c["gif_magic_text"] + c["spaces_then_text"] + c["short"] + c["min"]
+            + b" " * 70 + c["english"][1000:90000] + b"the the  the The tHe the.The\r\nthe\rthe\n" * 3000 + c["english"][:5000].upper() + c["english"][5000:40000])
+    return [data[i:i + bs] for i in range(0, len(data), bs)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chain,ent", [("TEXT", "NONE"), ("TEXT+UTF", "HUFFMAN"), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0"), ("TEXT", "FPAQ")])
+def test_text_forward_on_the_device(ctx, chain, ent, monkeypatch, capfd):
+    """Blocks of English, CRLF text, XML, escape bytes, many invented words (the word list doubles), runs of spaces, repeated short
+    words around the three-letter rule, upper-case text (the flipped-case lookups), UTF-8, binary, Magic-tagged and short blocks go
+    through kz_encode_blocks with the TEXT forward running on the device (k_tf_*: TextCodec2 streams; FPAQ's TextCodec1 stays on the
+    host): block streams, skip flags and lengths equal the oracle's, and the trace shows that the device took and finished blocks
+    (what it declines -- not text, too close to the block's length -- goes through the host stage)."""
+    monkeypatch.setenv("KZ_TEXT_FWD_GPU", "1")
+    monkeypatch.setenv("KZ_TEXT_GPU_TRACE", "1")
+    ctx = kz.Context(0)                                               # (its own "blockSize" entry)
+    for bs in (32768, 1 << 20):
+        ctx.set_block_size(bs)
+        blocks = _text_fwd_blocks(bs)
+        B = len(blocks)
+        inp = np.zeros((B, bs), dtype=np.uint8)
+        lens = np.array([len(d) for d in blocks], dtype=np.int32)
+        for i, d in enumerate(blocks):
+            inp[i, :len(d)] = np.frombuffer(d, dtype=np.uint8)
+        ostride = kz.max_block_stream_bytes(bs)
+        out = np.zeros((B, ostride), dtype=np.uint8)
+        res = kz.encode_blocks(ctx, chain, ent, inp, bs, lens, out, ostride)
+        for i, d in enumerate(blocks):
+            so, w, sf, pl = oracle.encode_block(chain, ent, d, block_size=bs)
+            assert res[i].status == 0 and (res[i].bits, res[i].skipFlags, res[i].length) == (w, sf, pl), (chain, ent, bs, i, len(d))
+            assert out[i, :(w + 7) // 8].tobytes() == so, (chain, ent, bs, i)
+    ctx.close()
+    err = capfd.readouterr().err
+    took = [int(l.split()[2]) for l in err.splitlines() if l.startswith("[textfwd] took")]
+    fin = [int(l.split()[5]) for l in err.splitlines() if l.startswith("[textfwd] took")]
+    if ent != "FPAQ":
+        assert took and sum(fin) >= sum(took) // 2, err[-400:]
+    else:
+        assert not took
