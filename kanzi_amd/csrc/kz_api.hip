@@ -588,6 +588,7 @@ struct HostFwd {
   const uint8_t* hsrc; int64_t hstride;             // the blocks in host memory
   const int32_t* lengths; const int32_t* copy;      // copy: blocks the chain does not apply to (null: those of <= 15 bytes)
   HostPre* P;
+  const uint8_t* const* ptrs = nullptr;             // a LIST of blocks instead (block k at ptrs[k]; hsrc / hstride unused)
 };
 static void host_forward_block(int b, void* arg) {
   HostFwd& H = *(HostFwd*)arg;
@@ -600,7 +601,8 @@ static void host_forward_block(int b, void* arg) {
   if (n == 0 || (H.copy ? H.copy[b] != 0 : n <= 15)) return;
   static thread_local std::vector<uint8_t> bufA;
   if ((int)bufA.size() < H.cap + 64) bufA.resize((size_t)H.cap + 64);
-  const uint8_t* cur = H.hsrc + (int64_t)b * H.hstride;
+  const uint8_t* const origin = H.ptrs ? H.ptrs[b] : H.hsrc + (int64_t)b * H.hstride;
+  const uint8_t* cur = origin;
   int dt = kz_host_block_data_type(cur, n, KZ_DT_UNDEFINED);            // CompressedOutputStream.java:795-804
   int len = n;
   uint8_t* mine = P.store + (int64_t)b * P.slot;
@@ -613,7 +615,7 @@ static void host_forward_block(int b, void* arg) {
     out = (out == mine) ? bufA.data() : mine;
   }
   P.dtype[b] = dt;
-  if (cur != H.hsrc + (int64_t)b * H.hstride) {                         // a stage applied
+  if (cur != origin) {                                                  // a stage applied
     if (cur != mine) memcpy(mine, cur, (size_t)len);
     P.changed[b] = 1;
     P.outLen[b] = len;
@@ -632,6 +634,20 @@ static void host_prestage(const int* types, int hp, int entropy, int blockSize, 
   H.types = types; H.hp = hp; H.entropy = entropy; H.cap = cap; H.blockSize = blockSize;
   H.hsrc = hsrc; H.hstride = hstride; H.lengths = lengths; H.copy = copy; H.P = &P;
   kz_parallel_for(B, KZ_HOST_STAGE_THREADS, host_forward_block, &H);
+}
+// the same over a list of blocks (block k at ptrs[k], lengths[k] bytes): the results are numbered like the list
+static void host_prestage_list(const int* types, int hp, int entropy, int blockSize, int cap, const std::vector<const uint8_t*>& ptrs,
+                               const std::vector<int32_t>& lengths, HostPre& P) {
+  const int K = (int)ptrs.size();
+  P.outLen.assign(K, 0); P.skip.assign(K, 0xFF); P.dtype.assign(K, 0); P.changed.assign(K, 0);
+  P.slot = host_pre_slot(cap);
+  P.own.reset(new uint8_t[(size_t)P.slot * (size_t)std::max(K, 1) + 64]); P.store = P.own.get();
+  if (K == 0) return;
+  std::vector<int32_t> none(K, 0);
+  HostFwd H;
+  H.types = types; H.hp = hp; H.entropy = entropy; H.cap = cap; H.blockSize = blockSize;
+  H.hsrc = nullptr; H.hstride = 0; H.lengths = lengths.data(); H.copy = none.data(); H.P = &P; H.ptrs = ptrs.data();
+  kz_parallel_for(K, KZ_HOST_STAGE_THREADS, host_forward_block, &H);
 }
 HostPre* kz_host_prestage(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize, const uint8_t* hsrc, int64_t hstride,
                           const int32_t* lengths, int32_t nBlocks, int slotId) {
@@ -1204,50 +1220,91 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
     // there) go on to the GPU stages
     hipEvent_t e0; kz_stage_begin(ctx, &e0);
     HostPre mine;
-    // TEXT forward on the device for the blocks it takes and finishes (they are rewritten in their slots; hashes and Magic tags were
-    // taken from the original bytes above, on the same stream); whatever it leaves goes through the host stages as before
+    // TEXT forward on the device (kz_text_fwd_gpu.hip) for the blocks it keeps after its statistics and finishes: they are rewritten
+    // in their slots (hashes and Magic tags were taken from the original bytes above, on the same stream).  The host stages run on
+    // the blocks it does not keep WHILE its walk runs, then on the few it kept and could not finish.
     std::vector<int32_t> gpuDone(B, 0);
+    std::vector<int> listOf(B, -1), listIdx(B, -1);                               // block -> (host pass, index in that pass's list)
+    HostPre passP[2];
     if (textFwdGpu) {
-      std::vector<int32_t> take(B);
+      std::unique_ptr<TextFwdJob, void (*)(TextFwdJob*)> J(kz_text_fwd_gpu_new(), kz_text_fwd_gpu_free);
+      std::vector<int32_t> take(B), keeps;
       for (int b = 0; b < B; b++) take[b] = (!h_copy[b] && lengths[b] > 0) ? 1 : 0;
-      rc = kz_stage_text_forward_gpu(ctx, bt, blockSize, take, gpuDone);
+      rc = kz_text_fwd_gpu_classify(ctx, bt, blockSize, take, keeps, *J);
       if (rc) return rc;
-    }
-    if (!pre) {
-      std::vector<int32_t> notHost(h_copy);                                       // blocks the host stages leave alone
-      for (int b = 0; b < B; b++) if (gpuDone[b]) notHost[b] = 1;
+      kz_ctx::Stage& stg = ctx->hsIn[0];                                           // pinned staging for device input
+      auto host_pass = [&](int pass, const std::vector<int>& blocks, bool overlap) -> int {
+        std::vector<const uint8_t*> ptrs(blocks.size());
+        std::vector<int32_t> lens(blocks.size());
+        if (!host && !blocks.empty()) {
+          int r2 = kz_stage_reserve(ctx, stg, (size_t)blocks.size() * (size_t)maxN + 64, true);
+          if (r2) return r2;
+        }
+        for (size_t k = 0; k < blocks.size(); k++) {
+          const int b = blocks[k];
+          lens[k] = lengths[b];
+          listOf[b] = pass; listIdx[b] = (int)k;
+          if (host) ptrs[k] = in + (int64_t)b * inStride;
+          else {
+            ptrs[k] = stg.p + k * (size_t)maxN;
+            KZ_HIP(hipMemcpyAsync(stg.p + k * (size_t)maxN, in + (int64_t)b * inStride, (size_t)lengths[b], hipMemcpyDeviceToHost, st));
+          }
+        }
+        if (overlap) {                                                             // the copies are queued in front of the walk: wait for them only
+          hipEvent_t ev = kz_ev(ctx);
+          KZ_HIP(hipEventRecord(ev, st));
+          int r2 = kz_text_fwd_gpu_launch(ctx, bt, *J);
+          if (r2) return r2;
+          KZ_HIP(hipEventSynchronize(ev));
+          ctx->evPool.push_back(ev);
+        } else KZ_HIP(kz_stream_sync(ctx, st));
+        host_prestage_list(types, hp, (int)entropyType, blockSize, maxLen, ptrs, lens, passP[pass]);
+        return 0;
+      };
+      std::vector<int> first, second;
+      for (int b = 0; b < B; b++) if (take[b] && !keeps[b]) first.push_back(b);
+      rc = host_pass(0, first, true);
+      if (rc) return rc;
+      rc = kz_text_fwd_gpu_finish(ctx, bt, *J, gpuDone);
+      if (rc) return rc;
+      for (int b = 0; b < B; b++) if (take[b] && keeps[b] && !gpuDone[b]) second.push_back(b);
+      if (!second.empty()) { rc = host_pass(1, second, false); if (rc) return rc; }
+    } else if (!pre) {
       std::unique_ptr<uint8_t[]> hostCopy;
       const uint8_t* hsrc = in;
       int64_t hstride = inStride;
       if (!host) {
         hostCopy.reset(new uint8_t[(size_t)B * (size_t)maxN + 64]);
         for (int b = 0; b < B; b++)
-          if (lengths[b] && !notHost[b]) KZ_HIP(hipMemcpyAsync(hostCopy.get() + (size_t)b * maxN, in + (int64_t)b * inStride, (size_t)lengths[b], hipMemcpyDeviceToHost, st));
+          if (lengths[b]) KZ_HIP(hipMemcpyAsync(hostCopy.get() + (size_t)b * maxN, in + (int64_t)b * inStride, (size_t)lengths[b], hipMemcpyDeviceToHost, st));
         hsrc = hostCopy.get(); hstride = maxN;
         KZ_HIP(kz_stream_sync(ctx, st));
       }
-      host_prestage(types, hp, (int)entropyType, blockSize, maxLen, hsrc, hstride, lengths, notHost.data(), B, mine);
+      host_prestage(types, hp, (int)entropyType, blockSize, maxLen, hsrc, hstride, lengths, h_copy.data(), B, mine);
       pre = &mine;
     }
     KZ_HIP(kz_stream_sync(ctx, st));                                            // the blocks are in HBM, hashed and tagged: slots may be rewritten
+    std::vector<int32_t> dts(B, KZ_DT_UNDEFINED);
     for (int b = 0; b < B; b++) {
       h_mask[b] = 0;
       if (h_copy[b]) { bt.h_len[b] = lengths[b]; continue; }                     // (a pre-staged block of <= 15 bytes was left alone as well)
-      if (gpuDone[b]) { h_skip[b] = 0xFF & ~(1 << 7); continue; }                // TEXT applied on the device (length set there); UTF declines a block tagged TEXT (UTFCodec.java:93-101)
-      h_skip[b] = pre->skip[b];
-      bt.h_len[b] = pre->outLen[b];
-      if (pre->changed[b] && pre->outLen[b] > 0) {
-        if (pre->pinned) h_mask[b] = 1;
-        else KZ_HIP(hipMemcpyAsync(bt.buf[0] + (int64_t)b * bt.stride, pre->data(b), (size_t)pre->outLen[b], hipMemcpyHostToDevice, st));
+      if (gpuDone[b]) { h_skip[b] = 0xFF & ~(1 << 7); dts[b] = KZ_DT_TEXT; continue; }   // TEXT applied on the device (length set there: TextCodec.java:667); UTF declines a block tagged TEXT (UTFCodec.java:93-101)
+      const HostPre* q = pre;
+      int k = b;
+      if (textFwdGpu) { if (listOf[b] < 0) { bt.h_len[b] = lengths[b]; continue; } q = &passP[listOf[b]]; k = listIdx[b]; }
+      h_skip[b] = q->skip[k];
+      dts[b] = q->dtype[k];
+      bt.h_len[b] = q->outLen[k];
+      if (q->changed[k] && q->outLen[k] > 0) {
+        if (q->pinned) h_mask[b] = 1;
+        else KZ_HIP(hipMemcpyAsync(bt.buf[0] + (int64_t)b * bt.stride, q->data(k), (size_t)q->outLen[k], hipMemcpyHostToDevice, st));
       }
     }
     KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-    if (pre->pinned) {                                                          // the stages' outputs sit in pinned slots: one gather kernel reads them in place
+    if (pre && pre->pinned) {                                                   // the stages' outputs sit in pinned slots: one gather kernel reads them in place
       KZ_HIP(hipMemcpyAsync(P.d_mask, h_mask.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
       KZ_LAUNCH(ctx, KID_COPY_BYTES, k_copy_bytes, dim3(64, B), dim3(256), pre->store, pre->slot, bt.buf[0], bt.stride, bt.d_len, (const int32_t*)nullptr, P.d_mask);
     }
-    std::vector<int32_t> dts(pre->dtype);
-    for (int b = 0; b < B; b++) if (gpuDone[b]) dts[b] = KZ_DT_TEXT;             // TextCodec.java:667
     KZ_HIP(hipMemcpyAsync(bt.d_dtype, dts.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     KZ_HIP(kz_stream_sync(ctx, st));                                            // pageable sources; `mine` and `dts` are locals
     kz_stage_end(ctx, e0, KZ_STAGE_HOST_FWD, 0);

@@ -178,7 +178,12 @@ int kz_host_transform_inverse(int type, int blockSize, const uint8_t* src, int n
 size_t kz_text_gpu_scratch_per_block(int blockSize);
 // kz_text_fwd_gpu.hip: the TEXT forward (TextCodec2) of blocks that sit in HBM (done[b] = 1 for the blocks it finished; the others: host stage)
 size_t kz_text_fwd_gpu_scratch(int B, int blockSize, int maxLen);
-int kz_stage_text_forward_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, const std::vector<int32_t>& take, std::vector<int32_t>& done);
+struct TextFwdJob;
+TextFwdJob* kz_text_fwd_gpu_new();
+void kz_text_fwd_gpu_free(TextFwdJob*);
+int kz_text_fwd_gpu_classify(kz_ctx* ctx, kz_batch& bt, int blockSize, const std::vector<int32_t>& take, std::vector<int32_t>& keeps, TextFwdJob& J);
+int kz_text_fwd_gpu_launch(kz_ctx* ctx, kz_batch& bt, TextFwdJob& J);
+int kz_text_fwd_gpu_finish(kz_ctx* ctx, kz_batch& bt, TextFwdJob& J, std::vector<int32_t>& done);
 size_t kz_utf_gpu_scratch_per_block(int maxLen);
 int kz_stage_utf_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int dstCap, const std::vector<int32_t>& take, std::vector<int32_t>& done);
 int kz_stage_text_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, int dstCap, bool variant1, const std::vector<int32_t>& take, std::vector<int32_t>& done, int form);

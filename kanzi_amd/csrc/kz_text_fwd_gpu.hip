@@ -55,9 +55,10 @@ void kz_text_static_tables(std::vector<uint32_t>& hash, std::vector<int32_t>& po
 #define TF_MARGIN 8
 
 struct TextFwd {
-  const u8* sText; const u8* delim; const u64* sMap; int sMapN; int sCount;   // static dictionary: text, delimiter set, (slot, e0, e1) triples
+  const u8* sText; const u8* delim; const u64* sMap; const int32_t* sPos; int sMapN; int sCount;   // static dictionary: text, delimiter set, (slot, e0, e1) triples
   u64* map;            // [A][slotsPer][2]: hash | (length << 24 | number) << 32,  position | valid << 32 | static << 33
   u32* tok;            // [A][NS]
+  u32* wpos;           // [A][TF_MAXDICT] position of a learned word's first letter, by word number
   int32_t* tileSum;    // [A][maxTiles] output bytes per tile, then their exclusive prefix
   int32_t* stats;      // [A][TF_STATS]
   int32_t* mode;       // [A] the block's mode byte (TextCodec.java:48-52), -1: not for the device
@@ -161,6 +162,15 @@ __global__ __launch_bounds__(256) void k_tf_init(TextFwd G, int B) {
 #define TF_STATIC (1ULL << 33)
 
 // ---- the walk: which words are found, under which number ----
+// One row of 64 bytes per step.  A lane whose byte closes a word (a delimiter behind 2 .. 31 letters) takes the word's letters from an
+// LDS ring (the previous row and this one) into registers, hashes it both ways and requests the two map entries; the NEXT row is
+// prepared and its entries requested before this row's are looked at, so the map's latency is paid once per two rows.  A lookup that
+// matches hash and length counts as found here; that the letters match too (sameWords :720-723) is checked for every found word by
+// k_tf_verify afterwards, in parallel -- a block with a single mismatch (a 32-bit hash collision at equal length) goes to the host
+// stage whole, so the speculation never shows.  Rows in which a word could be learned replay their words one by one from that word
+// on with fresh loads; the next row's entries are then requested again.
+struct TfRow { uint64_t candM; u32 h1, h2; int len, ws; u64 a0, a1, b0, b1; bool cand; };
+
 __global__ __launch_bounds__(64) void k_tf_walk(const u8* __restrict__ srcAll, int64_t stride, const int32_t* __restrict__ d_len, TextFwd G, int B) {
   const int b = blockIdx.x;
   if (b >= B) return;
@@ -171,8 +181,10 @@ __global__ __launch_bounds__(64) void k_tf_walk(const u8* __restrict__ srcAll, i
   const u8* src = srcAll + (int64_t)b * stride;
   u64* map = G.map + (int64_t)a * G.slotsPer * 2;
   u32* tok = G.tok + (int64_t)a * G.NS;
+  u32* wpos = G.wpos + (int64_t)a * TF_MAXDICT;
   const u32 mask = G.mask;
-  __shared__ u8 ring[128];                        // the previous row and this one: a word is at most 31 letters
+  __shared__ u32 ring32[32];                      // 128 bytes: the previous row and this one (a word is at most 31 letters)
+  u8* ring = (u8*)ring32;
   const uint64_t dm0 = kz_ballot(G.delim[lane] != 0), dm1 = kz_ballot(G.delim[64 + lane] != 0), dm2 = kz_ballot(G.delim[128 + lane] != 0), dm3 = kz_ballot(G.delim[192 + lane] != 0);
 #define TF_DELIM(cc) ((((cc) < 64u ? dm0 : ((cc) < 128u ? dm1 : ((cc) < 192u ? dm2 : dm3))) >> ((cc) & 63u)) & 1ULL)
   const uint64_t lt = kz_lanemask_lt();
@@ -180,103 +192,131 @@ __global__ __launch_bounds__(64) void k_tf_walk(const u8* __restrict__ srcAll, i
   int carry = -1;                                 // position of the last non-letter in front of the row (:694: a letter first = -1 / the last leading space)
   bool failed = false;
   u32 cNext = (lane < n) ? (u32)src[lane] : 0u;
+  // prepare the row at `row`: word ends, hashes, map requests
+#define TF_PREPARE(R, row)                                                                                            \
+  { const u32 c = cNext;                                                                                              \
+    const int p = (row) + lane;                                                                                       \
+    cNext = ((row) + 64 + lane < n) ? (u32)src[(row) + 64 + lane] : 0u;                                               \
+    __syncthreads();                                                                                                  \
+    ring[p & 127] = (u8)c;                                                                                            \
+    __syncthreads();                                                                                                  \
+    const bool inb = p < n;                                                                                           \
+    const bool isT = inb && tf_is_text(c);                                                                            \
+    const uint64_t NT = ~kz_ballot(isT);                                                                              \
+    const uint64_t below = NT & lt;                                                                                   \
+    const int anchor = below ? (row) + 63 - (int)__builtin_clzll(below) : carry;                                      \
+    R.len = p - anchor - 1;                                                                                           \
+    R.ws = anchor + 1;                                                                                                \
+    R.cand = inb && !isT && TF_DELIM(c) && R.len >= 2 && R.len <= TF_MAXWORD;                          /* :704, :708 */ \
+    if (NT) carry = (row) + 63 - (int)__builtin_clzll(NT);                                                            \
+    R.candM = kz_ballot(R.cand);                                                                                      \
+    R.h1 = 0; R.h2 = 0; R.a0 = 0; R.a1 = 0; R.b0 = 0; R.b1 = 0;                                                       \
+    if (R.candM) {                                                                                                    \
+      u32 xw[8];                                                                                                      \
+      { const int wb = (R.ws & 127) >> 2; const u32 sh = (u32)R.ws & 3u;                                              \
+        u32 rr[9];                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 9; i++) rr[i] = ring32[(wb + i) & 31];                                  \
+        _Pragma("unroll") for (int i = 0; i < 8; i++) xw[i] = __builtin_amdgcn_alignbyte(rr[i + 1], rr[i], sh); }     \
+      const u32 w0 = xw[0] & 0xFFu;                                                                    /* :709-718 */ \
+      u32 h1 = TF_HASH1 * TF_HASH1 ^ w0 * TF_HASH2, h2 = TF_HASH1 * TF_HASH1 ^ (w0 ^ 0x20u) * TF_HASH2;               \
+      _Pragma("unroll") for (int k = 1; k < TF_MAXWORD; k++) {                                                        \
+        const bool act = R.cand && k < R.len;                                                                         \
+        if (kz_ballot(act) == 0) break;                                                                               \
+        const u32 t = ((xw[k >> 2] >> (8 * (k & 3))) & 0xFFu) * TF_HASH2;                /* letters: no sign to extend */ \
+        const u32 n1 = h1 * TF_HASH1 ^ t, n2 = h2 * TF_HASH1 ^ t;                                                     \
+        h1 = act ? n1 : h1; h2 = act ? n2 : h2;                                                                       \
+      }                                                                                                               \
+      R.h1 = h1; R.h2 = h2;                                                                                           \
+      if (R.cand) {                                                                                                   \
+        const u32 s1 = h1 & mask, s2 = h2 & mask;                                                                     \
+        R.a0 = tf_ld(map + 2 * (u64)s1); R.a1 = tf_ld(map + 2 * (u64)s1 + 1);                                         \
+        R.b0 = tf_ld(map + 2 * (u64)s2); R.b1 = tf_ld(map + 2 * (u64)s2 + 1);                                         \
+      }                                                                                                               \
+    } }
+  TfRow S, N;
+  TF_PREPARE(S, 0)
   for (int row = 0; row < n && !failed; row += 64) {
-    const u32 c = cNext;
-    const int p = row + lane;
-    cNext = (row + 64 + lane < n) ? (u32)src[row + 64 + lane] : 0u;
-    __syncthreads();
-    ring[p & 127] = (u8)c;
-    __syncthreads();
-    const bool inb = p < n;
-    const bool isT = inb && tf_is_text(c);
-    const uint64_t NT = ~kz_ballot(isT);
-    const uint64_t below = NT & lt;
-    const int anchor = below ? row + 63 - (int)__builtin_clzll(below) : carry;
-    const int len = p - anchor - 1;
-    const bool cand = inb && !isT && TF_DELIM(c) && len >= 2 && len <= TF_MAXWORD;                       // :704, :708
-    if (NT) carry = row + 63 - (int)__builtin_clzll(NT);
-    const uint64_t candM = kz_ballot(cand);
-    if (candM == 0) continue;
-    const int ws = anchor + 1;
-    // ---- both hashes of every word the row closes (:709-718) ----
-    u32 h1 = 0, h2 = 0;
-    if (cand) {
-      const u32 w0 = ring[ws & 127];
-      h1 = TF_HASH1 * TF_HASH1 ^ tf_sx(w0) * TF_HASH2;
-      h2 = TF_HASH1 * TF_HASH1 ^ tf_sx(w0 ^ 0x20u) * TF_HASH2;
-    }
-    for (int k = 1; k < TF_MAXWORD; k++) {
-      const bool act = cand && k < len;
-      if (kz_ballot(act) == 0) break;
-      if (act) { const u32 t = tf_sx(ring[(ws + k) & 127]) * TF_HASH2; h1 = h1 * TF_HASH1 ^ t; h2 = h2 * TF_HASH1 ^ t; }
-    }
-    // ---- lookups, every lane on its own ----
-    u64 a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-    if (cand) {
-      const u32 s1 = h1 & mask, s2 = h2 & mask;
-      a0 = tf_ld(map + 2 * (u64)s1); a1 = tf_ld(map + 2 * (u64)s1 + 1);
-      b0 = tf_ld(map + 2 * (u64)s2); b1 = tf_ld(map + 2 * (u64)s2 + 1);
-    }
-    const bool v1 = (a1 & TF_VALID) != 0, v2 = (b1 & TF_VALID) != 0;
-    const bool m1 = cand && v1 && (u32)a0 == h1 && (int)(a0 >> 56) == len;
-    const bool m2 = cand && !m1 && v2 && (u32)b0 == h2 && (int)(b0 >> 56) == len;
-    const u64 e0 = m1 ? a0 : b0, e1 = m1 ? a1 : b1;
-    bool have = m1 || m2;
-    {                                             // sameWords on everything but the first letter (:720-723)
-      const u8* base = ((e1 & TF_STATIC) ? G.sText : src) + (int64_t)(u32)e1;
-      bool neq = false;
-      for (int k = 1; k < TF_MAXWORD; k++) {
-        const bool act = have && k < len;
-        if (kz_ballot(act) == 0) break;
-        if (act) neq |= ring[(ws + k) & 127] != base[k];
-      }
-      have = have && !neq;
-    }
-    bool found = have;
-    u32 number = (u32)(e0 >> 32) & 0x00FFFFFFu;
-    bool flip = m2 && !(v1 && ((u32)(a0 >> 32) & 0x00FFFFFFu) == number);                               // :761 `e == e1`: the same entry through both slots
-    // ---- rows that can learn a word: from that word on, one word at a time ----
-    const uint64_t learnM = kz_ballot(cand && !found && !v1 && (len > 3 || (len == 3 && words < TF_T2)));
-    if (learnM) {
-      uint64_t rest = candM & ~((1ULL << (int)__builtin_ctzll(learnM)) - 1ULL);
-      while (rest) {
-        const int j = (int)__builtin_ctzll(rest);
-        rest &= rest - 1;
-        const u32 uh1 = (u32)__builtin_amdgcn_readlane((int)h1, j), uh2 = (u32)__builtin_amdgcn_readlane((int)h2, j);
-        const int ulen = __builtin_amdgcn_readlane(len, j), uws = __builtin_amdgcn_readlane(ws, j);
-        const u32 us1 = uh1 & mask, us2 = uh2 & mask;
-        const u64 ua0 = tf_ld(map + 2 * (u64)us1), ua1 = tf_ld(map + 2 * (u64)us1 + 1);
-        const u64 ub0 = tf_ld(map + 2 * (u64)us2), ub1 = tf_ld(map + 2 * (u64)us2 + 1);
-        const bool uv1 = (ua1 & TF_VALID) != 0, uv2 = (ub1 & TF_VALID) != 0;
-        const bool um1 = uv1 && (u32)ua0 == uh1 && (int)(ua0 >> 56) == ulen;
-        const bool um2 = !um1 && uv2 && (u32)ub0 == uh2 && (int)(ub0 >> 56) == ulen;
-        const u64 ue0 = um1 ? ua0 : ub0, ue1 = um1 ? ua1 : ub1;
-        bool ufound = um1 || um2;
-        if (ufound) {                             // the letters behind the first, one per lane
-          const u8* base = ((ue1 & TF_STATIC) ? G.sText : src) + (int64_t)(u32)ue1;
-          const bool d = lane >= 1 && lane < ulen && ring[(uws + lane) & 127] != base[lane];
-          ufound = kz_ballot(d) == 0;
-        }
-        const u32 unum = (u32)(ue0 >> 32) & 0x00FFFFFFu;
-        const bool uflip = um2 && !(uv1 && ((u32)(ua0 >> 32) & 0x00FFFFFFu) == unum);
-        if (!ufound && !uv1 && (ulen > 3 || (ulen == 3 && words < TF_T2))) {                             // :725-747
-          // the word takes the next number; that number's record is a fresh one (hash 0): its "old" slot, slot 0, leaves the map (:729-731)
-          if (lane == 0) {
-            tf_st(map + 1, 0ULL);
-            tf_st(map + 2 * (u64)us1, (u64)uh1 | ((u64)(((u32)ulen << 24) | (u32)words) << 32));
-            tf_st(map + 2 * (u64)us1 + 1, (u64)(u32)uws | TF_VALID);
+    N.candM = 0; N.cand = false; N.h1 = N.h2 = 0; N.len = 0; N.ws = 0; N.a0 = N.a1 = N.b0 = N.b1 = 0;
+    if (row + 64 < n) TF_PREPARE(N, row + 64)
+    if (S.candM) {
+      const bool v1 = (S.a1 & TF_VALID) != 0, v2 = (S.b1 & TF_VALID) != 0;
+      const bool m1 = S.cand && v1 && (u32)S.a0 == S.h1 && (int)(S.a0 >> 56) == S.len;
+      const bool m2 = S.cand && !m1 && v2 && (u32)S.b0 == S.h2 && (int)(S.b0 >> 56) == S.len;
+      const u64 e0 = m1 ? S.a0 : S.b0;
+      bool found = m1 || m2;
+      u32 number = (u32)(e0 >> 32) & 0x00FFFFFFu;
+      bool flip = m2 && !(v1 && ((u32)(S.a0 >> 32) & 0x00FFFFFFu) == number);                           // :761 `e == e1`: the same entry through both slots
+      // ---- a row that can learn a word: from that word on, one word at a time ----
+      const uint64_t learnM = kz_ballot(S.cand && !found && !v1 && (S.len > 3 || (S.len == 3 && words < TF_T2)));
+      if (learnM) {
+        uint64_t rest = S.candM & ~((1ULL << (int)__builtin_ctzll(learnM)) - 1ULL);
+        bool learned = false;
+        while (rest) {
+          const int j = (int)__builtin_ctzll(rest);
+          rest &= rest - 1;
+          const u32 uh1 = (u32)__builtin_amdgcn_readlane((int)S.h1, j), uh2 = (u32)__builtin_amdgcn_readlane((int)S.h2, j);
+          const int ulen = __builtin_amdgcn_readlane(S.len, j), uws = __builtin_amdgcn_readlane(S.ws, j);
+          const u32 us1 = uh1 & mask, us2 = uh2 & mask;
+          const u64 ua0 = tf_ld(map + 2 * (u64)us1), ua1 = tf_ld(map + 2 * (u64)us1 + 1);
+          const u64 ub0 = tf_ld(map + 2 * (u64)us2), ub1 = tf_ld(map + 2 * (u64)us2 + 1);
+          const bool uv1 = (ua1 & TF_VALID) != 0, uv2 = (ub1 & TF_VALID) != 0;
+          const bool um1 = uv1 && (u32)ua0 == uh1 && (int)(ua0 >> 56) == ulen;
+          const bool um2 = !um1 && uv2 && (u32)ub0 == uh2 && (int)(ub0 >> 56) == ulen;
+          const u64 ue0 = um1 ? ua0 : ub0;
+          const bool ufound = um1 || um2;
+          const u32 unum = (u32)(ue0 >> 32) & 0x00FFFFFFu;
+          const bool uflip = um2 && !(uv1 && ((u32)(ua0 >> 32) & 0x00FFFFFFu) == unum);
+          if (!ufound && !uv1 && (ulen > 3 || (ulen == 3 && words < TF_T2))) {                           // :725-747
+            // the word takes the next number; that number's record is a fresh one (hash 0): its "old" slot, slot 0, leaves the map (:729-731)
+            if (lane == 0) {
+              tf_st(map + 1, 0ULL);
+              tf_st(map + 2 * (u64)us1, (u64)uh1 | ((u64)(((u32)ulen << 24) | (u32)words) << 32));
+              tf_st(map + 2 * (u64)us1 + 1, (u64)(u32)uws | TF_VALID);
+              wpos[words] = (u32)uws;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            learned = true;
+            words++;
+            if (words >= TF_MAXDICT - 1) { failed = true; break; }                                       // the numbering would restart (:742-746): host stage
           }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          words++;
-          if (words >= TF_MAXDICT - 1) { failed = true; break; }                                         // the numbering would restart (:742-746): host stage
+          if (lane == j) { found = ufound; number = unum; flip = uflip; }
         }
-        if (lane == j) { found = ufound; number = unum; flip = uflip; }
+        if (learned && N.cand) {                  // the next row's entries were requested before this row learned
+          const u32 s1 = N.h1 & mask, s2 = N.h2 & mask;
+          N.a0 = tf_ld(map + 2 * (u64)s1); N.a1 = tf_ld(map + 2 * (u64)s1 + 1);
+          N.b0 = tf_ld(map + 2 * (u64)s2); N.b1 = tf_ld(map + 2 * (u64)s2 + 1);
+        }
       }
+      if (found && S.cand) tok[S.ws] = (number + 1u) | ((u32)S.len << 24) | (flip ? 0x80000000u : 0u);
     }
-    if (found && cand) tok[ws] = (number + 1u) | ((u32)len << 24) | (flip ? 0x80000000u : 0u);
+    S = N;
   }
-  if (lane == 0) G.fail[a] = failed ? 1 : 0;
+  if (lane == 0 && failed) G.fail[a] = 1;
+#undef TF_PREPARE
 #undef TF_DELIM
+}
+
+// every found word's letters behind the first against the letters of the dictionary word it was matched with (sameWords :720-723:
+// the walk went by hash and length).  A mismatch fails the block (host stage).
+__global__ __launch_bounds__(256) void k_tf_verify(const u8* __restrict__ srcAll, int64_t stride, const int32_t* __restrict__ d_len, TextFwd G, int B) {
+  const int b = blockIdx.y;
+  const int a = G.ord[b];
+  if (a < 0 || G.mode[a] < 0) return;
+  const int n = d_len[b];
+  const int base = blockIdx.x * 4096;
+  if (base >= n) return;
+  const u8* src = srcAll + (int64_t)b * stride;
+  const u32* tok = G.tok + (int64_t)a * G.NS;
+  const u32* wpos = G.wpos + (int64_t)a * TF_MAXDICT;
+  bool bad = false;
+  for (int p = base + threadIdx.x; p < min(n, base + 4096); p += 256) {
+    const u32 t = tok[p];
+    if (t == 0) continue;
+    const int number = (int)(t & 0x00FFFFFFu) - 1, len = (int)((t >> 24) & 31u);
+    const u8* w = (number < G.sCount) ? G.sText + G.sPos[number] : src + wpos[number];
+    for (int k = 1; k < len; k++) bad |= src[p + k] != w[k];
+  }
+  if (bad) G.fail[a] = 1;
 }
 
 // ---- output: sizes per tile, then the bytes (:752-771 between the words, emitSymbols :1304-1367, emitWordIndex :1370-1394) ----
@@ -373,29 +413,45 @@ __global__ __launch_bounds__(256) void k_tf_copy_back(const u8* __restrict__ src
 }
 
 static int tf_log_v2(int blockSize) { int l = 13; if (blockSize >= 32) l = std::max(std::min(31 - __builtin_clz((unsigned)(blockSize / 32)), 24), 13); return l; }   // :1068-1081
-#define TF_CHUNK 1024            // blocks per pass: 4 bytes of `tok` per input byte and 16 bytes per hash slot are scratch
 
-// bytes of scratch the stage wants for a batch of B blocks of at most maxLen bytes (kz_api.hip sizes the arena with it)
+// bytes of scratch the stage wants for a batch of B blocks of at most maxLen bytes, all of them text (kz_api.hip sizes the arena with it):
+// 4 bytes of `tok` per input byte, 16 bytes per hash slot and 4 per word number
 size_t kz_text_fwd_gpu_scratch(int B, int blockSize, int maxLen) {
-  const size_t ch = (size_t)std::min(B, TF_CHUNK);
   const size_t NS = kz_align((size_t)maxLen + 64, 256);
-  return ch * (NS * 4 + ((size_t)32 << tf_log_v2(blockSize)) + (size_t)(maxLen / TF_TILE + 2) * 4 + TF_STATS * 4 + 64) + (size_t)B * 16 + (1 << 20);
+  return (size_t)B * (NS * 4 + ((size_t)32 << tf_log_v2(blockSize)) + (size_t)TF_MAXDICT * 4 + (size_t)(maxLen / TF_TILE + 2) * 4 + TF_STATS * 4 + 96) + (1 << 20);
 }
 
-// TEXT forward (TextCodec2) of the blocks with take[b] != 0: reads bt.buf[cur] (lengths bt.h_len / bt.d_len), leaves the result of the
-// blocks it finished in the same slots (bt.h_len / bt.d_len updated) and sets done[b] = 1 for them -- their skip bit, and "dataType" =
-// TEXT, are the caller's; every other block is untouched (the host stage takes it).  Returns 0 or a negative error.
-int kz_stage_text_forward_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, const std::vector<int32_t>& take, std::vector<int32_t>& done) {
+// The stage in three steps, so that the caller can run the host stages of the blocks the device does not keep while the walk runs:
+//   kz_text_fwd_gpu_classify: statistics of the blocks with take[b] != 0 in bt.buf[cur]; keeps[b] = 1 for the blocks the device goes on
+//                             with (text by computeStats' rules, no Magic number, 1 KiB .. 16 MiB); the stream is idle on return;
+//   kz_text_fwd_gpu_launch:   queues the walk and the output passes for them (no wait);
+//   kz_text_fwd_gpu_finish:   waits; done[b] = 1 for the blocks that were finished: their bytes are in their slots, bt.h_len / bt.d_len
+//                             updated -- their skip bit, and "dataType" = TEXT, are the caller's; every other block is untouched (host stage).
+// A job that found no room for its scratch keeps nothing.
+struct TextFwdJob {
+  TextFwd G;
+  std::vector<int32_t> ord;
+  int32_t *dOrd = nullptr, *dOut = nullptr, *dCond = nullptr;
+  size_t mark = 0;
+  int A = 0, kept = 0;
+  bool live = false;
+};
+TextFwdJob* kz_text_fwd_gpu_new() { return new TextFwdJob(); }
+void kz_text_fwd_gpu_free(TextFwdJob* J) { delete J; }
+
+int kz_text_fwd_gpu_classify(kz_ctx* ctx, kz_batch& bt, int blockSize, const std::vector<int32_t>& take, std::vector<int32_t>& keeps, TextFwdJob& J) {
   const int B = bt.B;
-  done.assign(B, 0);
-  std::vector<int32_t> ordAll(B, -1);
+  keeps.assign(B, 0);
+  J.ord.assign(B, -1);
+  J.live = false;
   int A = 0, maxLen = 0;
-  for (int b = 0; b < B; b++) if (take[b] && bt.h_len[b] >= TF_MINBLOCK && bt.h_len[b] < TF_MAXBLOCK) { ordAll[b] = A++; maxLen = std::max(maxLen, bt.h_len[b]); }
+  for (int b = 0; b < B; b++) if (take[b] && bt.h_len[b] >= TF_MINBLOCK && bt.h_len[b] < TF_MAXBLOCK) { J.ord[b] = A++; maxLen = std::max(maxLen, bt.h_len[b]); }
+  J.A = A;
   if (A == 0) return 0;
   static std::vector<uint32_t> hHash, hLenIdx; static std::vector<int32_t> hPos; static std::vector<uint8_t> hText, hDelim; static int hCount = -1;
   static std::once_flag once;
   std::call_once(once, [] { kz_text_static_tables(hHash, hPos, hLenIdx, hText, hDelim, &hCount); });
-  TextFwd G;
+  TextFwd& G = J.G;
   const int logV2 = tf_log_v2(blockSize);
   G.slotsPer = (int64_t)1 << logV2; G.mask = (u32)(G.slotsPer - 1);
   G.NS = (int64_t)kz_align((size_t)maxLen + 64, 256);
@@ -415,66 +471,102 @@ int kz_stage_text_forward_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, const st
   }
   G.sMapN = (int)(sMap.size() / 3);
   hipStream_t st = ctx->stream;
-  const bool trace = getenv("KZ_TEXT_GPU_TRACE") != nullptr;
-  int nDone = 0;
-  for (int c0 = 0; c0 < A; c0 += TF_CHUNK) {
-    const int CA = std::min(TF_CHUNK, A - c0);
-    std::vector<int32_t> ord(B, -1);
-    for (int b = 0; b < B; b++) if (ordAll[b] >= c0 && ordAll[b] < c0 + CA) ord[b] = ordAll[b] - c0;
-    const size_t mark = ctx->arenaTop;
-    u8* dText = (u8*)kz_arena_alloc(ctx, hText.size() + 64);
-    u8* dDelim = (u8*)kz_arena_alloc(ctx, 256);
-    u64* dSMap = (u64*)kz_arena_alloc(ctx, sMap.size() * 8 + 64);
-    int32_t* dOrd = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
-    int32_t* dOut = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
-    int32_t* dCond = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
-    G.mode = (int32_t*)kz_arena_alloc(ctx, (size_t)CA * 4);
-    G.fail = (int32_t*)kz_arena_alloc(ctx, (size_t)CA * 4);
-    G.stats = (int32_t*)kz_arena_alloc(ctx, (size_t)CA * TF_STATS * 4);
-    G.tileSum = (int32_t*)kz_arena_alloc(ctx, (size_t)CA * (size_t)G.maxTiles * 4);
-    G.map = (u64*)kz_arena_alloc(ctx, (size_t)CA * (size_t)G.slotsPer * 16);
-    G.tok = (u32*)kz_arena_alloc(ctx, (size_t)CA * (size_t)G.NS * 4);
-    if (!dText || !dDelim || !dSMap || !dOrd || !dOut || !dCond || !G.mode || !G.fail || !G.stats || !G.tileSum || !G.map || !G.tok) {
-      ctx->arenaTop = mark;                       // no room: the host stage takes the rest
-      if (trace) fprintf(stderr, "[textfwd] no scratch for %d blocks: host stage\n", CA);
-      break;
-    }
-    KZ_HIP(hipMemcpyAsync(dText, hText.data(), hText.size(), hipMemcpyHostToDevice, st));
-    KZ_HIP(hipMemcpyAsync(dDelim, hDelim.data(), 256, hipMemcpyHostToDevice, st));
-    KZ_HIP(hipMemcpyAsync(dSMap, sMap.data(), sMap.size() * 8, hipMemcpyHostToDevice, st));
-    KZ_HIP(hipMemcpyAsync(dOrd, ord.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-    KZ_HIP(hipMemsetAsync(dOut, 0xFF, (size_t)B * 4, st));
-    KZ_HIP(hipMemsetAsync(G.stats, 0, (size_t)CA * TF_STATS * 4, st));
-    KZ_HIP(hipMemsetAsync(G.fail, 0, (size_t)CA * 4, st));
-    KZ_HIP(hipMemsetAsync(G.tileSum, 0, (size_t)CA * (size_t)G.maxTiles * 4, st));
-    KZ_HIP(hipMemsetAsync(G.map, 0, (size_t)CA * (size_t)G.slotsPer * 16, st));
-    KZ_HIP(hipMemsetAsync(G.tok, 0, (size_t)CA * (size_t)G.NS * 4, st));
-    G.sText = dText; G.delim = dDelim; G.sMap = dSMap; G.ord = dOrd; G.outLen = dOut;
-    const u8* src = bt.buf[bt.cur]; u8* dst = bt.buf[bt.cur ^ 1];
-    KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_stats, dim3(16, B), dim3(256), src, bt.stride, bt.d_len, G, B);
-    KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_decide, dim3((B + 63) / 64), dim3(64), src, bt.stride, bt.d_len, G, B);
-    KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_init, dim3(2, B), dim3(256), G, B);
-    KZ_LAUNCH(ctx, KID_TEXT_WALK, k_tf_walk, dim3(B), dim3(64), src, bt.stride, bt.d_len, G, B);
-    KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_emit<false>, dim3((G.maxTiles + 3) / 4, B), dim3(256), src, dst, bt.stride, bt.d_len, G, B);
-    KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_scan, dim3(B), dim3(256), bt.d_len, G, B);
-    KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_emit<true>, dim3((G.maxTiles + 3) / 4, B), dim3(256), src, dst, bt.stride, bt.d_len, G, B);
-    std::vector<int32_t> outLen(B);
-    KZ_HIP(hipMemcpyAsync(outLen.data(), dOut, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    KZ_HIP(kz_stream_sync(ctx, st));
-    std::vector<int32_t> cond(B, 0), newLen(bt.h_len);
-    int any = 0;
-    for (int b = 0; b < B; b++) if (ord[b] >= 0 && outLen[b] >= 0) { cond[b] = 1; newLen[b] = outLen[b]; done[b] = 1; any = 1; nDone++; }
-    if (any) {
-      KZ_HIP(hipMemcpyAsync(dCond, cond.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-      KZ_HIP(hipMemcpyAsync(dOut, newLen.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(k_tf_copy_back, dim3(64, B), dim3(256), 0, st, bt.buf[bt.cur ^ 1], bt.buf[bt.cur], bt.stride, dOut, dCond);
-      for (int b = 0; b < B; b++) bt.h_len[b] = newLen[b];
-      KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-      KZ_HIP(kz_stream_sync(ctx, st));
-    }
-    KZ_HIP(hipGetLastError());
-    ctx->arenaTop = mark;
+  J.mark = ctx->arenaTop;
+  u8* dText = (u8*)kz_arena_alloc(ctx, hText.size() + 64);
+  u8* dDelim = (u8*)kz_arena_alloc(ctx, 256);
+  u64* dSMap = (u64*)kz_arena_alloc(ctx, sMap.size() * 8 + 64);
+  int32_t* dSPos = (int32_t*)kz_arena_alloc(ctx, (size_t)(hCount + 2) * 4);
+  J.dOrd = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  J.dOut = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  J.dCond = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
+  G.mode = (int32_t*)kz_arena_alloc(ctx, (size_t)A * 4);
+  G.fail = (int32_t*)kz_arena_alloc(ctx, (size_t)A * 4);
+  G.stats = (int32_t*)kz_arena_alloc(ctx, (size_t)A * TF_STATS * 4);
+  if (!dText || !dDelim || !dSMap || !dSPos || !J.dOrd || !J.dOut || !J.dCond || !G.mode || !G.fail || !G.stats) { ctx->arenaTop = J.mark; return 0; }
+  KZ_HIP(hipMemcpyAsync(dText, hText.data(), hText.size(), hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemcpyAsync(dDelim, hDelim.data(), 256, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemcpyAsync(dSMap, sMap.data(), sMap.size() * 8, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemcpyAsync(dSPos, hPos.data(), (size_t)(hCount + 2) * 4, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemcpyAsync(J.dOrd, J.ord.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemsetAsync(J.dOut, 0xFF, (size_t)B * 4, st));
+  KZ_HIP(hipMemsetAsync(G.stats, 0, (size_t)A * TF_STATS * 4, st));
+  KZ_HIP(hipMemsetAsync(G.fail, 0, (size_t)A * 4, st));
+  G.sText = dText; G.delim = dDelim; G.sMap = dSMap; G.sPos = dSPos; G.ord = J.dOrd; G.outLen = J.dOut;
+  G.map = nullptr; G.tok = nullptr; G.wpos = nullptr; G.tileSum = nullptr;
+  const u8* src = bt.buf[bt.cur];
+  KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_stats, dim3(16, B), dim3(256), src, bt.stride, bt.d_len, G, B);
+  KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_decide, dim3((B + 63) / 64), dim3(64), src, bt.stride, bt.d_len, G, B);
+  std::vector<int32_t> mode(A);
+  KZ_HIP(hipMemcpyAsync(mode.data(), G.mode, (size_t)A * 4, hipMemcpyDeviceToHost, st));
+  KZ_HIP(kz_stream_sync(ctx, st));              // (also: the pageable sources above)
+  // the blocks that are text get new dense numbers: the big tables are sized by them
+  std::vector<int32_t> ord2(B, -1);
+  int K = 0;
+  for (int b = 0; b < B; b++) if (J.ord[b] >= 0 && mode[J.ord[b]] >= 0) ord2[b] = K++;
+  J.kept = K;
+  if (K == 0) { ctx->arenaTop = J.mark; return 0; }
+  int32_t* dMode2 = (int32_t*)kz_arena_alloc(ctx, (size_t)K * 4);
+  int32_t* dFail2 = (int32_t*)kz_arena_alloc(ctx, (size_t)K * 4);
+  G.tileSum = (int32_t*)kz_arena_alloc(ctx, (size_t)K * (size_t)G.maxTiles * 4);
+  G.wpos = (u32*)kz_arena_alloc(ctx, (size_t)K * TF_MAXDICT * 4);
+  G.map = (u64*)kz_arena_alloc(ctx, (size_t)K * (size_t)G.slotsPer * 16);
+  G.tok = (u32*)kz_arena_alloc(ctx, (size_t)K * (size_t)G.NS * 4);
+  if (!dMode2 || !dFail2 || !G.tileSum || !G.wpos || !G.map || !G.tok) {
+    if (getenv("KZ_TEXT_GPU_TRACE")) fprintf(stderr, "[textfwd] no scratch for %d blocks: host stage\n", K);
+    ctx->arenaTop = J.mark; J.kept = 0; return 0;
   }
-  if (trace) fprintf(stderr, "[textfwd] took %d blocks, finished %d\n", A, nDone);
+  std::vector<int32_t> mode2(K);
+  for (int b = 0; b < B; b++) if (ord2[b] >= 0) { mode2[ord2[b]] = mode[J.ord[b]]; keeps[b] = 1; }
+  J.ord = ord2;
+  KZ_HIP(hipMemcpyAsync(J.dOrd, J.ord.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemcpyAsync(dMode2, mode2.data(), (size_t)K * 4, hipMemcpyHostToDevice, st));
+  KZ_HIP(hipMemsetAsync(dFail2, 0, (size_t)K * 4, st));
+  KZ_HIP(kz_stream_sync(ctx, st));              // pageable sources
+  G.mode = dMode2; G.fail = dFail2;
+  J.live = true;
+  return 0;
+}
+
+int kz_text_fwd_gpu_launch(kz_ctx* ctx, kz_batch& bt, TextFwdJob& J) {
+  if (!J.live) return 0;
+  const int B = bt.B, K = J.kept;
+  TextFwd& G = J.G;
+  hipStream_t st = ctx->stream;
+  KZ_HIP(hipMemsetAsync(G.tileSum, 0, (size_t)K * (size_t)G.maxTiles * 4, st));
+  KZ_HIP(hipMemsetAsync(G.map, 0, (size_t)K * (size_t)G.slotsPer * 16, st));
+  KZ_HIP(hipMemsetAsync(G.tok, 0, (size_t)K * (size_t)G.NS * 4, st));
+  const u8* src = bt.buf[bt.cur]; u8* dst = bt.buf[bt.cur ^ 1];
+  KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_init, dim3(2, B), dim3(256), G, B);
+  KZ_LAUNCH(ctx, KID_TEXT_WALK, k_tf_walk, dim3(B), dim3(64), src, bt.stride, bt.d_len, G, B);
+  KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_verify, dim3((int)((G.NS + 4095) / 4096), B), dim3(256), src, bt.stride, bt.d_len, G, B);
+  KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_emit<false>, dim3((G.maxTiles + 3) / 4, B), dim3(256), src, dst, bt.stride, bt.d_len, G, B);
+  KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_scan, dim3(B), dim3(256), bt.d_len, G, B);
+  KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_emit<true>, dim3((G.maxTiles + 3) / 4, B), dim3(256), src, dst, bt.stride, bt.d_len, G, B);
+  return 0;
+}
+
+int kz_text_fwd_gpu_finish(kz_ctx* ctx, kz_batch& bt, TextFwdJob& J, std::vector<int32_t>& done) {
+  const int B = bt.B;
+  done.assign(B, 0);
+  if (!J.live) return 0;
+  hipStream_t st = ctx->stream;
+  std::vector<int32_t> outLen(B);
+  KZ_HIP(hipMemcpyAsync(outLen.data(), J.dOut, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  KZ_HIP(kz_stream_sync(ctx, st));
+  std::vector<int32_t> cond(B, 0), newLen(bt.h_len);
+  int any = 0, nDone = 0;
+  for (int b = 0; b < B; b++) if (J.ord[b] >= 0 && outLen[b] >= 0) { cond[b] = 1; newLen[b] = outLen[b]; done[b] = 1; any = 1; nDone++; }
+  if (any) {
+    KZ_HIP(hipMemcpyAsync(J.dCond, cond.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    KZ_HIP(hipMemcpyAsync(J.dOut, newLen.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_tf_copy_back, dim3(64, B), dim3(256), 0, st, bt.buf[bt.cur ^ 1], bt.buf[bt.cur], bt.stride, J.dOut, J.dCond);
+    for (int b = 0; b < B; b++) bt.h_len[b] = newLen[b];
+    KZ_HIP(hipMemcpyAsync(bt.d_len, bt.h_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    KZ_HIP(kz_stream_sync(ctx, st));
+  }
+  KZ_HIP(hipGetLastError());
+  if (getenv("KZ_TEXT_GPU_TRACE")) fprintf(stderr, "[textfwd] took %d blocks, finished %d (kept %d after the statistics)\n", J.A, nDone, J.kept);
+  ctx->arenaTop = J.mark;
+  J.live = false;
   return 0;
 }
