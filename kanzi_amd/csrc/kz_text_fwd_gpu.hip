@@ -70,6 +70,7 @@ struct TextFwd {
   u32 mask;
 };
 
+typedef u32 __attribute__((aligned(1))) tf_u32u;
 __device__ __forceinline__ bool tf_is_text(u32 c) { const u32 l = c | 0x20u; return l >= 'a' && l <= 'z'; }     // (c < 256: bytes >= 0x80 never are)
 __device__ __forceinline__ u32 tf_sx(u32 c) { return (u32)(int32_t)(int8_t)c; }                                 // Java's bytes are signed
 __device__ __forceinline__ u64 tf_ld(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -163,12 +164,12 @@ __global__ __launch_bounds__(256) void k_tf_init(TextFwd G, int B) {
 
 // ---- the walk: which words are found, under which number ----
 // One row of 64 bytes per step.  A lane whose byte closes a word (a delimiter behind 2 .. 31 letters) takes the word's letters from an
-// LDS ring (the previous row and this one) into registers, hashes it both ways and requests the two map entries; the NEXT row is
-// prepared and its entries requested before this row's are looked at, so the map's latency is paid once per two rows.  A lookup that
+// LDS ring (the previous row and this one) into registers, hashes it both ways and requests the two map entries; four rows are
+// prepared and their entries requested before the first of them is looked at, so the map's latency is paid once per four rows.  A lookup that
 // matches hash and length counts as found here; that the letters match too (sameWords :720-723) is checked for every found word by
 // k_tf_verify afterwards, in parallel -- a block with a single mismatch (a 32-bit hash collision at equal length) goes to the host
 // stage whole, so the speculation never shows.  Rows in which a word could be learned replay their words one by one from that word
-// on with fresh loads; the next row's entries are then requested again.
+// on with fresh loads; the entries of the rows prepared behind it are then requested again.
 struct TfRow { uint64_t candM; u32 h1, h2; int len, ws; u64 a0, a1, b0, b1; bool cand; };
 
 __global__ __launch_bounds__(64) void k_tf_walk(const u8* __restrict__ srcAll, int64_t stride, const int32_t* __restrict__ d_len, TextFwd G, int B) {
@@ -191,15 +192,13 @@ __global__ __launch_bounds__(64) void k_tf_walk(const u8* __restrict__ srcAll, i
   int words = G.sCount;                           // the next word number (TextCodec2: the static words, nothing else fixed)
   int carry = -1;                                 // position of the last non-letter in front of the row (:694: a letter first = -1 / the last leading space)
   bool failed = false;
-  u32 cNext = (lane < n) ? (u32)src[lane] : 0u;
-  // prepare the row at `row`: word ends, hashes, map requests
-#define TF_PREPARE(R, row)                                                                                            \
-  { const u32 c = cNext;                                                                                              \
+  // prepare the row at `row` (its bytes: cc): word ends, hashes, map requests
+#define TF_PREPARE(R, row, cc)                                                                                        \
+  { const u32 c = (cc);                                                                                               \
     const int p = (row) + lane;                                                                                       \
-    cNext = ((row) + 64 + lane < n) ? (u32)src[(row) + 64 + lane] : 0u;                                               \
-    __syncthreads();                                                                                                  \
+    __builtin_amdgcn_wave_barrier();      /* one wave: its LDS accesses stay in order; a workgroup barrier would also wait for the map loads in flight */ \
     ring[p & 127] = (u8)c;                                                                                            \
-    __syncthreads();                                                                                                  \
+    __builtin_amdgcn_wave_barrier();                                                                                  \
     const bool inb = p < n;                                                                                           \
     const bool isT = inb && tf_is_text(c);                                                                            \
     const uint64_t NT = ~kz_ballot(isT);                                                                              \
@@ -227,72 +226,87 @@ __global__ __launch_bounds__(64) void k_tf_walk(const u8* __restrict__ srcAll, i
         h1 = act ? n1 : h1; h2 = act ? n2 : h2;                                                                       \
       }                                                                                                               \
       R.h1 = h1; R.h2 = h2;                                                                                           \
-      if (R.cand) {                                                                                                   \
-        const u32 s1 = h1 & mask, s2 = h2 & mask;                                                                     \
-        R.a0 = tf_ld(map + 2 * (u64)s1); R.a1 = tf_ld(map + 2 * (u64)s1 + 1);                                         \
-        R.b0 = tf_ld(map + 2 * (u64)s2); R.b1 = tf_ld(map + 2 * (u64)s2 + 1);                                         \
-      }                                                                                                               \
+      TF_REQUEST(R)                                                                                                   \
     } }
-  TfRow S, N;
-  TF_PREPARE(S, 0)
-  for (int row = 0; row < n && !failed; row += 64) {
-    N.candM = 0; N.cand = false; N.h1 = N.h2 = 0; N.len = 0; N.ws = 0; N.a0 = N.a1 = N.b0 = N.b1 = 0;
-    if (row + 64 < n) TF_PREPARE(N, row + 64)
-    if (S.candM) {
-      const bool v1 = (S.a1 & TF_VALID) != 0, v2 = (S.b1 & TF_VALID) != 0;
-      const bool m1 = S.cand && v1 && (u32)S.a0 == S.h1 && (int)(S.a0 >> 56) == S.len;
-      const bool m2 = S.cand && !m1 && v2 && (u32)S.b0 == S.h2 && (int)(S.b0 >> 56) == S.len;
-      const u64 e0 = m1 ? S.a0 : S.b0;
-      bool found = m1 || m2;
-      u32 number = (u32)(e0 >> 32) & 0x00FFFFFFu;
-      bool flip = m2 && !(v1 && ((u32)(S.a0 >> 32) & 0x00FFFFFFu) == number);                           // :761 `e == e1`: the same entry through both slots
-      // ---- a row that can learn a word: from that word on, one word at a time ----
-      const uint64_t learnM = kz_ballot(S.cand && !found && !v1 && (S.len > 3 || (S.len == 3 && words < TF_T2)));
-      if (learnM) {
-        uint64_t rest = S.candM & ~((1ULL << (int)__builtin_ctzll(learnM)) - 1ULL);
-        bool learned = false;
-        while (rest) {
-          const int j = (int)__builtin_ctzll(rest);
-          rest &= rest - 1;
-          const u32 uh1 = (u32)__builtin_amdgcn_readlane((int)S.h1, j), uh2 = (u32)__builtin_amdgcn_readlane((int)S.h2, j);
-          const int ulen = __builtin_amdgcn_readlane(S.len, j), uws = __builtin_amdgcn_readlane(S.ws, j);
-          const u32 us1 = uh1 & mask, us2 = uh2 & mask;
-          const u64 ua0 = tf_ld(map + 2 * (u64)us1), ua1 = tf_ld(map + 2 * (u64)us1 + 1);
-          const u64 ub0 = tf_ld(map + 2 * (u64)us2), ub1 = tf_ld(map + 2 * (u64)us2 + 1);
-          const bool uv1 = (ua1 & TF_VALID) != 0, uv2 = (ub1 & TF_VALID) != 0;
-          const bool um1 = uv1 && (u32)ua0 == uh1 && (int)(ua0 >> 56) == ulen;
-          const bool um2 = !um1 && uv2 && (u32)ub0 == uh2 && (int)(ub0 >> 56) == ulen;
-          const u64 ue0 = um1 ? ua0 : ub0;
-          const bool ufound = um1 || um2;
-          const u32 unum = (u32)(ue0 >> 32) & 0x00FFFFFFu;
-          const bool uflip = um2 && !(uv1 && ((u32)(ua0 >> 32) & 0x00FFFFFFu) == unum);
-          if (!ufound && !uv1 && (ulen > 3 || (ulen == 3 && words < TF_T2))) {                           // :725-747
-            // the word takes the next number; that number's record is a fresh one (hash 0): its "old" slot, slot 0, leaves the map (:729-731)
-            if (lane == 0) {
-              tf_st(map + 1, 0ULL);
-              tf_st(map + 2 * (u64)us1, (u64)uh1 | ((u64)(((u32)ulen << 24) | (u32)words) << 32));
-              tf_st(map + 2 * (u64)us1 + 1, (u64)(u32)uws | TF_VALID);
-              wpos[words] = (u32)uws;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            learned = true;
-            words++;
-            if (words >= TF_MAXDICT - 1) { failed = true; break; }                                       // the numbering would restart (:742-746): host stage
-          }
-          if (lane == j) { found = ufound; number = unum; flip = uflip; }
-        }
-        if (learned && N.cand) {                  // the next row's entries were requested before this row learned
-          const u32 s1 = N.h1 & mask, s2 = N.h2 & mask;
-          N.a0 = tf_ld(map + 2 * (u64)s1); N.a1 = tf_ld(map + 2 * (u64)s1 + 1);
-          N.b0 = tf_ld(map + 2 * (u64)s2); N.b1 = tf_ld(map + 2 * (u64)s2 + 1);
-        }
-      }
-      if (found && S.cand) tok[S.ws] = (number + 1u) | ((u32)S.len << 24) | (flip ? 0x80000000u : 0u);
-    }
-    S = N;
+#define TF_REQUEST(R)                                                                                                 \
+  if (R.cand) {                                                                                                       \
+    const u32 s1_ = R.h1 & mask, s2_ = R.h2 & mask;                                                                   \
+    R.a0 = tf_ld(map + 2 * (u64)s1_); R.a1 = tf_ld(map + 2 * (u64)s1_ + 1);                                           \
+    R.b0 = tf_ld(map + 2 * (u64)s2_); R.b1 = tf_ld(map + 2 * (u64)s2_ + 1);                                           \
+  }
+  // decide the row S (at `row`); `learned` is set when the dictionary changed: the rows prepared behind it ask again
+#define TF_DECIDE(S)                                                                                                  \
+  if (S.candM && !failed) {                                                                                           \
+    const bool v1 = (S.a1 & TF_VALID) != 0, v2 = (S.b1 & TF_VALID) != 0;                                              \
+    const bool m1 = S.cand && v1 && (u32)S.a0 == S.h1 && (int)(S.a0 >> 56) == S.len;                                  \
+    const bool m2 = S.cand && !m1 && v2 && (u32)S.b0 == S.h2 && (int)(S.b0 >> 56) == S.len;                           \
+    const u64 e0 = m1 ? S.a0 : S.b0;                                                                                  \
+    bool found = m1 || m2;                                                                                            \
+    u32 number = (u32)(e0 >> 32) & 0x00FFFFFFu;                                                                       \
+    bool flip = m2 && !(v1 && ((u32)(S.a0 >> 32) & 0x00FFFFFFu) == number);          /* :761 `e == e1`: the same entry through both slots */ \
+    /* a row that can learn a word: from that word on, one word at a time */                                           \
+    const uint64_t learnM = kz_ballot(S.cand && !found && !v1 && (S.len > 3 || (S.len == 3 && words < TF_T2)));        \
+    if (learnM) {                                                                                                     \
+      uint64_t rest = S.candM & ~((1ULL << (int)__builtin_ctzll(learnM)) - 1ULL);                                     \
+      while (rest) {                                                                                                  \
+        const int j = (int)__builtin_ctzll(rest);                                                                     \
+        rest &= rest - 1;                                                                                             \
+        const u32 uh1 = (u32)__builtin_amdgcn_readlane((int)S.h1, j), uh2 = (u32)__builtin_amdgcn_readlane((int)S.h2, j); \
+        const int ulen = __builtin_amdgcn_readlane(S.len, j), uws = __builtin_amdgcn_readlane(S.ws, j);               \
+        const u32 us1 = uh1 & mask, us2 = uh2 & mask;                                                                 \
+        const u64 ua0 = tf_ld(map + 2 * (u64)us1), ua1 = tf_ld(map + 2 * (u64)us1 + 1);                               \
+        const u64 ub0 = tf_ld(map + 2 * (u64)us2), ub1 = tf_ld(map + 2 * (u64)us2 + 1);                               \
+        const bool uv1 = (ua1 & TF_VALID) != 0, uv2 = (ub1 & TF_VALID) != 0;                                          \
+        const bool um1 = uv1 && (u32)ua0 == uh1 && (int)(ua0 >> 56) == ulen;                                          \
+        const bool um2 = !um1 && uv2 && (u32)ub0 == uh2 && (int)(ub0 >> 56) == ulen;                                  \
+        const u64 ue0 = um1 ? ua0 : ub0;                                                                              \
+        const bool ufound = um1 || um2;                                                                               \
+        const u32 unum = (u32)(ue0 >> 32) & 0x00FFFFFFu;                                                              \
+        const bool uflip = um2 && !(uv1 && ((u32)(ua0 >> 32) & 0x00FFFFFFu) == unum);                                 \
+        if (!ufound && !uv1 && (ulen > 3 || (ulen == 3 && words < TF_T2))) {                           /* :725-747 */ \
+          /* the word takes the next number; that number's record is a fresh one (hash 0): its "old" slot, slot 0, leaves the map (:729-731) */ \
+          if (lane == 0) {                                                                                            \
+            tf_st(map + 1, 0ULL);                                                                                     \
+            tf_st(map + 2 * (u64)us1, (u64)uh1 | ((u64)(((u32)ulen << 24) | (u32)words) << 32));                      \
+            tf_st(map + 2 * (u64)us1 + 1, (u64)(u32)uws | TF_VALID);                                                  \
+            wpos[words] = (u32)uws;                                                                                   \
+          }                                                                                                           \
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
+          learned = true;                                                                                             \
+          words++;                                                                                                    \
+          if (words >= TF_MAXDICT - 1) { failed = true; break; }        /* the numbering would restart (:742-746): host stage */ \
+        }                                                                                                             \
+        if (lane == j) { found = ufound; number = unum; flip = uflip; }                                               \
+      }                                                                                                               \
+    }                                                                                                                 \
+    if (found && S.cand) tok[S.ws] = (number + 1u) | ((u32)S.len << 24) | (flip ? 0x80000000u : 0u);                  \
+  }
+  // four rows per step: all four are prepared and their entries requested before the first is decided (the loads are used inside the
+  // step that issued them, so the compiler counts them exactly: no wait for the youngest load at the loop's back edge)
+#define TF_SRC(row) (((row) + lane < n) ? (u32)src[(row) + lane] : 0u)
+  u32 cN0 = TF_SRC(0), cN1 = TF_SRC(64), cN2 = TF_SRC(128), cN3 = TF_SRC(192);
+  for (int row = 0; row < n && !failed; row += 256) {
+    const u32 c0 = cN0, c1 = cN1, c2 = cN2, c3 = cN3;
+    cN0 = TF_SRC(row + 256); cN1 = TF_SRC(row + 320); cN2 = TF_SRC(row + 384); cN3 = TF_SRC(row + 448);
+    TfRow R0, R1, R2, R3;
+    TF_PREPARE(R0, row, c0)
+    TF_PREPARE(R1, row + 64, c1)
+    TF_PREPARE(R2, row + 128, c2)
+    TF_PREPARE(R3, row + 192, c3)
+    bool learned = false;
+    TF_DECIDE(R0)
+    if (learned) { TF_REQUEST(R1) TF_REQUEST(R2) TF_REQUEST(R3) learned = false; }
+    TF_DECIDE(R1)
+    if (learned) { TF_REQUEST(R2) TF_REQUEST(R3) learned = false; }
+    TF_DECIDE(R2)
+    if (learned) { TF_REQUEST(R3) learned = false; }
+    TF_DECIDE(R3)
   }
   if (lane == 0 && failed) G.fail[a] = 1;
 #undef TF_PREPARE
+#undef TF_REQUEST
+#undef TF_DECIDE
+#undef TF_SRC
 #undef TF_DELIM
 }
 
@@ -314,7 +328,13 @@ __global__ __launch_bounds__(256) void k_tf_verify(const u8* __restrict__ srcAll
     if (t == 0) continue;
     const int number = (int)(t & 0x00FFFFFFu) - 1, len = (int)((t >> 24) & 31u);
     const u8* w = (number < G.sCount) ? G.sText + G.sPos[number] : src + wpos[number];
-    for (int k = 1; k < len; k++) bad |= src[p + k] != w[k];
+    // four letters at a time (both buffers have slack behind them); the first letter is the hash's business (flipped case)
+    u32 diff = (*(const tf_u32u*)(src + p) ^ *(const tf_u32u*)w) & (len >= 4 ? 0xFFFFFF00u : ((1u << (8 * len)) - 1u) & 0xFFFFFF00u);
+    for (int k = 4; k < len; k += 4) {
+      const u32 m = (len - k >= 4) ? 0xFFFFFFFFu : (1u << (8 * (len - k))) - 1u;
+      diff |= (*(const tf_u32u*)(src + p + k) ^ *(const tf_u32u*)(w + k)) & m;
+    }
+    bad |= diff != 0;
   }
   if (bad) G.fail[a] = 1;
 }
