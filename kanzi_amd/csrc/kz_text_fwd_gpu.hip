@@ -19,7 +19,8 @@
 //                  (map entry = hash | length | number | position, 16 bytes, two loads in flight per lane); rows in which some word
 //                  could be learned replay their words one by one from that word on, with the dictionary updated in between;
 //                  a found word leaves (number + 1 | length << 24 | flip << 31) at its first letter in `tok`;
-//     k_tf_emit<false> / k_tf_scan / k_tf_emit<true> = output bytes per 1 024 positions, offsets and the verdict, the bytes.
+//     k_tf_emit<false> / k_tf_scan / k_tf_emit<true> = output bytes per 1 024 positions (and the letters of every found word against
+//                  its dictionary word), offsets and the verdict, the bytes.
 #include "kz_device.h"
 #include "kz_internal.h"
 #include "kz_magic.h"
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void k_tf_init(TextFwd G, int B) {
 // LDS ring (the previous row and this one) into registers, hashes it both ways and requests the two map entries; four rows are
 // prepared and their entries requested before the first of them is looked at, so the map's latency is paid once per four rows.  A lookup that
 // matches hash and length counts as found here; that the letters match too (sameWords :720-723) is checked for every found word by
-// k_tf_verify afterwards, in parallel -- a block with a single mismatch (a 32-bit hash collision at equal length) goes to the host
+// the size pass (k_tf_emit<false>) afterwards, in parallel -- a block with a single mismatch (a 32-bit hash collision at equal length) goes to the host
 // stage whole, so the speculation never shows.  Rows in which a word could be learned replay their words one by one from that word
 // on with fresh loads; the entries of the rows prepared behind it are then requested again.
 struct TfRow { uint64_t candM; u32 h1, h2; int len, ws; u64 a0, a1, b0, b1; bool cand; };
@@ -310,35 +311,6 @@ __global__ __launch_bounds__(64) void k_tf_walk(const u8* __restrict__ srcAll, i
 #undef TF_DELIM
 }
 
-// every found word's letters behind the first against the letters of the dictionary word it was matched with (sameWords :720-723:
-// the walk went by hash and length).  A mismatch fails the block (host stage).
-__global__ __launch_bounds__(256) void k_tf_verify(const u8* __restrict__ srcAll, int64_t stride, const int32_t* __restrict__ d_len, TextFwd G, int B) {
-  const int b = blockIdx.y;
-  const int a = G.ord[b];
-  if (a < 0 || G.mode[a] < 0) return;
-  const int n = d_len[b];
-  const int base = blockIdx.x * 4096;
-  if (base >= n) return;
-  const u8* src = srcAll + (int64_t)b * stride;
-  const u32* tok = G.tok + (int64_t)a * G.NS;
-  const u32* wpos = G.wpos + (int64_t)a * TF_MAXDICT;
-  bool bad = false;
-  for (int p = base + threadIdx.x; p < min(n, base + 4096); p += 256) {
-    const u32 t = tok[p];
-    if (t == 0) continue;
-    const int number = (int)(t & 0x00FFFFFFu) - 1, len = (int)((t >> 24) & 31u);
-    const u8* w = (number < G.sCount) ? G.sText + G.sPos[number] : src + wpos[number];
-    // four letters at a time (both buffers have slack behind them); the first letter is the hash's business (flipped case)
-    u32 diff = (*(const tf_u32u*)(src + p) ^ *(const tf_u32u*)w) & (len >= 4 ? 0xFFFFFF00u : ((1u << (8 * len)) - 1u) & 0xFFFFFF00u);
-    for (int k = 4; k < len; k += 4) {
-      const u32 m = (len - k >= 4) ? 0xFFFFFFFFu : (1u << (8 * (len - k))) - 1u;
-      diff |= (*(const tf_u32u*)(src + p + k) ^ *(const tf_u32u*)(w + k)) & m;
-    }
-    bad |= diff != 0;
-  }
-  if (bad) G.fail[a] = 1;
-}
-
 // ---- output: sizes per tile, then the bytes (:752-771 between the words, emitSymbols :1304-1367, emitWordIndex :1370-1394) ----
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_tf_emit(const u8* __restrict__ srcAll, u8* __restrict__ dstAll, int64_t stride, const int32_t* __restrict__ d_len, TextFwd G, int B) {
@@ -384,6 +356,18 @@ __global__ __launch_bounds__(256) void k_tf_emit(const u8* __restrict__ srcAll, 
     if (inb && !cov && !skipSp) lit = (c == TF_ESC1) ? 2u : ((c == TF_CR) ? (crlf ? 0u : 1u) : 1u + (c >> 7));
     const u32 v = tCur & 0x00FFFFFFu;
     const u32 code = tCur ? ((tCur >> 31) + (v >= TF_T4 ? 3u : (v >= TF_T3 ? 2u : 1u))) : 0u;
+    if (!WRITE && tCur) {
+      // sameWords (:720-723), which the walk left out: the letters behind the first against the dictionary word's, four at a time
+      // (both buffers have slack behind them).  A mismatch -- a hash collision at equal length -- fails the block: host stage.
+      const int number = (int)v - 1, len = (int)((tCur >> 24) & 31u);
+      const u8* w = (number < G.sCount) ? G.sText + G.sPos[number] : src + G.wpos[(int64_t)a * TF_MAXDICT + number];
+      u32 diff = (*(const tf_u32u*)(src + p) ^ *(const tf_u32u*)w) & (len >= 4 ? 0xFFFFFF00u : ((1u << (8 * len)) - 1u) & 0xFFFFFF00u);
+      for (int k = 4; k < len; k += 4) {
+        const u32 mm = (len - k >= 4) ? 0xFFFFFFFFu : (1u << (8 * (len - k))) - 1u;
+        diff |= (*(const tf_u32u*)(src + p + k) ^ *(const tf_u32u*)(w + k)) & mm;
+      }
+      if (diff) G.fail[a] = 1;
+    }
     const u32 sz = lit + code;
     const u32 incl = kz_wave_incl_sum(sz);
     if (WRITE && sz) {
@@ -558,7 +542,6 @@ int kz_text_fwd_gpu_launch(kz_ctx* ctx, kz_batch& bt, TextFwdJob& J) {
   const u8* src = bt.buf[bt.cur]; u8* dst = bt.buf[bt.cur ^ 1];
   KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_init, dim3(2, B), dim3(256), G, B);
   KZ_LAUNCH(ctx, KID_TEXT_WALK, k_tf_walk, dim3(B), dim3(64), src, bt.stride, bt.d_len, G, B);
-  KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_verify, dim3((int)((G.NS + 4095) / 4096), B), dim3(256), src, bt.stride, bt.d_len, G, B);
   KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_emit<false>, dim3((G.maxTiles + 3) / 4, B), dim3(256), src, dst, bt.stride, bt.d_len, G, B);
   KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_scan, dim3(B), dim3(256), bt.d_len, G, B);
   KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_emit<true>, dim3((G.maxTiles + 3) / 4, B), dim3(256), src, dst, bt.stride, bt.d_len, G, B);

@@ -23,7 +23,7 @@ import sys
 ALIASES = {"k_radix_hist0": "k_radix_hist", "k_radix_scatter0": "k_radix_scatter",
            "k_trk_hist16": "k_tr_hist16", "k_trk_count": "k_tr_count", "k_trk_scatter": "k_tr_scatter", "k_trk_sort": "k_tr_sort",   # the key trie rounds share the trie rounds' ids
            "k_fpaq_enc_wave": "k_fpaq_enc", "k_fpaq_dec_wave": "k_fpaq_dec", "k_fpaq_dec_wave2": "k_fpaq_dec",   # the one-wave-per-block forms share their ids
-           "k_tf_walk": "k_text_walk", "k_tf_stats": "k_text_fwd", "k_tf_decide": "k_text_fwd", "k_tf_init": "k_text_fwd", "k_tf_verify": "k_text_fwd",
+           "k_tf_walk": "k_text_walk", "k_tf_stats": "k_text_fwd", "k_tf_decide": "k_text_fwd", "k_tf_init": "k_text_fwd",
            "k_tf_emit": "k_text_fwd", "k_tf_scan": "k_text_fwd", "k_tf_copy_back": "k_text_fwd"}   # the device TEXT forward: the walk, and its parallel passes under one id
 
 

@@ -15,6 +15,7 @@ import oracle, textgen, datagen
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+small = len(sys.argv) > 3 and sys.argv[3] == "small"      # many blocks of 16 - 64 KiB from the word generator: more cases per second
 rng = np.random.default_rng(seed)
 print("seed", seed, flush=True)
 ctx = kz.Context(0)
@@ -36,6 +37,7 @@ def words(n, lo, hi, vocab):
 
 def material(n):
     k = int(rng.integers(0, 12)); s = int(rng.integers(0, 1 << 30))
+    if small and k in (0, 1, 2, 4, 5, 11) and rng.random() < 0.7: k = int(rng.choice([7, 8, 9]))   # textgen's generators are slow: mostly words()
     if k == 0: return bytes(textgen.english(n, s))
     if k == 1: return bytes(textgen.english(n, s, crlf=True))
     if k == 2: return bytes(textgen.xml(n, s))
@@ -53,9 +55,9 @@ def material(n):
 t0 = time.time(); cases = bad = taken = 0
 while time.time() - t0 < budget:
     chain, ent = [("TEXT", "NONE"), ("TEXT+UTF", "NONE"), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0"), ("TEXT", "HUFFMAN")][int(rng.integers(0, 4))]
-    bs = int(rng.choice([16384, 65536, 1 << 18, 1 << 20, 4 << 20]))
+    bs = int(rng.choice([16384, 32768, 65536])) if small else int(rng.choice([16384, 65536, 1 << 18, 1 << 20, 4 << 20]))
     ctx.set_block_size(bs)
-    nblk = int(rng.integers(2, 12)) if bs < (1 << 20) else int(rng.integers(1, 4))
+    nblk = int(rng.integers(20, 64)) if small else (int(rng.integers(2, 12)) if bs < (1 << 20) else int(rng.integers(1, 4)))
     blocks = []
     for _ in range(nblk):
         n = int(rng.integers(900, bs + 1)) if rng.random() < 0.5 else bs
