@@ -780,8 +780,9 @@ static int text_gpu_form(uint32_t entropyType, int nBlocks) {
 }
 static bool text_gpu_on(uint32_t entropyType, int nBlocks) { return text_gpu_form(entropyType, nBlocks) != 0; }
 // TEXT forward on the device (kz_text_fwd_gpu.hip): TextCodec2 streams (every entropy coder but FPAQ) in batches of KZ_TEXT_FWD_GPU_MIN
-// blocks (512) or more -- a block's dictionary walk takes the kernel ~0.1 s however few there are, so small batches stay on the host's
-// chunk pipeline.  KZ_TEXT_FWD_GPU=0: host stage, =1: any batch size.  (Read per call: the tests force both.)
+// blocks (256) or more -- a block's dictionary walk takes the kernel ~0.1 s however few there are, so small batches stay on the host's
+// chunk pipeline (measured with 16 host CPUs, level-exact -l 5 encode of 64 / 128 / 256 / 512 blocks: host 102 / 159 / 293 / 529 ms,
+// device 157 / 188 / 247 / 379 ms).  KZ_TEXT_FWD_GPU=0: host stage, =1: any batch size.  (Read per call: the tests force both.)
 static bool text_fwd_gpu_on(uint32_t entropyType, int nBlocks) {
   const bool type2 = entropyType == KZ_E_NONE || entropyType == KZ_E_ANS0 || entropyType == KZ_E_HUFFMAN;
   if (!type2) return false;
@@ -789,7 +790,7 @@ static bool text_fwd_gpu_on(uint32_t entropyType, int nBlocks) {
   if (e && e[0] == '0') return false;
   if (e && e[0] == '1') return true;
   const char* m = getenv("KZ_TEXT_FWD_GPU_MIN");
-  return nBlocks >= (m ? atoi(m) : 512);
+  return nBlocks >= (m ? atoi(m) : 256);
 }
 // UTF inverse on the device (kz_text_gpu.hip: parallel inside a block, so for any batch); KZ_UTF_GPU=0 keeps it on the host
 static bool utf_gpu_on() { const char* e = getenv("KZ_UTF_GPU"); return !(e && e[0] == '0'); }
