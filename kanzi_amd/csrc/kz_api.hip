@@ -636,12 +636,14 @@ static void host_prestage(const int* types, int hp, int entropy, int blockSize, 
   kz_parallel_for(B, KZ_HOST_STAGE_THREADS, host_forward_block, &H);
 }
 // the same over a list of blocks (block k at ptrs[k], lengths[k] bytes): the results are numbered like the list
+// store: K slots of host_pre_slot(cap) bytes (pinned: the per-block copies back to HBM are then real DMA), or null
 static void host_prestage_list(const int* types, int hp, int entropy, int blockSize, int cap, const std::vector<const uint8_t*>& ptrs,
-                               const std::vector<int32_t>& lengths, HostPre& P) {
+                               const std::vector<int32_t>& lengths, HostPre& P, uint8_t* store = nullptr) {
   const int K = (int)ptrs.size();
   P.outLen.assign(K, 0); P.skip.assign(K, 0xFF); P.dtype.assign(K, 0); P.changed.assign(K, 0);
   P.slot = host_pre_slot(cap);
-  P.own.reset(new uint8_t[(size_t)P.slot * (size_t)std::max(K, 1) + 64]); P.store = P.own.get();
+  if (store) P.store = store;                          // (P.pinned stays false: that flag selects the gather kernel, which indexes slots by block)
+  else { P.own.reset(new uint8_t[(size_t)P.slot * (size_t)std::max(K, 1) + 64]); P.store = P.own.get(); }
   if (K == 0) return;
   std::vector<int32_t> none(K, 0);
   HostFwd H;
@@ -1241,6 +1243,10 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
           int r2 = kz_stage_reserve(ctx, stg, (size_t)blocks.size() * (size_t)maxN + 64, true);
           if (r2) return r2;
         }
+        // the copies of a pass that runs beside the walk go on their own stream (the caller's input is not this context's to order:
+        // k_copy_bytes read it on the main stream without waiting either), the walk is queued on the main one meanwhile
+        if (overlap && !host && !ctx->copyDown) KZ_HIP(hipStreamCreateWithFlags(&ctx->copyDown, hipStreamNonBlocking));
+        hipStream_t cs = (overlap && !host) ? ctx->copyDown : st;
         for (size_t k = 0; k < blocks.size(); k++) {
           const int b = blocks[k];
           lens[k] = lengths[b];
@@ -1248,18 +1254,17 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
           if (host) ptrs[k] = in + (int64_t)b * inStride;
           else {
             ptrs[k] = stg.p + k * (size_t)maxN;
-            KZ_HIP(hipMemcpyAsync(stg.p + k * (size_t)maxN, in + (int64_t)b * inStride, (size_t)lengths[b], hipMemcpyDeviceToHost, st));
+            KZ_HIP(hipMemcpyAsync(stg.p + k * (size_t)maxN, in + (int64_t)b * inStride, (size_t)lengths[b], hipMemcpyDeviceToHost, cs));
           }
         }
-        if (overlap) {                                                             // the copies are queued in front of the walk: wait for them only
-          hipEvent_t ev = kz_ev(ctx);
-          KZ_HIP(hipEventRecord(ev, st));
+        if (overlap) {
           int r2 = kz_text_fwd_gpu_launch(ctx, bt, *J);
           if (r2) return r2;
-          KZ_HIP(hipEventSynchronize(ev));
-          ctx->evPool.push_back(ev);
+          if (!host) KZ_HIP(hipStreamSynchronize(cs));
         } else KZ_HIP(kz_stream_sync(ctx, st));
-        host_prestage_list(types, hp, (int)entropyType, blockSize, maxLen, ptrs, lens, passP[pass]);
+        uint8_t* store = nullptr;                                                  // pinned slots for the stages' outputs, when there is room for them
+        if (!blocks.empty() && kz_stage_reserve(ctx, ctx->hsOut[pass], (size_t)host_pre_slot(maxLen) * blocks.size() + 64, true) == 0) store = ctx->hsOut[pass].p;
+        host_prestage_list(types, hp, (int)entropyType, blockSize, maxLen, ptrs, lens, passP[pass], store);
         return 0;
       };
       std::vector<int> first, second;

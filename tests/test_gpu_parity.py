@@ -1487,11 +1487,12 @@ def test_bwt_forward_trie_rounds_match_oracle(ctx, monkeypatch, switch):
 
 # ---- round 5: the differential fuzz tools of round 4 as a driver-run test ----
 @pytest.mark.gpu
-@pytest.mark.parametrize("tool,seconds,seed", [("bwt_fuzz", 7, 5001), ("zrlt_fuzz", 6, 5002), ("tightcap_fuzz", 6, 5003), ("entropy_count_fuzz", 6, 5004)])
+@pytest.mark.parametrize("tool,seconds,seed", [("bwt_fuzz", 7, 5001), ("zrlt_fuzz", 6, 5002), ("tightcap_fuzz", 6, 5003), ("entropy_count_fuzz", 6, 5004), ("text_fwd_gpu_fuzz", 8, 5005)])
 def test_differential_fuzz_tools_bounded(tool, seconds, seed):
     """tools/bwt_fuzz.py (forward BWT on structured and degenerate strings, ragged batches), tools/zrlt_fuzz.py (row / wave / tile
     seams of the ZRLT kernels), tools/tightcap_fuzz.py (every inverse transform with the buffer cut to the byte) and
-    tools/entropy_count_fuzz.py (decoders asked for the wrong count or given cut bits): a fixed seed and a few seconds each, so the
+    tools/entropy_count_fuzz.py (decoders asked for the wrong count or given cut bits), tools/text_fwd_gpu_fuzz.py (the device TEXT
+    forward on generated words around its rules, small blocks): a fixed seed and a few seconds each, so the
     first cases of every campaign run wherever the GPU suite runs.  Each tool compares HIP with the oracle case by case and exits
     non-zero on the first campaign with a difference."""
     import subprocess

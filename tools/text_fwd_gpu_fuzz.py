@@ -15,7 +15,7 @@ import oracle, textgen, datagen
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
-small = len(sys.argv) > 3 and sys.argv[3] == "small"      # many blocks of 16 - 64 KiB from the word generator: more cases per second
+small = (len(sys.argv) > 3 and sys.argv[3] == "small") or budget <= 20      # many blocks of 16 - 64 KiB from the word generator: more cases per second
 rng = np.random.default_rng(seed)
 print("seed", seed, flush=True)
 ctx = kz.Context(0)
