@@ -193,6 +193,13 @@ __global__ __launch_bounds__(64) void k_tf_walk(const u8* __restrict__ srcAll, i
   int words = G.sCount;                           // the next word number (TextCodec2: the static words, nothing else fixed)
   int carry = -1;                                 // position of the last non-letter in front of the row (:694: a letter first = -1 / the last leading space)
   bool failed = false;
+  // one letter of the words the row closes (letters: no sign to extend), and a group of four behind a test that some word is that long
+#define TF_HSTEP(R, k)                                                                                                \
+  { const bool act = R.cand && (k) < R.len;                                                                           \
+    const u32 t = ((xw[(k) >> 2] >> (8 * ((k) & 3))) & 0xFFu) * TF_HASH2;                                             \
+    const u32 n1 = h1 * TF_HASH1 ^ t, n2 = h2 * TF_HASH1 ^ t;                                                         \
+    h1 = act ? n1 : h1; h2 = act ? n2 : h2; }
+#define TF_HGROUP(R, i) if (kz_ballot(R.cand && 4 * (i) < R.len) != 0) { TF_HSTEP(R, 4 * (i)) TF_HSTEP(R, 4 * (i) + 1) TF_HSTEP(R, 4 * (i) + 2) TF_HSTEP(R, 4 * (i) + 3)
   // prepare the row at `row` (its bytes: cc): word ends, hashes, map requests
 #define TF_PREPARE(R, row, cc)                                                                                        \
   { const u32 c = (cc);                                                                                               \
@@ -219,13 +226,10 @@ __global__ __launch_bounds__(64) void k_tf_walk(const u8* __restrict__ srcAll, i
         _Pragma("unroll") for (int i = 0; i < 8; i++) xw[i] = __builtin_amdgcn_alignbyte(rr[i + 1], rr[i], sh); }     \
       const u32 w0 = xw[0] & 0xFFu;                                                                    /* :709-718 */ \
       u32 h1 = TF_HASH1 * TF_HASH1 ^ w0 * TF_HASH2, h2 = TF_HASH1 * TF_HASH1 ^ (w0 ^ 0x20u) * TF_HASH2;               \
-      _Pragma("unroll") for (int k = 1; k < TF_MAXWORD; k++) {                                                        \
-        const bool act = R.cand && k < R.len;                                                                         \
-        if (kz_ballot(act) == 0) break;                                                                               \
-        const u32 t = ((xw[k >> 2] >> (8 * (k & 3))) & 0xFFu) * TF_HASH2;                /* letters: no sign to extend */ \
-        const u32 n1 = h1 * TF_HASH1 ^ t, n2 = h2 * TF_HASH1 ^ t;                                                     \
-        h1 = act ? n1 : h1; h2 = act ? n2 : h2;                                                                       \
-      }                                                                                                               \
+      /* four letters per group with constant register and shift (a loop over k indexes xw dynamically: seven selects per letter) */ \
+      TF_HSTEP(R, 1) TF_HSTEP(R, 2) TF_HSTEP(R, 3)                                                                    \
+      TF_HGROUP(R, 1) TF_HGROUP(R, 2) TF_HGROUP(R, 3) TF_HGROUP(R, 4) TF_HGROUP(R, 5) TF_HGROUP(R, 6) TF_HGROUP(R, 7)  \
+      }}}}}}}                                                                                                         \
       R.h1 = h1; R.h2 = h2;                                                                                           \
       TF_REQUEST(R)                                                                                                   \
     } }
@@ -305,6 +309,8 @@ __global__ __launch_bounds__(64) void k_tf_walk(const u8* __restrict__ srcAll, i
   }
   if (lane == 0 && failed) G.fail[a] = 1;
 #undef TF_PREPARE
+#undef TF_HSTEP
+#undef TF_HGROUP
 #undef TF_REQUEST
 #undef TF_DECIDE
 #undef TF_SRC
