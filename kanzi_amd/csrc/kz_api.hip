@@ -589,6 +589,8 @@ struct HostFwd {
   const int32_t* lengths; const int32_t* copy;      // copy: blocks the chain does not apply to (null: those of <= 15 bytes)
   HostPre* P;
   const uint8_t* const* ptrs = nullptr;             // a LIST of blocks instead (block k at ptrs[k]; hsrc / hstride unused)
+  const int32_t* first = nullptr;                   // list form: the stages in front of first[k] are done with block k (they declined:
+  const int32_t* dt0 = nullptr;                     //            data untouched, skip bits set) and left the "dataType" dt0[k]
 };
 static void host_forward_block(int b, void* arg) {
   HostFwd& H = *(HostFwd*)arg;
@@ -603,11 +605,12 @@ static void host_forward_block(int b, void* arg) {
   if ((int)bufA.size() < H.cap + 64) bufA.resize((size_t)H.cap + 64);
   const uint8_t* const origin = H.ptrs ? H.ptrs[b] : H.hsrc + (int64_t)b * H.hstride;
   const uint8_t* cur = origin;
-  int dt = kz_host_block_data_type(cur, n, KZ_DT_UNDEFINED);            // CompressedOutputStream.java:795-804
+  const int i0 = H.first ? H.first[b] : 0;
+  int dt = i0 > 0 ? H.dt0[b] : kz_host_block_data_type(cur, n, KZ_DT_UNDEFINED);   // CompressedOutputStream.java:795-804
   int len = n;
   uint8_t* mine = P.store + (int64_t)b * P.slot;
   uint8_t* out = mine;                                                  // ping-pong between the block's slot and a scratch buffer
-  for (int i = 0; i < H.hp; i++) {
+  for (int i = i0; i < H.hp; i++) {
     int produced = 0;
     if (!kz_host_transform_forward(H.types[i], H.entropy, H.blockSize, &dt, cur, len, out, H.cap, &produced)) continue;   // declined: data untouched
     P.skip[b] &= ~(1 << (7 - i));
@@ -638,7 +641,8 @@ static void host_prestage(const int* types, int hp, int entropy, int blockSize, 
 // the same over a list of blocks (block k at ptrs[k], lengths[k] bytes): the results are numbered like the list
 // store: K slots of host_pre_slot(cap) bytes (pinned: the per-block copies back to HBM are then real DMA), or null
 static void host_prestage_list(const int* types, int hp, int entropy, int blockSize, int cap, const std::vector<const uint8_t*>& ptrs,
-                               const std::vector<int32_t>& lengths, HostPre& P, uint8_t* store = nullptr) {
+                               const std::vector<int32_t>& lengths, HostPre& P, uint8_t* store = nullptr,
+                               const std::vector<int32_t>* first = nullptr, const std::vector<int32_t>* dt0 = nullptr) {
   const int K = (int)ptrs.size();
   P.outLen.assign(K, 0); P.skip.assign(K, 0xFF); P.dtype.assign(K, 0); P.changed.assign(K, 0);
   P.slot = host_pre_slot(cap);
@@ -649,6 +653,7 @@ static void host_prestage_list(const int* types, int hp, int entropy, int blockS
   HostFwd H;
   H.types = types; H.hp = hp; H.entropy = entropy; H.cap = cap; H.blockSize = blockSize;
   H.hsrc = nullptr; H.hstride = 0; H.lengths = lengths.data(); H.copy = none.data(); H.P = &P; H.ptrs = ptrs.data();
+  if (first && dt0) { H.first = first->data(); H.dt0 = dt0->data(); }
   kz_parallel_for(K, KZ_HOST_STAGE_THREADS, host_forward_block, &H);
 }
 HostPre* kz_host_prestage(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize, const uint8_t* hsrc, int64_t hstride,
@@ -1226,19 +1231,22 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
     // TEXT forward on the device (kz_text_fwd_gpu.hip) for the blocks it keeps after its statistics and finishes: they are rewritten
     // in their slots (hashes and Magic tags were taken from the original bytes above, on the same stream).  The host stages run on
     // the blocks it does not keep WHILE its walk runs, then on the few it kept and could not finish.
-    std::vector<int32_t> gpuDone(B, 0);
+    std::vector<int32_t> gpuDone(B, 0), textDeclined(B, -1), noHost(B, 0);
     std::vector<int> listOf(B, -1), listIdx(B, -1);                               // block -> (host pass, index in that pass's list)
     HostPre passP[2];
     if (textFwdGpu) {
       std::unique_ptr<TextFwdJob, void (*)(TextFwdJob*)> J(kz_text_fwd_gpu_new(), kz_text_fwd_gpu_free);
       std::vector<int32_t> take(B), keeps;
       for (int b = 0; b < B; b++) take[b] = (!h_copy[b] && lengths[b] > 0) ? 1 : 0;
-      rc = kz_text_fwd_gpu_classify(ctx, bt, blockSize, take, keeps, *J);
+      rc = kz_text_fwd_gpu_classify(ctx, bt, blockSize, take, keeps, textDeclined, *J);
       if (rc) return rc;
+      // a block that is not text: TEXT declined it on the device and left its "dataType"; UTF (if the chain has it) looks at UNDEFINED
+      // and UTF8 blocks only (UTFCodec.java:93-101), on the host, from that entry on; every other block is done with the host stages
+      for (int b = 0; b < B; b++) if (textDeclined[b] >= 0 && (hp == 1 || (textDeclined[b] != KZ_DT_UNDEFINED && textDeclined[b] != KZ_DT_UTF8))) noHost[b] = 1;
       kz_ctx::Stage& stg = ctx->hsIn[0];                                           // pinned staging for device input
       auto host_pass = [&](int pass, const std::vector<int>& blocks, bool overlap) -> int {
         std::vector<const uint8_t*> ptrs(blocks.size());
-        std::vector<int32_t> lens(blocks.size());
+        std::vector<int32_t> lens(blocks.size()), firstStage(blocks.size(), 0), dtIn(blocks.size(), KZ_DT_UNDEFINED);
         if (!host && !blocks.empty()) {
           int r2 = kz_stage_reserve(ctx, stg, (size_t)blocks.size() * (size_t)maxN + 64, true);
           if (r2) return r2;
@@ -1251,6 +1259,7 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
           const int b = blocks[k];
           lens[k] = lengths[b];
           listOf[b] = pass; listIdx[b] = (int)k;
+          if (textDeclined[b] >= 0) { firstStage[k] = 1; dtIn[k] = textDeclined[b]; }    // TEXT is done with it
           if (host) ptrs[k] = in + (int64_t)b * inStride;
           else {
             ptrs[k] = stg.p + k * (size_t)maxN;
@@ -1264,11 +1273,14 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
         } else KZ_HIP(kz_stream_sync(ctx, st));
         uint8_t* store = nullptr;                                                  // pinned slots for the stages' outputs, when there is room for them
         if (!blocks.empty() && kz_stage_reserve(ctx, ctx->hsOut[pass], (size_t)host_pre_slot(maxLen) * blocks.size() + 64, true) == 0) store = ctx->hsOut[pass].p;
-        host_prestage_list(types, hp, (int)entropyType, blockSize, maxLen, ptrs, lens, passP[pass], store);
+        const auto t0 = std::chrono::steady_clock::now();
+        host_prestage_list(types, hp, (int)entropyType, blockSize, maxLen, ptrs, lens, passP[pass], store, &firstStage, &dtIn);
+        if (getenv("KZ_TEXT_GPU_TRACE"))
+          fprintf(stderr, "[textfwd] host pass %d: %d blocks, %.0f ms\n", pass, (int)blocks.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         return 0;
       };
       std::vector<int> first, second;
-      for (int b = 0; b < B; b++) if (take[b] && !keeps[b]) first.push_back(b);
+      for (int b = 0; b < B; b++) if (take[b] && !keeps[b] && !noHost[b]) first.push_back(b);
       rc = host_pass(0, first, true);
       if (rc) return rc;
       rc = kz_text_fwd_gpu_finish(ctx, bt, *J, gpuDone);
@@ -1297,7 +1309,10 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
       if (gpuDone[b]) { h_skip[b] = 0xFF & ~(1 << 7); dts[b] = KZ_DT_TEXT; continue; }   // TEXT applied on the device (length set there: TextCodec.java:667); UTF declines a block tagged TEXT (UTFCodec.java:93-101)
       const HostPre* q = pre;
       int k = b;
-      if (textFwdGpu) { if (listOf[b] < 0) { bt.h_len[b] = lengths[b]; continue; } q = &passP[listOf[b]]; k = listIdx[b]; }
+      if (textFwdGpu) {
+        if (listOf[b] < 0) { bt.h_len[b] = lengths[b]; if (noHost[b]) dts[b] = textDeclined[b]; continue; }   // (noHost: every host stage declined, TEXT's entry stays)
+        q = &passP[listOf[b]]; k = listIdx[b];
+      }
       h_skip[b] = q->skip[k];
       dts[b] = q->dtype[k];
       bt.h_len[b] = q->outLen[k];

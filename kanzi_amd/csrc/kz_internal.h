@@ -181,7 +181,8 @@ size_t kz_text_fwd_gpu_scratch(int B, int blockSize, int maxLen);
 struct TextFwdJob;
 TextFwdJob* kz_text_fwd_gpu_new();
 void kz_text_fwd_gpu_free(TextFwdJob*);
-int kz_text_fwd_gpu_classify(kz_ctx* ctx, kz_batch& bt, int blockSize, const std::vector<int32_t>& take, std::vector<int32_t>& keeps, TextFwdJob& J);
+int kz_text_fwd_gpu_classify(kz_ctx* ctx, kz_batch& bt, int blockSize, const std::vector<int32_t>& take, std::vector<int32_t>& keeps,
+                             std::vector<int32_t>& declined, TextFwdJob& J);
 int kz_text_fwd_gpu_launch(kz_ctx* ctx, kz_batch& bt, TextFwdJob& J);
 int kz_text_fwd_gpu_finish(kz_ctx* ctx, kz_batch& bt, TextFwdJob& J, std::vector<int32_t>& done);
 size_t kz_utf_gpu_scratch_per_block(int maxLen);

@@ -24,6 +24,7 @@
 #include "kz_device.h"
 #include "kz_internal.h"
 #include "kz_magic.h"
+#include "kz_datatype.h"
 #include <algorithm>
 #include <mutex>
 #include <unordered_map>
@@ -62,7 +63,8 @@ struct TextFwd {
   u32* wpos;           // [A][TF_MAXDICT] position of a learned word's first letter, by word number
   int32_t* tileSum;    // [A][maxTiles] output bytes per tile, then their exclusive prefix
   int32_t* stats;      // [A][TF_STATS]
-  int32_t* mode;       // [A] the block's mode byte (TextCodec.java:48-52), -1: not for the device
+  int32_t* mode;       // [A] the block's mode byte (TextCodec.java:48-52); -1: not text (k_tf_pairs then says what detectType says); -2: not for the device
+  int32_t* tdt;        // [A] blocks that are not text: the "dataType" entry TEXT leaves when it declines (:650-665), -1: the host decides
   int32_t* fail;       // [A] the walk gave up
   const int32_t* ord;  // [B] dense index of the blocks this launch takes, -1: not taken
   int32_t* outLen;     // [B] produced bytes, -1: not done (host stage)
@@ -123,8 +125,9 @@ __global__ __launch_bounds__(64) void k_tf_decide(const u8* __restrict__ srcAll,
   if (a < 0) return;
   const int n = d_len[b];
   const int32_t* f = G.stats + (int64_t)a * TF_STATS;
-  int mode = -1;
+  int mode = -2;
   if (n >= TF_MINBLOCK && n < TF_MAXBLOCK && mm_magic_type(srcAll + (int64_t)b * stride) == 0) {       // :272-273, :491-492
+    mode = -1;
     long long letters = (long long)f[TF_CR] + f[TF_LF], ascii = 0;
     for (int c = 0; c < 128; c++) { if (tf_is_text((u32)c)) letters += f[c]; ascii += f[c]; }
     const long long bin = n - ascii;
@@ -145,6 +148,55 @@ __global__ __launch_bounds__(64) void k_tf_decide(const u8* __restrict__ srcAll,
     }
   }
   G.mode[a] = mode;
+}
+
+// Blocks that are not text: TextCodec.detectType (:386-440) = Global.detectSimpleType on the order-0 histogram, else the UTF-8
+// plausibility rules on the pair histogram (a lead byte followed by a byte outside its range anywhere: not UTF-8; continuation bytes
+// >= 1/8 of the block: UTF-8).  Only pairs whose FIRST byte is a lead byte (>= 0xC2) are consulted: 64 rows of the pair table in LDS.
+// The pair statistics start from a previous byte of 0 (:283), which is no lead byte.
+__global__ __launch_bounds__(256) void k_tf_pairs(const u8* __restrict__ srcAll, int64_t stride, const int32_t* __restrict__ d_len, TextFwd G, int B) {
+  const int b = blockIdx.x;
+  const int a = G.ord[b];
+  if (a < 0 || G.mode[a] != -1) return;
+  const int n = d_len[b];
+  const u8* src = srcAll + (int64_t)b * stride;
+  __shared__ u32 tab[64][256];
+  __shared__ long long lds4[4];
+  __shared__ int anyBad;
+  for (int i = threadIdx.x; i < 64 * 256; i += 256) (&tab[0][0])[i] = 0;
+  if (threadIdx.x == 0) anyBad = 0;
+  __syncthreads();
+  for (int i = 4 * (int)threadIdx.x; i < n; i += 1024) {                 // four bytes per thread and step (slack behind the block: masked by i + k < n)
+    const u32 w = *(const u32*)(src + i);
+    u32 p = (i > 0) ? (u32)src[i - 1] : 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u32 c = (w >> (8 * k)) & 0xFFu;
+      if (i + k < n && p >= 0xC0u) atomicAdd(&tab[p - 0xC0u][c], 1u);
+      p = c;
+    }
+  }
+  __syncthreads();
+  const int32_t* f = G.stats + (int64_t)a * TF_STATS;
+  const int i = threadIdx.x;
+  const int simple = kz_detect_simple_type_wg(n, f[i], f['='], lds4);
+#define TF_P(row, col) ((long long)tab[(row) - 0xC0][col])
+  long long sbad = 0;
+  if (i < 0xA0 || i > 0xBF) sbad += TF_P(0xE0, i);
+  if (i < 0x80 || i > 0x9F) sbad += TF_P(0xED, i);
+  if (i < 0x90 || i > 0xBF) sbad += TF_P(0xF0, i);
+  if (i < 0x80 || i > 0x8F) sbad += TF_P(0xF4, i);
+  long long cont = 0;
+  if (i < 0x80 || i > 0xBF) {
+    for (int j = 0xC2; j <= 0xDF; j++) sbad += TF_P(j, i);
+    for (int j = 0xE1; j <= 0xEC; j++) sbad += TF_P(j, i);
+    sbad += TF_P(0xF1, i) + TF_P(0xF2, i) + TF_P(0xF3, i) + TF_P(0xEE, i) + TF_P(0xEF, i);
+  } else cont = f[i];
+#undef TF_P
+  if (i == 0xC0 || i == 0xC1 || i >= 0xF5) sbad += f[i];                 // bytes no UTF-8 text holds
+  if (sbad) anyBad = 1;
+  const long long contAll = kz_wg256_sum64(cont, lds4);                  // (its barriers also publish anyBad)
+  if (threadIdx.x == 0) G.tdt[a] = (simple != DT_UNDEFINED) ? simple : ((!anyBad && contAll >= n / 8) ? DT_UTF8 : DT_UNDEFINED);
 }
 
 // the static dictionary's map entries (the map itself was cleared by the host call)
@@ -433,7 +485,9 @@ size_t kz_text_fwd_gpu_scratch(int B, int blockSize, int maxLen) {
 
 // The stage in three steps, so that the caller can run the host stages of the blocks the device does not keep while the walk runs:
 //   kz_text_fwd_gpu_classify: statistics of the blocks with take[b] != 0 in bt.buf[cur]; keeps[b] = 1 for the blocks the device goes on
-//                             with (text by computeStats' rules, no Magic number, 1 KiB .. 16 MiB); the stream is idle on return;
+//                             with (text by computeStats' rules, no Magic number, 1 KiB .. 16 MiB); declined[b] >= 0 for the blocks
+//                             that are NOT text: TEXT is done with them (it declines: data untouched) and leaves that "dataType"
+//                             (detectType on the device); -1 and not kept: the host stage decides; the stream is idle on return;
 //   kz_text_fwd_gpu_launch:   queues the walk and the output passes for them (no wait);
 //   kz_text_fwd_gpu_finish:   waits; done[b] = 1 for the blocks that were finished: their bytes are in their slots, bt.h_len / bt.d_len
 //                             updated -- their skip bit, and "dataType" = TEXT, are the caller's; every other block is untouched (host stage).
@@ -449,9 +503,11 @@ struct TextFwdJob {
 TextFwdJob* kz_text_fwd_gpu_new() { return new TextFwdJob(); }
 void kz_text_fwd_gpu_free(TextFwdJob* J) { delete J; }
 
-int kz_text_fwd_gpu_classify(kz_ctx* ctx, kz_batch& bt, int blockSize, const std::vector<int32_t>& take, std::vector<int32_t>& keeps, TextFwdJob& J) {
+int kz_text_fwd_gpu_classify(kz_ctx* ctx, kz_batch& bt, int blockSize, const std::vector<int32_t>& take, std::vector<int32_t>& keeps,
+                             std::vector<int32_t>& declined, TextFwdJob& J) {
   const int B = bt.B;
   keeps.assign(B, 0);
+  declined.assign(B, -1);
   J.ord.assign(B, -1);
   J.live = false;
   int A = 0, maxLen = 0;
@@ -492,7 +548,8 @@ int kz_text_fwd_gpu_classify(kz_ctx* ctx, kz_batch& bt, int blockSize, const std
   G.mode = (int32_t*)kz_arena_alloc(ctx, (size_t)A * 4);
   G.fail = (int32_t*)kz_arena_alloc(ctx, (size_t)A * 4);
   G.stats = (int32_t*)kz_arena_alloc(ctx, (size_t)A * TF_STATS * 4);
-  if (!dText || !dDelim || !dSMap || !dSPos || !J.dOrd || !J.dOut || !J.dCond || !G.mode || !G.fail || !G.stats) { ctx->arenaTop = J.mark; return 0; }
+  G.tdt = (int32_t*)kz_arena_alloc(ctx, (size_t)A * 4);
+  if (!dText || !dDelim || !dSMap || !dSPos || !J.dOrd || !J.dOut || !J.dCond || !G.mode || !G.fail || !G.stats || !G.tdt) { ctx->arenaTop = J.mark; return 0; }
   KZ_HIP(hipMemcpyAsync(dText, hText.data(), hText.size(), hipMemcpyHostToDevice, st));
   KZ_HIP(hipMemcpyAsync(dDelim, hDelim.data(), 256, hipMemcpyHostToDevice, st));
   KZ_HIP(hipMemcpyAsync(dSMap, sMap.data(), sMap.size() * 8, hipMemcpyHostToDevice, st));
@@ -501,14 +558,18 @@ int kz_text_fwd_gpu_classify(kz_ctx* ctx, kz_batch& bt, int blockSize, const std
   KZ_HIP(hipMemsetAsync(J.dOut, 0xFF, (size_t)B * 4, st));
   KZ_HIP(hipMemsetAsync(G.stats, 0, (size_t)A * TF_STATS * 4, st));
   KZ_HIP(hipMemsetAsync(G.fail, 0, (size_t)A * 4, st));
+  KZ_HIP(hipMemsetAsync(G.tdt, 0xFF, (size_t)A * 4, st));
   G.sText = dText; G.delim = dDelim; G.sMap = dSMap; G.sPos = dSPos; G.ord = J.dOrd; G.outLen = J.dOut;
   G.map = nullptr; G.tok = nullptr; G.wpos = nullptr; G.tileSum = nullptr;
   const u8* src = bt.buf[bt.cur];
   KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_stats, dim3(16, B), dim3(256), src, bt.stride, bt.d_len, G, B);
   KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_decide, dim3((B + 63) / 64), dim3(64), src, bt.stride, bt.d_len, G, B);
-  std::vector<int32_t> mode(A);
+  KZ_LAUNCH(ctx, KID_TEXT_FWD, k_tf_pairs, dim3(B), dim3(256), src, bt.stride, bt.d_len, G, B);
+  std::vector<int32_t> mode(A), tdt(A);
   KZ_HIP(hipMemcpyAsync(mode.data(), G.mode, (size_t)A * 4, hipMemcpyDeviceToHost, st));
+  KZ_HIP(hipMemcpyAsync(tdt.data(), G.tdt, (size_t)A * 4, hipMemcpyDeviceToHost, st));
   KZ_HIP(kz_stream_sync(ctx, st));              // (also: the pageable sources above)
+  for (int b = 0; b < B; b++) if (J.ord[b] >= 0 && mode[J.ord[b]] == -1) declined[b] = tdt[J.ord[b]];    // not text: TEXT declines, this is the "dataType" it leaves
   // the blocks that are text get new dense numbers: the big tables are sized by them
   std::vector<int32_t> ord2(B, -1);
   int K = 0;

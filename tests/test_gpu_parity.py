@@ -1605,7 +1605,17 @@ def _text_fwd_blocks(bs):
     data = (c["english"][:400000] + c["utf8"][:50000] + c["random"][:40000] + c["english_crlf"][:150000] + c["xml"][:200000] + c["english_escapes"][:120000]
             + c["many_words"][:600000] + datagen.stream(2, 30000).tobytes() + c["gif_magic_text"] + c["spaces_then_text"] + c["short"] + c["min"]
             + b" " * 70 + c["english"][1000:90000] + b"the the  the The tHe the.The\r\nthe\rthe\n" * 3000 + c["english"][:5000].upper() + c["english"][5000:40000])
-    return [data[i:i + bs] for i in range(0, len(data), bs)]
+    blocks = [data[i:i + bs] for i in range(0, len(data), bs)]
+    # blocks that are NOT text: what detectType says decides whether UTF looks at them (TextCodec.java:386-440, on the device: k_tf_pairs)
+    rng = np.random.default_rng(99)
+    n = min(bs, 200000)
+    pick = lambda alphabet: bytes(np.frombuffer(alphabet, dtype=np.uint8)[rng.integers(0, len(alphabet), n)])
+    bad_utf = bytearray(textgen.utf8(n, 3)); bad_utf[n // 2] = 0xC0                     # a byte no UTF-8 text holds
+    cut_utf = bytearray(textgen.utf8(n, 4)); cut_utf[n // 3] = 0x41                     # a lead byte followed by a letter
+    blocks += [pick(b"acgtn"), pick(b"0123456789+-*/=,.:; "), pick(b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/"),
+               pick(b"abc"), bytes(textgen.utf8(n, 5, bom=True)), bytes(bad_utf), bytes(cut_utf), bytes(textgen.utf8(n, 6))[1:],
+               pick(bytes(range(0x80, 0xC0)) + b"  etaoin"), bytes(rng.integers(0, 256, n, dtype=np.uint8))]
+    return blocks
 
 
 @pytest.mark.gpu

@@ -48,7 +48,11 @@ def material(n):
     if k == 7: return words(n, 2, 4, int(rng.integers(50, 40000)))          # two- and three-letter words, many of them: the 16 384 rule
     if k == 8: return words(n, 28, 34, int(rng.integers(20, 400)))          # around the longest word
     if k == 9: return words(n, 3, 9, int(rng.integers(2000, 60000)))        # the word list doubles
-    if k == 10: return datagen.block(s & 0xFFFF, n, int(rng.integers(0, 5))).tobytes()
+    if k == 10:
+        j = int(rng.integers(0, 9))                                          # not text: detectType's verdicts (on the device: k_tf_pairs)
+        if j < 5: return datagen.block(s & 0xFFFF, n, j).tobytes()
+        alpha = [b"acgtn", b"0123456789+-*/=,.:; ", b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/", b"ab\n"][j - 5]
+        return bytes(np.frombuffer(alpha, dtype=np.uint8)[rng.integers(0, len(alpha), n)])
     return b" " * int(rng.integers(1, 300)) + bytes(textgen.english(n, s))
 
 
