@@ -1044,6 +1044,15 @@ static int overlapped_rank_bwt_inverse(kz_ctx* ctx, Pipe& P, int mode, const std
   return rc ? rc : 1;
 }
 
+// does a batch of nBlocks blocks of this chain run its TEXT stage on the device (kz_stream.hip: such chunks are not pre-staged on the host)
+bool kz_text_fwd_gpu_applies(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int nBlocks) {
+  int types[8];
+  const int nb = split_types(transformType, types);
+  int hp = 0;
+  while (hp < nb && kz_is_host_transform(types[hp])) hp++;
+  return hp > 0 && !ctx->skipBlocks && types[0] == KZ_T_TEXT && (hp == 1 || types[1] == KZ_T_UTF) && text_fwd_gpu_on(entropyType, nBlocks);
+}
+
 // =================================================================================================
 // encode
 // blockSize = the stream's "blockSize" entry as TEXT reads it, fixed when the call was made (a queued job keeps the value of its

@@ -178,6 +178,7 @@ int kz_host_transform_inverse(int type, int blockSize, const uint8_t* src, int n
 size_t kz_text_gpu_scratch_per_block(int blockSize);
 // kz_text_fwd_gpu.hip: the TEXT forward (TextCodec2) of blocks that sit in HBM (done[b] = 1 for the blocks it finished; the others: host stage)
 size_t kz_text_fwd_gpu_scratch(int B, int blockSize, int maxLen);
+bool kz_text_fwd_gpu_applies(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int nBlocks);   // kz_api.hip
 struct TextFwdJob;
 TextFwdJob* kz_text_fwd_gpu_new();
 void kz_text_fwd_gpu_free(TextFwdJob*);

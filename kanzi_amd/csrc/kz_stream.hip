@@ -319,7 +319,9 @@ static int64_t compress_pipelined(kz_ctx* ctx, uint64_t transformType, uint32_t 
       ck[k].lens.resize(cnt);
       for (int i = 0; i < cnt; i++) ck[k].lens[i] = (int32_t)std::min<int64_t>(blockSize, n - (b0 + i) * blockSize);
       const uint8_t* cs = src + b0 * blockSize;
-      ck[k].pre = kz_host_prestage(ctx, transformType, entropyType, blockSize, cs, blockSize, ck[k].lens.data(), cnt, k & 1);
+      // (a chunk whose TEXT stage runs on the device is not pre-staged: kz_encode_blocks_pre does it from the uploaded blocks)
+      ck[k].pre = kz_text_fwd_gpu_applies(ctx, transformType, entropyType, cnt) ? nullptr
+                : kz_host_prestage(ctx, transformType, entropyType, blockSize, cs, blockSize, ck[k].lens.data(), cnt, k & 1);
       uint8_t* pin = ctx->pinIn[k & 1].p;
       const int64_t bytes = std::min<int64_t>((int64_t)cnt * blockSize, n - b0 * blockSize);
       const int pieces = (int)((bytes + (8 << 20) - 1) / (8 << 20));

@@ -1652,3 +1652,26 @@ def test_text_forward_on_the_device(ctx, chain, ent, monkeypatch, capfd):
         assert took and sum(fin) >= sum(took) // 2, err[-400:]
     else:
         assert not took
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chain,ent", [("TEXT+UTF+BWT+RANK+ZRLT", "ANS0"), ("TEXT", "HUFFMAN")])
+def test_text_forward_on_the_device_in_kz_compress(chain, ent, monkeypatch, capfd):
+    """kz_compress on a host buffer of 700 blocks: its pipeline's chunks of 256 blocks run the TEXT stage on the device (they are not
+    pre-staged on the host), the last chunk of 188 blocks takes the host stages as before; the .knz is the oracle's, byte for byte."""
+    monkeypatch.setenv("KZ_STREAM_CHUNK", "256")
+    monkeypatch.setenv("KZ_TEXT_GPU_TRACE", "1")
+    monkeypatch.delenv("KZ_TEXT_FWD_GPU", raising=False)
+    bs = 32768
+    c = textgen.cases()
+    base = (c["english"][:900000] + c["utf8"][:120000] + c["xml"][:300000] + c["random"][:70000] + c["english_crlf"][:400000] + c["many_words"][:500000])
+    data = (base * 11)[:700 * bs - 777]
+    ctx = kz.Context(0)
+    out = kz.CompressedOutputStream(ctx, chain, ent, bs)
+    out.write(data)
+    out.close()
+    got = bytes(out.output)
+    ctx.close()
+    assert got == oracle.compress(chain, ent, bs, data, jobs=8)
+    err = capfd.readouterr().err
+    assert sum(int(l.split()[5]) for l in err.splitlines() if l.startswith("[textfwd] took")) > 200, err[-300:]

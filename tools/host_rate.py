@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the host-buffer entry points (kz_compress / kz_decompress): pageable host memory in,
 .knz bytes in host memory out.  Not the headline metric (bench.py times device-resident buffers); reported in
-DESIGN.md 5.   usage: tools/host_rate.py [blocks]"""
+DESIGN.md 5.   usage: tools/host_rate.py [blocks] [chain] [entropy] [mix|text]   (text = bench.py's text-heavy mix, for the level-exact chains)"""
 import os
 import sys
 import time
@@ -19,13 +19,20 @@ def main():
     nb = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     bs = 4 * 1024 * 1024
     D = min(64, nb)
-    host = np.empty((D, bs), dtype=np.uint8)
-    for i in range(D):
-        host[i] = datagen.block(i, bs)
+    chain = sys.argv[2] if len(sys.argv) > 2 else "BWT+RANK+ZRLT"
+    ent = sys.argv[3] if len(sys.argv) > 3 else "ANS0"
+    if len(sys.argv) > 4 and sys.argv[4] == "text":
+        import bench
+        D = min(16, nb)
+        host = bench.text_mix(D, bs)
+    else:
+        host = np.empty((D, bs), dtype=np.uint8)
+        for i in range(D):
+            host[i] = datagen.block(i, bs)
     data = np.ascontiguousarray(np.tile(host, ((nb + D - 1) // D, 1))[:nb]).reshape(-1)
     n = data.size
     ctx = kz.Context(0)
-    tt, et = kz.transform_type("BWT+RANK+ZRLT"), kz.ENTROPY_IDS["ANS0"]
+    tt, et = kz.transform_type(chain), kz.ENTROPY_IDS[ent.upper()]
     cap = n + n // 4 + 65536
     knz = np.empty(cap, dtype=np.uint8)
     back = np.empty(n, dtype=np.uint8)
