@@ -710,9 +710,10 @@ def main():
         if rank == 0:
             tt, et = kz.transform_type(args.chain), kz.ENTROPY_IDS[args.entropy.upper()]
 
-            def host_rate(nbytes, reps):
+            def host_rate(nbytes, reps, tt=tt, et=et, blocks=None):
                 nblk = (nbytes + bs - 1) // bs
-                hdata = np.ascontiguousarray(np.tile(host, ((nblk + D - 1) // D, 1))[:nblk]).reshape(-1)[:nbytes]
+                src_blocks = host if blocks is None else blocks
+                hdata = np.ascontiguousarray(np.tile(src_blocks, ((nblk + src_blocks.shape[0] - 1) // src_blocks.shape[0], 1))[:nblk]).reshape(-1)[:nbytes]
                 cap = int(ctx.lib.kz_compress_bound(hdata.size, bs))
                 knz = np.empty(cap, dtype=np.uint8)
                 back = np.empty(hdata.size, dtype=np.uint8)
@@ -735,6 +736,12 @@ def main():
             shapes["input_host_pcie" if args.input else "silesia_host_pcie"] = host_rate(input_bytes if args.input else SILESIA_BYTES, 2)
             if args.bulk_host_blocks > 0:
                 shapes["bulk_host_pcie"] = host_rate(args.bulk_host_blocks * bs, 2)
+                if not args.no_chains and not args.input:
+                    # the level-exact -l 5 chain through the same entry points, text-heavy mix: the chunks of kz_compress's pipeline run
+                    # the TEXT stage on the device, kz_decompress the TEXT / UTF inverses
+                    row = host_rate(args.bulk_host_blocks * bs, 2, kz.transform_type(L5[0]), kz.ENTROPY_IDS[L5[1]], text_mix(min(16, D), bs))
+                    row["chain"] = "%s & %s, text-heavy mix" % L5
+                    shapes["bulk_level5_host_pcie"] = row
         barrier()
 
     out = {
