@@ -2119,3 +2119,218 @@ def _knz_block(block, names, entropy, block_size, static_words):
     ck = (ck >> 23) ^ (ck >> 3)
     blob[ck_index] = ck & 0xFF
     return bytes(blob), written
+
+
+# ---- decoders, written from the Java (not from oracle/*.c): what a malformed input does is part of the model.  A Java exception
+# (array index past the physical array, null table entry) is JavaException: the block fails like a "false" ----
+def zrlt_inverse(data, cap):
+    """K/transform/ZRLT.java inverse :146-231 with output.length = cap.  -> (ok, bytes written).  The run is refused when it would
+    reach dstEnd (`>=`, :186) but the trailing run may end exactly there (`>`, :221)."""
+    src = bytes(data)
+    count = len(src)
+    if count == 0:
+        return True, b""
+    dst = bytearray()
+    dst_end = cap
+    i = 0
+    run = 0
+    while True:
+        val = src[i]
+        if val <= 1:
+            run = 1
+            out_of_input = False
+            while True:
+                run += run + val
+                i += 1
+                if i >= count:
+                    out_of_input = True
+                    break
+                val = src[i]
+                if val > 1:
+                    break
+            if out_of_input:
+                break                                                             # break mainLoop :177 (run still holds its +1)
+            run -= 1
+            if run > 0:
+                if len(dst) + run >= dst_end:
+                    break
+                dst += bytes(run)
+                run = 0
+        if val == 0xFF:
+            i += 1
+            if i >= count:
+                break
+            dst.append((0xFE + src[i]) & 0xFF)
+        else:
+            dst.append(val - 1)
+        i += 1
+        if i >= count or len(dst) >= dst_end:
+            break
+    if run > 0:
+        run -= 1
+        if len(dst) + run > dst_end:
+            return False, bytes(dst)
+        dst += bytes(run)
+    return i == count, bytes(dst)
+
+
+def sbrt_inverse(data, mode):
+    """K/transform/SBRT.java inverse :154-214 (no failing input exists: every rank names a symbol)."""
+    src = bytes(data)
+    m1 = 0 if mode == 3 else -1
+    m2 = 0 if mode == 1 else -1
+    s = 1 if mode == 2 else 0
+    p, q, r2s = [0] * 256, [0] * 256, list(range(256))
+    out = bytearray(len(src))
+    for i, r in enumerate(src):
+        c = r2s[r]
+        out[i] = c
+        qc = ((i & m1) + (p[c] & m2)) >> s
+        p[c] = i
+        q[c] = qc
+        while r > 0 and q[r2s[r - 1]] <= qc:
+            r2s[r] = r2s[r - 1]
+            r -= 1
+        r2s[r] = c
+    return bytes(out)
+
+
+def srt_inverse(data, cap):
+    """K/transform/SRT.java inverse :178-263, decodeHeader :327-346 (at most five bytes per count: a fifth byte's bits land at 28 and
+    may make the int negative), preprocess :266-302.  Reads past the input are a Java array fault here (the model's array is the input)."""
+    src = bytes(data)
+    n_in = len(src)
+    if n_in == 0:
+        return True, b""
+
+    def rd(k):
+        if k < 0 or k >= n_in:
+            raise JavaException("ArrayIndexOutOfBounds")
+        return src[k]
+
+    freqs = [0] * 256
+    k = 0
+    for i in range(256):
+        val = rd(k); k += 1
+        res = val & 0x7F
+        shift = 7
+        while val >= 128:
+            val = rd(k); k += 1
+            res = _i32(res | ((val & 0x7F) << shift))
+            if shift > 21:
+                break
+            shift += 7
+        freqs[i] = res
+    header = k
+    count = n_in - header
+    if count > cap:
+        return False, b""
+    symbols = [i for i in range(256) if freqs[i] > 0]
+    nb = len(symbols)
+    h = 4
+    while h < nb:
+        h = h * 3 + 1
+    while True:
+        h //= 3
+        for i in range(h, nb):
+            t = symbols[i]
+            b = i - h
+            while b >= 0 and (freqs[symbols[b]] < freqs[t] or (freqs[t] == freqs[symbols[b]] and t < symbols[b])):
+                symbols[b + h] = symbols[b]
+                b -= h
+            symbols[b + h] = t
+        if h == 1:
+            break
+    buckets, ends, r2s = [0] * 256, [0] * 256, [0] * 256
+    pos = 0
+    for i in range(nb):
+        c = symbols[i]
+        if header + pos < 0 or header + pos >= n_in:
+            return False, b""
+        r2s[rd(header + pos)] = c
+        buckets[c] = pos + 1
+        pos = _i32(pos + freqs[c])
+        ends[c] = pos
+    c = r2s[0]
+    out = bytearray(max(count, 0))
+    for i in range(count):
+        out[i] = c
+        if buckets[c] < ends[c]:
+            r = rd(header + buckets[c])
+            buckets[c] += 1
+            if r == 0:
+                continue
+            r2s[0:r] = r2s[1:r + 1]
+            r2s[r] = c
+            c = r2s[0]
+        else:
+            if nb == 1:
+                continue
+            nb -= 1
+            if nb < 0:
+                continue                                                          # (nb 0: nothing was ever listed; the loop shifts nothing)
+            r2s[0:nb] = r2s[1:nb + 1]
+            c = r2s[0]
+    return True, bytes(out)
+
+
+def utf_inverse(data, cap):
+    """K/transform/UTFCodec.java inverse :224-306 (bit stream version >= 4: unpackV1 :508-541) with output.length = cap; the physical
+    output array is taken as cap + 64 bytes for writeInt32's four-byte store; a null table entry (alias >= n) is a JavaException."""
+    src = bytes(data)
+    count = len(src)
+    if count == 0:
+        return True, b""
+    if count < 4:
+        return False, b""
+    start = src[0] & 3
+    adjust = src[1] & 3
+    n = (src[2] << 8) + src[3]
+    src_end = count - 4 + adjust
+    dst_end = cap - 4
+    if n == 0 or n >= 32768 or 3 * n >= count:
+        return False, b""
+    table = []
+    k = 4
+    for _ in range(n):
+        s = (src[k] << 16) | (src[k + 1] << 8) | src[k + 2]
+        tag = s >> 19
+        if tag == 0:
+            le, ln = s, 1
+        elif tag == 1:
+            le, ln = ((s & 0xFF) << 8) | ((s >> 8) & 0xFF), 2
+        elif tag == 2:
+            le, ln = (((s >> 12) & 0x0F) | 0xE0) | ((((s >> 6) & 0x3F) | 0x80) << 8) | (((s & 0x3F) | 0x80) << 16), 3
+        elif 4 <= tag <= 7:
+            le = (((s >> 18) & 7) | 0xF0) | ((((s >> 12) & 0x3F) | 0x80) << 8) | ((((s >> 6) & 0x3F) | 0x80) << 16) | (((s & 0x3F) | 0x80) << 24)
+            ln = 4
+        else:
+            return False, b""
+        table.append((le, ln))
+        k += 3
+    if dst_end < 0:
+        return False, b""
+    dst = bytearray(cap + 64)
+    d = 0
+
+    def rd(j):
+        if j >= count:
+            raise JavaException("ArrayIndexOutOfBounds")
+        return src[j]
+
+    for _ in range(start):
+        dst[d] = rd(k); d += 1; k += 1
+    while k < src_end and d < dst_end:
+        alias = rd(k); k += 1
+        if alias >= 128:
+            alias = (rd(k) << 7) + (alias & 0x7F); k += 1
+        if alias >= n:
+            raise JavaException("NullPointer")
+        le, ln = table[alias]
+        dst[d:d + 4] = le.to_bytes(4, "little")
+        d += ln
+    if k < src_end or d >= dst_end - count + src_end:
+        return False, bytes(dst[:d])
+    for _ in range(src_end, count):
+        dst[d] = rd(k); d += 1; k += 1
+    return True, bytes(dst[:d])
