@@ -847,3 +847,40 @@ def test_utf_inverse_from_a_python_model_of_the_reference_decoder(built):
             checked += 1
             failed += not got[0]
     assert applied >= 2 and checked > 250 and 0 < failed < checked
+
+
+def test_bwt_block_inverse_from_a_python_model_of_the_reference_decoder(built):
+    """BWTBlockCodec.inverse (BWTBlockCodec.java:131-201) + BWT.inverse / inverseMergeTPSI (BWT.java:203-235, :289-381): valid
+    blocks of every header shape, short outputs, damaged mode bytes and primary indexes (a wrong index in range = wrong bytes with
+    a success verdict, in the model as in the oracle)"""
+    import katmodels
+    rng = np.random.default_rng(8)
+    inputs = [(n, d[:9000]) for n, d in _model_inputs() if d][:8]
+    inputs += [("n%d" % n, bytes(rng.integers(97, 101, n, dtype=np.uint8))) for n in (1, 2, 3, 4, 5, 9, 63, 64, 255, 256, 257, 263, 264, 1000, 70001)]
+    checked = failed = wrong_but_ok = 0
+    for name, d in inputs:
+        ok, enc = oracle.transform_forward("BWT", d)
+        if not ok:                                                               # (the forward declines the smallest blocks)
+            continue
+        for cap in (len(d), len(d) + 7, len(d) - 1):
+            got, want = _model_verdict(katmodels.bwt_block_inverse, enc, cap), oracle.transform_inverse("BWT", enc, cap)
+            assert got[0] == want[0] and (not got[0] or got[1] == want[1]), (name, cap, got[0], want[0])
+            assert not got[0] or got[1] == d or len(d) < 6, (name, cap)          # (tiny blocks: the header is longer than the body, BWT.inverse's index test)
+        if len(d) < 256:
+            continue
+        hdr = len(enc) - len(d)
+        for j in range(60):
+            b = bytearray(enc)
+            if j % 3 == 0:
+                b[0] = int(rng.integers(0, 256))
+            elif j % 3 == 1:
+                b[int(rng.integers(1, hdr))] = int(rng.integers(0, 256))
+            else:
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            bad = bytes(b)
+            got, want = _model_verdict(katmodels.bwt_block_inverse, bad, len(d) + 64), oracle.transform_inverse("BWT", bad, len(d) + 64)
+            assert got[0] == want[0] and (not got[0] or got[1] == want[1]), (name, j, got[0], want[0])
+            checked += 1
+            failed += not got[0]
+            wrong_but_ok += got[0] and got[1] != d
+    assert checked > 500 and failed > 0 and wrong_but_ok > 0
