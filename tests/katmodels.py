@@ -610,8 +610,8 @@ def lz_decode(src, out_cap):
                 return None
             dst += src[pos:pos + lit]
             pos += lit
-            if pos >= src_end + 13:                                            # srcIdx >= srcEnd, srcEnd = token stream - 13 + the 13-byte header
-                break
+            if pos >= src_end:                                                 # srcIdx >= srcEnd (:676), srcEnd = tkIdx - 13 (:647): a literal run that ends within 13
+                break                                                          # bytes of the token stream ends the walk; only one that ends AT it succeeds (:754)
         f = token & 0x18
         if f == 0:
             mlen = token & 3

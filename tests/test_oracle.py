@@ -884,3 +884,30 @@ def test_bwt_block_inverse_from_a_python_model_of_the_reference_decoder(built):
             failed += not got[0]
             wrong_but_ok += got[0] and got[1] != d
     assert checked > 500 and failed > 0 and wrong_but_ok > 0
+
+
+def test_lz_inverse_on_damaged_frames_from_the_python_model(built):
+    """LZCodec.inverseV6 (LZCodec.java:627-756) on damaged LZ / LZX frames: verdict and bytes of katmodels.lz_decode (a Python
+    IndexError = the Java's array fault).  Writing this test found an error in the MODEL (the walk ends at the first literal run that
+    reaches tkIdx - 13, :647/:676, not the token stream itself); the oracle had it right."""
+    import katmodels
+    rng = np.random.default_rng(9)
+    cases = [b"abc" * 420, datagen.block(0, 20000).tobytes(), datagen.block(2, 30000).tobytes(), bytes(rng.integers(0, 4, 20000, dtype=np.uint8)),
+             bytes(1000) + b"xyz" * 500]
+    checked = failed = 0
+    for name in ("LZ", "LZX"):
+        for d in cases:
+            ok, enc = oracle.transform_forward(name, d)
+            if not ok:
+                continue
+            for bad in _damaged(rng, enc, 80):
+                cap = len(d) + 64
+                try:
+                    m = katmodels.lz_decode(bad, cap)
+                except IndexError:
+                    m = None
+                o = oracle.transform_inverse(name, bad, cap)
+                assert (m is not None) == o[0] and (m is None or m == o[1]), (name, len(d), bad[:13].hex())
+                checked += 1
+                failed += m is None
+    assert checked >= 700 and 0 < failed < checked
