@@ -2411,3 +2411,48 @@ def bwt_block_inverse(data, cap):
             out[n + ck * j] = ptr & 0xFF
             ts[j] = ptr >> 8
     return True, bytes(out)
+
+
+def fsd_inverse(data, cap):
+    """K/transform/FSDCodec.java inverse :249-313 with output.length = cap; the physical output array is taken as cap bytes too (the
+    XOR branch does not test dstEnd: a write past it is the Java's array fault)."""
+    src = bytes(data)
+    count = len(src)
+    if count == 0:
+        return True, b""
+    if count < 2:
+        raise JavaException("ArrayIndexOutOfBounds")
+    mode, dist = src[0], src[1]
+    if dist < 1 or (dist > 4 and dist != 8 and dist != 16):
+        return False, b""
+    dst = bytearray()
+
+    def put(v):
+        if len(dst) >= cap:
+            raise JavaException("ArrayIndexOutOfBounds")
+        dst.append(v & 0xFF)
+
+    k = 2
+    for _ in range(dist):
+        if k >= count:
+            raise JavaException("ArrayIndexOutOfBounds")
+        put(src[k]); k += 1
+    if mode == 0:
+        while k < count and len(dst) < cap:
+            if src[k] == 0xFF:
+                k += 1
+                if k == count:
+                    break
+                put(src[k] ^ dst[len(dst) - dist])
+                k += 1
+                continue
+            delta = (src[k] >> 1) ^ -(src[k] & 1)
+            put(dst[len(dst) - dist] + delta)
+            k += 1
+    elif mode == 1:
+        while k < count:
+            put(src[k] ^ dst[len(dst) - dist])
+            k += 1
+    else:
+        return False, b""
+    return k == count, bytes(dst)

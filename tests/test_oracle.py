@@ -911,3 +911,27 @@ def test_lz_inverse_on_damaged_frames_from_the_python_model(built):
                 checked += 1
                 failed += m is None
     assert checked >= 700 and 0 < failed < checked
+
+
+def test_mm_inverse_from_a_python_model_of_the_reference_decoder(built):
+    """FSDCodec.inverse (FSDCodec.java:249-313), both codings: valid blocks, exact-fit / one-short / one-spare outputs, damaged copies
+    (mode and distance bytes, escapes at the very end, insertions that overrun the output)"""
+    import katmodels
+    rng = np.random.default_rng(10)
+    applied = checked = failed = 0
+    for kind in range(5):
+        d = refinputs.multimedia_like(kind, 30000, seed=kind)
+        ok, enc = oracle.transform_forward("MM", d)
+        if not ok:
+            continue
+        applied += 1
+        for cap in (len(d), len(d) + 1, len(d) - 1, len(d) + 64):
+            got, want = _model_verdict(katmodels.fsd_inverse, enc, cap), oracle.transform_inverse("MM", enc, cap)
+            assert got[0] == want[0] and (not got[0] or got[1] == want[1] == d), (kind, cap - len(d))
+        for bad in _damaged(rng, enc, 100):
+            for cap in (len(d) + 64, len(d)):
+                got, want = _model_verdict(katmodels.fsd_inverse, bad, cap), oracle.transform_inverse("MM", bad, cap)
+                assert got[0] == want[0] and (not got[0] or got[1] == want[1]), (kind, cap - len(d), bad[:3].hex())
+                checked += 1
+                failed += not got[0]
+    assert applied >= 3 and checked >= 600 and 0 < failed < checked
