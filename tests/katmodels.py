@@ -2456,3 +2456,96 @@ def fsd_inverse(data, cap):
     else:
         return False, b""
     return k == count, bytes(dst)
+
+
+def alias_inverse(data, cap):
+    """K/transform/AliasCodec.java inverse :281-418 with output.length = cap and a physical output array of cap bytes (the packed
+    branches store without testing the output's end: a store past it is the Java's array fault, like a read past the input)."""
+    src = bytes(data)
+    count = len(src)
+    if count == 0:
+        return True, b""
+    dst = bytearray()
+
+    def rd(k):
+        if k < 0 or k >= count:
+            raise JavaException("ArrayIndexOutOfBounds")
+        return src[k]
+
+    def put_at(pos, v):
+        if pos >= cap:
+            raise JavaException("ArrayIndexOutOfBounds")
+        while len(dst) <= pos:
+            dst.append(0)
+        dst[pos] = v & 0xFF
+
+    k = 0
+    n = rd(k); k += 1
+    d = 0
+    if n < 16:
+        return False, b""
+    if n >= 240:
+        n = 256 - n
+        if n == 1:
+            val = rd(k); k += 1
+            size = _i32(rd(k) | (rd(k + 1) << 8) | (rd(k + 2) << 16) | (rd(k + 3) << 24))
+            if size > cap:
+                return False, b""
+            if size < 0:                                                          # :306-312: the test passes, nothing is written, output.index moves BACKWARDS and
+                return False, b""                                                 # the call returns true; the block then fails in Sequence (negative length): a failure
+            for i in range(size):
+                put_at(i, val)
+            return True, bytes(dst[:max(size, 0)])
+        idx2symb = [0] * 16
+        for i in range(n):
+            idx2symb[i] = rd(k); k += 1
+        adjust = rd(k); k += 1
+        if adjust >= 4:
+            return False, b""
+        if n <= 4:
+            for _ in range(adjust):
+                put_at(d, rd(k)); d += 1; k += 1
+            while k < count:
+                b = src[k]; k += 1
+                for j in range(4):                                                # writeInt32, little endian, of the word built :322-331: the low byte is bits 6..7's symbol
+                    put_at(d + j, idx2symb[(b >> (6 - 2 * j)) & 3])
+                d += 4
+        else:
+            if adjust != 0:
+                put_at(d, rd(k)); d += 1; k += 1
+            while k < count:
+                b = src[k]; k += 1
+                put_at(d, idx2symb[b >> 4])
+                put_at(d + 1, idx2symb[b & 15])
+                d += 2
+        return True, bytes(dst[:d])
+    adjust = rd(k); k += 1
+    src_end = count - adjust
+    map16 = [0x10000 | i for i in range(256)]
+    for _ in range(n):
+        map16[rd(k + 2)] = 0x20000 | rd(k) | (rd(k + 1) << 8)
+        k += 3
+    nb = src_end - k
+    if nb <= ((cap - d) >> 1):
+        while k < src_end:
+            val = map16[rd(k)]; k += 1
+            put_at(d, val); put_at(d + 1, val >> 8)
+            d += val >> 16
+    else:
+        while k < src_end and d + 1 < cap:
+            val = map16[rd(k)]; k += 1
+            put_at(d, val); put_at(d + 1, val >> 8)
+            d += val >> 16
+        while k < src_end:
+            val = map16[rd(k)]; k += 1
+            inc = val >> 16
+            if d + inc > cap:
+                return False, bytes(dst[:d])
+            put_at(d + inc - 1, val >> 8)
+            put_at(d, val)
+            d += inc
+    if adjust != 0:
+        if d >= cap:
+            return False, bytes(dst[:d])
+        put_at(d, rd(k)); d += 1; k += 1
+    return True, bytes(dst[:d])

@@ -935,3 +935,29 @@ def test_mm_inverse_from_a_python_model_of_the_reference_decoder(built):
                 checked += 1
                 failed += not got[0]
     assert applied >= 3 and checked >= 600 and 0 < failed < checked
+
+
+def test_alias_inverse_from_a_python_model_of_the_reference_decoder(built):
+    """AliasCodec.inverse (AliasCodec.java:281-418): the one-symbol, 2-bit, 4-bit and digram-alias forms of PACK / DNA blocks, tight
+    outputs, damaged copies (a negative one-symbol size makes the Java call 'succeed' with a negative length: a failed block)"""
+    import katmodels
+    rng = np.random.default_rng(11)
+    ins = [("four", bytes(rng.choice(np.frombuffer(b"acgt", dtype=np.uint8), 4099))), ("one", b"z" * 3000),
+           ("sixteen", bytes(rng.integers(64, 80, 5001, dtype=np.uint8))), ("three", bytes(rng.integers(64, 67, 4002, dtype=np.uint8)))]
+    ins += [(k, bytes(v)[:30000]) for k, v in refinputs.alias_inputs()]
+    forms, checked, failed = set(), 0, 0
+    for name, d in ins:
+        for t in ("PACK", "DNA"):
+            ok, enc = oracle.transform_forward(t, d)
+            if not ok:
+                continue
+            forms.add("one" if enc[0] == 255 else "2bit" if enc[0] >= 252 else "4bit" if enc[0] >= 240 else "alias")
+            for cap in (len(d), len(d) + 1, len(d) - 1, len(d) + 64):
+                got, want = _model_verdict(katmodels.alias_inverse, enc, cap), oracle.transform_inverse(t, enc, cap)
+                assert got[0] == want[0] and (not got[0] or got[1] == want[1] == d), (name, t, enc[0], cap - len(d))
+            for bad in _damaged(rng, enc, 60):
+                got, want = _model_verdict(katmodels.alias_inverse, bad, len(d) + 64), oracle.transform_inverse(t, bad, len(d) + 64)
+                assert got[0] == want[0] and (not got[0] or got[1] == want[1]), (name, t, bad[:6].hex())
+                checked += 1
+                failed += not got[0]
+    assert forms == {"one", "2bit", "4bit", "alias"} and checked > 1500 and 0 < failed < checked
