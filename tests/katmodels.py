@@ -2549,3 +2549,78 @@ def alias_inverse(data, cap):
             return False, bytes(dst[:d])
         put_at(d, rd(k)); d += 1; k += 1
     return True, bytes(dst[:d])
+
+
+def fpaq_decode(data, nbits, count):
+    """K/entropy/FPAQDecoder.java decode :164-234 (bit stream version >= 4: decodeBitV2 :294-314), read :322-334,
+    EntropyUtils.readVarInt :284-300, on a block's bit string of nbits bits.  -> (return value, bytes, bits consumed); a read past
+    the end of the bits is the bit stream's exception, a negative chunk size Arrays.fill's: JavaException."""
+    M56, MASK_24_56, PSCALE = (1 << 56) - 1, 0x00FFFFFFFF000000, 65536
+    src = bytes(data)
+    big = int.from_bytes(src, "big") if src else 0
+    total = len(src) * 8
+    pos = 0
+
+    def read_bits(n):
+        nonlocal pos
+        if pos + n > nbits or pos + n > total:
+            raise JavaException("BitStreamException: end of stream")
+        v = (big >> (total - pos - n)) & ((1 << n) - 1)
+        pos += n
+        return v
+
+    if count == 0:
+        return 0, b"", 0
+    low, high, current = 0, M56, 0
+    probs = [[PSCALE >> 1] * 256 for _ in range(4)]
+    out = bytearray(count)
+    start = 0
+    while start < count:
+        value = read_bits(8)
+        sz = value & 0x7F
+        shift = 7
+        while value >= 128:
+            value = read_bits(8)
+            sz |= (value & 0x7F) << shift
+            if shift == 28:
+                break
+            shift += 7
+        sz = _i32(sz)
+        if sz >= 2 * count:
+            return 0, bytes(out), pos
+        current = read_bits(56)
+        if sz < 0:
+            raise JavaException("ArrayIndexOutOfBounds (Arrays.fill from a negative index)")
+        buf = read_bits(8 * sz).to_bytes(sz, "big") + bytes(max(sz + (sz >> 2), 1024) - sz + 4) if sz else bytes(1028)
+        idx = 0
+        end = start + min(4 * 1024 * 1024, count - start)
+        p = probs[0]
+        for i in range(start, end):
+            ctx = 1
+            for _ in range(8):
+                split = (((((high - low) & M64) >> 8) * p[ctx] & M64) >> 8) + low
+                if split >= current:
+                    high = split
+                    p[ctx] -= (p[ctx] - PSCALE + 64) >> 6
+                    ctx = (ctx << 1) + 1
+                else:
+                    low = split + 1
+                    p[ctx] -= p[ctx] >> 6
+                    ctx <<= 1
+                while ((low ^ high) & MASK_24_56) == 0:
+                    low = (low << 32) & M56
+                    high = ((high << 32) | 0xFFFFFFFF) & M56
+                    if idx + 4 > sz:
+                        current = (current << 32) & M56
+                        idx = sz + 1
+                    else:
+                        current = ((current << 32) | int.from_bytes(buf[idx:idx + 4], "big")) & M56
+                        idx += 4
+            out[i] = ctx & 0xFF
+            if idx > sz:
+                return 0, bytes(out), pos
+            p = probs[(ctx & 0xFF) >> 6]
+        if idx > sz:
+            return 0, bytes(out), pos
+        start = end
+    return count, bytes(out), pos

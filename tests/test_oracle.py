@@ -961,3 +961,30 @@ def test_alias_inverse_from_a_python_model_of_the_reference_decoder(built):
                 checked += 1
                 failed += not got[0]
     assert forms == {"one", "2bit", "4bit", "alias"} and checked > 1500 and 0 < failed < checked
+
+
+def test_fpaq_decoder_from_a_python_model_of_the_reference_decoder(built):
+    """FPAQDecoder.decode (FPAQDecoder.java:164-234, decodeBitV2 :294-314, read :322-334): return value, bytes and bits consumed on
+    valid bit strings; verdict and bytes on damaged ones (most damaged FPAQ strings still decode -- to the same wrong bytes)"""
+    import katmodels
+    rng = np.random.default_rng(12)
+    cases = [datagen.block(c, 6000, c).tobytes() for c in range(5)] + [b"a" * 3000, bytes(rng.integers(0, 256, 40, dtype=np.uint8))]
+
+    def model(enc, nbits, n):
+        try:
+            return katmodels.fpaq_decode(enc, nbits, n)
+        except katmodels.JavaException:
+            return -1, b"", 0
+
+    checked = failed = 0
+    for d in cases:
+        enc, nbits = oracle.entropy_encode("FPAQ", d)
+        m, o = model(enc, nbits, len(d)), oracle.entropy_decode("FPAQ", enc, nbits, len(d))
+        assert m[0] == o[0] == len(d) and m[1] == o[1] == d and m[2] == o[2] == nbits
+        for bad in _damaged(rng, enc, 40):
+            nb = min(nbits, len(bad) * 8) if len(bad) < len(enc) else nbits + (len(bad) - len(enc)) * 8
+            m, o = model(bad, nb, len(d)), oracle.entropy_decode("FPAQ", bad, nb, len(d))
+            assert (m[0] == len(d)) == (o[0] == len(d)) and (m[0] != len(d) or m[1] == o[1]), (len(d), m[0], o[0], bad[:4].hex())
+            checked += 1
+            failed += m[0] != len(d)
+    assert checked >= 250 and 0 < failed < checked
