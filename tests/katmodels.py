@@ -2624,3 +2624,130 @@ def fpaq_decode(data, nbits, count):
             return 0, bytes(out), pos
         start = end
     return count, bytes(out), pos
+
+
+def ans0_decode(data, nbits, count):
+    """K/entropy/ANSRangeDecoder.java, order 0, bit stream version >= 4: decode :158-206, decodeHeader :374-466,
+    EntropyUtils.decodeAlphabet :86-118, decodeChunkV2 :281-366, decodeSymbol :266-279 (32-bit int states: the compare with ANS_TOP
+    is SIGNED), readVarInt.  -> (return value, bytes, bits consumed, clean): a chunk whose byte count does not come out (`n == sz`
+    false, :365) only ENDS the walk -- decode still returns count (:192-193, :204); clean says that did not happen.  BitStreamException
+    and array faults are JavaException."""
+    src = bytes(data)
+    big = int.from_bytes(src, "big") if src else 0
+    total = len(src) * 8
+    pos = 0
+
+    def read_bits(n):
+        nonlocal pos
+        if n == 0:
+            return 0
+        if pos + n > nbits or pos + n > total:
+            raise JavaException("BitStreamException: end of stream")
+        v = (big >> (total - pos - n)) & ((1 << n) - 1)
+        pos += n
+        return v
+
+    out = bytearray(count)
+    if count <= 32:
+        for i in range(count):
+            out[i] = read_bits(8)
+        return count, bytes(out), pos, True
+    freqs = [0] * 256
+    f2s = bytearray()
+    sym_freq, sym_cum = [0] * 256, [0] * 256
+    buf_len = 0
+    start = 0
+    while start < count:
+        end = min(start + 16384, count)
+        # decodeHeader
+        log_range = 8 + read_bits(3)
+        scale = 1 << log_range
+        if read_bits(1) == 0:                                                     # FULL_ALPHABET
+            alphabet = [] if read_bits(1) == 1 else list(range(256))                # ALPHABET_0 = 1, ALPHABET_256 = 0 (EntropyUtils.java:31-34)
+        else:
+            last = read_bits(5)
+            alphabet = []
+            for i in range(last + 1):
+                m = read_bits(8)
+                alphabet += [(i << 3) + j for j in range(8) if m & (1 << j)]
+        asz = len(alphabet)
+        if asz == 0:
+            return start, bytes(out), pos, True
+        llr = 3
+        while (1 << llr) <= log_range:
+            llr += 1
+        if asz != 256:
+            freqs = [0] * 256
+        if len(f2s) < scale:
+            f2s = bytearray(scale)
+        chk = 8 if asz >= 64 else 6
+        s = 0
+        for i in range(1, asz, chk):
+            log_max = read_bits(llr)
+            if (1 << log_max) > scale:
+                raise JavaException("BitStreamException: incorrect frequency size")
+            for j in range(i, min(i + chk, asz)):
+                fr = 1 if log_max == 0 else 1 + read_bits(log_max)
+                if fr <= 0 or fr >= scale:
+                    raise JavaException("BitStreamException: incorrect frequency")
+                freqs[alphabet[j]] = fr
+                s += fr
+        if scale <= s:
+            raise JavaException("BitStreamException: incorrect frequency (first symbol)")
+        freqs[alphabet[0]] = scale - s
+        s = 0
+        for i in range(256):
+            if freqs[i] == 0:
+                continue
+            if s + freqs[i] > len(f2s):
+                raise JavaException("ArrayIndexOutOfBounds")
+            f2s[s:s + freqs[i]] = bytes([i]) * freqs[i]
+            sym_cum[i] = s
+            sym_freq[i] = scale - 1 if freqs[i] >= scale else freqs[i]
+            s += freqs[i]
+        if asz == 1:
+            out[start:end] = bytes([alphabet[0]]) * (end - start)
+            start = end
+            continue
+        # decodeChunkV2
+        value = read_bits(8)
+        sz = value & 0x7F
+        shift = 7
+        while value >= 128:
+            value = read_bits(8)
+            sz |= (value & 0x7F) << shift
+            if shift == 28:
+                break
+            shift += 7
+        sz = _i32(sz)
+        if sz >= (1 << 27):
+            return count, bytes(out), pos, False
+        st = [read_bits(32) for _ in range(4)]                                   # st0 .. st3
+        buf_len = max(buf_len, 2 * (end - start), 256)
+        if sz < 0 or sz > buf_len:
+            raise JavaException("ArrayIndexOutOfBounds / negative length")
+        buf = (read_bits(8 * sz).to_bytes(sz, "big") if sz else b"") + bytes(buf_len - sz)
+        n = 0
+        mask = scale - 1
+        end4 = start + ((end - start) & -4)
+        for i in range(start, end4, 4):
+            for lane in (3, 2, 1, 0):
+                x = st[lane]
+                cur = f2s[x & mask]
+                out[i + 3 - lane] = cur
+                x = (sym_freq[cur] * (x >> log_range) + (x & mask) - sym_cum[cur]) & 0xFFFFFFFF
+                if _i32(x) < (1 << 15):
+                    if n + 1 >= buf_len:
+                        raise JavaException("ArrayIndexOutOfBounds")
+                    x = ((x << 16) | (buf[n] << 8) | buf[n + 1]) & 0xFFFFFFFF
+                    n += 2
+                st[lane] = x
+        for i in range(end4, end):
+            if n >= buf_len:
+                raise JavaException("ArrayIndexOutOfBounds")
+            out[i] = buf[n]
+            n += 1
+        if n != sz:
+            return count, bytes(out), pos, False
+        start = end
+    return count, bytes(out), pos, True

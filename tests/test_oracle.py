@@ -988,3 +988,35 @@ def test_fpaq_decoder_from_a_python_model_of_the_reference_decoder(built):
             checked += 1
             failed += m[0] != len(d)
     assert checked >= 250 and 0 < failed < checked
+
+
+def test_ans0_decoder_from_a_python_model_of_the_reference_decoder(built):
+    """ANSRangeDecoder order 0 (ANSRangeDecoder.java: decode :158-206, decodeHeader :374-466, decodeChunkV2 :281-366) +
+    EntropyUtils.decodeAlphabet (:86-118): return value, bytes and bits consumed on valid bit strings; the verdict on damaged ones
+    (a chunk whose byte count does not come out ends the walk but decode STILL returns count: the oracle does the same), the bytes
+    too whenever every chunk came out"""
+    import katmodels
+    rng = np.random.default_rng(13)
+    cases = [datagen.block(c, 40000, c).tobytes() for c in range(5)] + [b"a" * 3000, bytes(rng.integers(0, 256, 30, dtype=np.uint8)),
+             bytes(rng.integers(0, 256, 5000, dtype=np.uint8)), bytes(rng.integers(0, 3, 20001, dtype=np.uint8))]
+
+    def model(enc, nbits, n):
+        try:
+            return katmodels.ans0_decode(enc, nbits, n)
+        except katmodels.JavaException:
+            return -1, b"", 0, True
+
+    checked = failed = early = 0
+    for d in cases:
+        enc, nbits = oracle.entropy_encode("ANS0", d)
+        m, o = model(enc, nbits, len(d)), oracle.entropy_decode("ANS0", enc, nbits, len(d))
+        assert m[0] == o[0] == len(d) and m[1] == o[1] == d and m[2] == o[2] == nbits and m[3]
+        for bad in _damaged(rng, enc, 30):
+            nb = min(nbits, len(bad) * 8) if len(bad) < len(enc) else nbits + (len(bad) - len(enc)) * 8
+            m, o = model(bad, nb, len(d)), oracle.entropy_decode("ANS0", bad, nb, len(d))
+            ok_m = m[0] == len(d)
+            assert ok_m == (o[0] == len(d)) and (not (ok_m and m[3]) or m[1] == o[1]), (len(d), m[0], o[0], m[3], bad[:4].hex())
+            checked += 1
+            failed += not ok_m
+            early += ok_m and not m[3]
+    assert checked >= 250 and failed > 0 and early > 0
