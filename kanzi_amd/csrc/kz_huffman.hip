@@ -562,6 +562,8 @@ __global__ __launch_bounds__(64) void k_huf_dec_chunk(const u8* __restrict__ in,
       oo[i] = (u8)t;
       bp += (u64)(t >> 8);
     }
+    // decodeChunk's verdict (HuffmanDecoder.java, the four-way `== szBits` at its end): a fragment's symbols take exactly its stated bits
+    if (bp != fe) atomicExch(&D.status[b], -KZ_ERR_PROCESS_BLOCK);
   }
   const u64 tailPos = pos + nbq[0] + nbq[1] + nbq[2] + nbq[3];
   const int rem = size - 4 * szFrag;

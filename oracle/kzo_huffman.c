@@ -281,6 +281,9 @@ int kzo_huffman_decode(kzo_ibs* bs, uint8_t* block, int count) {
         blk[j * szFrag + i] = (uint8_t)t;
         p += (uint64_t)(t >> 8);
       }
+      /* decodeChunk's return value (HuffmanDecoder.java: `((idx - base) << 3) - (bs + MAX_SYMBOL_SIZE_V4) == szBits` for each of the four
+       * fragments): the bits a fragment's symbols took must be exactly its stated size, else decodeV6 returns startChunk - blkptr */
+      if (p != endp) { bad = 1; break; }
       pos = endp;
     }
     if (bad) { ret = startChunk; break; }

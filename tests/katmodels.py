@@ -2751,3 +2751,177 @@ def ans0_decode(data, nbits, count):
             return count, bytes(out), pos, False
         start = end
     return count, bytes(out), pos, True
+
+
+def huffman_decode(data, nbits, count):
+    """K/entropy/HuffmanDecoder.java, bit stream version >= 6: decodeV6 :353-383, readLengths :116-150 (ExpGolombDecoder.decodeByte
+    :60-78 signed, HuffmanCommon.generateCanonicalCodes :71-111), buildDecodingTables :153-172, decodeChunk :386-560 (four fragments,
+    64-bit states, Java shift counts taken mod 64 / mod 32), 16 KiB chunks.  -> (return value, bytes, bits consumed).  Bit stream
+    exceptions and array faults are JavaException."""
+    src = bytes(data)
+    big = int.from_bytes(src, "big") if src else 0
+    total = len(src) * 8
+    pos = 0
+
+    def read_bits(n):
+        nonlocal pos
+        if n == 0:
+            return 0
+        if n < 0 or pos + n > nbits or pos + n > total:
+            raise JavaException("BitStreamException")
+        v = (big >> (total - pos - n)) & ((1 << n) - 1)
+        pos += n
+        return v
+
+    def varint():
+        value = read_bits(8)
+        res = value & 0x7F
+        shift = 7
+        while value >= 128:
+            value = read_bits(8)
+            res |= (value & 0x7F) << shift
+            if shift == 28:
+                break
+            shift += 7
+        return _i32(res)
+
+    def s64(x):
+        x &= M64
+        return x - (1 << 64) if x >> 63 else x
+
+    out = bytearray(count)
+    if count == 0:
+        return 0, b"", 0
+    sizes = [0] * 256
+    codes = [0] * 256
+    table = [0] * 4096
+    CH, MAXS = 16384, 12
+    start = 0
+    while start < count:
+        n_chunk = min(CH, count - start)
+        end = start + n_chunk
+        if n_chunk < 32:
+            for i in range(start, end):
+                out[i] = read_bits(8)
+            start = end
+            continue
+        # readLengths
+        if read_bits(1) == 0:
+            alphabet = [] if read_bits(1) == 1 else list(range(256))
+        else:
+            last = read_bits(5)
+            alphabet = []
+            for i in range(last + 1):
+                m = read_bits(8)
+                alphabet += [(i << 3) + j for j in range(8) if m & (1 << j)]
+        asz = len(alphabet)
+        if asz == 0:
+            return start, bytes(out), pos
+        cur = 2
+        for s in alphabet:
+            codes[s] = 0
+            if read_bits(1) == 1:
+                delta = 0
+            else:
+                log2 = 1
+                while read_bits(1) == 0:
+                    log2 += 1
+                if log2 + 1 > 64:
+                    raise JavaException("IllegalArgumentException: readBits count")
+                res = read_bits(log2 + 1)
+                sgn = res & 1
+                res = (res >> 1) + _i32(1 << (log2 & 31)) - 1
+                delta = ((res - sgn) ^ -sgn) & 0xFF
+                delta = delta - 256 if delta >= 128 else delta
+            cur += delta
+            if cur <= 0 or cur > MAXS:
+                raise JavaException("BitStreamException: incorrect size")
+            sizes[s] = cur
+        if asz > 1:
+            alphabet = sorted(alphabet, key=lambda s: (sizes[s], s))
+        code = 0
+        cur_len = sizes[alphabet[0]]
+        for s in alphabet:
+            code <<= sizes[s] - cur_len
+            cur_len = sizes[s]
+            codes[s] = code
+            code += 1
+        if asz == 1:
+            out[start:end] = bytes([alphabet[0]]) * n_chunk
+            start = end
+            continue
+        # buildDecodingTables
+        table = [7] * 4096
+        length = 0
+        for s in alphabet:
+            if sizes[s] > length:
+                length = sizes[s]
+            val = (sizes[s] << 8) | s
+            idx = codes[s] << (MAXS - length)
+            stop = idx + (1 << (MAXS - length))
+            if stop > 4096:
+                raise JavaException("ArrayIndexOutOfBounds")
+            for t in range(idx, stop):
+                table[t] = val
+        # decodeChunk
+        sz_bits = [varint() for _ in range(4)]
+        if min(sz_bits) < 0:
+            return start, bytes(out), pos
+        buf = bytearray(2 * CH)
+        stride = (2 * CH) // 4
+        for f in range(4):
+            nb = sz_bits[f]
+            if (nb >> 3) > len(buf) - f * stride:
+                raise JavaException("IllegalArgumentException: readBits count")
+            whole = nb >> 3
+            if whole:
+                if pos + 8 * whole > nbits:
+                    raise JavaException("BitStreamException")
+                buf[f * stride:f * stride + whole] = read_bits(8 * whole).to_bytes(whole, "big")
+            if nb & 7:
+                if f * stride + whole >= len(buf):
+                    raise JavaException("ArrayIndexOutOfBounds")
+                buf[f * stride + whole] = read_bits(nb & 7) << (8 - (nb & 7))
+        frag = n_chunk // 4
+
+        def long_at(i):
+            if i < 0 or i + 8 > len(buf):
+                raise JavaException("ArrayIndexOutOfBounds")
+            return int.from_bytes(buf[i:i + 8], "big")
+
+        consumed = []
+        for f in range(4):
+            state, bits, idx = 0, 0, f * stride
+            o = start + f * frag
+            n = 0
+
+            def refill():
+                nonlocal state, bits, idx
+                shift = _i32((56 - bits) & -8)
+                state = ((state << (shift & 63)) | ((long_at(idx) >> ((63 - shift) & 63)) >> 1)) & M64
+                idx = _i32(idx + ((shift & 0xFFFFFFFF) >> 3))
+                return bits + shift - MAXS
+
+            def take(bs):
+                v = table[(s64(state) >> (bs & 63)) & 0xFFF]
+                return v, bs - (v >> 8)
+
+            while n < frag - 4:
+                bs = refill()
+                for k in range(4):
+                    v, bs = take(bs)
+                    out[o + n + k] = v & 0xFF
+                n += 4
+                bits = bs + MAXS
+            bs = refill()
+            while n < frag:
+                v, bs = take(bs)
+                out[o + n] = v & 0xFF
+                n += 1
+            consumed.append(((idx - f * stride) << 3) - (bs + MAXS))
+        for i in range(4 * frag, n_chunk):
+            out[start + i] = read_bits(8)
+        if consumed != sz_bits:
+            return start, bytes(out), pos
+        start = end
+    return count, bytes(out), pos

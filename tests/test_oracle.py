@@ -1020,3 +1020,34 @@ def test_ans0_decoder_from_a_python_model_of_the_reference_decoder(built):
             failed += not ok_m
             early += ok_m and not m[3]
     assert checked >= 250 and failed > 0 and early > 0
+
+
+def test_huffman_decoder_from_a_python_model_of_the_reference_decoder(built):
+    """HuffmanDecoder (HuffmanDecoder.java: decodeV6 :353-383, readLengths :116-150, buildDecodingTables :153-172, decodeChunk with
+    its closing test that each of the four fragments took exactly its stated bits): return value, bytes, bits consumed on valid bit
+    strings; verdict and bytes on damaged ones.  This model found a difference: the oracle (and the HIP decoder) did not make
+    decodeChunk's closing test and accepted damaged fragments the reference refuses -- fixed in both."""
+    import katmodels
+    rng = np.random.default_rng(14)
+    cases = [datagen.block(c, 40000, c).tobytes() for c in range(5)] + [b"a" * 3000, bytes(rng.integers(0, 256, 30, dtype=np.uint8)),
+             bytes(rng.integers(0, 256, 5000, dtype=np.uint8)), bytes(rng.integers(0, 3, 20001, dtype=np.uint8))]
+
+    def model(enc, nbits, n):
+        try:
+            return katmodels.huffman_decode(enc, nbits, n)
+        except katmodels.JavaException:
+            return -1, b"", 0
+
+    checked = failed = 0
+    for d in cases:
+        enc, nbits = oracle.entropy_encode("HUFFMAN", d)
+        m, o = model(enc, nbits, len(d)), oracle.entropy_decode("HUFFMAN", enc, nbits, len(d))
+        assert m[0] == o[0] == len(d) and m[1] == o[1] == d and m[2] == o[2] == nbits
+        for bad in _damaged(rng, enc, 40):
+            nb = min(nbits, len(bad) * 8) if len(bad) < len(enc) else nbits + (len(bad) - len(enc)) * 8
+            m, o = model(bad, nb, len(d)), oracle.entropy_decode("HUFFMAN", bad, nb, len(d))
+            ok_m = m[0] == len(d)
+            assert ok_m == (o[0] == len(d)) and (not ok_m or m[1] == o[1]), (len(d), m[0], o[0], bad[:4].hex())
+            checked += 1
+            failed += not ok_m
+    assert checked >= 350 and 0 < failed < checked
