@@ -194,6 +194,9 @@ def compact(out):
                              "roofline": compact_roofline(ch["roofline"])}
         if ch.get("host_stage_ms_per_step"):
             cc["chains"][key]["host_stage_ms"] = {k: _r(v) for k, v in ch["host_stage_ms_per_step"].items()}
+        for a in ("knz_identical_to_hip", "blocks_compared_with_oracle"):
+            if a in ch:
+                cc["chains"][key][a] = ch[a]
         if ch.get("host_share8"):
             cc["chains"][key]["host_share8"] = {k: _r(v) for k, v in ch["host_share8"].items() if k != "what"}
     cc["shapes"] = {}
@@ -205,6 +208,9 @@ def compact(out):
         for a, b in (("encode_MBps", "enc"), ("decode_MBps", "dec"), ("compress_MBps", "enc"), ("decompress_MBps", "dec"), ("enc_dec_MBps", "enc_dec")):
             if a in sh:
                 row[b] = _r(sh[a])
+        for a in ("knz_identical_to_hip", "blocks_compared_with_oracle"):
+            if a in sh:
+                row[a] = sh[a]
         cc["shapes"][key] = row
     o = {k: _r(v) for k, v in out.items() if k not in ("config", "roofline", "kernels", "cpu_baseline")}
     o["config"] = cc
@@ -220,11 +226,17 @@ def compact(out):
         o["cpu_baseline"]["usable_cpus"] = cb["host"]["usable_cpus"]
     else:
         o["cpu_baseline"] = None
-    o["detail"] = "per-kernel tables and per-stage rooflines: profiles/%s_bench_kernels.json (same run, written by --detail-json)" % out.get("_tag", "r05")
+    o["detail"] = "per-kernel tables and per-stage rooflines of THIS run: %s (--detail-json; tools/profile_round.sh copies its own run's file to profiles/%s_bench_kernels.json)" % (out.get("_detail_path", "?"), out.get("_tag", "r06"))
     return o
 
 
 def load_traffic(path, B, chain, entropy):
+    if not os.path.exists(path):                                       # this round's PMC passes not collected (yet): the newest earlier round's,
+        import glob                                                    # named as such in roofline.traffic_source
+        base = os.path.basename(path).split("_", 1)[1]
+        older = sorted(glob.glob(os.path.join(os.path.dirname(path), "r[0-9][0-9]_" + base)))
+        if older:
+            path = older[-1]
     try:
         with open(path) as f:
             tj = json.load(f)
@@ -319,7 +331,7 @@ def main():
     ap.add_argument("--data-class", type=int, default=-1, help="diagnostic: force one class of the synthetic generator (0..4) instead of the mix")
     ap.add_argument("--detail-json", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
                     help="the full record (per-kernel tables, per-stage rooflines of every chain) is written here; the printed line is the compact form")
-    ap.add_argument("--profiles-tag", default="r05", help="profiles/<tag>_pmc_traffic*.json: per-kernel HBM bytes from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)")
+    ap.add_argument("--profiles-tag", default="r06", help="profiles/<tag>_pmc_traffic*.json: per-kernel HBM bytes from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)")
     ap.add_argument("--traffic-json", default="", help="override the PMC traffic file of the headline chain")
     ap.add_argument("--cpu-sample-blocks", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
     args = ap.parse_args()
@@ -497,8 +509,10 @@ def main():
                "enc_dec_MBps": step_bytes * world * steps / elapsed / 1e6, "encode_MBps": step_bytes * world * steps / te / 1e6,
                "decode_MBps": step_bytes * world * steps / td / 1e6, "ms_per_step": elapsed / steps * 1e3,
                "roofline": roof, "kernels": kernels, "host_stage_ms_per_step": host_ms}
-        if keep:
-            out["_batch"] = bt
+        if keep:                                                       # a sample of the HIP block streams for the oracle comparison in the cpu_baseline leg
+            nsm = min(nb, src.shape[0], 16)                            # (rows 0 .. d-1 of the batch are the d distinct blocks)
+            out["_sample"] = [(int(res[k].bits), int(res[k].skipFlags), int(res[k].length), bt.d_enc[k, :(int(res[k].bits) + 7) // 8].cpu().numpy().tobytes(),
+                               src[k, :int(bt.lengths[k])].cpu().numpy().tobytes()) for k in range(nsm)]
         return out
 
     d_host = torch.from_numpy(host).to(dev)
@@ -588,20 +602,23 @@ def main():
 
     # ================= config.chains: the other BASELINE configs, same harness, one short pass each =================
     chains = {}
+    oracle_checks = []          # (section, row, chain, entropy, sample): HIP outputs kept for the cpu_baseline leg, where the oracle may be used
     if not args.no_chains:
         d_text = None
         for key, chain, entropy, data, what in (
                 ("lz_ans0", "LZ", "ANS0", "mix", "configs[1]: silesia.tar -l 3 shorthand (LZ+ANS) as the explicit chain -t LZ -e ANS0"),
                 ("bwt_srt_zrlt_fpaq", "BWT+SRT+ZRLT", "FPAQ", "mix", "configs[4]: synthetic 8 GiB mixed-entropy stream, the level-6 core chain (HBM-roofline report)"),
-                ("level5_exact", "TEXT+UTF+BWT+RANK+ZRLT", "ANS0", "text", "level-exact -l 5 (BlockCompressor.java:539-573) on a text-heavy mix; TEXT / UTF run on host threads inside the timed region")):
+                ("level5_exact", "TEXT+UTF+BWT+RANK+ZRLT", "ANS0", "text", "level-exact -l 5 (BlockCompressor.java:539-573) on a text-heavy mix; the TEXT forward, the TEXT and UTF inverses run on the device, the UTF forward of the UTF-8 blocks on host threads, all inside the timed region")):
             if data == "text" and d_text is None:
                 d_text = d_host if args.input else torch.from_numpy(text_mix(min(16, D), bs)).to(dev)
-            r = timed_pass(d_text if data == "text" else d_host, B, chain, entropy, args.chain_steps, 1, prof("pmc_traffic_%s.json" % key))
+            r = timed_pass(d_text if data == "text" else d_host, B, chain, entropy, args.chain_steps, 1, prof("pmc_traffic_%s.json" % key), keep=(key == "level5_exact"))
             chains[key] = {"what": what, "chain": chain, "entropy": entropy, "data": ("file %s" % os.path.basename(args.input)) if args.input else "synthetic %s" % data,
                            "blocks_per_gpu_per_step": B, "steps": r["steps"], "warmup": r["warmup"], "ms_per_step": r["ms_per_step"],
                            "encode_MBps": r["encode_MBps"], "decode_MBps": r["decode_MBps"], "enc_dec_MBps": r["enc_dec_MBps"],
                            "z_post_transform_ratio": r["z"], "c_compressed_ratio": r["c"], "round_trip_ok": True,
                            "host_stage_ms_per_step": r["host_stage_ms_per_step"], "roofline": r["roofline"], "kernels": r["kernels"][:6]}
+            if "_sample" in r:
+                oracle_checks.append(("chains", key, chain, entropy, r["_sample"]))
             if key == "level5_exact":
                 # what ONE of eight ranks on a node gets: the host pool capped to 1/8 of the box's CPUs (TEXT / UTF run on the host;
                 # VERDICT r4 item 4).  One timed step, same batch.
@@ -710,7 +727,7 @@ def main():
         if rank == 0:
             tt, et = kz.transform_type(args.chain), kz.ENTROPY_IDS[args.entropy.upper()]
 
-            def host_rate(nbytes, reps, tt=tt, et=et, blocks=None):
+            def host_rate(nbytes, reps, tt=tt, et=et, blocks=None, keep_first=0):
                 nblk = (nbytes + bs - 1) // bs
                 src_blocks = host if blocks is None else blocks
                 hdata = np.ascontiguousarray(np.tile(src_blocks, ((nblk + src_blocks.shape[0] - 1) // src_blocks.shape[0], 1))[:nblk]).reshape(-1)[:nbytes]
@@ -731,6 +748,14 @@ def main():
                     if best is None or row["enc_dec_MBps"] > best["enc_dec_MBps"]:
                         best = row
                 best["what"] = "kz_compress / kz_decompress on host buffers: H2D, codec, D2H and host bit assembly inside the timed region; one GPU"
+                if keep_first:                                         # the first blocks' bit strings of the .knz just written, for the oracle comparison
+                    off = np.zeros(keep_first, dtype=np.int64)
+                    nbits = np.zeros(keep_first, dtype=np.int64)
+                    nb_ = int(ctx.lib.kz_knz_index(knz.ctypes.data, m, None, None, None, None, None, off.ctypes.data, nbits.ctypes.data, keep_first))
+                    kf = min(keep_first, max(nb_, 0))
+                    head_bytes = knz[:int((off[kf - 1] + nbits[kf - 1] + 7) // 8) + 8].tobytes() if kf else b""
+                    best["_sample"] = ([(int(off[i]), int(nbits[i]), kz.extract_bits(head_bytes, int(off[i]), int(nbits[i]))) for i in range(kf)],
+                                       hdata[:kf * bs].tobytes())
                 return best
 
             shapes["input_host_pcie" if args.input else "silesia_host_pcie"] = host_rate(input_bytes if args.input else SILESIA_BYTES, 2)
@@ -739,8 +764,10 @@ def main():
                 if not args.no_chains and not args.input:
                     # the level-exact -l 5 chain through the same entry points, text-heavy mix: the chunks of kz_compress's pipeline run
                     # the TEXT stage on the device, kz_decompress the TEXT / UTF inverses
-                    row = host_rate(args.bulk_host_blocks * bs, 2, kz.transform_type(L5[0]), kz.ENTROPY_IDS[L5[1]], text_mix(min(16, D), bs))
+                    row = host_rate(args.bulk_host_blocks * bs, 2, kz.transform_type(L5[0]), kz.ENTROPY_IDS[L5[1]], text_mix(min(16, D), bs), keep_first=min(16, D, args.bulk_host_blocks))
                     row["chain"] = "%s & %s, text-heavy mix" % L5
+                    if "_sample" in row:
+                        oracle_checks.append(("shapes", "bulk_level5_host_pcie", L5[0], L5[1], row.pop("_sample")))
                     shapes["bulk_level5_host_pcie"] = row
         barrier()
 
@@ -756,7 +783,7 @@ def main():
                    "chains": chains, "shapes": shapes},
         "roofline": head["roofline"],
         "kernels": head["kernels"][:nk],
-        "_tag": tag,
+        "_tag": tag, "_detail_path": os.path.relpath(args.detail_json, ROOT),
     }
 
     # ---- CPU baseline: the oracle (C restatement) on this box's host cores, bounded sample; rank 0, once ----
@@ -802,6 +829,30 @@ def main():
         out["cpu_baseline"] = cb
         if cos.output != pref:
             raise SystemExit("PARITY FAILURE: HIP .knz differs from the oracle on the cpu_baseline sample")
+        # the level-exact rows (device TEXT / UTF kernels at 4 MiB blocks): a sample of their HIP outputs against the oracle, not against
+        # the HIP decoder.  chains.*: block streams, bit counts, skip flags, lengths of up to 16 distinct blocks of the
+        # bulk batch == oracle.encode_block; shapes.bulk_level5_host_pcie: the first 16 blocks' bit strings inside kz_compress's .knz ==
+        # the same blocks' bit strings inside the oracle's .knz of those 16 blocks
+        from concurrent.futures import ThreadPoolExecutor
+        for section, key, chain_, ent_, sample in oracle_checks:
+            row = out["config"][section].get(key)
+            if row is None:
+                continue
+            if section == "chains":
+                with ThreadPoolExecutor(max(1, min(usable, 16))) as ex:
+                    want = list(ex.map(lambda t: oracle.encode_block(chain_, ent_, t[4], block_size=bs), sample))
+                same = all((w[1], w[2], w[3]) == (t[0], t[1], t[2]) and w[0] == t[3] for w, t in zip(want, sample))
+                n_cmp = len(sample)
+            else:
+                blocks_, raw = sample
+                pref2 = oracle.compress(chain_, ent_, bs, raw, jobs=max(1, min(usable, 16)))
+                idx = kz.knz_index(pref2)["blocks"]
+                same = len(idx) == len(blocks_) and all(b[1] == o[1] and b[2] == kz.extract_bits(pref2, o[0], o[1]) for b, o in zip(blocks_, idx))
+                n_cmp = len(blocks_)
+            row["knz_identical_to_hip"] = bool(same)
+            row["blocks_compared_with_oracle"] = n_cmp
+            if not same:
+                raise SystemExit("PARITY FAILURE: %s.%s: HIP output differs from the oracle on the sampled blocks" % (section, key))
         # one thread alone (its suffix array stays in cache): the reference's README row implies about 7.7 MB/s per thread for encode
         # INCLUDING TEXT+UTF on its 16-core host
         one = np.ascontiguousarray(host[:min(D, 5)]).reshape(-1)

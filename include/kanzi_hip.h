@@ -93,6 +93,11 @@ int32_t     kz_ctx_set_skip_blocks(kz_ctx* ctx, int32_t on);
  * size explicitly and a silent default would write blocks another block size cannot read; kz_decode_blocks takes it from its
  * blockSize argument; kz_transform_forward / _inverse take both from here; kz_compress / kz_decompress set them from the
  * stream.  kz_ctx_set_entropy refuses TPAQX (9): TEXT's extra hash bit under it (TextCodec.java:561-575) is not modelled. */
+/* The library's environment switches (KZ_*: diagnostics, A/B runs, the tests' forced schedules -- DESIGN.md 7; none is needed for
+ * normal use) are read ONCE, by kz_ctx_create, into the context; no call reads the environment afterwards.  A test or A/B tool
+ * that changes the environment of a live context calls this to have it read again.  (No reference counterpart: the reference
+ * takes its options through the context map, K/io/CompressedOutputStream.java:140-190.) */
+void        kz_ctx_reload_switches(kz_ctx* ctx);
 int32_t     kz_ctx_set_block_size(kz_ctx* ctx, int32_t blockSize);
 int32_t     kz_ctx_set_entropy(kz_ctx* ctx, uint32_t entropyType);
 int32_t     kz_ctx_set_data_type(kz_ctx* ctx, int32_t dataType);

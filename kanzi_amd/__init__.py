@@ -18,6 +18,7 @@ Reference interfaces mirrored (K/ = java/src/main/java/io/github/flanglet/kanzi/
 # touches the process environment.  Without it the library measures that its streams share queues and falls back to a
 # three-stream schedule.
 import ctypes
+import weakref
 import os
 
 import numpy as np
@@ -78,6 +79,7 @@ def load_library():
         "kz_ctx_set_checksum": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_set_skip_blocks": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_set_block_size": (c.c_int32, [vp, c.c_int32]),
+        "kz_ctx_reload_switches": (None, [vp]),
         "kz_ctx_set_entropy": (c.c_int32, [vp, c.c_uint32]),
         "kz_ctx_set_data_type": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_get_data_type": (c.c_int32, [vp]),
@@ -127,7 +129,7 @@ def load_library():
 
 
 ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_error", "kz_ctx_stream", "kz_pin_to_device_numa", "kz_host_cpus", "kz_host_share", "kz_ctx_set_checksum",
-               "kz_ctx_set_data_type", "kz_ctx_get_data_type", "kz_ctx_reset", "kz_ctx_set_skip_blocks", "kz_ctx_set_block_size", "kz_ctx_set_entropy",
+               "kz_ctx_set_data_type", "kz_ctx_get_data_type", "kz_ctx_reset", "kz_ctx_set_skip_blocks", "kz_ctx_set_block_size", "kz_ctx_reload_switches", "kz_ctx_set_entropy",
                "kz_transform_forward", "kz_transform_inverse", "kz_transform_max_encoded_len", "kz_host_stage_forward", "kz_host_stage_inverse",
                "kz_entropy_encode", "kz_entropy_decode", "kz_encode_blocks", "kz_decode_blocks",
                "kz_max_block_stream_bytes", "kz_submit_encode_blocks", "kz_submit_decode_blocks", "kz_wait", "kz_poll", "kz_compress", "kz_decompress", "kz_compress_bound", "kz_transform_type",
@@ -205,6 +207,15 @@ def _ptr(a):
     return int(a)
 
 
+_LIVE = weakref.WeakSet()
+
+
+def reload_switches():
+    """every live Context reads the KZ_* environment switches again (they are read once, at creation)"""
+    for c in list(_LIVE):
+        c.reload_switches()
+
+
 class Context:
     """One HIP stream + scratch arena on one GPU (kz_ctx). Not thread-safe, like a reference codec instance."""
 
@@ -213,6 +224,7 @@ class Context:
         self.h = self.lib.kz_ctx_create(int(device))
         if not self.h:
             raise RuntimeError("kz_ctx_create(%d) failed: no usable HIP device (the HIP path has no CPU fallback)" % device)
+        _LIVE.add(self)
 
     def close(self):
         if getattr(self, "h", None):
@@ -224,6 +236,11 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def reload_switches(self):
+        """The KZ_* environment switches are read once, when the context is created: read them again (tests, A/B tools)."""
+        if getattr(self, "h", None):
+            self.lib.kz_ctx_reload_switches(self.h)
 
     def error(self):
         return self.lib.kz_last_error(self.h).decode("utf-8", "replace")

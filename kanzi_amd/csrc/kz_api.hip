@@ -35,12 +35,49 @@ extern "C" kz_ctx* kz_ctx_create(int32_t deviceId) {
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
   if (hipHostMalloc((void**)&ctx->hpin, 1 << 20, hipHostMallocDefault) != hipSuccess) { hipStreamDestroy(ctx->stream); delete ctx; return nullptr; }
   ctx->hpinInts = (1 << 20) / 4;
+  kz_switches_read(ctx->sw);
   {
-    const char* e = getenv("KZ_BLOCKING_WAITS");
     const int hw = (int)std::thread::hardware_concurrency();
-    ctx->blockingWaits = e ? (atoi(e) ? 1 : 0) : ((hw > 0 && kz_usable_cpus() < hw) ? 1 : 0);
+    ctx->blockingWaits = ctx->sw.blockingWaits >= 0 ? ctx->sw.blockingWaits : ((hw > 0 && kz_usable_cpus() < hw) ? 1 : 0);
   }
   return ctx;
+}
+// every environment switch of the library, in one place (kz_internal.h: kz_switches)
+void kz_switches_read(kz_switches& s) {
+  s = kz_switches();
+  auto num = [](const char* name, int unset) { const char* e = getenv(name); return e ? atoi(e) : unset; };
+  auto flag = [](const char* name) { return getenv(name) != nullptr ? 1 : 0; };
+  auto digit = [](const char* name, int lo, int hi, int unset) { const char* e = getenv(name); return (e && e[0] >= '0' + lo && e[0] <= '0' + hi) ? e[0] - '0' : unset; };
+  { const char* e = getenv("KZ_BLOCKING_WAITS"); s.blockingWaits = e ? (atoi(e) ? 1 : 0) : -1; }
+  s.textGpu = digit("KZ_TEXT_GPU", 0, 3, -1);
+  s.textGpuMin = num("KZ_TEXT_GPU_MIN", 512);
+  s.textFwdGpu = digit("KZ_TEXT_FWD_GPU", 0, 1, -1);
+  s.textFwdGpuMin = num("KZ_TEXT_FWD_GPU_MIN", 256);
+  s.utfGpu = digit("KZ_UTF_GPU", 0, 0, 1);
+  s.utfFwdGpu = digit("KZ_UTF_FWD_GPU", 0, 1, -1);
+  s.textGpuTrace = flag("KZ_TEXT_GPU_TRACE");
+  s.fuseMinBlocks = num("KZ_FUSE_MIN_BLOCKS", 32);
+  s.overlapClasses = num("KZ_OVERLAP_CLASSES", 3);
+  { const char* e = getenv("KZ_WIDE_QUEUES"); s.wideQueues = e ? (atoi(e) ? 1 : 0) : -1; }
+  s.noSFirst = flag("KZ_NO_SFIRST");
+  s.traceSched = flag("KZ_TRACE_SCHED");
+  s.tracePipe = flag("KZ_TRACE_PIPE");
+  s.hostChunk = num("KZ_HOST_CHUNK", 0);
+  { const int v = num("KZ_HOST_CHUNK_DEC", 512); s.hostChunkDec = v < 8 ? 8 : v; }
+  { const char* e = getenv("KZ_HOST_INV_STAGED"); s.hostInvStaged = e ? atoi(e) : -1; }
+  s.streamChunk = num("KZ_STREAM_CHUNK", 0);
+  s.streamSerial = flag("KZ_STREAM_SERIAL");
+  s.bwtTrie = num("KZ_BWT_TRIE", -1); s.bwtTrieWin = num("KZ_BWT_TRIEWIN", -1); s.bwtBuckets = num("KZ_BWT_BUCKETS", -1);
+  s.bwtDmax = num("KZ_BWT_DMAX", -1); s.bwtRetire = num("KZ_BWT_RETIRE", -1);
+  s.bwtTrace = flag("KZ_BWT_TRACE");
+  s.bwtTestTrieOverflow = digit("KZ_BWT_TEST_TRIE_OVERFLOW", 0, 9, -1);
+  { const char* f = getenv("KZ_FPAQ_FORCE"); s.fpaqForce = f ? ((f[0] == 'w' || f[0] == 'W' || f[0] == '1') ? 1 : ((f[0] == 'l' || f[0] == 'L' || f[0] == '2') ? 2 : 0)) : 0; }
+  s.sbrtForm = num("KZ_SBRT_FORM", -1);
+}
+extern "C" void kz_ctx_reload_switches(kz_ctx* ctx) {
+  if (!ctx) return;
+  kz_switches_read(ctx->sw);
+  if (ctx->sw.blockingWaits >= 0) ctx->blockingWaits = ctx->sw.blockingWaits;
 }
 extern "C" void kz_ctx_destroy(kz_ctx* ctx) {
   if (!ctx) return;
@@ -58,11 +95,14 @@ extern "C" void kz_ctx_destroy(kz_ctx* ctx) {
     if (ctx->pinOut[i].p) hipHostFree(ctx->pinOut[i].p);
     if (ctx->hsIn[i].p) hipHostFree(ctx->hsIn[i].p);
     if (ctx->hsOut[i].p) hipHostFree(ctx->hsOut[i].p);
+    if (ctx->tfOut[i].p) hipHostFree(ctx->tfOut[i].p);
     if (ctx->hiAux[i].p) hipFree(ctx->hiAux[i].p);
     if (ctx->hiStream[i]) hipStreamDestroy(ctx->hiStream[i]);
     if (ctx->devIn[i].p) hipFree(ctx->devIn[i].p);
     if (ctx->devOut[i].p) hipFree(ctx->devOut[i].p);
   }
+  if (ctx->tfIn.p) hipHostFree(ctx->tfIn.p);
+  if (ctx->tfCopy) hipStreamDestroy(ctx->tfCopy);
   if (ctx->evBlock) hipEventDestroy(ctx->evBlock);
   if (ctx->copyUp) hipStreamDestroy(ctx->copyUp);
   if (ctx->copyDown) hipStreamDestroy(ctx->copyDown);
@@ -778,34 +818,25 @@ __global__ void k_merge_group(const int32_t* __restrict__ in, const int32_t* __r
 // coder selects TextCodec2 (every coder but FPAQ / the CM family, TextCodec.java:73-88) in batches of KZ_TEXT_GPU_MIN blocks or more
 // (512: a block takes the kernel ~0.1 s however few there are, the host stage ~10 ms per block and thread), else the host stage;
 // 0 = host stage only; 1 = row form, three waves; 2 = serial token walk (both codecs); 3 = row form, one wave (1-3: any batch).
-static int text_gpu_form(uint32_t entropyType, int nBlocks) {
-  const char* e = getenv("KZ_TEXT_GPU");
-  if (e && e[0] >= '0' && e[0] <= '3') return e[0] - '0';
-  const char* m = getenv("KZ_TEXT_GPU_MIN");
-  const int minBlocks = m ? atoi(m) : 512;
-  return (entropyType == KZ_E_FPAQ || nBlocks < minBlocks) ? 0 : 1;
+static int text_gpu_form(const kz_ctx* ctx, uint32_t entropyType, int nBlocks) {
+  if (ctx->sw.textGpu >= 0) return ctx->sw.textGpu;
+  return (entropyType == KZ_E_FPAQ || nBlocks < ctx->sw.textGpuMin) ? 0 : 1;
 }
-static bool text_gpu_on(uint32_t entropyType, int nBlocks) { return text_gpu_form(entropyType, nBlocks) != 0; }
+static bool text_gpu_on(const kz_ctx* ctx, uint32_t entropyType, int nBlocks) { return text_gpu_form(ctx, entropyType, nBlocks) != 0; }
 // TEXT forward on the device (kz_text_fwd_gpu.hip): TextCodec2 streams (every entropy coder but FPAQ) in batches of KZ_TEXT_FWD_GPU_MIN
 // blocks (256) or more -- a block's dictionary walk takes the kernel ~0.1 s however few there are, so small batches stay on the host's
 // chunk pipeline (measured with 16 host CPUs, level-exact -l 5 encode of 64 / 128 / 256 / 512 blocks: host 102 / 159 / 293 / 529 ms,
 // device 157 / 188 / 247 / 379 ms).  KZ_TEXT_FWD_GPU=0: host stage, =1: any batch size.  (Read per call: the tests force both.)
-static bool text_fwd_gpu_on(uint32_t entropyType, int nBlocks) {
+static bool text_fwd_gpu_on(const kz_ctx* ctx, uint32_t entropyType, int nBlocks) {
   const bool type2 = entropyType == KZ_E_NONE || entropyType == KZ_E_ANS0 || entropyType == KZ_E_HUFFMAN;
   if (!type2) return false;
-  const char* e = getenv("KZ_TEXT_FWD_GPU");
-  if (e && e[0] == '0') return false;
-  if (e && e[0] == '1') return true;
-  const char* m = getenv("KZ_TEXT_FWD_GPU_MIN");
-  return nBlocks >= (m ? atoi(m) : 256);
+  if (ctx->sw.textFwdGpu >= 0) return ctx->sw.textFwdGpu == 1;
+  return nBlocks >= ctx->sw.textFwdGpuMin;
 }
 // UTF inverse on the device (kz_text_gpu.hip: parallel inside a block, so for any batch); KZ_UTF_GPU=0 keeps it on the host
-static bool utf_gpu_on() { const char* e = getenv("KZ_UTF_GPU"); return !(e && e[0] == '0'); }
+static bool utf_gpu_on(const kz_ctx* ctx) { return ctx->sw.utfGpu != 0; }
 
-static int fuse_min_blocks() {                                      // batches below this take the stages one after the other
-  const char* e = getenv("KZ_FUSE_MIN_BLOCKS");                     // (read per call: the tests force both schedules)
-  return e ? atoi(e) : 32;
-}
+static int fuse_min_blocks(const kz_ctx* ctx) { return ctx->sw.fuseMinBlocks; }   // batches below this take the stages one after the other
 // One cost class of the batch: a lengths-masked view of the same slots with its own length / flag arrays.
 struct OverlapGroup {
   std::vector<int32_t> in;
@@ -820,12 +851,11 @@ struct Overlap { std::vector<OverlapGroup> groups; std::vector<int> launchOrder,
 #define KZ_OVERLAP_MAXG 5
 // host side: classes by cost relative to the largest: >= 3/4 | >= 3/8 | >= 3/16 | >= 3/32 | the rest; classes of fewer than 8
 // blocks join the class below (the cheapest one: the class above).  false when there is nothing to overlap.
-static bool overlap_classify(int B, const std::vector<int32_t>& h_mask, const std::vector<int32_t>& cost, Overlap& O) {
-  if (B < fuse_min_blocks()) return false;
+static bool overlap_classify(const kz_ctx* ctx, int B, const std::vector<int32_t>& h_mask, const std::vector<int32_t>& cost, Overlap& O) {
+  if (B < fuse_min_blocks(ctx)) return false;
   int64_t maxCost = 0;
   for (int b = 0; b < B; b++) if (h_mask[b]) maxCost = std::max<int64_t>(maxCost, cost[b]);
-  const char* e3 = getenv("KZ_OVERLAP_CLASSES");
-  int nClasses = e3 ? atoi(e3) : 3;                                // main + two side streams fit HIP's default of 4 hardware queues
+  int nClasses = ctx->sw.overlapClasses;                           // 3: main + two side streams fit HIP's default of 4 hardware queues
   nClasses = std::min(std::max(nClasses, 2), KZ_OVERLAP_MAXG);
   std::vector<int> cls(B, -1);
   int cnt[KZ_OVERLAP_MAXG] = {0};
@@ -846,7 +876,7 @@ static bool overlap_classify(int B, const std::vector<int32_t>& h_mask, const st
     for (int c = 1; c < nClasses; c++) if (cnt[c] > 0) { up = c; break; }
     if (up > 0) { cnt[up] += cnt[0]; cnt[0] = 0; for (int k = 0; k < KZ_OVERLAP_MAXG; k++) if (to[k] == 0) to[k] = up; }
   }
-  if (getenv("KZ_TRACE_SCHED")) {
+  if (ctx->sw.traceSched) {
     int raw[KZ_OVERLAP_MAXG] = {0};
     for (int b = 0; b < B; b++) if (cls[b] >= 0) raw[cls[b]]++;
     fprintf(stderr, "[sched] classes (cheap..expensive) raw %d %d %d %d %d merged %d %d %d %d %d maxCost %lld\n", raw[0], raw[1], raw[2], raw[3], raw[4],
@@ -856,13 +886,11 @@ static bool overlap_classify(int B, const std::vector<int32_t>& h_mask, const st
   for (int c = 0; c < nClasses; c++) if (cnt[c] > 0) order[n++] = c;
   if (n < 2) return false;
   O.groups.resize(n);
-  // issue priority of the classes' RANK-inverse waves (s_setprio 3 / 1 / 0).  KZ_OVERLAP_PRIO = one digit per class, cheapest first
-  // (0, 1 or 2), overrides the default "the more expensive, the higher" for experiments
-  const char* ep = getenv("KZ_OVERLAP_PRIO");
+  // issue priority of the classes' RANK-inverse waves (s_setprio 3 / 1 / 0): the more expensive, the higher (every other
+  // assignment measured slower in round 5)
   for (int g = 0; g < n; g++) {
     O.groups[g].in.assign(B, 0);
     O.groups[g].prio = (g == n - 1) ? 2 : (g > 0 ? 1 : 0);
-    if (ep && (int)strlen(ep) >= n && ep[g] >= '0' && ep[g] <= '2') O.groups[g].prio = ep[g] - '0';
   }
   for (int b = 0; b < B; b++) {
     if (cls[b] < 0) continue;
@@ -909,8 +937,7 @@ static int overlap_streams(kz_ctx* ctx) {
     KZ_HIP(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
     KZ_HIP(hipEventCreateWithFlags(&ctx->evJoin[i], hipEventDisableTiming));
   }
-  const char* e = getenv("KZ_WIDE_QUEUES");                         // (read per call: the tests force both schedules)
-  if (e) { ctx->wideNow = atoi(e) ? 1 : 0; return 0; }
+  if (ctx->sw.wideQueues >= 0) { ctx->wideNow = ctx->sw.wideQueues; return 0; }   // (the tests force both schedules)
   if (ctx->wideQueues < 0) {
     KZ_HIP(kz_stream_sync(ctx, ctx->stream));
     hipStream_t q[4] = {ctx->stream, ctx->side[0], ctx->side[1], ctx->side[2]};
@@ -921,7 +948,7 @@ static int overlap_streams(kz_ctx* ctx) {
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       ctx->wideQueues = ms < 3.5 ? 1 : 0;
     }
-    if (getenv("KZ_TRACE_SCHED")) fprintf(stderr, "[sched] four streams run %s\n", ctx->wideQueues ? "side by side" : "on shared hardware queues: three-stream schedule");
+    if (ctx->sw.traceSched) fprintf(stderr, "[sched] four streams run %s\n", ctx->wideQueues ? "side by side" : "on shared hardware queues: three-stream schedule");
   }
   ctx->wideNow = ctx->wideQueues;
   return 0;
@@ -965,18 +992,7 @@ static void overlap_plan(kz_ctx* ctx, Overlap& O, const std::vector<int32_t>& zl
     if (tb < bestT - 1e-9) { bestT = tb; best = perm; O.bwtOrder = byEnd; }
   } while (std::next_permutation(perm.begin(), perm.end()));
   O.launchOrder = best;
-  if (const char* eo = getenv("KZ_OVERLAP_ORDER")) {                  // experiments: launch order of the classes as digits, e.g. "201"
-    std::vector<int> forced;
-    for (const char* c = eo; *c; c++) if (*c >= '0' && *c < '0' + n && std::find(forced.begin(), forced.end(), *c - '0') == forced.end()) forced.push_back(*c - '0');
-    if ((int)forced.size() == n) {
-      O.launchOrder = forced;
-      double t = 0, endR[KZ_OVERLAP_MAXG];
-      for (int i = 0; i < n; i++) { t += O.groups[forced[i]].tPre; endR[forced[i]] = t + O.groups[forced[i]].tRank; }
-      O.bwtOrder = forced;
-      std::sort(O.bwtOrder.begin(), O.bwtOrder.end(), [&](int a, int b) { return endR[a] < endR[b]; });
-    }
-  }
-  if (getenv("KZ_TRACE_SCHED")) {
+  if (ctx->sw.traceSched) {
     fprintf(stderr, "[sched] plan %.0f ms: launch", bestT * 1e3);
     for (int g : O.launchOrder) fprintf(stderr, " %d(pre %.0f rank %.0f bwt %.0f)", g, O.groups[g].tPre * 1e3, O.groups[g].tRank * 1e3, O.groups[g].tBwt * 1e3);
     fprintf(stderr, " | bwt order"); for (int g : O.bwtOrder) fprintf(stderr, " %d", g); fprintf(stderr, "\n");
@@ -1032,7 +1048,7 @@ static int overlap_finish(kz_ctx* ctx, Pipe& P, Overlap& O, std::vector<int32_t>
 static int overlapped_rank_bwt_inverse(kz_ctx* ctx, Pipe& P, int mode, const std::vector<int32_t>& h_mask, const std::vector<int32_t>& cost,
                                        std::vector<int32_t>& h_applied) {
   Overlap O;
-  if (!overlap_classify(P.bt.B, h_mask, cost, O)) return 0;
+  if (!overlap_classify(ctx, P.bt.B, h_mask, cost, O)) return 0;
   int rc = overlap_alloc(ctx, P.bt.B, O);
   if (rc) return rc;
   {
@@ -1050,7 +1066,7 @@ bool kz_text_fwd_gpu_applies(kz_ctx* ctx, uint64_t transformType, uint32_t entro
   const int nb = split_types(transformType, types);
   int hp = 0;
   while (hp < nb && kz_is_host_transform(types[hp])) hp++;
-  return hp > 0 && !ctx->skipBlocks && types[0] == KZ_T_TEXT && (hp == 1 || types[1] == KZ_T_UTF) && text_fwd_gpu_on(entropyType, nBlocks);
+  return hp > 0 && !ctx->skipBlocks && types[0] == KZ_T_TEXT && (hp == 1 || types[1] == KZ_T_UTF) && text_fwd_gpu_on(ctx, entropyType, nBlocks);
 }
 
 // =================================================================================================
@@ -1063,9 +1079,8 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
                              uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind, const HostPre* pre);
 // blocks per step of the encoder's host-stage pipeline: 256 for bulk batches; batches of a few dozen blocks (the silesia shape: 51)
 // take thirds, so that the TEXT / UTF stages of all but the first third run under the GPU work of the third before
-static int host_chunk_blocks(int B) {
-  const char* e = getenv("KZ_HOST_CHUNK");
-  if (e) { const int v = atoi(e); return v < 8 ? 8 : v; }
+static int host_chunk_blocks(const kz_ctx* ctx, int B) {
+  if (ctx->sw.hostChunk > 0) return ctx->sw.hostChunk < 8 ? 8 : ctx->sw.hostChunk;
   if (B >= 512) return 256;
   return std::max(12, (B + 2) / 3);
 }
@@ -1127,9 +1142,9 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
   // ---- chains led by TEXT / UTF on large batches: the host stages of chunk k+1 run on a helper thread (and the host pool) while
   //      the GPU codes chunk k.  Blocks are independent, so chunking changes nothing in the output.  (With "skipBlocks" the copy
   //      decision comes from the device and precedes the host stages: that case takes the one-pass path below.) ----
-  const bool textFwdGpu = hp > 0 && !pre && types[0] == KZ_T_TEXT && (hp == 1 || types[1] == KZ_T_UTF) && text_fwd_gpu_on(entropyType, B);
-  if (hp > 0 && !pre && !ctx->skipBlocks && B >= 2 * host_chunk_blocks(B) && !textFwdGpu) {
-    const int CH = host_chunk_blocks(B);
+  const bool textFwdGpu = !pre && kz_text_fwd_gpu_applies(ctx, transformType, entropyType, B);   // ONE predicate (kz_stream.hip asks the same one)
+  if (hp > 0 && !pre && !ctx->skipBlocks && B >= 2 * host_chunk_blocks(ctx, B) && !textFwdGpu) {
+    const int CH = host_chunk_blocks(ctx, B);
     const int nch = (B + CH - 1) / CH;
     const bool hostIn = memKind == KZ_MEM_HOST;
     struct Chunk { HostPre P; int rc = 0; };
@@ -1140,7 +1155,7 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
       if (!rc && !hostIn) rc = kz_stage_reserve(ctx, ctx->hsIn[q], (size_t)CH * (size_t)maxN + 64, true);
       if (rc) return rc;
     }
-    const bool trace = getenv("KZ_TRACE_PIPE") != nullptr;
+    const bool trace = ctx->sw.tracePipe != 0;
     const auto tStart = std::chrono::steady_clock::now();
     auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tStart).count(); };
     auto stage = [&](int k) {
@@ -1252,7 +1267,7 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
       // a block that is not text: TEXT declined it on the device and left its "dataType"; UTF (if the chain has it) looks at UNDEFINED
       // and UTF8 blocks only (UTFCodec.java:93-101), on the host, from that entry on; every other block is done with the host stages
       for (int b = 0; b < B; b++) if (textDeclined[b] >= 0 && (hp == 1 || (textDeclined[b] != KZ_DT_UNDEFINED && textDeclined[b] != KZ_DT_UTF8))) noHost[b] = 1;
-      kz_ctx::Stage& stg = ctx->hsIn[0];                                           // pinned staging for device input
+      kz_ctx::Stage& stg = ctx->tfIn;                                              // pinned staging for device input (not hsIn: ADVICE r5)
       auto host_pass = [&](int pass, const std::vector<int>& blocks, bool overlap) -> int {
         std::vector<const uint8_t*> ptrs(blocks.size());
         std::vector<int32_t> lens(blocks.size()), firstStage(blocks.size(), 0), dtIn(blocks.size(), KZ_DT_UNDEFINED);
@@ -1262,8 +1277,8 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
         }
         // the copies of a pass that runs beside the walk go on their own stream (the caller's input is not this context's to order:
         // k_copy_bytes read it on the main stream without waiting either), the walk is queued on the main one meanwhile
-        if (overlap && !host && !ctx->copyDown) KZ_HIP(hipStreamCreateWithFlags(&ctx->copyDown, hipStreamNonBlocking));
-        hipStream_t cs = (overlap && !host) ? ctx->copyDown : st;
+        if (overlap && !host && !ctx->tfCopy) KZ_HIP(hipStreamCreateWithFlags(&ctx->tfCopy, hipStreamNonBlocking));
+        hipStream_t cs = (overlap && !host) ? ctx->tfCopy : st;
         for (size_t k = 0; k < blocks.size(); k++) {
           const int b = blocks[k];
           lens[k] = lengths[b];
@@ -1281,10 +1296,10 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
           if (!host) KZ_HIP(hipStreamSynchronize(cs));
         } else KZ_HIP(kz_stream_sync(ctx, st));
         uint8_t* store = nullptr;                                                  // pinned slots for the stages' outputs, when there is room for them
-        if (!blocks.empty() && kz_stage_reserve(ctx, ctx->hsOut[pass], (size_t)host_pre_slot(maxLen) * blocks.size() + 64, true) == 0) store = ctx->hsOut[pass].p;
+        if (!blocks.empty() && kz_stage_reserve(ctx, ctx->tfOut[pass], (size_t)host_pre_slot(maxLen) * blocks.size() + 64, true) == 0) store = ctx->tfOut[pass].p;
         const auto t0 = std::chrono::steady_clock::now();
         host_prestage_list(types, hp, (int)entropyType, blockSize, maxLen, ptrs, lens, passP[pass], store, &firstStage, &dtIn);
-        if (getenv("KZ_TEXT_GPU_TRACE"))
+        if (ctx->sw.textGpuTrace)
           fprintf(stderr, "[textfwd] host pass %d: %d blocks, %.0f ms\n", pass, (int)blocks.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         return 0;
       };
@@ -1530,9 +1545,9 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
   // larger (corrupt) length is rejected with the same error code.
   const int maxLen = std::min(maxTL, dataCap + 1024);
   ChainSpec CS; CS.nb = nb; CS.entropy = (int)entropyType; for (int i = 0; i < nb; i++) CS.types[i] = types[i];
-  const bool textGpu = hp > 0 && !deferHost && types[0] == KZ_T_TEXT && text_gpu_on((uint32_t)entropyType, B);
+  const bool textGpu = hp > 0 && !deferHost && types[0] == KZ_T_TEXT && text_gpu_on(ctx, (uint32_t)entropyType, B);
   const int iu = (hp > 0 && types[hp - 1] == KZ_T_UTF) ? hp - 1 : -1;      // UTF as the host stage undone first
-  const bool utfGpu = iu >= 0 && !deferHost && utf_gpu_on();
+  const bool utfGpu = iu >= 0 && !deferHost && utf_gpu_on(ctx);
   {
     const size_t perBlock = pipeline_scratch(1, maxLen, true, CS) + (size_t)maxLen * 2 + (size_t)(host ? maxInBytes : 0) + (1 << 16) +
                             (textGpu ? kz_text_gpu_scratch_per_block(blockSize) : 0) + (utfGpu ? kz_utf_gpu_scratch_per_block(maxLen) : 0);
@@ -1653,13 +1668,13 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
   //      the side stream; the others follow on the main stream underneath it (overlap_* above). ----
   bool chainDone = false;
   if (nb - hp == 3 && types[hp] == KZ_T_BWT && (types[hp + 1] == KZ_T_RANK || types[hp + 1] == KZ_T_MTFT) && types[hp + 2] == KZ_T_ZRLT &&
-      (entropyType == KZ_E_ANS0 || entropyType == KZ_E_HUFFMAN) && !getenv("KZ_NO_SFIRST")) {
+      (entropyType == KZ_E_ANS0 || entropyType == KZ_E_HUFFMAN) && !ctx->sw.noSFirst) {
     bool all = true;
     const int need = (1 << (7 - hp)) | (1 << (7 - (hp + 1)));       // BWT and RANK applied to every block
     for (int b = 0; b < B && all; b++) all = !h_status[b] && bt.h_len[b] > 0 && !(h_skip[b] & need);   // (copy blocks carry all skip bits)
     Overlap O;
     std::vector<int32_t> ones(B, 1);
-    if (getenv("KZ_TRACE_SCHED")) {
+    if (ctx->sw.traceSched) {
       int nst = 0, ntc = 0, nz = 0, nsk = 0, nraw = 0;
       for (int b = 0; b < B; b++) { nst += h_status[b] != 0; ntc += h_tc[b] != 0; nz += bt.h_len[b] <= 0; nsk += (h_skip[b] & need) != 0; nraw += h_raw[b] != 0; }
       fprintf(stderr, "[sched] B=%d all=%d status=%d tcopy=%d empty=%d skipBwtRank=%d raw=%d\n", B, (int)all, nst, ntc, nz, nsk, nraw);
@@ -1668,7 +1683,7 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
     // does the entropy coder's output; the ZRLT-coded length alone puts skewed and uniform data in one class (68 vs 134 ns / rank)
     std::vector<int32_t> cost(B);
     for (int b = 0; b < B; b++) cost[b] = (int32_t)std::min<int64_t>((bitLengths[b] + 7) >> 3, 0x7FFFFFFF);
-    if (all && overlap_classify(B, ones, cost, O)) {
+    if (all && overlap_classify(ctx, B, ones, cost, O)) {
       const int mode = types[hp + 1] == KZ_T_RANK ? 2 : 1;
       rc = overlap_alloc(ctx, B, O);
       if (rc) return rc;
@@ -1746,7 +1761,7 @@ static int32_t decode_blocks_impl(kz_ctx* ctx, uint64_t transformType, uint32_t 
       take[b] = t ? 1 : 0;
     }
     hipEvent_t e0; kz_stage_begin(ctx, &e0);
-    rc = kz_stage_text_inverse_gpu(ctx, bt, blockSize, dataCap, entropyType == KZ_E_FPAQ, take, done, text_gpu_form((uint32_t)entropyType, B));
+    rc = kz_stage_text_inverse_gpu(ctx, bt, blockSize, dataCap, entropyType == KZ_E_FPAQ, take, done, text_gpu_form(ctx, (uint32_t)entropyType, B));
     if (rc) return rc;
     kz_stage_end(ctx, e0, KZ_STAGE_HOST_INV, 0);
     for (int b = 0; b < B; b++) if (done[b]) h_skipHost[b] |= 0x80;
@@ -1801,7 +1816,6 @@ static void decode_error_sync(kz_ctx* ctx) {
   for (int i = 0; i < 5; i++) if (ctx->side[i]) hipStreamSynchronize(ctx->side[i]);
   hipStreamSynchronize(ctx->stream);
 }
-static int host_chunk_blocks_dec() { const char* e = getenv("KZ_HOST_CHUNK_DEC"); const int v = e ? atoi(e) : 512; return v < 8 ? 8 : v; }
 extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int32_t blockSize,
                                     const uint8_t* in, int64_t inStride, const int64_t* bitLengths, int32_t nBlocks,
                                     uint8_t* out, int64_t outStride, kz_block_result* results, int32_t memKind) {
@@ -1810,23 +1824,22 @@ extern "C" int32_t kz_decode_blocks(kz_ctx* ctx, uint64_t transformType, uint32_
   const int nb = split_types(transformType, types);
   int hp = 0;
   while (hp < nb && kz_is_host_transform(types[hp])) hp++;
-  const int CH = host_chunk_blocks_dec();
+  const int CH = ctx->sw.hostChunkDec;
   // ---- chains led by TEXT / UTF on large batches: the host inverse stages of chunk k run on a helper thread (and the host pool)
   //      while the GPU decodes chunk k+1.  (Block checksums are verified on the device AFTER the host stages: that case takes the
   //      one-pass path.) ----
-  if (hp > 0 && ctx->checksum == 0 && nBlocks >= 2 * CH && !(types[0] == KZ_T_TEXT && text_gpu_on((uint32_t)entropyType, nBlocks))) {
+  if (hp > 0 && ctx->checksum == 0 && nBlocks >= 2 * CH && !(types[0] == KZ_T_TEXT && text_gpu_on(ctx, (uint32_t)entropyType, nBlocks))) {
     const int B = nBlocks, nch = (B + CH - 1) / CH;
     const int dataCap = blockSize + std::max(512, blockSize >> 4);
     std::vector<std::thread> finishers;
     std::vector<std::unique_ptr<HostInv>> jobs;
     std::vector<std::vector<int32_t>> lens(nch), skips(nch), stats(nch);
     int rc = 0;
-    const bool trace = getenv("KZ_TRACE_PIPE") != nullptr;
-    // KZ_HOST_INV_STAGED=1 (read once per call): the chunk's blocks go through pinned slots with one gather / scatter kernel per
+    const bool trace = ctx->sw.tracePipe != 0;
+    // KZ_HOST_INV_STAGED=1: the chunk's blocks go through pinned slots with one gather / scatter kernel per
     // sub-chunk instead of a copy pair per block.  Measured slower on the level-exact bench row (1 200 vs 1 066 ms per 2 048-block
     // decode), so it is opt-in.
-    const char* est = getenv("KZ_HOST_INV_STAGED");
-    const bool staged = est && est[0] == '1' && memKind != KZ_MEM_HOST;
+    const bool staged = ctx->sw.hostInvStaged == 1 && memKind != KZ_MEM_HOST;
     const int64_t pslot = (int64_t)kz_align((size_t)std::max<int64_t>(outStride, dataCap) + 64, 64);
     if (staged) {                                                     // everything that can fail, before the first chunk is in flight
       for (int q = 0; q < 2 && !rc; q++) {

@@ -1769,9 +1769,7 @@ static inline int tr_max_buckets(int maxN) {
   const int med = maxN / (int)(TR_MERGE + 1) + 1, big = maxN / (int)(TR_CAP + 1) + 1;
   return med + 2 * (maxN / (int)TR_CAP) + 2 + tr_max_nodes(maxN) + med + (TR_DMAX_LIMIT - 2) * big + big;
 }
-static inline bool tr_applies(int maxN) {
-  const char* e = getenv("KZ_BWT_TRIE");
-  if (e && e[0] == '0') return false;
+static inline bool tr_applies(int maxN) {                          // (KZ_BWT_TRIE=0 switches the trie rounds off at the call: ctx->sw.bwtTrie)
   return maxN >= TR_MIN_N && maxN <= TR_MAX_N && tr_max_buckets(maxN) <= TR_MAXB && tr_max_nodes(maxN) <= 65535;
 }
 
@@ -1813,7 +1811,7 @@ static int bwt_forward_run(kz_ctx* ctx, kz_batch& bt, bool allowTrie, bool* trie
   int32_t* d_act = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   A.act = nullptr;
   if (!d_act || !A.d_m2 || !A.tileB || !A.tileLive || !A.sa || !A.d_big || !A.bucketCnt) { snprintf(ctx->err, sizeof(ctx->err), "bwt_forward: arena overflow"); return -KZ_ERR_DEVICE; }
-  bool useTrie = allowTrie && tr_applies(maxN);
+  bool useTrie = allowTrie && ctx->sw.bwtTrie != 0 && tr_applies(maxN);
   TrieArrays TR;
   memset(&TR, 0, sizeof(TR));
   const size_t markTrie = ctx->arenaTop;
@@ -1848,8 +1846,7 @@ static int bwt_forward_run(kz_ctx* ctx, kz_batch& bt, bool allowTrie, bool* trie
   int bitsG = 1;
   while ((1LL << bitsG) < (int64_t)maxN) bitsG++;
 
-  const char* ek = getenv("KZ_BWT_K");
-  const int K0 = (ek && ek[0] >= '2' && ek[0] <= '7') ? ek[0] - '0' : 7;   // bytes of the first-round key
+  const int K0 = 7;                                                // bytes of the first-round key
   u64 *kC = A.key[0], *kF = A.key[1];
   u32 *vC = A.val[0], *vF = A.val[1];
   KZ_LAUNCH(ctx, KID_BWT_INIT, k_bwt_init, dim3((B + 255) / 256), dim3(256), A, B);
@@ -1857,25 +1854,18 @@ static int bwt_forward_run(kz_ctx* ctx, kz_batch& bt, bool allowTrie, bool* trie
   int mMax = maxN;
   int h = 0;
   // bucket path of the later rounds: the packed LDS element needs BK_BITS + bitsR + bitsG <= 64
-  const char* eb = getenv("KZ_BWT_BUCKETS");
-  const bool useBuckets = (BK_BITS + bitsR + bitsG <= 64) && (1 << (bitsG > BK_BITS ? bitsG - BK_BITS : 0)) <= MSD_BINS && !(eb && eb[0] == '0');
+  const bool useBuckets = (BK_BITS + bitsR + bitsG <= 64) && (1 << (bitsG > BK_BITS ? bitsG - BK_BITS : 0)) <= MSD_BINS && ctx->sw.bwtBuckets != 0;
   const int nBuckets = 1 << (bitsG > BK_BITS ? bitsG - BK_BITS : 0);
   const int bucketMin = 4096;                                      // below: the whole list is a handful of LSD tiles
   bool windowed = false;
-  const char* eg = getenv("KZ_BWT_GMAX");
-  const u32 gmax = eg ? (u32)atoi(eg) : (u32)BK_GMAX;
+  const u32 gmax = (u32)BK_GMAX;
   const int tilesN = gridFor(maxN, RS_TILE);
-  // experiment switches: read once per call (the tests flip them between calls), not per round
-  const char* ed = getenv("KZ_BWT_DMAX");
-  const int Dmax = (ed && ed[0] >= '6' && ed[0] <= '0' + TR_DMAX_LIMIT) ? ed[0] - '0' : 6;
-  const char* ep = getenv("KZ_TR_PARTS");
-  const char* ert = getenv("KZ_BWT_RETIRE");
-  const bool noRetire = ert && ert[0] == '0';                        // A/B switch: every block rides through every round, as before
-  const char* etw = getenv("KZ_BWT_TRIEWIN");
-  const bool trieWinOff = etw && etw[0] == '0';
-  const bool trace = getenv("KZ_BWT_TRACE") != nullptr;
-  const char* eo = getenv("KZ_BWT_TEST_TRIE_OVERFLOW");              // tests: pretend the tables overflowed in round <digit>
-  const int forceOvfRound = (eo && eo[0] >= '0' && eo[0] <= '9') ? eo[0] - '0' : -1;
+  // the context's switches (kz_switches: read when the context was created)
+  const int Dmax = (ctx->sw.bwtDmax >= 6 && ctx->sw.bwtDmax <= TR_DMAX_LIMIT) ? ctx->sw.bwtDmax : 6;
+  const bool noRetire = ctx->sw.bwtRetire == 0;                      // A/B switch: every block rides through every round, as before
+  const bool trieWinOff = ctx->sw.bwtTrieWin == 0;
+  const bool trace = ctx->sw.bwtTrace != 0;
+  const int forceOvfRound = ctx->sw.bwtTestTrieOverflow;             // tests: pretend the tables overflowed in round <digit>
   if (useTrie) KZ_HIP(hipMemsetAsync(TR.err, 0, 4, st));
   int nAct = B;                                                      // grid rows of the later rounds: blocks with live suffixes (A.act)
   int32_t* const h_act = ctx->hpin + B + 16;                         // their indices, host side (pipe_setup reserves 9 B + 64 ints)
@@ -1893,7 +1883,7 @@ static int bwt_forward_run(kz_ctx* ctx, kz_batch& bt, bool allowTrie, bool* trie
       KZ_HIP(hipMemsetAsync(TR.meta, 0, (size_t)B * TR_META * 4, st));
       KZ_LAUNCH(ctx, KID_TR_HIST16, k_tr_hist16, dim3(2, B), dim3(1024), src, bt.stride, A, TR);
       KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, 1, Dmax, 0);
-      const int P = ep ? std::max(1, atoi(ep)) : (B >= 2048 ? 1 : (B >= 1024 ? 2 : 8));
+      const int P = B >= 2048 ? 1 : (B >= 1024 ? 2 : 8);
       for (int L = 2; L < Dmax; L++) {
         KZ_LAUNCH(ctx, KID_TR_COUNT, k_tr_count, dim3(P, B), dim3(1024), src, bt.stride, A.val[0], A, TR, L);
         KZ_LAUNCH(ctx, KID_TR_ASSIGN, k_tr_assign, dim3(B), dim3(256), A, TR, L, Dmax, 0);

@@ -516,10 +516,8 @@ int kz_stage_bwt_inverse(kz_ctx* ctx, kz_batch& bt) {
     // cache line per step once enough walkers are in flight.  Walking the batch in small groups (so that the
     // group's link arrays stay in the 256 MB Infinity Cache) was measured 4-7x SLOWER: fewer walkers in
     // flight (and segment lengths are geometric, so most lanes of a wave idle behind its longest segment).
-    // KZ_BWTI_GROUP is kept for experiments; the default walks the whole batch at once.
-    static const int groupEnv = getenv("KZ_BWTI_GROUP") ? atoi(getenv("KZ_BWTI_GROUP")) : 0;
-    int group = groupEnv > 0 ? groupEnv : B;
-    if (group > B) group = B;
+    // The whole batch is walked at once.
+    const int group = B;
     for (int b0 = 0; b0 < B; b0 += group) {
       const int nb = (B - b0 < group) ? B - b0 : group;
       if (V.wide) { KZ_LAUNCH(ctx, KID_BWTI_WALK1, k_bwti_walk1<true>, dim3((V.GS + 63) / 64, nb), dim3(64), V, b0); }

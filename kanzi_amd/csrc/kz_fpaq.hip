@@ -329,94 +329,10 @@ __global__ __launch_bounds__(512) void k_fpaq_enc_wave(const u8* __restrict__ sr
   if (lane == 0) d_bits[b] = 8LL * opos;
 }
 
-// One decoder step (FPAQDecoder.java:290-314 decodeBitV2 + :322-335 read).  PR = probability of the current
-// context (scalar); the two children of the context were fetched from LDS one level earlier.
-#define FPW_DEC_BIT(LEVEL)                                                                      \
-  { int2 ch = make_int2(0, 0);                                                                 \
-    if (LEVEL < 7) ch = *(const int2*)&probs[tb + 2 * ctx];        /* children of ctx: used at the next level */ \
-    const u64 split = ((((high - low) >> 8) * (u64)(u32)pr) >> 8) + low;                       \
-    const bool one = (int)((split - current) >> 32) >= 0;           /* split >= current (both < 2^56): sign of a scalar subtract */ \
-    const int np = one ? pr - ((pr - FP_PSCALE + 64) >> 6) : pr - (pr >> 6);                   \
-    high = one ? split : high; low = one ? low : split + 1;                                    \
-    probs[tb + ctx] = np;                                                                      \
-    ctx = (ctx << 1) + (one ? 1 : 0);                                                          \
-    if (LEVEL == 1) rootNext = probs[((ctx & 3) << 8) + 1];        /* next byte's first context (:233-239) */ \
-    while (__builtin_expect(((low ^ high) & FP_M2456) == 0, 0)) {                              \
-      low = (low << 32) & FP_M056;                                                             \
-      high = ((high << 32) | FP_M032) & FP_M056;                                               \
-      if (idx + 4 > bufLimit) { current = (current << 32) & FP_M056; idx = bufLimit + 1; continue; } \
-      if (idx >= wbase + 256) { wbase = idx; const u8* q = buf + wbase + 4 * lane; win = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3]; } \
-      const u64 val = (u64)(u32)__builtin_amdgcn_readlane((int)win, (idx - wbase) >> 2);       \
-      current = ((current << 32) | val) & FP_M056;                                             \
-      idx += 4;                                                                                \
-    }                                                                                          \
-    if (LEVEL < 7) pr = __builtin_amdgcn_readfirstlane(one ? ch.y : ch.x); }
-
-// Decoder: every bit's context depends on the previous bit, so the chain is serial; what can be hidden is the
-// LDS latency of the probability: both children of the current context (adjacent ints) are fetched with one
-// 8-byte LDS read while the current bit is decoded, the next byte's first context after its top two bits are
-// known.  Range arithmetic runs on the scalar unit; output bytes are collected with v_writelane and stored
-// 64 at a time.
-__global__ __launch_bounds__(512) void k_fpaq_dec_wave(const u8* __restrict__ in, int64_t inStride, const int64_t* __restrict__ d_bitOff,
-                                                  const int64_t* __restrict__ d_bitEnd, const int32_t* __restrict__ d_len,
-                                                  u8* __restrict__ dst, int64_t stride, int32_t* __restrict__ d_len2, int32_t* __restrict__ d_flag,
-                                                  const int32_t* __restrict__ order, int wavesPerGroup, long long* __restrict__ endOut) {
-  __shared__ __attribute__((aligned(8))) int probsAll[8][1024];
-  const int wv = (int)(threadIdx.x >> 6);
-  const int b = __builtin_amdgcn_readfirstlane(order[blockIdx.x * wavesPerGroup + __builtin_amdgcn_readfirstlane(wv)]);   // uniform on purpose: the coder state stays on the scalar unit
-  if (b < 0) return;
-  int* probs = probsAll[wv];
-  const int count = d_len[b];
-  const int lane = kz_lane();
-  if (lane == 0) { d_len2[b] = count; d_flag[b] = 1; }
-  if (count <= 0) { if (endOut && lane == 0) endOut[b] = d_bitOff[b]; return; }
-  for (int i = lane; i < 1024; i += 64) probs[i] = FP_PSCALE >> 1;
-  FPW_SYNC();
-  const u8* p = in + (int64_t)b * inStride + (d_bitOff[b] >> 3);   // payload is byte aligned behind the block header
-  const int64_t avail = (d_bitEnd[b] - d_bitOff[b]) >> 3;
-  u8* o = dst + (int64_t)b * stride;
-  int64_t ipos = 0;
-  u64 low = 0, high = FP_TOP, current = 0;
-  bool bad = ((d_bitOff[b] & 7) != 0);
-  int startChunk = 0;
-  while (startChunk < count && !bad) {
-    // varint (EntropyUtils.readVarInt)
-    u32 v = p[ipos++]; u32 sz = v & 0x7F; int shift = 7;
-    while (v >= 128) { v = p[ipos++]; sz |= (v & 0x7F) << shift; if (shift == 28) break; shift += 7; }
-    const int szBytes = (int)sz;
-    if (szBytes < 0 || szBytes >= 2 * count || ipos + 7 + szBytes > avail) { bad = true; break; }   // :176-177
-    current = 0;
-    for (int k = 0; k < 7; k++) current = (current << 8) | (u64)p[ipos + k];
-    ipos += 7;
-    const u8* buf = p + ipos;
-    const int bufLimit = szBytes;
-    int idx = 0;
-    // 256-byte read window (one big-endian word per lane) over the chunk's byte stream
-    int wbase = 0;
-    u32 win;
-    { const u8* q = buf + 4 * lane; win = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3]; }
-    const int chunkSize = min(FP_CHUNK, count - startChunk);
-    int tb = 0;
-    int rootNext = probs[1];
-    u32 outv = 0;
-    for (int i = startChunk; i < startChunk + chunkSize; i++) {
-      int ctx = 1;
-      int pr = __builtin_amdgcn_readfirstlane(rootNext);
-      FPW_DEC_BIT(0) FPW_DEC_BIT(1) FPW_DEC_BIT(2) FPW_DEC_BIT(3) FPW_DEC_BIT(4) FPW_DEC_BIT(5) FPW_DEC_BIT(6) FPW_DEC_BIT(7)
-      const int j = (i - startChunk) & 63;
-      { const u32 cb = (u32)__builtin_amdgcn_readfirstlane(ctx & 0xFF); asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(cb), "s"(j) : "m0"); }
-      if (j == 63 || i + 1 == startChunk + chunkSize) { if (lane <= j) o[i - j + lane] = (u8)outv; }
-      if (idx > szBytes) { bad = true; break; }                      // :231-232
-      tb = ((ctx & 0xFF) >> 6) << 8;
-    }
-    ipos += szBytes;
-    startChunk += chunkSize;
-  }
-  if (endOut && lane == 0) endOut[b] = (long long)(d_bitOff[b] + 8LL * ipos);
-  if (bad && lane == 0) d_flag[b] = 0;
-}
-
-
+// One decoder step (FPAQDecoder.java:290-314 decodeBitV2 + :322-335 read): every bit's context depends on the previous bit, so the
+// chain is serial; what can be hidden is the LDS latency of the probability (both children of the current context are requested
+// while the current bit is decoded).  Range arithmetic runs on the scalar unit; output bytes are collected per row and stored 64 at a
+// time.  (The round-2 form of the step, k_fpaq_dec_wave, was removed in round 6: the round-3 restatement below replaced it.)
 // Round 3: the step restated so that a wave issues fewer instructions for it.  A lone wave issues one instruction every ~5.7 cycles
 // whatever unit it goes to (two waves per SIMD interleave at that rate each: 2048 blocks take as long as one), so the cost of a
 // bit is its instruction count.  The probability and its LDS address never leave the vector unit (update: 4 VALU; the address of
@@ -531,7 +447,7 @@ __global__ __launch_bounds__(512) void k_fpaq_dec_wave2(const u8* __restrict__ i
         FPW_DEC_OPEN();
         FPW_DEC_BIT2(0) FPW_DEC_BIT2(1) FPW_DEC_BIT2(2) FPW_DEC_BIT2(3) FPW_DEC_BIT2(4) FPW_DEC_BIT2(5) FPW_DEC_BIT2(6) FPW_DEC_BIT2(7)
         const u32 cb = (u32)__builtin_amdgcn_readfirstlane((vw + vNegTb) >> 2);   // 256 + the byte (v_writelane takes bits 7..0 below)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(cb), "s"(j) : "m0");
+        outv = (lane == j) ? cb : outv;                                // (no inline v_writelane: its lane select needs m0, which inline asm may not clobber)
         if (__builtin_expect(idx > szBytes, 0)) { bad = true; break; }   // :231-232
       }
       if (!bad && lane < rowCnt) o[i + lane] = (u8)outv;
@@ -547,9 +463,8 @@ __global__ __launch_bounds__(512) void k_fpaq_dec_wave2(const u8* __restrict__ i
 // which arrangement: one wave per block up to 8 blocks per CU, one lane per block above (KZ_FPAQ_FORCE=lanes|waves
 // overrides, for tests)
 static bool fpaq_use_waves(const kz_ctx* ctx, int B) {
-  const char* f = getenv("KZ_FPAQ_FORCE");
-  if (f && f[0] == 'l') return false;
-  if (f && f[0] == 'w') return true;
+  if (ctx->sw.fpaqForce == 2) return false;
+  if (ctx->sw.fpaqForce == 1) return true;
   return B <= 8 * ctx->numCUs;
 }
 
@@ -594,13 +509,8 @@ int kz_stage_fpaq_decode(kz_ctx* ctx, kz_batch& bt, const uint8_t* in, int64_t i
     view.h_cost = bt.h_len;                                         // decoded length ~ coding steps
     KzPlacement PL;
     { const int prc = kz_place_blocks(ctx, view, PL); if (prc) return prc; }
-    static const bool oldStep = getenv("KZ_FPAQ_OLDSTEP") != nullptr;   // A/B: the round-2 bit step
     for (int rr = 0; rr < PL.R; rr++) {
-      if (oldStep)
-        KZ_LAUNCH(ctx, KID_FPAQ_DEC, k_fpaq_dec_wave, dim3(PL.G[rr]), dim3(64 * PL.wpg), in, inStride, d_bitOff, d_bitEnd, bt.d_len, dst, bt.stride,
-                  bt.d_len2, bt.d_flag, PL.d_order + PL.off[rr], PL.wpg, ctx->d_endBits);
-      else
-        KZ_LAUNCH(ctx, KID_FPAQ_DEC, k_fpaq_dec_wave2, dim3(PL.G[rr]), dim3(64 * PL.wpg), in, inStride, d_bitOff, d_bitEnd, bt.d_len, dst, bt.stride,
+      KZ_LAUNCH(ctx, KID_FPAQ_DEC, k_fpaq_dec_wave2, dim3(PL.G[rr]), dim3(64 * PL.wpg), in, inStride, d_bitOff, d_bitEnd, bt.d_len, dst, bt.stride,
                   bt.d_len2, bt.d_flag, PL.d_order + PL.off[rr], PL.wpg, ctx->d_endBits);
     }
   } else {

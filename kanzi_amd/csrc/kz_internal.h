@@ -16,14 +16,46 @@
 
 enum KzKernelId { KID_ANS_ENC_CHUNK, KID_ANS_ENC_SCAN, KID_ANS_ENC_CONCAT, KID_ANS_DEC_INDEX, KID_ANS_DEC_CHUNK, KID_ANS_DEC_FIN, KID_MASK_LEN, KID_PASSTHROUGH, KID_FRAME_PREPARE, KID_COPY_BYTES, KID_FRAME_DECIDE, KID_FRAME_HEADER, KID_FRAME_PARSE, KID_COPY_PAYLOAD, KID_BWT_INIT, KID_RADIX_HIST, KID_RADIX_SCAN, KID_RADIX_SCATTER, KID_SEG_REDUCE, KID_SEG_SCAN, KID_SEG_APPLY, KID_LIVE_EMIT, KID_BWT_EMIT, KID_BWTI_PARSE, KID_BWTI_HIST, KID_BWTI_SCAN, KID_BWTI_SCATTER, KID_BWTI_WALK1, KID_BWTI_RESOLVE, KID_BWTI_COPY, KID_BWTI_LITERAL, KID_BWTI_FIN, KID_SBRT_LAST2, KID_SBRT_SCAN, KID_SBRT_REPLAY, KID_COPY_LEN, KID_SBRT_INVERSE, KID_ZRLT_F1, KID_ZRLT_F2, KID_ZRLT_F3, KID_ZRLT_FFIN, KID_ZRLT_I1, KID_ZRLT_I2, KID_ZRLT_I3, KID_ZRLT_IFIN, KID_HUF_ENC_CHUNK, KID_HUF_DEC_INDEX, KID_HUF_DEC_CHUNK, KID_HUF_DEC_FIN, KID_FPAQ_ENC, KID_FPAQ_PACK, KID_FPAQ_DEC, KID_SRT_HIST, KID_SRT_PREP, KID_SRT_SCATTER, KID_SRT_INV, KID_LZ_FWD, KID_LZ_INV, KID_XXHASH, KID_BLOCK_MAGIC, KID_MM_ANALYZE, KID_MM_EMIT, KID_MM_CHECK, KID_MM_INV, KID_ALIAS_ANALYZE, KID_ALIAS_HIST1, KID_ALIAS_SELECT, KID_ALIAS_EMIT, KID_ALIAS_INV, KID_SKIP_DECIDE, KID_MSD_HIST, KID_MSD_SCAN, KID_MSD_SCATTER, KID_BUCKET_SORT, KID_BUCKET_COUNT, KID_BUCKET_COUNT_S, KID_TR_HIST16, KID_TR_ASSIGN, KID_TR_COUNT, KID_TR_SCATTER, KID_TR_SORT, KID_TEXT_INV, KID_UTF_INV, KID_TEXT_FWD, KID_TEXT_WALK, KID_COUNT };
 #define KZ_KERNEL_NAMES { "k_ans_enc_chunk", "k_ans_enc_scan", "k_ans_enc_concat", "k_ans_dec_index", "k_ans_dec_chunk", "k_ans_dec_fin", "k_mask_len", "k_passthrough", "k_frame_prepare", "k_copy_bytes", "k_frame_decide", "k_frame_header", "k_frame_parse", "k_copy_payload", "k_bwt_init", "k_radix_hist", "k_radix_scan", "k_radix_scatter", "k_seg_reduce", "k_seg_scan", "k_seg_apply", "k_live_emit", "k_bwt_emit", "k_bwti_parse", "k_bwti_hist", "k_bwti_scan", "k_bwti_scatter", "k_bwti_walk1", "k_bwti_resolve", "k_bwti_copy", "k_bwti_literal", "k_bwti_fin", "k_sbrt_last2", "k_sbrt_scan", "k_sbrt_replay", "k_copy_len", "k_sbrt_inverse", "k_zrlt_f1", "k_zrlt_f2", "k_zrlt_f3", "k_zrlt_ffin", "k_zrlt_i1", "k_zrlt_i2", "k_zrlt_i3", "k_zrlt_ifin", "k_huf_enc_chunk", "k_huf_dec_index", "k_huf_dec_chunk", "k_huf_dec_fin", "k_fpaq_enc", "k_fpaq_pack", "k_fpaq_dec", "k_srt_hist", "k_srt_prep", "k_srt_scatter", "k_srt_inv", "k_lz_fwd", "k_lz_inv", "k_xxhash", "k_block_magic", "k_mm_analyze", "k_mm_emit", "k_mm_check", "k_mm_inv", "k_alias_analyze", "k_alias_hist1", "k_alias_select", "k_alias_emit", "k_alias_inv", "k_skip_decide", "k_msd_hist", "k_msd_scan", "k_msd_scatter", "k_bucket_sort", "k_bucket_count", "k_bucket_count_s", "k_tr_hist16", "k_tr_assign", "k_tr_count", "k_tr_scatter", "k_tr_sort", "k_text_inv", "k_utf_inv", "k_text_fwd", "k_text_walk" }
+// Environment switches (diagnostics, A/B runs, the tests' forced schedules; none is needed for normal use).  Read ONCE, when the
+// context is created (kz_switches_read, kz_api.hip); kz_ctx_reload_switches re-reads them for a live context (tests, A/B tools).
+// Nothing on a call's path calls getenv.
+struct kz_switches {
+  int blockingWaits = -1;        // KZ_BLOCKING_WAITS: -1 unset (decided from the CPU quota), 0 / 1
+  int textGpu = -1;              // KZ_TEXT_GPU: -1 unset, 0 host, 1 rows x 3 waves, 2 serial walk, 3 rows x 1 wave
+  int textGpuMin = 512;          // KZ_TEXT_GPU_MIN
+  int textFwdGpu = -1;           // KZ_TEXT_FWD_GPU: -1 unset, 0 host, 1 any batch
+  int textFwdGpuMin = 256;       // KZ_TEXT_FWD_GPU_MIN
+  int utfGpu = 1;                // KZ_UTF_GPU=0: UTF inverse on the host
+  int utfFwdGpu = -1;            // KZ_UTF_FWD_GPU: -1 unset (with the device TEXT forward), 0 host, 1 any batch
+  int textGpuTrace = 0;          // KZ_TEXT_GPU_TRACE
+  int fuseMinBlocks = 32;        // KZ_FUSE_MIN_BLOCKS: smaller batches run the decoder's stages one after the other
+  int overlapClasses = 3;        // KZ_OVERLAP_CLASSES
+  int wideQueues = -1;           // KZ_WIDE_QUEUES: -1 = measured once per context
+  int noSFirst = 0;              // KZ_NO_SFIRST
+  int traceSched = 0;            // KZ_TRACE_SCHED
+  int tracePipe = 0;             // KZ_TRACE_PIPE
+  int hostChunk = 0;             // KZ_HOST_CHUNK (0: by the batch)
+  int hostChunkDec = 512;        // KZ_HOST_CHUNK_DEC
+  int hostInvStaged = -1;        // KZ_HOST_INV_STAGED: -1 unset
+  int streamChunk = 0;           // KZ_STREAM_CHUNK (0: default)
+  int streamSerial = 0;          // KZ_STREAM_SERIAL
+  int bwtTrie = -1, bwtTrieWin = -1, bwtBuckets = -1, bwtDmax = -1, bwtRetire = -1;   // KZ_BWT_TRIE / _TRIEWIN / _BUCKETS / _DMAX / _RETIRE (-1 unset)
+  int bwtTrace = 0;              // KZ_BWT_TRACE
+  int bwtTestTrieOverflow = -1;  // KZ_BWT_TEST_TRIE_OVERFLOW=<round> (tests)
+  int fpaqForce = 0;             // KZ_FPAQ_FORCE: 0 unset, 1 wave, 2 lane
+  int sbrtForm = -1;             // KZ_SBRT_FORM: -1 default, 0 = the 32-bit list forms of rounds 2-5 (A/B)
+};
+void kz_switches_read(kz_switches& s);   // kz_api.hip
+
 struct KzPending { hipEvent_t e0, e1; int id; };
 struct kz_ctx {
   int device = 0;
+  kz_switches sw;                // environment switches as read at creation
   hipStream_t stream = nullptr;
   hipStream_t side[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // side streams of the overlapped RANK-inverse / BWT-inverse schedule (created on first use)
   hipEvent_t evJoin[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int wideQueues = -1;           // main + three side streams run side by side (-1: not measured yet)
-  int wideNow = 0;               // what the current call uses (KZ_WIDE_QUEUES overrides the measurement)
+  int wideNow = 0;               // what the current call uses (sw.wideQueues overrides the measurement)
   // grow-only device arena, bump-allocated per API call
   uint8_t* arena = nullptr;
   size_t arenaCap = 0, arenaTop = 0;
@@ -66,6 +98,8 @@ struct kz_ctx {
   Stage pinIn[2], pinOut[2];       // pinned host memory (hipHostMalloc)
   Stage devIn[2], devOut[2];       // HBM outside the arena (the arena is reset by every batched call)
   Stage hsIn[2], hsOut[2];         // pinned: the host-stage pipeline's copy of a chunk's blocks / the stages' outputs (kz_api.hip)
+  Stage tfIn, tfOut[2];           // pinned: the device TEXT forward's host passes (kz_encode_blocks_pre).  Their own buffers and
+  hipStream_t tfCopy = nullptr;    // stream: kz_compress's upload thread fills hsOut[k & 1] / drains on copyDown for the NEXT chunk meanwhile
   hipStream_t copyUp = nullptr, copyDown = nullptr;
   Stage hiAux[2];                  // HBM: per-block lengths / masks of the decoder's host-inverse chunks (kz_api.hip)
   hipStream_t hiStream[2] = {nullptr, nullptr};   // their gather / scatter kernels run beside the main stream's next chunk
@@ -75,6 +109,9 @@ struct kz_ctx {
   int blockingWaits = 0;
   hipEvent_t evBlock = nullptr;
 };
+
+// scratch taken from the context's arena inside one function: given back on every way out (KZ_HIP returns early)
+struct kz_arena_guard { kz_ctx* c; size_t mark; ~kz_arena_guard() { c->arenaTop = mark; } };
 
 #define KZ_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
   snprintf(ctx->err, sizeof(ctx->err), "%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \

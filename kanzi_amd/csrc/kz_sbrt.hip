@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
       u64 upd = (lane == cl) ? nk : ok;
       asm volatile("" : "+v"(upd));                                 // one 64-bit value: one indexed store (the halves took a gpr_idx region each)
       K[cs] = upd;
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(outv) : "s"(cntv), "s"(j) : "m0");   // outv[lane j] = rank
+      outv = (lane == j) ? (u32)cntv : outv;                        // outv[lane j] = rank (no inline v_writelane: its lane select needs m0, which inline asm may not clobber)
       cp = c;
     }
     if ((R >> (cnt - 1)) & 1ULL) KZ_SBRT_FIX_RUN(cp, row + cnt - 1)    // the row ends inside a skipped stretch
@@ -653,6 +653,7 @@ __global__ __launch_bounds__(64) void k_sbrt_inverse_wide(const u8* __restrict__
             const bool mv = j > rp && j <= r;
             ts[k] = mv ? S[j - 1] : 0; tq[k] = mv ? Q[j - 1] : 0; tp[k] = mv ? P[j - 1] : 0;
           }
+          __syncthreads();                                  // every lane's loads before any lane's stores (lane 0 of group k+1 reads what lane 63 of group k writes)
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const int j = k * 64 + lane;
@@ -793,7 +794,7 @@ int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
   const std::vector<int>& launchG = PL.G;
   const std::vector<int>& launchOff = PL.off;
   const int32_t* d_order = PL.d_order;
-  const int oldCold = getenv("KZ_SBRT_OLDCOLD") ? 8 : 0;            // A/B: cold rows in the by-position layout
+  const int oldCold = 0;                                            // (bit 3 of prio = cold rows in the by-position layout: the round-3 A/B, closed)
   for (int rr = 0; rr < R; rr++) {
     const int G = launchG[rr];
     const int32_t* ord = d_order + launchOff[rr];

@@ -275,9 +275,8 @@ static int stage_streams(kz_ctx* ctx) {
   if (!ctx->copyDown) KZ_HIP(hipStreamCreateWithFlags(&ctx->copyDown, hipStreamNonBlocking));
   return 0;
 }
-static int stream_chunk_blocks(int blockSize) {                   // blocks per pipeline step of kz_compress: about 1 GiB of input
-  const char* e = getenv("KZ_STREAM_CHUNK");
-  if (e && atoi(e) > 0) return atoi(e);
+static int stream_chunk_blocks(const kz_ctx* ctx, int blockSize) {   // blocks per pipeline step of kz_compress: about 1 GiB of input
+  if (ctx->sw.streamChunk > 0) return ctx->sw.streamChunk;
   return (int)std::max<int64_t>(8, std::min<int64_t>(2048, (1LL << 30) / blockSize));
 }
 struct BlockSizeScope {                                            // the context's "blockSize" entry = this stream's (TEXT reads it)
@@ -378,8 +377,8 @@ extern "C" int64_t kz_compress(kz_ctx* ctx, uint64_t transformType, uint32_t ent
   write_stream_header(bs, transformType, entropyType, blockSize, n, ctx->checksum);
   const int64_t nblocks = (n + blockSize - 1) / blockSize;
   BlockSizeScope scope(ctx, blockSize);
-  const int CH = stream_chunk_blocks(blockSize);
-  if (nblocks >= 2LL * CH && !getenv("KZ_STREAM_SERIAL")) {
+  const int CH = stream_chunk_blocks(ctx, blockSize);
+  if (nblocks >= 2LL * CH && !ctx->sw.streamSerial) {
     const int64_t rc = compress_pipelined(ctx, transformType, entropyType, blockSize, src, n, bs, nblocks, CH);
     if (rc == -KZ_ERR_WRITE_FILE) snprintf(ctx->err, sizeof(ctx->err), "kz_compress: destination too small");
     if (rc) return rc;
@@ -497,7 +496,7 @@ extern "C" int64_t kz_decompress(kz_ctx* ctx, const uint8_t* src, int64_t n, uin
       if (fit < cnt) { cnt = (int)fit; pending = -KZ_ERR_WRITE_FILE; done = true; }
       if (cnt == 0) break;
     }
-    if (cnt >= 16 && !getenv("KZ_STREAM_SERIAL")) {
+    if (cnt >= 16 && !ctx->sw.streamSerial) {
       // ---- staged batch: payloads are extracted (bit-shifted) straight into pinned memory, go to HBM with asynchronous copies,
       //      the batch is decoded HBM -> HBM, and the blocks come back through a pinned ring while host threads move the previous
       //      piece to its place in dst ----

@@ -497,11 +497,13 @@ struct TextFwdJob {
   std::vector<int32_t> ord;
   int32_t *dOrd = nullptr, *dOut = nullptr, *dCond = nullptr;
   size_t mark = 0;
+  kz_ctx* holder = nullptr;                         // the context whose arena holds this job's scratch above `mark` (null: nothing held)
   int A = 0, kept = 0;
   bool live = false;
 };
 TextFwdJob* kz_text_fwd_gpu_new() { return new TextFwdJob(); }
-void kz_text_fwd_gpu_free(TextFwdJob* J) { delete J; }
+// the job's owner drops it on every path out of the encode call: an early error return gives the arena back here
+void kz_text_fwd_gpu_free(TextFwdJob* J) { if (J && J->holder) J->holder->arenaTop = J->mark; delete J; }
 
 int kz_text_fwd_gpu_classify(kz_ctx* ctx, kz_batch& bt, int blockSize, const std::vector<int32_t>& take, std::vector<int32_t>& keeps,
                              std::vector<int32_t>& declined, TextFwdJob& J) {
@@ -537,7 +539,7 @@ int kz_text_fwd_gpu_classify(kz_ctx* ctx, kz_batch& bt, int blockSize, const std
   }
   G.sMapN = (int)(sMap.size() / 3);
   hipStream_t st = ctx->stream;
-  J.mark = ctx->arenaTop;
+  J.mark = ctx->arenaTop; J.holder = ctx;
   u8* dText = (u8*)kz_arena_alloc(ctx, hText.size() + 64);
   u8* dDelim = (u8*)kz_arena_alloc(ctx, 256);
   u64* dSMap = (u64*)kz_arena_alloc(ctx, sMap.size() * 8 + 64);
@@ -549,7 +551,7 @@ int kz_text_fwd_gpu_classify(kz_ctx* ctx, kz_batch& bt, int blockSize, const std
   G.fail = (int32_t*)kz_arena_alloc(ctx, (size_t)A * 4);
   G.stats = (int32_t*)kz_arena_alloc(ctx, (size_t)A * TF_STATS * 4);
   G.tdt = (int32_t*)kz_arena_alloc(ctx, (size_t)A * 4);
-  if (!dText || !dDelim || !dSMap || !dSPos || !J.dOrd || !J.dOut || !J.dCond || !G.mode || !G.fail || !G.stats || !G.tdt) { ctx->arenaTop = J.mark; return 0; }
+  if (!dText || !dDelim || !dSMap || !dSPos || !J.dOrd || !J.dOut || !J.dCond || !G.mode || !G.fail || !G.stats || !G.tdt) { ctx->arenaTop = J.mark; J.holder = nullptr; return 0; }
   KZ_HIP(hipMemcpyAsync(dText, hText.data(), hText.size(), hipMemcpyHostToDevice, st));
   KZ_HIP(hipMemcpyAsync(dDelim, hDelim.data(), 256, hipMemcpyHostToDevice, st));
   KZ_HIP(hipMemcpyAsync(dSMap, sMap.data(), sMap.size() * 8, hipMemcpyHostToDevice, st));
@@ -575,7 +577,7 @@ int kz_text_fwd_gpu_classify(kz_ctx* ctx, kz_batch& bt, int blockSize, const std
   int K = 0;
   for (int b = 0; b < B; b++) if (J.ord[b] >= 0 && mode[J.ord[b]] >= 0) ord2[b] = K++;
   J.kept = K;
-  if (K == 0) { ctx->arenaTop = J.mark; return 0; }
+  if (K == 0) { ctx->arenaTop = J.mark; J.holder = nullptr; return 0; }
   int32_t* dMode2 = (int32_t*)kz_arena_alloc(ctx, (size_t)K * 4);
   int32_t* dFail2 = (int32_t*)kz_arena_alloc(ctx, (size_t)K * 4);
   G.tileSum = (int32_t*)kz_arena_alloc(ctx, (size_t)K * (size_t)G.maxTiles * 4);
@@ -583,8 +585,8 @@ int kz_text_fwd_gpu_classify(kz_ctx* ctx, kz_batch& bt, int blockSize, const std
   G.map = (u64*)kz_arena_alloc(ctx, (size_t)K * (size_t)G.slotsPer * 16);
   G.tok = (u32*)kz_arena_alloc(ctx, (size_t)K * (size_t)G.NS * 4);
   if (!dMode2 || !dFail2 || !G.tileSum || !G.wpos || !G.map || !G.tok) {
-    if (getenv("KZ_TEXT_GPU_TRACE")) fprintf(stderr, "[textfwd] no scratch for %d blocks: host stage\n", K);
-    ctx->arenaTop = J.mark; J.kept = 0; return 0;
+    if (ctx->sw.textGpuTrace) fprintf(stderr, "[textfwd] no scratch for %d blocks: host stage\n", K);
+    ctx->arenaTop = J.mark; J.holder = nullptr; J.kept = 0; return 0;
   }
   std::vector<int32_t> mode2(K);
   for (int b = 0; b < B; b++) if (ord2[b] >= 0) { mode2[ord2[b]] = mode[J.ord[b]]; keeps[b] = 1; }
@@ -635,8 +637,8 @@ int kz_text_fwd_gpu_finish(kz_ctx* ctx, kz_batch& bt, TextFwdJob& J, std::vector
     KZ_HIP(kz_stream_sync(ctx, st));
   }
   KZ_HIP(hipGetLastError());
-  if (getenv("KZ_TEXT_GPU_TRACE")) fprintf(stderr, "[textfwd] took %d blocks, finished %d (kept %d after the statistics)\n", J.A, nDone, J.kept);
-  ctx->arenaTop = J.mark;
+  if (ctx->sw.textGpuTrace) fprintf(stderr, "[textfwd] took %d blocks, finished %d (kept %d after the statistics)\n", J.A, nDone, J.kept);
+  ctx->arenaTop = J.mark; J.holder = nullptr;
   J.live = false;
   return 0;
 }

@@ -844,6 +844,7 @@ int kz_stage_text_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, int dstC
   std::call_once(once, [] { kz_text_static_tables(hHash, hPos, hLenIdx, hText, hDelim, &hCount); });
   if (hCount + 2 > TG_SMAX || (int)hText.size() > TG_STEXT) return 0;      // (cannot happen: the dictionary is a fixed table)
   const size_t mark = ctx->arenaTop;
+  kz_arena_guard arenaGuard{ctx, mark};
   const int NW = hCount + 2;
   u32* dHash = (u32*)kz_arena_alloc(ctx, (size_t)NW * 4);
   int32_t* dPos = (int32_t*)kz_arena_alloc(ctx, (size_t)NW * 4);
@@ -875,7 +876,7 @@ int kz_stage_text_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int blockSize, int dstC
   std::vector<int32_t> cond(B, 0), newLen(bt.h_len);
   int any = 0;
   for (int b = 0; b < B; b++) if (ord[b] >= 0 && outLen[b] >= 0) { cond[b] = 1; newLen[b] = outLen[b]; done[b] = 1; any = 1; }
-  if (getenv("KZ_TEXT_GPU_TRACE")) { int nd = 0; for (int b = 0; b < B; b++) nd += done[b]; fprintf(stderr, "[textgpu] took %d blocks, finished %d\n", A, nd); }
+  if (ctx->sw.textGpuTrace) { int nd = 0; for (int b = 0; b < B; b++) nd += done[b]; fprintf(stderr, "[textgpu] took %d blocks, finished %d\n", A, nd); }
   if (any) {
     // the finished blocks go back to the slots the rest of the decoder reads (the untouched ones are still there)
     KZ_HIP(hipMemcpyAsync(dCond, cond.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
@@ -1065,6 +1066,7 @@ int kz_stage_utf_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int dstCap, const std::v
   UtfGpu G;
   G.maxTiles = maxLen / UG_TILE + 2; G.dstCap = dstCap;
   const size_t mark = ctx->arenaTop;
+  kz_arena_guard arenaGuard{ctx, mark};
   int32_t* dOrd = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   int32_t* dOut = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
   int32_t* dCond = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4);
@@ -1088,7 +1090,7 @@ int kz_stage_utf_inverse_gpu(kz_ctx* ctx, kz_batch& bt, int dstCap, const std::v
   std::vector<int32_t> cond(B, 0), newLen(bt.h_len);
   int any = 0, nd = 0;
   for (int b = 0; b < B; b++) if (ord[b] >= 0 && outLen[b] >= 0) { cond[b] = 1; newLen[b] = outLen[b]; done[b] = 1; any = 1; nd++; }
-  if (getenv("KZ_TEXT_GPU_TRACE")) fprintf(stderr, "[utfgpu] took %d blocks, finished %d\n", A, nd);
+  if (ctx->sw.textGpuTrace) fprintf(stderr, "[utfgpu] took %d blocks, finished %d\n", A, nd);
   if (any) {
     KZ_HIP(hipMemcpyAsync(dCond, cond.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     KZ_HIP(hipMemcpyAsync(dOut, newLen.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));

@@ -40,3 +40,25 @@ def ctx(built):
     c = kz.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(autouse=True)
+def _switches_follow_the_environment(monkeypatch):
+    """The library reads its KZ_* environment switches once, when a context is created.  Tests flip them with
+    monkeypatch on live contexts (the session's `ctx`): every setenv / delenv of a test is followed by a re-read in the live
+    contexts, and so is the restoration at the end of the test."""
+    import kanzi_amd as kz
+    set0, del0 = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(*a, **k):
+        set0(*a, **k)
+        kz.reload_switches()
+
+    def delenv(*a, **k):
+        del0(*a, **k)
+        kz.reload_switches()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield
+    monkeypatch.undo()
+    kz.reload_switches()

@@ -1675,3 +1675,131 @@ def test_text_forward_on_the_device_in_kz_compress(chain, ent, monkeypatch, capf
     assert got == oracle.compress(chain, ent, bs, data, jobs=8)
     err = capfd.readouterr().err
     assert sum(int(l.split()[5]) for l in err.splitlines() if l.startswith("[textfwd] took")) > 200, err[-300:]
+
+
+# ---- round 6: the device TEXT / UTF kernels at BASELINE's block size, and the staging race of kz_compress ----
+_BIG = {}
+
+
+def _big_blocks():
+    if "b" not in _BIG:
+        _BIG["b"] = textgen.big_blocks(4 << 20)
+    return _BIG["b"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chain,ent", [("TEXT+UTF+BWT+RANK+ZRLT", "ANS0"), ("TEXT+UTF", "NONE")])
+def test_text_forward_on_the_device_at_4mib_blocks(chain, ent, monkeypatch, capfd):
+    """Nine blocks of 4 MiB (BASELINE's block size: TextCodec2's map starts at 2^17 entries there, TextCodec.java:1071-1081) --
+    English LF / CRLF, XML, UTF-8, invented words that grow the word list past 2^17 entries, invented words that wrap it at 2^19,
+    escape bytes inside text, binary, a ragged last block -- go through kz_encode_blocks with the TEXT forward forced onto the
+    device: block streams, bit counts, skip flags and lengths equal oracle.encode_block(..., block_size=4 MiB), and the trace shows
+    that the device took and finished blocks."""
+    monkeypatch.setenv("KZ_TEXT_FWD_GPU", "1")
+    monkeypatch.setenv("KZ_TEXT_FWD_GPU_MIN", "1")
+    monkeypatch.setenv("KZ_TEXT_GPU_TRACE", "1")
+    bs = 4 << 20
+    blocks = _big_blocks()
+    B = len(blocks)
+    ctx = kz.Context(0)
+    ctx.set_block_size(bs)
+    inp = np.zeros((B, bs), dtype=np.uint8)
+    lens = np.array([len(d) for d in blocks], dtype=np.int32)
+    for i, d in enumerate(blocks):
+        inp[i, :len(d)] = np.frombuffer(d, dtype=np.uint8)
+    ostride = kz.max_block_stream_bytes(bs)
+    out = np.zeros((B, ostride), dtype=np.uint8)
+    res = kz.encode_blocks(ctx, chain, ent, inp, bs, lens, out, ostride)
+    ctx.close()
+    for i, d in enumerate(blocks):
+        so, w, sf, pl = oracle.encode_block(chain, ent, d, block_size=bs)
+        assert res[i].status == 0 and (res[i].bits, res[i].skipFlags, res[i].length) == (w, sf, pl), (chain, ent, i, len(d))
+        assert out[i, :(w + 7) // 8].tobytes() == so, (chain, ent, i)
+    err = capfd.readouterr().err
+    took = [int(l.split()[2]) for l in err.splitlines() if l.startswith("[textfwd] took")]
+    fin = [int(l.split()[5]) for l in err.splitlines() if l.startswith("[textfwd] took")]
+    assert took and sum(took) >= 6 and sum(fin) >= 5, err[-400:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["", "2", "3"])
+def test_text_and_utf_inverse_on_the_device_at_4mib_blocks(form, monkeypatch, capfd):
+    """The oracle's level-5 .knz of the nine 4 MiB blocks is decoded with the TEXT inverse (default row form / serial walk / one-wave
+    rows) and the UTF inverse running on the device: the input comes back; corrupted copies get the oracle's verdict and bytes; the
+    trace shows that the device took and finished blocks."""
+    if form:
+        monkeypatch.setenv("KZ_TEXT_GPU", form)
+    else:
+        monkeypatch.delenv("KZ_TEXT_GPU", raising=False)
+    monkeypatch.setenv("KZ_TEXT_GPU_MIN", "1")
+    monkeypatch.delenv("KZ_UTF_GPU", raising=False)
+    monkeypatch.setenv("KZ_TEXT_GPU_TRACE", "1")
+    bs = 4 << 20
+    data = b"".join(_big_blocks())
+    chain, ent = "TEXT+UTF+BWT+RANK+ZRLT", "ANS0"
+    if "knz" not in _BIG:
+        _BIG["knz"] = oracle.compress(chain, ent, bs, data, jobs=8)
+    ref = _BIG["knz"]
+    ctx = kz.Context(0)
+    assert kz.CompressedInputStream(ctx, ref).read() == data
+    rng = np.random.default_rng(600 + len(form))
+    for _ in range(2):
+        bad = bytearray(ref)
+        pos = int(rng.integers(40, len(bad) - 8))
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        try:
+            want = oracle.decompress(bytes(bad), len(data) + 4 * bs, jobs=8)
+        except Exception:
+            want = None
+        try:
+            got = kz.CompressedInputStream(ctx, bytes(bad)).read()
+        except Exception:
+            got = None
+        assert (got is None) == (want is None) and (got is None or got == want), (form, pos)
+    ctx.close()
+    err = capfd.readouterr().err
+    took = [int(l.split()[2]) for l in err.splitlines() if l.startswith("[textgpu]")]
+    fin = [int(l.split()[5]) for l in err.splitlines() if l.startswith("[textgpu]")]
+    assert took and sum(fin) >= 5, err[-400:]
+    utook = [int(l.split()[2]) for l in err.splitlines() if l.startswith("[utfgpu]")]
+    ufin = [int(l.split()[5]) for l in err.splitlines() if l.startswith("[utfgpu]")]
+    assert utook and sum(ufin) >= 1, err[-400:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tool", ["text_fwd_gpu_fuzz", "text_gpu_fuzz"])
+def test_device_text_fuzz_with_a_4mib_case(tool):
+    import subprocess
+    import sys
+    """the two device-TEXT differential fuzzers in their full-size mode (block sizes up to 4 MiB) for a bounded time, fixed seed"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", tool + ".py"), "40", "606", "big4"], capture_output=True, text=True, timeout=600)
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout and "4MiB cases: 0" not in r.stdout, tail
+
+
+@pytest.mark.gpu
+def test_kz_compress_device_text_chunks_do_not_share_staging_with_the_upload_thread(monkeypatch):
+    """kz_compress's pipeline pre-stages chunk k+1 on its upload thread (pinned hsOut[k & 1]) while the main thread
+    encodes chunk k; a device-TEXT chunk used to run its host passes in the same pinned buffers.  Three chunks of 256 / 256 / 61
+    blocks whose text blocks are non-ASCII UTF-8 (TEXT declines them on the device, UTF applies on the host: the host passes write
+    real output), interleaved with English: the .knz must be the oracle's on every one of five runs."""
+    monkeypatch.setenv("KZ_STREAM_CHUNK", "256")
+    monkeypatch.delenv("KZ_TEXT_FWD_GPU", raising=False)
+    bs = 32768
+    rng = np.random.default_rng(77)
+    cps = [0x400 + i for i in range(200)] + [0x4E00 + 7 * i for i in range(300)] + [32] * 60
+    wide = "".join(chr(cps[int(i)]) for i in rng.integers(0, len(cps), 150000)).encode("utf-8")
+    c = textgen.cases()
+    base = wide[:bs * 5] + c["english"][:bs * 2] + textgen.utf8(bs * 3, 5) + c["xml"][:bs]
+    data = (base * 60)[:573 * bs - 333]
+    chain, ent = "TEXT+UTF+BWT+RANK+ZRLT", "ANS0"
+    want = oracle.compress(chain, ent, bs, data, jobs=8)
+    ctx = kz.Context(0)
+    for run in range(5):
+        out = kz.CompressedOutputStream(ctx, chain, ent, bs)
+        out.write(data)
+        out.close()
+        assert bytes(out.output) == want, run
+    ctx.close()

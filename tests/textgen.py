@@ -124,3 +124,37 @@ def bulk_text(n, seed, kind="english"):
     if len(out) < n:
         out = np.resize(out, n)
     return np.ascontiguousarray(out[:n])
+
+
+def vocab_words(n, seed, vocab, lo=3, hi=9):
+    """n bytes of words drawn uniformly from `vocab` distinct invented words (array operations only): with ~150 000 words in a
+    4 MiB block TextCodec's word list grows past 2^17 entries (its map doubles, TextCodec.java:1071-1081) without wrapping at 2^19"""
+    rng = np.random.default_rng(seed)
+    L = rng.integers(lo, hi + 1, vocab)
+    starts = np.concatenate(([0], np.cumsum(L + 1)[:-1]))
+    blob = rng.integers(97, 123, int((L + 1).sum()), dtype=np.uint8)
+    blob[starts + L] = 32
+    need = int(n // (L.mean() + 1)) + 64
+    ids = rng.integers(0, vocab, need)
+    Li = L[ids] + 1
+    off = np.cumsum(Li) - Li
+    src = np.repeat(starts[ids] - off, Li) + np.arange(int(Li.sum()))
+    out = blob[src]
+    out[rng.random(len(out)) < 0.002] = 10
+    if len(out) < n:
+        out = np.resize(out, n)
+    return np.ascontiguousarray(out[:n])
+
+
+def big_blocks(bs):
+    """Blocks of `bs` bytes (meant for BASELINE's 4 MiB) for the device TEXT / UTF parity tests: English (LF), English (CRLF), XML,
+    UTF-8 (Cyrillic), invented words that push the word list past 2^17 entries, invented words that make it wrap at 2^19,
+    English with escape bytes and bytes >= 0x80 sprinkled in, binary, and a ragged last block"""
+    rng = np.random.default_rng(4242)
+    esc = bulk_text(bs, 31, "english").copy()
+    pos = rng.integers(0, bs, bs // 3000)
+    esc[pos] = rng.choice(np.array([0x0F, 0x0E, 0x80, 0xFF, 0x0D, 0xC3], dtype=np.uint8), len(pos))
+    blocks = [bulk_text(bs, 20, "english"), bulk_text(bs, 23, "english"), bulk_text(bs, 21, "xml"), bulk_text(bs, 22, "utf8"),
+              vocab_words(bs, 24, 150000), np.frombuffer(many_words(bs, 25), dtype=np.uint8), esc,
+              rng.integers(0, 256, bs, dtype=np.uint8), bulk_text(bs // 3 + 12345, 26, "english")]
+    return [np.ascontiguousarray(b).tobytes() for b in blocks]

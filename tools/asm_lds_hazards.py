@@ -8,7 +8,7 @@ Used by tests/test_abi.py on every CPU test run, i.e. with whatever hipcc builds
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT_KERNELS = ("k_fpaq_dec_wave2", "k_fpaq_dec_wave", "k_fpaq_enc_wave")
+DEFAULT_KERNELS = ("k_fpaq_dec_wave2", "k_fpaq_enc_wave")
 
 
 def device_asm(source, hipcc=None):

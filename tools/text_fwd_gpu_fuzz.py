@@ -15,7 +15,8 @@ import oracle, textgen, datagen
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
-small = (len(sys.argv) > 3 and sys.argv[3] == "small") or budget <= 20      # many blocks of 16 - 64 KiB from the word generator: more cases per second
+big4 = len(sys.argv) > 3 and sys.argv[3] == "big4"                         # the first batch is three 4 MiB blocks (BASELINE's block size), the rest as usual
+small = (len(sys.argv) > 3 and sys.argv[3] == "small") or (budget <= 20 and not big4)   # many blocks of 16 - 64 KiB from the word generator: more cases per second
 rng = np.random.default_rng(seed)
 print("seed", seed, flush=True)
 ctx = kz.Context(0)
@@ -37,6 +38,10 @@ def words(n, lo, hi, vocab):
 
 def material(n):
     k = int(rng.integers(0, 12)); s = int(rng.integers(0, 1 << 30))
+    if n > (1 << 19) and k in (0, 1, 2, 4, 5, 11):                           # the per-line generators take seconds per MiB: array-built text instead
+        j = int(rng.integers(0, 4))
+        if j == 3: return textgen.vocab_words(n, s, int(rng.integers(1000, 200000))).tobytes()
+        return textgen.bulk_text(n, s, ["english", "xml", "utf8"][j]).tobytes()
     if small and k in (0, 1, 2, 4, 5, 11) and rng.random() < 0.7: k = int(rng.choice([7, 8, 9]))   # textgen's generators are slow: mostly words()
     if k == 0: return bytes(textgen.english(n, s))
     if k == 1: return bytes(textgen.english(n, s, crlf=True))
@@ -56,12 +61,16 @@ def material(n):
     return b" " * int(rng.integers(1, 300)) + bytes(textgen.english(n, s))
 
 
-t0 = time.time(); cases = bad = taken = 0
+t0 = time.time(); cases = bad = taken = big = 0
 while time.time() - t0 < budget:
     chain, ent = [("TEXT", "NONE"), ("TEXT+UTF", "NONE"), ("TEXT+UTF+BWT+RANK+ZRLT", "ANS0"), ("TEXT", "HUFFMAN")][int(rng.integers(0, 4))]
     bs = int(rng.choice([16384, 32768, 65536])) if small else int(rng.choice([16384, 65536, 1 << 18, 1 << 20, 4 << 20]))
     ctx.set_block_size(bs)
     nblk = int(rng.integers(20, 64)) if small else (int(rng.integers(2, 12)) if bs < (1 << 20) else int(rng.integers(1, 4)))
+    if big4 and cases == 0:
+        bs, nblk = 4 << 20, 3
+        ctx.set_block_size(bs)
+    big += nblk if bs == (4 << 20) else 0
     blocks = []
     for _ in range(nblk):
         n = int(rng.integers(900, bs + 1)) if rng.random() < 0.5 else bs
@@ -94,5 +103,6 @@ while time.time() - t0 < budget:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             open(os.path.join(ROOT, "gpurun_out", "textfwd_fail_%d_%d.bin" % (seed, cases)), "wb").write(d)
     if bad > 10: break
+print("4MiB cases: %d" % big)
 print("%d blocks (%d of them TEXT-coded), %d mismatches in %.0f s" % (cases, taken, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
