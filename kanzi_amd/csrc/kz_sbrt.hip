@@ -487,6 +487,7 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
 #define KZ6I_STEP2(A, B, C, XS) KZ6I_STEP(A, B, "s42", "s43", XS) KZ6I_STEP(B, C, "s43", "s42", XS)
 #define KZ6I_STEP8(A, B, C, D, E, F, G, H, I, XS) KZ6I_STEP2(A, B, C, XS) KZ6I_STEP2(C, D, E, XS) KZ6I_STEP2(E, F, G, XS) KZ6I_STEP2(G, H, I, XS)
 #define KZ6I_ROWCOLD(XS) asm volatile(                                                         \
+    "s_mov_b32 s41, m0\n\t"                      /* s_set_gpr_idx_on writes m0: saved and restored, not clobbered */ \
     "v_mov_b32 v80, %[q0]\n\tv_mov_b32 v81, %[q1]\n\tv_mov_b32 v82, %[q2]\n\tv_mov_b32 v83, %[q3]\n\t"  \
     "v_mov_b32 v84, %[p0]\n\tv_mov_b32 v85, %[p1]\n\tv_mov_b32 v86, %[p2]\n\tv_mov_b32 v87, %[p3]\n\t"  \
     "v_mov_b32 v72, %[lane4]\n\tv_add_u32 v73, 1, %[lane4]\n\tv_add_u32 v74, 2, %[lane4]\n\tv_add_u32 v75, 3, %[lane4]\n\t" \
@@ -498,10 +499,11 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
     KZ6I_STEP8(48, 49, 50, 51, 52, 53, 54, 55, 56, XS) KZ6I_STEP8(56, 57, 58, 59, 60, 61, 62, 63, 0, XS)  \
     "v_mov_b32 %[q0], v80\n\tv_mov_b32 %[q1], v81\n\tv_mov_b32 %[q2], v82\n\tv_mov_b32 %[q3], v83\n\t"  \
     "v_mov_b32 %[p0], v84\n\tv_mov_b32 %[p1], v85\n\tv_mov_b32 %[p2], v86\n\tv_mov_b32 %[p3], v87\n\t"  \
+    "s_mov_b32 m0, s41\n\t"                                                                      \
     : [q0]"+v"(Q0), [p0]"+v"(P0), [q1]"+v"(Q1), [p1]"+v"(P1), [q2]"+v"(Q2), [p2]"+v"(P2), [q3]"+v"(Q3), [p3]"+v"(P3),           \
       [tq0]"+v"(tq0), [outv]"+v"(outv)                                                                                         \
     : [cur]"v"(cur), [lane4]"v"(lane4), [ff]"v"(ff), [row]"s"(row)                                                             \
-    : "vcc", "scc", "m0", "v72", "v73", "v74", "v75", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87",                  \
+    : "vcc", "scc", "s41", "v72", "v73", "v74", "v75", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87",                  \
       "v90", "v92", "v93", "v94", "v95", "s42", "s43", "s44", "s45", "s50", "s53", "s54", "s55", "s58", "s59");
 // layout changes: by position (register k = positions 64k..64k+63) <-> interleaved (register k = positions 4l + k)
 __device__ __forceinline__ void kz6_to_interleaved(u32& A0, u32& A1, u32& A2, u32& A3, int lane) {
@@ -528,6 +530,8 @@ __device__ __forceinline__ void kz6_from_interleaved(u32& A0, u32& A1, u32& A2, 
   }
   A0 = N[0]; A1 = N[1]; A2 = N[2]; A3 = N[3];
 }
+
+#include "kz_sbrt_f64.h"
 
 // zero run of zr ranks ending at index pl, compiler form (row tails and all-zero rows)
 #define KZ6_ZERO_RUN(zr, plv)                                                                  \
@@ -558,6 +562,14 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
   u32 fmv = 0;
   const u32 lane4 = 4u * (u32)lane;
   bool inter = false;                         // the list is in the interleaved layout (between consecutive cold rows)
+  // Round 6: rows that cost the 32-bit forms more than 64 x 28 instructions (many ranks >= 64, or many non-zero ranks) run in the
+  // 64-bit-key form of kz_sbrt_f64.h (interleaved layout, Qk / Pk then hold the low / high words of register k).
+  bool keyed = false;
+  int s0 = -1;                                // the symbol decoded at i = 0 (kzf_pack)
+  const bool allowKeyed = (prio & 16) == 0 && n <= (1 << 23);
+  u32 &A0 = Q0, &A1 = Q1, &A2 = Q2, &A3 = Q3, &B0 = P0, &B1 = P1, &B2 = P2, &B3 = P3;
+  const u32 m256 = 0xFFFFFF00u, infHi = 0x7FF00000u;
+  const u32 c100 = 0x100u, c80 = 0x80u, c512 = 512u;                // 0x100 << 22 = 0x80 << 23 = bit 30 of a key's high word
   u32 cur = (lane < n) ? (u32)s[lane] : 0u;
   for (int row = 0; row < n; row += 64) {
     const int cnt = min(64, n - row);
@@ -566,17 +578,37 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
     const uint64_t nz = kz_ballot(cur != 0 && lane < cnt);
     // non-zero lanes receive their symbol with v_writelane; zero ranks output the front symbol of their time
     u32 outv = 0;
-    const u32 f0 = (u32)__builtin_amdgcn_readfirstlane((int)Q0) & 0xFFu;
     int prev = -1;
     const bool dense = cnt == 64 && __builtin_popcountll(nz) >= 48;
     const bool cold = dense && __builtin_popcountll(kz_ballot(cur >= 64u)) > 6;
-    const bool wantInter = cold && !useOldCold;
+    bool wantKeyed = false;
+    if (allowKeyed && cnt == 64) {
+      // what the 32-bit forms would spend on this row (instructions): the row walk pays ~40 for a non-zero rank below 64,
+      // ~62 / 76 / 88 for one in rows 1 / 2 / 3 of the list and ~11 per zero run; the dense rows 22 per rank (+ ~50 per rank >= 64),
+      // the interleaved 32-bit form 47 per rank.  The keyed form: 28 per rank, zero or not.  (Hysteresis: a change of form costs
+      // two layout conversions.)
+      const int n1 = __builtin_popcountll(kz_ballot(cur >= 64u && cur < 128u)), n2 = __builtin_popcountll(kz_ballot(cur >= 128u && cur < 192u));
+      const int n3 = __builtin_popcountll(kz_ballot(cur >= 192u)), nn = __builtin_popcountll(nz), n0 = nn - n1 - n2 - n3;
+      const int runs = __builtin_popcountll(nz & ~(nz << 1));
+      const int est = dense ? (cold ? 47 * 64 : 22 * 64 + 50 * (n1 + n2 + n3)) : 14 + 40 * n0 + 62 * n1 + 76 * n2 + 88 * n3 + 11 * runs;
+      wantKeyed = est > (keyed ? 1700 : 1950);
+    }
+    const bool wantInter = wantKeyed || (cold && !useOldCold);
+    if (keyed && !wantKeyed) { kzf_unpack(A0, B0); kzf_unpack(A1, B1); kzf_unpack(A2, B2); kzf_unpack(A3, B3); keyed = false; }
     if (wantInter != inter) {                                             // (uniform) change of layout
       if (wantInter) { kz6_to_interleaved(Q0, Q1, Q2, Q3, lane); kz6_to_interleaved(P0, P1, P2, P3, lane); }
       else { kz6_from_interleaved(Q0, Q1, Q2, Q3, lane); kz6_from_interleaved(P0, P1, P2, P3, lane); }
       inter = wantInter;
     }
-    if (dense) {
+    const u32 f0 = (u32)__builtin_amdgcn_readfirstlane((int)Q0) & 0xFFu;   // the front symbol at the start of the row (32-bit forms; position 0 is lane 0 of Q0 in both layouts)
+    if (wantKeyed && !keyed) { kzf_pack(Q0, P0, s0); kzf_pack(Q1, P1, s0); kzf_pack(Q2, P2, s0); kzf_pack(Q3, P3, s0); keyed = true; }
+    if (keyed) {
+      const u32 c2 = (((u32)row << 1) << 8) - 256u;                 // the step adds 512 first: ((2 i + 1) << 8) at step i
+      const u32 h0 = 0x40000000u + (u32)row - 1u;                   // MTF: x.hi = 0x40000000 | i, counted up by the step
+      if (MODE == 2) { if (row + 64 <= (1 << 22)) { KZF_ROW(KZF_X_RANK) } else { KZF_ROW(KZF_X_RANK_HI) } }
+      else if (MODE == 1) { KZF_ROW(KZF_X_MTF) } else { KZF_ROW(KZF_X_TS) }
+      outv = ~outv;                                                 // (the keys hold 255 - symbol)
+    } else if (dense) {
       if (!cold) {
         if (MODE == 2) { KZ6_ROWDENSE(KZ6_XI_RANK) } else if (MODE == 1) { KZ6_ROWDENSE(KZ6_XI_MTF) } else { KZ6_ROWDENSE(KZ6_XI_TS) }
       } else if (useOldCold) {
@@ -587,7 +619,7 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
     } else if (nz) {
       if (MODE == 2) { KZ6_ROWLOOP(KZ6_XI_RANK, KZ6_ZQ_RANK) } else if (MODE == 1) { KZ6_ROWLOOP(KZ6_XI_MTF, KZ6_ZQ_MTF) } else { KZ6_ROWLOOP(KZ6_XI_TS, KZ6_ZQ_TS) }
     }
-    if (!dense) {
+    if (!dense && !keyed) {
     { const int zr = cnt - prev - 1; if (zr > 0) KZ6_ZERO_RUN(zr, row + cnt - 1) }
     {
       // zero-rank lane l: symbol of the last front change before l (held by that lane), else the front at row start
@@ -599,6 +631,7 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
     }
     }
     if (lane < cnt) d[row + lane] = (u8)outv;
+    if (row == 0) s0 = __builtin_amdgcn_readfirstlane((int)(outv & 0xFFu));
     cur = nxt;
   }
 }
@@ -795,12 +828,13 @@ int kz_stage_sbrt_inverse(kz_ctx* ctx, kz_batch& bt, int mode) {
   const std::vector<int>& launchOff = PL.off;
   const int32_t* d_order = PL.d_order;
   const int oldCold = 0;                                            // (bit 3 of prio = cold rows in the by-position layout: the round-3 A/B, closed)
+  const int oldForms = ctx->sw.sbrtForm == 0 ? 16 : 0;              // KZ_SBRT_FORM=0 (prio bit 4): the 32-bit list forms of rounds 2-5 only (A/B)
   for (int rr = 0; rr < R; rr++) {
     const int G = launchG[rr];
     const int32_t* ord = d_order + launchOff[rr];
-    if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<2>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio | oldCold); }
-    else if (mode == 1) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<1>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio | oldCold); }
-    else { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<3>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio | oldCold); }
+    if (mode == 2) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<2>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio | oldCold | oldForms); }
+    else if (mode == 1) { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<1>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio | oldCold | oldForms); }
+    else { KZ_LAUNCH(ctx, KID_SBRT_INVERSE, k_sbrt_inverse<3>, dim3(G), dim3(64 * wpg), src, dst, bt.stride, bt.d_len, ord, wpg, bt.prio | oldCold | oldForms); }
   }
   KZ_LAUNCH(ctx, KID_COPY_LEN, k_copy_len, dim3((B + 255) / 256), dim3(256), bt.d_len, bt.d_len2, bt.d_flag, B);
   KZ_HIP(hipGetLastError());

@@ -1,0 +1,98 @@
+// kz_sbrt_f64.h -- SBRT inverse (RANK / MTF / TIMESTAMP; K/transform/SBRT.java:154-214): the round-6 row form of k_sbrt_inverse
+// (kz_sbrt.hip, which includes this file) for rows with many ranks >= 64 or many non-zero ranks, blocks up to 8 MiB.
+//
+// The list BY POSITION as in the other row forms, but every entry is ONE 64-bit key
+//     hi = 0x40000000 | q                      lo = (p << 9) | (touched << 8) | (255 - symbol)
+// read as an IEEE double: bit 62 is set, the exponent stays in 0x400..0x40F, so every key is a positive normal number and the order
+// of the doubles is the order of the 64-bit integers.  That order IS the list order of the reference: q descending; among equal q
+// the entry moved last first (the bubble loop of SBRT.java:203 passes every q <= qc, so a moved entry lands above its equals: larger
+// p); entries never touched (q = p = 0) by ascending symbol, below the entry touched at i = 0 (the `touched` bit).  Keys are distinct.
+// A step with rank r takes the entry at position r, gives it the key x of (qc, i) -- larger than its old key and than every key
+// below -- and re-inserts it.  On a list sorted by key the whole move of SBRT.java:203-209 is, for every position j <= r,
+//     new[j] = max(min(x, old[j-1]), old[j])          (old[-1] = +inf)
+// (above the landing place min gives x > ... no: old[j] wins; at it x; below it old[j-1]; the entry's old key at j = r is dropped),
+// i.e. one v_min_f64 + one v_max_f64 per register, the payload travelling inside the key: no threshold compare, no select pair, no
+// second register to shift.  Positions above r are kept by the EXEC mask of a v_cmpx on the position number.
+//
+// Layout: position j sits in register pair (j & 3), lane (j >> 2) ("interleaved": old[j-1] is the neighbouring register of the same
+// lane, one DPP wave_shr for register 0), so every rank runs the same straight-line code whatever its depth -- 28 instructions for
+// RANK (the 32-bit forms of rounds 2-5: 22 for ranks below 64 in dense rows, 47 in the interleaved form, 40-90 in the row walk).
+//   qc:  RANK (i + p) >> 1 = (lo + (i << 9)) >> 10  (one v_add3 + one v_alignbit that also ORs bit 30 in);  MTF i;  TIMESTAMP p = lo >> 9.
+// p < 2^23 must hold for lo: blocks above 2^23 bytes keep the round-2 kernel (24-bit timestamps in a 32-bit word), blocks of 2^24 - 256
+// and more the LDS form.
+#define KZF_DPP " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+// x.hi (v91) from the accessed entry's lo (s54); v71 = ((2 i + 1) << 8) of this step, v68 = -256, v76 scratch
+#define KZF_X_RANK "v_add3_u32 v76, s54, v71, v68\n\t" "v_alignbit_b32 v91, %[c100], v76, 10\n\t"
+// the same where i + p may reach 2^23 (the rows past 2^22 of a block: lo + (i << 9) no longer fits 32 bits): (lo >> 8) + 2 i, >> 2
+#define KZF_X_RANK_HI "v_lshrrev_b32_e64 v76, 8, s54\n\t" "v_lshrrev_b32 v77, 8, v71\n\t" "v_add3_u32 v76, v76, v77, -1\n\t" "v_alignbit_b32 v91, 1, v76, 2\n\t"
+#define KZF_X_MTF  "v_add_u32 v91, 1, v91\n\t"
+#define KZF_X_TS   "v_mov_b32 v76, s54\n\t" "v_alignbit_b32 v91, %[c80], v76, 9\n\t"
+// one rank at row position J (a constant); RC holds its rank, RN receives the next one
+#define KZF_STEP(J, JN, RC, RN, X)                                 \
+    "s_lshl_b32 s45, " RC ", 1\n\t"                                  \
+    "s_and_b32 s45, s45, 6\n\t"                                      \
+    "s_lshr_b32 s44, " RC ", 2\n\t"                                  \
+    "s_set_gpr_idx_on s45, gpr_idx(SRC0)\n\t"                        \
+    "v_mov_b32 v70, v80\n\t"                     /* lo of register pair r & 3 */ \
+    "s_set_gpr_idx_off\n\t"                                          \
+    "v_mov_b32_dpp v88, v86" KZF_DPP                                 \
+    "v_mov_b32_dpp v89, v87" KZF_DPP                                 \
+    "v_readlane_b32 s54, v70, s44\n\t"                               \
+    "v_readlane_b32 " RN ", %[cur], " #JN "\n\t"                     \
+    "v_add_u32 v71, %[c512], v71\n\t"                                \
+    X                                                                \
+    "v_bfi_b32 v90, %[ff], s54, v71\n\t"                             \
+    "v_writelane_b32 %[outv], s54, " #J "\n\t"                       \
+    "v_min_f64 v[98:99], v[90:91], v[84:85]\n\t"                     \
+    "v_min_f64 v[96:97], v[90:91], v[82:83]\n\t"                     \
+    "v_min_f64 v[94:95], v[90:91], v[80:81]\n\t"                     \
+    "v_min_f64 v[92:93], v[90:91], v[88:89]\n\t"                     \
+    "v_cmpx_ge_u32 vcc, " RC ", v72\n\t"                             \
+    "v_max_f64 v[80:81], v[92:93], v[80:81]\n\t"                     \
+    "v_cmpx_ge_u32 vcc, " RC ", v73\n\t"                             \
+    "v_max_f64 v[82:83], v[94:95], v[82:83]\n\t"                     \
+    "v_cmpx_ge_u32 vcc, " RC ", v74\n\t"                             \
+    "v_max_f64 v[84:85], v[96:97], v[84:85]\n\t"                     \
+    "v_cmpx_ge_u32 vcc, " RC ", v75\n\t"                             \
+    "v_max_f64 v[86:87], v[98:99], v[86:87]\n\t"                     \
+    "s_mov_b64 exec, -1\n\t"
+#define KZF_STEP2(A, B, C, X) KZF_STEP(A, B, "s42", "s43", X) KZF_STEP(B, C, "s43", "s42", X)
+#define KZF_STEP8(A, B, C, D, E, F, G, H, I, X) KZF_STEP2(A, B, C, X) KZF_STEP2(C, D, E, X) KZF_STEP2(E, F, G, X) KZF_STEP2(G, H, I, X)
+// one row of 64 ranks, every rank an ordinary step (a rank 0 re-keys the front entry in place)
+#define KZF_ROW(X) asm volatile(                                                                 \
+    "s_mov_b32 s41, m0\n\t"                                                                        \
+    "v_mov_b32 v80, %[a0]\n\tv_mov_b32 v81, %[b0]\n\tv_mov_b32 v82, %[a1]\n\tv_mov_b32 v83, %[b1]\n\t" \
+    "v_mov_b32 v84, %[a2]\n\tv_mov_b32 v85, %[b2]\n\tv_mov_b32 v86, %[a3]\n\tv_mov_b32 v87, %[b3]\n\t" \
+    "v_mov_b32 v72, %[lane4]\n\tv_add_u32 v73, 1, %[lane4]\n\tv_add_u32 v74, 2, %[lane4]\n\tv_add_u32 v75, 3, %[lane4]\n\t" \
+    "v_mov_b32 v88, 0\n\tv_mov_b32 v89, %[inf]\n\t"                                                \
+    "v_mov_b32 v71, %[c2]\n\tv_mov_b32 v91, %[h0]\n\tv_mov_b32 v68, %[m256]\n\t"                   \
+    "v_readlane_b32 s42, %[cur], 0\n\t"                                                            \
+    KZF_STEP8(0, 1, 2, 3, 4, 5, 6, 7, 8, X) KZF_STEP8(8, 9, 10, 11, 12, 13, 14, 15, 16, X)          \
+    KZF_STEP8(16, 17, 18, 19, 20, 21, 22, 23, 24, X) KZF_STEP8(24, 25, 26, 27, 28, 29, 30, 31, 32, X) \
+    KZF_STEP8(32, 33, 34, 35, 36, 37, 38, 39, 40, X) KZF_STEP8(40, 41, 42, 43, 44, 45, 46, 47, 48, X) \
+    KZF_STEP8(48, 49, 50, 51, 52, 53, 54, 55, 56, X) KZF_STEP8(56, 57, 58, 59, 60, 61, 62, 63, 0, X)  \
+    "v_mov_b32 %[a0], v80\n\tv_mov_b32 %[b0], v81\n\tv_mov_b32 %[a1], v82\n\tv_mov_b32 %[b1], v83\n\t" \
+    "v_mov_b32 %[a2], v84\n\tv_mov_b32 %[b2], v85\n\tv_mov_b32 %[a3], v86\n\tv_mov_b32 %[b3], v87\n\t" \
+    "s_mov_b32 m0, s41\n\t"                                                                        \
+    : [a0]"+v"(A0), [b0]"+v"(B0), [a1]"+v"(A1), [b1]"+v"(B1), [a2]"+v"(A2), [b2]"+v"(B2), [a3]"+v"(A3), [b3]"+v"(B3), [outv]"+v"(outv) \
+    : [cur]"v"(cur), [lane4]"v"(lane4), [ff]"v"(ff), [m256]"v"(m256), [inf]"v"(infHi), [c2]"v"(c2), [h0]"v"(h0), [c100]"s"(c100), [c80]"s"(c80), [c512]"s"(c512) \
+    : "vcc", "scc", "v68", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87",  \
+      "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "s41", "s42", "s43", "s44", "s45", "s54");
+
+
+// ---- the two representations of an entry (both in the interleaved layout: position j = register j & 3, lane j >> 2) ----
+//   32-bit forms: Q = (q << 8) | symbol, P = p                    64-bit key: lo = (p << 9) | (touched << 8) | (255 - symbol), hi = 0x40000000 | q
+// touched: the entry has been accessed.  Q and P show it (q or p non-zero) except for the entry accessed at i = 0 and not since
+// (q = p = 0 like the untouched ones: its place above them is its position in the 32-bit forms): that entry holds symbol s0, the
+// first symbol decoded (s0 < 0: nothing decoded yet).
+__device__ __forceinline__ void kzf_pack(uint32_t& Q, uint32_t& P, int s0) {
+  const uint32_t sym = Q & 0xFFu, q = Q >> 8;
+  const uint32_t touched = ((q | P) != 0u || (int)sym == s0) ? 0x100u : 0u;
+  Q = (P << 9) | touched | (255u - sym);
+  P = 0x40000000u | q;
+}
+__device__ __forceinline__ void kzf_unpack(uint32_t& A, uint32_t& B) {
+  const uint32_t sym = 255u - (A & 0xFFu), p = A >> 9;
+  A = ((B & 0x00FFFFFFu) << 8) | sym;
+  B = p;
+}
