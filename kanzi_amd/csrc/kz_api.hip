@@ -958,8 +958,8 @@ static int overlap_streams(kz_ctx* ctx) {
 // yet) and then runs the BWT inverses as the RANK inverses finish (HBM-bound kernels with huge grids do not share the GPU with
 // another queue's kernels anyway: chains "RANK, BWT" per stream were measured, the BWT stages ran one after the other and
 // started late).  The order of the preparation decides which serial chain is on the critical path; it is picked by trying all
-// permutations against a three-constant model: RANK inverse = 115 ns per byte of the group's longest ZRLT-coded block (a
-// serial chain per block; batches this large keep two waves per SIMD), BWT inverse = 40 ps per byte, preparation = 12 ps per
+// permutations against a three-constant model: RANK inverse = 115 ns per byte of the group's longest ZRLT-coded block, at most 64 ns
+// per byte of the block (a serial chain per block; batches this large keep two waves per SIMD), BWT inverse = 40 ps per byte, preparation = 12 ps per
 // entropy-coded byte (MI355X, profiles/).  Narrow schedule: two side streams, the cheapest group's RANK inverse on the main
 // stream behind all the preparations.
 static void overlap_plan(kz_ctx* ctx, Overlap& O, const std::vector<int32_t>& zlen, const std::vector<int32_t>& rawp, int blockSize, bool withPre) {
@@ -975,7 +975,14 @@ static void overlap_plan(kz_ctx* ctx, Overlap& O, const std::vector<int32_t>& zl
   for (auto& G : O.groups) {
     int64_t maxZ = 0, pre = 0, cnt = 0;
     for (size_t b = 0; b < G.in.size(); b++) if (G.in[b]) { maxZ = std::max<int64_t>(maxZ, zlen[b]); cnt++; pre += rawp[b] ? zlen[b] / 16 : zlen[b]; }
-    G.tRank = 115e-9 * (double)maxZ;
+    // round 6: a block whose ranks are nearly all non-zero and mostly >= 64 (ZRLT-coded length ~ its own: incompressible data)
+    // runs at ~64 ns per rank in the keyed rows of kz_sbrt_f64.h (blocks up to 8 MiB).  Measured in the bulk batch (two waves per
+    // SIMD, the other classes' waves and the BWT inverses beside it): such a class 347 ms, a class of skewed bytes (dense rows of the
+    // 32-bit forms) 461 ms = 115 ns x its ZRLT-coded length, the class of cheap blocks (three fifths of the batch) 312 ms = 1.65 x
+    // that product: the factor 1 + blocks / (2 x SIMDs' worth) below.
+    const bool keyed = ctx->sw.sbrtForm != 0 && blockSize <= (1 << 23) && maxZ >= (int64_t)blockSize - (blockSize >> 5);
+    const double crowd = 1.0 + 0.55 * (double)cnt / (4.0 * (double)std::max(1, ctx->numCUs));
+    G.tRank = (keyed ? 72e-9 * (double)blockSize : 115e-9 * (double)maxZ) * crowd;
     G.tBwt = 40e-12 * (double)cnt * (double)blockSize;
     G.tPre = withPre ? 12e-12 * (double)pre : 0.0;
   }

@@ -587,11 +587,13 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
       // ~62 / 76 / 88 for one in rows 1 / 2 / 3 of the list and ~11 per zero run; the dense rows 22 per rank (+ ~50 per rank >= 64),
       // the interleaved 32-bit form 47 per rank.  The keyed form: 28 per rank, zero or not.  (Hysteresis: a change of form costs
       // two layout conversions.)
-      const int n1 = __builtin_popcountll(kz_ballot(cur >= 64u && cur < 128u)), n2 = __builtin_popcountll(kz_ballot(cur >= 128u && cur < 192u));
-      const int n3 = __builtin_popcountll(kz_ballot(cur >= 192u)), nn = __builtin_popcountll(nz), n0 = nn - n1 - n2 - n3;
-      const int runs = __builtin_popcountll(nz & ~(nz << 1));
-      const int est = dense ? (cold ? 47 * 64 : 22 * 64 + 50 * (n1 + n2 + n3)) : 14 + 40 * n0 + 62 * n1 + 76 * n2 + 88 * n3 + 11 * runs;
-      wantKeyed = est > (keyed ? 1700 : 1950);
+      const int nn = __builtin_popcountll(nz);
+      if (keyed || nn >= 20) {                                      // (fewer than 20 non-zero ranks never reach 1950)
+        const int nd = __builtin_popcountll(kz_ballot(cur >= 64u)), nd2 = __builtin_popcountll(kz_ballot(cur >= 160u));
+        const int runs = __builtin_popcountll(nz & ~(nz << 1));
+        const int est = dense ? (cold ? 47 * 64 : 22 * 64 + 50 * nd) : 14 + 40 * (nn - nd) + 65 * (nd - nd2) + 84 * nd2 + 11 * runs;
+        wantKeyed = est > (keyed ? 1700 : 1950);
+      }
     }
     const bool wantInter = wantKeyed || (cold && !useOldCold);
     if (keyed && !wantKeyed) { kzf_unpack(A0, B0); kzf_unpack(A1, B1); kzf_unpack(A2, B2); kzf_unpack(A3, B3); keyed = false; }

@@ -1,5 +1,5 @@
 """The RANK inverse alone, per data class, a few blocks at a time (every block a lone wave: the latency the small batches pay):
-   python tools/sbrt_inv_probe.py [copies] [chain]
+   python tools/sbrt_inv_probe.py [copies] [chain] [class,class...]
 prints the k_sbrt_inverse time of one decode of `copies` identical 4 MiB blocks per class, for the 64-bit-key form (default) and the
 32-bit forms of rounds 2-5 (KZ_SBRT_FORM=0), after checking the round trip."""
 import os, sys, time
@@ -14,6 +14,8 @@ chain = sys.argv[2] if len(sys.argv) > 2 else "BWT+RANK"
 bs = 4 << 20
 classes = [("uniform", datagen.block(3, bs, 3)), ("geometric", datagen.block(1, bs, 1)), ("text-like", datagen.block(0, bs, 0)), ("records", datagen.block(2, bs, 2)),
            ("sparse", datagen.block(4, bs, 4)), ("sensor", datagen.sensor_like(bs, 4000)), ("exe", datagen.exe_like(bs, 3000)), ("english", textgen.bulk_text(bs, 2000, "english"))]
+if len(sys.argv) > 3:
+    classes = [c for c in classes if c[0] in sys.argv[3].split(",")]
 ctx = kz.Context(0); ctx.set_block_size(bs)
 os_ = kz.max_block_stream_bytes(bs)
 for name, blk in classes:
@@ -21,6 +23,7 @@ for name, blk in classes:
     d_enc = torch.zeros((copies, os_), dtype=torch.uint8, device="cuda")
     d_dec = torch.zeros((copies, bs), dtype=torch.uint8, device="cuda")
     lens = np.full(copies, bs, dtype=np.int32)
+    torch.cuda.synchronize()                               # (the library runs on its own stream: torch's fills must be done)
     res = kz.encode_blocks(ctx, chain, "NONE", d_in.data_ptr(), bs, lens, d_enc.data_ptr(), os_, kz.MEM_DEVICE)
     bits = np.array([r.bits for r in res], dtype=np.int64)
     row = []
@@ -28,7 +31,7 @@ for name, blk in classes:
         if form: os.environ["KZ_SBRT_FORM"] = form
         else: os.environ.pop("KZ_SBRT_FORM", None)
         ctx.reload_switches()
-        d_dec.zero_()
+        d_dec.zero_(); torch.cuda.synchronize()
         kz.decode_blocks(ctx, chain, "NONE", bs, d_enc.data_ptr(), os_, bits, d_dec.data_ptr(), bs, kz.MEM_DEVICE)
         ok = torch.equal(d_in, d_dec)
         ctx.set_kernel_timing(True); ctx.reset_kernel_timing()
