@@ -568,7 +568,8 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
   int s0 = -1;                                // the symbol decoded at i = 0 (kzf_pack)
   const bool allowKeyed = (prio & 16) == 0 && n <= (1 << 23);
   u32 &A0 = Q0, &A1 = Q1, &A2 = Q2, &A3 = Q3, &B0 = P0, &B1 = P1, &B2 = P2, &B3 = P3;
-  const u32 m256 = 0xFFFFFF00u, infHi = 0x7FF00000u;
+  const u32 m256 = 0xFFFFFF00u, infHi = 0x7FF00000u, lanev = (u32)lane;
+  const u32 c128 = 128u, c192 = 192u;
   const u32 c100 = 0x100u, c80 = 0x80u, c512 = 512u;                // 0x100 << 22 = 0x80 << 23 = bit 30 of a key's high word
   u32 cur = (lane < n) ? (u32)s[lane] : 0u;
   for (int row = 0; row < n; row += 64) {
@@ -581,34 +582,48 @@ __global__ __launch_bounds__(512) void k_sbrt_inverse(const u8* __restrict__ src
     int prev = -1;
     const bool dense = cnt == 64 && __builtin_popcountll(nz) >= 48;
     const bool cold = dense && __builtin_popcountll(kz_ballot(cur >= 64u)) > 6;
-    bool wantKeyed = false;
+    bool wantKeyed = false, wantFlat = false, flatDeep = false;                       // keyed rows: interleaved (any rank), or by position (no rank >= 64: 13 instructions per rank)
     if (allowKeyed && cnt == 64) {
       // what the 32-bit forms would spend on this row (instructions): the row walk pays ~40 for a non-zero rank below 64,
       // ~62 / 76 / 88 for one in rows 1 / 2 / 3 of the list and ~11 per zero run; the dense rows 22 per rank (+ ~50 per rank >= 64),
       // the interleaved 32-bit form 47 per rank.  The keyed form: 28 per rank, zero or not.  (Hysteresis: a change of form costs
       // two layout conversions.)
       const int nn = __builtin_popcountll(nz);
-      if (keyed || nn >= 20) {                                      // (fewer than 20 non-zero ranks never reach 1950)
+      if (keyed || nn >= 16) {                                      // (fewer than 16 non-zero ranks never reach the thresholds)
         const int nd = __builtin_popcountll(kz_ballot(cur >= 64u)), nd2 = __builtin_popcountll(kz_ballot(cur >= 160u));
         const int runs = __builtin_popcountll(nz & ~(nz << 1));
         const int est = dense ? (cold ? 47 * 64 : 22 * 64 + 50 * nd) : 14 + 40 * (nn - nd) + 65 * (nd - nd2) + 84 * nd2 + 11 * runs;
-        wantKeyed = est > (keyed ? 1700 : 1950);
+        const int flatCost = nd == 0 ? 64 * 13 : 64 * 15 + 70 * nd;             // by position: a rank >= 64 takes the row-spanning stub
+        const int interCost = 64 * 28;
+        if (nd <= 8 && flatCost <= interCost) wantFlat = est > flatCost + ((keyed && !inter) ? -10 : 190);
+        else wantKeyed = est > interCost + ((keyed && inter) ? -90 : 160);
+        flatDeep = nd > 0;
       }
     }
-    const bool wantInter = wantKeyed || (cold && !useOldCold);
-    if (keyed && !wantKeyed) { kzf_unpack(A0, B0); kzf_unpack(A1, B1); kzf_unpack(A2, B2); kzf_unpack(A3, B3); keyed = false; }
+    const bool wantInter = wantKeyed || (!wantFlat && cold && !useOldCold);
+    if (keyed && !(wantKeyed || wantFlat)) { kzf_unpack(A0, B0); kzf_unpack(A1, B1); kzf_unpack(A2, B2); kzf_unpack(A3, B3); keyed = false; }
     if (wantInter != inter) {                                             // (uniform) change of layout
       if (wantInter) { kz6_to_interleaved(Q0, Q1, Q2, Q3, lane); kz6_to_interleaved(P0, P1, P2, P3, lane); }
       else { kz6_from_interleaved(Q0, Q1, Q2, Q3, lane); kz6_from_interleaved(P0, P1, P2, P3, lane); }
       inter = wantInter;
     }
     const u32 f0 = (u32)__builtin_amdgcn_readfirstlane((int)Q0) & 0xFFu;   // the front symbol at the start of the row (32-bit forms; position 0 is lane 0 of Q0 in both layouts)
-    if (wantKeyed && !keyed) { kzf_pack(Q0, P0, s0); kzf_pack(Q1, P1, s0); kzf_pack(Q2, P2, s0); kzf_pack(Q3, P3, s0); keyed = true; }
+    if ((wantKeyed || wantFlat) && !keyed) { kzf_pack(Q0, P0, s0); kzf_pack(Q1, P1, s0); kzf_pack(Q2, P2, s0); kzf_pack(Q3, P3, s0); keyed = true; }
     if (keyed) {
       const u32 c2 = (((u32)row << 1) << 8) - 256u;                 // the step adds 512 first: ((2 i + 1) << 8) at step i
       const u32 h0 = 0x40000000u + (u32)row - 1u;                   // MTF: x.hi = 0x40000000 | i, counted up by the step
-      if (MODE == 2) { if (row + 64 <= (1 << 22)) { KZF_ROW(KZF_X_RANK) } else { KZF_ROW(KZF_X_RANK_HI) } }
-      else if (MODE == 1) { KZF_ROW(KZF_X_MTF) } else { KZF_ROW(KZF_X_TS) }
+      if (inter) {
+        if (MODE == 2) { if (row + 64 <= (1 << 22)) { KZF_ROW(KZF_X_RANK) } else { KZF_ROW(KZF_X_RANK_HI) } }
+        else if (MODE == 1) { KZF_ROW(KZF_X_MTF) } else { KZF_ROW(KZF_X_TS) }
+      } else {
+        if (flatDeep) {
+          if (MODE == 2) { if (row + 64 <= (1 << 22)) { KZD_ROWC(KZF_X_RANK) } else { KZD_ROWC(KZF_X_RANK_HI) } }
+          else if (MODE == 1) { KZD_ROWC(KZF_X_MTF) } else { KZD_ROWC(KZF_X_TS) }
+        } else {
+          if (MODE == 2) { if (row + 64 <= (1 << 22)) { KZD_ROW(KZF_X_RANK) } else { KZD_ROW(KZF_X_RANK_HI) } }
+          else if (MODE == 1) { KZD_ROW(KZF_X_MTF) } else { KZD_ROW(KZF_X_TS) }
+        }
+      }
       outv = ~outv;                                                 // (the keys hold 255 - symbol)
     } else if (dense) {
       if (!cold) {
