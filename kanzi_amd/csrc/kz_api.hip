@@ -973,16 +973,21 @@ static void overlap_plan(kz_ctx* ctx, Overlap& O, const std::vector<int32_t>& zl
     return;
   }
   for (auto& G : O.groups) {
-    int64_t maxZ = 0, pre = 0, cnt = 0;
-    for (size_t b = 0; b < G.in.size(); b++) if (G.in[b]) { maxZ = std::max<int64_t>(maxZ, zlen[b]); cnt++; pre += rawp[b] ? zlen[b] / 16 : zlen[b]; }
+    int64_t maxZ = 0, pre = 0, cnt = 0, raws = 0;
+    for (size_t b = 0; b < G.in.size(); b++) if (G.in[b]) { maxZ = std::max<int64_t>(maxZ, zlen[b]); cnt++; raws += rawp[b] ? 1 : 0; pre += rawp[b] ? zlen[b] / 16 : zlen[b]; }
     // round 6: a block whose ranks are nearly all non-zero and mostly >= 64 (ZRLT-coded length ~ its own: incompressible data)
-    // runs at ~64 ns per rank in the keyed rows of kz_sbrt_f64.h (blocks up to 8 MiB).  Measured in the bulk batch (two waves per
-    // SIMD, the other classes' waves and the BWT inverses beside it): such a class 347 ms, a class of skewed bytes (dense rows of the
-    // 32-bit forms) 461 ms = 115 ns x its ZRLT-coded length, the class of cheap blocks (three fifths of the batch) 312 ms = 1.65 x
-    // that product: the factor 1 + blocks / (2 x SIMDs' worth) below.
-    const bool keyed = ctx->sw.sbrtForm != 0 && blockSize <= (1 << 23) && maxZ >= (int64_t)blockSize - (blockSize >> 5);
+    // runs in the interleaved keyed rows of kz_sbrt_f64.h (blocks up to 8 MiB), rows without ranks >= 64 in the by-position keyed
+    // rows.  Measured in the bulk batch (two waves per SIMD, the other classes' waves and the BWT inverses beside them); the class
+    // of cheap blocks (three fifths of the batch) takes 1.65 x what its longest block suggests: the factor 1 + blocks / (2 x SIMDs'
+    // worth) below.  (Tried and measured slower: the large class cut in two at its median cost on six streams, 643 - 805 ms against
+    // 593; the longest chain first, 695 against 665.)
+    const bool keyedForms = ctx->sw.sbrtForm != 0 && blockSize <= (1 << 23);
+    const bool keyed = keyedForms && maxZ >= (int64_t)blockSize - (blockSize >> 5) && raws * 2 > cnt;   // incompressible (stored raw): ranks of every depth
     const double crowd = 1.0 + 0.55 * (double)cnt / (4.0 * (double)std::max(1, ctx->numCUs));
-    G.tRank = (keyed ? 72e-9 * (double)blockSize : 115e-9 * (double)maxZ) * crowd;
+    // (with the keyed rows: incompressible class 464 ms = 95 ns per byte of the block, skewed bytes 331 ms = at most 65 ns per byte,
+    // cheap blocks 232 ms = 86 ns per ZRLT-coded byte, each times the crowding factor)
+    if (!keyedForms) G.tRank = 115e-9 * (double)maxZ * crowd;
+    else G.tRank = (keyed ? 95e-9 * (double)blockSize : std::min(86e-9 * (double)maxZ, 65e-9 * (double)blockSize)) * crowd;
     G.tBwt = 40e-12 * (double)cnt * (double)blockSize;
     G.tPre = withPre ? 12e-12 * (double)pre : 0.0;
   }
