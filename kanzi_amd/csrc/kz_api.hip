@@ -886,11 +886,13 @@ static bool overlap_classify(const kz_ctx* ctx, int B, const std::vector<int32_t
   for (int c = 0; c < nClasses; c++) if (cnt[c] > 0) order[n++] = c;
   if (n < 2) return false;
   O.groups.resize(n);
-  // issue priority of the classes' RANK-inverse waves (s_setprio 3 / 1 / 0): the more expensive, the higher (every other
-  // assignment measured slower in round 5)
+  // issue priority of the classes' RANK-inverse waves (s_setprio 3 / 1 / 0).  Round 6: the class whose BWT inverse comes FIRST
+  // gets the highest one -- the main stream has nothing to do until that class's last RANK chain has ended, and the long chains of the
+  // other classes end under its BWT inverse anyway (bulk decode 595 -> 539 ms; with the 32-bit forms of round 5 the opposite order
+  // was the faster one: the incompressible class's chain was then the critical path)
   for (int g = 0; g < n; g++) {
     O.groups[g].in.assign(B, 0);
-    O.groups[g].prio = (g == n - 1) ? 2 : (g > 0 ? 1 : 0);
+    O.groups[g].prio = (g == n - 1) ? 2 : (g > 0 ? 1 : 0);          // (the wide schedule: overlap_plan re-assigns by the order of the BWT inverses)
   }
   for (int b = 0; b < B; b++) {
     if (cls[b] < 0) continue;
@@ -1004,6 +1006,8 @@ static void overlap_plan(kz_ctx* ctx, Overlap& O, const std::vector<int32_t>& zl
     if (tb < bestT - 1e-9) { bestT = tb; best = perm; O.bwtOrder = byEnd; }
   } while (std::next_permutation(perm.begin(), perm.end()));
   O.launchOrder = best;
+  if ((int)zlen.size() > 4 * ctx->numCUs)                           // (batches of one wave per SIMD or less: the longest chain keeps the highest priority)
+    for (size_t i = 0; i < O.bwtOrder.size(); i++) O.groups[O.bwtOrder[i]].prio = i == 0 ? 2 : (i == 1 ? 1 : 0);
   if (ctx->sw.traceSched) {
     fprintf(stderr, "[sched] plan %.0f ms: launch", bestT * 1e3);
     for (int g : O.launchOrder) fprintf(stderr, " %d(pre %.0f rank %.0f bwt %.0f)", g, O.groups[g].tPre * 1e3, O.groups[g].tRank * 1e3, O.groups[g].tBwt * 1e3);
