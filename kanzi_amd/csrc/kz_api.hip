@@ -1271,7 +1271,7 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
     // TEXT forward on the device (kz_text_fwd_gpu.hip) for the blocks it keeps after its statistics and finishes: they are rewritten
     // in their slots (hashes and Magic tags were taken from the original bytes above, on the same stream).  The host stages run on
     // the blocks it does not keep WHILE its walk runs, then on the few it kept and could not finish.
-    std::vector<int32_t> gpuDone(B, 0), textDeclined(B, -1), noHost(B, 0);
+    std::vector<int32_t> gpuDone(B, 0), textDeclined(B, -1), noHost(B, 0), utfDone(B, 0);
     std::vector<int> listOf(B, -1), listIdx(B, -1);                               // block -> (host pass, index in that pass's list)
     HostPre passP[2];
     if (textFwdGpu) {
@@ -1283,6 +1283,15 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
       // a block that is not text: TEXT declined it on the device and left its "dataType"; UTF (if the chain has it) looks at UNDEFINED
       // and UTF8 blocks only (UTFCodec.java:93-101), on the host, from that entry on; every other block is done with the host stages
       for (int b = 0; b < B; b++) if (textDeclined[b] >= 0 && (hp == 1 || (textDeclined[b] != KZ_DT_UNDEFINED && textDeclined[b] != KZ_DT_UTF8))) noHost[b] = 1;
+      // UTF forward on the device for the blocks TEXT declined as UTF-8 (kz_utf_fwd_gpu.hip; KZ_UTF_FWD_GPU=0: host stage): what it
+      // finishes or declines by the reference's rules needs no host stage
+      if (hp == 2 && ctx->sw.utfFwdGpu != 0) {
+        std::vector<int32_t> takeU(B, 0);
+        int nU = 0;
+        for (int b = 0; b < B; b++) if (take[b] && textDeclined[b] == KZ_DT_UTF8) { takeU[b] = 1; nU++; }
+        if (nU) { rc = kz_utf_fwd_gpu(ctx, bt, takeU, utfDone); if (rc) return rc; }
+        for (int b = 0; b < B; b++) if (utfDone[b]) noHost[b] = 1;
+      }
       kz_ctx::Stage& stg = ctx->tfIn;                                              // pinned staging for device input (not hsIn: ADVICE r5)
       auto host_pass = [&](int pass, const std::vector<int>& blocks, bool overlap) -> int {
         std::vector<const uint8_t*> ptrs(blocks.size());
@@ -1346,6 +1355,7 @@ int32_t kz_encode_blocks_pre(kz_ctx* ctx, uint64_t transformType, uint32_t entro
     for (int b = 0; b < B; b++) {
       h_mask[b] = 0;
       if (h_copy[b]) { bt.h_len[b] = lengths[b]; continue; }                     // (a pre-staged block of <= 15 bytes was left alone as well)
+      if (utfDone[b] == 1) { h_skip[b] = 0xFF & ~(1 << 6); dts[b] = KZ_DT_UTF8; continue; }   // UTF applied on the device (length set there); TEXT declined it
       if (gpuDone[b]) { h_skip[b] = 0xFF & ~(1 << 7); dts[b] = KZ_DT_TEXT; continue; }   // TEXT applied on the device (length set there: TextCodec.java:667); UTF declines a block tagged TEXT (UTFCodec.java:93-101)
       const HostPre* q = pre;
       int k = b;

@@ -14,8 +14,8 @@
 #include <thread>
 #include "../../include/kanzi_hip.h"
 
-enum KzKernelId { KID_ANS_ENC_CHUNK, KID_ANS_ENC_SCAN, KID_ANS_ENC_CONCAT, KID_ANS_DEC_INDEX, KID_ANS_DEC_CHUNK, KID_ANS_DEC_FIN, KID_MASK_LEN, KID_PASSTHROUGH, KID_FRAME_PREPARE, KID_COPY_BYTES, KID_FRAME_DECIDE, KID_FRAME_HEADER, KID_FRAME_PARSE, KID_COPY_PAYLOAD, KID_BWT_INIT, KID_RADIX_HIST, KID_RADIX_SCAN, KID_RADIX_SCATTER, KID_SEG_REDUCE, KID_SEG_SCAN, KID_SEG_APPLY, KID_LIVE_EMIT, KID_BWT_EMIT, KID_BWTI_PARSE, KID_BWTI_HIST, KID_BWTI_SCAN, KID_BWTI_SCATTER, KID_BWTI_WALK1, KID_BWTI_RESOLVE, KID_BWTI_COPY, KID_BWTI_LITERAL, KID_BWTI_FIN, KID_SBRT_LAST2, KID_SBRT_SCAN, KID_SBRT_REPLAY, KID_COPY_LEN, KID_SBRT_INVERSE, KID_ZRLT_F1, KID_ZRLT_F2, KID_ZRLT_F3, KID_ZRLT_FFIN, KID_ZRLT_I1, KID_ZRLT_I2, KID_ZRLT_I3, KID_ZRLT_IFIN, KID_HUF_ENC_CHUNK, KID_HUF_DEC_INDEX, KID_HUF_DEC_CHUNK, KID_HUF_DEC_FIN, KID_FPAQ_ENC, KID_FPAQ_PACK, KID_FPAQ_DEC, KID_SRT_HIST, KID_SRT_PREP, KID_SRT_SCATTER, KID_SRT_INV, KID_LZ_FWD, KID_LZ_INV, KID_XXHASH, KID_BLOCK_MAGIC, KID_MM_ANALYZE, KID_MM_EMIT, KID_MM_CHECK, KID_MM_INV, KID_ALIAS_ANALYZE, KID_ALIAS_HIST1, KID_ALIAS_SELECT, KID_ALIAS_EMIT, KID_ALIAS_INV, KID_SKIP_DECIDE, KID_MSD_HIST, KID_MSD_SCAN, KID_MSD_SCATTER, KID_BUCKET_SORT, KID_BUCKET_COUNT, KID_BUCKET_COUNT_S, KID_TR_HIST16, KID_TR_ASSIGN, KID_TR_COUNT, KID_TR_SCATTER, KID_TR_SORT, KID_TEXT_INV, KID_UTF_INV, KID_TEXT_FWD, KID_TEXT_WALK, KID_COUNT };
-#define KZ_KERNEL_NAMES { "k_ans_enc_chunk", "k_ans_enc_scan", "k_ans_enc_concat", "k_ans_dec_index", "k_ans_dec_chunk", "k_ans_dec_fin", "k_mask_len", "k_passthrough", "k_frame_prepare", "k_copy_bytes", "k_frame_decide", "k_frame_header", "k_frame_parse", "k_copy_payload", "k_bwt_init", "k_radix_hist", "k_radix_scan", "k_radix_scatter", "k_seg_reduce", "k_seg_scan", "k_seg_apply", "k_live_emit", "k_bwt_emit", "k_bwti_parse", "k_bwti_hist", "k_bwti_scan", "k_bwti_scatter", "k_bwti_walk1", "k_bwti_resolve", "k_bwti_copy", "k_bwti_literal", "k_bwti_fin", "k_sbrt_last2", "k_sbrt_scan", "k_sbrt_replay", "k_copy_len", "k_sbrt_inverse", "k_zrlt_f1", "k_zrlt_f2", "k_zrlt_f3", "k_zrlt_ffin", "k_zrlt_i1", "k_zrlt_i2", "k_zrlt_i3", "k_zrlt_ifin", "k_huf_enc_chunk", "k_huf_dec_index", "k_huf_dec_chunk", "k_huf_dec_fin", "k_fpaq_enc", "k_fpaq_pack", "k_fpaq_dec", "k_srt_hist", "k_srt_prep", "k_srt_scatter", "k_srt_inv", "k_lz_fwd", "k_lz_inv", "k_xxhash", "k_block_magic", "k_mm_analyze", "k_mm_emit", "k_mm_check", "k_mm_inv", "k_alias_analyze", "k_alias_hist1", "k_alias_select", "k_alias_emit", "k_alias_inv", "k_skip_decide", "k_msd_hist", "k_msd_scan", "k_msd_scatter", "k_bucket_sort", "k_bucket_count", "k_bucket_count_s", "k_tr_hist16", "k_tr_assign", "k_tr_count", "k_tr_scatter", "k_tr_sort", "k_text_inv", "k_utf_inv", "k_text_fwd", "k_text_walk" }
+enum KzKernelId { KID_ANS_ENC_CHUNK, KID_ANS_ENC_SCAN, KID_ANS_ENC_CONCAT, KID_ANS_DEC_INDEX, KID_ANS_DEC_CHUNK, KID_ANS_DEC_FIN, KID_MASK_LEN, KID_PASSTHROUGH, KID_FRAME_PREPARE, KID_COPY_BYTES, KID_FRAME_DECIDE, KID_FRAME_HEADER, KID_FRAME_PARSE, KID_COPY_PAYLOAD, KID_BWT_INIT, KID_RADIX_HIST, KID_RADIX_SCAN, KID_RADIX_SCATTER, KID_SEG_REDUCE, KID_SEG_SCAN, KID_SEG_APPLY, KID_LIVE_EMIT, KID_BWT_EMIT, KID_BWTI_PARSE, KID_BWTI_HIST, KID_BWTI_SCAN, KID_BWTI_SCATTER, KID_BWTI_WALK1, KID_BWTI_RESOLVE, KID_BWTI_COPY, KID_BWTI_LITERAL, KID_BWTI_FIN, KID_SBRT_LAST2, KID_SBRT_SCAN, KID_SBRT_REPLAY, KID_COPY_LEN, KID_SBRT_INVERSE, KID_ZRLT_F1, KID_ZRLT_F2, KID_ZRLT_F3, KID_ZRLT_FFIN, KID_ZRLT_I1, KID_ZRLT_I2, KID_ZRLT_I3, KID_ZRLT_IFIN, KID_HUF_ENC_CHUNK, KID_HUF_DEC_INDEX, KID_HUF_DEC_CHUNK, KID_HUF_DEC_FIN, KID_FPAQ_ENC, KID_FPAQ_PACK, KID_FPAQ_DEC, KID_SRT_HIST, KID_SRT_PREP, KID_SRT_SCATTER, KID_SRT_INV, KID_LZ_FWD, KID_LZ_INV, KID_XXHASH, KID_BLOCK_MAGIC, KID_MM_ANALYZE, KID_MM_EMIT, KID_MM_CHECK, KID_MM_INV, KID_ALIAS_ANALYZE, KID_ALIAS_HIST1, KID_ALIAS_SELECT, KID_ALIAS_EMIT, KID_ALIAS_INV, KID_SKIP_DECIDE, KID_MSD_HIST, KID_MSD_SCAN, KID_MSD_SCATTER, KID_BUCKET_SORT, KID_BUCKET_COUNT, KID_BUCKET_COUNT_S, KID_TR_HIST16, KID_TR_ASSIGN, KID_TR_COUNT, KID_TR_SCATTER, KID_TR_SORT, KID_TEXT_INV, KID_UTF_INV, KID_TEXT_FWD, KID_TEXT_WALK, KID_UTF_FWD, KID_COUNT };
+#define KZ_KERNEL_NAMES { "k_ans_enc_chunk", "k_ans_enc_scan", "k_ans_enc_concat", "k_ans_dec_index", "k_ans_dec_chunk", "k_ans_dec_fin", "k_mask_len", "k_passthrough", "k_frame_prepare", "k_copy_bytes", "k_frame_decide", "k_frame_header", "k_frame_parse", "k_copy_payload", "k_bwt_init", "k_radix_hist", "k_radix_scan", "k_radix_scatter", "k_seg_reduce", "k_seg_scan", "k_seg_apply", "k_live_emit", "k_bwt_emit", "k_bwti_parse", "k_bwti_hist", "k_bwti_scan", "k_bwti_scatter", "k_bwti_walk1", "k_bwti_resolve", "k_bwti_copy", "k_bwti_literal", "k_bwti_fin", "k_sbrt_last2", "k_sbrt_scan", "k_sbrt_replay", "k_copy_len", "k_sbrt_inverse", "k_zrlt_f1", "k_zrlt_f2", "k_zrlt_f3", "k_zrlt_ffin", "k_zrlt_i1", "k_zrlt_i2", "k_zrlt_i3", "k_zrlt_ifin", "k_huf_enc_chunk", "k_huf_dec_index", "k_huf_dec_chunk", "k_huf_dec_fin", "k_fpaq_enc", "k_fpaq_pack", "k_fpaq_dec", "k_srt_hist", "k_srt_prep", "k_srt_scatter", "k_srt_inv", "k_lz_fwd", "k_lz_inv", "k_xxhash", "k_block_magic", "k_mm_analyze", "k_mm_emit", "k_mm_check", "k_mm_inv", "k_alias_analyze", "k_alias_hist1", "k_alias_select", "k_alias_emit", "k_alias_inv", "k_skip_decide", "k_msd_hist", "k_msd_scan", "k_msd_scatter", "k_bucket_sort", "k_bucket_count", "k_bucket_count_s", "k_tr_hist16", "k_tr_assign", "k_tr_count", "k_tr_scatter", "k_tr_sort", "k_text_inv", "k_utf_inv", "k_text_fwd", "k_text_walk", "k_utf_fwd" }
 // Environment switches (diagnostics, A/B runs, the tests' forced schedules; none is needed for normal use).  Read ONCE, when the
 // context is created (kz_switches_read, kz_api.hip); kz_ctx_reload_switches re-reads them for a live context (tests, A/B tools).
 // Nothing on a call's path calls getenv.
@@ -215,6 +215,8 @@ int kz_host_transform_inverse(int type, int blockSize, const uint8_t* src, int n
 size_t kz_text_gpu_scratch_per_block(int blockSize);
 // kz_text_fwd_gpu.hip: the TEXT forward (TextCodec2) of blocks that sit in HBM (done[b] = 1 for the blocks it finished; the others: host stage)
 size_t kz_text_fwd_gpu_scratch(int B, int blockSize, int maxLen);
+// kz_utf_fwd_gpu.hip: UTFCodec.forward of the blocks TEXT declined with "dataType" UTF8 (done[b]: 1 applied, 2 declined by the reference's rules, 0 host stage)
+int kz_utf_fwd_gpu(kz_ctx* ctx, kz_batch& bt, const std::vector<int32_t>& take, std::vector<int32_t>& done);
 bool kz_text_fwd_gpu_applies(kz_ctx* ctx, uint64_t transformType, uint32_t entropyType, int nBlocks);   // kz_api.hip
 struct TextFwdJob;
 TextFwdJob* kz_text_fwd_gpu_new();

@@ -670,6 +670,10 @@ int utf_forward(int* dataType, const u8* src, int n, u8* dst, int dstCap, int* p
     seenMap.at((uint32_t)key) = (uint32_t)((r < 128) ? r : (0x10080 | ((r << 1) & 0xFF00) | (r & 0x7F)));                        // two-byte alias + its size in bits 16..
   }
   if (estimate >= maxTarget) return 0;
+  // the map is not part of `estimate`: map + aliases can pass n + 8192 bytes (small blocks, thousands of distinct code points).  Such
+  // an output is declined at the end in any case (:214): declined here, before a byte of it is written (the reference with buffers of
+  // exactly getMaxEncodedLength bytes runs over its array instead: INTEGRATION.md 4)
+  if ((int64_t)at + start + (estimate - 10) + 1 >= (int64_t)maxTarget) return 0;
   for (int i = 0; i < start; i++) dst[at++] = src[i];
   int i = start;
   {

@@ -148,6 +148,13 @@ int kzo_utf_forward(int* dataType, const uint8_t* src, int count, uint8_t* dst, 
     aliasMap[s] = (i < 128) ? i : (0x10080 | ((i << 1) & 0xFF00) | (i & 0x7F));
   }
   if (estimate >= maxTarget) { free(aliasMap); free(symb); return 0; }
+  /* The map (3 n bytes) is not part of `estimate`: map + aliases can exceed count + 8192 bytes (getMaxEncodedLength, the size the
+     buffers are given, Sequence.java:82-90) for small blocks with thousands of distinct code points.  The reference then either
+     runs over its array (ArrayIndexOutOfBoundsException: the block fails) or, when the array was sized by an earlier, larger
+     block, finishes and declines at the end (dstIdx >= maxTarget, :214).  Restated as the second outcome -- decline -- decided
+     before anything is written: the output is at least map + start + aliases + 1 tail byte.  (The HIP path does the same;
+     INTEGRATION.md 4.) */
+  if ((long long)dstIdx + start + (estimate - 10) + 1 >= (long long)maxTarget) { free(aliasMap); free(symb); return 0; }
   for (int i = 0; i < start; i++) dst[dstIdx++] = src[srcIdx + i];
   srcIdx += start;
   while (srcIdx < srcEnd) {

@@ -1487,12 +1487,13 @@ def test_bwt_forward_trie_rounds_match_oracle(ctx, monkeypatch, switch):
 
 # ---- round 5: the differential fuzz tools of round 4 as a driver-run test ----
 @pytest.mark.gpu
-@pytest.mark.parametrize("tool,seconds,seed", [("bwt_fuzz", 7, 5001), ("zrlt_fuzz", 6, 5002), ("tightcap_fuzz", 6, 5003), ("entropy_count_fuzz", 6, 5004), ("text_fwd_gpu_fuzz", 8, 5005)])
+@pytest.mark.parametrize("tool,seconds,seed", [("bwt_fuzz", 7, 5001), ("zrlt_fuzz", 6, 5002), ("tightcap_fuzz", 6, 5003), ("entropy_count_fuzz", 6, 5004), ("text_fwd_gpu_fuzz", 8, 5005), ("utf_fwd_gpu_fuzz", 10, 5006)])
 def test_differential_fuzz_tools_bounded(tool, seconds, seed):
     """tools/bwt_fuzz.py (forward BWT on structured and degenerate strings, ragged batches), tools/zrlt_fuzz.py (row / wave / tile
     seams of the ZRLT kernels), tools/tightcap_fuzz.py (every inverse transform with the buffer cut to the byte) and
     tools/entropy_count_fuzz.py (decoders asked for the wrong count or given cut bits), tools/text_fwd_gpu_fuzz.py (the device TEXT
-    forward on generated words around its rules, small blocks): a fixed seed and a few seconds each, so the
+    forward on generated words around its rules, small blocks), tools/utf_fwd_gpu_fuzz.py (the device UTF forward on UTF-8 of
+    two- and three-unit code points with mutations the pair statistics do not see): a fixed seed and a few seconds each, so the
     first cases of every campaign run wherever the GPU suite runs.  Each tool compares HIP with the oracle case by case and exits
     non-zero on the first campaign with a difference."""
     import subprocess
@@ -1612,6 +1613,12 @@ def _text_fwd_blocks(bs):
     pick = lambda alphabet: bytes(np.frombuffer(alphabet, dtype=np.uint8)[rng.integers(0, len(alphabet), n)])
     bad_utf = bytearray(textgen.utf8(n, 3)); bad_utf[n // 2] = 0xC0                     # a byte no UTF-8 text holds
     cut_utf = bytearray(textgen.utf8(n, 4)); cut_utf[n // 3] = 0x41                     # a lead byte followed by a letter
+    # UTF-8 without four-unit code points (the device UTF forward takes these: kz_utf_fwd_gpu.hip): Cyrillic + CJK, with a byte order
+    # mark, cut in front (continuation bytes first) and behind (a code point reaching into the four tail bytes), few and many symbols
+    cps3 = [0x400 + i for i in range(220)] + [0x4E00 + 5 * i for i in range(900)] + list(range(0x20, 0x7F)) * 3 + [0xA0, 0x7FF, 0x800, 0xFFFD]
+    u3 = lambda m, k: "".join(chr(cps3[int(i)]) for i in rng.integers(0, m, k)).encode("utf-8")
+    blocks += [u3(len(cps3), n)[:n], b"\xef\xbb\xbf" + u3(200, n)[:n - 3], u3(len(cps3), n)[1:n + 1], u3(300, n)[2:n - 1], u3(40, n)[:n],
+               (u3(len(cps3), n // 2) + "\u0436".encode("utf-8") * (n // 4))[:n]]
     blocks += [pick(b"acgtn"), pick(b"0123456789+-*/=,.:; "), pick(b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/"),
                pick(b"abc"), bytes(textgen.utf8(n, 5, bom=True)), bytes(bad_utf), bytes(cut_utf), bytes(textgen.utf8(n, 6))[1:],
                pick(bytes(range(0x80, 0xC0)) + b"  etaoin"), bytes(rng.integers(0, 256, n, dtype=np.uint8))]
@@ -1652,6 +1659,9 @@ def test_text_forward_on_the_device(ctx, chain, ent, monkeypatch, capfd):
         assert took and sum(fin) >= sum(took) // 2, err[-400:]
     else:
         assert not took
+    if "UTF" in chain and ent != "FPAQ":                              # round 6: the UTF forward of the blocks TEXT declined as UTF-8 ran on the device
+        u = [l.split() for l in err.splitlines() if l.startswith("[utffwd] took")]
+        assert u and sum(int(x[2]) for x in u) >= 6 and sum(int(x[5].rstrip(",")) for x in u) >= 4, err[-400:]
 
 
 @pytest.mark.gpu

@@ -123,3 +123,19 @@ def test_tpaqx_is_refused_and_utf_alias_map_is_reused(built):
     assert not kz.host_stage_forward("UTF", c["random"], "ANS0")[0]       # declined half way through its key counting
     assert kz.host_stage_forward("UTF", c["utf8_bom"], "ANS0")[0]
     assert kz.host_stage_forward("UTF", c["utf8"], "ANS0") == first
+
+
+def test_utf_forward_declines_an_output_that_cannot_fit_before_writing_it():
+    """Round 6: UTFCodec's size estimate (UTFCodec.java:185-196) leaves the map out, so a small block with thousands of distinct code
+    points gets past it with map + aliases larger than count + 8192 bytes -- the reference then runs over its array or, with a larger
+    array, declines at the end (:214).  The oracle and the host stage decline BEFORE writing (they used to write past the buffer);
+    both agree, with and without UTFCodec's own validation, and the bytes behind the given capacity stay untouched."""
+    rng = np.random.default_rng(61)
+    for n, span in ((35307, 20000), (16384, 12000), (65536, 20000), (20000, 6000)):
+        cps = rng.integers(0x4E00, 0x4E00 + span, n // 3 + 8)
+        d = "".join(chr(int(c)) for c in cps).encode("utf-8")[:n]
+        for dt in (oracle.DT["UTF8"], oracle.DT["UNDEFINED"]):
+            want = oracle.transform_forward("UTF", d, data_type=dt)
+            got = kz.host_stage_forward("UTF", d, "NONE", 1 << 20, data_type=dt)
+            assert (got[0], got[2]) == (want[0], want[2]), (n, span, dt)
+            assert not got[0] or got[1] == want[1]
