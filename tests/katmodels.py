@@ -2925,3 +2925,145 @@ def huffman_decode(data, nbits, count):
             return start, bytes(out), pos
         start = end
     return count, bytes(out), pos
+
+
+def text_inverse(data, block_size, static_dict, dst_cap):
+    """TextCodec.inverse :512-534 over TextCodec1.inverse :876-1031 (first byte without MASK_TEXT_CODEC) or TextCodec2.inverse
+    :1410-1603 (with it; bitstream version >= 6 word indexes), written from the Java.  dst_cap = dst.length = output.length (the
+    dictionary's first size comes from it: reset(output.length) :886 / :1420).  Returns (ok, bytes); a read outside the coded block
+    or outside the dictionary (in Java: stale buffer bytes or an ArrayIndexOutOfBoundsException, depending on the arrays' real
+    lengths) raises JavaException."""
+    src = bytes(data)
+    count = len(src)
+    if count == 0:
+        return True, b""
+    if count > (1 << 30):                                                        # MAX_BLOCK_SIZE, no minimum :520-521
+        return False, b""
+    variant = 1 if (src[0] & _T_MASK_TEXT_CODEC) == 0 else 2                      # :527-530 (bsVersion 7)
+    m = _TextCodecModel(variant, block_size, static_dict)
+    m.reset(dst_cap)
+    dst = bytearray(dst_cap + 4)
+    src_end, dst_end = count, dst_cap
+
+    def rd(i):                                                                   # src[i] inside the coded block only
+        if i >= src_end:
+            raise JavaException("read behind the coded block")
+        return src[i]
+
+    src_idx, dst_idx = 1, 0
+    is_crlf = (src[0] & _T_MASK_CRLF) != 0
+    if src_idx >= src_end:                                                       # a one-byte block: src[srcIdx] of :893 / :1429 reads the (longer) array's
+        return True, b""                                                         # next byte, only for delimAnchor; the loop does not run: true, no output
+    delim_anchor = src_idx - 1 if _t_is_text(src[src_idx]) else src_idx
+    words = m.static_size
+    word_run = False
+    res = True
+    while src_idx < src_end and dst_idx < dst_end:
+        cur = src[src_idx]
+        if _t_is_text(cur):
+            dst[dst_idx] = cur
+            src_idx += 1
+            dst_idx += 1
+            continue
+        if src_idx > delim_anchor + 3 and _T_DELIMS[cur]:                        # a word of more than two letters ended: learn it like the encoder
+            length = src_idx - delim_anchor - 1
+            if length <= _T_MAX_WORD_LENGTH:
+                h1 = _T_HASH1
+                for i in range(delim_anchor + 1, src_idx):
+                    h1 = _i32(_i32(h1 * _T_HASH1) ^ _i32(_sb(src[i]) * _T_HASH2))
+                e = None
+                e1 = m.dict_map.get(h1 & m.hash_mask)
+                if e1 is not None and e1.hash == h1 and (e1.data >> 24) == length:
+                    if src[delim_anchor + 2:delim_anchor + 1 + length] == bytes(e1.buf[e1.pos + 1:e1.pos + length]):
+                        e = e1
+                if e is None:
+                    if (length > 3 or words < _T_THRESHOLD2) and e1 is None:
+                        e = m.dict_list[words]
+                        if (e.data & _T_MASK_LENGTH) >= m.static_size:
+                            if m.dict_map.get(e.hash & m.hash_mask) is not None:
+                                m.dict_map[e.hash & m.hash_mask] = None
+                            e.buf, e.pos, e.hash, e.data = src, delim_anchor + 1, h1, (length << 24) | words
+                        m.dict_map[h1 & m.hash_mask] = e
+                        words += 1
+                        if words >= m.dict_size:
+                            if not m.expand():
+                                words = m.static_size
+        src_idx += 1
+        flip = 0
+        is_ref = (cur == _T_ESC1 or cur == _T_ESC2) if variant == 1 else (cur & 0x80) != 0
+        if is_ref:
+            if variant == 1:                                                     # :945-963: varint 5 + 7 + 7 bits
+                idx = rd(src_idx)
+                src_idx += 1
+                if idx >= 128:
+                    idx &= 0x7F
+                    idx2 = _sb(rd(src_idx))
+                    src_idx += 1
+                    if idx2 & 0x80:
+                        idx = ((idx & 0x1F) << 7) | (idx2 & 0x7F)
+                        idx2 = rd(src_idx) & 0x7F
+                        src_idx += 1
+                    idx = (idx << 7) | idx2                                      # (idx2 < 0 here would have taken the branch above)
+                    if idx >= m.dict_size:
+                        res = False
+                        break
+                flip = 0x20 if cur == _T_ESC2 else 0
+            else:                                                                # :1503-1540
+                if cur == 0x80:                                                  # MASK_FLIP_CASE
+                    flip = 0x20
+                    cur = rd(src_idx)
+                    src_idx += 1
+                idx = cur & 0x7F
+                if idx >= 64:
+                    if idx >= 112:
+                        idx = ((idx & 0x0F) << 16) | (rd(src_idx) << 8) | rd(src_idx + 1)
+                        src_idx += 2
+                    else:
+                        idx = ((idx & 0x1F) << 8) | rd(src_idx)
+                        src_idx += 1
+                    if idx > m.dict_size:
+                        res = False
+                        break
+                elif idx == 0:
+                    res = False
+                    break
+                idx -= 1
+            if idx < 0 or idx >= m.dict_size:
+                raise JavaException("dictList[%d]" % idx)
+            e = m.dict_list[idx]
+            length = (e.data >> 24) & 0xFF
+            if word_run and length > 1:
+                if dst_idx >= len(dst):
+                    raise JavaException("dst")
+                dst[dst_idx] = 0x20
+                dst_idx += 1
+            if e.pos < 0 or dst_idx + length >= dst_end:
+                res = False
+                break
+            dst[dst_idx] = e.buf[e.pos] ^ flip
+            dst_idx += 1
+            if length > 1:
+                dst[dst_idx:dst_idx + length - 1] = e.buf[e.pos + 1:e.pos + length]
+                dst_idx += length - 1
+                word_run = True
+                delim_anchor = src_idx
+            else:
+                word_run = False
+                delim_anchor = src_idx - 1
+        else:
+            if variant == 2 and cur == _T_ESC1:                                  # an escaped byte :1580-1581
+                dst[dst_idx] = rd(src_idx)
+                dst_idx += 1
+                src_idx += 1
+            else:
+                if is_crlf and cur == _T_LF:
+                    dst[dst_idx] = _T_CR
+                    dst_idx += 1
+                    if dst_idx >= dst_end:
+                        res = False
+                        break
+                dst[dst_idx] = cur
+                dst_idx += 1
+            word_run = False
+            delim_anchor = src_idx - 1
+    return (res and src_idx == src_end), bytes(dst[:dst_idx])
