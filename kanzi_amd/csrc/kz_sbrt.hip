@@ -112,8 +112,8 @@ typedef u64 kz_u64x8 __attribute__((ext_vector_type(8)));
     K[fs] = (lane == (int)((sym) & 63u)) ? (((u64)fq << 32) | (u64)(pl + 256u)) : ok; }
 
 template <int MODE>
-__global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
-                                                     const int32_t* __restrict__ d_len, const int2* __restrict__ tab, int T) {
+__device__ __forceinline__ void sbrt_replay_by_symbol(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                                                      const int32_t* __restrict__ d_len, const int2* __restrict__ tab, int T) {
   const int b = blockIdx.y, t = blockIdx.x;
   const int n = d_len[b];
   const int start = t * SB_TS;
@@ -175,6 +175,155 @@ __global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, 
     }
     if ((R >> (cnt - 1)) & 1ULL) KZ_SBRT_FIX_RUN(cp, row + cnt - 1)    // the row ends inside a skipped stretch
     if (lane < cnt) d[row + lane] = (u8)outv;
+    cur = nxt;
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_sbrt_replay(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                                                     const int32_t* __restrict__ d_len, const int2* __restrict__ tab, int T) {
+  sbrt_replay_by_symbol<MODE>(src, dst, stride, d_len, tab, T);
+}
+
+// ---- forward 3/3, round 6: the same replay with the list BY POSITION on 64-bit keys (kz_sbrt_f64.h: hi = 0x40000000 | q,
+// lo = p << 9 | touched << 8 | 255 - symbol; register pair k = positions 64 k .. 64 k + 63).  The rank of a symbol IS its position:
+// one byte compare + ballot finds it (row 0 first: after a BWT most symbols sit there), and the update is the inverse's step -- the
+// entry takes its new key x and every position above it takes max(min(x, left neighbour), own): no four 64-bit compares + bit
+// counts per symbol, no indexed register file.  ~28 instructions per ranked symbol against ~45.  The tile's first list comes from
+// the symbols' last two occurrences (k_sbrt_last2 / k_sbrt_scan) sorted by key: 256 keys ranked against each other once per 8 KiB.
+// Blocks up to 2^23 bytes (p < 2^23); MODE 1 MTF, 2 RANK, 3 TIMESTAMP (SRT's variant, mode 4, keeps k_sbrt_replay).
+__device__ __forceinline__ u64 kzr_min(u64 a, u64 b) { u64 r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ u64 kzr_max(u64 a, u64 b) { u64 r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// the left neighbour's key; lane 0 receives `first`
+__device__ __forceinline__ u64 kzr_shr(u64 v, u64 first) {
+  const u32 lo = (u32)__builtin_amdgcn_update_dpp((int)(u32)first, (int)(u32)v, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+  const u32 hi = (u32)__builtin_amdgcn_update_dpp((int)(u32)(first >> 32), (int)(u32)(v >> 32), 0x138, 0xF, 0xF, false);
+  return ((u64)hi << 32) | lo;
+}
+template <int MODE>
+__device__ __forceinline__ u64 kzr_key(u32 i, u32 p, u32 sym255) {     // the key of a symbol accessed at i whose last access was p
+  const u32 q = (MODE == 2) ? ((i + p) >> 1) : ((MODE == 1) ? i : p);
+  return ((u64)(0x40000000u | q) << 32) | (u64)((i << 9) | 0x100u | sym255);
+}
+#define KZR_FIX_RUN(plv)                                                                        \
+  { const u32 pl = (u32)(plv), pp = pl - 1u;                                                   \
+    const u32 fq = (MODE == 2) ? ((pl + pp) >> 1) : ((MODE == 1) ? pl : pp);                   \
+    const u64 nk = ((u64)(0x40000000u | fq) << 32) | (u64)((pl << 9) | 0x100u | ((u32)R0 & 0xFFu)); \
+    R0 = (lane == 0) ? nk : R0; }
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_sbrt_replay_keyed(const u8* __restrict__ src, u8* __restrict__ dst, int64_t stride,
+                                                           const int32_t* __restrict__ d_len, const int2* __restrict__ tab, int T) {
+  const int b = blockIdx.y, t = blockIdx.x;
+  const int n = d_len[b];
+  const int start = t * SB_TS;
+  if (start >= n) return;
+  const int end = min(n, start + SB_TS);
+  const u8* s = src + (int64_t)b * stride;
+  u8* d = dst + (int64_t)b * stride;
+  const int lane = kz_lane();
+  const int2* pre = tab + ((int64_t)b * T + t) * 256;
+  __shared__ u64 sk[256];
+  {
+    // Tiles of many different bytes (incompressible data: three ranks of four lie beyond position 63, where this form pays a
+    // row-spanning step of ~60 instructions) take the by-symbol replay, whose rank costs the same at every depth: the distinct
+    // byte values among the tile's first 256 bytes decide (uniform bytes ~160, text and skewed bytes under 70).
+    u32* flags = (u32*)sk;
+#pragma unroll
+    for (int k = 0; k < 4; k++) flags[64 * k + lane] = 0;
+    __syncthreads();
+    for (int k = 0; k < 4; k++) { const int i = start + 64 * k + lane; if (i < end) flags[s[i]] = 1; }
+    __syncthreads();
+    int distinct = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) distinct += __builtin_popcountll(kz_ballot(flags[64 * k + lane] != 0));
+    __syncthreads();
+    if (distinct > 96) { sbrt_replay_by_symbol<MODE>(src, dst, stride, d_len, tab, T); return; }
+  }
+  // keys by symbol (symbol = lane + 64 k), then each key's rank among the 256 = its position in the list
+  u64 K[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int2 v = pre[64 * k + lane];
+    const u32 sym255 = 255u - (u32)(64 * k + lane);
+    if (v.x < 0) K[k] = ((u64)0x40000000u << 32) | sym255;                                       // never accessed: q = p = 0, by ascending symbol
+    else {
+      const u32 a1 = (u32)v.x, pp = v.y < 0 ? 0u : (u32)v.y;
+      const u32 q = (MODE == 2) ? ((a1 + pp) >> 1) : ((MODE == 1) ? a1 : pp);
+      K[k] = ((u64)(0x40000000u | q) << 32) | (u64)((a1 << 9) | 0x100u | sym255);
+    }
+    sk[64 * k + lane] = K[k];
+  }
+  __syncthreads();
+  u32 rk[4] = {0, 0, 0, 0};
+  for (int j = 0; j < 256; j++) {
+    const u64 kj = sk[j];                                                                        // (uniform address: a broadcast read)
+#pragma unroll
+    for (int k = 0; k < 4; k++) rk[k] += kj > K[k] ? 1u : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++) sk[rk[k]] = K[k];
+  __syncthreads();
+  u64 R0 = sk[lane], R1 = sk[64 + lane], R2 = sk[128 + lane], R3 = sk[192 + lane];
+  const u64 INF = 0x7FF0000000000000ULL;
+  // bytes before the tile (run detection across the tile boundary)
+  u32 cp = (start >= 1) ? (u32)s[start - 1] : 0x100u;
+  uint64_t carryE = (start >= 2 && s[start - 1] == s[start - 2]) ? 1ULL : 0ULL;
+  u32 cur = (start + lane < end) ? (u32)s[start + lane] : 0u;
+  for (int row = start; row < end; row += 64) {
+    const int cnt = min(64, end - row);
+    const int nrow = row + 64;
+    const u32 nxt = (nrow + lane < end) ? (u32)s[nrow + lane] : 0u;
+    u32 prevb = (u32)__builtin_amdgcn_update_dpp(0, (int)cur, 0x138, 0xF, 0xF, true);
+    if (lane == 0) prevb = cp;
+    const uint64_t valid = (cnt == 64) ? ~0ULL : ((1ULL << cnt) - 1ULL);
+    const uint64_t E = kz_ballot(cur == prevb) & valid;
+    const uint64_t R = E & ((E << 1) | carryE);
+    carryE = E >> 63;
+    uint64_t N = valid & ~R;
+    uint64_t F = N & (R << 1);                                        // ranked positions right behind a skipped stretch: repair the front key first
+    int jf;
+    asm("s_ff1_i32_b64 %0, %1" : "=s"(jf) : "s"(F));
+    u32 outv = 0;
+    while (N) {
+      const int j = (int)__builtin_ctzll(N);
+      asm("s_bitset0_b64 %0, %1" : "+s"(N) : "s"(j));
+      if (__builtin_expect(j == jf, 0)) {
+        KZR_FIX_RUN(row + j - 1)
+        asm("s_bitset0_b64 %0, %1" : "+s"(F) : "s"(j));
+        asm("s_ff1_i32_b64 %0, %1" : "=s"(jf) : "s"(F));
+      }
+      const u32 c = (u32)__builtin_amdgcn_readlane((int)cur, j);
+      const u32 tb = 255u - c;
+      const u32 iv = (u32)(row + j);
+      const uint64_t m0 = kz_ballot(((u32)R0 & 0xFFu) == tb);
+      u32 r;
+      if (__builtin_expect(m0 != 0, 1)) {                             // in the first 64 positions: only pair 0 moves
+        r = (u32)__builtin_ctzll(m0);
+        const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)R0, (int)r);
+        const u64 x = kzr_key<MODE>(iv, lo >> 9, tb);
+        const u64 t0 = kzr_min(x, kzr_shr(R0, INF));
+        if ((u32)lane <= r) R0 = kzr_max(t0, R0);
+      } else {
+        const uint64_t m1 = kz_ballot(((u32)R1 & 0xFFu) == tb), m2 = kz_ballot(((u32)R2 & 0xFFu) == tb), m3 = kz_ballot(((u32)R3 & 0xFFu) == tb);
+        u32 lo;
+        if (m1) { r = 64u + (u32)__builtin_ctzll(m1); lo = (u32)__builtin_amdgcn_readlane((int)(u32)R1, (int)(r & 63u)); }
+        else if (m2) { r = 128u + (u32)__builtin_ctzll(m2); lo = (u32)__builtin_amdgcn_readlane((int)(u32)R2, (int)(r & 63u)); }
+        else { r = 192u + (u32)__builtin_ctzll(m3); lo = (u32)__builtin_amdgcn_readlane((int)(u32)R3, (int)(r & 63u)); }
+        const u64 x = kzr_key<MODE>(iv, lo >> 9, tb);
+        const u64 c0 = kz_readlane64(R0, 63), c1 = kz_readlane64(R1, 63), c2 = kz_readlane64(R2, 63);
+        const u64 t0 = kzr_min(x, kzr_shr(R0, INF)), t1 = kzr_min(x, kzr_shr(R1, c0)), t2 = kzr_min(x, kzr_shr(R2, c1)), t3 = kzr_min(x, kzr_shr(R3, c2));
+        R0 = kzr_max(t0, R0);                                         // row 0 lies above every position >= 64
+        if (64u + (u32)lane <= r) R1 = kzr_max(t1, R1);
+        if (128u + (u32)lane <= r) R2 = kzr_max(t2, R2);
+        if (192u + (u32)lane <= r) R3 = kzr_max(t3, R3);
+      }
+      outv = (lane == j) ? r : outv;
+    }
+    if ((R >> (cnt - 1)) & 1ULL) KZR_FIX_RUN(row + cnt - 1)            // the row ends inside a skipped stretch
+    if (lane < cnt) d[row + lane] = (u8)outv;
+    cp = (u32)__builtin_amdgcn_readlane((int)cur, cnt - 1);
     cur = nxt;
   }
 }
@@ -741,7 +890,11 @@ int kz_stage_sbrt_forward(kz_ctx* ctx, kz_batch& bt, int mode) {
   if (maxN > 0) {
     KZ_LAUNCH(ctx, KID_SBRT_LAST2, k_sbrt_last2, dim3(T, B), dim3(64), src, bt.stride, bt.d_len, tab, T);
     KZ_LAUNCH(ctx, KID_SBRT_SCAN, k_sbrt_scan, dim3(B), dim3(256), bt.d_len, tab, T);
-    switch (mode) {
+    const bool keyed = maxN <= (1 << 23) && mode != 4 && ctx->sw.sbrtForm != 0;   // KZ_SBRT_FORM=0: the by-symbol replay of rounds 1-5 (A/B)
+    switch (keyed ? mode + 10 : mode) {
+      case 11: KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay_keyed<1>, dim3(T, B), dim3(64), src, dst, bt.stride, bt.d_len, tab, T); break;
+      case 12: KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay_keyed<2>, dim3(T, B), dim3(64), src, dst, bt.stride, bt.d_len, tab, T); break;
+      case 13: KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay_keyed<3>, dim3(T, B), dim3(64), src, dst, bt.stride, bt.d_len, tab, T); break;
       case 1: KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay<1>, dim3(T, B), dim3(64), src, dst, bt.stride, bt.d_len, tab, T); break;
       case 2: KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay<2>, dim3(T, B), dim3(64), src, dst, bt.stride, bt.d_len, tab, T); break;
       case 4: KZ_LAUNCH(ctx, KID_SBRT_REPLAY, k_sbrt_replay<4>, dim3(T, B), dim3(64), src, dst, bt.stride, bt.d_len, tab, T); break;
