@@ -811,6 +811,13 @@ __global__ void k_merge_group(const int32_t* __restrict__ in, const int32_t* __r
   lenOut[b] = flag[b] > 0 ? len[b] : old[b];
   applied[b] = flag[b] > 0 ? 1 : 0;
 }
+// the arrays of one group copied into those of a view that holds several groups (their BWT inverses run as one: overlap_finish)
+__global__ void k_gather_group(const int32_t* __restrict__ in, const int32_t* __restrict__ len, const int32_t* __restrict__ flag, const int32_t* __restrict__ old,
+                               int32_t* __restrict__ mIn, int32_t* __restrict__ mLen, int32_t* __restrict__ mFlag, int32_t* __restrict__ mOld, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B || !in[b]) return;
+  mIn[b] = 1; mLen[b] = len[b]; mFlag[b] = flag[b]; mOld[b] = old[b];
+}
 // the TEXT inverse on the device (kz_text_gpu.hip) instead of the host stage: opt-in, KZ_TEXT_GPU=1 (read per call).  Its first
 // form is one serial walk per block: 1.07 s for 1 536 text blocks of 4 MiB side by side -- and as long for 384 of them -- where 16
 // host CPUs need 0.87 s under the GPU's next chunk; it pays only where the host has next to no CPUs for the process.
@@ -847,7 +854,8 @@ struct OverlapGroup {
   kz_batch v;
 };
 // groups[0] goes on the main stream (the cheapest class), groups[1..] on the side streams, most expensive last
-struct Overlap { std::vector<OverlapGroup> groups; std::vector<int> launchOrder, bwtOrder; int mainGroup = -1; int64_t started = 0; };
+struct Overlap { std::vector<OverlapGroup> groups; std::vector<int> launchOrder, bwtOrder; int mainGroup = -1; int64_t started = 0;
+                 std::vector<std::vector<int>> bwtCalls; };   // bwtCalls: the groups of bwtOrder whose BWT inverses run as ONE call (empty: one call per group)
 #define KZ_OVERLAP_MAXG 5
 // host side: classes by cost relative to the largest: >= 3/4 | >= 3/8 | >= 3/16 | >= 3/32 | the rest; classes of fewer than 8
 // blocks join the class below (the cheapest one: the class above).  false when there is nothing to overlap.
@@ -1006,6 +1014,27 @@ static void overlap_plan(kz_ctx* ctx, Overlap& O, const std::vector<int32_t>& zl
     if (tb < bestT - 1e-9) { bestT = tb; best = perm; O.bwtOrder = byEnd; }
   } while (std::next_permutation(perm.begin(), perm.end()));
   O.launchOrder = best;
+  {
+    // Round 6: groups whose RANK chains are (by the model) over before the main stream gets to them have their BWT inverses run as
+    // ONE call: the walk of 416 blocks takes 45 ms, of 832 about 80, and the per-call tails and launches are paid once
+    // (the two trailing classes of the bulk batch: 2 x 60 -> 85 ms).
+    double t = 0, endR[KZ_OVERLAP_MAXG];
+    for (int i = 0; i < n; i++) { t += O.groups[O.launchOrder[i]].tPre; endR[O.launchOrder[i]] = t + O.groups[O.launchOrder[i]].tRank; }
+    double tb = t;
+    O.bwtCalls.clear();
+    for (size_t i = 0; i < O.bwtOrder.size();) {
+      std::vector<int> call(1, O.bwtOrder[i]);
+      const double begin = std::max(tb, endR[O.bwtOrder[i]]);
+      double dur = O.groups[O.bwtOrder[i]].tBwt;
+      size_t k = i + 1;
+      // (only chains over by then: taking in a chain that ends later -- tried with `<= begin + dur` -- holds the call back behind the longest
+      // one: bulk decode 544 -> 587 ms)
+      while (i > 0 && k < O.bwtOrder.size() && endR[O.bwtOrder[k]] <= begin) { call.push_back(O.bwtOrder[k]); dur += O.groups[O.bwtOrder[k]].tBwt; k++; }
+      O.bwtCalls.push_back(call);
+      tb = begin + dur;
+      i = k;
+    }
+  }
   if ((int)zlen.size() > 4 * ctx->numCUs)                           // (batches of one wave per SIMD or less: the longest chain keeps the highest priority)
     for (size_t i = 0; i < O.bwtOrder.size(); i++) O.groups[O.bwtOrder[i]].prio = i == 0 ? 2 : (i == 1 ? 1 : 0);
   if (ctx->sw.traceSched) {
@@ -1041,18 +1070,50 @@ static int overlap_finish(kz_ctx* ctx, Pipe& P, Overlap& O, std::vector<int32_t>
   kz_batch& bt = P.bt;
   const int B = bt.B;
   hipStream_t st = ctx->stream;
-  const size_t mark = ctx->arenaTop;
   int rc = 0;
-  for (int g : O.bwtOrder) {
-    if (O.groups[g].ev >= 0) KZ_HIP(hipStreamWaitEvent(st, ctx->evJoin[O.groups[g].ev], 0));
+  if (O.bwtCalls.empty()) for (int g : O.bwtOrder) O.bwtCalls.push_back(std::vector<int>(1, g));
+  // a call of several groups works on a view of its own: the groups' masks, lengths, flags and old lengths gathered (allocated in
+  // front of `mark`: the stages' scratch behind it is given back between the calls)
+  struct Merged { OverlapGroup M; bool used = false; };
+  std::vector<Merged> merged(O.bwtCalls.size());
+  for (size_t c = 0; c < O.bwtCalls.size(); c++) {
+    if (O.bwtCalls[c].size() < 2) continue;
+    OverlapGroup& M = merged[c].M;
+    int32_t* d = (int32_t*)kz_arena_alloc(ctx, (size_t)B * 4 * 5);
+    if (!d) { snprintf(ctx->err, sizeof(ctx->err), "overlapped inverse: arena overflow"); return -KZ_ERR_DEVICE; }
+    M.d_in = d; M.len = d + B; M.len2 = d + 2 * B; M.flag = d + 3 * B; M.old = d + 4 * B;
+    merged[c].used = true;
+  }
+  const size_t mark = ctx->arenaTop;
+  for (size_t c = 0; c < O.bwtCalls.size(); c++) {
+    const std::vector<int>& call = O.bwtCalls[c];
+    for (int g : call) if (O.groups[g].ev >= 0) KZ_HIP(hipStreamWaitEvent(st, ctx->evJoin[O.groups[g].ev], 0));
     ctx->arenaTop = mark;                                           // same stream, in order: the scratch is free again
-    rc = kz_stage_bwt_inverse(ctx, O.groups[g].v);
+    if (!merged[c].used) { rc = kz_stage_bwt_inverse(ctx, O.groups[call[0]].v); if (rc) return rc; continue; }
+    OverlapGroup& M = merged[c].M;
+    M.v = O.groups[call[0]].v;                                      // (same buffers, same `cur`: every view has run one stage)
+    KZ_HIP(hipMemsetAsync(M.d_in, 0, (size_t)B * 4 * 5, st));
+    for (size_t q = 0; q < call.size(); q++) {
+      OverlapGroup& G = O.groups[call[q]];
+      if (G.v.cur != M.v.cur) { snprintf(ctx->err, sizeof(ctx->err), "overlapped inverse: views out of step"); return -KZ_ERR_DEVICE; }
+      if (q > 0) for (int b = 0; b < B; b++) if (G.in[b]) M.v.h_len[b] = G.v.h_len[b];
+      hipLaunchKernelGGL(k_gather_group, dim3((B + 255) / 256), dim3(256), 0, st, G.d_in, G.v.d_len, G.v.d_flag, G.old, M.d_in, M.len, M.flag, M.old, B);
+    }
+    M.v.d_len = M.len; M.v.d_len2 = M.len2; M.v.d_flag = M.flag;
+    rc = kz_stage_bwt_inverse(ctx, M.v);
     if (rc) return rc;
   }
   // every view is back in the buffer it started from (two stages each); the batch's own state is untouched except lengths
   KZ_HIP(hipMemsetAsync(P.d_applied, 0, (size_t)B * 4, st));
-  for (auto& G : O.groups)
-    KZ_LAUNCH(ctx, KID_MASK_LEN, k_merge_group, dim3((B + 255) / 256), dim3(256), G.d_in, G.v.d_len, G.v.d_flag, G.old, bt.d_len, P.d_applied, B);
+  for (size_t c = 0; c < O.bwtCalls.size(); c++) {
+    if (merged[c].used) {
+      OverlapGroup& M = merged[c].M;
+      KZ_LAUNCH(ctx, KID_MASK_LEN, k_merge_group, dim3((B + 255) / 256), dim3(256), M.d_in, M.v.d_len, M.v.d_flag, M.old, bt.d_len, P.d_applied, B);
+    } else {
+      OverlapGroup& G = O.groups[O.bwtCalls[c][0]];
+      KZ_LAUNCH(ctx, KID_MASK_LEN, k_merge_group, dim3((B + 255) / 256), dim3(256), G.d_in, G.v.d_len, G.v.d_flag, G.old, bt.d_len, P.d_applied, B);
+    }
+  }
   KZ_HIP(hipMemcpyAsync(ctx->hpin + B, P.d_applied, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   rc = sync_lengths(ctx, bt);
   if (rc) return rc;
