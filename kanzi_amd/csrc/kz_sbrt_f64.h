@@ -15,7 +15,7 @@
 // second register to shift.  Positions above r are kept by the EXEC mask of a v_cmpx on the position number.
 //
 // Layout: position j sits in register pair (j & 3), lane (j >> 2) ("interleaved": old[j-1] is the neighbouring register of the same
-// lane, one DPP wave_shr for register 0), so every rank runs the same straight-line code whatever its depth -- 28 instructions for
+// lane, one DPP wave_shr for register 0), so every rank runs the same straight-line code whatever its depth -- 27 instructions for
 // RANK (the 32-bit forms of rounds 2-5: 22 for ranks below 64 in dense rows, 47 in the interleaved form, 40-90 in the row walk).
 //   qc:  RANK (i + p) >> 1 = (lo + (i << 9)) >> 10  (one v_add3 + one v_alignbit that also ORs bit 30 in);  MTF i;  TIMESTAMP p = lo >> 9.
 // p < 2^23 must hold for lo: blocks above 2^23 bytes keep the round-2 kernel (24-bit timestamps in a 32-bit word), blocks of 2^24 - 256
@@ -28,17 +28,17 @@
 #define KZF_X_MTF  "v_alignbit_b32 v91, %[c80], v71, 9\n\t"         /* i = ((2 i + 1) << 8) >> 9 (no counter of its own: x is computed under the step's EXEC mask in the by-position rows) */
 #define KZF_X_TS   "v_mov_b32 v76, s54\n\t" "v_alignbit_b32 v91, %[c80], v76, 9\n\t"
 // one rank at row position J (a constant); RC holds its rank, RN receives the next one
-#define KZF_STEP(J, JN, RC, RN, X)                                 \
-    "s_lshl_b32 s45, " RC ", 1\n\t"                                  \
-    "s_and_b32 s45, s45, 6\n\t"                                      \
-    "s_lshr_b32 s44, " RC ", 2\n\t"                                  \
-    "s_set_gpr_idx_on s45, gpr_idx(SRC0)\n\t"                        \
+// (RC / LC / IC: the rank, its lane r >> 2 and its register offset 2 (r & 3), read from per-row vectors one step ahead)
+#define KZF_STEP(J, JN, RC, RN, LC, LN, IC, IN, X)                 \
+    "s_set_gpr_idx_on " IC ", gpr_idx(SRC0)\n\t"                     \
     "v_mov_b32 v70, v80\n\t"                     /* lo of register pair r & 3 */ \
     "s_set_gpr_idx_off\n\t"                                          \
     "v_mov_b32_dpp v88, v86" KZF_DPP                                 \
     "v_mov_b32_dpp v89, v87" KZF_DPP                                 \
-    "v_readlane_b32 s54, v70, s44\n\t"                               \
+    "v_readlane_b32 s54, v70, " LC "\n\t"                            \
     "v_readlane_b32 " RN ", %[cur], " #JN "\n\t"                     \
+    "v_readlane_b32 " LN ", v78, " #JN "\n\t"                        \
+    "v_readlane_b32 " IN ", v79, " #JN "\n\t"                        \
     "v_add_u32 v71, %[c512], v71\n\t"                                \
     X                                                                \
     "v_bfi_b32 v90, %[ff], s54, v71\n\t"                             \
@@ -56,7 +56,7 @@
     "v_cmpx_ge_u32 vcc, " RC ", v75\n\t"                             \
     "v_max_f64 v[86:87], v[98:99], v[86:87]\n\t"                     \
     "s_mov_b64 exec, -1\n\t"
-#define KZF_STEP2(A, B, C, X) KZF_STEP(A, B, "s42", "s43", X) KZF_STEP(B, C, "s43", "s42", X)
+#define KZF_STEP2(A, B, C, X) KZF_STEP(A, B, "s42", "s43", "s44", "s46", "s45", "s47", X) KZF_STEP(B, C, "s43", "s42", "s46", "s44", "s47", "s45", X)
 #define KZF_STEP8(A, B, C, D, E, F, G, H, I, X) KZF_STEP2(A, B, C, X) KZF_STEP2(C, D, E, X) KZF_STEP2(E, F, G, X) KZF_STEP2(G, H, I, X)
 // one row of 64 ranks, every rank an ordinary step (a rank 0 re-keys the front entry in place)
 #define KZF_ROW(X) asm volatile(                                                                 \
@@ -66,7 +66,9 @@
     "v_mov_b32 v72, %[lane4]\n\tv_add_u32 v73, 1, %[lane4]\n\tv_add_u32 v74, 2, %[lane4]\n\tv_add_u32 v75, 3, %[lane4]\n\t" \
     "v_mov_b32 v88, 0\n\tv_mov_b32 v89, %[inf]\n\t"                                                \
     "v_mov_b32 v71, %[c2]\n\tv_mov_b32 v91, %[h0]\n\tv_mov_b32 v68, %[m256]\n\t"                   \
-    "v_readlane_b32 s42, %[cur], 0\n\t"                                                            \
+    "v_lshrrev_b32 v78, 2, %[cur]\n\tv_lshlrev_b32 v79, 1, %[cur]\n\tv_and_b32 v79, 6, v79\n\t"  /* lane and register offset of every rank of the row */ \
+    "v_readlane_b32 s42, %[cur], 0\n\tv_readlane_b32 s44, v78, 0\n\tv_readlane_b32 s45, v79, 0\n\t" \
+    "s_nop 3\n\t"                                    /* VALU-written SGPR -> lane select of v_readlane: 4 wait states */ \
     KZF_STEP8(0, 1, 2, 3, 4, 5, 6, 7, 8, X) KZF_STEP8(8, 9, 10, 11, 12, 13, 14, 15, 16, X)          \
     KZF_STEP8(16, 17, 18, 19, 20, 21, 22, 23, 24, X) KZF_STEP8(24, 25, 26, 27, 28, 29, 30, 31, 32, X) \
     KZF_STEP8(32, 33, 34, 35, 36, 37, 38, 39, 40, X) KZF_STEP8(40, 41, 42, 43, 44, 45, 46, 47, 48, X) \
@@ -77,7 +79,7 @@
     : [a0]"+v"(A0), [b0]"+v"(B0), [a1]"+v"(A1), [b1]"+v"(B1), [a2]"+v"(A2), [b2]"+v"(B2), [a3]"+v"(A3), [b3]"+v"(B3), [outv]"+v"(outv) \
     : [cur]"v"(cur), [lane4]"v"(lane4), [ff]"v"(ff), [m256]"v"(m256), [inf]"v"(infHi), [c2]"v"(c2), [h0]"v"(h0), [c100]"s"(c100), [c80]"s"(c80), [c512]"s"(c512) \
     : "vcc", "scc", "v68", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87",  \
-      "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "s41", "s42", "s43", "s44", "s45", "s54");
+      "v78", "v79", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s54");
 
 
 // ---- rows without a rank >= 64, by-position layout (register pair k = positions 64 k .. 64 k + 63, one per lane) ----
