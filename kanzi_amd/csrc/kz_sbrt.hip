@@ -344,18 +344,18 @@ __global__ __launch_bounds__(64) void k_sbrt_replay_keyed(const u8* __restrict__
 // VGPR -> DPP 2 / v_readlane 1, VALU-written EXEC -> DPP 5 / v_readlane, v_writelane 4.
 // One asm statement walks the non-zero ranks of a 64-rank row (the compiler cannot be trusted to keep eleven loop-carried
 // registers in place around per-step asm statements, nor to keep the rank uniform).  Physical temporaries, listed as
-// clobbers: v90 tp, v91 tq, v92 xi, v93 th, v94 nq, v95 vi; s40 j, s41 jn, s42 r, s43 r_next, s44 r&63, s45 t,
+// clobbers: v74 tp, v75 tq, v76 xi, v77 th, v78 nq, v79 vi; s40 j, s41 jn, s42 r, s43 r_next, s44 r&63, s45 t,
 // s[46:47] lanes <= r&63, s[48:49] non-zero positions left, s50 i, s51 j-prev, s52 pl, s53 x, s54 accessed Q, s55/s56 carries,
 // s57 r>>6, s[58:59] insert mask, s60 2i.
 #define KZ6_DPP " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-#define KZ6_XI_RANK(P) "v_add_u32 v92, s50, %[" P "]\n\t"
-#define KZ6_XI_MTF(P)  "v_mov_b32 v92, s60\n\t"
-#define KZ6_XI_TS(P)   "v_lshlrev_b32 v92, 1, %[" P "]\n\t"
+#define KZ6_XI_RANK(P) "v_add_u32 v76, s50, %[" P "]\n\t"
+#define KZ6_XI_MTF(P)  "v_mov_b32 v76, s60\n\t"
+#define KZ6_XI_TS(P)   "v_lshlrev_b32 v76, 1, %[" P "]\n\t"
 // zero run in front of position j: the front entry (row 0, lane 0) repeats, only its (q,p) change (SBRT.java:194-201):
 // p = pl, q = RANK (pl + (run >= 2 ? pl - 1 : p)) >> 1, MTF pl, TIMESTAMP run >= 2 ? pl - 1 : p
-#define KZ6_ZQ_RANK "v_mov_b32 v93, s45\n\tv_cndmask_b32 v92, %[p0], v93, vcc\n\tv_add_u32 v92, s52, v92\n\tv_lshrrev_b32 v92, 1, v92\n\t"
-#define KZ6_ZQ_MTF  "v_mov_b32 v92, s52\n\t"
-#define KZ6_ZQ_TS   "v_mov_b32 v93, s45\n\tv_cndmask_b32 v92, %[p0], v93, vcc\n\t"
+#define KZ6_ZQ_RANK "v_mov_b32 v77, s45\n\tv_cndmask_b32 v76, %[p0], v77, vcc\n\tv_add_u32 v76, s52, v76\n\tv_lshrrev_b32 v76, 1, v76\n\t"
+#define KZ6_ZQ_MTF  "v_mov_b32 v76, s52\n\t"
+#define KZ6_ZQ_TS   "v_mov_b32 v77, s45\n\tv_cndmask_b32 v76, %[p0], v77, vcc\n\t"
 #define KZ6_ZERO(ZQ)                                           \
     "s_sub_u32 s52, s50, 1\n\t"                                  \
     "s_cmp_gt_u32 s51, 2\n\t"                                    \
@@ -363,37 +363,37 @@ __global__ __launch_bounds__(64) void k_sbrt_replay_keyed(const u8* __restrict__
     "s_sub_u32 s45, s52, 1\n\t"                                  \
     "s_mov_b64 exec, 1\n\t"                                      \
     ZQ                                                           \
-    "v_lshlrev_b32 v92, 8, v92\n\t"                              \
-    "v_bfi_b32 %[q0], %[ff], %[q0], v92\n\t"                     \
+    "v_lshlrev_b32 v76, 8, v76\n\t"                              \
+    "v_bfi_b32 %[q0], %[ff], %[q0], v76\n\t"                     \
     "v_mov_b32 %[p0], s52\n\t"                                   \
     "s_mov_b64 exec, -1\n\t"
 // head: read the accessed entry (row KR, lane r&63): x and Q
 #define KZ6_HEAD(XI, QK, PK)                                   \
     XI(PK)                                                       \
-    "v_mov_b32 v95, s50\n\t"                                     \
-    "v_readlane_b32 s53, v92, s44\n\t"                           \
+    "v_mov_b32 v79, s50\n\t"                                     \
+    "v_readlane_b32 s53, v76, s44\n\t"                           \
     "v_readlane_b32 s54, %[" QK "], s44\n\t"
 #define KZ6_THNQ                                               \
-    "v_lshl_or_b32 v93, s53, 7, %[ff]\n\t"                       \
-    "v_bfi_b32 v94, %[ff], s54, v93\n\t"
+    "v_lshl_or_b32 v77, s53, 7, %[ff]\n\t"                       \
+    "v_bfi_b32 v78, %[ff], s54, v77\n\t"
 // rows 1..3: shifted copies with the carry from the row above in lane 0
 #define KZ6_ROW_SHIFT(QK, PK, QM, PM)                          \
     "v_readlane_b32 s55, %[" QM "], 63\n\t"                      \
     "v_readlane_b32 s56, %[" PM "], 63\n\t"                      \
-    "v_mov_b32_dpp v91, %[" QK "]" KZ6_DPP                       \
-    "v_mov_b32_dpp v90, %[" PK "]" KZ6_DPP                       \
-    "v_writelane_b32 v91, s55, 0\n\t"                            \
-    "v_writelane_b32 v90, s56, 0\n\t"
+    "v_mov_b32_dpp v75, %[" QK "]" KZ6_DPP                       \
+    "v_mov_b32_dpp v74, %[" PK "]" KZ6_DPP                       \
+    "v_writelane_b32 v75, s55, 0\n\t"                            \
+    "v_writelane_b32 v74, s56, 0\n\t"
 #define KZ6_ROW_APPLY(QK, PK, TQ)                              \
-    "v_cmpx_le_u32 vcc, %[" QK "], v93\n\t"                      \
-    "v_cmp_lt_u32_e64 s[58:59], v93, " TQ "\n\t"                 \
+    "v_cmpx_le_u32 vcc, %[" QK "], v77\n\t"                      \
+    "v_cmp_lt_u32_e64 s[58:59], v77, " TQ "\n\t"                 \
     "s_nop 1\n\t"                                                \
-    "v_cndmask_b32_e64 %[" QK "], " TQ ", v94, s[58:59]\n\t"     \
-    "v_cndmask_b32_e64 %[" PK "], v90, v95, s[58:59]\n\t"        \
+    "v_cndmask_b32_e64 %[" QK "], " TQ ", v78, s[58:59]\n\t"     \
+    "v_cndmask_b32_e64 %[" PK "], v74, v79, s[58:59]\n\t"        \
     "s_mov_b64 exec, -1\n\t"
 #define KZ6_ROW0                                               \
     "v_mov_b32_dpp %[tq0], %[q0]" KZ6_DPP                        \
-    "v_mov_b32_dpp v90, %[p0]" KZ6_DPP
+    "v_mov_b32_dpp v74, %[p0]" KZ6_DPP
 // tail: lane j of outv <- accessed entry (low byte = symbol), lane j of fmv <- M of row 0 (bit 0: the symbol became the front)
 #define KZ6_TAIL                                               \
     "s_mov_b32 m0, s40\n\t"                                      \
@@ -441,23 +441,23 @@ __global__ __launch_bounds__(64) void k_sbrt_replay_keyed(const u8* __restrict__
     "s_cbranch_scc1 L_k1%=\n\t"                                                                  \
     "s_cmp_eq_u32 s57, 2\n\t"                                                                    \
     "s_cbranch_scc1 L_k2%=\n\t"                                                                  \
-    KZ6_HEAD(XI, "q3", "p3") KZ6_ROW_SHIFT("q3", "p3", "q2", "p2") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q3", "p3", "v91") \
-    KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_ROW_APPLY("q2", "p2", "v91") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v91") \
+    KZ6_HEAD(XI, "q3", "p3") KZ6_ROW_SHIFT("q3", "p3", "q2", "p2") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q3", "p3", "v75") \
+    KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_ROW_APPLY("q2", "p2", "v75") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v75") \
     KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL                                        \
     KZ6_NEXT                                                                                     \
   "L_k2%=:\n\t"                                                                                  \
-    KZ6_HEAD(XI, "q2", "p2") KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q2", "p2", "v91") \
-    KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v91") KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL \
+    KZ6_HEAD(XI, "q2", "p2") KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q2", "p2", "v75") \
+    KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v75") KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL \
     KZ6_NEXT                                                                                     \
   "L_k1%=:\n\t"                                                                                  \
-    KZ6_HEAD(XI, "q1", "p1") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q1", "p1", "v91") \
+    KZ6_HEAD(XI, "q1", "p1") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q1", "p1", "v75") \
     KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL                                        \
     KZ6_NEXT                                                                                     \
   "L_done%=:\n\t"                                                                                \
     : [q0]"+v"(Q0), [p0]"+v"(P0), [q1]"+v"(Q1), [p1]"+v"(P1), [q2]"+v"(Q2), [p2]"+v"(P2), [q3]"+v"(Q3), [p3]"+v"(P3),           \
       [tq0]"+v"(tq0), [outv]"+v"(outv), [fmv]"+v"(fmv), [prev]"=&s"(prev)                                                      \
     : [cur]"v"(cur), [ff]"v"(ff), [nz]"s"(nz), [row]"s"(row)                                                                   \
-    : "vcc", "scc", "v90", "v91", "v92", "v93", "v94", "v95", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", \
+    : "vcc", "scc", "v74", "v75", "v76", "v77", "v78", "v79", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", \
       "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60");
 
 // Rows of 64 ranks with few zeros and few ranks >= 64 (poorly compressible data: the blocks that set the run time): straight-line
@@ -473,12 +473,12 @@ __global__ __launch_bounds__(64) void k_sbrt_replay_keyed(const u8* __restrict__
     "s_cmp_ge_u32 " RC ", 64\n\t"                                 \
     "s_cbranch_scc1 L_stub" J "_%=\n\t"                           \
     KZ6_HEAD(XI, "q0", "p0") KZ6_ROW0 KZ6_THNQ KZ6_SETLE         \
-    "v_cmpx_le_u32 vcc, %[q0], v93\n\t"                          \
-    "v_cmp_lt_u32_e64 s[58:59], v93, %[tq0]\n\t"                 \
+    "v_cmpx_le_u32 vcc, %[q0], v77\n\t"                          \
+    "v_cmp_lt_u32_e64 s[58:59], v77, %[tq0]\n\t"                 \
     "s_add_u32 s50, s50, 1\n\t"                                  \
     "s_nop 0\n\t"                                                \
-    "v_cndmask_b32_e64 %[q0], %[tq0], v94, s[58:59]\n\t"         \
-    "v_cndmask_b32_e64 %[p0], v90, v95, s[58:59]\n\t"            \
+    "v_cndmask_b32_e64 %[q0], %[tq0], v78, s[58:59]\n\t"         \
+    "v_cndmask_b32_e64 %[p0], v74, v79, s[58:59]\n\t"            \
     "s_mov_b64 exec, -1\n\t"                                     \
     "v_writelane_b32 %[outv], s54, " J "\n\t"                    \
   "L_after" J "_%=:\n\t"
@@ -522,20 +522,20 @@ __global__ __launch_bounds__(64) void k_sbrt_replay_keyed(const u8* __restrict__
     "s_cbranch_scc1 L_k1%=\n\t"                                                                  \
     "s_cmp_eq_u32 s57, 2\n\t"                                                                    \
     "s_cbranch_scc1 L_k2%=\n\t"                                                                  \
-    KZ6_HEAD(XI, "q3", "p3") KZ6_ROW_SHIFT("q3", "p3", "q2", "p2") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q3", "p3", "v91") \
-    KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_ROW_APPLY("q2", "p2", "v91") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v91") \
+    KZ6_HEAD(XI, "q3", "p3") KZ6_ROW_SHIFT("q3", "p3", "q2", "p2") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q3", "p3", "v75") \
+    KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_ROW_APPLY("q2", "p2", "v75") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v75") \
     KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL KZ6A_RET                               \
   "L_k2%=:\n\t"                                                                                  \
-    KZ6_HEAD(XI, "q2", "p2") KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q2", "p2", "v91") \
-    KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v91") KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL KZ6A_RET \
+    KZ6_HEAD(XI, "q2", "p2") KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q2", "p2", "v75") \
+    KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v75") KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL KZ6A_RET \
   "L_k1%=:\n\t"                                                                                  \
-    KZ6_HEAD(XI, "q1", "p1") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q1", "p1", "v91") \
+    KZ6_HEAD(XI, "q1", "p1") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q1", "p1", "v75") \
     KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6_TAIL KZ6A_RET                               \
   "L_done%=:\n\t"                                                                                \
     : [q0]"+v"(Q0), [p0]"+v"(P0), [q1]"+v"(Q1), [p1]"+v"(P1), [q2]"+v"(Q2), [p2]"+v"(P2), [q3]"+v"(Q3), [p3]"+v"(P3),           \
       [tq0]"+v"(tq0), [outv]"+v"(outv), [fmv]"+v"(fmv)                                                                         \
     : [cur]"v"(cur), [ff]"v"(ff), [row]"s"(row)                                                                                \
-    : "vcc", "scc", "v90", "v91", "v92", "v93", "v94", "v95", "s40", "s42", "s44", "s45", "s46", "s47",                        \
+    : "vcc", "scc", "v74", "v75", "v76", "v77", "v78", "v79", "s40", "s42", "s44", "s45", "s46", "s47",                        \
       "s50", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s62", "s63", "s64", "s65");
 
 // Dense rows with many ranks >= 64 (incompressible data): a plain loop over the 64 positions, zero ranks as ordinary steps (no run
@@ -570,22 +570,22 @@ __global__ __launch_bounds__(64) void k_sbrt_replay_keyed(const u8* __restrict__
     "s_cbranch_scc1 L_k1%=\n\t"                                                                  \
     KZ6_HEAD(XI, "q0", "p0") KZ6_ROW0 KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6C_TAIL KZ6C_NEXT \
   "L_k1%=:\n\t"                                                                                  \
-    KZ6_HEAD(XI, "q1", "p1") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q1", "p1", "v91") \
+    KZ6_HEAD(XI, "q1", "p1") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q1", "p1", "v75") \
     KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6C_TAIL KZ6C_NEXT                             \
   "L_hi%=:\n\t"                                                                                  \
     "s_bitcmp1_b32 s42, 6\n\t"                                                                   \
     "s_cbranch_scc1 L_k3%=\n\t"                                                                  \
-    KZ6_HEAD(XI, "q2", "p2") KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q2", "p2", "v91") \
-    KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v91") KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6C_TAIL KZ6C_NEXT \
+    KZ6_HEAD(XI, "q2", "p2") KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q2", "p2", "v75") \
+    KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v75") KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6C_TAIL KZ6C_NEXT \
   "L_k3%=:\n\t"                                                                                  \
-    KZ6_HEAD(XI, "q3", "p3") KZ6_ROW_SHIFT("q3", "p3", "q2", "p2") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q3", "p3", "v91") \
-    KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_ROW_APPLY("q2", "p2", "v91") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v91") \
+    KZ6_HEAD(XI, "q3", "p3") KZ6_ROW_SHIFT("q3", "p3", "q2", "p2") KZ6_THNQ KZ6_SETLE KZ6_ROW_APPLY("q3", "p3", "v75") \
+    KZ6_ROW_SHIFT("q2", "p2", "q1", "p1") KZ6_ROW_APPLY("q2", "p2", "v75") KZ6_ROW_SHIFT("q1", "p1", "q0", "p0") KZ6_ROW_APPLY("q1", "p1", "v75") \
     KZ6_ROW0 KZ6_ROW_APPLY("q0", "p0", "%[tq0]") KZ6C_TAIL KZ6C_NEXT                             \
   "L_done%=:\n\t"                                                                                \
     : [q0]"+v"(Q0), [p0]"+v"(P0), [q1]"+v"(Q1), [p1]"+v"(P1), [q2]"+v"(Q2), [p2]"+v"(P2), [q3]"+v"(Q3), [p3]"+v"(P3),           \
       [tq0]"+v"(tq0), [outv]"+v"(outv)                                                                                         \
     : [cur]"v"(cur), [ff]"v"(ff), [row]"s"(row)                                                                                \
-    : "vcc", "scc", "v90", "v91", "v92", "v93", "v94", "v95", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",          \
+    : "vcc", "scc", "v74", "v75", "v76", "v77", "v78", "v79", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",          \
       "s50", "s53", "s54", "s55", "s56", "s58", "s59", "s60");
 
 // ---- cold rows, interleaved layout -------------------------------------------------------------------------------------
@@ -605,8 +605,8 @@ __global__ __launch_bounds__(64) void k_sbrt_replay_keyed(const u8* __restrict__
     "v_cmpx_ge_u32 vcc, s55, " Q "\n\t"                         \
     "v_cmp_lt_u32_e64 s[58:59], s55, " NQ "\n\t"                \
     "s_nop 1\n\t"                                               \
-    "v_cndmask_b32_e64 " Q ", " NQ ", v94, s[58:59]\n\t"        \
-    "v_cndmask_b32_e64 " P ", " NP ", v95, s[58:59]\n\t"        \
+    "v_cndmask_b32_e64 " Q ", " NQ ", v78, s[58:59]\n\t"        \
+    "v_cndmask_b32_e64 " P ", " NP ", v79, s[58:59]\n\t"        \
     "s_mov_b64 exec, -1\n\t"
 // one rank at row position J (a constant); RC holds its rank, RN receives the next one (the two alternate)
 #define KZ6I_STEP(J, JN, RC, RN, XS)                           \
@@ -614,46 +614,46 @@ __global__ __launch_bounds__(64) void k_sbrt_replay_keyed(const u8* __restrict__
     "v_readlane_b32 " RN ", %[cur], " #JN "\n\t"                \
     "s_lshr_b32 s44, " RC ", 2\n\t"                             \
     "s_set_gpr_idx_on s45, gpr_idx(SRC0)\n\t"                   \
-    "v_mov_b32 v92, v80\n\t"                                    \
-    "v_mov_b32 v93, v84\n\t"                                    \
+    "v_mov_b32 v76, v64\n\t"                                    \
+    "v_mov_b32 v77, v68\n\t"                                    \
     "s_set_gpr_idx_off\n\t"                                     \
-    "v_mov_b32 v95, s50\n\t"                                    \
-    "v_readlane_b32 s54, v92, s44\n\t"                          \
-    "v_readlane_b32 s53, v93, s44\n\t"                          \
-    "v_mov_b32_dpp %[tq0], v83" KZ6_DPP                         \
-    "v_mov_b32_dpp v90, v87" KZ6_DPP                            \
+    "v_mov_b32 v79, s50\n\t"                                    \
+    "v_readlane_b32 s54, v76, s44\n\t"                          \
+    "v_readlane_b32 s53, v77, s44\n\t"                          \
+    "v_mov_b32_dpp %[tq0], v67" KZ6_DPP                         \
+    "v_mov_b32_dpp v74, v71" KZ6_DPP                            \
     XS                                                          \
     "s_lshl_b32 s55, s53, 7\n\t"                                \
     "s_or_b32 s55, s55, 0xff\n\t"                               \
-    "v_mov_b32 v93, s55\n\t"                                    \
-    "v_bfi_b32 v94, %[ff], s54, v93\n\t"                        \
-    KZ6I_REG("v75", "v83", "v87", "v82", "v86", RC)             \
-    KZ6I_REG("v74", "v82", "v86", "v81", "v85", RC)             \
-    KZ6I_REG("v73", "v81", "v85", "v80", "v84", RC)             \
-    KZ6I_REG("v72", "v80", "v84", "%[tq0]", "v90", RC)          \
+    "v_mov_b32 v77, s55\n\t"                                    \
+    "v_bfi_b32 v78, %[ff], s54, v77\n\t"                        \
+    KZ6I_REG("v59", "v67", "v71", "v66", "v70", RC)             \
+    KZ6I_REG("v58", "v66", "v70", "v65", "v69", RC)             \
+    KZ6I_REG("v57", "v65", "v69", "v64", "v68", RC)             \
+    KZ6I_REG("v56", "v64", "v68", "%[tq0]", "v74", RC)          \
     "v_writelane_b32 %[outv], s54, " #J "\n\t"                  \
     "s_add_u32 s50, s50, 1\n\t"
 #define KZ6I_STEP2(A, B, C, XS) KZ6I_STEP(A, B, "s42", "s43", XS) KZ6I_STEP(B, C, "s43", "s42", XS)
 #define KZ6I_STEP8(A, B, C, D, E, F, G, H, I, XS) KZ6I_STEP2(A, B, C, XS) KZ6I_STEP2(C, D, E, XS) KZ6I_STEP2(E, F, G, XS) KZ6I_STEP2(G, H, I, XS)
 #define KZ6I_ROWCOLD(XS) asm volatile(                                                         \
     "s_mov_b32 s41, m0\n\t"                      /* s_set_gpr_idx_on writes m0: saved and restored, not clobbered */ \
-    "v_mov_b32 v80, %[q0]\n\tv_mov_b32 v81, %[q1]\n\tv_mov_b32 v82, %[q2]\n\tv_mov_b32 v83, %[q3]\n\t"  \
-    "v_mov_b32 v84, %[p0]\n\tv_mov_b32 v85, %[p1]\n\tv_mov_b32 v86, %[p2]\n\tv_mov_b32 v87, %[p3]\n\t"  \
-    "v_mov_b32 v72, %[lane4]\n\tv_add_u32 v73, 1, %[lane4]\n\tv_add_u32 v74, 2, %[lane4]\n\tv_add_u32 v75, 3, %[lane4]\n\t" \
+    "v_mov_b32 v64, %[q0]\n\tv_mov_b32 v65, %[q1]\n\tv_mov_b32 v66, %[q2]\n\tv_mov_b32 v67, %[q3]\n\t"  \
+    "v_mov_b32 v68, %[p0]\n\tv_mov_b32 v69, %[p1]\n\tv_mov_b32 v70, %[p2]\n\tv_mov_b32 v71, %[p3]\n\t"  \
+    "v_mov_b32 v56, %[lane4]\n\tv_add_u32 v57, 1, %[lane4]\n\tv_add_u32 v58, 2, %[lane4]\n\tv_add_u32 v59, 3, %[lane4]\n\t" \
     "s_mov_b32 s50, %[row]\n\t"                                                                  \
     "v_readlane_b32 s42, %[cur], 0\n\t"                                                          \
     KZ6I_STEP8(0, 1, 2, 3, 4, 5, 6, 7, 8, XS) KZ6I_STEP8(8, 9, 10, 11, 12, 13, 14, 15, 16, XS)    \
     KZ6I_STEP8(16, 17, 18, 19, 20, 21, 22, 23, 24, XS) KZ6I_STEP8(24, 25, 26, 27, 28, 29, 30, 31, 32, XS) \
     KZ6I_STEP8(32, 33, 34, 35, 36, 37, 38, 39, 40, XS) KZ6I_STEP8(40, 41, 42, 43, 44, 45, 46, 47, 48, XS) \
     KZ6I_STEP8(48, 49, 50, 51, 52, 53, 54, 55, 56, XS) KZ6I_STEP8(56, 57, 58, 59, 60, 61, 62, 63, 0, XS)  \
-    "v_mov_b32 %[q0], v80\n\tv_mov_b32 %[q1], v81\n\tv_mov_b32 %[q2], v82\n\tv_mov_b32 %[q3], v83\n\t"  \
-    "v_mov_b32 %[p0], v84\n\tv_mov_b32 %[p1], v85\n\tv_mov_b32 %[p2], v86\n\tv_mov_b32 %[p3], v87\n\t"  \
+    "v_mov_b32 %[q0], v64\n\tv_mov_b32 %[q1], v65\n\tv_mov_b32 %[q2], v66\n\tv_mov_b32 %[q3], v67\n\t"  \
+    "v_mov_b32 %[p0], v68\n\tv_mov_b32 %[p1], v69\n\tv_mov_b32 %[p2], v70\n\tv_mov_b32 %[p3], v71\n\t"  \
     "s_mov_b32 m0, s41\n\t"                                                                      \
     : [q0]"+v"(Q0), [p0]"+v"(P0), [q1]"+v"(Q1), [p1]"+v"(P1), [q2]"+v"(Q2), [p2]"+v"(P2), [q3]"+v"(Q3), [p3]"+v"(P3),           \
       [tq0]"+v"(tq0), [outv]"+v"(outv)                                                                                         \
     : [cur]"v"(cur), [lane4]"v"(lane4), [ff]"v"(ff), [row]"s"(row)                                                             \
-    : "vcc", "scc", "s41", "v72", "v73", "v74", "v75", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87",                  \
-      "v90", "v92", "v93", "v94", "v95", "s42", "s43", "s44", "s45", "s50", "s53", "s54", "s55", "s58", "s59");
+    : "vcc", "scc", "s41", "v56", "v57", "v58", "v59", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71",                  \
+      "v74", "v76", "v77", "v78", "v79", "s42", "s43", "s44", "s45", "s50", "s53", "s54", "s55", "s58", "s59");
 // layout changes: by position (register k = positions 64k..64k+63) <-> interleaved (register k = positions 4l + k)
 __device__ __forceinline__ void kz6_to_interleaved(u32& A0, u32& A1, u32& A2, u32& A3, int lane) {
   const int grp = lane >> 4;
