@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the judged artefacts of tools/profile_round.sh (merged back under gpurun_out/<tag>/) into profiles/<tag>_*.
-TAG=${1:-r04}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p profiles
 for f in $OUT/pmc_traffic*.json $OUT/kernel_stats*.csv; do [ -f "$f" ] && cp $f profiles/${TAG}_$(basename $f); done

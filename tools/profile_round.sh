@@ -9,7 +9,7 @@
 # 4. bench.py defaults with the measured traffic attached                -> bench_default.json
 # Copy the files you want judged to profiles/<tag>_*.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
