@@ -193,7 +193,7 @@ def compact(out):
                              "ms_per_step": _r(ch["ms_per_step"]), "z": _r(ch["z_post_transform_ratio"]), "c": _r(ch["c_compressed_ratio"]),
                              "roofline": compact_roofline(ch["roofline"])}
         if ch.get("host_stage_ms_per_step"):
-            cc["chains"][key]["host_stage_ms"] = {k: _r(v) for k, v in ch["host_stage_ms_per_step"].items()}
+            cc["chains"][key]["text_utf_stage_ms_incl_device_forms"] = {k: _r(v) for k, v in ch["host_stage_ms_per_step"].items()}
         for a in ("knz_identical_to_hip", "blocks_compared_with_oracle"):
             if a in ch:
                 cc["chains"][key][a] = ch[a]
@@ -479,11 +479,16 @@ def main():
         if "TEXT" in chain.upper().split("+") or "UTF" in chain.upper().split("+"):
             ctx.set_timing(True)
             ctx.reset_timing()
+            ctx.lib.kz_host_stage_blocks(0, 1)
+            ctx.lib.kz_host_stage_blocks(1, 1)
             bt.step()
             torch.cuda.synchronize()
             ctx.set_timing(False)
             stt = ctx.stage_times()
-            host_ms = {"forward": stt.get("host_fwd", {}).get("ms", 0.0), "inverse": stt.get("host_inv", {}).get("ms", 0.0)}
+            # wall time of the TEXT / UTF stage INCLUDING its device forms' kernels, and how many blocks of that step really went
+            # through a host thread (kz_host_stage_blocks)
+            host_ms = {"forward": stt.get("host_fwd", {}).get("ms", 0.0), "inverse": stt.get("host_inv", {}).get("ms", 0.0),
+                       "forward_blocks_on_host_threads": int(ctx.lib.kz_host_stage_blocks(0, 0)), "inverse_blocks_on_host_threads": int(ctx.lib.kz_host_stage_blocks(1, 0))}
         copy_gbs = None
         if copy_rate:                                                  # measured stream-copy rate of this GPU, next to the 8 TB/s spec peak
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -226,6 +226,10 @@ int32_t kz_knz_index(const uint8_t* src, int64_t n, uint64_t* transformType, uin
                      int64_t* blockBitOff, int64_t* blockBits, int32_t cap);
 
 /* ---- instrumentation (bench.py / roofline) ----------------------------------------------------- */
+/* blocks that went through a TEXT / UTF stage on a HOST thread since the last reset (process-wide counter; inverse = 0: forward,
+ * 1: inverse).  The stage timers KZ_STAGE_HOST_FWD / _INV measure the TEXT / UTF stage's wall time INCLUDING its device forms
+ * (kz_text_fwd_gpu.hip, kz_utf_fwd_gpu.hip, kz_text_gpu.hip): this counter says how much of the stage the host really did. */
+int64_t kz_host_stage_blocks(int32_t inverse, int32_t reset);
 void    kz_set_timing(kz_ctx* ctx, int32_t enable);     /* hipEvent-bracket every stage of the next calls */
 int32_t kz_get_stage_count(kz_ctx* ctx);
 float   kz_get_stage_ms(kz_ctx* ctx, int32_t stage);    /* accumulated since last kz_reset_timing */

@@ -80,6 +80,7 @@ def load_library():
         "kz_ctx_set_skip_blocks": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_set_block_size": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_reload_switches": (None, [vp]),
+        "kz_host_stage_blocks": (c.c_int64, [c.c_int32, c.c_int32]),
         "kz_ctx_set_entropy": (c.c_int32, [vp, c.c_uint32]),
         "kz_ctx_set_data_type": (c.c_int32, [vp, c.c_int32]),
         "kz_ctx_get_data_type": (c.c_int32, [vp]),
@@ -129,7 +130,7 @@ def load_library():
 
 
 ABI_SYMBOLS = ["kz_abi_version", "kz_ctx_create", "kz_ctx_destroy", "kz_last_error", "kz_ctx_stream", "kz_pin_to_device_numa", "kz_host_cpus", "kz_host_share", "kz_ctx_set_checksum",
-               "kz_ctx_set_data_type", "kz_ctx_get_data_type", "kz_ctx_reset", "kz_ctx_set_skip_blocks", "kz_ctx_set_block_size", "kz_ctx_reload_switches", "kz_ctx_set_entropy",
+               "kz_ctx_set_data_type", "kz_ctx_get_data_type", "kz_ctx_reset", "kz_ctx_set_skip_blocks", "kz_ctx_set_block_size", "kz_ctx_reload_switches", "kz_host_stage_blocks", "kz_ctx_set_entropy",
                "kz_transform_forward", "kz_transform_inverse", "kz_transform_max_encoded_len", "kz_host_stage_forward", "kz_host_stage_inverse",
                "kz_entropy_encode", "kz_entropy_decode", "kz_encode_blocks", "kz_decode_blocks",
                "kz_max_block_stream_bytes", "kz_submit_encode_blocks", "kz_submit_decode_blocks", "kz_wait", "kz_poll", "kz_compress", "kz_decompress", "kz_compress_bound", "kz_transform_type",

@@ -632,6 +632,13 @@ struct HostFwd {
   const int32_t* first = nullptr;                   // list form: the stages in front of first[k] are done with block k (they declined:
   const int32_t* dt0 = nullptr;                     //            data untouched, skip bits set) and left the "dataType" dt0[k]
 };
+// blocks that went through a TEXT / UTF stage on a HOST thread since the last reset (process-wide; bench.py reports them next to the
+// stage's wall time, which includes the device forms' kernels): [0] forward, [1] inverse
+static std::atomic<int64_t> g_hostStageBlocks[2];
+extern "C" int64_t kz_host_stage_blocks(int32_t inverse, int32_t reset) {
+  std::atomic<int64_t>& c = g_hostStageBlocks[inverse ? 1 : 0];
+  return reset ? c.exchange(0) : c.load();
+}
 static void host_forward_block(int b, void* arg) {
   HostFwd& H = *(HostFwd*)arg;
   HostPre& P = *H.P;
@@ -641,6 +648,7 @@ static void host_forward_block(int b, void* arg) {
   P.skip[b] = 0xFF;
   P.changed[b] = 0;
   if (n == 0 || (H.copy ? H.copy[b] != 0 : n <= 15)) return;
+  g_hostStageBlocks[0]++;
   static thread_local std::vector<uint8_t> bufA;
   if ((int)bufA.size() < H.cap + 64) bufA.resize((size_t)H.cap + 64);
   const uint8_t* const origin = H.ptrs ? H.ptrs[b] : H.hsrc + (int64_t)b * H.hstride;
@@ -727,6 +735,7 @@ static void host_inverse_block(int b, void* arg) {
   bool any = false;
   for (int i = 0; i < H.hp; i++) any |= !(H.skip[b] & (1 << (7 - i)));
   if (!any) return;
+  g_hostStageBlocks[1]++;
   static thread_local std::vector<uint8_t> bufA, bufB;
   const size_t need = (size_t)std::max(H.cap, len) + 64;
   if (bufA.size() < need) { bufA.resize(need); bufB.resize(need); }
