@@ -68,7 +68,7 @@ void kz_switches_read(kz_switches& s) {
   s.streamChunk = num("KZ_STREAM_CHUNK", 0);
   s.streamSerial = flag("KZ_STREAM_SERIAL");
   s.bwtTrie = num("KZ_BWT_TRIE", -1); s.bwtTrieWin = num("KZ_BWT_TRIEWIN", -1); s.bwtBuckets = num("KZ_BWT_BUCKETS", -1);
-  s.bwtDmax = num("KZ_BWT_DMAX", -1); s.bwtRetire = num("KZ_BWT_RETIRE", -1);
+  s.bwtDmax = num("KZ_BWT_DMAX", -1); s.bwtRetire = num("KZ_BWT_RETIRE", -1); s.bwtLazyRank = num("KZ_BWT_LAZYRANK", -1);
   s.bwtTrace = flag("KZ_BWT_TRACE");
   s.bwtTestTrieOverflow = digit("KZ_BWT_TEST_TRIE_OVERFLOW", 0, 9, -1);
   { const char* f = getenv("KZ_FPAQ_FORCE"); s.fpaqForce = f ? ((f[0] == 'w' || f[0] == 'W' || f[0] == '1') ? 1 : ((f[0] == 'l' || f[0] == 'L' || f[0] == '2') ? 2 : 0)) : 0; }

@@ -174,15 +174,26 @@ __global__ __launch_bounds__(MSD_BINS) void k_msd_scan(BwtArrays A) {
 #define RSC_WAVES 16                      // scatter workgroup: 16 waves x 16 rows of 64 keys = one radix tile
 #define RSC_ITEMS (RSORT_TILE / (64 * RSC_WAVES))
 #define RSC_WG (64 * RSC_WAVES)
+// lanes of the wave whose NBITS-bit digit equals this lane's (0 for a lane that is not valid).
+// Per digit bit: x = the lane's bit spread over a word (0 / ~0), bal = the lanes whose bit is set; the lanes that agree with this lane
+// in the bit are ~(bal ^ x).  Kept in 32-bit halves: the compiler then spends six VALU instructions per bit (shift, v_bfe_i32, v_cmp,
+// two v_xor and half a v_or3 over the differences) instead of the nine of `m &= bit ? bal : ~bal` on 64-bit masks; the ranking phase of
+// the LDS sorts is VALU bound (k_tr_sort 39.8 -> 36.8 ms, k_bucket_sort 16.9 -> 15.3 ms per 342 mixed blocks).  A hand-scheduled
+// four-instruction form (v_bfe_i32, v_cmp into an SGPR pair, two v_bitop3_b32 reading it) is correct but SLOWER (50.7 ms): an
+// instruction with an SGPR operand occupies the SIMD twice as long as a VGPR-only one (tools/ubench_valu_rate.hip) and a VALU read of an
+// SGPR that a VALU compare just wrote stalls the wave for about 16 cycles.
 template <int NBITS>
 __device__ __forceinline__ uint64_t bw_match(u32 d, bool valid) {
-  uint64_t m = kz_ballot(valid);
+  const uint64_t m0 = kz_ballot(valid);
+  u32 mlo = (u32)m0, mhi = (u32)(m0 >> 32);
 #pragma unroll
   for (int b = 0; b < NBITS; b++) {
-    const uint64_t bal = kz_ballot((d >> b) & 1u);
-    m &= ((d >> b) & 1u) ? bal : ~bal;
+    const u32 x = (u32)(((int32_t)(d << (31 - b))) >> 31);
+    const uint64_t bal = kz_ballot(x != 0u);
+    mlo &= ~((u32)bal ^ x);
+    mhi &= ~((u32)(bal >> 32) ^ x);
   }
-  return valid ? m : 0ULL;
+  return valid ? (((uint64_t)mhi << 32) | mlo) : 0ULL;
 }
 template <int BINS, int NBITS, bool MSD, typename CNT, bool TEXT>
 __device__ __forceinline__ void radix_scatter_body(const u64* __restrict__ keyIn, const u32* __restrict__ valIn,
@@ -807,17 +818,24 @@ __global__ __launch_bounds__(1024) void k_bucket_count(const u64* __restrict__ k
   bucket_count_body<16, BK_CAP / 1024, BK_SMALL, BK_CAP, u32>(keyS, valS, A, bitsR, bitsG, gmax);
 }
 
+// (the trie rounds' per-block counters, defined further down; k_live_emit reads two of them)
+#define TR_META 32               // ints per block: [0] nodes, [1] buckets, [2 + L] first node of depth L, [10 + L] end, [18] error, [20] lazy ranks: live suffixes found
 // ---------------------------------------------------------------------------------------------
 // step 1 (text order): compact the LIVE suffixes and build their keys from sequential rank reads
 // The compact list need not be in text order (its only readers partition it by group: k_msd_* / the key trie round), so a tile
 // reserves its slice with ONE returning atomic on the block's counter instead of a count kernel + a scan kernel + a second read of
 // every rank (k_live_count / k_live_scan until round 4: 36 ms and 122 GB of rank reads per 8 GiB).  Inside a tile the order stays
 // the text order.  tileLive[tile] = live suffixes of the tile after the previous round (0 stays 0: suffixes only become final).
-__global__ __launch_bounds__(KZ_WG) void k_live_emit(u64* __restrict__ keyN, u32* __restrict__ valN, BwtArrays A, int h, int bitsR, int first) {
+__global__ __launch_bounds__(KZ_WG) void k_live_emit(u64* __restrict__ keyN, u32* __restrict__ valN, BwtArrays A, int h, int bitsR, int first, const int32_t* __restrict__ lazyMeta) {
   const int b = bw_row_block(A, blockIdx.y);
   const int n = A.d_n[b];
   const int tile = blockIdx.x;
   if ((int64_t)tile * RS_TILE >= n) return;
+  if (lazyMeta && lazyMeta[(int64_t)b * TR_META] == 256 && lazyMeta[(int64_t)b * TR_META + 18] == 0 && lazyMeta[(int64_t)b * TR_META + 20] == 0) {
+    // round 0 left no live suffix in this block and stored no ranks (k_tr_sort, lazy ranks): nothing to read, nothing to emit
+    if (threadIdx.x == 0) A.tileLive[(int64_t)b * A.T + tile] = 0;
+    return;
+  }
   if (!first && A.tileLive[(int64_t)b * A.T + tile] == 0) return;     // nothing left here: neither read nor written
   __shared__ u32 rowCnt[RS_ITEMS * 4 + 1];   // live suffixes per (wave, row), then exclusive prefix
   __shared__ u32 tileBase;
@@ -896,7 +914,6 @@ __global__ __launch_bounds__(KZ_WG) void k_live_emit(u64* __restrict__ keyN, u32
 #define TR_K_EXP 2u
 #define TR_K_TERM 3u
 #define TR_UNCHANGED (1u << 29)     // key rounds, terminal child: the new group keeps the old group's head slot (its members' ranks stay)
-#define TR_META 32               // ints per block: [0] nodes, [1] buckets, [2 + L] first node of depth L, [10 + L] end, [18] error
 #define TR_NODECHUNK 128         // nodes whose counters fit the LDS of k_tr_count
 struct TrieArrays {
   u32* cnt;        // [B][MN][256] children counts
@@ -1278,13 +1295,27 @@ __global__ __launch_bounds__(1024) void k_tr_scatter(const u8* __restrict__ srcA
 __global__ __launch_bounds__(1024) void k_tr_scatter_f(const u8* __restrict__ srcAll, int64_t stride, const u32* __restrict__ stateAll,
                                                         u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) { tr_scatter_body<TRS_TILE / 2, TRS_FASTB, true>(srcAll, stride, stateAll, elemAll, A, T, bitsG); }
 
+// round 0: a block whose trie has only the 256 depth-1 nodes (see the lazy ranks of k_tr_sort)
+__device__ __forceinline__ bool tr_lazy_candidate(const int32_t* meta) { return meta[0] == 256 && meta[18] == 0; }
 // one bucket at a time in LDS: sort by the key bits that differ, groups of equal keys, ranks and final suffixes
 #define TRQ_WAVES 16
 #define TRQ_ROWS 8
 template <bool KEYS>
-__device__ __forceinline__ void tr_sort_body(const u64* __restrict__ elemAll, const BwtArrays& A, const TrieArrays& T, int bitsG) {
+__device__ __forceinline__ void tr_sort_body(const u64* __restrict__ elemAll, const BwtArrays& A, const TrieArrays& T, int bitsG, int lazyMode) {
   const int b = bw_row_block(A, blockIdx.y);
   const int nB = T.meta[(int64_t)b * TR_META + 1];
+  // LAZY RANKS (round 0 only).  A block without a single expanded node (no 2-byte prefix above TR_CAP suffixes: high-entropy data)
+  // almost always leaves round 0 with every suffix final, and then nobody reads its ranks except k_bwt_emit (the 8 primary indexes):
+  // the scattered 4-byte rank stores are a quarter of this kernel's time on such blocks.  Pass 1 (lazyMode 1) sorts such a block,
+  // writes its final suffixes and the 8 ranks k_bwt_emit reads, and COUNTS the live suffixes in meta[20]; pass 2 (lazyMode 2) runs the
+  // blocks whose count is not zero again, storing every rank (the elements are untouched by pass 1; the sa stores repeat).
+  // k_live_emit skips the blocks pass 1 finished.
+  const bool lazyCand = !KEYS && lazyMode != 0 && tr_lazy_candidate(T.meta + (int64_t)b * TR_META);
+  if (!KEYS && lazyMode == 2 && !(lazyCand && T.meta[(int64_t)b * TR_META + 20] > 0)) return;
+  const bool lazy = lazyCand && lazyMode == 1;
+  u32 pstep = 0;
+  if (lazy) { const int n = A.d_n[b]; const int st = n >> 3; pstep = (u32)((st * 8 != n) ? st + 1 : st); }   // k_bwt_emit: primary index k = rank[k * step]
+  u32 liveMine = 0;
   __shared__ u64 buf[TR_CAP];
   __shared__ uint16_t cw[TRQ_WAVES][BK_DBINS];
   __shared__ u32 wsum[BK_DBINS / 64];
@@ -1445,7 +1476,12 @@ __device__ __forceinline__ void tr_sort_body(const u64* __restrict__ elemAll, co
           const bool live = !(hh == (u32)idx && headN);
           const u32 sv = (u32)(k[r] & vmask);
           if (!KEYS) {
-            rank[sv] = (bo + hh) | (live ? BW_LIVE : 0u);
+            if (!lazy) rank[sv] = (bo + hh) | (live ? BW_LIVE : 0u);
+            else {
+              const u32 q = sv / pstep;
+              if (q * pstep == sv && q < 8u) rank[sv] = (bo + hh) | (live ? BW_LIVE : 0u);
+              liveMine += live ? 1u : 0u;
+            }
             if (!live) sa[bo + (u32)idx] = sv;
           } else {
             u32 g, headSlot, slot;
@@ -1464,10 +1500,16 @@ __device__ __forceinline__ void tr_sort_body(const u64* __restrict__ elemAll, co
     }
     __syncthreads();
   }
+  if (!KEYS && lazy) {
+    if (kz_ballot(liveMine != 0) != 0) {
+      for (int dd = 32; dd > 0; dd >>= 1) liveMine += __shfl_xor(liveMine, dd, 64);
+      if (lane == 0) atomicAdd(&T.meta[(int64_t)b * TR_META + 20], (int32_t)liveMine);
+    }
+  }
 }
 // (two workgroups per CU at 64 VGPRs with 16 registers spilled beat one workgroup without spills: 45 vs 50 ms per 357 uniform blocks)
-__global__ __launch_bounds__(1024, 8) void k_tr_sort(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) { tr_sort_body<false>(elemAll, A, T, bitsG); }
-__global__ __launch_bounds__(1024, 8) void k_trk_sort(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) { tr_sort_body<true>(elemAll, A, T, bitsG); }
+__global__ __launch_bounds__(1024, 8) void k_tr_sort(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG, int lazyMode) { tr_sort_body<false>(elemAll, A, T, bitsG, lazyMode); }
+__global__ __launch_bounds__(1024, 8) void k_trk_sort(const u64* __restrict__ elemAll, BwtArrays A, TrieArrays T, int bitsG) { tr_sort_body<true>(elemAll, A, T, bitsG, 0); }
 
 // ---------------------------------------------------------------------------------------------
 // KEY rounds: the same trie round over the WINDOW of a doubling round -- the compact pairs (old group g << bitsR | secondary key r2,
@@ -1864,6 +1906,7 @@ static int bwt_forward_run(kz_ctx* ctx, kz_batch& bt, bool allowTrie, bool* trie
   const int Dmax = (ctx->sw.bwtDmax >= 6 && ctx->sw.bwtDmax <= TR_DMAX_LIMIT) ? ctx->sw.bwtDmax : 6;
   const bool noRetire = ctx->sw.bwtRetire == 0;                      // A/B switch: every block rides through every round, as before
   const bool trieWinOff = ctx->sw.bwtTrieWin == 0;
+  const bool lazyRank = ctx->sw.bwtLazyRank != 0;
   const bool trace = ctx->sw.bwtTrace != 0;
   const int forceOvfRound = ctx->sw.bwtTestTrieOverflow;             // tests: pretend the tables overflowed in round <digit>
   if (useTrie) KZ_HIP(hipMemsetAsync(TR.err, 0, 4, st));
@@ -1891,7 +1934,8 @@ static int bwt_forward_run(kz_ctx* ctx, kz_batch& bt, bool allowTrie, bool* trie
       KZ_LAUNCH(ctx, KID_TR_SCATTER, k_tr_scatter_f, dim3(gridFor(maxN, TRS_TILE / 2), B), dim3(1024), src, bt.stride, A.val[0], A.key[0], A, TR, bitsG);
       KZ_LAUNCH(ctx, KID_TR_SCATTER, k_tr_scatter, dim3(gridFor(maxN, TRS_TILE), B), dim3(1024), src, bt.stride, A.val[0], A.key[0], A, TR, bitsG);
       const int G = std::max(16, std::min(1024, 8192 / B));
-      KZ_LAUNCH(ctx, KID_TR_SORT, k_tr_sort, dim3(G, B), dim3(1024), A.key[0], A, TR, bitsG);
+      KZ_LAUNCH(ctx, KID_TR_SORT, k_tr_sort, dim3(G, B), dim3(1024), A.key[0], A, TR, bitsG, lazyRank ? 1 : 0);
+      if (lazyRank) KZ_LAUNCH(ctx, KID_TR_SORT, k_tr_sort, dim3(G, B), dim3(1024), A.key[0], A, TR, bitsG, 2);   // the blocks pass 1 guessed wrong (workgroups of the others leave at once)
       wMax = 0;
     } else
     if (buckets) {
@@ -1959,7 +2003,7 @@ static int bwt_forward_run(kz_ctx* ctx, kz_batch& bt, bool allowTrie, bool* trie
     // ---- text order: compact the live suffixes, keys for the next round ----
     h = (round == 0) ? (useTrie ? 6 : K0) : h * 2;
     KZ_HIP(hipMemsetAsync(A.d_m2, 0, (size_t)B * 4, st));
-    KZ_LAUNCH(ctx, KID_LIVE_EMIT, k_live_emit, dim3(tilesN, nAct), dim3(KZ_WG), kF, vF, A, h, bitsR, round == 0 ? 1 : 0);
+    KZ_LAUNCH(ctx, KID_LIVE_EMIT, k_live_emit, dim3(tilesN, nAct), dim3(KZ_WG), kF, vF, A, h, bitsR, round == 0 ? 1 : 0, (round == 0 && useTrie && lazyRank) ? TR.meta : (const int32_t*)nullptr);
     { u64* tk = kC; kC = kF; kF = tk; u32* tv = vC; vC = vF; vF = tv; }
     // ---- read back the next compact sizes ----
     KZ_HIP(hipMemcpyAsync(ctx->hpin, A.d_m2, (size_t)B * 4, hipMemcpyDeviceToHost, st));

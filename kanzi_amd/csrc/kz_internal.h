@@ -40,6 +40,7 @@ struct kz_switches {
   int streamChunk = 0;           // KZ_STREAM_CHUNK (0: default)
   int streamSerial = 0;          // KZ_STREAM_SERIAL
   int bwtTrie = -1, bwtTrieWin = -1, bwtBuckets = -1, bwtDmax = -1, bwtRetire = -1;   // KZ_BWT_TRIE / _TRIEWIN / _BUCKETS / _DMAX / _RETIRE (-1 unset)
+  int bwtLazyRank = -1;         // KZ_BWT_LAZYRANK=0: round 0 stores every rank (A/B; see k_tr_sort)
   int bwtTrace = 0;              // KZ_BWT_TRACE
   int bwtTestTrieOverflow = -1;  // KZ_BWT_TEST_TRIE_OVERFLOW=<round> (tests)
   int fpaqForce = 0;             // KZ_FPAQ_FORCE: 0 unset, 1 wave, 2 lane

@@ -1446,10 +1446,15 @@ def _trie_inputs():
             repeats(700000, 3, 33), repeats(1 << 19, 12, 40), repeats(300000, 900, 16),
             rng.integers(0, 256, 200000, dtype=np.uint8).tobytes() + bytes(70000), bytes(99999) + b"\x01",
             b"\xff" * 150000 + rng.integers(0, 256, 50000, dtype=np.uint8).tobytes()]
+    # lazy ranks (k_tr_sort): blocks without an expanded node whose round 0 still leaves live suffixes (the second pass stores the ranks
+    # after all): noise twice in a row (every suffix of the first copy live), noise with one planted repeat (a handful live), and
+    # noise whose length is not a multiple of 8 (the 8 primary indexes are the only ranks a finished block stores)
+    noise = rng.integers(0, 256, 300001, dtype=np.uint8).tobytes()
+    ins += [noise[:150000] * 2, noise[:150000] + noise[1000:1100] + noise[150000:250000], noise, noise[:262147] + noise[:7]]
     return ins
 
 
-@pytest.mark.parametrize("switch", ["default", "KZ_BWT_DMAX=7", "KZ_BWT_TRIEWIN=0", "KZ_BWT_TRIE=0", "KZ_BWT_RETIRE=0"])
+@pytest.mark.parametrize("switch", ["default", "KZ_BWT_DMAX=7", "KZ_BWT_TRIEWIN=0", "KZ_BWT_TRIE=0", "KZ_BWT_RETIRE=0", "KZ_BWT_LAZYRANK=0"])
 def test_bwt_forward_trie_rounds_match_oracle(ctx, monkeypatch, switch):
     """Round 0 as a trie round (count by byte, move once, finish buckets in LDS) and the key trie round over the window of oversized
     buckets in the doubling rounds, against the oracle's induced-sorting BWT (the BWT is unique): default depth 6, depth 7, the
@@ -1467,7 +1472,7 @@ def test_bwt_forward_trie_rounds_match_oracle(ctx, monkeypatch, switch):
         # list has holes), the text-like and sparse ones stay to the end; KZ_BWT_RETIRE=0 = every block in every round, as before
         blocks = ([datagen.block(3, 1 << 20, 3).tobytes(), datagen.block(0, 4 << 20, 0).tobytes(), datagen.block(1, 4 << 20, 1).tobytes(),
                    datagen.block(3, 4 << 20, 3).tobytes(), datagen.block(4, 4 << 20, 4).tobytes()]
-                  + [_trie_inputs()[k] for k in (3, 15, 21)] + [b"short block", b"", datagen.block(8, 300000, 3).tobytes(), datagen.block(2, 1 << 21, 2).tobytes()])
+                  + [_trie_inputs()[k] for k in (3, 15, 21, -4, -3)] + [b"short block", b"", datagen.block(8, 300000, 3).tobytes(), datagen.block(2, 1 << 21, 2).tobytes()])
         bs = 4 << 20
         B = len(blocks)
         inp = np.zeros((B, bs), dtype=np.uint8)

@@ -12,6 +12,7 @@ rng = np.random.default_rng(1)
 def gen(k):
     if kind == "text": return datagen.block(5 * k, bs)                   # class 0: Markov text
     if kind == "dna": return np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, bs)]
+    if kind == "uni": return datagen.block(k, bs, 3)
     if kind == "mm": return np.frombuffer(refinputs.multimedia_like(k % 5, bs, seed=k), dtype=np.uint8)
     return datagen.block(k, bs)
 dev = torch.device("cuda", 0)

@@ -22,6 +22,10 @@ __global__ __launch_bounds__(1024) void k_rate(long long* out, int* sink) {
     if (K == 5) asm volatile(X16("v_readlane_b32 s40, %0, 5\n\tv_readlane_b32 s41, %1, 9\n\t") : : "v"(x), "v"(y) : "s40", "s41");
     if (K == 6) asm volatile(X16("v_add_f64 %0, %0, %1\n\tv_add_f64 %1, %0, %1\n\t") : "+v"(a), "+v"(b));
     if (K == 7) asm volatile(X16("s_add_u32 s40, s40, 1\n\ts_add_u32 s41, s41, 3\n\t") : : : "s40", "s41", "scc");      // 32 SALU
+    if (K == 9) asm volatile(X16("v_bitop3_b32 %0, %0, %1, %0 bitop3:0xf6\n\tv_bitop3_b32 %1, %1, %0, %1 bitop3:0xf6\n\t") : "+v"(x), "+v"(y));   // gfx950's 3-input boolean
+    if (K == 10) asm volatile(X16("v_bitop3_b32 %0, %0, s40, %1 bitop3:0xf6\n\tv_bitop3_b32 %1, %1, s41, %0 bitop3:0xf6\n\t") : "+v"(x), "+v"(y) : : "s40", "s41");
+    if (K == 11) asm volatile(X16("v_cmp_ne_u32_e64 s[40:41], 0, %0\n\tv_add_u32 %1, 3, %1\n\t") : "+v"(x), "+v"(y) : : "s40", "s41");   // compare into an SGPR pair + plain
+    if (K == 12) asm volatile(X16("v_cmp_ne_u32_e64 s[40:41], 0, %0\n\tv_add_u32 %1, 3, %1\n\tv_add_u32 %0, 5, %0\n\tv_xor_b32 %1, s40, %1\n\t") : "+v"(x), "+v"(y) : : "s40", "s41");   // 64 instructions: the SGPR read back by a VALU two slots later
     if (K == 8) asm volatile(X16("v_alignbit_b32 %0, %1, %0, 10\n\tv_bfi_b32 %1, %0, %1, %0\n\t") : "+v"(x), "+v"(y));  // VOP3 32-bit
   }
   const long long w1 = wall_clock64();
@@ -30,8 +34,8 @@ __global__ __launch_bounds__(1024) void k_rate(long long* out, int* sink) {
 }
 int main() {
   long long* d; int* s; hipMalloc(&d, 64); hipMalloc(&s, 8192);
-  const char* names[] = {"v_add_u32", "v_min_f64 / v_max_f64", "v_mov_b32_dpp wave_shr", "v_cmpx + s_mov exec", "v_cmp + v_cndmask", "v_readlane", "v_add_f64", "s_add_u32", "v_alignbit / v_bfi"};
-  for (int k = 0; k < 9; k++) {
+  const char* names[] = {"v_add_u32", "v_min_f64 / v_max_f64", "v_mov_b32_dpp wave_shr", "v_cmpx + s_mov exec", "v_cmp + v_cndmask", "v_readlane", "v_add_f64", "s_add_u32", "v_alignbit / v_bfi", "v_bitop3 (VGPRs)", "v_bitop3 (one SGPR)", "v_cmp -> SGPR + v_add", "cmp,add,add,xor(SGPR) x2"};
+  for (int k = 0; k < 13; k++) {
     printf("%-26s", names[k]);
     for (int W = 1; W <= 4; W *= 2) {
       long long h = 0;
@@ -47,6 +51,10 @@ int main() {
           case 6: hipLaunchKernelGGL(k_rate<6>, dim3(1), dim3(256 * W), 0, 0, d, s); break;
           case 7: hipLaunchKernelGGL(k_rate<7>, dim3(1), dim3(256 * W), 0, 0, d, s); break;
           case 8: hipLaunchKernelGGL(k_rate<8>, dim3(1), dim3(256 * W), 0, 0, d, s); break;
+          case 9: hipLaunchKernelGGL(k_rate<9>, dim3(1), dim3(256 * W), 0, 0, d, s); break;
+          case 10: hipLaunchKernelGGL(k_rate<10>, dim3(1), dim3(256 * W), 0, 0, d, s); break;
+          case 11: hipLaunchKernelGGL(k_rate<11>, dim3(1), dim3(256 * W), 0, 0, d, s); break;
+          case 12: hipLaunchKernelGGL(k_rate<12>, dim3(1), dim3(256 * W), 0, 0, d, s); break;
         }
         hipDeviceSynchronize();
         hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
