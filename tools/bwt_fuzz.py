@@ -18,7 +18,7 @@ print("seed", seed, flush=True)
 def piece(n):
     if n <= 0:
         return np.zeros(0, np.uint8)
-    k = int(rng.integers(0, 13))
+    k = int(rng.integers(0, 14))
     if k < 5:
         return datagen.block(int(rng.integers(0, 1 << 20)), n, k)
     if k == 5:
@@ -40,6 +40,15 @@ def piece(n):
     if k == 10:
         a = piece(n // 2)
         return np.concatenate([a, a[:n - len(a)]])             # the second half repeats the first: repeats of n / 2
+    if k == 13:
+        # noise with planted repeats: no 2-byte prefix reaches the LDS sort's capacity (the trie has no expanded node: the block is
+        # a candidate for round 0's lazy ranks) and yet some suffixes stay live after round 0, few or many
+        x = rng.integers(0, 256, n, dtype=np.uint8)
+        for _ in range(int(rng.integers(0, 6))):
+            L = int(min(n, rng.choice([6, 7, 8, 40, 1000, 70000])))
+            a, b = int(rng.integers(0, n - L + 1)), int(rng.integers(0, n - L + 1))
+            x[b:b + L] = x[a:a + L].copy()
+        return x
     return structured(n)
 
 
