@@ -267,11 +267,18 @@ __global__ __launch_bounds__(64) void k_sbrt_replay_keyed(const u8* __restrict__
   __syncthreads();
   u64 R0 = sk[lane], R1 = sk[64 + lane], R2 = sk[128 + lane], R3 = sk[192 + lane];
   const u64 INF = 0x7FF0000000000000ULL;
+  // The replay is bound by the scalar unit and the VALU alike (SQ counters: ~11 instructions of each per input byte, both near
+  // their issue limits), so what a step needs from the symbol's position is prepared per ROW in VGPRs and fetched with one
+  // v_readlane each: xl = the new key's low word (i << 9 | touched | 255 - symbol), ivb = i + 2^31 (RANK: (p + ivb) >> 1 is
+  // 0x40000000 | (i + p) >> 1) or 0x40000000 | i (MTF).  sh0 = row 0 shifted up by one lane; its lane 0 is never written by the
+  // DPP move (no source lane, bound_ctrl off) and keeps the +inf it starts with.
+  u32 sh0lo = 0u, sh0hi = 0x7FF00000u;
+  u32 pos = (u32)(start + lane);
   // bytes before the tile (run detection across the tile boundary)
   u32 cp = (start >= 1) ? (u32)s[start - 1] : 0x100u;
   uint64_t carryE = (start >= 2 && s[start - 1] == s[start - 2]) ? 1ULL : 0ULL;
   u32 cur = (start + lane < end) ? (u32)s[start + lane] : 0u;
-  for (int row = start; row < end; row += 64) {
+  for (int row = start; row < end; row += 64, pos += 64u) {
     const int cnt = min(64, end - row);
     const int nrow = row + 64;
     const u32 nxt = (nrow + lane < end) ? (u32)s[nrow + lane] : 0u;
@@ -285,6 +292,8 @@ __global__ __launch_bounds__(64) void k_sbrt_replay_keyed(const u8* __restrict__
     uint64_t F = N & (R << 1);                                        // ranked positions right behind a skipped stretch: repair the front key first
     int jf;
     asm("s_ff1_i32_b64 %0, %1" : "=s"(jf) : "s"(F));
+    const u32 xl = (pos << 9) | 0x100u | (255u - cur);
+    const u32 ivb = (MODE == 2) ? pos + 0x80000000u : (0x40000000u | pos);
     u32 outv = 0;
     while (N) {
       const int j = (int)__builtin_ctzll(N);
@@ -294,32 +303,48 @@ __global__ __launch_bounds__(64) void k_sbrt_replay_keyed(const u8* __restrict__
         asm("s_bitset0_b64 %0, %1" : "+s"(F) : "s"(j));
         asm("s_ff1_i32_b64 %0, %1" : "=s"(jf) : "s"(F));
       }
-      const u32 c = (u32)__builtin_amdgcn_readlane((int)cur, j);
-      const u32 tb = 255u - c;
-      const u32 iv = (u32)(row + j);
+      const u32 xlo = (u32)__builtin_amdgcn_readlane((int)xl, j);
+      const u32 tb = xlo & 0xFFu;
       const uint64_t m0 = kz_ballot(((u32)R0 & 0xFFu) == tb);
-      u32 r;
-      if (__builtin_expect(m0 != 0, 1)) {                             // in the first 64 positions: only pair 0 moves
+      // where the symbol sits (row 0 first: after a BWT most symbols are there) and the low word of its key (p << 9 | ...)
+      u32 r, lo = 0;
+      if (__builtin_expect(m0 != 0, 1)) {
         r = (u32)__builtin_ctzll(m0);
-        const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)R0, (int)r);
-        const u64 x = kzr_key<MODE>(iv, lo >> 9, tb);
-        const u64 t0 = kzr_min(x, kzr_shr(R0, INF));
-        if ((u32)lane <= r) R0 = kzr_max(t0, R0);
+        if (MODE != 1) lo = (u32)__builtin_amdgcn_readlane((int)(u32)R0, (int)r);
       } else {
         const uint64_t m1 = kz_ballot(((u32)R1 & 0xFFu) == tb), m2 = kz_ballot(((u32)R2 & 0xFFu) == tb), m3 = kz_ballot(((u32)R3 & 0xFFu) == tb);
-        u32 lo;
         if (m1) { r = 64u + (u32)__builtin_ctzll(m1); lo = (u32)__builtin_amdgcn_readlane((int)(u32)R1, (int)(r & 63u)); }
         else if (m2) { r = 128u + (u32)__builtin_ctzll(m2); lo = (u32)__builtin_amdgcn_readlane((int)(u32)R2, (int)(r & 63u)); }
         else { r = 192u + (u32)__builtin_ctzll(m3); lo = (u32)__builtin_amdgcn_readlane((int)(u32)R3, (int)(r & 63u)); }
-        const u64 x = kzr_key<MODE>(iv, lo >> 9, tb);
-        const u64 c0 = kz_readlane64(R0, 63), c1 = kz_readlane64(R1, 63), c2 = kz_readlane64(R2, 63);
-        const u64 t0 = kzr_min(x, kzr_shr(R0, INF)), t1 = kzr_min(x, kzr_shr(R1, c0)), t2 = kzr_min(x, kzr_shr(R2, c1)), t3 = kzr_min(x, kzr_shr(R3, c2));
-        R0 = kzr_max(t0, R0);                                         // row 0 lies above every position >= 64
-        if (64u + (u32)lane <= r) R1 = kzr_max(t1, R1);
-        if (128u + (u32)lane <= r) R2 = kzr_max(t2, R2);
-        if (192u + (u32)lane <= r) R3 = kzr_max(t3, R3);
       }
-      outv = (lane == j) ? r : outv;
+      const u32 ivs = (MODE == 3) ? 0u : (u32)__builtin_amdgcn_readlane((int)ivb, j);
+      const u32 xhi = (MODE == 1) ? ivs : ((MODE == 2) ? (((lo >> 9) + ivs) >> 1) : (0x40000000u | (lo >> 9)));
+      const u64 x = ((u64)xhi << 32) | xlo;
+      if (__builtin_expect(r >= 64u, 0)) {
+        // the rows below row 0 up to the symbol's (selects, not branches: a divergent branch in this loop makes the compiler copy row
+        // 0, the shifted row and the output row into temporaries and back around every step: nine moves).  Row 0 itself moves as a
+        // whole, which is what the step below does for r >= 63.
+        const u64 c0 = kz_readlane64(R0, 63), c1 = kz_readlane64(R1, 63), c2 = kz_readlane64(R2, 63);
+        const u64 t1 = kzr_min(x, kzr_shr(R1, c0)), t2 = kzr_min(x, kzr_shr(R2, c1)), t3 = kzr_min(x, kzr_shr(R3, c2));
+        const u64 n1 = kzr_max(t1, R1), n2 = kzr_max(t2, R2), n3 = kzr_max(t3, R3);
+        R1 = (64u + (u32)lane <= r) ? n1 : R1;
+        R2 = (128u + (u32)lane <= r) ? n2 : R2;
+        R3 = (192u + (u32)lane <= r) ? n3 : R3;
+      }
+      sh0lo = (u32)__builtin_amdgcn_update_dpp((int)sh0lo, (int)(u32)R0, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+      sh0hi = (u32)__builtin_amdgcn_update_dpp((int)sh0hi, (int)(u32)(R0 >> 32), 0x138, 0xF, 0xF, false);
+      u64 t0;
+      // positions <= r of row 0 take max(min(x, left neighbour), own), lane j of the output row takes the rank: both under EXEC masks
+      // made here (EXEC is all ones in this loop and is again when the block ends; the scalar unit writes it: no VALU hazard applies)
+      asm volatile("v_min_f64 %[t], %[x], %[sh]\n\t"
+                   "v_cmp_ge_u32 vcc, %[r], %[lane]\n\t"
+                   "s_mov_b64 exec, vcc\n\t"
+                   "v_max_f64 %[R], %[t], %[R]\n\t"
+                   "s_lshl_b64 exec, 1, %[j]\n\t"
+                   "v_mov_b32 %[o], %[r]\n\t"
+                   "s_mov_b64 exec, -1"
+                   : [R] "+v"(R0), [o] "+v"(outv), [t] "=&v"(t0)
+                   : [x] "s"(x), [sh] "v"(((u64)sh0hi << 32) | sh0lo), [r] "s"(r), [lane] "v"(lane), [j] "s"(j) : "vcc", "scc");   // (s_lshl_b64 writes SCC)
     }
     if ((R >> (cnt - 1)) & 1ULL) KZR_FIX_RUN(row + cnt - 1)            // the row ends inside a skipped stretch
     if (lane < cnt) d[row + lane] = (u8)outv;
