@@ -78,14 +78,20 @@ __device__ __forceinline__ uint32_t kz_wg_incl_max(uint32_t v, uint32_t* lds, ui
 }
 
 // match-any on an 8-bit digit within a wave: mask of lanes (among `valid` lanes) holding the same digit
+// (per bit: x = the lane's bit spread over a word, bal = the lanes whose bit is set, the lanes that agree are ~(bal ^ x); in 32-bit
+// halves the compiler spends six VALU instructions per bit, with `m &= bit ? bal : ~bal` on 64-bit masks nine: see bw_match in
+// kz_bwt_fwd.hip, round 6)
 __device__ __forceinline__ uint64_t kz_match8(uint32_t d, bool valid) {
-  uint64_t m = kz_ballot(valid);
+  const uint64_t m0 = kz_ballot(valid);
+  uint32_t mlo = (uint32_t)m0, mhi = (uint32_t)(m0 >> 32);
 #pragma unroll
   for (int b = 0; b < 8; b++) {
-    uint64_t bal = kz_ballot((d >> b) & 1u);
-    m &= ((d >> b) & 1u) ? bal : ~bal;
+    const uint32_t x = (uint32_t)(((int32_t)(d << (31 - b))) >> 31);
+    const uint64_t bal = kz_ballot(x != 0u);
+    mlo &= ~((uint32_t)bal ^ x);
+    mhi &= ~((uint32_t)(bal >> 32) ^ x);
   }
-  return valid ? m : 0ULL;
+  return valid ? (((uint64_t)mhi << 32) | mlo) : 0ULL;
 }
 
 __device__ __forceinline__ int kz_ilog2(uint32_t x) { return 31 - __clz(x); }
